@@ -1,0 +1,145 @@
+"""Frozen per-detection modality encoders (ADJACENT to the hot path).
+
+``GNN.__init__`` receives three encoder modules and freezes them (reference
+clr_att_gnn.py:17-33); the hot path only calls ``img_encoder.encode``,
+``lidar_encoder.forward_feat`` and ``radar_encoder.forward_feat`` (clr_att_gnn.py:125,131,139).
+They are ordinary conv / batch-norm stacks and stay on PyTorch-ROCm (MIOpen / rocBLAS) in this
+round.  The classes below restate the three architectures with the reference's parameter names
+so that reference checkpoints load (``resnet.*``, ``pointnet.*``, ``radarnet.*`` keys):
+
+* ``ResNetAE.encode``            models/resnet_fully_conv.py:56-161   3x32x32 -> 96
+* ``PointNetClassifier.forward_feat`` models/pointnet.py:9-57,111-192  3x128 -> 256
+* ``RadarNetClassifier.forward_feat`` models/radarnet.py:9-64          4x64 -> 256
+
+Only the sub-modules whose weights a checkpoint holds are declared; decoder halves that the
+hot path never calls are declared too (unused) so ``load_state_dict(strict=True)`` works.
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+import torch.nn.functional as F
+
+
+class _ResidualBlock(nn.Module):
+    def __init__(self, cin, cout, k, stride, down):
+        super().__init__()
+        self.downsample = down
+        self.conv1 = nn.Conv2d(cin, cout, k, stride, padding=1)
+        self.bn1 = nn.BatchNorm2d(cout)
+        self.conv2 = nn.Conv2d(cout, cout, k, stride, padding=1)
+        self.bn2 = nn.BatchNorm2d(cout)
+
+    def forward(self, x):
+        skip = self.downsample(x) if self.downsample is not None else x
+        y = F.relu(self.bn1(self.conv1(x)))
+        y = self.bn2(self.conv2(y))
+        return F.relu(y + skip)
+
+
+def _down(cin, cout, k, s):
+    return nn.Sequential(nn.Conv2d(cin, cout, k, s), nn.BatchNorm2d(cout))
+
+
+class ResNetAE(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.conv = nn.Conv2d(3, 12, kernel_size=4, stride=2, padding=1)
+        self.bn = nn.BatchNorm2d(12)          # declared by the reference, not used by encode()
+        self.res_block1 = _ResidualBlock(12, 24, 4, 2, _down(12, 24, 5, 3))
+        self.res_block2 = _ResidualBlock(24, 48, 3, 1, _down(24, 48, 1, 1))
+        self.res_block3 = _ResidualBlock(48, 96, 3, 2, _down(48, 96, 3, 2))
+        self.fc_encoder = nn.Sequential(nn.Linear(192, 128), nn.BatchNorm1d(128, momentum=0.01), nn.ReLU(),
+                                        nn.Linear(128, 64), nn.BatchNorm1d(64, momentum=0.01), nn.ReLU())
+        self.fc_decoder = nn.Sequential(nn.Linear(64, 128), nn.BatchNorm1d(128, momentum=0.01), nn.ReLU(),
+                                        nn.Linear(128, 192), nn.BatchNorm1d(192, momentum=0.01), nn.ReLU())
+        self.conv_decoder = nn.Sequential(
+            nn.ConvTranspose2d(96, 72, 4, stride=2, padding=1), nn.ReLU(),
+            nn.ConvTranspose2d(72, 48, 4, stride=2, padding=1), nn.ReLU(),
+            nn.ConvTranspose2d(48, 24, 4, stride=2, padding=1), nn.ReLU(),
+            nn.ConvTranspose2d(24, 12, 4, stride=2, padding=1), nn.ReLU(),
+            nn.ConvTranspose2d(12, 3, 4, stride=2, padding=1), nn.Sigmoid())
+
+    def encode(self, x):
+        out = self.res_block3(self.res_block2(self.res_block1(self.conv(x))))
+        return out.view(out.size(0), -1)
+
+
+class _STN3d(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.conv1, self.conv2, self.conv3 = nn.Conv1d(3, 64, 1), nn.Conv1d(64, 128, 1), nn.Conv1d(128, 1024, 1)
+        self.fc1, self.fc2, self.fc3 = nn.Linear(1024, 512), nn.Linear(512, 256), nn.Linear(256, 9)
+        self.bn1, self.bn2, self.bn3 = nn.BatchNorm1d(64), nn.BatchNorm1d(128), nn.BatchNorm1d(1024)
+        self.bn4, self.bn5 = nn.BatchNorm1d(512), nn.BatchNorm1d(256)
+
+    def forward(self, x):
+        b = x.size(0)
+        x = F.relu(self.bn1(self.conv1(x)))
+        x = F.relu(self.bn2(self.conv2(x)))
+        x = F.relu(self.bn3(self.conv3(x)))
+        x = torch.max(x, 2, keepdim=True)[0].view(-1, 1024)
+        x = F.relu(self.bn4(self.fc1(x)))
+        x = F.relu(self.bn5(self.fc2(x)))
+        x = self.fc3(x)
+        iden = torch.eye(3, dtype=x.dtype, device=x.device).view(1, 9).repeat(b, 1)
+        return (x + iden).view(-1, 3, 3)
+
+
+class _PointNetFeat(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.stn = _STN3d()
+        self.conv1, self.conv2, self.conv3 = nn.Conv1d(3, 64, 1), nn.Conv1d(64, 128, 1), nn.Conv1d(128, 1024, 1)
+        self.bn1, self.bn2, self.bn3 = nn.BatchNorm1d(64), nn.BatchNorm1d(128), nn.BatchNorm1d(1024)
+
+    def forward(self, x):
+        trans = self.stn(x)
+        x = torch.bmm(x.transpose(2, 1), trans).transpose(2, 1)
+        x = F.relu(self.bn1(self.conv1(x)))
+        x = F.relu(self.bn2(self.conv2(x)))
+        x = self.bn3(self.conv3(x))
+        return torch.max(x, 2, keepdim=True)[0].view(-1, 1024)
+
+
+class PointNetClassifier(nn.Module):
+    def __init__(self, k=7, feature_transform=False):
+        super().__init__()
+        if feature_transform:
+            raise NotImplementedError("feature_transform=True is not used by the GNN path")
+        self.feat = _PointNetFeat()
+        self.fc1, self.fc2, self.fc3 = nn.Linear(1024, 512), nn.Linear(512, 256), nn.Linear(256, k)
+        self.dropout = nn.Dropout(p=0.3)
+        self.bn1, self.bn2 = nn.BatchNorm1d(512), nn.BatchNorm1d(256)
+
+    def forward_feat(self, x):
+        x = self.feat(x)
+        x = F.relu(self.bn1(self.fc1(x)))
+        return F.relu(self.bn2(self.dropout(self.fc2(x))))
+
+
+class _RadarNetFeat(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.conv1, self.conv2, self.conv3 = nn.Conv1d(4, 64, 1), nn.Conv1d(64, 128, 1), nn.Conv1d(128, 1024, 1)
+        self.bn1, self.bn2, self.bn3 = nn.BatchNorm1d(64), nn.BatchNorm1d(128), nn.BatchNorm1d(1024)
+
+    def forward(self, x):
+        x = F.relu(self.bn1(self.conv1(x)))
+        x = F.relu(self.bn2(self.conv2(x)))
+        x = self.bn3(self.conv3(x))
+        return torch.max(x, 2, keepdim=True)[0].view(-1, 1024)
+
+
+class RadarNetClassifier(nn.Module):
+    def __init__(self, k=2, feature_transform=False):
+        super().__init__()
+        self.feat = _RadarNetFeat()
+        self.fc1, self.fc2, self.fc3 = nn.Linear(1024, 512), nn.Linear(512, 256), nn.Linear(256, k)
+        self.dropout = nn.Dropout(p=0.3)
+        self.bn1, self.bn2 = nn.BatchNorm1d(512), nn.BatchNorm1d(256)
+
+    def forward_feat(self, x):
+        x = self.feat(x)
+        x = F.relu(self.bn1(self.fc1(x)))
+        return F.relu(self.bn2(self.dropout(self.fc2(x))))

@@ -1,0 +1,329 @@
+"""TEST INFRASTRUCTURE ONLY -- pure-torch CPU restatement of the reference hot path.
+
+Restates, without torch_geometric / torch_scatter / torch_cluster:
+
+* ``PoseGNN`` + its ``CausalMessagePassing``      (reference batch_3dmot/models/pose_gnn.py:24-252)
+* ``GNN`` (camera+LiDAR+radar) + its message passing (reference batch_3dmot/models/clr_att_gnn.py:16-356)
+* the third-party ops those files call: ``MessagePassing.__collect__`` (index_select by
+  edge_index row), ``torch_scatter.scatter(reduce='add')`` (index_add_), ``GATConv(heads=1,
+  add_self_loops=False)`` and ``knn_graph(k, loop=False)``.
+
+Parity status: the modules below are pinned against the reference's own source executed
+verbatim in the authoring container through stand-in PyG modules (``oracle/make_golden.py``),
+fixtures under ``tests/golden``.  The kNN + GAT block is third-party code that is absent from
+/root/reference and un-pinned by version (setup.py:3-17 lists no dependency): its semantics
+follow SURVEY.md section 8c and are "parity unpinned"; the reference discards its result
+(pose_gnn.py:80, clr_att_gnn.py:184 are comparisons, not assignments), so it cannot influence
+any reference output.
+
+``state_dict`` keys equal the reference's so golden weights load with ``strict=True``.
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+import torch.nn.functional as F
+
+
+# --------------------------------------------------------------------------------------
+# third-party ops restated
+# --------------------------------------------------------------------------------------
+def scatter_add(src: torch.Tensor, index: torch.Tensor, dim_size: int) -> torch.Tensor:
+    """torch_scatter.scatter(src, index, dim=0, dim_size=N, reduce='add')
+    (call sites pose_gnn.py:240, clr_att_gnn.py:344)."""
+    out = src.new_zeros((dim_size, src.size(1)))
+    return out.index_add_(0, index, src)
+
+
+def knn_graph(x: torch.Tensor, k: int) -> torch.Tensor:
+    """torch_geometric.nn.knn_graph(x, k, loop=False, flow='source_to_target')
+    (call sites pose_gnn.py:78, clr_att_gnn.py:182): for every centre ``c`` the ``min(k, n-1)``
+    rows ``q != c`` with the smallest Euclidean distance; row 0 = neighbour (source), row 1 =
+    centre (target), grouped by centre in ascending order, neighbours by ascending distance.
+    """
+    n = x.size(0)
+    if n <= 1:
+        return torch.zeros((2, 0), dtype=torch.long, device=x.device)
+    kk = min(k, n - 1)
+    d = torch.cdist(x, x)  # [n, n]
+    d.fill_diagonal_(float("inf"))
+    nbr = torch.topk(d, kk, dim=1, largest=False, sorted=True).indices  # [n, kk]
+    centre = torch.arange(n, device=x.device).unsqueeze(1).expand(n, kk)
+    return torch.stack([nbr.reshape(-1), centre.reshape(-1)], dim=0)
+
+
+class GATConv(nn.Module):
+    """torch_geometric.nn.GATConv(D, D, heads=1, add_self_loops=False) restated
+    (constructed at pose_gnn.py:55 / clr_att_gnn.py:93, called at :79 / :183).
+
+    h = W x (no bias, lin_dst aliases lin_src); a = leaky_relu(h_j.att_src + h_i.att_dst, 0.2);
+    alpha = softmax over the incoming edges of i, exp(a - max) / (sum + 1e-16);
+    out_i = sum_j alpha_ij h_j + bias.
+    """
+
+    def __init__(self, dim: int):
+        super().__init__()
+        self.dim = dim
+        self.lin_src = nn.Linear(dim, dim, bias=False)
+        self.lin_dst = self.lin_src
+        self.att_src = nn.Parameter(torch.empty(1, 1, dim))
+        self.att_dst = nn.Parameter(torch.empty(1, 1, dim))
+        self.bias = nn.Parameter(torch.zeros(dim))
+        nn.init.xavier_uniform_(self.lin_src.weight)
+        nn.init.xavier_uniform_(self.att_src)
+        nn.init.xavier_uniform_(self.att_dst)
+
+    def forward(self, x: torch.Tensor, edge_index: torch.Tensor) -> torch.Tensor:
+        n = x.size(0)
+        h = self.lin_src(x)
+        a_src = (h * self.att_src.view(1, -1)).sum(-1)
+        a_dst = (h * self.att_dst.view(1, -1)).sum(-1)
+        src, dst = edge_index[0], edge_index[1]
+        a = F.leaky_relu(a_src[src] + a_dst[dst], 0.2)
+        amax = a.new_full((n,), float("-inf")).scatter_reduce(0, dst, a, reduce="amax", include_self=True)
+        amax = torch.where(torch.isinf(amax), torch.zeros_like(amax), amax)
+        ex = torch.exp(a - amax[dst])
+        den = ex.new_zeros((n,)).index_add_(0, dst, ex) + 1e-16
+        alpha = ex / den[dst]
+        out = h.new_zeros((n, self.dim)).index_add_(0, dst, h[src] * alpha.unsqueeze(1))
+        return out + self.bias
+
+
+def _mlp(dims, last_act=None, inplace_relu=False):
+    layers = []
+    for i in range(len(dims) - 1):
+        layers.append(nn.Linear(dims[i], dims[i + 1]))
+        if i < len(dims) - 2:
+            layers.append(nn.ReLU(inplace=inplace_relu))
+    if last_act is not None:
+        layers.append(last_act)
+    return nn.Sequential(*layers)
+
+
+# --------------------------------------------------------------------------------------
+# CausalMessagePassing (both width sets)
+# --------------------------------------------------------------------------------------
+class CausalMessagePassing(nn.Module):
+    """pose_gnn.py:89-252 (widths 'p') and clr_att_gnn.py:191-356 (widths 'clr')."""
+
+    def __init__(self, widths: str):
+        super().__init__()
+        if widths == "p":
+            self.edge_update = _mlp([128, 96, 64, 32])            # pose_gnn.py:94-100
+            self.create_past_msgs = _mlp([128, 96, 64])           # :102-106
+            self.create_future_msgs = _mlp([128, 96, 64])         # :108-112
+            self.combine_future_past = _mlp([128, 96, 64, 48])    # :114-120
+        else:
+            self.edge_update = _mlp([320, 256, 128, 64])          # clr_att_gnn.py:196-202
+            self.create_past_msgs = _mlp([256, 192, 128])         # :204-208
+            self.create_future_msgs = _mlp([256, 192, 128])       # :210-214
+            self.combine_future_past = _mlp([256, 192, 128, 96])  # :216-222
+
+    def forward(self, x, edge_index, edge_attr, initial_x, att_edge_attr=None):
+        rows, cols = edge_index[0], edge_index[1]
+        # __collect__: *_j = index_select(0, edge_index[0]); *_i = index_select(0, edge_index[1])
+        x_i, x_j = x.index_select(0, cols), x.index_select(0, rows)
+        i_i, i_j = initial_x.index_select(0, cols), initial_x.index_select(0, rows)
+        # message(): pose_gnn.py:198-226 / clr_att_gnn.py:302-330
+        if att_edge_attr is None:
+            feats = torch.cat([x_i, x_j, edge_attr], dim=1)
+        else:
+            feats = torch.cat([x_i, x_j, edge_attr, att_edge_attr], dim=1)
+        updated_edge_attr = self.edge_update(feats)
+        future_msgs = self.create_future_msgs(torch.cat([x_i, updated_edge_attr, i_i], dim=1))
+        past_msgs = self.create_past_msgs(torch.cat([x_j, updated_edge_attr, i_j], dim=1))
+        # aggregate(): past at cols (destination), future at rows (source): pose_gnn.py:187-191
+        n = x.size(0)
+        messages_past = scatter_add(past_msgs, cols, n)
+        messages_future = scatter_add(future_msgs, rows, n)
+        messages = torch.cat([messages_past, messages_future], dim=1)   # :193
+        return self.combine_future_past(messages), updated_edge_attr    # update(): :242-252
+
+
+def _dead_knn_block(x, node_timestamps, knn_conv, k=20):
+    """pose_gnn.py:75-80 / clr_att_gnn.py:180-184.  The result of the attention convolution is
+    compared with, not assigned to, ``x`` -- the block has no effect on any output."""
+    outs = []
+    for t in torch.unique(node_timestamps).tolist():
+        m = node_timestamps == t
+        x_t = x[m]
+        ei = knn_graph(x_t, k)
+        x_t = knn_conv(x_t, ei)
+        x[m] == x_t  # noqa: B015  (reference behaviour: comparison, result dropped)
+        outs.append(x_t)
+    return outs
+
+
+# --------------------------------------------------------------------------------------
+# PoseGNN
+# --------------------------------------------------------------------------------------
+class PoseGNN(nn.Module):
+    """pose_gnn.py:24-86."""
+
+    def __init__(self, gnn_depth=6, edge_dim=16, node_dim=19, mp_type: str = "attention",
+                 run_dead_knn: bool = True):
+        super().__init__()
+        self.depth = gnn_depth
+        self.run_dead_knn = run_dead_knn
+        self.edge_encoder = _mlp([4, 8, 16, 32], inplace_relu=True)     # :29-35
+        self.node_encoder = _mlp([19, 24, 36, 48])                       # :37-43
+        self.edge_classifier = _mlp([32, 16, 8, 4, 1])                   # :45-53
+        self.knn_conv = GATConv(48)                                      # :55
+        self.message_passing = CausalMessagePassing("p")                 # :56
+
+    def forward(self, data, capture=None):
+        pose_feats, edge_index, edge_attr, node_timestamps = (
+            data.pose_feats, data.edge_index, data.edge_attr, data.node_timestamps)
+        edge_attr = self.edge_encoder(edge_attr.float())                 # :67
+        initial_x = self.node_encoder(pose_feats)                        # :68
+        x = self.node_encoder(pose_feats)                                # :69
+        x_enc = x
+        for i in range(self.depth):
+            if i % 2 == 0 and self.run_dead_knn:
+                _dead_knn_block(x, node_timestamps, self.knn_conv)       # :75-80
+            x, edge_attr = self.message_passing(x, edge_index, edge_attr, initial_x)  # :83
+            if capture is not None:
+                capture.append((x, edge_attr))
+        return self.edge_classifier(edge_attr), x_enc                    # :86
+
+
+# --------------------------------------------------------------------------------------
+# GNN (camera + LiDAR + radar)
+# --------------------------------------------------------------------------------------
+class GNN(nn.Module):
+    """clr_att_gnn.py:16-188.  ``use_attention=False`` is a shape error in the reference
+    (:166-170 feeds 512 features into Linear(640, ...)) and is not restated."""
+
+    def __init__(self, img_encoder, lidar_encoder, radar_encoder, use_attention=True,
+                 gnn_depth=6, edge_dim=64, node_dim=179, run_dead_knn: bool = True,
+                 loop_masks: bool = True):
+        super().__init__()
+        self.depth = gnn_depth
+        self.use_attention = use_attention
+        self.run_dead_knn = run_dead_knn
+        self.loop_masks = loop_masks
+        self.resnet, self.pointnet, self.radarnet = img_encoder, lidar_encoder, radar_encoder
+        for enc in (self.resnet, self.pointnet, self.radarnet):          # :26-33
+            for p in enc.parameters():
+                p.requires_grad = False
+        self.edge_encoder = _mlp([4, 16, 32, 64], inplace_relu=True)     # :35-41
+        self.node_encoder = _mlp([19, 48, 96])                           # :43-47
+        self.edge_classifier = _mlp([64, 32, 16, 8, 1], last_act=nn.Sigmoid())  # :49-58
+        self.fc_lidar_encoder = _mlp([256, 192, 128], inplace_relu=True)        # :60-64
+        self.fc_radar_encoder = _mlp([256, 192, 128, 64], inplace_relu=True)    # :66-72
+        self.message_passing = CausalMessagePassing("clr")               # :74
+        self.c2c_att = nn.MultiheadAttention(96, 2, kdim=96, vdim=96, batch_first=True)     # :77
+        self.l2l_att = nn.MultiheadAttention(128, 2, kdim=128, vdim=128, batch_first=True)  # :78
+        self.r2r_att = nn.MultiheadAttention(64, 2, kdim=64, vdim=64, batch_first=True)     # :79
+        self.att_edge_encoder = _mlp([640, 512, 384, 256, 128, 64])      # :81-91
+        self.knn_conv = GATConv(96)                                      # :93
+
+    def modality_masks(self, lidar_feats, radar_feats):
+        """clr_att_gnn.py:107-121."""
+        n = lidar_feats.size(0)
+        if self.loop_masks:
+            pcl = torch.zeros(n, dtype=torch.bool, device=lidar_feats.device)
+            pr = torch.zeros(n, dtype=torch.bool, device=lidar_feats.device)
+            for i, f in enumerate(lidar_feats):
+                if torch.sum(f):
+                    pcl[i] = 1
+            for i, f in enumerate(radar_feats):
+                if torch.sum(f):
+                    pr[i] = 1
+            return pcl, pr
+        return (lidar_feats.reshape(n, -1).sum(1) != 0), (radar_feats.reshape(n, -1).sum(1) != 0)
+
+    def forward(self, data, capture=None):
+        if not self.use_attention:
+            raise NotImplementedError("reference use_attention=False branch is a shape error "
+                                      "(clr_att_gnn.py:166-170 vs :82)")
+        pose_feats, img_feats, lidar_feats, radar_feats, edge_index, edge_attr, node_timestamps = (
+            data.pose_feats, data.img_feats, data.lidar_feats, data.radar_feats,
+            data.edge_index, data.edge_attr, data.node_timestamps)
+        n = pose_feats.size(0)
+        pcl_nodes, pr_nodes = self.modality_masks(lidar_feats, radar_feats)
+        edge_attr = self.edge_encoder(edge_attr.float())                 # :123
+        x_img = self.resnet.encode(img_feats)                            # :125
+
+        pointnet_out = lidar_feats.new_zeros((n, 256))                   # :127-133
+        if lidar_feats[pcl_nodes].view(-1, 3, 128).size(0) < 2:
+            self.pointnet.eval()
+            self.fc_lidar_encoder.eval()
+        pointnet_out[pcl_nodes] = self.pointnet.forward_feat(lidar_feats[pcl_nodes].view(-1, 3, 128))
+        x_lidar = lidar_feats.new_zeros((n, 128))
+        x_lidar[pcl_nodes] = self.fc_lidar_encoder(pointnet_out[pcl_nodes])
+
+        radarnet_out = radar_feats.new_zeros((n, 256))                   # :135-141
+        if radar_feats[pr_nodes].view(-1, 4, 64).size(0) < 2:
+            self.radarnet.eval()
+            self.fc_radar_encoder.eval()
+        radarnet_out[pr_nodes] = self.radarnet.forward_feat(radar_feats[pr_nodes].view(-1, 4, 64))
+        x_radar = radar_feats.new_zeros((n, 64))
+        x_radar[pr_nodes] = self.fc_radar_encoder(radarnet_out[pr_nodes])
+
+        # cross-edge modality attention: :143-164
+        x_j_img, x_i_img = x_img[edge_index[0]].view(-1, 1, 96), x_img[edge_index[1]].view(-1, 1, 96)
+        x_j_lidar, x_i_lidar = x_lidar[edge_index[0]].view(-1, 1, 128), x_lidar[edge_index[1]].view(-1, 1, 128)
+        x_j_radar, x_i_radar = x_radar[edge_index[0]].view(-1, 1, 64), x_radar[edge_index[1]].view(-1, 1, 64)
+        x_j_img_att, _ = self.c2c_att(query=x_i_img, key=x_j_img, value=x_j_img, need_weights=False)
+        x_i_img_att, _ = self.c2c_att(query=x_j_img, key=x_i_img, value=x_i_img, need_weights=False)
+        x_j_lidar_att, _ = self.l2l_att(query=x_i_lidar, key=x_j_lidar, value=x_j_lidar, need_weights=False)
+        x_i_lidar_att, _ = self.l2l_att(query=x_j_lidar, key=x_i_lidar, value=x_i_lidar, need_weights=False)
+        x_j_radar_att, _ = self.r2r_att(query=x_i_radar, key=x_j_radar, value=x_j_radar, need_weights=False)
+        x_i_radar_att, _ = self.r2r_att(query=x_j_radar, key=x_i_radar, value=x_i_radar, need_weights=False)
+        x_sens_j = torch.cat([x_j_radar_att.squeeze(1), x_j_lidar_att.squeeze(1), x_j_img_att.squeeze(1)], dim=1)
+        x_sens_i = torch.cat([x_i_radar_att.squeeze(1), x_i_lidar_att.squeeze(1), x_i_img_att.squeeze(1)], dim=1)
+        att_edge_attr = self.att_edge_encoder(torch.cat([x_sens_i, x_sens_j, edge_attr], dim=1))
+
+        x_sens = torch.cat([x_img, x_lidar, x_radar], dim=1)             # :172
+        x = self.node_encoder(pose_feats)                                # :174-176
+        initial_x = x
+        if capture is not None:
+            capture.append(("att_edge_attr", att_edge_attr))
+        for i in range(self.depth):                                      # :178-186
+            if i % 2 == 0 and self.run_dead_knn:
+                _dead_knn_block(x, node_timestamps, self.knn_conv)
+            x, edge_attr = self.message_passing(x, edge_index, edge_attr, initial_x, att_edge_attr)
+            if capture is not None:
+                capture.append((x, edge_attr))
+        return self.edge_classifier(edge_attr), x_sens                   # :188
+
+
+# --------------------------------------------------------------------------------------
+# callers restated
+# --------------------------------------------------------------------------------------
+def train_step(gnn, data, optimizer, batch_size: int, loss_kind: str = "cb", logits: bool = False):
+    """One optimisation step as Batch3DMOT.train does it (train.py:124-160):
+    BCELoss(weight=edge_weights)(out.squeeze(1), y.float()) / batch_size, zero_grad, backward,
+    Adam step.  ``logits=True`` is for PoseGNN whose head emits logits (pose_gnn.py:45-53; the
+    release holds no trainer for it): BCE-with-logits, the same loss on sigmoid(out)."""
+    gt = data.y.float()
+    out, aux = gnn(data)
+    out = out.squeeze(1)
+    w = data.edge_weights if loss_kind == "cb" else None
+    if logits:
+        loss = F.binary_cross_entropy_with_logits(out, gt, weight=w) / batch_size
+    else:
+        loss = F.binary_cross_entropy(out, gt, weight=w) / batch_size
+    optimizer.zero_grad()
+    loss.backward()
+    optimizer.step()
+    return loss.detach(), out.detach(), aux
+
+
+def greedy_flux(num_nodes: int, edges, scores, thresholds):
+    """predict.py:227-259 restated on integer node ids: keep edges whose (window-averaged) score
+    exceeds the per-source-class threshold (:231-233), then for every node keep the best
+    incoming and the best outgoing edge (greedy_filter_node_flux, :92-117; ``max`` keeps the
+    first of equal keys in insertion order).  Returns (kept edge ids, pred[n], succ[n]) with -1
+    for none."""
+    kept = [k for k in range(len(edges)) if scores[k] > thresholds[k]]
+    incoming = [dict() for _ in range(num_nodes)]
+    outgoing = [dict() for _ in range(num_nodes)]
+    for k in kept:
+        o, i = int(edges[k][0]), int(edges[k][1])
+        incoming[i][o] = float(scores[k])
+        outgoing[o][i] = float(scores[k])
+    pred = [max(d, key=d.get) if d else -1 for d in incoming]
+    succ = [max(d, key=d.get) if d else -1 for d in outgoing]
+    return kept, pred, succ
