@@ -1,0 +1,137 @@
+"""ctypes binding of ``libb3d_hip.so`` (C ABI declared in ``include/b3d.h``).
+
+The product path has no CPU fallback: if the HIP library is missing or a call fails this module
+raises -- it never routes through PyTorch ops or the oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libb3d_hip.so")
+
+B3D_FLAG_TRAINING = 1
+B3D_FLAG_RUN_DEAD_KNN = 2
+
+c_float_p = C.POINTER(C.c_float)
+
+
+class b3d_graph(C.Structure):
+    _fields_ = [("N", C.c_int32), ("E", C.c_int32), ("src", C.c_void_p), ("dst", C.c_void_p),
+                ("dst_ptr", C.c_void_p), ("dst_perm", C.c_void_p), ("src_ptr", C.c_void_p),
+                ("src_perm", C.c_void_p)]
+
+
+class b3d_linear(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("b", C.c_void_p)]
+
+
+class b3d_gat(C.Structure):
+    _fields_ = [("lin", C.c_void_p), ("att_src", C.c_void_p), ("att_dst", C.c_void_p), ("bias", C.c_void_p)]
+
+
+class b3d_mp_weights(C.Structure):
+    _fields_ = [("edge_update", b3d_linear * 3), ("create_past_msgs", b3d_linear * 2),
+                ("create_future_msgs", b3d_linear * 2), ("combine_future_past", b3d_linear * 3)]
+
+
+class b3d_pose_weights(C.Structure):
+    _fields_ = [("edge_encoder", b3d_linear * 3), ("node_encoder", b3d_linear * 3),
+                ("edge_classifier", b3d_linear * 4), ("mp", b3d_mp_weights), ("knn_conv", b3d_gat)]
+
+
+class b3d_pose_grads(C.Structure):       # same layout as the weights minus knn_conv
+    _fields_ = [("edge_encoder", b3d_linear * 3), ("node_encoder", b3d_linear * 3),
+                ("edge_classifier", b3d_linear * 4), ("mp", b3d_mp_weights)]
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load the HIP library or fail loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `make -C batch3dmot_amd/csrc` (or "
+            "`python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    lib.b3d_version.restype = C.c_int
+    lib.b3d_last_error.restype = C.c_char_p
+    lib.b3d_graph_workspace_bytes.restype = C.c_size_t
+    lib.b3d_graph_workspace_bytes.argtypes = [C.c_int32, C.c_int32]
+    lib.b3d_graph_build.restype = C.c_int
+    lib.b3d_graph_build.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t,
+                                    C.POINTER(b3d_graph), C.c_void_p]
+    lib.b3d_pose_workspace_bytes.restype = C.c_size_t
+    lib.b3d_pose_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_uint32]
+    lib.b3d_pose_forward.restype = C.c_int
+    lib.b3d_pose_forward.argtypes = [C.POINTER(b3d_pose_weights), C.POINTER(b3d_graph), C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p,
+                                     C.c_void_p, C.c_void_p]
+    lib.b3d_pose_backward.restype = C.c_int
+    lib.b3d_pose_backward.argtypes = [C.POINTER(b3d_pose_weights), C.POINTER(b3d_graph), C.c_void_p, C.c_void_p,
+                                      C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
+                                      C.POINTER(b3d_pose_grads), C.c_void_p]
+    lib.b3d_pose_debug_layer_ptrs.restype = C.c_int
+    lib.b3d_pose_debug_layer_ptrs.argtypes = [C.c_void_p, C.c_size_t, C.c_int32, C.c_int32, C.c_int32, C.c_uint32,
+                                              C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        msg = load().b3d_last_error()
+        raise RuntimeError(f"{what} failed ({status}): {msg.decode() if msg else '?'}")
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def current_stream(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def require_cuda(t: torch.Tensor, name: str, dtype=None) -> None:
+    if not t.is_cuda:
+        raise ValueError(f"{name} must live on the GPU (got {t.device}); the HIP path has no CPU fallback")
+    if dtype is not None and t.dtype != dtype:
+        raise ValueError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+
+
+class Graph:
+    """Device-side graph structure built once per batch and reused by all layers and by backward."""
+
+    def __init__(self, edge_index: torch.Tensor, num_nodes: int):
+        require_cuda(edge_index, "edge_index", torch.int64)
+        if edge_index.dim() != 2 or edge_index.size(0) != 2:
+            raise ValueError(f"edge_index must be [2, E], got {tuple(edge_index.shape)}")
+        lib = load()
+        self.N, self.E = int(num_nodes), int(edge_index.size(1))
+        nbytes = lib.b3d_graph_workspace_bytes(self.N, self.E)
+        self.ws = torch.empty(nbytes, dtype=torch.uint8, device=edge_index.device)
+        self.c = b3d_graph()
+        check(lib.b3d_graph_build(edge_index.data_ptr(), self.N, self.E, self.ws.data_ptr(), nbytes,
+                                  C.byref(self.c), current_stream(edge_index.device)), "b3d_graph_build")
+        self._keep = edge_index
+
+    def _view(self, p, n):
+        off = (p - self.ws.data_ptr())
+        return self.ws[off:off + 4 * n].view(torch.int32)
+
+    def arrays(self):
+        """int32 views (for tests): src, dst, dst_ptr, dst_perm, src_ptr, src_perm."""
+        g = self.c
+        return {"src": self._view(g.src, self.E), "dst": self._view(g.dst, self.E),
+                "dst_ptr": self._view(g.dst_ptr, self.N + 1), "dst_perm": self._view(g.dst_perm, self.E),
+                "src_ptr": self._view(g.src_ptr, self.N + 1), "src_perm": self._view(g.src_perm, self.E)}

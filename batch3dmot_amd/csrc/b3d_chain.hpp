@@ -1,0 +1,232 @@
+// Plain row-wise MLP stacks (edge / node encoders, edge classifier, modality heads, the
+// cross-edge attention encoder): the same register-resident MFMA chain as the message-passing
+// kernels, parameterised by how a row's input blocks are fetched and how its result is written.
+#pragma once
+#include "b3d_dev.hpp"
+
+namespace b3d {
+
+constexpr int kChainMaxLayers = 6;
+
+// ---- row loaders: fill NB feature blocks (layout L) for one row -------------------------------
+template <int NB_>
+struct LoadAligned {                 // [rows, stride] fp32, optional row gather
+  static constexpr int NB = NB_;
+  const float* ptr; const int* idx; int stride; int col0;
+  __device__ __forceinline__ void operator()(long row, bool valid, v4f* dst) const {
+    long r = row;
+    if (idx && valid) r = idx[row];
+    load_row<NB>(ptr, r, stride, col0, valid, dst);
+  }
+};
+
+struct LoadEdgeAttrF64 {             // edge_attr [E,4] float64 -> .float() (pose_gnn.py:67)
+  static constexpr int NB = 1;
+  const double* ptr;
+  __device__ __forceinline__ void operator()(long row, bool valid, v4f* dst) const {
+    const int q = (threadIdx.x & 63) >> 4;
+    v4f v = {0.f, 0.f, 0.f, 0.f};
+    if (valid && q == 0) {
+      const double* p = ptr + row * 4;
+      v.x = (float)p[0]; v.y = (float)p[1]; v.z = (float)p[2]; v.w = (float)p[3];
+    }
+    dst[0] = v;
+  }
+};
+
+template <int W>                     // [rows, W] fp32 with W not a multiple of 4 (pose_feats, W = 19)
+struct LoadUnaligned {
+  static constexpr int NB = (W + 15) / 16;
+  const float* ptr;
+  __device__ __forceinline__ void operator()(long row, bool valid, v4f* dst) const {
+    const int q = (threadIdx.x & 63) >> 4;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      float* v = reinterpret_cast<float*>(&dst[b]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = 16 * b + 4 * q + e;
+        v[e] = (valid && c < W) ? ptr[row * W + c] : 0.f;
+      }
+    }
+  }
+};
+
+struct LoadScalar {                  // [rows, 1] -> feature 0
+  static constexpr int NB = 1;
+  const float* ptr;                  // nullptr = zero
+  __device__ __forceinline__ void operator()(long row, bool valid, v4f* dst) const {
+    const int q = (threadIdx.x & 63) >> 4;
+    v4f v = {0.f, 0.f, 0.f, 0.f};
+    if (valid && q == 0 && ptr) v.x = ptr[row];
+    dst[0] = v;
+  }
+};
+
+template <int NB0, int NB1, int NB2>
+struct LoadConcat3 {                 // three aligned segments side by side
+  static constexpr int NB = NB0 + NB1 + NB2;
+  LoadAligned<NB0> a; LoadAligned<NB1> b; LoadAligned<NB2> c;
+  __device__ __forceinline__ void operator()(long row, bool valid, v4f* dst) const {
+    a(row, valid, dst); b(row, valid, dst + NB0); c(row, valid, dst + NB0 + NB1);
+  }
+};
+
+// Gradient arriving at the node encoder output (x = initial_x = x_enc):
+//   upstream d x_enc + running d initial_x + the layer-0 edge backward's per-edge rows
+//   (d x | d x0 at dst, d x | d x0 at src) summed over the node's CSR / CSC lists.
+template <int XB>
+struct LoadNodeEncGrad {
+  static constexpr int NB = XB;
+  const float* d_x_enc;   // [N, DX] or nullptr
+  const float* dx0_acc;   // [N, DX] or nullptr
+  const float* gdst; const float* gsrc;   // [E, 2 DX]
+  const int* dst_ptr; const int* dst_perm; const int* src_ptr; const int* src_perm;
+  __device__ __forceinline__ void operator()(long row, bool valid, v4f* dst) const {
+    v4f g[2 * XB];
+#pragma unroll
+    for (int b = 0; b < 2 * XB; ++b) g[b] = v4f{0.f, 0.f, 0.f, 0.f};
+    if (valid) {
+      segment_sum<2 * XB>(gdst, 32 * XB, 0, dst_perm, dst_ptr[row], dst_ptr[row + 1], g);
+      segment_sum<2 * XB>(gsrc, 32 * XB, 0, src_perm, src_ptr[row], src_ptr[row + 1], g);
+    }
+    v4f t[XB];
+    if (d_x_enc) { load_row<XB>(d_x_enc, row, 16 * XB, 0, valid, t); add_blocks<XB>(g, t); }
+    if (dx0_acc) { load_row<XB>(dx0_acc, row, 16 * XB, 0, valid, t); add_blocks<XB>(g, t); }
+#pragma unroll
+    for (int b = 0; b < XB; ++b) dst[b] = g[b] + g[XB + b];
+  }
+};
+
+// ---- row storers ------------------------------------------------------------------------------
+template <int NB_>
+struct StoreAligned {
+  static constexpr int NB = NB_;
+  float* ptr; const int* idx; int stride; int col0;
+  __device__ __forceinline__ void operator()(long row, bool valid, const v4f* src) const {
+    long r = row;
+    if (idx && valid) r = idx[row];
+    if (ptr) store_row<NB>(ptr, r, stride, col0, valid, src);
+  }
+};
+
+struct StoreScalar {                 // feature 0 -> [rows, 1], optional sigmoid (clr_att_gnn.py:57)
+  static constexpr int NB = 1;
+  float* ptr; int sigmoid;
+  __device__ __forceinline__ void operator()(long row, bool valid, const v4f* src) const {
+    const int q = (threadIdx.x & 63) >> 4;
+    if (valid && q == 0) {
+      float v = src[0].x;
+      if (sigmoid) v = 1.f / (1.f + __expf(-v));
+      ptr[row] = v;
+    }
+  }
+};
+
+struct StoreNone {
+  static constexpr int NB = 1;
+  __device__ __forceinline__ void operator()(long, bool, const v4f*) const {}
+};
+
+// ---- forward chain ------------------------------------------------------------------------------
+template <class In, class Out>
+struct ChainFwdArgs {
+  int rows;
+  In in;
+  Out out;
+  float* save_in;                       // padded copy of the input row [rows, KP0] or nullptr
+  float* save[kChainMaxLayers];         // hidden activations [rows, NP_l] (training) or nullptr
+  const float* wpack;
+};
+
+template <class Seq, unsigned RELU_MASK, int LI, class Args, class WS>
+__device__ __forceinline__ void chain_fwd_rec(WS& ws, bool more, const Args& a, long row,
+                                              bool valid, const v4f* in) {
+  constexpr int NB = Seq::np(LI) / 16;
+  v4f out[NB];
+  linear<Seq, LI, ((RELU_MASK >> LI) & 1u) != 0>(ws, more, in, out);
+  if constexpr (LI + 1 < Seq::NL) {
+    if (a.save[LI]) store_row<NB>(a.save[LI], row, Seq::np(LI), 0, valid, out);
+    chain_fwd_rec<Seq, RELU_MASK, LI + 1>(ws, more, a, row, valid, out);
+  } else {
+    a.out(row, valid, out);
+  }
+}
+
+template <class Seq, unsigned RELU_MASK, class In, class Out, int NW>
+__global__ __launch_bounds__(NW * 64, NW >= 4 ? 2 : 1) void chain_fwd_kernel(const ChainFwdArgs<In, Out> a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  static_assert(In::NB == Seq::kp(0) / 16, "loader width != first layer input width");
+  WStreamT<NW * 64> ws;
+  ws.init(a.wpack, smem);
+  ws.template start<Seq>();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int ntiles = (a.rows + NW * 16 - 1) / (NW * 16);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const bool more = tile + (int)gridDim.x < ntiles;
+    const long row = (long)tile * (NW * 16) + wave * kRowsPerWave + (lane & 15);
+    const bool valid = row < a.rows;
+    v4f in[In::NB];
+    a.in(row, valid, in);
+    if (a.save_in) store_row<In::NB>(a.save_in, row, 16 * In::NB, 0, valid, in);
+    chain_fwd_rec<Seq, RELU_MASK, 0>(ws, more, a, row, valid, in);
+  }
+}
+
+// ---- backward chain (data gradient) -------------------------------------------------------------
+// SeqT lists the TRANSPOSED images from the last layer down: L<NP_L, NP_{L-1}>, ..., and, when the
+// gradient of the input is wanted, finally L<NP_1, KP_1>.  G_L comes from the loader; for each
+// further step G_{l-1} = (W_l^T G_l) * (h_{l-1} > 0).  Every G_l (l < L) is stored for the weight
+// gradient; act[i] is the saved activation that masks the output of step i (nullptr: no mask,
+// i.e. the final step that yields the input gradient).
+template <class In, class Out>
+struct ChainBwdArgs {
+  int rows;
+  In in;
+  Out out;                              // receives the result of the LAST step
+  float* gtop;                          // padded copy of G_L [rows, KP of SeqT layer 0] or nullptr
+  const float* act[kChainMaxLayers];
+  float* gsave[kChainMaxLayers];        // G after step i [rows, NP of SeqT layer i] or nullptr
+  const float* wpack;
+};
+
+template <class SeqT, int LI, class Args, class WS>
+__device__ __forceinline__ void chain_bwd_rec(WS& ws, bool more, const Args& a, long row,
+                                              bool valid, const v4f* g) {
+  constexpr int NB = SeqT::np(LI) / 16;
+  v4f d[NB];
+  linear<SeqT, LI, false, false>(ws, more, g, d);
+  if (a.act[LI]) {
+    v4f act[NB];
+    load_row<NB>(a.act[LI], row, SeqT::np(LI), 0, valid, act);
+    relu_bwd<NB>(d, act);
+  }
+  if (a.gsave[LI]) store_row<NB>(a.gsave[LI], row, SeqT::np(LI), 0, valid, d);
+  if constexpr (LI + 1 < SeqT::NL) {
+    chain_bwd_rec<SeqT, LI + 1>(ws, more, a, row, valid, d);
+  } else {
+    a.out(row, valid, d);
+  }
+}
+
+template <class SeqT, class In, class Out, int NW>
+__global__ __launch_bounds__(NW * 64, NW >= 4 ? 2 : 1) void chain_bwd_kernel(const ChainBwdArgs<In, Out> a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  static_assert(In::NB == SeqT::kp(0) / 16, "loader width != top gradient width");
+  WStreamT<NW * 64> ws;
+  ws.init(a.wpack, smem);
+  ws.template start<SeqT>();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int ntiles = (a.rows + NW * 16 - 1) / (NW * 16);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const bool more = tile + (int)gridDim.x < ntiles;
+    const long row = (long)tile * (NW * 16) + wave * kRowsPerWave + (lane & 15);
+    const bool valid = row < a.rows;
+    v4f g[In::NB];
+    a.in(row, valid, g);
+    if (a.gtop) store_row<In::NB>(a.gtop, row, 16 * In::NB, 0, valid, g);
+    chain_bwd_rec<SeqT, 0>(ws, more, a, row, valid, g);
+  }
+}
+
+}  // namespace b3d

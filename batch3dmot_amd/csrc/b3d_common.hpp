@@ -1,0 +1,65 @@
+// Host-side helpers shared by the translation units of libb3d_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/b3d.h"
+
+namespace b3d {
+
+// thread-local error string returned by b3d_last_error(); the only mutable global state.
+char* last_error_buf();
+int fail(int code, const char* fmt, ...);
+
+#define B3D_HIP_CHECK(expr)                                                            \
+  do {                                                                                 \
+    hipError_t _e = (expr);                                                            \
+    if (_e != hipSuccess)                                                              \
+      return ::b3d::fail(B3D_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                         __FILE__, __LINE__);                                          \
+  } while (0)
+
+#define B3D_TRY(expr)          \
+  do {                         \
+    int _r = (expr);           \
+    if (_r != B3D_OK) return _r; \
+  } while (0)
+
+#define B3D_REQUIRE(cond, ...) \
+  do {                         \
+    if (!(cond)) return ::b3d::fail(B3D_ERR_ARG, __VA_ARGS__); \
+  } while (0)
+
+inline int launch_check(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(B3D_ERR_HIP, "launch of %s failed: %s", what, hipGetErrorString(e));
+  return B3D_OK;
+}
+
+// Number of workgroups for a row-tiled kernel: one 128-row tile per workgroup, capped so that
+// very large inputs grid-stride (256 CUs, at most a few resident workgroups each).
+inline int grid_for_tiles(long rows, int tile_rows, int cap = 2048) {
+  long t = (rows + tile_rows - 1) / tile_rows;
+  if (t < 1) t = 1;
+  return (int)(t < cap ? t : cap);
+}
+
+// Bump allocator over a caller-provided workspace (the library allocates nothing).
+struct Carver {
+  char* base;
+  size_t off, cap;
+  bool dry;     // size query: only count
+  Carver(void* p, size_t bytes) : base((char*)p), off(0), cap(bytes), dry(p == nullptr) {}
+  template <class T>
+  T* take(size_t n) {
+    size_t a = (off + 255) & ~(size_t)255;
+    off = a + n * sizeof(T);
+    if (dry) return nullptr;
+    return (off <= cap) ? (T*)(base + a) : nullptr;
+  }
+  bool ok() const { return dry || off <= cap; }
+};
+
+}  // namespace b3d

@@ -1,0 +1,342 @@
+// Device building blocks for the gfx950 (MI355X, CDNA4) message-passing kernels.
+//
+// Execution shape shared by every MLP kernel in this library
+// ----------------------------------------------------------
+//  * workgroup = 512 threads = 8 wavefronts (2 per SIMD); a wavefront owns 16 rows (edges or
+//    nodes) and carries their activations through a whole MLP stack IN REGISTERS.
+//  * every Linear layer is computed transposed, Y^T[out][row] = W[out][in] . X^T[in][row], with
+//    v_mfma_f32_16x16x4_f32 (exact fp32, bitwise an fmaf chain): the 16x16 accumulator of one
+//    layer (lane = row, registers = 4 consecutive output features) is directly the B operand of
+//    the next layer, so activations never leave the register file and need no transposition.
+//    "Layout L": lane l = (i = l & 15, q = l >> 4) holds, for feature block b (16 features),
+//    features 16 b + 4 q + {0,1,2,3} of row i as one float4.
+//  * weights are the A operand.  They are pre-packed ("images": row stride K+4 floats, bias in
+//    column K) and streamed global -> LDS in chunks of <= 52 KB through a two-buffer ring,
+//    asynchronously with LDS-DMA (global_load_lds_dwordx4) while the previous chunk is being
+//    multiplied; one workgroup barrier per chunk.
+//
+// No CUDA compatibility layer, no multi-backend dispatch: this file only builds for gfx950.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <utility>
+
+namespace b3d {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+constexpr int kWaves = 8;                 // wavefronts per workgroup
+constexpr int kThreads = kWaves * 64;     // 512
+constexpr int kRowsPerWave = 16;
+constexpr int kTileRows = kWaves * kRowsPerWave;   // 128 rows per workgroup tile
+constexpr int kWBufFloats = 13312;        // one weight ring slot: 52 KB
+constexpr int kChunkAlign = 256;          // floats; 1 KB = one wave-wide 16-byte LDS-DMA
+constexpr int kLdsBytes = 2 * kWBufFloats * 4;
+
+__host__ __device__ constexpr int round_up(int a, int b) { return (a + b - 1) / b * b; }
+__host__ __device__ constexpr int pad16(int a) { return round_up(a, 16); }
+
+// ---- packed weight image geometry (shared by host packer and device consumer) ------------
+// image of Linear(K -> N): NP = pad16(N) rows, row stride KP + 4 floats (KP = pad16(K)),
+// columns [0,K) = W[r][c], column KP = bias[r], everything else zero.  The image is cut into
+// row chunks that fit one ring slot; every chunk is padded to a multiple of 1 KB.
+__host__ __device__ constexpr int chunk_rows(int KP, int NP) {
+  int r = (kWBufFloats / (KP + 4)) / 16 * 16;
+  return r < NP ? r : NP;
+}
+__host__ __device__ constexpr int n_chunks(int KP, int NP) {
+  return (NP + chunk_rows(KP, NP) - 1) / chunk_rows(KP, NP);
+}
+__host__ __device__ constexpr int chunk_nrows(int KP, int NP, int c) {   // rows in chunk c
+  int cr = chunk_rows(KP, NP);
+  int left = NP - c * cr;
+  return left < cr ? left : cr;
+}
+__host__ __device__ constexpr int chunk_floats(int KP, int rows) {
+  return round_up(rows * (KP + 4), kChunkAlign);
+}
+__host__ __device__ constexpr int image_floats(int KP, int NP) {
+  int tot = 0;
+  for (int c = 0; c < n_chunks(KP, NP); ++c) tot += chunk_floats(KP, chunk_nrows(KP, NP, c));
+  return tot;
+}
+
+// A layer of a kernel's weight sequence: padded input width KP, padded output width NP.
+template <int KP_, int NP_>
+struct L {
+  static constexpr int KP = KP_, NP = NP_;
+  static_assert(KP_ % 16 == 0 && NP_ % 16 == 0, "pad layer widths to multiples of 16");
+};
+
+// The ordered list of layers a kernel consumes (one weight image each).
+template <class... Ls>
+struct LayerSeq {
+  static constexpr int NL = sizeof...(Ls);
+  __host__ __device__ static constexpr int kp(int li) { constexpr int a[] = {Ls::KP...}; return a[li]; }
+  __host__ __device__ static constexpr int np(int li) { constexpr int a[] = {Ls::NP...}; return a[li]; }
+  __host__ __device__ static constexpr int layer_chunks(int li) { return n_chunks(kp(li), np(li)); }
+  __host__ __device__ static constexpr int first_chunk(int li) {
+    int c = 0;
+    for (int i = 0; i < li; ++i) c += layer_chunks(i);
+    return c;
+  }
+  static constexpr int NCH = first_chunk(NL);
+  __host__ __device__ static constexpr int layer_off(int li) {     // float offset of the image
+    int o = 0;
+    for (int i = 0; i < li; ++i) o += image_floats(kp(i), np(i));
+    return o;
+  }
+  static constexpr int TOTAL_FLOATS = layer_off(NL);
+  __host__ __device__ static constexpr int chunk_layer(int ci) {
+    int li = 0;
+    while (ci >= first_chunk(li + 1)) ++li;
+    return li;
+  }
+  __host__ __device__ static constexpr int chunk_off(int ci) {
+    int li = chunk_layer(ci);
+    int o = layer_off(li);
+    for (int c = 0; c < ci - first_chunk(li); ++c) o += chunk_floats(kp(li), chunk_nrows(kp(li), np(li), c));
+    return o;
+  }
+  __host__ __device__ static constexpr int chunk_size(int ci) {    // floats, padded
+    int li = chunk_layer(ci);
+    return chunk_floats(kp(li), chunk_nrows(kp(li), np(li), ci - first_chunk(li)));
+  }
+};
+
+// ---- weight stream: global -> LDS, two slots ----------------------------------------------
+#ifndef B3D_USE_LDS_DMA
+#define B3D_USE_LDS_DMA 1
+#endif
+
+template <int NT>
+struct WStreamT {
+  const float* g;      // packed images of this kernel (global)
+  float* lds;          // 2 * kWBufFloats
+  int slot;            // slot that the NEXT acquire returns
+#if !B3D_USE_LDS_DMA
+  v4f pre[(kWBufFloats / 4 + NT - 1) / NT];
+#endif
+
+  __device__ __forceinline__ void init(const float* gw, float* l) { g = gw; lds = l; slot = 0; }
+
+  template <class Seq, int CI>
+  __device__ __forceinline__ void issue(int to_slot) {
+    constexpr int off = Seq::chunk_off(CI);
+    constexpr int n4 = Seq::chunk_size(CI) / 4;          // multiple of 64
+    static_assert(Seq::chunk_size(CI) <= kWBufFloats, "chunk larger than a ring slot");
+#if B3D_USE_LDS_DMA
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float* src = g + off;
+    float* dst = lds + to_slot * kWBufFloats;
+#pragma unroll
+    for (int i0 = 0; i0 < n4; i0 += NT) {
+      const int base = i0 + wave * 64;                   // wave-uniform
+      if (base < n4) {
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(src + (size_t)(base + lane) * 4),
+            (__attribute__((address_space(3))) void*)(dst + (size_t)base * 4), 16, 0, 0);
+      }
+    }
+#else
+    (void)to_slot;
+    const float* src = g + off;
+#pragma unroll
+    for (int j = 0; j < (n4 + NT - 1) / NT; ++j) {
+      const int i = j * NT + threadIdx.x;
+      if (i < n4) pre[j] = *reinterpret_cast<const v4f*>(src + (size_t)i * 4);
+    }
+#endif
+  }
+
+  // Start the stream: chunk 0 of the first tile.
+  template <class Seq>
+  __device__ __forceinline__ void start() { issue<Seq, 0>(slot); }
+
+  // Make chunk CI visible to the whole workgroup and start fetching the next one.
+  // more == false suppresses the wrap-around prefetch after the kernel's last chunk.
+  template <class Seq, int CI>
+  __device__ __forceinline__ const float* acquire(bool more) {
+    constexpr int NXT = (CI + 1) % Seq::NCH;
+#if B3D_USE_LDS_DMA
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (NXT != 0 || more) issue<Seq, NXT>(slot ^ 1);
+#else
+    {
+      constexpr int n4 = Seq::chunk_size(CI) / 4;
+      float* dst = lds + slot * kWBufFloats;
+#pragma unroll
+      for (int j = 0; j < (n4 + NT - 1) / NT; ++j) {
+        const int i = j * NT + threadIdx.x;
+        if (i < n4) *reinterpret_cast<v4f*>(dst + (size_t)i * 4) = pre[j];
+      }
+    }
+    __syncthreads();
+    if (NXT != 0 || more) issue<Seq, NXT>(slot ^ 1);
+#endif
+    const float* cur = lds + slot * kWBufFloats;
+    slot ^= 1;
+    return cur;
+  }
+};
+
+using WStream = WStreamT<kThreads>;
+
+// ---- one Linear layer on a 16-row wave tile, activations in registers ---------------------
+__device__ __forceinline__ v4f mfma4(const v4f a, const v4f b, v4f c) {
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, c, 0, 0, 0);
+  return c;
+}
+
+__device__ __forceinline__ v4f relu4(v4f a) {
+  v4f r;
+  r.x = fmaxf(a.x, 0.f); r.y = fmaxf(a.y, 0.f); r.z = fmaxf(a.z, 0.f); r.w = fmaxf(a.w, 0.f);
+  return r;
+}
+
+// out = act(W . in + b) for layer LI of Seq.  in: KB feature blocks (layout L), out: NB blocks.
+template <class Seq, int LI, bool RELU, bool BIAS, int CH, class WS>
+__device__ __forceinline__ void linear_chunk(WS& ws, bool more, const v4f* __restrict__ in,
+                                             v4f* __restrict__ out) {
+  constexpr int KP = Seq::kp(LI), NP = Seq::np(LI);
+  constexpr int KB = KP / 16, NB = NP / 16;
+  constexpr int STRIDE = KP + 4;
+  constexpr int CR = chunk_rows(KP, NP);
+  constexpr int C0 = Seq::first_chunk(LI);
+  constexpr int mb0 = CH * (CR / 16);
+  constexpr int mbn = (mb0 + CR / 16 < NB) ? mb0 + CR / 16 : NB;
+  const int lane = threadIdx.x & 63;
+  const int m = lane & 15, q = lane >> 4;
+  const float* w = ws.template acquire<Seq, C0 + CH>(more);
+  // two output blocks at a time: two independent accumulator chains hide the 40-cycle
+  // dependent latency of v_mfma_f32_16x16x4_f32 behind its 32-cycle issue interval.
+#pragma unroll
+  for (int mb = mb0; mb < mbn; mb += 2) {
+    const bool two = (mb + 1 < mbn);
+    const float* wr0 = w + ((mb - mb0) * 16 + m) * STRIDE + 4 * q;
+    const float* wr1 = wr0 + 16 * STRIDE;
+    v4f acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (BIAS) {
+      const float* wb0 = w + ((mb - mb0) * 16 + 4 * q) * STRIDE + KP;
+      acc0.x = wb0[0]; acc0.y = wb0[STRIDE]; acc0.z = wb0[2 * STRIDE]; acc0.w = wb0[3 * STRIDE];
+      if (two) {
+        const float* wb1 = wb0 + 16 * STRIDE;
+        acc1.x = wb1[0]; acc1.y = wb1[STRIDE]; acc1.z = wb1[2 * STRIDE]; acc1.w = wb1[3 * STRIDE];
+      }
+    }
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      const v4f a0 = *reinterpret_cast<const v4f*>(wr0 + 16 * kb);
+      acc0 = mfma4(a0, in[kb], acc0);
+      if (two) {
+        const v4f a1 = *reinterpret_cast<const v4f*>(wr1 + 16 * kb);
+        acc1 = mfma4(a1, in[kb], acc1);
+      }
+    }
+    out[mb] = RELU ? relu4(acc0) : acc0;
+    if (two) out[mb + 1] = RELU ? relu4(acc1) : acc1;
+  }
+}
+
+template <class Seq, int LI, bool RELU, bool BIAS, class WS, int... CH>
+__device__ __forceinline__ void linear_impl(WS& ws, bool more, const v4f* __restrict__ in,
+                                            v4f* __restrict__ out, std::integer_sequence<int, CH...>) {
+  (linear_chunk<Seq, LI, RELU, BIAS, CH, WS>(ws, more, in, out), ...);
+}
+
+template <class Seq, int LI, bool RELU, bool BIAS = true, class WS>
+__device__ __forceinline__ void linear(WS& ws, bool more, const v4f* __restrict__ in,
+                                       v4f* __restrict__ out) {
+  linear_impl<Seq, LI, RELU, BIAS, WS>(ws, more, in, out,
+                                   std::make_integer_sequence<int, n_chunks(Seq::kp(LI), Seq::np(LI))>{});
+}
+
+// ---- row <-> register helpers (layout L) -----------------------------------------------------
+// NBLK feature blocks of one row, starting at column col0 (multiple of 4 floats).
+template <int NBLK>
+__device__ __forceinline__ void load_row(const float* __restrict__ base, long row, int stride,
+                                         int col0, bool valid, v4f* __restrict__ dst) {
+  const int q = (threadIdx.x & 63) >> 4;
+  const float* p = base + row * (long)stride + col0 + 4 * q;
+#pragma unroll
+  for (int b = 0; b < NBLK; ++b) {
+    dst[b] = valid ? *reinterpret_cast<const v4f*>(p + 16 * b) : v4f{0.f, 0.f, 0.f, 0.f};
+  }
+}
+
+template <int NBLK>
+__device__ __forceinline__ void store_row(float* __restrict__ base, long row, int stride, int col0,
+                                          bool valid, const v4f* __restrict__ src) {
+  const int q = (threadIdx.x & 63) >> 4;
+  float* p = base + row * (long)stride + col0 + 4 * q;
+  if (valid) {
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b) *reinterpret_cast<v4f*>(p + 16 * b) = src[b];
+  }
+}
+
+// relu mask: g where act > 0 else 0
+template <int NBLK>
+__device__ __forceinline__ void relu_bwd(v4f* __restrict__ g, const v4f* __restrict__ act) {
+#pragma unroll
+  for (int b = 0; b < NBLK; ++b) {
+    g[b].x = act[b].x > 0.f ? g[b].x : 0.f;
+    g[b].y = act[b].y > 0.f ? g[b].y : 0.f;
+    g[b].z = act[b].z > 0.f ? g[b].z : 0.f;
+    g[b].w = act[b].w > 0.f ? g[b].w : 0.f;
+  }
+}
+
+template <int NBLK>
+__device__ __forceinline__ void add_blocks(v4f* __restrict__ a, const v4f* __restrict__ b) {
+#pragma unroll
+  for (int i = 0; i < NBLK; ++i) a[i] += b[i];
+}
+
+template <int NBLK>
+__device__ __forceinline__ void copy_blocks(v4f* __restrict__ a, const v4f* __restrict__ b) {
+#pragma unroll
+  for (int i = 0; i < NBLK; ++i) a[i] = b[i];
+}
+
+// Sum of rows listed in perm[beg..end) (a CSR / CSC segment), NBLK blocks starting at col0.
+// perm == nullptr means identity.  Rows are fetched four (two for wide rows) at a time so that
+// several independent loads are in flight per lane, and added in list order (fixed summation
+// order -> bitwise reproducible).
+template <int NBLK>
+__device__ __forceinline__ void segment_sum(const float* __restrict__ base, int stride, int col0,
+                                            const int* __restrict__ perm, int beg, int end,
+                                            v4f* __restrict__ acc) {
+  constexpr int U = (NBLK <= 6) ? 4 : 2;
+  const int q = (threadIdx.x & 63) >> 4;
+  const float* b0 = base + col0 + 4 * q;
+  int k = beg;
+  for (; k + U <= end; k += U) {
+    long r[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) r[u] = perm ? perm[k + u] : (k + u);
+    v4f t[U][NBLK];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float* p = b0 + r[u] * (long)stride;
+#pragma unroll
+      for (int b = 0; b < NBLK; ++b) t[u][b] = *reinterpret_cast<const v4f*>(p + 16 * b);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int b = 0; b < NBLK; ++b) acc[b] += t[u][b];
+  }
+  for (; k < end; ++k) {
+    const long r = perm ? perm[k] : k;
+    const float* p = b0 + r * (long)stride;
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b) acc[b] += *reinterpret_cast<const v4f*>(p + 16 * b);
+  }
+}
+
+}  // namespace b3d

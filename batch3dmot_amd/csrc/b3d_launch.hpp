@@ -1,0 +1,112 @@
+// Host-side launch helpers shared by the model orchestration files.
+#pragma once
+#include "b3d_common.hpp"
+#include "b3d_chain.hpp"
+#include "b3d_mp.hpp"
+#include "b3d_pack.hpp"
+#include "b3d_wgrad.hpp"
+
+namespace b3d {
+
+template <class K>
+inline int set_lds(K kernel, int bytes) {
+  if (bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return fail(B3D_ERR_HIP, "hipFuncSetAttribute(%d B LDS): %s", bytes, hipGetErrorString(e));
+  }
+  return B3D_OK;
+}
+
+// Row-tiled MLP kernels.  NW = wavefronts per workgroup (each owns 16 rows).  Edge-sized inputs
+// use 8; node-sized inputs (a few thousand rows) use 1 so the launch still covers ~200 CUs.
+template <int NW, class Kern, class Args>
+inline int launch_rows(Kern kernel, const char* name, const Args& a, long rows, hipStream_t stream) {
+  if (rows <= 0) return B3D_OK;
+  B3D_TRY(set_lds(kernel, kLdsBytes));
+  hipLaunchKernelGGL(kernel, dim3(grid_for_tiles(rows, NW * 16)), dim3(NW * 64), kLdsBytes, stream, a);
+  return launch_check(name);
+}
+constexpr int kNWEdge = 8, kNWNode = 1;
+
+inline WgSeg seg(const float* p, const int* idx, int stride, int col0, int width) {
+  WgSeg s;
+  s.ptr = p; s.idx = idx; s.stride = stride; s.col0 = col0; s.width = width;
+  s.aligned = ((stride & 3) == 0 && (col0 & 3) == 0 && ((uintptr_t)p & 15) == 0) ? 1 : 0;
+  return s;
+}
+
+// Chunk count of a weight-gradient job.  A workgroup's time is dominated by per-tile latency, not by
+// the matrix size, so every job gets the same number of rows per chunk (8 tiles of 32 rows).
+constexpr int kWgRowsPerChunk = 8 * kWgRT;
+inline int wg_nchunks(long rows, int /*NP*/, int /*KP*/, long /*launch_weight*/) {
+  if (rows <= 0) return 1;
+  return (int)((rows + kWgRowsPerChunk - 1) / kWgRowsPerChunk);
+}
+inline int wg_rows_per_chunk(long /*rows*/, int /*nchunks*/) { return kWgRowsPerChunk; }
+inline size_t wg_slab_floats(int nchunks, int NP, int KP) { return (size_t)nchunks * ((size_t)NP * KP + NP); }
+
+template <int MAXMB, int MAXNBW>
+inline int launch_wgrad(WgArgs& a, hipStream_t stream) {
+  constexpr int SLOTS = (kWgRT * (16 * MAXMB + 128 * MAXNBW) / 4 + kThreads - 1) / kThreads;
+  if (a.njobs == 0) return B3D_OK;
+  int wgs = 0, maxkp = 0;
+  for (int j = 0; j < a.njobs; ++j) {
+    WgJob& job = a.jobs[j];
+    if (job.KP / 16 > 8 * MAXNBW)
+      return fail(B3D_ERR_ARG, "wgrad job %d (%dx%d) exceeds kernel configuration <%d,%d>", j, job.NP, job.KP, MAXMB, MAXNBW);
+    job.mgroups = (job.NP / 16 + MAXMB - 1) / MAXMB;
+    job.wg_begin = wgs;
+    wgs += job.nchunks * job.mgroups;
+    if (job.KP > maxkp) maxkp = job.KP;
+  }
+  const int lds = kWgRT * ((MAXMB * 16 + 4) + (maxkp + 4)) * 4;
+  auto kern = wgrad_kernel<MAXMB, MAXNBW, SLOTS>;
+  B3D_TRY(set_lds(kern, lds));
+  hipLaunchKernelGGL(kern, dim3(wgs), dim3(kThreads), lds, stream, a);
+  return launch_check("wgrad_kernel");
+}
+
+inline int launch_reduce(RedArgs& a, hipStream_t stream) {
+  int total = 0;
+  for (int i = 0; i < a.nentries; ++i) {
+    a.e[i].begin = total;
+    total += a.e[i].N * a.e[i].K + a.e[i].N;
+  }
+  a.total = total;
+  if (total == 0) return B3D_OK;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, a);
+  return launch_check("wgrad_reduce_kernel");
+}
+
+// One Linear layer's weight-gradient bookkeeping: slab + job template.
+struct LinSlab {
+  float* slab;
+  int nchunks, NP, KP, N, K;
+  bool used;     // already written during this backward -> accumulate
+};
+
+inline WgJob make_job(LinSlab& ls, long rows, const WgSeg& g) {
+  WgJob j;
+  memset(&j, 0, sizeof(j));
+  j.g = g;
+  j.nact = 0;
+  j.NP = ls.NP; j.KP = ls.KP;
+  j.rows = (int)rows;
+  j.nchunks = ls.nchunks;
+  j.rows_per_chunk = wg_rows_per_chunk(rows, ls.nchunks);
+  j.slab = ls.slab;
+  j.accumulate = ls.used ? 1 : 0;
+  ls.used = true;
+  return j;
+}
+inline void add_act(WgJob& j, const WgSeg& s) { j.act[j.nact++] = s; }
+
+inline RedEntry red_entry(const LinSlab& ls, float* dw, float* db) {
+  RedEntry e;
+  e.slab = ls.slab; e.nchunks = ls.nchunks; e.NP = ls.NP; e.KP = ls.KP; e.N = ls.N; e.K = ls.K;
+  e.dw = dw; e.db = db; e.begin = 0;
+  return e;
+}
+
+}  // namespace b3d

@@ -1,0 +1,488 @@
+// PoseGNN.forward / backward (reference batch_3dmot/models/pose_gnn.py:24-86) as a sequence of
+// gfx950 kernel launches on one stream.  All scratch lives in the caller's workspace.
+#include "b3d_launch.hpp"
+#include "b3d_knn.hpp"
+
+namespace b3d {
+
+using D = DimsP;
+// encoders / classifier, widths padded to multiples of 16
+using SeqEdgeEnc = LayerSeq<L<16, 16>, L<16, 16>, L<16, 32>>;            // 4-8-16-32    pose_gnn.py:29-35
+using SeqNodeEnc = LayerSeq<L<32, 32>, L<32, 48>, L<48, 48>>;            // 19-24-36-48  :37-43
+using SeqCls = LayerSeq<L<32, 16>, L<16, 16>, L<16, 16>, L<16, 16>>;     // 32-16-8-4-1  :45-53
+using SeqClsT = LayerSeq<L<16, 16>, L<16, 16>, L<16, 16>, L<16, 32>>;    // W4^T, W3^T, W2^T, W1^T
+using SeqEdgeEncT = LayerSeq<L<32, 16>, L<16, 16>>;                      // W3^T, W2^T
+using SeqNodeEncT = LayerSeq<L<48, 48>, L<48, 32>>;                      // W3^T, W2^T
+
+enum { LIN_EE0, LIN_EE1, LIN_EE2, LIN_NE0, LIN_NE1, LIN_NE2, LIN_C0, LIN_C1, LIN_C2, LIN_C3,
+       LIN_EU0, LIN_EU1, LIN_EU2, LIN_PA0, LIN_PA1, LIN_FU0, LIN_FU1, LIN_CF0, LIN_CF1, LIN_CF2, LIN_COUNT };
+
+struct LinDim { int N, K; };
+static const LinDim kLinDims[LIN_COUNT] = {
+    {8, 4}, {16, 8}, {32, 16}, {24, 19}, {36, 24}, {48, 36}, {16, 32}, {8, 16}, {4, 8}, {1, 4},
+    {96, 128}, {64, 96}, {32, 64}, {96, 128}, {64, 96}, {96, 128}, {64, 96}, {96, 128}, {64, 96}, {48, 64}};
+static const bool kLinOnEdges[LIN_COUNT] = {1, 1, 1, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0};
+
+struct PoseWs {
+  // packed weight images
+  float *wp_ee, *wp_ne, *wp_cls, *wp_efwd, *wp_nfwd, *wp_ebwd, *wp_ebwd_nm, *wp_nbwd, *wp_clsT, *wp_eeT, *wp_neT;
+  // encoder / classifier activations
+  float *ea_pad, *ee_a1, *ee_a2, *pose_pad, *ne_a1, *ne_a2, *c_a1, *c_a2, *c_a3;
+  float* x[16];      // x[0] = x_enc ... x[depth]
+  float* e[16];      // e[0] = encoded edge_attr ... e[depth]
+  float *sH1[16], *sH2[16], *sF1[16], *sP1[16], *M[16], *nH1[16], *nH2[16];
+  float *fut, *past;
+  // backward scratch
+  float *de[2], *gdst, *gsrc, *dM, *dx0_acc;
+  float *GdH1, *GdH2, *Gde, *GdF1, *GdP1, *Gdx, *GnH2, *GnH1;
+  float *gc3, *gc2, *gc1, *ge2, *ge1, *gn_top, *gn2, *gn1;
+  LinSlab lin[LIN_COUNT];
+  KnnWs knn;
+  size_t bytes;
+  bool ok;
+};
+
+static void carve(PoseWs& w, void* ws, size_t ws_bytes, int N, int E, int depth, uint32_t flags) {
+  Carver c(ws, ws_bytes);
+  const bool tr = flags & B3D_FLAG_TRAINING;
+  const size_t e_ = (size_t)(E > 0 ? E : 1), n_ = (size_t)(N > 0 ? N : 1);
+  memset(&w, 0, sizeof(w));
+  w.wp_ee = c.take<float>(SeqEdgeEnc::TOTAL_FLOATS);
+  w.wp_ne = c.take<float>(SeqNodeEnc::TOTAL_FLOATS);
+  w.wp_cls = c.take<float>(SeqCls::TOTAL_FLOATS);
+  w.wp_efwd = c.take<float>(D::EdgeFwdSeq::TOTAL_FLOATS);
+  w.wp_nfwd = c.take<float>(D::NodeFwdSeq::TOTAL_FLOATS);
+  w.x[0] = c.take<float>(n_ * D::DX);
+  w.e[0] = c.take<float>(e_ * D::DE);
+  w.fut = c.take<float>(e_ * D::DM);
+  w.past = c.take<float>(e_ * D::DM);
+  if (!tr) {
+    // inference: ping-pong x / e, nothing saved
+    w.x[1] = c.take<float>(n_ * D::DX);
+    w.x[2] = c.take<float>(n_ * D::DX);
+    w.e[1] = c.take<float>(e_ * D::DE);
+    w.e[2] = c.take<float>(e_ * D::DE);
+    for (int l = 3; l <= depth; ++l) { w.x[l] = w.x[1 + (l - 1) % 2]; w.e[l] = w.e[1 + (l - 1) % 2]; }
+  } else {
+    w.wp_ebwd = c.take<float>(D::EdgeBwdSeq::TOTAL_FLOATS);
+    w.wp_ebwd_nm = c.take<float>(D::EdgeBwdSeqNoMsg::TOTAL_FLOATS);
+    w.wp_nbwd = c.take<float>(D::NodeBwdSeq::TOTAL_FLOATS);
+    w.wp_clsT = c.take<float>(SeqClsT::TOTAL_FLOATS);
+    w.wp_eeT = c.take<float>(SeqEdgeEncT::TOTAL_FLOATS);
+    w.wp_neT = c.take<float>(SeqNodeEncT::TOTAL_FLOATS);
+    w.ea_pad = c.take<float>(e_ * 16);
+    w.ee_a1 = c.take<float>(e_ * 16);
+    w.ee_a2 = c.take<float>(e_ * 16);
+    w.pose_pad = c.take<float>(n_ * 32);
+    w.ne_a1 = c.take<float>(n_ * 32);
+    w.ne_a2 = c.take<float>(n_ * 48);
+    w.c_a1 = c.take<float>(e_ * 16);
+    w.c_a2 = c.take<float>(e_ * 16);
+    w.c_a3 = c.take<float>(e_ * 16);
+    for (int l = 1; l <= depth; ++l) { w.x[l] = c.take<float>(n_ * D::DX); w.e[l] = c.take<float>(e_ * D::DE); }
+    for (int l = 0; l < depth; ++l) {
+      w.sH1[l] = c.take<float>(e_ * D::EH1);
+      w.sH2[l] = c.take<float>(e_ * D::EH2);
+      w.sF1[l] = c.take<float>(e_ * D::MH);
+      w.sP1[l] = c.take<float>(e_ * D::MH);
+      w.M[l] = c.take<float>(n_ * D::NIN);
+      w.nH1[l] = c.take<float>(n_ * D::NH1);
+      w.nH2[l] = c.take<float>(n_ * D::NH2);
+    }
+    w.de[0] = c.take<float>(e_ * D::DE);
+    w.de[1] = c.take<float>(e_ * D::DE);
+    w.gdst = c.take<float>(e_ * 2 * D::DX);
+    w.gsrc = c.take<float>(e_ * 2 * D::DX);
+    w.dM = c.take<float>(n_ * D::NIN);
+    w.dx0_acc = c.take<float>(n_ * D::DX);
+    w.GdH1 = c.take<float>(e_ * D::EH1);
+    w.GdH2 = c.take<float>(e_ * D::EH2);
+    w.Gde = c.take<float>(e_ * D::DE);
+    w.GdF1 = c.take<float>(e_ * D::MH);
+    w.GdP1 = c.take<float>(e_ * D::MH);
+    w.Gdx = c.take<float>(n_ * D::DX);
+    w.GnH2 = c.take<float>(n_ * D::NH2);
+    w.GnH1 = c.take<float>(n_ * D::NH1);
+    w.gc3 = c.take<float>(e_ * 16);
+    w.gc2 = c.take<float>(e_ * 16);
+    w.gc1 = c.take<float>(e_ * 16);
+    w.ge2 = c.take<float>(e_ * 16);
+    w.ge1 = c.take<float>(e_ * 16);
+    w.gn_top = c.take<float>(n_ * 48);
+    w.gn2 = c.take<float>(n_ * 48);
+    w.gn1 = c.take<float>(n_ * 32);
+    // weight-gradient slabs; chunk counts are a pure function of (rows, dims)
+    long w_edge = 0, w_node = 0;
+    for (int i = LIN_EU0; i <= LIN_FU1; ++i) w_edge += (long)pad16(kLinDims[i].N) * pad16(kLinDims[i].K);
+    for (int i = LIN_CF0; i <= LIN_CF2; ++i) w_node += (long)pad16(kLinDims[i].N) * pad16(kLinDims[i].K);
+    for (int i = 0; i < LIN_COUNT; ++i) {
+      LinSlab& ls = w.lin[i];
+      ls.N = kLinDims[i].N; ls.K = kLinDims[i].K;
+      ls.NP = pad16(ls.N); ls.KP = pad16(ls.K);
+      const long rows = kLinOnEdges[i] ? E : N;
+      long lw;
+      if (i >= LIN_EU0 && i <= LIN_FU1) lw = w_edge;
+      else if (i >= LIN_CF0) lw = w_node;
+      else lw = (long)ls.NP * ls.KP * 4;           // encoders / classifier: ~128 chunks each
+      ls.nchunks = wg_nchunks(rows, ls.NP, ls.KP, lw);
+      ls.slab = c.take<float>(wg_slab_floats(ls.nchunks, ls.NP, ls.KP));
+      ls.used = false;
+    }
+  }
+  if (flags & B3D_FLAG_RUN_DEAD_KNN) knn_carve(w.knn, c, N, D::DX);
+  w.bytes = c.off + 256;
+  w.ok = c.ok();
+}
+
+// ---- forward ------------------------------------------------------------------------------------
+static int pack_forward(const b3d_pose_weights* pw, PoseWs& w, bool training, hipStream_t stream) {
+  PackDesc d[48];
+  int n = 0;
+  const b3d_linear* ee = pw->edge_encoder;
+  const b3d_linear* ne = pw->node_encoder;
+  const b3d_linear* cl = pw->edge_classifier;
+  const b3d_mp_weights& mp = pw->mp;
+  for (int i = 0; i < 3; ++i) d[n++] = pack_desc<SeqEdgeEnc>(i, w.wp_ee, ee[i].w, ee[i].b, kLinDims[LIN_EE0 + i].N, kLinDims[LIN_EE0 + i].K, false);
+  for (int i = 0; i < 3; ++i) d[n++] = pack_desc<SeqNodeEnc>(i, w.wp_ne, ne[i].w, ne[i].b, kLinDims[LIN_NE0 + i].N, kLinDims[LIN_NE0 + i].K, false);
+  for (int i = 0; i < 4; ++i) d[n++] = pack_desc<SeqCls>(i, w.wp_cls, cl[i].w, cl[i].b, kLinDims[LIN_C0 + i].N, kLinDims[LIN_C0 + i].K, false);
+  using EF = D::EdgeFwdSeq;
+  for (int i = 0; i < 3; ++i) d[n++] = pack_desc<EF>(i, w.wp_efwd, mp.edge_update[i].w, mp.edge_update[i].b, kLinDims[LIN_EU0 + i].N, kLinDims[LIN_EU0 + i].K, false);
+  for (int i = 0; i < 2; ++i) d[n++] = pack_desc<EF>(3 + i, w.wp_efwd, mp.create_future_msgs[i].w, mp.create_future_msgs[i].b, kLinDims[LIN_FU0 + i].N, kLinDims[LIN_FU0 + i].K, false);
+  for (int i = 0; i < 2; ++i) d[n++] = pack_desc<EF>(5 + i, w.wp_efwd, mp.create_past_msgs[i].w, mp.create_past_msgs[i].b, kLinDims[LIN_PA0 + i].N, kLinDims[LIN_PA0 + i].K, false);
+  for (int i = 0; i < 3; ++i) d[n++] = pack_desc<D::NodeFwdSeq>(i, w.wp_nfwd, mp.combine_future_past[i].w, mp.combine_future_past[i].b, kLinDims[LIN_CF0 + i].N, kLinDims[LIN_CF0 + i].K, false);
+  if (training) {
+    // transposed images: image rows = forward inputs (K), image cols = forward outputs (N)
+    auto T = [&](auto seq_tag, int li, float* base, const b3d_linear& l, int lin) {
+      using S = decltype(seq_tag);
+      d[n++] = pack_desc<S>(li, base, l.w, nullptr, kLinDims[lin].K, kLinDims[lin].N, true);
+    };
+    using EB = D::EdgeBwdSeq;
+    T(EB{}, 0, w.wp_ebwd, mp.create_past_msgs[1], LIN_PA1);
+    T(EB{}, 1, w.wp_ebwd, mp.create_past_msgs[0], LIN_PA0);
+    T(EB{}, 2, w.wp_ebwd, mp.create_future_msgs[1], LIN_FU1);
+    T(EB{}, 3, w.wp_ebwd, mp.create_future_msgs[0], LIN_FU0);
+    T(EB{}, 4, w.wp_ebwd, mp.edge_update[2], LIN_EU2);
+    T(EB{}, 5, w.wp_ebwd, mp.edge_update[1], LIN_EU1);
+    T(EB{}, 6, w.wp_ebwd, mp.edge_update[0], LIN_EU0);
+    using EN = D::EdgeBwdSeqNoMsg;
+    T(EN{}, 0, w.wp_ebwd_nm, mp.edge_update[2], LIN_EU2);
+    T(EN{}, 1, w.wp_ebwd_nm, mp.edge_update[1], LIN_EU1);
+    T(EN{}, 2, w.wp_ebwd_nm, mp.edge_update[0], LIN_EU0);
+    using NB = D::NodeBwdSeq;
+    T(NB{}, 0, w.wp_nbwd, mp.combine_future_past[2], LIN_CF2);
+    T(NB{}, 1, w.wp_nbwd, mp.combine_future_past[1], LIN_CF1);
+    T(NB{}, 2, w.wp_nbwd, mp.combine_future_past[0], LIN_CF0);
+    T(SeqClsT{}, 0, w.wp_clsT, cl[3], LIN_C3);
+    T(SeqClsT{}, 1, w.wp_clsT, cl[2], LIN_C2);
+    T(SeqClsT{}, 2, w.wp_clsT, cl[1], LIN_C1);
+    T(SeqClsT{}, 3, w.wp_clsT, cl[0], LIN_C0);
+    T(SeqEdgeEncT{}, 0, w.wp_eeT, ee[2], LIN_EE2);
+    T(SeqEdgeEncT{}, 1, w.wp_eeT, ee[1], LIN_EE1);
+    T(SeqNodeEncT{}, 0, w.wp_neT, ne[2], LIN_NE2);
+    T(SeqNodeEncT{}, 1, w.wp_neT, ne[1], LIN_NE1);
+  }
+  return pack_images(d, n, stream);
+}
+
+static int check_weights(const b3d_pose_weights* pw) {
+  B3D_REQUIRE(pw != nullptr, "weights struct is null");
+  const b3d_linear* all[] = {pw->edge_encoder, pw->node_encoder, pw->edge_classifier, pw->mp.edge_update,
+                             pw->mp.create_past_msgs, pw->mp.create_future_msgs, pw->mp.combine_future_past};
+  const int cnt[] = {3, 3, 4, 3, 2, 2, 3};
+  for (int g = 0; g < 7; ++g)
+    for (int i = 0; i < cnt[g]; ++i)
+      B3D_REQUIRE(all[g][i].w != nullptr && all[g][i].b != nullptr, "null weight/bias pointer (group %d layer %d)", g, i);
+  return B3D_OK;
+}
+
+}  // namespace b3d
+
+using namespace b3d;
+
+extern "C" size_t b3d_pose_workspace_bytes(int32_t N, int32_t E, int32_t depth, uint32_t flags) {
+  if (depth < 1 || depth > 15) return 0;
+  PoseWs w;
+  carve(w, nullptr, 0, N, E, depth, flags);
+  return w.bytes;
+}
+
+extern "C" int b3d_pose_debug_layer_ptrs(void* workspace, size_t workspace_bytes, int32_t N, int32_t E,
+                                         int32_t depth, uint32_t flags, int32_t layer, float** x, float** e) {
+  B3D_REQUIRE(depth >= 1 && depth <= 15 && layer >= 0 && layer <= depth, "bad layer");
+  PoseWs w;
+  carve(w, workspace, workspace_bytes, N, E, depth, flags);
+  if (!w.ok) return fail(B3D_ERR_WORKSPACE, "workspace too small");
+  *x = w.x[layer];
+  *e = w.e[layer];
+  return B3D_OK;
+}
+
+extern "C" int b3d_pose_forward(const b3d_pose_weights* pw, const b3d_graph* g, const float* pose_feats,
+                                const double* edge_attr, const int64_t* node_timestamps, int32_t depth,
+                                uint32_t flags, void* workspace, size_t workspace_bytes, float* out_logits,
+                                float* out_x_enc, b3d_stream stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  B3D_TRY(check_weights(pw));
+  B3D_REQUIRE(g && pose_feats && edge_attr && workspace && out_logits && out_x_enc, "b3d_pose_forward: null argument");
+  B3D_REQUIRE(depth >= 1 && depth <= 15, "b3d_pose_forward: depth %d outside [1,15]", depth);
+  const int N = g->N, E = g->E;
+  B3D_REQUIRE(N > 0 && E > 0, "b3d_pose_forward: empty graph (N=%d, E=%d); callers skip these (predict.py:179)", N, E);
+  const bool tr = flags & B3D_FLAG_TRAINING;
+  PoseWs w;
+  carve(w, workspace, workspace_bytes, N, E, depth, flags);
+  if (!w.ok) return fail(B3D_ERR_WORKSPACE, "b3d_pose_forward: workspace %zu < %zu bytes", workspace_bytes, w.bytes);
+  B3D_TRY(pack_forward(pw, w, tr, stream));
+
+  {  // edge encoder: edge_attr.float() -> 4-8-16-32                      pose_gnn.py:67
+    ChainFwdArgs<LoadEdgeAttrF64, StoreAligned<2>> a;
+    memset(&a, 0, sizeof(a));
+    a.rows = E; a.in.ptr = edge_attr;
+    a.out = StoreAligned<2>{w.e[0], nullptr, D::DE, 0};
+    a.save_in = w.ea_pad; a.save[0] = w.ee_a1; a.save[1] = w.ee_a2;
+    a.wpack = w.wp_ee;
+    B3D_TRY(launch_rows<kNWEdge>(chain_fwd_kernel<SeqEdgeEnc, 0x3u, LoadEdgeAttrF64, StoreAligned<2>, kNWEdge>, "edge_encoder", a, E, stream));
+  }
+  {  // node encoder 19-24-36-48 (initial_x == x == x_enc)                  pose_gnn.py:68-71
+    ChainFwdArgs<LoadUnaligned<19>, StoreAligned<3>> a;
+    memset(&a, 0, sizeof(a));
+    a.rows = N; a.in.ptr = pose_feats;
+    a.out = StoreAligned<3>{w.x[0], nullptr, D::DX, 0};
+    a.save_in = w.pose_pad; a.save[0] = w.ne_a1; a.save[1] = w.ne_a2;
+    a.wpack = w.wp_ne;
+    B3D_TRY(launch_rows<kNWNode>(chain_fwd_kernel<SeqNodeEnc, 0x3u, LoadUnaligned<19>, StoreAligned<3>, kNWNode>, "node_encoder", a, N, stream));
+  }
+  B3D_HIP_CHECK(hipMemcpyAsync(out_x_enc, w.x[0], (size_t)N * D::DX * sizeof(float), hipMemcpyDeviceToDevice, stream));
+
+  for (int l = 0; l < depth; ++l) {
+    if ((flags & B3D_FLAG_RUN_DEAD_KNN) && (l % 2 == 0)) {
+      // frame-wise k-NN + GAT whose result the reference discards          pose_gnn.py:74-80
+      B3D_REQUIRE(node_timestamps != nullptr, "node_timestamps required with B3D_FLAG_RUN_DEAD_KNN");
+      B3D_TRY(knn_gat_block<D::DX>(w.knn, w.x[l], node_timestamps, N, pw->knn_conv, 20, stream));
+    }
+    EdgeFwdArgs ea;
+    memset(&ea, 0, sizeof(ea));
+    ea.E = E; ea.src = g->src; ea.dst = g->dst;
+    ea.x = w.x[l]; ea.x0 = w.x[0]; ea.e_in = w.e[l]; ea.a_in = nullptr;
+    ea.e_out = w.e[l + 1]; ea.fut = w.fut; ea.past = w.past;
+    ea.sH1 = w.sH1[l]; ea.sH2 = w.sH2[l]; ea.sF1 = w.sF1[l]; ea.sP1 = w.sP1[l];
+    ea.wpack = w.wp_efwd;
+    B3D_TRY(launch_rows<kNWEdge>(mp_edge_fwd_kernel<D, kNWEdge>, "mp_edge_fwd", ea, E, stream));
+    NodeFwdArgs na;
+    memset(&na, 0, sizeof(na));
+    na.N = N; na.dst_ptr = g->dst_ptr; na.dst_perm = g->dst_perm; na.src_ptr = g->src_ptr; na.src_perm = g->src_perm;
+    na.past = w.past; na.fut = w.fut; na.M = w.M[l]; na.x_out = w.x[l + 1]; na.sH1 = w.nH1[l]; na.sH2 = w.nH2[l];
+    na.wpack = w.wp_nfwd;
+    B3D_TRY(launch_rows<kNWNode>(mp_node_fwd_kernel<D, kNWNode>, "mp_node_fwd", na, N, stream));
+  }
+  {  // edge classifier 32-16-8-4-1 -> logits                                pose_gnn.py:86
+    ChainFwdArgs<LoadAligned<2>, StoreScalar> a;
+    memset(&a, 0, sizeof(a));
+    a.rows = E; a.in = LoadAligned<2>{w.e[depth], nullptr, D::DE, 0};
+    a.out = StoreScalar{out_logits, 0};
+    a.save[0] = w.c_a1; a.save[1] = w.c_a2; a.save[2] = w.c_a3;
+    a.wpack = w.wp_cls;
+    B3D_TRY(launch_rows<kNWEdge>(chain_fwd_kernel<SeqCls, 0x7u, LoadAligned<2>, StoreScalar, kNWEdge>, "edge_classifier", a, E, stream));
+  }
+  return B3D_OK;
+}
+
+extern "C" int b3d_pose_backward(const b3d_pose_weights* pw, const b3d_graph* g, const float* pose_feats,
+                                 const double* edge_attr, int32_t depth, void* workspace, size_t workspace_bytes,
+                                 const float* d_logits, const float* d_x_enc, const b3d_pose_grads* gr,
+                                 b3d_stream stream_) {
+  (void)pose_feats; (void)edge_attr;
+  hipStream_t stream = (hipStream_t)stream_;
+  B3D_TRY(check_weights(pw));
+  B3D_REQUIRE(g && workspace && gr, "b3d_pose_backward: null argument");
+  B3D_REQUIRE(depth >= 1 && depth <= 15, "b3d_pose_backward: depth %d outside [1,15]", depth);
+  const int N = g->N, E = g->E;
+  B3D_REQUIRE(N > 0 && E > 0, "b3d_pose_backward: empty graph");
+  PoseWs w;
+  carve(w, workspace, workspace_bytes, N, E, depth, B3D_FLAG_TRAINING);
+  if (!w.ok) return fail(B3D_ERR_WORKSPACE, "b3d_pose_backward: workspace %zu < %zu bytes", workspace_bytes, w.bytes);
+  const int* src = g->src;
+  const int* dst = g->dst;
+
+  // ---- classifier: d_logits -> d e[depth] -------------------------------------------------------
+  int cur = 0;
+  {
+    ChainBwdArgs<LoadScalar, StoreAligned<2>> a;
+    memset(&a, 0, sizeof(a));
+    a.rows = E; a.in.ptr = d_logits;
+    a.out = StoreAligned<2>{w.de[cur], nullptr, D::DE, 0};
+    a.act[0] = w.c_a3; a.act[1] = w.c_a2; a.act[2] = w.c_a1; a.act[3] = nullptr;
+    a.gsave[0] = w.gc3; a.gsave[1] = w.gc2; a.gsave[2] = w.gc1; a.gsave[3] = nullptr;
+    a.wpack = w.wp_clsT;
+    B3D_TRY(launch_rows<kNWEdge>(chain_bwd_kernel<SeqClsT, LoadScalar, StoreAligned<2>, kNWEdge>, "edge_classifier_bwd", a, E, stream));
+    WgArgs wa;
+    wa.njobs = 0;
+    if (d_logits) {
+      WgJob j3 = make_job(w.lin[LIN_C3], E, seg(d_logits, nullptr, 1, 0, 1));
+      add_act(j3, seg(w.c_a3, nullptr, 16, 0, 4));
+      wa.jobs[wa.njobs++] = j3;
+    }
+    WgJob j2 = make_job(w.lin[LIN_C2], E, seg(w.gc3, nullptr, 16, 0, 4));
+    add_act(j2, seg(w.c_a2, nullptr, 16, 0, 8));
+    wa.jobs[wa.njobs++] = j2;
+    WgJob j1 = make_job(w.lin[LIN_C1], E, seg(w.gc2, nullptr, 16, 0, 8));
+    add_act(j1, seg(w.c_a1, nullptr, 16, 0, 16));
+    wa.jobs[wa.njobs++] = j1;
+    WgJob j0 = make_job(w.lin[LIN_C0], E, seg(w.gc1, nullptr, 16, 0, 16));
+    add_act(j0, seg(w.e[depth], nullptr, D::DE, 0, D::DE));
+    wa.jobs[wa.njobs++] = j0;
+    B3D_TRY((launch_wgrad<6, 1>(wa, stream)));
+  }
+
+  // ---- message-passing layers, last to first -----------------------------------------------------
+  bool dx0_first = true;
+  for (int l = depth - 1; l >= 0; --l) {
+    const bool msgs = (l < depth - 1);   // the last layer's node update feeds nothing (pose_gnn.py:86)
+    if (msgs) {
+      // node backward of layer l consumes the per-edge node gradients written by layer l+1
+      NodeBwdArgs nb;
+      memset(&nb, 0, sizeof(nb));
+      nb.N = N; nb.dst_ptr = g->dst_ptr; nb.dst_perm = g->dst_perm; nb.src_ptr = g->src_ptr; nb.src_perm = g->src_perm;
+      nb.gdst = w.gdst; nb.gsrc = w.gsrc; nb.dx0_acc = w.dx0_acc; nb.dx0_first = dx0_first ? 1 : 0;
+      nb.sH1 = w.nH1[l]; nb.sH2 = w.nH2[l]; nb.dM = w.dM; nb.Gdx = w.Gdx; nb.GdH2 = w.GnH2; nb.GdH1 = w.GnH1;
+      nb.wpack = w.wp_nbwd;
+      B3D_TRY(launch_rows<kNWNode>(mp_node_bwd_kernel<D, kNWNode>, "mp_node_bwd", nb, N, stream));
+      dx0_first = false;
+      WgArgs wn;
+      wn.njobs = 0;
+      WgJob c2 = make_job(w.lin[LIN_CF2], N, seg(w.Gdx, nullptr, D::DX, 0, D::DX));
+      add_act(c2, seg(w.nH2[l], nullptr, D::NH2, 0, D::NH2));
+      wn.jobs[wn.njobs++] = c2;
+      WgJob c1 = make_job(w.lin[LIN_CF1], N, seg(w.GnH2, nullptr, D::NH2, 0, D::NH2));
+      add_act(c1, seg(w.nH1[l], nullptr, D::NH1, 0, D::NH1));
+      wn.jobs[wn.njobs++] = c1;
+      WgJob c0 = make_job(w.lin[LIN_CF0], N, seg(w.GnH1, nullptr, D::NH1, 0, D::NH1));
+      add_act(c0, seg(w.M[l], nullptr, D::NIN, 0, D::NIN));
+      wn.jobs[wn.njobs++] = c0;
+      B3D_TRY((launch_wgrad<6, 1>(wn, stream)));
+    }
+    EdgeBwdArgs eb;
+    memset(&eb, 0, sizeof(eb));
+    eb.E = E; eb.src = src; eb.dst = dst;
+    eb.dM = msgs ? w.dM : nullptr;
+    eb.de_out = w.de[cur]; eb.de_in = w.de[cur ^ 1];
+    eb.sH1 = w.sH1[l]; eb.sH2 = w.sH2[l]; eb.sF1 = w.sF1[l]; eb.sP1 = w.sP1[l];
+    eb.da_acc = nullptr; eb.da_first = 0;
+    eb.gdst = w.gdst; eb.gsrc = w.gsrc;
+    eb.GdH1 = w.GdH1; eb.GdH2 = w.GdH2; eb.Gde = w.Gde; eb.GdF1 = w.GdF1; eb.GdP1 = w.GdP1;
+    if (msgs) {
+      eb.wpack = w.wp_ebwd;
+      B3D_TRY(launch_rows<kNWEdge>(mp_edge_bwd_kernel<D, true, kNWEdge>, "mp_edge_bwd", eb, E, stream));
+    } else {
+      eb.wpack = w.wp_ebwd_nm;
+      B3D_TRY(launch_rows<kNWEdge>(mp_edge_bwd_kernel<D, false, kNWEdge>, "mp_edge_bwd_last", eb, E, stream));
+    }
+    cur ^= 1;
+    WgArgs we;
+    we.njobs = 0;
+    const float* xl = w.x[l];
+    const float* x0 = w.x[0];
+    if (msgs) {
+      WgJob p1 = make_job(w.lin[LIN_PA1], E, seg(w.dM, dst, D::NIN, 0, D::DM));
+      add_act(p1, seg(w.sP1[l], nullptr, D::MH, 0, D::MH));
+      we.jobs[we.njobs++] = p1;
+      WgJob p0 = make_job(w.lin[LIN_PA0], E, seg(w.GdP1, nullptr, D::MH, 0, D::MH));
+      add_act(p0, seg(xl, src, D::DX, 0, D::DX));
+      add_act(p0, seg(w.e[l + 1], nullptr, D::DE, 0, D::DE));
+      add_act(p0, seg(x0, src, D::DX, 0, D::DX));
+      we.jobs[we.njobs++] = p0;
+      WgJob f1 = make_job(w.lin[LIN_FU1], E, seg(w.dM, src, D::NIN, D::DM, D::DM));
+      add_act(f1, seg(w.sF1[l], nullptr, D::MH, 0, D::MH));
+      we.jobs[we.njobs++] = f1;
+      WgJob f0 = make_job(w.lin[LIN_FU0], E, seg(w.GdF1, nullptr, D::MH, 0, D::MH));
+      add_act(f0, seg(xl, dst, D::DX, 0, D::DX));
+      add_act(f0, seg(w.e[l + 1], nullptr, D::DE, 0, D::DE));
+      add_act(f0, seg(x0, dst, D::DX, 0, D::DX));
+      we.jobs[we.njobs++] = f0;
+    }
+    WgJob u2 = make_job(w.lin[LIN_EU2], E, seg(w.Gde, nullptr, D::DE, 0, D::DE));
+    add_act(u2, seg(w.sH2[l], nullptr, D::EH2, 0, D::EH2));
+    we.jobs[we.njobs++] = u2;
+    WgJob u1 = make_job(w.lin[LIN_EU1], E, seg(w.GdH2, nullptr, D::EH2, 0, D::EH2));
+    add_act(u1, seg(w.sH1[l], nullptr, D::EH1, 0, D::EH1));
+    we.jobs[we.njobs++] = u1;
+    WgJob u0 = make_job(w.lin[LIN_EU0], E, seg(w.GdH1, nullptr, D::EH1, 0, D::EH1));
+    add_act(u0, seg(xl, dst, D::DX, 0, D::DX));
+    add_act(u0, seg(xl, src, D::DX, 0, D::DX));
+    add_act(u0, seg(w.e[l], nullptr, D::DE, 0, D::DE));
+    we.jobs[we.njobs++] = u0;
+    B3D_TRY((launch_wgrad<6, 1>(we, stream)));
+  }
+
+  // ---- encoders ---------------------------------------------------------------------------------
+  {  // node encoder: gradient at x_enc = upstream + running d initial_x + layer-0 scatter transposes
+    using In = LoadNodeEncGrad<3>;
+    ChainBwdArgs<In, StoreNone> a;
+    memset(&a, 0, sizeof(a));
+    a.rows = N;
+    a.in = In{d_x_enc, dx0_first ? nullptr : w.dx0_acc, w.gdst, w.gsrc, g->dst_ptr, g->dst_perm, g->src_ptr, g->src_perm};
+    a.gtop = w.gn_top;
+    a.act[0] = w.ne_a2; a.act[1] = w.ne_a1;
+    a.gsave[0] = w.gn2; a.gsave[1] = w.gn1;
+    a.wpack = w.wp_neT;
+    B3D_TRY(launch_rows<kNWNode>(chain_bwd_kernel<SeqNodeEncT, In, StoreNone, kNWNode>, "node_encoder_bwd", a, N, stream));
+    WgArgs wa;
+    wa.njobs = 0;
+    WgJob n2 = make_job(w.lin[LIN_NE2], N, seg(w.gn_top, nullptr, 48, 0, 48));
+    add_act(n2, seg(w.ne_a2, nullptr, 48, 0, 36));
+    wa.jobs[wa.njobs++] = n2;
+    WgJob n1 = make_job(w.lin[LIN_NE1], N, seg(w.gn2, nullptr, 48, 0, 36));
+    add_act(n1, seg(w.ne_a1, nullptr, 32, 0, 24));
+    wa.jobs[wa.njobs++] = n1;
+    WgJob n0 = make_job(w.lin[LIN_NE0], N, seg(w.gn1, nullptr, 32, 0, 24));
+    add_act(n0, seg(w.pose_pad, nullptr, 32, 0, 19));
+    wa.jobs[wa.njobs++] = n0;
+    B3D_TRY((launch_wgrad<6, 1>(wa, stream)));
+  }
+  {  // edge encoder: G_3 = d e[0]
+    ChainBwdArgs<LoadAligned<2>, StoreNone> a;
+    memset(&a, 0, sizeof(a));
+    a.rows = E;
+    a.in = LoadAligned<2>{w.de[cur], nullptr, D::DE, 0};
+    a.act[0] = w.ee_a2; a.act[1] = w.ee_a1;
+    a.gsave[0] = w.ge2; a.gsave[1] = w.ge1;
+    a.wpack = w.wp_eeT;
+    B3D_TRY(launch_rows<kNWEdge>(chain_bwd_kernel<SeqEdgeEncT, LoadAligned<2>, StoreNone, kNWEdge>, "edge_encoder_bwd", a, E, stream));
+    WgArgs wa;
+    wa.njobs = 0;
+    WgJob e2 = make_job(w.lin[LIN_EE2], E, seg(w.de[cur], nullptr, D::DE, 0, 32));
+    add_act(e2, seg(w.ee_a2, nullptr, 16, 0, 16));
+    wa.jobs[wa.njobs++] = e2;
+    WgJob e1 = make_job(w.lin[LIN_EE1], E, seg(w.ge2, nullptr, 16, 0, 16));
+    add_act(e1, seg(w.ee_a1, nullptr, 16, 0, 8));
+    wa.jobs[wa.njobs++] = e1;
+    WgJob e0 = make_job(w.lin[LIN_EE0], E, seg(w.ge1, nullptr, 16, 0, 8));
+    add_act(e0, seg(w.ea_pad, nullptr, 16, 0, 4));
+    wa.jobs[wa.njobs++] = e0;
+    B3D_TRY((launch_wgrad<6, 1>(wa, stream)));
+  }
+
+  // ---- slabs -> parameter gradients -------------------------------------------------------------
+  {
+    RedArgs ra;
+    ra.nentries = 0;
+    const b3d_linear_grad* groups[] = {gr->edge_encoder, gr->node_encoder, gr->edge_classifier, gr->mp.edge_update,
+                                       gr->mp.create_past_msgs, gr->mp.create_future_msgs, gr->mp.combine_future_past};
+    const int first[] = {LIN_EE0, LIN_NE0, LIN_C0, LIN_EU0, LIN_PA0, LIN_FU0, LIN_CF0};
+    const int cnt[] = {3, 3, 4, 3, 2, 2, 3};
+    for (int gi = 0; gi < 7; ++gi)
+      for (int i = 0; i < cnt[gi]; ++i) {
+        LinSlab& ls = w.lin[first[gi] + i];
+        float* dw = groups[gi][i].w;
+        float* db = groups[gi][i].b;
+        if (!ls.used) {
+          // no gradient reached this layer (e.g. d_logits == NULL, or depth == 1 for the message stacks)
+          if (dw) B3D_HIP_CHECK(hipMemsetAsync(dw, 0, (size_t)ls.N * ls.K * sizeof(float), stream));
+          if (db) B3D_HIP_CHECK(hipMemsetAsync(db, 0, (size_t)ls.N * sizeof(float), stream));
+          continue;
+        }
+        ra.e[ra.nentries++] = red_entry(ls, dw, db);
+      }
+    B3D_TRY(launch_reduce(ra, stream));
+  }
+  return B3D_OK;
+}

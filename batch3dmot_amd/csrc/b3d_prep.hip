@@ -1,0 +1,206 @@
+// Graph structure (int64 COO -> int32 src/dst + CSR by destination + CSC by source) and weight
+// image packing.  Small integer / copy kernels; HBM- and latency-bound, nothing to tile.
+#include "b3d_common.hpp"
+#include "b3d_dev.hpp"
+#include "b3d_pack.hpp"
+
+namespace b3d {
+
+// ---- graph ------------------------------------------------------------------------------------
+__global__ void graph_convert_count(const int64_t* __restrict__ ei, int E, int N, int* __restrict__ src,
+                                    int* __restrict__ dst, int* __restrict__ cnt_dst,
+                                    int* __restrict__ cnt_src, int* __restrict__ bad) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= E) return;
+  const long s = ei[k], d = ei[(long)E + k];
+  if (s < 0 || s >= N || d < 0 || d >= N) { atomicAdd(bad, 1); src[k] = 0; dst[k] = 0; return; }
+  src[k] = (int)s;
+  dst[k] = (int)d;
+  atomicAdd(&cnt_dst[d], 1);
+  atomicAdd(&cnt_src[s], 1);
+}
+
+// Exclusive scan of two count arrays (one workgroup each): ptr[0..N], cursor copy for the fill.
+__global__ __launch_bounds__(1024) void graph_scan(const int* __restrict__ cnt_dst, const int* __restrict__ cnt_src,
+                                                   int N, int* __restrict__ dst_ptr, int* __restrict__ src_ptr,
+                                                   int* __restrict__ cur_dst, int* __restrict__ cur_src) {
+  const int* cnt = blockIdx.x == 0 ? cnt_dst : cnt_src;
+  int* ptr = blockIdx.x == 0 ? dst_ptr : src_ptr;
+  int* cur = blockIdx.x == 0 ? cur_dst : cur_src;
+  __shared__ int part[1024];
+  const int per = (N + 1023) / 1024;
+  const int b = threadIdx.x * per;
+  int s = 0;
+  for (int i = b; i < b + per && i < N; ++i) s += cnt[i];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    int v = (threadIdx.x >= off) ? part[threadIdx.x - off] : 0;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  int run = part[threadIdx.x] - s;
+  for (int i = b; i < b + per && i < N; ++i) {
+    ptr[i] = run;
+    cur[i] = run;
+    run += cnt[i];
+  }
+  if (threadIdx.x == 1023) ptr[N] = part[1023];
+}
+
+__global__ void graph_fill(const int* __restrict__ src, const int* __restrict__ dst, int E,
+                           int* __restrict__ cur_dst, int* __restrict__ cur_src,
+                           int* __restrict__ dst_perm, int* __restrict__ src_perm) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= E) return;
+  dst_perm[atomicAdd(&cur_dst[dst[k]], 1)] = k;
+  src_perm[atomicAdd(&cur_src[src[k]], 1)] = k;
+}
+
+// The atomic fill leaves each segment in arrival order; sort every segment by edge id so that the
+// summation order of all segment sums is fixed (bitwise reproducible results).  One wavefront per
+// list: lists of <= 64 edges are rank-sorted with wavefront shuffles, longer ones by lane 0.
+__global__ __launch_bounds__(256) void graph_sort_segments(const int* __restrict__ dst_ptr, const int* __restrict__ src_ptr,
+                                                           int N, int* __restrict__ dst_perm, int* __restrict__ src_perm) {
+  const int w = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (w >= 2 * N) return;
+  const int n = w >> 1;
+  const int* ptr = (w & 1) ? src_ptr : dst_ptr;
+  int* perm = (w & 1) ? src_perm : dst_perm;
+  const int b = ptr[n], e = ptr[n + 1], len = e - b;
+  if (len <= 1) return;
+  if (len <= 64) {
+    const int v = (lane < len) ? perm[b + lane] : 0x7fffffff;
+    int rank = 0;
+    for (int j = 0; j < len; ++j) rank += (__shfl(v, j, 64) < v);
+    if (lane < len) perm[b + rank] = v;
+  } else if (lane == 0) {
+    for (int i = b + 1; i < e; ++i) {
+      const int v = perm[i];
+      int j = i - 1;
+      while (j >= b && perm[j] > v) { perm[j + 1] = perm[j]; --j; }
+      perm[j + 1] = v;
+    }
+  }
+}
+
+struct GraphLayout {
+  int *src, *dst, *dst_ptr, *dst_perm, *src_ptr, *src_perm, *cnt_dst, *cnt_src, *cur_dst, *cur_src, *bad;
+  size_t bytes;
+  bool ok;
+};
+
+static GraphLayout graph_layout(void* ws, size_t ws_bytes, int N, int E) {
+  Carver c(ws, ws_bytes);
+  GraphLayout g;
+  g.src = c.take<int>(E > 0 ? E : 1);
+  g.dst = c.take<int>(E > 0 ? E : 1);
+  g.dst_ptr = c.take<int>(N + 1);
+  g.src_ptr = c.take<int>(N + 1);
+  g.dst_perm = c.take<int>(E > 0 ? E : 1);
+  g.src_perm = c.take<int>(E > 0 ? E : 1);
+  // zero-initialised block: counts + bad flag, contiguous
+  g.cnt_dst = c.take<int>(2 * (size_t)N + 64);
+  g.cnt_src = g.cnt_dst ? g.cnt_dst + N : nullptr;
+  g.bad = g.cnt_dst ? g.cnt_dst + 2 * (size_t)N : nullptr;
+  g.cur_dst = c.take<int>(N > 0 ? N : 1);
+  g.cur_src = c.take<int>(N > 0 ? N : 1);
+  g.bytes = c.off + 256;
+  g.ok = c.ok();
+  return g;
+}
+
+}  // namespace b3d
+
+using namespace b3d;
+
+extern "C" size_t b3d_graph_workspace_bytes(int32_t N, int32_t E) {
+  return graph_layout(nullptr, 0, N, E).bytes;
+}
+
+extern "C" int b3d_graph_build(const int64_t* edge_index, int32_t N, int32_t E, void* workspace,
+                               size_t workspace_bytes, b3d_graph* out, b3d_stream stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  B3D_REQUIRE(out != nullptr && workspace != nullptr, "b3d_graph_build: null argument");
+  B3D_REQUIRE(N >= 0 && E >= 0, "b3d_graph_build: negative size");
+  B3D_REQUIRE(E == 0 || edge_index != nullptr, "b3d_graph_build: edge_index is null");
+  GraphLayout g = graph_layout(workspace, workspace_bytes, N, E);
+  if (!g.ok) return fail(B3D_ERR_WORKSPACE, "b3d_graph_build: workspace %zu < %zu bytes", workspace_bytes, g.bytes);
+  B3D_HIP_CHECK(hipMemsetAsync(g.cnt_dst, 0, (2 * (size_t)N + 64) * sizeof(int), stream));
+  if (E > 0) {
+    hipLaunchKernelGGL(graph_convert_count, dim3((E + 255) / 256), dim3(256), 0, stream, edge_index, E, N,
+                       g.src, g.dst, g.cnt_dst, g.cnt_src, g.bad);
+    B3D_TRY(launch_check("graph_convert_count"));
+  }
+  hipLaunchKernelGGL(graph_scan, dim3(2), dim3(1024), 0, stream, g.cnt_dst, g.cnt_src, N, g.dst_ptr,
+                     g.src_ptr, g.cur_dst, g.cur_src);
+  B3D_TRY(launch_check("graph_scan"));
+  if (E > 0) {
+    hipLaunchKernelGGL(graph_fill, dim3((E + 255) / 256), dim3(256), 0, stream, g.src, g.dst, E, g.cur_dst,
+                       g.cur_src, g.dst_perm, g.src_perm);
+    B3D_TRY(launch_check("graph_fill"));
+    hipLaunchKernelGGL(graph_sort_segments, dim3((2 * N + 3) / 4), dim3(256), 0, stream, g.dst_ptr,
+                       g.src_ptr, N, g.dst_perm, g.src_perm);
+    B3D_TRY(launch_check("graph_sort_segments"));
+  }
+  out->N = N;
+  out->E = E;
+  out->src = g.src;
+  out->dst = g.dst;
+  out->dst_ptr = g.dst_ptr;
+  out->dst_perm = g.dst_perm;
+  out->src_ptr = g.src_ptr;
+  out->src_perm = g.src_perm;
+  return B3D_OK;
+}
+
+// ---- weight images -----------------------------------------------------------------------------
+namespace b3d {
+
+__global__ void pack_kernel(const PackArgs a) {
+  // one workgroup column per descriptor (blockIdx.y), grid-stride over the image's floats
+  const PackDesc& d = a.d[blockIdx.y];
+  const int stride = d.KP + 4;
+  const int cr = chunk_rows(d.KP, d.NP);
+  const int total = d.NP * stride;
+  for (int id = blockIdx.x * blockDim.x + threadIdx.x; id < total; id += gridDim.x * blockDim.x) {
+    const int r = id / stride, c = id - r * stride;
+    float v = 0.f;
+    if (!d.transposed) {
+      if (r < d.N) {
+        if (c < d.K) v = d.w[(size_t)r * d.K + c];
+        else if (c == d.KP && d.b) v = d.b[r];
+      }
+    } else {
+      // image of W^T: rows = input features of the forward layer (K_fwd = d.N here), cols = outputs
+      // d.N / d.K describe the IMAGE (N rows, K cols); the source is [K, N] row-major.
+      if (r < d.N && c < d.K) v = d.w[(size_t)c * d.N + r];
+    }
+    // chunked placement: chunk ch holds rows [ch*cr, ...), each chunk padded to 1 KB
+    const int ch = r / cr, rl = r - ch * cr;
+    size_t off = 0;
+    for (int i = 0; i < ch; ++i) off += chunk_floats(d.KP, chunk_nrows(d.KP, d.NP, i));
+    d.dst[off + (size_t)rl * stride + c] = v;
+  }
+}
+
+int pack_images(const PackDesc* descs, int n, hipStream_t stream) {
+  for (int i0 = 0; i0 < n; i0 += kPackMax) {
+    PackArgs a;
+    a.n = (n - i0 < kPackMax) ? n - i0 : kPackMax;
+    int maxtot = 0;
+    for (int i = 0; i < a.n; ++i) {
+      a.d[i] = descs[i0 + i];
+      const int t = a.d[i].NP * (a.d[i].KP + 4);
+      if (t > maxtot) maxtot = t;
+    }
+    int gx = (maxtot + 255) / 256;
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(pack_kernel, dim3(gx, a.n), dim3(256), 0, stream, a);
+    B3D_TRY(launch_check("pack_kernel"));
+  }
+  return B3D_OK;
+}
+
+}  // namespace b3d

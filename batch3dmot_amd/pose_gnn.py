@@ -1,0 +1,211 @@
+"""Drop-in for the reference's ``batch_3dmot.models.pose_gnn`` (PoseGNN, CausalMessagePassing).
+
+Same constructor signatures, ``forward(data)`` contract and ``state_dict`` keys as
+``/root/reference/batch_3dmot/models/pose_gnn.py:24-252``; the arithmetic runs in the HIP kernels
+of ``libb3d_hip.so`` (edge/node MLP stacks on fp32 MFMA, CSR/CSC segment sums, k-NN + GAT).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List
+
+import torch
+from torch import nn
+
+from . import _lib
+from ._lib import B3D_FLAG_RUN_DEAD_KNN, B3D_FLAG_TRAINING
+
+
+def _mlp(dims, inplace_relu=False):
+    layers = []
+    for i in range(len(dims) - 1):
+        layers.append(nn.Linear(dims[i], dims[i + 1]))
+        if i < len(dims) - 2:
+            layers.append(nn.ReLU(inplace=inplace_relu))
+    return nn.Sequential(*layers)
+
+
+def _linears(seq: nn.Sequential) -> List[nn.Linear]:
+    return [m for m in seq if isinstance(m, nn.Linear)]
+
+
+class GATConvParams(nn.Module):
+    """Parameter holder with torch_geometric ``GATConv(D, D, heads=1, add_self_loops=False)`` names
+    (reference pose_gnn.py:55): ``att_src/att_dst [1,1,D]``, ``bias [D]``, ``lin_src.weight [D,D]``
+    aliased as ``lin_dst.weight`` (PyG 2.0.x); newer ``lin.weight`` checkpoints are accepted."""
+
+    def __init__(self, dim: int):
+        super().__init__()
+        self.dim = dim
+        self.lin_src = nn.Linear(dim, dim, bias=False)
+        self.lin_dst = self.lin_src
+        self.att_src = nn.Parameter(torch.empty(1, 1, dim))
+        self.att_dst = nn.Parameter(torch.empty(1, 1, dim))
+        self.bias = nn.Parameter(torch.zeros(dim))
+        nn.init.xavier_uniform_(self.lin_src.weight)
+        nn.init.xavier_uniform_(self.att_src)
+        nn.init.xavier_uniform_(self.att_dst)
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        k = prefix + "lin.weight"
+        if k in state_dict:
+            w = state_dict.pop(k)
+            state_dict[prefix + "lin_src.weight"] = w
+            state_dict[prefix + "lin_dst.weight"] = w
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+
+class CausalMessagePassing(nn.Module):
+    """Parameters of reference pose_gnn.py:91-120 (aggr='add', node_dim=0)."""
+
+    def __init__(self):
+        super().__init__()
+        self.edge_update = _mlp([128, 96, 64, 32])
+        self.create_past_msgs = _mlp([128, 96, 64])
+        self.create_future_msgs = _mlp([128, 96, 64])
+        self.combine_future_past = _mlp([128, 96, 64, 48])
+
+    def forward(self, x, edge_index, edge_attr, initial_x):
+        from .mp_layer import mp_layer_forward   # layer-level operator (own C-ABI entry)
+        return mp_layer_forward(self, "p", x, edge_index, edge_attr, initial_x, None)
+
+
+def _param_list(m: "PoseGNN") -> List[torch.Tensor]:
+    out = []
+    for seq in (m.edge_encoder, m.node_encoder, m.edge_classifier, m.message_passing.edge_update,
+                m.message_passing.create_past_msgs, m.message_passing.create_future_msgs,
+                m.message_passing.combine_future_past):
+        for lin in _linears(seq):
+            out += [lin.weight, lin.bias]
+    return out
+
+
+def _fill_linears(dst, tensors, start):
+    """dst: ctypes array of b3d_linear; tensors: flat [w0, b0, w1, b1, ...]."""
+    for i in range(len(dst)):
+        dst[i].w = tensors[start + 2 * i].data_ptr()
+        dst[i].b = tensors[start + 2 * i + 1].data_ptr()
+    return start + 2 * len(dst)
+
+
+def _pose_struct(cls, tensors):
+    s = cls()
+    k = 0
+    k = _fill_linears(s.edge_encoder, tensors, k)
+    k = _fill_linears(s.node_encoder, tensors, k)
+    k = _fill_linears(s.edge_classifier, tensors, k)
+    k = _fill_linears(s.mp.edge_update, tensors, k)
+    k = _fill_linears(s.mp.create_past_msgs, tensors, k)
+    k = _fill_linears(s.mp.create_future_msgs, tensors, k)
+    k = _fill_linears(s.mp.combine_future_past, tensors, k)
+    assert k == len(tensors)
+    return s
+
+
+class _PoseGNNFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, graph, pose_feats, edge_attr, node_timestamps, training, *params):
+        lib = _lib.load()
+        dev = pose_feats.device
+        N, E = graph.N, graph.E
+        flags = (B3D_FLAG_TRAINING if training else 0) | (B3D_FLAG_RUN_DEAD_KNN if module.run_dead_knn else 0)
+        nbytes = lib.b3d_pose_workspace_bytes(N, E, module.depth, flags)
+        if nbytes == 0:
+            raise ValueError(f"unsupported gnn_depth {module.depth} (1..15)")
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        params = [p.detach() for p in params]
+        w = _pose_struct(_lib.b3d_pose_weights, params)
+        kc = module.knn_conv
+        gat = [kc.lin_src.weight.detach(), kc.att_src.detach().reshape(-1), kc.att_dst.detach().reshape(-1),
+               kc.bias.detach()]
+        w.knn_conv.lin, w.knn_conv.att_src, w.knn_conv.att_dst, w.knn_conv.bias = (t.data_ptr() for t in gat)
+        logits = torch.empty((E, 1), dtype=torch.float32, device=dev)
+        x_enc = torch.empty((N, 48), dtype=torch.float32, device=dev)
+        _lib.check(lib.b3d_pose_forward(C.byref(w), C.byref(graph.c), pose_feats.data_ptr(), edge_attr.data_ptr(),
+                                        node_timestamps.data_ptr(), module.depth, flags, ws.data_ptr(), nbytes,
+                                        logits.data_ptr(), x_enc.data_ptr(), _lib.current_stream(dev)),
+                   "b3d_pose_forward")
+        ctx.set_materialize_grads(False)
+        ctx.module, ctx.graph, ctx.ws, ctx.nbytes, ctx.flags = module, graph, ws, nbytes, flags
+        ctx.params, ctx.inputs, ctx.keep = params, (pose_feats, edge_attr), gat
+        module._last_workspace = (ws, nbytes, flags, N, E) if module.keep_workspace else None
+        return logits, x_enc
+
+    @staticmethod
+    def backward(ctx, d_logits, d_x_enc):
+        lib = _lib.load()
+        if not (ctx.flags & B3D_FLAG_TRAINING):
+            raise RuntimeError("backward through a PoseGNN forward that ran without gradient tracking")
+        params = ctx.params
+        pose_feats, edge_attr = ctx.inputs
+        dev = pose_feats.device
+        if d_logits is not None:
+            d_logits = d_logits.contiguous().float()
+        if d_x_enc is not None:
+            d_x_enc = d_x_enc.contiguous().float()
+        grads = [torch.empty_like(p) for p in params]
+        w = _pose_struct(_lib.b3d_pose_weights, params)
+        g = _pose_struct(_lib.b3d_pose_grads, grads)
+        _lib.check(lib.b3d_pose_backward(C.byref(w), C.byref(ctx.graph.c), pose_feats.data_ptr(), edge_attr.data_ptr(),
+                                         ctx.module.depth, ctx.ws.data_ptr(), ctx.nbytes, _lib.ptr(d_logits),
+                                         _lib.ptr(d_x_enc), C.byref(g), _lib.current_stream(dev)),
+                   "b3d_pose_backward")
+        return (None, None, None, None, None, None) + tuple(grads)
+
+
+class PoseGNN(nn.Module):
+    """``PoseGNN(gnn_depth=6, edge_dim=16, node_dim=19, mp_type="attention")`` -- reference
+    pose_gnn.py:24-86.  ``edge_dim``, ``node_dim`` and ``mp_type`` are accepted and ignored exactly
+    as the reference ignores them (layer widths are fixed).
+
+    ``forward(data)`` reads ``data.pose_feats [N,19] f32``, ``data.edge_index [2,E] i64``,
+    ``data.edge_attr [E,4]`` (f64, cast inside), ``data.node_timestamps [N] i64`` and ``data.batch``
+    (read, unused) and returns ``(edge_logits [E,1], x_enc [N,48])``.
+
+    Extra, non-reference switches (attributes): ``run_dead_knn`` (default True) executes the
+    frame-wise k-NN + GAT block whose result the reference computes and discards
+    (pose_gnn.py:74-80); it cannot change any output.
+    """
+
+    def __init__(self, gnn_depth=6, edge_dim=16, node_dim=19, mp_type: str = "attention"):
+        super().__init__()
+        self.depth = gnn_depth
+        self.edge_encoder = _mlp([4, 8, 16, 32], inplace_relu=True)
+        self.node_encoder = _mlp([19, 24, 36, 48])
+        self.edge_classifier = _mlp([32, 16, 8, 4, 1])
+        self.knn_conv = GATConvParams(48)
+        self.message_passing = CausalMessagePassing()
+        self.run_dead_knn = True
+        self.keep_workspace = False
+        self._last_workspace = None
+
+    def forward(self, data):
+        pose_feats, edge_index, edge_attr, node_timestamps, _batch = (
+            data.pose_feats, data.edge_index, data.edge_attr, data.node_timestamps,
+            getattr(data, "batch", None))
+        _lib.require_cuda(pose_feats, "data.pose_feats", torch.float32)
+        if pose_feats.dim() != 2 or pose_feats.size(1) != 19:
+            raise ValueError(f"data.pose_feats must be [N, 19], got {tuple(pose_feats.shape)}")
+        if edge_attr.dim() != 2 or edge_attr.size(1) != 4 or edge_attr.size(0) != edge_index.size(1):
+            raise ValueError(f"data.edge_attr must be [E, 4], got {tuple(edge_attr.shape)}")
+        if edge_index.size(1) == 0 or pose_feats.size(0) == 0:
+            raise ValueError("empty graph: the reference's callers skip these (predict.py:179-180)")
+        edge_attr = edge_attr.to(torch.float64).contiguous()   # kernel applies .float() (pose_gnn.py:67)
+        _lib.require_cuda(edge_attr, "data.edge_attr")
+        node_timestamps = node_timestamps.to(torch.int64).contiguous()
+        _lib.require_cuda(node_timestamps, "data.node_timestamps")
+        if node_timestamps.numel() != pose_feats.size(0):
+            raise ValueError("data.node_timestamps must have one entry per node")
+        graph = getattr(data, "_b3d_graph", None)
+        if graph is None or graph.N != pose_feats.size(0) or graph.E != edge_index.size(1) \
+                or graph._keep.data_ptr() != edge_index.data_ptr():
+            graph = _lib.Graph(edge_index.contiguous(), pose_feats.size(0))
+            try:
+                data._b3d_graph = graph
+            except Exception:
+                pass
+        params = _param_list(self)
+        for p in params:
+            _lib.require_cuda(p, "parameter", torch.float32)
+        training = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        return _PoseGNNFunction.apply(self, graph, pose_feats, edge_attr, node_timestamps, training, *params)

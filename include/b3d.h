@@ -1,0 +1,129 @@
+/* libb3d_hip.so -- C ABI of the MI355X (gfx950) GNN message-passing path for Batch3DMOT graphs.
+ *
+ * What this boundary replaces.  The reference is pure Python: its hot path is reached through
+ * two nn.Module.forward calls,
+ *     PoseGNN.forward(data) -> (edge_logits [E,1], x_enc [N,48])      batch_3dmot/models/pose_gnn.py:58-86
+ *     GNN.forward(data)     -> (edge_prob  [E,1], x_sens [N,288])     batch_3dmot/models/clr_att_gnn.py:95-188
+ * called from Batch3DMOT.train (train.py:133,174) and combine_batches_to_scene (predict.py:194),
+ * and all of its arithmetic lives in torch / torch_geometric / torch_scatter / torch_cluster
+ * kernels.  The entry points below are what a ctypes binding of those two forwards (and of the
+ * autograd backward that train.py:159 triggers) binds; batch3dmot_amd/_lib.py is that binding
+ * and INTEGRATION.md shows the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless a comment says "host"; tensors are dense,
+ *    row-major, fp32 unless stated; Linear weights are [out, in] as torch stores them.
+ *  - the library allocates nothing, frees nothing and keeps no pointer after a call returns:
+ *    scratch comes from the caller as a workspace whose size the *_workspace_* queries report.
+ *  - every call is asynchronous on the given hipStream_t and never synchronises the device.
+ *  - return value: B3D_OK (0) or a negative b3d_status; b3d_last_error() gives the message of
+ *    the calling thread's last failure.  Nothing throws or aborts.
+ *  - re-entrant; the only global state is the thread-local error string.
+ */
+#ifndef B3D_H_
+#define B3D_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* b3d_stream;   /* = hipStream_t */
+
+typedef enum b3d_status {
+  B3D_OK = 0,
+  B3D_ERR_ARG = -1,        /* bad shape / null pointer / unsupported option */
+  B3D_ERR_HIP = -2,        /* a HIP runtime call or kernel launch failed */
+  B3D_ERR_WORKSPACE = -3   /* workspace too small */
+} b3d_status;
+
+int b3d_version(void);                 /* 10000*major + 100*minor + patch */
+const char* b3d_last_error(void);      /* host string, valid until the thread's next failing call */
+
+/* ---- graph structure (replaces MessagePassing.__collect__ index plumbing, pose_gnn.py:180,
+ *      and torch_scatter's index handling, pose_gnn.py:240) ---------------------------------- */
+typedef struct b3d_graph {
+  int32_t N, E;
+  const int32_t* src;        /* [E] edge_index[0]: past / source node j          */
+  const int32_t* dst;        /* [E] edge_index[1]: current / destination node i  */
+  const int32_t* dst_ptr;    /* [N+1] CSR by destination                         */
+  const int32_t* dst_perm;   /* [E] edge ids grouped by destination, ascending   */
+  const int32_t* src_ptr;    /* [N+1] CSC by source                              */
+  const int32_t* src_perm;   /* [E] edge ids grouped by source, ascending        */
+} b3d_graph;
+
+size_t b3d_graph_workspace_bytes(int32_t N, int32_t E);
+/* edge_index: [2,E] int64 contiguous (row 0 = source, row 1 = destination), any order. */
+int b3d_graph_build(const int64_t* edge_index, int32_t N, int32_t E, void* workspace,
+                    size_t workspace_bytes, b3d_graph* out /* host */, b3d_stream stream);
+
+/* ---- parameters ------------------------------------------------------------------------------ */
+typedef struct b3d_linear { const float* w; const float* b; } b3d_linear;   /* w [out,in], b [out] */
+typedef struct b3d_linear_grad { float* w; float* b; } b3d_linear_grad;
+
+typedef struct b3d_gat {           /* torch_geometric GATConv(D, D, heads=1, add_self_loops=False) */
+  const float* lin;                /* [D,D]  (lin_src == lin_dst) */
+  const float* att_src;            /* [D] */
+  const float* att_dst;            /* [D] */
+  const float* bias;               /* [D] */
+} b3d_gat;
+
+/* CausalMessagePassing parameters (pose_gnn.py:91-120 / clr_att_gnn.py:193-222) */
+typedef struct b3d_mp_weights {
+  b3d_linear edge_update[3];
+  b3d_linear create_past_msgs[2];
+  b3d_linear create_future_msgs[2];
+  b3d_linear combine_future_past[3];
+} b3d_mp_weights;
+typedef struct b3d_mp_grads {
+  b3d_linear_grad edge_update[3];
+  b3d_linear_grad create_past_msgs[2];
+  b3d_linear_grad create_future_msgs[2];
+  b3d_linear_grad combine_future_past[3];
+} b3d_mp_grads;
+
+/* PoseGNN parameters (pose_gnn.py:29-56) */
+typedef struct b3d_pose_weights {
+  b3d_linear edge_encoder[3];      /* 4-8-16-32   */
+  b3d_linear node_encoder[3];      /* 19-24-36-48 */
+  b3d_linear edge_classifier[4];   /* 32-16-8-4-1 */
+  b3d_mp_weights mp;
+  b3d_gat knn_conv;                /* D = 48 */
+} b3d_pose_weights;
+typedef struct b3d_pose_grads {
+  b3d_linear_grad edge_encoder[3];
+  b3d_linear_grad node_encoder[3];
+  b3d_linear_grad edge_classifier[4];
+  b3d_mp_grads mp;
+} b3d_pose_grads;
+
+/* flags */
+#define B3D_FLAG_TRAINING      1u   /* keep what backward needs in the workspace            */
+#define B3D_FLAG_RUN_DEAD_KNN  2u   /* execute the frame-wise k-NN + GAT block whose result the
+                                       reference discards (pose_gnn.py:74-80)                 */
+
+/* ---- PoseGNN.forward / backward ------------------------------------------------------------ */
+size_t b3d_pose_workspace_bytes(int32_t N, int32_t E, int32_t depth, uint32_t flags);
+
+/* pose_feats [N,19] f32; edge_attr [E,4] f64 (cast to f32 inside, pose_gnn.py:67);
+ * node_timestamps [N] int64 (only read with B3D_FLAG_RUN_DEAD_KNN);
+ * out_logits [E,1]; out_x_enc [N,48] (the pre-message-passing node encoding, pose_gnn.py:71,86). */
+int b3d_pose_forward(const b3d_pose_weights* w /* host struct of device pointers */,
+                     const b3d_graph* g /* host */, const float* pose_feats, const double* edge_attr,
+                     const int64_t* node_timestamps, int32_t depth, uint32_t flags, void* workspace,
+                     size_t workspace_bytes, float* out_logits, float* out_x_enc, b3d_stream stream);
+
+/* Gradients of every parameter for upstream d_logits [E,1] and d_x_enc [N,48] (either may be
+ * NULL = zero).  `workspace` is the one a B3D_FLAG_TRAINING forward filled.  knn_conv receives no
+ * gradient (the reference's result is discarded), so there is no field for it. */
+int b3d_pose_backward(const b3d_pose_weights* w, const b3d_graph* g, const float* pose_feats,
+                      const double* edge_attr, int32_t depth, void* workspace, size_t workspace_bytes,
+                      const float* d_logits, const float* d_x_enc, const b3d_pose_grads* grads /* host */,
+                      b3d_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* B3D_H_ */

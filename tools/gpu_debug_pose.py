@@ -1,0 +1,113 @@
+"""GPU diagnostic (not a test): PoseGNN HIP path vs the oracle, layer by layer."""
+import ctypes as C
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from batch3dmot_amd import _lib, synth
+from batch3dmot_amd.data import Data
+from batch3dmot_amd.pose_gnn import PoseGNN
+from oracle import ref_torch
+from oracle.seeded import seeded_fill_
+
+
+def layer_tensors(m, N, E):
+    ws, nbytes, flags, _, _ = m._last_workspace
+    lib = _lib.load()
+    out = []
+    for l in range(m.depth + 1):
+        px, pe = C.c_void_p(), C.c_void_p()
+        _lib.check(lib.b3d_pose_debug_layer_ptrs(ws.data_ptr(), nbytes, N, E, m.depth, flags, l, C.byref(px), C.byref(pe)), "dbg")
+        ox = (px.value - ws.data_ptr()); oe = (pe.value - ws.data_ptr())
+        x = ws[ox:ox + N * 48 * 4].view(torch.float32).view(N, 48).clone()
+        e = ws[oe:oe + E * 32 * 4].view(torch.float32).view(E, 32).clone()
+        out.append((x, e))
+    return out
+
+
+def rel(a, b):
+    return ((a.double().cpu() - b.double().cpu()).abs().max() / b.double().abs().max().clamp_min(1e-30)).item()
+
+
+def main():
+    dev = torch.device("cuda:0")
+    g = torch.load(os.path.join(ROOT, "tests/golden/g1_pose.pt"), weights_only=False)
+    data = Data(**g["data"])
+    m = PoseGNN().to(dev)
+    m.load_state_dict(g["state_dict"], strict=True)
+    m.keep_workspace = True
+    d = data.to(dev)
+    graph = _lib.Graph(d.edge_index, d.pose_feats.size(0))
+    arr = graph.arrays()
+    ei = data.edge_index
+    print("src ok", torch.equal(arr["src"].cpu().long(), ei[0]), "dst ok", torch.equal(arr["dst"].cpu().long(), ei[1]))
+    dp = arr["dst_perm"].cpu().long(); dptr = arr["dst_ptr"].cpu().long()
+    print("dst_perm sorted by dst:", bool((ei[1][dp][1:] >= ei[1][dp][:-1]).all()), "ptr end", int(dptr[-1]), "E", ei.size(1))
+    sp = arr["src_perm"].cpu().long()
+    print("src_perm sorted by src:", bool((ei[0][sp][1:] >= ei[0][sp][:-1]).all()))
+    for run_dead in (False, True):
+        m.run_dead_knn = run_dead
+        out, x_enc = m(d)
+        torch.cuda.synchronize()
+        print(f"[dead_knn={run_dead}] logits rel err {rel(out, g['out']):.3e}  x_enc rel err {rel(x_enc, g['x_enc']):.3e}")
+    N, E = d.pose_feats.size(0), d.edge_index.size(1)
+    lt = layer_tensors(m, N, E)
+    print("x0 vs x_enc", rel(lt[0][0], g["x_enc"]))
+    for l, ((x, e), (gx, ge)) in enumerate(zip(lt[1:], g["layers"])):
+        print(f"layer {l}: x rel {rel(x, gx):.3e}  e rel {rel(e, ge):.3e}")
+    # backward
+    gw = torch.Generator().manual_seed(1234); w0 = torch.randn(out.shape, generator=gw).to(dev)
+    gw = torch.Generator().manual_seed(1235); w1 = torch.randn(x_enc.shape, generator=gw).to(dev)
+    loss = (out * w0).sum() + (x_enc * w1).sum()
+    m.zero_grad()
+    loss.backward()
+    torch.cuda.synchronize()
+    worst = 0
+    for n, p in m.named_parameters():
+        gg = g["grads"][n]
+        if gg is None:
+            print(f"  {n}: ref None, ours {None if p.grad is None else 'tensor'}")
+            continue
+        r = rel(p.grad, gg)
+        worst = max(worst, r)
+        print(f"  grad {n:45s} rel {r:.3e}  |ref|max {gg.abs().max():.3e}")
+    print("worst grad rel err", worst)
+
+    # medium synthetic graph vs oracle on CPU, timing
+    big = synth.make_batch(2, 1500, 15000)
+    ora = ref_torch.PoseGNN(run_dead_knn=False)
+    seeded_fill_(ora, 5)
+    m2 = PoseGNN().to(dev); m2.load_state_dict(ora.state_dict()); m2.run_dead_knn = True
+    db = big.to(dev)
+    with torch.no_grad():
+        o_ref, _ = ora(big)
+    out, x_enc = m2(db)
+    print("big: N", big.pose_feats.size(0), "E", big.edge_index.size(1), "logits rel", rel(out, o_ref))
+    lw = torch.randn(out.shape, device=dev)
+    for it in range(3):
+        torch.cuda.synchronize(); t0 = time.time()
+        if hasattr(db, "_b3d_graph"):
+            del db._b3d_graph
+        m2.zero_grad(set_to_none=True)
+        out, x_enc = m2(db)
+        torch.cuda.synchronize(); t1 = time.time()
+        (out * lw).sum().backward()
+        torch.cuda.synchronize(); t2 = time.time()
+        print(f"  iter {it}: fwd {1e3*(t1-t0):.3f} ms  bwd {1e3*(t2-t1):.3f} ms  -> {big.edge_index.size(1)/(t2-t0)/1e6:.2f} M edges/s")
+    o2 = ora(big)[0]
+    (o2 * lw.cpu()).sum().backward()
+    worst = 0
+    for (n, p), (_, q) in zip(m2.named_parameters(), ora.named_parameters()):
+        if q.grad is None:
+            continue
+        worst = max(worst, rel(p.grad, q.grad))
+    print("big: worst grad rel err", worst)
+
+
+if __name__ == "__main__":
+    main()
