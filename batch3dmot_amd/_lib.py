@@ -82,6 +82,8 @@ def load() -> C.CDLL:
     lib.b3d_pose_debug_layer_ptrs.restype = C.c_int
     lib.b3d_pose_debug_layer_ptrs.argtypes = [C.c_void_p, C.c_size_t, C.c_int32, C.c_int32, C.c_int32, C.c_uint32,
                                               C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    lib.b3d_prof_enable.argtypes = [C.c_int]
+    lib.b3d_prof_read.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]
     _lib = lib
     return lib
 
@@ -135,3 +137,22 @@ class Graph:
         return {"src": self._view(g.src, self.E), "dst": self._view(g.dst, self.E),
                 "dst_ptr": self._view(g.dst_ptr, self.N + 1), "dst_perm": self._view(g.dst_perm, self.E),
                 "src_ptr": self._view(g.src_ptr, self.N + 1), "src_perm": self._view(g.src_perm, self.E)}
+
+
+KERNEL_FAMILIES = {"mp_edge_fwd": 0, "mp_edge_bwd": 1, "mp_node_fwd": 2, "mp_node_bwd": 3, "wgrad_edge": 4,
+                   "wgrad_other": 5, "other": 6}
+
+
+def prof_enable(on: bool) -> None:
+    check(load().b3d_prof_enable(1 if on else 0), "b3d_prof_enable")
+    check(load().b3d_prof_reset(), "b3d_prof_reset")
+
+
+def prof_read() -> dict:
+    """{family: (total_ms, launches)} measured with HIP events on the launch stream."""
+    out = {}
+    for name, fam in KERNEL_FAMILIES.items():
+        ms, n = C.c_double(), C.c_int()
+        check(load().b3d_prof_read(fam, C.byref(ms), C.byref(n)), "b3d_prof_read")
+        out[name] = (ms.value, n.value)
+    return out

@@ -46,6 +46,17 @@ inline int grid_for_tiles(long rows, int tile_rows, int cap = 2048) {
   return (int)(t < cap ? t : cap);
 }
 
+// Kernel-family timers (b3d_prof_*): records an event pair around a launch when enabled.
+bool prof_on();
+void prof_begin(int family, hipStream_t stream);
+void prof_end(hipStream_t stream);
+struct ProfScope {
+  hipStream_t s;
+  bool on;
+  ProfScope(int family, hipStream_t stream) : s(stream), on(prof_on()) { if (on) prof_begin(family, s); }
+  ~ProfScope() { if (on) prof_end(s); }
+};
+
 // Bump allocator over a caller-provided workspace (the library allocates nothing).
 struct Carver {
   char* base;

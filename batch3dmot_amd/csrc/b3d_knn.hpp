@@ -25,6 +25,7 @@ struct KnnWs {
   int* fend;      // [N] one past the last
   int* nbr;       // [N, kKnnMaxK] neighbour node ids (-1 padded)
   int* cnt;       // [N] number of neighbours
+  int* rcnt;      // [3, N] rank counters
   float* h;       // [N, D]
   float* s_src;   // [N]
   float* s_dst;   // [N]
@@ -36,39 +37,62 @@ struct KnnWs {
 inline void knn_carve(KnnWs& k, Carver& c, int N, int D) {
   const size_t n = (size_t)(N > 0 ? N : 1);
   k.rank = c.take<int>(n); k.order = c.take<int>(n); k.fbeg = c.take<int>(n); k.fend = c.take<int>(n);
-  k.nbr = c.take<int>(n * kKnnMaxK); k.cnt = c.take<int>(n);
+  k.nbr = c.take<int>(n * kKnnMaxK); k.cnt = c.take<int>(n); k.rcnt = c.take<int>(3 * n);
   k.h = c.take<float>(n * D); k.s_src = c.take<float>(n); k.s_dst = c.take<float>(n); k.y = c.take<float>(n * D);
   k.wp = c.take<float>(image_floats(D, D));
   k.ranked = false;
 }
 
-// O(N^2 / 256) rank by (timestamp, node id) with the timestamps staged through LDS.
-__global__ __launch_bounds__(256) void knn_rank_kernel(const int64_t* __restrict__ ts, int N, int* __restrict__ rank,
-                                                       int* __restrict__ order, int* __restrict__ fbeg,
-                                                       int* __restrict__ fend) {
-  __shared__ int64_t tile[256];
+// Rank by (timestamp, node id).  O(N^2) comparisons spread over N x kRankSlices threads: thread
+// (i, s) counts over slice s of the nodes (timestamps staged through LDS as 32-bit offsets from
+// ts[0]) and adds its partial counts with integer atomics (exact, order independent).
+constexpr int kRankSlices = 16;
+__global__ __launch_bounds__(256) void knn_rank_count_kernel(const int64_t* __restrict__ ts, int N,
+                                                             int* __restrict__ cnt /* [3][N] zeroed */) {
+  __shared__ int tile[256];
+  const int64_t t0 = ts[0];
+  auto rel = [&](int64_t v) {
+    int64_t d = v - t0;
+    d = d > (1 << 30) ? (1 << 30) : d;
+    d = d < -(1 << 30) ? -(1 << 30) : d;
+    return (int)d;
+  };
   const int i = blockIdx.x * 256 + threadIdx.x;
-  const int64_t t = (i < N) ? ts[i] : 0;
+  const int t = (i < N) ? rel(ts[i]) : 0;
+  const int per = ((N + kRankSlices - 1) / kRankSlices + 255) / 256 * 256;
+  const int jb = blockIdx.y * per;
+  const int je = (jb + per < N) ? jb + per : N;
   int less = 0, leq = 0, r = 0;
-  for (int j0 = 0; j0 < N; j0 += 256) {
+  for (int j0 = jb; j0 < je; j0 += 256) {
     const int j = j0 + threadIdx.x;
-    tile[threadIdx.x] = (j < N) ? ts[j] : INT64_MAX;
+    tile[threadIdx.x] = (j < N) ? rel(ts[j]) : 0x7fffffff;
     __syncthreads();
-    const int lim = (N - j0 < 256) ? N - j0 : 256;
-    for (int jj = 0; jj < lim; ++jj) {
-      const int64_t u = tile[jj];
+    const int split = i - j0;                    // tile entries below `split` have a smaller node id
+#pragma unroll 16
+    for (int jj = 0; jj < 256; ++jj) {
+      const int u = tile[jj];
       less += (u < t);
       leq += (u <= t);
-      r += (u < t) || (u == t && j0 + jj < i);
+      r += (u < t) || (u == t && jj < split);
     }
     __syncthreads();
   }
   if (i < N) {
-    rank[i] = r;
-    order[r] = i;
-    fbeg[i] = less;
-    fend[i] = leq;
+    atomicAdd(&cnt[i], less);
+    atomicAdd(&cnt[N + i], leq);
+    atomicAdd(&cnt[2 * N + i], r);
   }
+}
+
+__global__ void knn_rank_finish_kernel(const int* __restrict__ cnt, int N, int* __restrict__ rank,
+                                       int* __restrict__ order, int* __restrict__ fbeg, int* __restrict__ fend) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int r = cnt[2 * N + i];
+  rank[i] = r;
+  order[r] = i;
+  fbeg[i] = cnt[i];
+  fend[i] = cnt[N + i];
 }
 
 __device__ __forceinline__ void wave_argmin(float& d, int& j) {
@@ -216,8 +240,11 @@ inline int knn_gat_block(KnnWs& ws, const float* x, const int64_t* ts, int N, co
   B3D_REQUIRE(k >= 1 && k <= kKnnMaxK, "k-NN k=%d outside [1,%d]", k, kKnnMaxK);
   if (N <= 0) return B3D_OK;
   if (!ws.ranked) {
-    hipLaunchKernelGGL(knn_rank_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, ts, N, ws.rank, ws.order, ws.fbeg, ws.fend);
-    B3D_TRY(launch_check("knn_rank_kernel"));
+    B3D_HIP_CHECK(hipMemsetAsync(ws.rcnt, 0, 3 * (size_t)N * sizeof(int), stream));
+    hipLaunchKernelGGL(knn_rank_count_kernel, dim3((N + 255) / 256, kRankSlices), dim3(256), 0, stream, ts, N, ws.rcnt);
+    B3D_TRY(launch_check("knn_rank_count_kernel"));
+    hipLaunchKernelGGL(knn_rank_finish_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, ws.rcnt, N, ws.rank, ws.order, ws.fbeg, ws.fend);
+    B3D_TRY(launch_check("knn_rank_finish_kernel"));
     using S = LayerSeq<L<D, D>>;
     PackDesc d = pack_desc<S>(0, ws.wp, gat.lin, nullptr, D, D, false);
     B3D_TRY(pack_images(&d, 1, stream));

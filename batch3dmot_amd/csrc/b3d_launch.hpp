@@ -21,9 +21,11 @@ inline int set_lds(K kernel, int bytes) {
 // Row-tiled MLP kernels.  NW = wavefronts per workgroup (each owns 16 rows).  Edge-sized inputs
 // use 8; node-sized inputs (a few thousand rows) use 1 so the launch still covers ~200 CUs.
 template <int NW, class Kern, class Args>
-inline int launch_rows(Kern kernel, const char* name, const Args& a, long rows, hipStream_t stream) {
+inline int launch_rows(Kern kernel, const char* name, const Args& a, long rows, hipStream_t stream,
+                       int family = B3D_K_OTHER) {
   if (rows <= 0) return B3D_OK;
   B3D_TRY(set_lds(kernel, kLdsBytes));
+  ProfScope ps(family, stream);
   hipLaunchKernelGGL(kernel, dim3(grid_for_tiles(rows, NW * 16)), dim3(NW * 64), kLdsBytes, stream, a);
   return launch_check(name);
 }
@@ -36,18 +38,24 @@ inline WgSeg seg(const float* p, const int* idx, int stride, int col0, int width
   return s;
 }
 
-// Chunk count of a weight-gradient job.  A workgroup's time is dominated by per-tile latency, not by
-// the matrix size, so every job gets the same number of rows per chunk (8 tiles of 32 rows).
-constexpr int kWgRowsPerChunk = 8 * kWgRT;
+// Chunk geometry of a weight-gradient job.  A workgroup's time is dominated by per-tile latency,
+// not by the matrix size, so the chunk length depends on the row count only: ~128 chunks per
+// matrix, between 1 and 8 tiles of 32 rows each.
+inline int wg_rows_per_chunk(long rows, int /*nchunks*/ = 0) {
+  long rpc = ((rows + 127) / 128 + kWgRT - 1) / kWgRT * kWgRT;
+  if (rpc < kWgRT) rpc = kWgRT;
+  if (rpc > 8 * kWgRT) rpc = 8 * kWgRT;
+  return (int)rpc;
+}
 inline int wg_nchunks(long rows, int /*NP*/, int /*KP*/, long /*launch_weight*/) {
   if (rows <= 0) return 1;
-  return (int)((rows + kWgRowsPerChunk - 1) / kWgRowsPerChunk);
+  const int rpc = wg_rows_per_chunk(rows);
+  return (int)((rows + rpc - 1) / rpc);
 }
-inline int wg_rows_per_chunk(long /*rows*/, int /*nchunks*/) { return kWgRowsPerChunk; }
 inline size_t wg_slab_floats(int nchunks, int NP, int KP) { return (size_t)nchunks * ((size_t)NP * KP + NP); }
 
 template <int MAXMB, int MAXNBW>
-inline int launch_wgrad(WgArgs& a, hipStream_t stream) {
+inline int launch_wgrad(WgArgs& a, hipStream_t stream, int family = B3D_K_WGRAD_OTHER) {
   constexpr int SLOTS = (kWgRT * (16 * MAXMB + 128 * MAXNBW) / 4 + kThreads - 1) / kThreads;
   if (a.njobs == 0) return B3D_OK;
   int wgs = 0, maxkp = 0;
@@ -63,6 +71,7 @@ inline int launch_wgrad(WgArgs& a, hipStream_t stream) {
   const int lds = kWgRT * ((MAXMB * 16 + 4) + (maxkp + 4)) * 4;
   auto kern = wgrad_kernel<MAXMB, MAXNBW, SLOTS>;
   B3D_TRY(set_lds(kern, lds));
+  ProfScope ps(family, stream);
   hipLaunchKernelGGL(kern, dim3(wgs), dim3(kThreads), lds, stream, a);
   return launch_check("wgrad_kernel");
 }

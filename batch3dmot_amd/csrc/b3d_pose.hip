@@ -266,13 +266,13 @@ extern "C" int b3d_pose_forward(const b3d_pose_weights* pw, const b3d_graph* g, 
     ea.e_out = w.e[l + 1]; ea.fut = w.fut; ea.past = w.past;
     ea.sH1 = w.sH1[l]; ea.sH2 = w.sH2[l]; ea.sF1 = w.sF1[l]; ea.sP1 = w.sP1[l];
     ea.wpack = w.wp_efwd;
-    B3D_TRY(launch_rows<kNWEdge>(mp_edge_fwd_kernel<D, kNWEdge>, "mp_edge_fwd", ea, E, stream));
+    B3D_TRY(launch_rows<kNWEdge>(mp_edge_fwd_kernel<D, kNWEdge>, "mp_edge_fwd", ea, E, stream, B3D_K_EDGE_FWD));
     NodeFwdArgs na;
     memset(&na, 0, sizeof(na));
     na.N = N; na.dst_ptr = g->dst_ptr; na.dst_perm = g->dst_perm; na.src_ptr = g->src_ptr; na.src_perm = g->src_perm;
     na.past = w.past; na.fut = w.fut; na.M = w.M[l]; na.x_out = w.x[l + 1]; na.sH1 = w.nH1[l]; na.sH2 = w.nH2[l];
     na.wpack = w.wp_nfwd;
-    B3D_TRY(launch_rows<kNWNode>(mp_node_fwd_kernel<D, kNWNode>, "mp_node_fwd", na, N, stream));
+    B3D_TRY(launch_rows<kNWNode>(mp_node_fwd_kernel<D, kNWNode>, "mp_node_fwd", na, N, stream, B3D_K_NODE_FWD));
   }
   {  // edge classifier 32-16-8-4-1 -> logits                                pose_gnn.py:86
     ChainFwdArgs<LoadAligned<2>, StoreScalar> a;
@@ -345,7 +345,7 @@ extern "C" int b3d_pose_backward(const b3d_pose_weights* pw, const b3d_graph* g,
       nb.gdst = w.gdst; nb.gsrc = w.gsrc; nb.dx0_acc = w.dx0_acc; nb.dx0_first = dx0_first ? 1 : 0;
       nb.sH1 = w.nH1[l]; nb.sH2 = w.nH2[l]; nb.dM = w.dM; nb.Gdx = w.Gdx; nb.GdH2 = w.GnH2; nb.GdH1 = w.GnH1;
       nb.wpack = w.wp_nbwd;
-      B3D_TRY(launch_rows<kNWNode>(mp_node_bwd_kernel<D, kNWNode>, "mp_node_bwd", nb, N, stream));
+      B3D_TRY(launch_rows<kNWNode>(mp_node_bwd_kernel<D, kNWNode>, "mp_node_bwd", nb, N, stream, B3D_K_NODE_BWD));
       dx0_first = false;
       WgArgs wn;
       wn.njobs = 0;
@@ -371,10 +371,10 @@ extern "C" int b3d_pose_backward(const b3d_pose_weights* pw, const b3d_graph* g,
     eb.GdH1 = w.GdH1; eb.GdH2 = w.GdH2; eb.Gde = w.Gde; eb.GdF1 = w.GdF1; eb.GdP1 = w.GdP1;
     if (msgs) {
       eb.wpack = w.wp_ebwd;
-      B3D_TRY(launch_rows<kNWEdge>(mp_edge_bwd_kernel<D, true, kNWEdge>, "mp_edge_bwd", eb, E, stream));
+      B3D_TRY(launch_rows<kNWEdge>(mp_edge_bwd_kernel<D, true, kNWEdge>, "mp_edge_bwd", eb, E, stream, B3D_K_EDGE_BWD));
     } else {
       eb.wpack = w.wp_ebwd_nm;
-      B3D_TRY(launch_rows<kNWEdge>(mp_edge_bwd_kernel<D, false, kNWEdge>, "mp_edge_bwd_last", eb, E, stream));
+      B3D_TRY(launch_rows<kNWEdge>(mp_edge_bwd_kernel<D, false, kNWEdge>, "mp_edge_bwd_last", eb, E, stream, B3D_K_OTHER));
     }
     cur ^= 1;
     WgArgs we;
@@ -410,7 +410,7 @@ extern "C" int b3d_pose_backward(const b3d_pose_weights* pw, const b3d_graph* g,
     add_act(u0, seg(xl, src, D::DX, 0, D::DX));
     add_act(u0, seg(w.e[l], nullptr, D::DE, 0, D::DE));
     we.jobs[we.njobs++] = u0;
-    B3D_TRY((launch_wgrad<6, 1>(we, stream)));
+    B3D_TRY((launch_wgrad<6, 1>(we, stream, msgs ? B3D_K_WGRAD_EDGE : B3D_K_WGRAD_OTHER)));
   }
 
   // ---- encoders ---------------------------------------------------------------------------------

@@ -52,17 +52,20 @@ __device__ __forceinline__ float wg_load1(const WgSeg& s, long r, int c) {
 
 // One float4 of the LDS tile and where it comes from (fixed per thread for the whole kernel).
 struct WgSlot {
-  int rl;            // tile-local row, -1: unused slot
+  const float* sp;   // source base + col0 + column (fast slots)
+  const int* ip;     // row gather or nullptr
+  int stride;
+  int rl;            // tile-local row
   int lds_off;       // float offset inside the tile
   int seg;           // -1: G, >= 0: activation segment that holds element 0 of this float4
   int c;             // column inside that segment (for G: true output column)
-  int fast;          // whole float4 inside one aligned segment -> one 16-byte load
+  int mode;          // 0: always zero / unused, 1: one aligned 16-byte load, 2: element-wise (slow)
 };
 
 // MAXMB: 16-row output blocks per workgroup; MAXNBW: 16-col input blocks per wave (8 waves);
 // SLOTS: float4 loads per thread per 32-row tile (ceil(32 * (16 MAXMB + KPmax) / 4 / 512)).
 template <int MAXMB, int MAXNBW, int SLOTS>
-__global__ __launch_bounds__(kThreads) void wgrad_kernel(const WgArgs args) {
+__global__ __launch_bounds__(kThreads, 4) void wgrad_kernel(const WgArgs args) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ WgJob sjob;
   // ---- which job / chunk / output-row group ---------------------------------------------
@@ -95,25 +98,26 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(const WgArgs args) {
   for (int e = 0; e < SLOTS; ++e) {
     const int id = threadIdx.x + e * kThreads;
     WgSlot sl;
-    sl.rl = -1; sl.lds_off = 0; sl.seg = -1; sl.c = 0; sl.fast = 0;
+    sl.sp = nullptr; sl.ip = nullptr; sl.stride = 0; sl.rl = 0; sl.lds_off = -1; sl.seg = -1; sl.c = 0; sl.mode = 0;
     if (id < kWgRT * c4tot) {
       const int rl = id / c4tot, c4 = id - rl * c4tot;
       sl.rl = rl;
       if (c4 < gc4) {
-        sl.seg = -1;
         sl.c = mb_base * 16 + c4 * 4;
         sl.lds_off = rl * gstride + c4 * 4;
-        sl.fast = (job.g.aligned && sl.c + 4 <= job.g.width) ? 1 : 0;
-        if (sl.c >= job.g.width) sl.seg = -2;    // padding column: always zero
+        if (sl.c < job.g.width) {
+          sl.mode = (job.g.aligned && sl.c + 4 <= job.g.width) ? 1 : 2;
+          sl.sp = job.g.ptr + job.g.col0 + sl.c; sl.ip = job.g.idx; sl.stride = job.g.stride;
+        }
       } else {
         int c = (c4 - gc4) * 4;
         sl.lds_off = kWgRT * gstride + rl * astride + c;
-        sl.seg = -2;
         for (int sgi = 0; sgi < job.nact; ++sgi) {
           const int w = job.act[sgi].width;
           if (c < w) {
             sl.seg = sgi; sl.c = c;
-            sl.fast = (job.act[sgi].aligned && (c & 3) == 0 && c + 4 <= w) ? 1 : 0;
+            sl.mode = (job.act[sgi].aligned && (c & 3) == 0 && c + 4 <= w) ? 1 : 2;
+            sl.sp = job.act[sgi].ptr + job.act[sgi].col0 + c; sl.ip = job.act[sgi].idx; sl.stride = job.act[sgi].stride;
             break;
           }
           c -= w;
@@ -123,26 +127,18 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(const WgArgs args) {
     slot[e] = sl;
   }
 
-  auto fetch = [&](const WgSlot& sl, long rt, long r1) -> v4f {
+  // element-wise path: unaligned source or a float4 that straddles segments (rare, small jobs)
+  auto fetch_slow = [&](const WgSlot& sl, long row) -> v4f {
     v4f v = {0.f, 0.f, 0.f, 0.f};
-    if (sl.rl < 0 || sl.seg == -2) return v;
-    const long row = rt + sl.rl;
-    if (row >= r1) return v;
+    float* vp = reinterpret_cast<float*>(&v);
     if (sl.seg == -1) {
       const WgSeg& sg = job.g;
       const long r = sg.idx ? sg.idx[row] : row;
-      if (sl.fast) return *reinterpret_cast<const v4f*>(sg.ptr + r * (long)sg.stride + sg.col0 + sl.c);
-      float* vp = reinterpret_cast<float*>(&v);
 #pragma unroll
       for (int e = 0; e < 4; ++e)
         if (sl.c + e < sg.width) vp[e] = wg_load1(sg, r, sl.c + e);
       return v;
     }
-    const WgSeg& sg = job.act[sl.seg];
-    const long r = sg.idx ? sg.idx[row] : row;
-    if (sl.fast) return *reinterpret_cast<const v4f*>(sg.ptr + r * (long)sg.stride + sg.col0 + sl.c);
-    // slow path: unaligned source or a float4 that straddles segments
-    float* vp = reinterpret_cast<float*>(&v);
     int sgi = sl.seg, c = sl.c;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -157,6 +153,30 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(const WgArgs args) {
     return v;
   };
 
+  // All slots of a thread are fetched together: first every row index, then every row chunk, so
+  // that the (up to SLOTS) dependent index -> data chains overlap instead of running one by one.
+  auto fetch_all = [&](long rt, long r1, v4f* pre) {
+    long r[SLOTS];
+    bool ok[SLOTS];
+#pragma unroll
+    for (int e = 0; e < SLOTS; ++e) {
+      const long row = rt + slot[e].rl;
+      ok[e] = (slot[e].mode == 1) && (row < r1);
+      r[e] = row;
+      if (ok[e] && slot[e].ip) r[e] = slot[e].ip[row];
+    }
+#pragma unroll
+    for (int e = 0; e < SLOTS; ++e) {
+      pre[e] = v4f{0.f, 0.f, 0.f, 0.f};
+      if (ok[e]) pre[e] = *reinterpret_cast<const v4f*>(slot[e].sp + r[e] * (long)slot[e].stride);
+    }
+#pragma unroll
+    for (int e = 0; e < SLOTS; ++e) {
+      const long row = rt + slot[e].rl;
+      if (slot[e].mode == 2 && row < r1) pre[e] = fetch_slow(slot[e], row);
+    }
+  };
+
   v4f acc[MAXMB][MAXNBW];
 #pragma unroll
   for (int a = 0; a < MAXMB; ++a)
@@ -169,19 +189,15 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(const WgArgs args) {
   if (r1 > job.rows) r1 = job.rows;
 
   v4f pre[SLOTS];
-#pragma unroll
-  for (int e = 0; e < SLOTS; ++e) pre[e] = fetch(slot[e], r0, r1);
+  fetch_all(r0, r1, pre);
 
   for (long rt = r0; rt < r1; rt += kWgRT) {
     // ---- registers -> LDS tile, then prefetch the next tile while this one is multiplied ---
 #pragma unroll
     for (int e = 0; e < SLOTS; ++e)
-      if (slot[e].rl >= 0) *reinterpret_cast<v4f*>(smem + slot[e].lds_off) = pre[e];
+      if (slot[e].lds_off >= 0) *reinterpret_cast<v4f*>(smem + slot[e].lds_off) = pre[e];
     __syncthreads();
-    if (rt + kWgRT < r1) {
-#pragma unroll
-      for (int e = 0; e < SLOTS; ++e) pre[e] = fetch(slot[e], rt + kWgRT, r1);
-    }
+    if (rt + kWgRT < r1) fetch_all(rt + kWgRT, r1, pre);
     // ---- bias gradient: column sums of G -----------------------------------------------
     if ((int)threadIdx.x < gw) {
 #pragma unroll 8
@@ -276,7 +292,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedArgs a) {
   }
   if (!out) return;
   float s = 0.f;
-  for (int c = 0; c < e.nchunks; ++c) s += e.slab[(size_t)c * cs + off];
+  int c = 0;
+  for (; c + 8 <= e.nchunks; c += 8) {
+    float t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = e.slab[(size_t)(c + u) * cs + off];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += t[u];
+  }
+  for (; c < e.nchunks; ++c) s += e.slab[(size_t)c * cs + off];
   *out = s;
 }
 

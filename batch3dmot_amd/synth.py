@@ -114,9 +114,15 @@ def make_graph(num_nodes: int = 1500, target_edges: Optional[int] = None, k: int
     start = torch.cumsum(counts, 0) - counts
     rank = torch.arange(cdst.numel()) - start[cdst]
     if target_edges is not None:
-        k = 1
-        while int(torch.minimum(counts, torch.tensor(k)).sum()) < target_edges and k < int(counts.max()):
-            k += 1
+        # the K whose edge count is closest to the target
+        best = None
+        for kk in range(1, int(counts.max()) + 1):
+            n_e = int(torch.minimum(counts, torch.tensor(kk)).sum())
+            if best is None or abs(n_e - target_edges) < best[0]:
+                best = (abs(n_e - target_edges), kk)
+            if n_e >= target_edges:
+                break
+        k = best[1]
     keep = rank < k
     src, dst = cs[keep], cdst[keep]
     edge_index = torch.stack([src, dst]).long().contiguous()

@@ -123,6 +123,24 @@ int b3d_pose_backward(const b3d_pose_weights* w, const b3d_graph* g, const float
                       const float* d_logits, const float* d_x_enc, const b3d_pose_grads* grads /* host */,
                       b3d_stream stream);
 
+/* ---- kernel-family timers (measurement aid for bench.py; off by default) --------------------
+ * When enabled, every launch of the listed kernel families is bracketed by hipEventRecord on the
+ * launch stream.  b3d_prof_read synchronises on the recorded events and returns the summed device
+ * time and launch count of one family since the last reset.  Process-global, mutex-protected. */
+typedef enum b3d_kernel_family {
+  B3D_K_EDGE_FWD = 0,   /* mp_edge_fwd  : fused edge phase, forward              */
+  B3D_K_EDGE_BWD = 1,   /* mp_edge_bwd  : fused edge phase, data gradient        */
+  B3D_K_NODE_FWD = 2,   /* mp_node_fwd  : segment sums + node MLP                */
+  B3D_K_NODE_BWD = 3,   /* mp_node_bwd                                           */
+  B3D_K_WGRAD_EDGE = 4, /* wgrad launch over the edge stacks of one layer        */
+  B3D_K_WGRAD_OTHER = 5,
+  B3D_K_OTHER = 6,
+  B3D_K_COUNT = 7
+} b3d_kernel_family;
+int b3d_prof_enable(int on);
+int b3d_prof_reset(void);
+int b3d_prof_read(int family, double* total_ms /* host */, int* launches /* host */);
+
 #ifdef __cplusplus
 }
 #endif

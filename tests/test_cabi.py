@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
 def test_version_and_workspace_queries():
     lib = _lib.load()
     assert lib.b3d_version() >= 100
-    assert lib.b3d_graph_workspace_bytes(3000, 30000) > 6 * 30000 * 4
+    assert lib.b3d_graph_workspace_bytes(3000, 30000) > 4 * 30000 * 4
     inf = lib.b3d_pose_workspace_bytes(3000, 30000, 6, 0)
     tr = lib.b3d_pose_workspace_bytes(3000, 30000, 6, _lib.B3D_FLAG_TRAINING)
     assert 0 < inf < tr

@@ -105,8 +105,32 @@ def main():
     for (n, p), (_, q) in zip(m2.named_parameters(), ora.named_parameters()):
         if q.grad is None:
             continue
-        worst = max(worst, rel(p.grad, q.grad))
+        r = rel(p.grad, q.grad)
+        if r > 1e-4:
+            print(f"   big grad {n}: rel {r:.3e} |ref|max {q.grad.abs().max():.3e}")
+        worst = max(worst, r)
     print("big: worst grad rel err", worst)
+    # who is closer to float64?
+    import copy
+    ora64 = copy.deepcopy(ora).double(); ora64.zero_grad()
+    big64 = Data(**{k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in big.__dict__.items()})
+    class _F(torch.nn.Module):
+        pass
+    # edge_encoder applies .float(): emulate in double
+    e64 = ora64.edge_encoder(big64.edge_attr.float().double())
+    x64 = ora64.node_encoder(big64.pose_feats)
+    x0 = x64
+    for i in range(6):
+        x64, e64 = ora64.message_passing(x64, big64.edge_index, e64, x0)
+    o64 = ora64.edge_classifier(e64)
+    (o64 * lw.cpu().double()).sum().backward()
+    print("logits: hip vs f64", rel(out, o64), " cpu-f32 vs f64", rel(o_ref, o64))
+    w_h = w_c = 0
+    for (n, p), (_, q), (_, r64) in zip(m2.named_parameters(), ora.named_parameters(), ora64.named_parameters()):
+        if r64.grad is None:
+            continue
+        w_h = max(w_h, rel(p.grad, r64.grad)); w_c = max(w_c, rel(q.grad, r64.grad))
+    print("grads: worst hip vs f64", w_h, " worst cpu-f32 vs f64", w_c)
 
 
 if __name__ == "__main__":
