@@ -1,5 +1,6 @@
 // Host-side launch helpers shared by the model orchestration files.
 #pragma once
+#include <stdlib.h>
 #include "b3d_common.hpp"
 #include "b3d_chain.hpp"
 #include "b3d_mp.hpp"
@@ -45,6 +46,7 @@ inline int wg_rows_per_chunk(long rows, int /*nchunks*/ = 0) {
   long rpc = ((rows + 127) / 128 + kWgRT - 1) / kWgRT * kWgRT;
   if (rpc < kWgRT) rpc = kWgRT;
   if (rpc > 8 * kWgRT) rpc = 8 * kWgRT;
+  if (const char* ev = getenv("B3D_WG_RPC")) { long v = atol(ev); if (v >= kWgRT && rows > 4096) rpc = v / kWgRT * kWgRT; }
   return (int)rpc;
 }
 inline int wg_nchunks(long rows, int /*NP*/, int /*KP*/, long /*launch_weight*/) {
@@ -56,7 +58,10 @@ inline size_t wg_slab_floats(int nchunks, int NP, int KP) { return (size_t)nchun
 
 template <int MAXMB, int MAXNBW>
 inline int launch_wgrad(WgArgs& a, hipStream_t stream, int family = B3D_K_WGRAD_OTHER) {
-  constexpr int SLOTS = (kWgRT * (16 * MAXMB + 128 * MAXNBW) / 4 + kThreads - 1) / kThreads;
+  // row passes per 32-row tile: a thread stages one 16-byte column chunk of kThreads / c4tot rows
+  constexpr int kMaxC4 = (16 * MAXMB + 128 * MAXNBW) / 4;
+  constexpr int SLOTS = (kWgRT + (kThreads / kMaxC4) - 1) / (kThreads / kMaxC4);
+  static_assert(kMaxC4 <= kThreads, "tile row wider than the workgroup");
   if (a.njobs == 0) return B3D_OK;
   int wgs = 0, maxkp = 0;
   for (int j = 0; j < a.njobs; ++j) {
@@ -68,7 +73,7 @@ inline int launch_wgrad(WgArgs& a, hipStream_t stream, int family = B3D_K_WGRAD_
     wgs += job.nchunks * job.mgroups;
     if (job.KP > maxkp) maxkp = job.KP;
   }
-  const int lds = kWgRT * ((MAXMB * 16 + 4) + (maxkp + 4)) * 4;
+  const int lds = 2 * kWgRT * ((MAXMB * 16 + 4) + (maxkp + 4)) * 4;
   auto kern = wgrad_kernel<MAXMB, MAXNBW, SLOTS>;
   B3D_TRY(set_lds(kern, lds));
   ProfScope ps(family, stream);

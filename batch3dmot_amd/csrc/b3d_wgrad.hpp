@@ -50,25 +50,18 @@ __device__ __forceinline__ float wg_load1(const WgSeg& s, long r, int c) {
   return s.ptr[r * (long)s.stride + s.col0 + c];
 }
 
-// One float4 of the LDS tile and where it comes from (fixed per thread for the whole kernel).
-struct WgSlot {
-  const float* sp;   // source base + col0 + column (fast slots)
-  const int* ip;     // row gather or nullptr
-  int stride;
-  int rl;            // tile-local row
-  int lds_off;       // float offset inside the tile
-  int seg;           // -1: G, >= 0: activation segment that holds element 0 of this float4
-  int c;             // column inside that segment (for G: true output column)
-  int mode;          // 0: always zero / unused, 1: one aligned 16-byte load, 2: element-wise (slow)
-};
-
 // MAXMB: 16-row output blocks per workgroup; MAXNBW: 16-col input blocks per wave (8 waves);
-// SLOTS: float4 loads per thread per 32-row tile (ceil(32 * (16 MAXMB + KPmax) / 4 / 512)).
+// SLOTS: row passes per 32-row tile.  Thread t stages ONE fixed 16-byte column chunk
+// (t % c4tot) of rows (t / c4tot) + e * RPT, e < SLOTS, so it carries a single source descriptor.
+//
+// Pipeline per workgroup: tile t is multiplied out of LDS buffer t & 1 while the row chunks of tiles
+// t+1 and t+2 are in flight in two register sets and the gather indices of tile t+3 are being
+// fetched -- the dependent index -> row chain and the HBM/L2 latency are both off the critical
+// path; one workgroup barrier per tile.
 template <int MAXMB, int MAXNBW, int SLOTS>
 __global__ __launch_bounds__(kThreads, 4) void wgrad_kernel(const WgArgs args) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ WgJob sjob;
-  // ---- which job / chunk / output-row group ---------------------------------------------
   int j = 0;
 #pragma unroll
   for (int t = 1; t < kWgMaxJobs; ++t)
@@ -86,60 +79,57 @@ __global__ __launch_bounds__(kThreads, 4) void wgrad_kernel(const WgArgs args) {
   if (MBW > MAXMB) MBW = MAXMB;
   const int gw = MBW * 16;                       // G columns staged by this workgroup
   const int gstride = gw + 4, astride = job.KP + 4;
-  float* Gl = smem;                              // [kWgRT][gstride]
-  float* Al = smem + kWgRT * gstride;            // [kWgRT][astride]
+  const int tile_floats = kWgRT * (gstride + astride);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int m = lane & 15, q = lane >> 4;
 
-  // ---- per-thread load plan -----------------------------------------------------------------
+  // ---- this thread's column chunk ----------------------------------------------------------
   const int gc4 = gw / 4, ac4 = job.KP / 4, c4tot = gc4 + ac4;
-  WgSlot slot[SLOTS];
-#pragma unroll
-  for (int e = 0; e < SLOTS; ++e) {
-    const int id = threadIdx.x + e * kThreads;
-    WgSlot sl;
-    sl.sp = nullptr; sl.ip = nullptr; sl.stride = 0; sl.rl = 0; sl.lds_off = -1; sl.seg = -1; sl.c = 0; sl.mode = 0;
-    if (id < kWgRT * c4tot) {
-      const int rl = id / c4tot, c4 = id - rl * c4tot;
-      sl.rl = rl;
-      if (c4 < gc4) {
-        sl.c = mb_base * 16 + c4 * 4;
-        sl.lds_off = rl * gstride + c4 * 4;
-        if (sl.c < job.g.width) {
-          sl.mode = (job.g.aligned && sl.c + 4 <= job.g.width) ? 1 : 2;
-          sl.sp = job.g.ptr + job.g.col0 + sl.c; sl.ip = job.g.idx; sl.stride = job.g.stride;
-        }
-      } else {
-        int c = (c4 - gc4) * 4;
-        sl.lds_off = kWgRT * gstride + rl * astride + c;
-        for (int sgi = 0; sgi < job.nact; ++sgi) {
-          const int w = job.act[sgi].width;
-          if (c < w) {
-            sl.seg = sgi; sl.c = c;
-            sl.mode = (job.act[sgi].aligned && (c & 3) == 0 && c + 4 <= w) ? 1 : 2;
-            sl.sp = job.act[sgi].ptr + job.act[sgi].col0 + c; sl.ip = job.act[sgi].idx; sl.stride = job.act[sgi].stride;
-            break;
-          }
-          c -= w;
-        }
-      }
+  const int RPT = kThreads / c4tot;              // rows staged per pass (host guarantees >= 1)
+  const int my_c4 = threadIdx.x % c4tot, my_r = threadIdx.x / c4tot;
+  const bool active = my_r < RPT;
+  const float* sp = nullptr;                     // source base + col0 + column
+  const int* ip = nullptr;                       // row gather
+  int sstride = 0, mode = 0, seg = -1, col = 0;  // mode 0: zero, 1: one 16-byte load, 2: element-wise
+  int lds_off, lds_rstride;
+  if (my_c4 < gc4) {
+    col = mb_base * 16 + my_c4 * 4;
+    lds_off = my_r * gstride + my_c4 * 4;
+    lds_rstride = gstride;
+    if (col < job.g.width) {
+      mode = (job.g.aligned && col + 4 <= job.g.width) ? 1 : 2;
+      sp = job.g.ptr + job.g.col0 + col; ip = job.g.idx; sstride = job.g.stride;
     }
-    slot[e] = sl;
+  } else {
+    int c = (my_c4 - gc4) * 4;
+    lds_off = kWgRT * gstride + my_r * astride + c;
+    lds_rstride = astride;
+    for (int sgi = 0; sgi < job.nact; ++sgi) {
+      const int w = job.act[sgi].width;
+      if (c < w) {
+        seg = sgi; col = c;
+        mode = (job.act[sgi].aligned && (c & 3) == 0 && c + 4 <= w) ? 1 : 2;
+        sp = job.act[sgi].ptr + job.act[sgi].col0 + c; ip = job.act[sgi].idx; sstride = job.act[sgi].stride;
+        break;
+      }
+      c -= w;
+    }
   }
+  if (!active) mode = 0;
 
   // element-wise path: unaligned source or a float4 that straddles segments (rare, small jobs)
-  auto fetch_slow = [&](const WgSlot& sl, long row) -> v4f {
+  auto fetch_slow = [&](long row) -> v4f {
     v4f v = {0.f, 0.f, 0.f, 0.f};
     float* vp = reinterpret_cast<float*>(&v);
-    if (sl.seg == -1) {
+    if (seg == -1) {
       const WgSeg& sg = job.g;
       const long r = sg.idx ? sg.idx[row] : row;
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        if (sl.c + e < sg.width) vp[e] = wg_load1(sg, r, sl.c + e);
+        if (col + e < sg.width) vp[e] = wg_load1(sg, r, col + e);
       return v;
     }
-    int sgi = sl.seg, c = sl.c;
+    int sgi = seg, c = col;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       while (sgi < job.nact && c >= job.act[sgi].width) { c -= job.act[sgi].width; ++sgi; }
@@ -153,27 +143,39 @@ __global__ __launch_bounds__(kThreads, 4) void wgrad_kernel(const WgArgs args) {
     return v;
   };
 
-  // All slots of a thread are fetched together: first every row index, then every row chunk, so
-  // that the (up to SLOTS) dependent index -> data chains overlap instead of running one by one.
-  auto fetch_all = [&](long rt, long r1, v4f* pre) {
-    long r[SLOTS];
-    bool ok[SLOTS];
+  const long r0 = (long)chunk * job.rows_per_chunk;
+  long r1 = r0 + job.rows_per_chunk;
+  if (r1 > job.rows) r1 = job.rows;
+  const int T = (r1 > r0) ? (int)((r1 - r0 + kWgRT - 1) / kWgRT) : 0;
+
+  // gather indices of tile `tile` (-1: nothing to load -> zeros)
+  auto load_idx = [&](int tile, int* ridx) {
 #pragma unroll
     for (int e = 0; e < SLOTS; ++e) {
-      const long row = rt + slot[e].rl;
-      ok[e] = (slot[e].mode == 1) && (row < r1);
-      r[e] = row;
-      if (ok[e] && slot[e].ip) r[e] = slot[e].ip[row];
+      const int rl = e * RPT + my_r;
+      const long row = r0 + (long)tile * kWgRT + rl;
+      int v = -1;
+      if (mode != 0 && tile < T && rl < kWgRT && row < r1) v = (mode == 1 && ip) ? ip[row] : (int)row;
+      ridx[e] = v;
     }
+  };
+  auto load_data = [&](const int* ridx, v4f* P) {
 #pragma unroll
     for (int e = 0; e < SLOTS; ++e) {
-      pre[e] = v4f{0.f, 0.f, 0.f, 0.f};
-      if (ok[e]) pre[e] = *reinterpret_cast<const v4f*>(slot[e].sp + r[e] * (long)slot[e].stride);
+      P[e] = v4f{0.f, 0.f, 0.f, 0.f};
+      if (mode == 1 && ridx[e] >= 0) P[e] = *reinterpret_cast<const v4f*>(sp + (long)ridx[e] * sstride);
     }
+    if (mode == 2) {
 #pragma unroll
-    for (int e = 0; e < SLOTS; ++e) {
-      const long row = rt + slot[e].rl;
-      if (slot[e].mode == 2 && row < r1) pre[e] = fetch_slow(slot[e], row);
+      for (int e = 0; e < SLOTS; ++e)
+        if (ridx[e] >= 0) P[e] = fetch_slow(ridx[e]);
+    }
+  };
+  auto write_tile = [&](const v4f* P, float* buf) {
+    if (active) {
+#pragma unroll
+      for (int e = 0; e < SLOTS; ++e)
+        if (e * RPT + my_r < kWgRT) *reinterpret_cast<v4f*>(buf + lds_off + e * RPT * lds_rstride) = P[e];
     }
   };
 
@@ -184,26 +186,13 @@ __global__ __launch_bounds__(kThreads, 4) void wgrad_kernel(const WgArgs args) {
     for (int b = 0; b < MAXNBW; ++b) acc[a][b] = v4f{0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;
 
-  const long r0 = (long)chunk * job.rows_per_chunk;
-  long r1 = r0 + job.rows_per_chunk;
-  if (r1 > job.rows) r1 = job.rows;
-
-  v4f pre[SLOTS];
-  fetch_all(r0, r1, pre);
-
-  for (long rt = r0; rt < r1; rt += kWgRT) {
-    // ---- registers -> LDS tile, then prefetch the next tile while this one is multiplied ---
-#pragma unroll
-    for (int e = 0; e < SLOTS; ++e)
-      if (slot[e].lds_off >= 0) *reinterpret_cast<v4f*>(smem + slot[e].lds_off) = pre[e];
-    __syncthreads();
-    if (rt + kWgRT < r1) fetch_all(rt + kWgRT, r1, pre);
-    // ---- bias gradient: column sums of G -----------------------------------------------
+  auto multiply = [&](const float* buf) {
+    const float* Gl = buf;
+    const float* Al = buf + kWgRT * gstride;
     if ((int)threadIdx.x < gw) {
 #pragma unroll 8
       for (int rl = 0; rl < kWgRT; ++rl) bsum += Gl[rl * gstride + threadIdx.x];
     }
-    // ---- MFMA over the tile's 32 rows (8 k-steps of 4 rows) -----------------------------
 #pragma unroll 2
     for (int st = 0; st < kWgRT / 4; ++st) {
       const float* gr = Gl + (4 * st + q) * gstride + m;
@@ -226,6 +215,36 @@ __global__ __launch_bounds__(kThreads, 4) void wgrad_kernel(const WgArgs args) {
         }
       }
     }
+  };
+
+  // ---- software pipeline ----------------------------------------------------------------------
+  v4f P0[SLOTS], P1[SLOTS];
+  int I0[SLOTS], I1[SLOTS];
+  float* buf0 = smem;
+  float* buf1 = smem + tile_floats;
+  load_idx(0, I0);
+  load_idx(1, I1);
+  load_data(I0, P0);            // tile 0
+  load_idx(2, I0);
+  load_data(I1, P1);            // tile 1
+  load_idx(3, I1);
+  write_tile(P0, buf0);
+  load_data(I0, P0);            // tile 2
+  load_idx(4, I0);
+  __syncthreads();
+  // invariant at the top of iteration t (even): buf0 = tile t, P1 = tile t+1, P0 = tile t+2,
+  // I1 = indices of tile t+3, I0 = indices of tile t+4
+  for (int t = 0; t < T; t += 2) {
+    write_tile(P1, buf1);       // tile t+1
+    load_data(I1, P1);          // tile t+3
+    load_idx(t + 5, I1);
+    multiply(buf0);             // tile t
+    __syncthreads();
+    if (t + 1 >= T) break;
+    write_tile(P0, buf0);       // tile t+2
+    load_data(I0, P0);          // tile t+4
+    load_idx(t + 6, I0);
+    multiply(buf1);             // tile t+1
     __syncthreads();
   }
 
