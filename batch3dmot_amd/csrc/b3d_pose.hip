@@ -2,6 +2,7 @@
 // gfx950 kernel launches on one stream.  All scratch lives in the caller's workspace.
 #include "b3d_launch.hpp"
 #include "b3d_knn.hpp"
+#include "b3d_wstream.hpp"
 
 namespace b3d {
 
@@ -23,6 +24,53 @@ static const LinDim kLinDims[LIN_COUNT] = {
     {96, 128}, {64, 96}, {32, 64}, {96, 128}, {64, 96}, {96, 128}, {64, 96}, {96, 128}, {64, 96}, {48, 64}};
 static const bool kLinOnEdges[LIN_COUNT] = {1, 1, 1, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0};
 
+// Task plan of the streaming weight gradient: 14 jobs over the 10 message-passing Linear layers
+// (96x128 matrices are split into two column groups that share a slab), a work-proportional
+// share of ~2048 wavefront tasks each.  Jobs that share a slab get the same task count.
+enum { WJ_EU0A, WJ_EU0B, WJ_EU1, WJ_EU2, WJ_PA0A, WJ_PA0B, WJ_PA1, WJ_FU0A, WJ_FU0B, WJ_FU1,
+       WJ_CF0A, WJ_CF0B, WJ_CF1, WJ_CF2, WJ_COUNT };
+struct WsPlan {
+  int shape[WJ_COUNT], lin[WJ_COUNT], rows[WJ_COUNT], nvar[WJ_COUNT], rows_per_task[WJ_COUNT], ntasks[WJ_COUNT];
+};
+static WsPlan ws_plan(int N, int E, int depth);
+
+__global__ void iota_kernel(int* p, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = i;
+}
+
+static WsPlan ws_plan(int N, int E, int depth) {
+  WsPlan p;
+  const int shp[WJ_COUNT] = {WS_96_48_32, WS_96_48, WS_64_96, WS_32_64, WS_96_48_32, WS_96_48, WS_64_96,
+                             WS_96_48_32, WS_96_48, WS_64_96, WS_96_64, WS_96_64, WS_64_96, WS_48_64};
+  const int lin[WJ_COUNT] = {LIN_EU0, LIN_EU0, LIN_EU1, LIN_EU2, LIN_PA0, LIN_PA0, LIN_PA1,
+                             LIN_FU0, LIN_FU0, LIN_FU1, LIN_CF0, LIN_CF0, LIN_CF1, LIN_CF2};
+  double total = 0;
+  for (int i = 0; i < WJ_COUNT; ++i) {
+    p.shape[i] = shp[i];
+    p.lin[i] = lin[i];
+    p.rows[i] = (i < WJ_CF0A) ? E : N;
+    p.nvar[i] = (i <= WJ_EU2) ? depth : depth - 1;
+    total += (double)p.rows[i] * ws_shape_blocks(shp[i]) * (p.nvar[i] > 0 ? p.nvar[i] : 0);
+  }
+  for (int i = 0; i < WJ_COUNT; ++i) {
+    // column groups of one matrix share the slab: size both by the larger group's work
+    int ref = i;
+    if (i == WJ_EU0B || i == WJ_PA0B || i == WJ_FU0B || i == WJ_CF0B) ref = i - 1;
+    const double work = (double)p.rows[ref] * ws_shape_blocks(shp[ref]) * (p.nvar[ref] > 0 ? p.nvar[ref] : 0);
+    long t = (long)(2048.0 * work / (total > 0 ? total : 1) + 0.5);
+    const long maxt = (p.rows[i] + 15) / 16;
+    if (t > maxt) t = maxt;
+    if (t < 1) t = 1;
+    long rpt = ((p.rows[i] + t - 1) / t + 3) / 4 * 4;
+    if (rpt < 4) rpt = 4;
+    p.rows_per_task[i] = (int)rpt;
+    p.ntasks[i] = (int)((p.rows[i] + rpt - 1) / rpt);
+    if (p.ntasks[i] < 1) p.ntasks[i] = 1;
+  }
+  return p;
+}
+
 struct PoseWs {
   // packed weight images
   float *wp_ee, *wp_ne, *wp_cls, *wp_efwd, *wp_nfwd, *wp_ebwd, *wp_ebwd_nm, *wp_nbwd, *wp_clsT, *wp_eeT, *wp_neT;
@@ -33,8 +81,13 @@ struct PoseWs {
   float *sH1[16], *sH2[16], *sF1[16], *sP1[16], *M[16], *nH1[16], *nH2[16];
   float *fut, *past;
   // backward scratch
-  float *de[2], *gdst, *gsrc, *dM, *dx0_acc;
-  float *GdH1, *GdH2, *Gde, *GdF1, *GdP1, *Gdx, *GnH2, *GnH1;
+  float *de[2], *gdst, *gsrc, *dx0_acc;
+  // per-layer G tensors (kept for the single weight-gradient launch after the sweep); index 0 is
+  // layer 0 and consecutive layers are `*_ls` floats apart
+  float *dM, *GdH1, *GdH2, *Gde, *GdF1, *GdP1, *Gdx, *GnH2, *GnH1;
+  WsPlan plan;
+  float* zrow;          // 256 zero floats
+  int* iota;            // 0, 1, 2, ... (identity gather for the streaming weight gradient)
   float *gc3, *gc2, *gc1, *ge2, *ge1, *gn_top, *gn2, *gn1;
   LinSlab lin[LIN_COUNT];
   KnnWs knn;
@@ -52,8 +105,10 @@ static void carve(PoseWs& w, void* ws, size_t ws_bytes, int N, int E, int depth,
   w.wp_cls = c.take<float>(SeqCls::TOTAL_FLOATS);
   w.wp_efwd = c.take<float>(D::EdgeFwdSeq::TOTAL_FLOATS);
   w.wp_nfwd = c.take<float>(D::NodeFwdSeq::TOTAL_FLOATS);
-  w.x[0] = c.take<float>(n_ * D::DX);
-  w.e[0] = c.take<float>(e_ * D::DE);
+  if (!tr) {
+    w.x[0] = c.take<float>(n_ * D::DX);
+    w.e[0] = c.take<float>(e_ * D::DE);
+  }
   w.fut = c.take<float>(e_ * D::DM);
   w.past = c.take<float>(e_ * D::DM);
   if (!tr) {
@@ -79,30 +134,41 @@ static void carve(PoseWs& w, void* ws, size_t ws_bytes, int N, int E, int depth,
     w.c_a1 = c.take<float>(e_ * 16);
     w.c_a2 = c.take<float>(e_ * 16);
     w.c_a3 = c.take<float>(e_ * 16);
-    for (int l = 1; l <= depth; ++l) { w.x[l] = c.take<float>(n_ * D::DX); w.e[l] = c.take<float>(e_ * D::DE); }
-    for (int l = 0; l < depth; ++l) {
-      w.sH1[l] = c.take<float>(e_ * D::EH1);
-      w.sH2[l] = c.take<float>(e_ * D::EH2);
-      w.sF1[l] = c.take<float>(e_ * D::MH);
-      w.sP1[l] = c.take<float>(e_ * D::MH);
-      w.M[l] = c.take<float>(n_ * D::NIN);
-      w.nH1[l] = c.take<float>(n_ * D::NH1);
-      w.nH2[l] = c.take<float>(n_ * D::NH2);
+    // x[0..depth] / e[0..depth]: contiguous, uniform layer stride (the streaming weight gradient
+    // walks layers by pointer stride)
+    {
+      float* xb = c.take<float>((size_t)(depth + 1) * n_ * D::DX);
+      float* eb = c.take<float>((size_t)(depth + 1) * e_ * D::DE);
+      for (int l = 0; l <= depth; ++l) {
+        w.x[l] = xb ? xb + (size_t)l * n_ * D::DX : nullptr;
+        w.e[l] = eb ? eb + (size_t)l * e_ * D::DE : nullptr;
+      }
     }
+    auto per_layer = [&](float** arr, size_t per) {
+      float* b = c.take<float>((size_t)depth * per);
+      for (int l = 0; l < depth; ++l) arr[l] = b ? b + (size_t)l * per : nullptr;
+    };
+    per_layer(w.sH1, e_ * D::EH1);
+    per_layer(w.sH2, e_ * D::EH2);
+    per_layer(w.sF1, e_ * D::MH);
+    per_layer(w.sP1, e_ * D::MH);
+    per_layer(w.M, n_ * D::NIN);
+    per_layer(w.nH1, n_ * D::NH1);
+    per_layer(w.nH2, n_ * D::NH2);
     w.de[0] = c.take<float>(e_ * D::DE);
     w.de[1] = c.take<float>(e_ * D::DE);
     w.gdst = c.take<float>(e_ * 2 * D::DX);
     w.gsrc = c.take<float>(e_ * 2 * D::DX);
-    w.dM = c.take<float>(n_ * D::NIN);
     w.dx0_acc = c.take<float>(n_ * D::DX);
-    w.GdH1 = c.take<float>(e_ * D::EH1);
-    w.GdH2 = c.take<float>(e_ * D::EH2);
-    w.Gde = c.take<float>(e_ * D::DE);
-    w.GdF1 = c.take<float>(e_ * D::MH);
-    w.GdP1 = c.take<float>(e_ * D::MH);
-    w.Gdx = c.take<float>(n_ * D::DX);
-    w.GnH2 = c.take<float>(n_ * D::NH2);
-    w.GnH1 = c.take<float>(n_ * D::NH1);
+    w.dM = c.take<float>((size_t)depth * n_ * D::NIN);
+    w.GdH1 = c.take<float>((size_t)depth * e_ * D::EH1);
+    w.GdH2 = c.take<float>((size_t)depth * e_ * D::EH2);
+    w.Gde = c.take<float>((size_t)depth * e_ * D::DE);
+    w.GdF1 = c.take<float>((size_t)depth * e_ * D::MH);
+    w.GdP1 = c.take<float>((size_t)depth * e_ * D::MH);
+    w.Gdx = c.take<float>((size_t)depth * n_ * D::DX);
+    w.GnH2 = c.take<float>((size_t)depth * n_ * D::NH2);
+    w.GnH1 = c.take<float>((size_t)depth * n_ * D::NH1);
     w.gc3 = c.take<float>(e_ * 16);
     w.gc2 = c.take<float>(e_ * 16);
     w.gc1 = c.take<float>(e_ * 16);
@@ -111,20 +177,18 @@ static void carve(PoseWs& w, void* ws, size_t ws_bytes, int N, int E, int depth,
     w.gn_top = c.take<float>(n_ * 48);
     w.gn2 = c.take<float>(n_ * 48);
     w.gn1 = c.take<float>(n_ * 32);
-    // weight-gradient slabs; chunk counts are a pure function of (rows, dims)
-    long w_edge = 0, w_node = 0;
-    for (int i = LIN_EU0; i <= LIN_FU1; ++i) w_edge += (long)pad16(kLinDims[i].N) * pad16(kLinDims[i].K);
-    for (int i = LIN_CF0; i <= LIN_CF2; ++i) w_node += (long)pad16(kLinDims[i].N) * pad16(kLinDims[i].K);
+    w.iota = c.take<int>((size_t)(E > N ? E : N) + 64);
+    w.zrow = c.take<float>(256);
+    // weight-gradient slabs; chunk / task counts are a pure function of (N, E, depth)
+    w.plan = ws_plan(N, E, depth);
     for (int i = 0; i < LIN_COUNT; ++i) {
       LinSlab& ls = w.lin[i];
       ls.N = kLinDims[i].N; ls.K = kLinDims[i].K;
       ls.NP = pad16(ls.N); ls.KP = pad16(ls.K);
       const long rows = kLinOnEdges[i] ? E : N;
-      long lw;
-      if (i >= LIN_EU0 && i <= LIN_FU1) lw = w_edge;
-      else if (i >= LIN_CF0) lw = w_node;
-      else lw = (long)ls.NP * ls.KP * 4;           // encoders / classifier: ~128 chunks each
-      ls.nchunks = wg_nchunks(rows, ls.NP, ls.KP, lw);
+      ls.nchunks = wg_nchunks(rows, ls.NP, ls.KP, 0);
+      for (int jx = WJ_COUNT - 1; jx >= 0; --jx)
+        if (w.plan.lin[jx] == i) ls.nchunks = w.plan.ntasks[jx];
       ls.slab = c.take<float>(wg_slab_floats(ls.nchunks, ls.NP, ls.KP));
       ls.used = false;
     }
@@ -303,6 +367,11 @@ extern "C" int b3d_pose_backward(const b3d_pose_weights* pw, const b3d_graph* g,
   const int* src = g->src;
   const int* dst = g->dst;
 
+  const size_t eL1 = (size_t)E * D::EH1, eL2 = (size_t)E * D::EH2, eLe = (size_t)E * D::DE, eLm = (size_t)E * D::MH;
+  const size_t nLm = (size_t)N * D::NIN, nLx = (size_t)N * D::DX, nL1 = (size_t)N * D::NH1, nL2 = (size_t)N * D::NH2;
+  WgArgs small;                 // classifier + encoder weight gradients (tiny / unaligned layers)
+  small.njobs = 0;
+
   // ---- classifier: d_logits -> d e[depth] -------------------------------------------------------
   int cur = 0;
   {
@@ -314,26 +383,24 @@ extern "C" int b3d_pose_backward(const b3d_pose_weights* pw, const b3d_graph* g,
     a.gsave[0] = w.gc3; a.gsave[1] = w.gc2; a.gsave[2] = w.gc1; a.gsave[3] = nullptr;
     a.wpack = w.wp_clsT;
     B3D_TRY(launch_rows<kNWEdge>(chain_bwd_kernel<SeqClsT, LoadScalar, StoreAligned<2>, kNWEdge>, "edge_classifier_bwd", a, E, stream));
-    WgArgs wa;
-    wa.njobs = 0;
     if (d_logits) {
       WgJob j3 = make_job(w.lin[LIN_C3], E, seg(d_logits, nullptr, 1, 0, 1));
       add_act(j3, seg(w.c_a3, nullptr, 16, 0, 4));
-      wa.jobs[wa.njobs++] = j3;
+      small.jobs[small.njobs++] = j3;
     }
     WgJob j2 = make_job(w.lin[LIN_C2], E, seg(w.gc3, nullptr, 16, 0, 4));
     add_act(j2, seg(w.c_a2, nullptr, 16, 0, 8));
-    wa.jobs[wa.njobs++] = j2;
+    small.jobs[small.njobs++] = j2;
     WgJob j1 = make_job(w.lin[LIN_C1], E, seg(w.gc2, nullptr, 16, 0, 8));
     add_act(j1, seg(w.c_a1, nullptr, 16, 0, 16));
-    wa.jobs[wa.njobs++] = j1;
+    small.jobs[small.njobs++] = j1;
     WgJob j0 = make_job(w.lin[LIN_C0], E, seg(w.gc1, nullptr, 16, 0, 16));
     add_act(j0, seg(w.e[depth], nullptr, D::DE, 0, D::DE));
-    wa.jobs[wa.njobs++] = j0;
-    B3D_TRY((launch_wgrad<6, 1>(wa, stream)));
+    small.jobs[small.njobs++] = j0;
   }
 
-  // ---- message-passing layers, last to first -----------------------------------------------------
+  // ---- message-passing layers, last to first: data gradients only; the G tensors of every layer
+  //      are kept for ONE streaming weight-gradient launch after the sweep -------------------------
   bool dx0_first = true;
   for (int l = depth - 1; l >= 0; --l) {
     const bool msgs = (l < depth - 1);   // the last layer's node update feeds nothing (pose_gnn.py:86)
@@ -343,32 +410,22 @@ extern "C" int b3d_pose_backward(const b3d_pose_weights* pw, const b3d_graph* g,
       memset(&nb, 0, sizeof(nb));
       nb.N = N; nb.dst_ptr = g->dst_ptr; nb.dst_perm = g->dst_perm; nb.src_ptr = g->src_ptr; nb.src_perm = g->src_perm;
       nb.gdst = w.gdst; nb.gsrc = w.gsrc; nb.dx0_acc = w.dx0_acc; nb.dx0_first = dx0_first ? 1 : 0;
-      nb.sH1 = w.nH1[l]; nb.sH2 = w.nH2[l]; nb.dM = w.dM; nb.Gdx = w.Gdx; nb.GdH2 = w.GnH2; nb.GdH1 = w.GnH1;
+      nb.sH1 = w.nH1[l]; nb.sH2 = w.nH2[l];
+      nb.dM = w.dM + l * nLm; nb.Gdx = w.Gdx + l * nLx; nb.GdH2 = w.GnH2 + l * nL2; nb.GdH1 = w.GnH1 + l * nL1;
       nb.wpack = w.wp_nbwd;
       B3D_TRY(launch_rows<kNWNode>(mp_node_bwd_kernel<D, kNWNode>, "mp_node_bwd", nb, N, stream, B3D_K_NODE_BWD));
       dx0_first = false;
-      WgArgs wn;
-      wn.njobs = 0;
-      WgJob c2 = make_job(w.lin[LIN_CF2], N, seg(w.Gdx, nullptr, D::DX, 0, D::DX));
-      add_act(c2, seg(w.nH2[l], nullptr, D::NH2, 0, D::NH2));
-      wn.jobs[wn.njobs++] = c2;
-      WgJob c1 = make_job(w.lin[LIN_CF1], N, seg(w.GnH2, nullptr, D::NH2, 0, D::NH2));
-      add_act(c1, seg(w.nH1[l], nullptr, D::NH1, 0, D::NH1));
-      wn.jobs[wn.njobs++] = c1;
-      WgJob c0 = make_job(w.lin[LIN_CF0], N, seg(w.GnH1, nullptr, D::NH1, 0, D::NH1));
-      add_act(c0, seg(w.M[l], nullptr, D::NIN, 0, D::NIN));
-      wn.jobs[wn.njobs++] = c0;
-      B3D_TRY((launch_wgrad<6, 1>(wn, stream)));
     }
     EdgeBwdArgs eb;
     memset(&eb, 0, sizeof(eb));
     eb.E = E; eb.src = src; eb.dst = dst;
-    eb.dM = msgs ? w.dM : nullptr;
+    eb.dM = msgs ? w.dM + l * nLm : nullptr;
     eb.de_out = w.de[cur]; eb.de_in = w.de[cur ^ 1];
     eb.sH1 = w.sH1[l]; eb.sH2 = w.sH2[l]; eb.sF1 = w.sF1[l]; eb.sP1 = w.sP1[l];
     eb.da_acc = nullptr; eb.da_first = 0;
     eb.gdst = w.gdst; eb.gsrc = w.gsrc;
-    eb.GdH1 = w.GdH1; eb.GdH2 = w.GdH2; eb.Gde = w.Gde; eb.GdF1 = w.GdF1; eb.GdP1 = w.GdP1;
+    eb.GdH1 = w.GdH1 + l * eL1; eb.GdH2 = w.GdH2 + l * eL2; eb.Gde = w.Gde + l * eLe;
+    eb.GdF1 = w.GdF1 + l * eLm; eb.GdP1 = w.GdP1 + l * eLm;
     if (msgs) {
       eb.wpack = w.wp_ebwd;
       B3D_TRY(launch_rows<kNWEdge>(mp_edge_bwd_kernel<D, true, kNWEdge>, "mp_edge_bwd", eb, E, stream, B3D_K_EDGE_BWD));
@@ -377,40 +434,6 @@ extern "C" int b3d_pose_backward(const b3d_pose_weights* pw, const b3d_graph* g,
       B3D_TRY(launch_rows<kNWEdge>(mp_edge_bwd_kernel<D, false, kNWEdge>, "mp_edge_bwd_last", eb, E, stream, B3D_K_OTHER));
     }
     cur ^= 1;
-    WgArgs we;
-    we.njobs = 0;
-    const float* xl = w.x[l];
-    const float* x0 = w.x[0];
-    if (msgs) {
-      WgJob p1 = make_job(w.lin[LIN_PA1], E, seg(w.dM, dst, D::NIN, 0, D::DM));
-      add_act(p1, seg(w.sP1[l], nullptr, D::MH, 0, D::MH));
-      we.jobs[we.njobs++] = p1;
-      WgJob p0 = make_job(w.lin[LIN_PA0], E, seg(w.GdP1, nullptr, D::MH, 0, D::MH));
-      add_act(p0, seg(xl, src, D::DX, 0, D::DX));
-      add_act(p0, seg(w.e[l + 1], nullptr, D::DE, 0, D::DE));
-      add_act(p0, seg(x0, src, D::DX, 0, D::DX));
-      we.jobs[we.njobs++] = p0;
-      WgJob f1 = make_job(w.lin[LIN_FU1], E, seg(w.dM, src, D::NIN, D::DM, D::DM));
-      add_act(f1, seg(w.sF1[l], nullptr, D::MH, 0, D::MH));
-      we.jobs[we.njobs++] = f1;
-      WgJob f0 = make_job(w.lin[LIN_FU0], E, seg(w.GdF1, nullptr, D::MH, 0, D::MH));
-      add_act(f0, seg(xl, dst, D::DX, 0, D::DX));
-      add_act(f0, seg(w.e[l + 1], nullptr, D::DE, 0, D::DE));
-      add_act(f0, seg(x0, dst, D::DX, 0, D::DX));
-      we.jobs[we.njobs++] = f0;
-    }
-    WgJob u2 = make_job(w.lin[LIN_EU2], E, seg(w.Gde, nullptr, D::DE, 0, D::DE));
-    add_act(u2, seg(w.sH2[l], nullptr, D::EH2, 0, D::EH2));
-    we.jobs[we.njobs++] = u2;
-    WgJob u1 = make_job(w.lin[LIN_EU1], E, seg(w.GdH2, nullptr, D::EH2, 0, D::EH2));
-    add_act(u1, seg(w.sH1[l], nullptr, D::EH1, 0, D::EH1));
-    we.jobs[we.njobs++] = u1;
-    WgJob u0 = make_job(w.lin[LIN_EU0], E, seg(w.GdH1, nullptr, D::EH1, 0, D::EH1));
-    add_act(u0, seg(xl, dst, D::DX, 0, D::DX));
-    add_act(u0, seg(xl, src, D::DX, 0, D::DX));
-    add_act(u0, seg(w.e[l], nullptr, D::DE, 0, D::DE));
-    we.jobs[we.njobs++] = u0;
-    B3D_TRY((launch_wgrad<6, 1>(we, stream, msgs ? B3D_K_WGRAD_EDGE : B3D_K_WGRAD_OTHER)));
   }
 
   // ---- encoders ---------------------------------------------------------------------------------
@@ -425,18 +448,15 @@ extern "C" int b3d_pose_backward(const b3d_pose_weights* pw, const b3d_graph* g,
     a.gsave[0] = w.gn2; a.gsave[1] = w.gn1;
     a.wpack = w.wp_neT;
     B3D_TRY(launch_rows<kNWNode>(chain_bwd_kernel<SeqNodeEncT, In, StoreNone, kNWNode>, "node_encoder_bwd", a, N, stream));
-    WgArgs wa;
-    wa.njobs = 0;
     WgJob n2 = make_job(w.lin[LIN_NE2], N, seg(w.gn_top, nullptr, 48, 0, 48));
     add_act(n2, seg(w.ne_a2, nullptr, 48, 0, 36));
-    wa.jobs[wa.njobs++] = n2;
+    small.jobs[small.njobs++] = n2;
     WgJob n1 = make_job(w.lin[LIN_NE1], N, seg(w.gn2, nullptr, 48, 0, 36));
     add_act(n1, seg(w.ne_a1, nullptr, 32, 0, 24));
-    wa.jobs[wa.njobs++] = n1;
+    small.jobs[small.njobs++] = n1;
     WgJob n0 = make_job(w.lin[LIN_NE0], N, seg(w.gn1, nullptr, 32, 0, 24));
     add_act(n0, seg(w.pose_pad, nullptr, 32, 0, 19));
-    wa.jobs[wa.njobs++] = n0;
-    B3D_TRY((launch_wgrad<6, 1>(wa, stream)));
+    small.jobs[small.njobs++] = n0;
   }
   {  // edge encoder: G_3 = d e[0]
     ChainBwdArgs<LoadAligned<2>, StoreNone> a;
@@ -447,18 +467,72 @@ extern "C" int b3d_pose_backward(const b3d_pose_weights* pw, const b3d_graph* g,
     a.gsave[0] = w.ge2; a.gsave[1] = w.ge1;
     a.wpack = w.wp_eeT;
     B3D_TRY(launch_rows<kNWEdge>(chain_bwd_kernel<SeqEdgeEncT, LoadAligned<2>, StoreNone, kNWEdge>, "edge_encoder_bwd", a, E, stream));
-    WgArgs wa;
-    wa.njobs = 0;
     WgJob e2 = make_job(w.lin[LIN_EE2], E, seg(w.de[cur], nullptr, D::DE, 0, 32));
     add_act(e2, seg(w.ee_a2, nullptr, 16, 0, 16));
-    wa.jobs[wa.njobs++] = e2;
+    small.jobs[small.njobs++] = e2;
     WgJob e1 = make_job(w.lin[LIN_EE1], E, seg(w.ge2, nullptr, 16, 0, 16));
     add_act(e1, seg(w.ee_a1, nullptr, 16, 0, 8));
-    wa.jobs[wa.njobs++] = e1;
+    small.jobs[small.njobs++] = e1;
     WgJob e0 = make_job(w.lin[LIN_EE0], E, seg(w.ge1, nullptr, 16, 0, 8));
     add_act(e0, seg(w.ea_pad, nullptr, 16, 0, 4));
-    wa.jobs[wa.njobs++] = e0;
-    B3D_TRY((launch_wgrad<6, 1>(wa, stream)));
+    small.jobs[small.njobs++] = e0;
+  }
+  B3D_TRY((launch_wgrad<6, 1>(small, stream, B3D_K_WGRAD_OTHER)));
+
+  // ---- message-passing weight gradients: all layers, one streaming launch ---------------------
+  {
+    WsArgs wa;
+    memset(&wa, 0, sizeof(wa));
+    hipLaunchKernelGGL(iota_kernel, dim3(((E > N ? E : N) + 255) / 256), dim3(256), 0, stream, w.iota, E > N ? E : N);
+    B3D_TRY(launch_check("iota_kernel"));
+    B3D_HIP_CHECK(hipMemsetAsync(w.zrow, 0, 256 * sizeof(float), stream));
+    wa.zero_row = w.zrow;
+    const int* iota = w.iota;
+    auto sg = [iota](const float* p, const int* idx, long vstride, int stride, int col0) {
+      WsSeg s; s.ptr = p; s.idx = idx ? idx : iota; s.vstride = vstride; s.stride = stride; s.col0 = col0; return s;
+    };
+    const WsSeg none = sg(nullptr, nullptr, 0, 0, 0);
+    auto add = [&](int wj, const WsSeg& gseg, const WsSeg& a0, int c0, const WsSeg& a1, int c1, bool bias) {
+      if (w.plan.nvar[wj] <= 0) return;
+      const int lin = w.plan.lin[wj];
+      WsJob& jb = wa.jobs[wa.njobs++];
+      jb.g = gseg; jb.act[0] = a0; jb.act[1] = a1; jb.wcol[0] = c0; jb.wcol[1] = c1; jb.write_bias = bias ? 1 : 0;
+      jb.shape = w.plan.shape[wj]; jb.rows = w.plan.rows[wj]; jb.nvar = w.plan.nvar[wj];
+      jb.rows_per_task = w.plan.rows_per_task[wj]; jb.ntasks = w.plan.ntasks[wj];
+      jb.NP = w.lin[lin].NP; jb.KP = w.lin[lin].KP; jb.slab = w.lin[lin].slab;
+      jb.task_begin = wa.total_tasks;
+      wa.total_tasks += jb.ntasks;
+      w.lin[lin].used = true;
+    };
+    const float* x0 = w.x[0];
+    const WsSeg xd = sg(w.x[0], dst, nLx, D::DX, 0), xs = sg(w.x[0], src, nLx, D::DX, 0);
+    const WsSeg x0d = sg(x0, dst, 0, D::DX, 0), x0s = sg(x0, src, 0, D::DX, 0);
+    const WsSeg e_l = sg(w.e[0], nullptr, eLe, D::DE, 0), e_l1 = sg(w.e[1], nullptr, eLe, D::DE, 0);
+    // edge_update (every layer): dW columns [x[dst] 0:48 | x[src] 48:96 | e 96:128]
+    const WsSeg gH1 = sg(w.GdH1, nullptr, eL1, D::EH1, 0);
+    add(WJ_EU0A, gH1, xd, 0, e_l, 2 * D::DX, true);
+    add(WJ_EU0B, gH1, xs, D::DX, none, 0, false);
+    add(WJ_EU1, sg(w.GdH2, nullptr, eL2, D::EH2, 0), sg(w.sH1[0], nullptr, eL1, D::EH1, 0), 0, none, 0, true);
+    add(WJ_EU2, sg(w.Gde, nullptr, eLe, D::DE, 0), sg(w.sH2[0], nullptr, eL2, D::EH2, 0), 0, none, 0, true);
+    // message stacks (layers 0 .. depth-2): columns [x[.] 0:48 | e' 48:80 | x0[.] 80:128]
+    const WsSeg gP1 = sg(w.GdP1, nullptr, eLm, D::MH, 0), gF1 = sg(w.GdF1, nullptr, eLm, D::MH, 0);
+    add(WJ_PA0A, gP1, xs, 0, e_l1, D::DX, true);
+    add(WJ_PA0B, gP1, x0s, D::DX + D::DE, none, 0, false);
+    add(WJ_PA1, sg(w.dM, dst, nLm, D::NIN, 0), sg(w.sP1[0], nullptr, eLm, D::MH, 0), 0, none, 0, true);
+    add(WJ_FU0A, gF1, xd, 0, e_l1, D::DX, true);
+    add(WJ_FU0B, gF1, x0d, D::DX + D::DE, none, 0, false);
+    add(WJ_FU1, sg(w.dM, src, nLm, D::NIN, D::DM), sg(w.sF1[0], nullptr, eLm, D::MH, 0), 0, none, 0, true);
+    // node update (layers 0 .. depth-2)
+    const WsSeg gN1 = sg(w.GnH1, nullptr, nL1, D::NH1, 0);
+    add(WJ_CF0A, gN1, sg(w.M[0], nullptr, nLm, D::NIN, 0), 0, none, 0, true);
+    add(WJ_CF0B, gN1, sg(w.M[0], nullptr, nLm, D::NIN, D::DM), D::DM, none, 0, false);
+    add(WJ_CF1, sg(w.GnH2, nullptr, nL2, D::NH2, 0), sg(w.nH1[0], nullptr, nL1, D::NH1, 0), 0, none, 0, true);
+    add(WJ_CF2, sg(w.Gdx, nullptr, nLx, D::DX, 0), sg(w.nH2[0], nullptr, nL2, D::NH2, 0), 0, none, 0, true);
+    if (wa.njobs > 0) {
+      ProfScope ps(B3D_K_WGRAD_EDGE, stream);
+      hipLaunchKernelGGL(wstream_kernel, dim3((wa.total_tasks + kWsWaves - 1) / kWsWaves), dim3(kWsWaves * 64), 0, stream, wa);
+      B3D_TRY(launch_check("wstream_kernel"));
+    }
   }
 
   // ---- slabs -> parameter gradients -------------------------------------------------------------

@@ -15,7 +15,7 @@
 namespace b3d {
 
 constexpr int kWgRT = 32;          // rows per LDS tile
-constexpr int kWgMaxJobs = 8;
+constexpr int kWgMaxJobs = 12;
 constexpr int kWgMaxSegs = 4;
 
 struct WgSeg {

@@ -1,0 +1,266 @@
+// Streaming weight gradient (the large, 16-aligned Linear layers of the message-passing stacks).
+//
+//   dW[n][k] = sum over layers v, rows r of  G_v[r][n] * Act_v[r][k]        db[n] = sum G_v[r][n]
+//
+// The GNN applies ONE set of message-passing weights in all of its layers, so the contraction runs
+// over (layer, edge): a single launch after the backward sweep handles every layer.
+//
+// One wavefront owns a whole weight matrix for a range of rows ("task").  Per step it takes 4 rows:
+// lane (m, q) loads row r+q -- 16 bytes at a time, feature order permuted so that the 16 lanes of a
+// quarter cover 64 consecutive features with one dwordx4 each -- straight into the registers that
+// v_mfma_f32_16x16x4_f32 consumes as A (gradient features) and B (activation features); the rows are
+// the MFMA K index.  Every byte of G and Act is read exactly once, by exactly one wavefront, in full
+// 256-byte segments; there is no LDS staging, no barrier and no float atomic.  All (NP/16)x(KP/16)
+// accumulator blocks stay in registers for the whole task; the partial goes to a per-task slab with
+// plain stores and a later fixed-order sum makes the result bitwise reproducible.
+//
+// Gathered operands (x[dst], x[src], dM[dst] ...) take their row through an index that is fetched two
+// steps ahead of the row itself, which is fetched two steps ahead of its use.
+#pragma once
+#include "b3d_dev.hpp"
+
+namespace b3d {
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+constexpr int kWsMaxJobs = 16;
+constexpr int kWsWaves = 4;            // tasks per workgroup
+
+struct WsSeg {
+  const float* ptr;      // [*, stride] of layer variant 0
+  const int* idx;        // row gather (never null: identity segments use an iota array)
+  long vstride;          // floats between consecutive layer variants
+  int stride;            // floats per row
+  int col0;
+};
+
+struct WsJob {
+  WsSeg g;               // gradient rows, width GW
+  WsSeg act[2];          // activation segments, widths S0, S1
+  int wcol[2];           // column of dW where each segment's features start
+  int write_bias;        // exactly one of the jobs that share a slab writes the bias gradient
+  int shape;             // index into the compiled shape list
+  int rows;
+  int nvar;              // layer variants accumulated into the same partial
+  int rows_per_task;     // multiple of 4
+  int ntasks;
+  int NP, KP;
+  float* slab;           // [ntasks][NP*KP + NP]
+  int task_begin;        // first task (wavefront) of this job in the launch
+};
+
+struct WsArgs {
+  int njobs;
+  int total_tasks;
+  const float* zero_row;   // >= 128 zero floats
+  WsJob jobs[kWsMaxJobs];
+};
+
+// Feature <-> (virtual 16-block, lane) map of a W-wide segment loaded with 16/8/4-byte pieces:
+// groups of 64 features (dwordx4: lane j holds 4j..4j+3), then 32 (dwordx2), then 16 (dword).
+template <int W>
+struct SegMap {
+  static constexpr int n4 = W / 64, n2 = (W % 64) / 32, n1 = (W % 32) / 16;
+  static constexpr int NB = W / 16;
+  static_assert(W % 16 == 0, "segment width must be a multiple of 16");
+  __device__ static constexpr int feat(int vb, int j) {
+    if (vb < 4 * n4) return 64 * (vb / 4) + 4 * j + (vb % 4);
+    vb -= 4 * n4;
+    if (vb < 2 * n2) return 64 * n4 + 2 * j + vb;
+    return 64 * n4 + 32 * n2 + j;
+  }
+};
+
+// Plain loads only: nothing at load time may depend on the loaded VALUES (rows that must not
+// contribute are redirected by the caller to an all-zero gradient row).
+template <int W>
+__device__ __forceinline__ void seg_load(const float* __restrict__ p, int m, float* __restrict__ out) {
+  using M = SegMap<W>;
+#pragma unroll
+  for (int g = 0; g < M::n4; ++g) {
+    const v4f t = *reinterpret_cast<const v4f*>(p + 64 * g + 4 * m);
+    out[4 * g + 0] = t.x; out[4 * g + 1] = t.y; out[4 * g + 2] = t.z; out[4 * g + 3] = t.w;
+  }
+  if constexpr (M::n2 > 0) {
+    const v2f t = *reinterpret_cast<const v2f*>(p + 64 * M::n4 + 2 * m);
+    out[4 * M::n4 + 0] = t.x; out[4 * M::n4 + 1] = t.y;
+  }
+  if constexpr (M::n1 > 0) {
+    out[4 * M::n4 + 2 * M::n2] = p[64 * M::n4 + 32 * M::n2 + m];
+  }
+}
+template <int GW, int S0, int S1>
+struct WsShape {
+  static constexpr int MB = GW / 16, K = S0 + S1, NB = K / 16;
+  static constexpr int B0 = S0 / 16, B1 = S1 / 16;
+};
+
+template <class SH>
+struct WsStage {
+  float a[SH::MB];
+  float b[SH::NB];
+};
+
+// A wavefront never holds more than 30 accumulator blocks (120 VGPRs): wide matrices are split
+// into column groups handled by different jobs that share one slab.
+template <int GW, int S0, int S1>
+__device__ __forceinline__ void ws_task(const WsJob& job, int chunk, const float* __restrict__ zero_row) {
+  using SH = WsShape<GW, S0, S1>;
+  constexpr int MB = SH::MB, NB = SH::NB;
+  static_assert(MB * NB <= 30, "too many accumulator blocks for one wavefront");
+  const int lane = threadIdx.x & 63, m = lane & 15, q = lane >> 4;
+  v4f acc[MB][NB];
+#pragma unroll
+  for (int a = 0; a < MB; ++a)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[a][b] = v4f{0.f, 0.f, 0.f, 0.f};
+  float bsum[MB];
+#pragma unroll
+  for (int a = 0; a < MB; ++a) bsum[a] = 0.f;
+
+  const int r0 = chunk * job.rows_per_task;
+  int r1 = r0 + job.rows_per_task;
+  if (r1 > job.rows) r1 = job.rows;
+  const int nsteps = (r1 > r0) ? (r1 - r0 + 3) / 4 : 0;
+  const int gstride = job.g.stride, s0stride = job.act[0].stride, s1stride = (S1 > 0) ? job.act[1].stride : 0;
+  // every segment carries an index array (identity segments point at an iota array), so the loop
+  // body is straight-line code: loads, selects, MFMAs.
+  const int* ig = job.g.idx;
+  const int* i0 = job.act[0].idx;
+  const int* i1 = (S1 > 0) ? job.act[1].idx : i0;
+
+  for (int v = 0; v < job.nvar; ++v) {
+    const float* gp = job.g.ptr + v * job.g.vstride + job.g.col0;
+    const float* p0 = job.act[0].ptr + v * job.act[0].vstride + job.act[0].col0;
+    const float* p1 = (S1 > 0) ? job.act[1].ptr + v * job.act[1].vstride + job.act[1].col0 : p0;
+
+    struct Rows { int g, a0, a1; bool ok; };
+    auto rows_of = [&](int step) {
+      Rows r;
+      const int row = r0 + 4 * step + q;
+      r.ok = (step < nsteps) && (row < r1);
+      const int rr = r.ok ? row : r0;
+      r.g = ig[rr];
+      r.a0 = i0[rr];
+      r.a1 = (S1 > 0) ? i1[rr] : 0;
+      return r;
+    };
+    auto fetch = [&](const Rows& r, WsStage<SH>& st) {
+      const float* pg = r.ok ? gp + (long)r.g * gstride : zero_row;   // zero gradient row: no contribution
+      seg_load<GW>(pg, m, st.a);
+      seg_load<S0>(p0 + (long)r.a0 * s0stride, m, st.b);
+      if constexpr (S1 > 0) seg_load<S1>(p1 + (long)r.a1 * s1stride, m, st.b + SH::B0);
+    };
+    auto compute = [&](const WsStage<SH>& st) {
+#pragma unroll
+      for (int a = 0; a < MB; ++a) bsum[a] += st.a[a];
+#pragma unroll
+      for (int a = 0; a < MB; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(st.a[a], st.b[b], acc[a][b], 0, 0, 0);
+    };
+
+    // Blocks of BS steps (4 BS rows), two register sets.  While block k is multiplied, the rows of
+    // block k+1 are in flight (issued right after the first step of block k) and the gather indices
+    // of block k+2 are being fetched: the only wait on the critical path is the one in front of a
+    // block's first step, BS-1 steps of MFMAs after its loads were issued.
+    constexpr int BS = 4;
+    WsStage<SH> SA[BS], SB[BS];
+    Rows RA[BS], RB[BS];
+    const int nblk = (nsteps + BS - 1) / BS;
+#pragma unroll
+    for (int i = 0; i < BS; ++i) RA[i] = rows_of(i);
+#pragma unroll
+    for (int i = 0; i < BS; ++i) RB[i] = rows_of(BS + i);
+#pragma unroll
+    for (int i = 0; i < BS; ++i) fetch(RA[i], SA[i]);
+#pragma unroll
+    for (int i = 0; i < BS; ++i) RA[i] = rows_of(2 * BS + i);
+    for (int k = 0; k < nblk; k += 2) {
+      compute(SA[0]);                                   // block k
+#pragma unroll
+      for (int i = 0; i < BS; ++i) fetch(RB[i], SB[i]); // block k+1
+#pragma unroll
+      for (int i = 0; i < BS; ++i) RB[i] = rows_of((k + 3) * BS + i);
+#pragma unroll
+      for (int i = 1; i < BS; ++i) compute(SA[i]);
+      compute(SB[0]);                                   // block k+1 (zero rows beyond the range)
+#pragma unroll
+      for (int i = 0; i < BS; ++i) fetch(RA[i], SA[i]); // block k+2
+#pragma unroll
+      for (int i = 0; i < BS; ++i) RA[i] = rows_of((k + 4) * BS + i);
+#pragma unroll
+      for (int i = 1; i < BS; ++i) compute(SB[i]);
+    }
+  }
+
+  // ---- partial -> slab (row-major [NP][KP], then bias) ---------------------------------------
+  float* slab = job.slab + (size_t)chunk * ((size_t)job.NP * job.KP + job.NP);
+#pragma unroll
+  for (int a = 0; a < MB; ++a) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const float* vv = reinterpret_cast<const float*>(&acc[a][b]);
+      const int colf = (b < SH::B0) ? job.wcol[0] + SegMap<S0>::feat(b, m)
+                                    : job.wcol[1] + SegMap<(S1 > 0 ? S1 : 16)>::feat(b - SH::B0, m);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int rowf = SegMap<GW>::feat(a, 4 * q + j);
+        slab[(size_t)rowf * job.KP + colf] = vv[j];
+      }
+    }
+  }
+  if (job.write_bias) {
+#pragma unroll
+    for (int a = 0; a < MB; ++a) {
+      float sum = bsum[a];
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      if (q == 0) slab[(size_t)job.NP * job.KP + SegMap<GW>::feat(a, m)] = sum;
+    }
+  }
+}
+
+// compiled shapes (GW; S0, S1)
+enum {
+  WS_96_48_32 = 0,      // 96-row stacks, columns of x[.] and e / e'
+  WS_96_48 = 1,         // 96-row stacks, columns of x[src] / x0[.]
+  WS_64_96 = 2,         // edge_update.2, create_*_msgs.2, combine.2
+  WS_32_64 = 3,         // edge_update.4
+  WS_48_64 = 4,         // combine_future_past.4
+  WS_96_64 = 5,         // combine_future_past.0 (two column halves)
+  WS_SHAPES = 6
+};
+
+__global__ __launch_bounds__(kWsWaves * 64, 1) void wstream_kernel(const WsArgs args) {
+  __shared__ WsJob sjobs[kWsMaxJobs];
+  for (int i = threadIdx.x; i < (int)(args.njobs * sizeof(WsJob) / 4); i += blockDim.x)
+    reinterpret_cast<int*>(sjobs)[i] = reinterpret_cast<const int*>(args.jobs)[i];
+  __syncthreads();
+  const int task = blockIdx.x * kWsWaves + (threadIdx.x >> 6);
+  if (task >= args.total_tasks) return;
+  int j = 0;
+#pragma unroll
+  for (int t = 1; t < kWsMaxJobs; ++t)
+    if (t < args.njobs && task >= sjobs[t].task_begin) j = t;
+  const WsJob& job = sjobs[j];
+  const int chunk = task - job.task_begin;
+  switch (job.shape) {
+    case WS_96_48_32: ws_task<96, 48, 32>(job, chunk, args.zero_row); break;
+    case WS_96_48: ws_task<96, 48, 0>(job, chunk, args.zero_row); break;
+    case WS_64_96: ws_task<64, 96, 0>(job, chunk, args.zero_row); break;
+    case WS_32_64: ws_task<32, 64, 0>(job, chunk, args.zero_row); break;
+    case WS_48_64: ws_task<48, 64, 0>(job, chunk, args.zero_row); break;
+    case WS_96_64: ws_task<96, 64, 0>(job, chunk, args.zero_row); break;
+    default: break;
+  }
+}
+
+// blocks (MFMAs per 4-row step) of a shape: the unit of work used to balance tasks
+inline int ws_shape_blocks(int shape) {
+  static const int b[WS_SHAPES] = {6 * 5, 6 * 3, 4 * 6, 2 * 4, 3 * 4, 6 * 4};
+  return b[shape];
+}
+
+}  // namespace b3d
