@@ -154,7 +154,7 @@ __device__ __forceinline__ void chain_fwd_rec(WS& ws, bool more, const Args& a, 
 }
 
 template <class Seq, unsigned RELU_MASK, class In, class Out, int NW>
-__global__ __launch_bounds__(NW * 64, NW >= 4 ? 2 : 1) void chain_fwd_kernel(const ChainFwdArgs<In, Out> a) {
+__global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void chain_fwd_kernel(const ChainFwdArgs<In, Out> a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   static_assert(In::NB == Seq::kp(0) / 16, "loader width != first layer input width");
   WStreamT<NW * 64> ws;
@@ -210,7 +210,7 @@ __device__ __forceinline__ void chain_bwd_rec(WS& ws, bool more, const Args& a, 
 }
 
 template <class SeqT, class In, class Out, int NW>
-__global__ __launch_bounds__(NW * 64, NW >= 4 ? 2 : 1) void chain_bwd_kernel(const ChainBwdArgs<In, Out> a) {
+__global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void chain_bwd_kernel(const ChainBwdArgs<In, Out> a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   static_assert(In::NB == SeqT::kp(0) / 16, "loader width != top gradient width");
   WStreamT<NW * 64> ws;

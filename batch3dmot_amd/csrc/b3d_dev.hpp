@@ -236,6 +236,11 @@ __device__ __forceinline__ void linear_chunk(WS& ws, bool more, const v4f* __res
         const v4f a1 = *reinterpret_cast<const v4f*>(wr1 + 16 * kb);
         acc1 = mfma4(a1, in[kb], acc1);
       }
+      // wide layers: stop the scheduler from hoisting every weight fragment of the K loop to its
+      // top (that costs 8 VGPRs per step and spills at K >= 192)
+      if constexpr (KB > 8) {
+        if ((kb & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      }
     }
     out[mb] = RELU ? relu4(acc0) : acc0;
     if (two) out[mb + 1] = RELU ? relu4(acc1) : acc1;

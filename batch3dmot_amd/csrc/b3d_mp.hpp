@@ -120,7 +120,7 @@ struct EdgeBwdArgs {
 
 // ------------------------------------------------------------------------------------------
 template <class D, int NW>
-__global__ __launch_bounds__(NW * 64, NW >= 4 ? 2 : 1) void mp_edge_fwd_kernel(const EdgeFwdArgs a) {
+__global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void mp_edge_fwd_kernel(const EdgeFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   using Seq = typename D::EdgeFwdSeq;
   constexpr int XB = D::DX / 16, EB = D::DE / 16, AB = D::DA / 16;
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(NW * 64, NW >= 4 ? 2 : 1) void mp_edge_fwd_kernel(c
 
 // ------------------------------------------------------------------------------------------
 template <class D, int NW>
-__global__ __launch_bounds__(NW * 64, NW >= 4 ? 2 : 1) void mp_node_fwd_kernel(const NodeFwdArgs a) {
+__global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void mp_node_fwd_kernel(const NodeFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   using Seq = typename D::NodeFwdSeq;
   constexpr int XB = D::DX / 16, DMB = D::DM / 16, H1B = D::NH1 / 16, H2B = D::NH2 / 16;
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(NW * 64, NW >= 4 ? 2 : 1) void mp_node_fwd_kernel(c
 
 // ------------------------------------------------------------------------------------------
 template <class D, int NW>
-__global__ __launch_bounds__(NW * 64, NW >= 4 ? 2 : 1) void mp_node_bwd_kernel(const NodeBwdArgs a) {
+__global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void mp_node_bwd_kernel(const NodeBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   using Seq = typename D::NodeBwdSeq;
   constexpr int XB = D::DX / 16, DMB = D::DM / 16, H1B = D::NH1 / 16, H2B = D::NH2 / 16;
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(NW * 64, NW >= 4 ? 2 : 1) void mp_node_bwd_kernel(c
 // MSGS == false: the last layer, whose node update (and therefore both message stacks) receives
 // no gradient because the final x is not an output (pose_gnn.py:86, clr_att_gnn.py:188).
 template <class D, bool MSGS, int NW>
-__global__ __launch_bounds__(NW * 64, NW >= 4 ? 2 : 1) void mp_edge_bwd_kernel(const EdgeBwdArgs a) {
+__global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void mp_edge_bwd_kernel(const EdgeBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   using Seq = typename std::conditional<MSGS, typename D::EdgeBwdSeq, typename D::EdgeBwdSeqNoMsg>::type;
   constexpr int L0 = MSGS ? 4 : 0;             // index of edge_update.4^T in Seq
