@@ -229,4 +229,49 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void chain_bwd_kernel(con
   }
 }
 
+// ---- one WIDE Linear layer (input up to 640 features in registers, output streamed to memory) ------
+// Used for att_edge_encoder (640-512-384-256-128-64, clr_att_gnn.py:81-91): input + output of such a
+// layer do not fit the register file together, so every finished 16-feature output block goes
+// straight to HBM.  mask != nullptr: multiply by (mask > 0) -- the ReLU derivative in backward.
+template <class In>
+struct WideArgs {
+  int rows;
+  In in;
+  float* out;            // [rows, out_stride]
+  int out_stride;
+  int out_col0;
+  const float* mask;     // same geometry as out, or nullptr
+  const float* wpack;
+};
+
+template <class Seq, bool RELU, bool BIAS, class In, int NW>
+__global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void wide_linear_kernel(const WideArgs<In> a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  static_assert(Seq::NL == 1 && In::NB == Seq::kp(0) / 16, "one layer; loader width = input width");
+  WStreamT<NW * 64> ws;
+  ws.init(a.wpack, smem);
+  ws.template start<Seq>();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane >> 4;
+  const int ntiles = (a.rows + NW * 16 - 1) / (NW * 16);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const bool more = tile + (int)gridDim.x < ntiles;
+    const long row = (long)tile * (NW * 16) + wave * kRowsPerWave + (lane & 15);
+    const bool valid = row < a.rows;
+    v4f in[In::NB];
+    a.in(row, valid, in);
+    float* orow = a.out + row * (long)a.out_stride + a.out_col0 + 4 * q;
+    const float* mrow = a.mask ? a.mask + row * (long)a.out_stride + a.out_col0 + 4 * q : nullptr;
+    linear_emit<Seq, 0, RELU, BIAS>(ws, more, in, [=](int mb, v4f v) {
+      if (valid) {
+        if (mrow) {
+          const v4f mk = *reinterpret_cast<const v4f*>(mrow + 16 * mb);
+          v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
+          v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+        }
+        *reinterpret_cast<v4f*>(orow + 16 * mb) = v;
+      }
+    });
+  }
+}
+
 }  // namespace b3d

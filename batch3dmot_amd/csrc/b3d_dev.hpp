@@ -198,10 +198,11 @@ __device__ __forceinline__ v4f relu4(v4f a) {
   return r;
 }
 
-// out = act(W . in + b) for layer LI of Seq.  in: KB feature blocks (layout L), out: NB blocks.
-template <class Seq, int LI, bool RELU, bool BIAS, int CH, class WS>
-__device__ __forceinline__ void linear_chunk(WS& ws, bool more, const v4f* __restrict__ in,
-                                             v4f* __restrict__ out) {
+// act(W . in + b) for layer LI of Seq.  in: KB feature blocks (layout L); every finished output
+// block is handed to emit(mb, value) -- either kept in registers (linear) or streamed to memory
+// (linear_emit, for layers whose input + output do not fit the register file together).
+template <class Seq, int LI, bool RELU, bool BIAS, int CH, class WS, class Emit>
+__device__ __forceinline__ void linear_chunk(WS& ws, bool more, const v4f* __restrict__ in, Emit& emit) {
   constexpr int KP = Seq::kp(LI), NP = Seq::np(LI);
   constexpr int KB = KP / 16, NB = NP / 16;
   constexpr int STRIDE = KP + 4;
@@ -236,28 +237,27 @@ __device__ __forceinline__ void linear_chunk(WS& ws, bool more, const v4f* __res
         const v4f a1 = *reinterpret_cast<const v4f*>(wr1 + 16 * kb);
         acc1 = mfma4(a1, in[kb], acc1);
       }
-      // wide layers: stop the scheduler from hoisting every weight fragment of the K loop to its
-      // top (that costs 8 VGPRs per step and spills at K >= 192)
-      if constexpr (KB > 8) {
-        if ((kb & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-      }
     }
-    out[mb] = RELU ? relu4(acc0) : acc0;
-    if (two) out[mb + 1] = RELU ? relu4(acc1) : acc1;
+    emit(mb, RELU ? relu4(acc0) : acc0);
+    if (two) emit(mb + 1, RELU ? relu4(acc1) : acc1);
   }
 }
 
-template <class Seq, int LI, bool RELU, bool BIAS, class WS, int... CH>
-__device__ __forceinline__ void linear_impl(WS& ws, bool more, const v4f* __restrict__ in,
-                                            v4f* __restrict__ out, std::integer_sequence<int, CH...>) {
-  (linear_chunk<Seq, LI, RELU, BIAS, CH, WS>(ws, more, in, out), ...);
+template <class Seq, int LI, bool RELU, bool BIAS, class WS, class Emit, int... CH>
+__device__ __forceinline__ void linear_impl(WS& ws, bool more, const v4f* __restrict__ in, Emit& emit,
+                                            std::integer_sequence<int, CH...>) {
+  (linear_chunk<Seq, LI, RELU, BIAS, CH, WS, Emit>(ws, more, in, emit), ...);
+}
+
+template <class Seq, int LI, bool RELU, bool BIAS = true, class WS, class Emit>
+__device__ __forceinline__ void linear_emit(WS& ws, bool more, const v4f* __restrict__ in, Emit emit) {
+  linear_impl<Seq, LI, RELU, BIAS, WS, Emit>(ws, more, in, emit,
+                                             std::make_integer_sequence<int, n_chunks(Seq::kp(LI), Seq::np(LI))>{});
 }
 
 template <class Seq, int LI, bool RELU, bool BIAS = true, class WS>
-__device__ __forceinline__ void linear(WS& ws, bool more, const v4f* __restrict__ in,
-                                       v4f* __restrict__ out) {
-  linear_impl<Seq, LI, RELU, BIAS, WS>(ws, more, in, out,
-                                   std::make_integer_sequence<int, n_chunks(Seq::kp(LI), Seq::np(LI))>{});
+__device__ __forceinline__ void linear(WS& ws, bool more, const v4f* __restrict__ in, v4f* __restrict__ out) {
+  linear_emit<Seq, LI, RELU, BIAS>(ws, more, in, [out](int mb, v4f v) { out[mb] = v; });
 }
 
 // ---- row <-> register helpers (layout L) -----------------------------------------------------

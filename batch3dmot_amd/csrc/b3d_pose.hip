@@ -87,6 +87,8 @@ struct PoseWs {
   float *dM, *GdH1, *GdH2, *Gde, *GdF1, *GdP1, *Gdx, *GnH2, *GnH1;
   WsPlan plan;
   float* zrow;          // 256 zero floats
+  WsJob* ws_table;      // device job table of the streaming weight gradient
+  int* ws_task_job;
   int* iota;            // 0, 1, 2, ... (identity gather for the streaming weight gradient)
   float *gc3, *gc2, *gc1, *ge2, *ge1, *gn_top, *gn2, *gn1;
   LinSlab lin[LIN_COUNT];
@@ -179,6 +181,8 @@ static void carve(PoseWs& w, void* ws, size_t ws_bytes, int N, int E, int depth,
     w.gn1 = c.take<float>(n_ * 32);
     w.iota = c.take<int>((size_t)(E > N ? E : N) + 64);
     w.zrow = c.take<float>(256);
+    w.ws_table = c.take<WsJob>(32);
+    w.ws_task_job = c.take<int>(8192);
     // weight-gradient slabs; chunk / task counts are a pure function of (N, E, depth)
     w.plan = ws_plan(N, E, depth);
     for (int i = 0; i < LIN_COUNT; ++i) {
@@ -481,12 +485,11 @@ extern "C" int b3d_pose_backward(const b3d_pose_weights* pw, const b3d_graph* g,
 
   // ---- message-passing weight gradients: all layers, one streaming launch ---------------------
   {
-    WsArgs wa;
-    memset(&wa, 0, sizeof(wa));
+    WsLauncher wl;
+    wl.begin(w.ws_table, 32, w.ws_task_job, 8192, stream);
     hipLaunchKernelGGL(iota_kernel, dim3(((E > N ? E : N) + 255) / 256), dim3(256), 0, stream, w.iota, E > N ? E : N);
     B3D_TRY(launch_check("iota_kernel"));
     B3D_HIP_CHECK(hipMemsetAsync(w.zrow, 0, 256 * sizeof(float), stream));
-    wa.zero_row = w.zrow;
     const int* iota = w.iota;
     auto sg = [iota](const float* p, const int* idx, long vstride, int stride, int col0) {
       WsSeg s; s.ptr = p; s.idx = idx ? idx : iota; s.vstride = vstride; s.stride = stride; s.col0 = col0; return s;
@@ -495,13 +498,14 @@ extern "C" int b3d_pose_backward(const b3d_pose_weights* pw, const b3d_graph* g,
     auto add = [&](int wj, const WsSeg& gseg, const WsSeg& a0, int c0, const WsSeg& a1, int c1, bool bias) {
       if (w.plan.nvar[wj] <= 0) return;
       const int lin = w.plan.lin[wj];
-      WsJob& jb = wa.jobs[wa.njobs++];
+      WsJob jb;
+      memset(&jb, 0, sizeof(jb));
       jb.g = gseg; jb.act[0] = a0; jb.act[1] = a1; jb.wcol[0] = c0; jb.wcol[1] = c1; jb.write_bias = bias ? 1 : 0;
       jb.shape = w.plan.shape[wj]; jb.rows = w.plan.rows[wj]; jb.nvar = w.plan.nvar[wj];
       jb.rows_per_task = w.plan.rows_per_task[wj]; jb.ntasks = w.plan.ntasks[wj];
       jb.NP = w.lin[lin].NP; jb.KP = w.lin[lin].KP; jb.slab = w.lin[lin].slab;
-      jb.task_begin = wa.total_tasks;
-      wa.total_tasks += jb.ntasks;
+      jb.wrow = 0;
+      wl.add(jb);
       w.lin[lin].used = true;
     };
     const float* x0 = w.x[0];
@@ -528,11 +532,9 @@ extern "C" int b3d_pose_backward(const b3d_pose_weights* pw, const b3d_graph* g,
     add(WJ_CF0B, gN1, sg(w.M[0], nullptr, nLm, D::NIN, D::DM), D::DM, none, 0, false);
     add(WJ_CF1, sg(w.GnH2, nullptr, nL2, D::NH2, 0), sg(w.nH1[0], nullptr, nL1, D::NH1, 0), 0, none, 0, true);
     add(WJ_CF2, sg(w.Gdx, nullptr, nLx, D::DX, 0), sg(w.nH2[0], nullptr, nL2, D::NH2, 0), 0, none, 0, true);
-    if (wa.njobs > 0) {
-      ProfScope ps(B3D_K_WGRAD_EDGE, stream);
-      hipLaunchKernelGGL(wstream_kernel, dim3((wa.total_tasks + kWsWaves - 1) / kWsWaves), dim3(kWsWaves * 64), 0, stream, wa);
-      B3D_TRY(launch_check("wstream_kernel"));
-    }
+    wl.launch(w.zrow, B3D_K_WGRAD_EDGE);
+    B3D_REQUIRE(wl.status == 0, "streaming weight gradient: job table overflow");
+    B3D_TRY(launch_check("wstream_kernel"));
   }
 
   // ---- slabs -> parameter gradients -------------------------------------------------------------

@@ -17,6 +17,7 @@
 // Gathered operands (x[dst], x[src], dM[dst] ...) take their row through an index that is fetched two
 // steps ahead of the row itself, which is fetched two steps ahead of its use.
 #pragma once
+#include "b3d_common.hpp"
 #include "b3d_dev.hpp"
 
 namespace b3d {
@@ -38,6 +39,7 @@ struct WsJob {
   WsSeg g;               // gradient rows, width GW
   WsSeg act[2];          // activation segments, widths S0, S1
   int wcol[2];           // column of dW where each segment's features start
+  int wrow;              // row of dW where this job's gradient features start
   int write_bias;        // exactly one of the jobs that share a slab writes the bias gradient
   int shape;             // index into the compiled shape list
   int rows;
@@ -49,10 +51,13 @@ struct WsJob {
   int task_begin;        // first task (wavefront) of this job in the launch
 };
 
-struct WsArgs {
-  int njobs;
-  int total_tasks;
-  const float* zero_row;   // >= 128 zero floats
+// Jobs live in a device table (a backward pass of the camera+LiDAR+radar model has > 100 of them);
+// ws_table_kernel copies them there kWsMaxJobs at a time through its kernel arguments.
+struct WsTableArgs {
+  int n;
+  int first;             // index of jobs[0] in the device table
+  WsJob* table;
+  int* task_job;         // [total tasks] job index of every task
   WsJob jobs[kWsMaxJobs];
 };
 
@@ -206,7 +211,7 @@ __device__ __forceinline__ void ws_task(const WsJob& job, int chunk, const float
                                     : job.wcol[1] + SegMap<(S1 > 0 ? S1 : 16)>::feat(b - SH::B0, m);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int rowf = SegMap<GW>::feat(a, 4 * q + j);
+        const int rowf = job.wrow + SegMap<GW>::feat(a, 4 * q + j);
         slab[(size_t)rowf * job.KP + colf] = vv[j];
       }
     }
@@ -217,50 +222,103 @@ __device__ __forceinline__ void ws_task(const WsJob& job, int chunk, const float
       float sum = bsum[a];
       sum += __shfl_xor(sum, 16, 64);
       sum += __shfl_xor(sum, 32, 64);
-      if (q == 0) slab[(size_t)job.NP * job.KP + SegMap<GW>::feat(a, m)] = sum;
+      if (q == 0) slab[(size_t)job.NP * job.KP + job.wrow + SegMap<GW>::feat(a, m)] = sum;
     }
   }
 }
 
 // compiled shapes (GW; S0, S1)
 enum {
-  WS_96_48_32 = 0,      // 96-row stacks, columns of x[.] and e / e'
-  WS_96_48 = 1,         // 96-row stacks, columns of x[src] / x0[.]
-  WS_64_96 = 2,         // edge_update.2, create_*_msgs.2, combine.2
-  WS_32_64 = 3,         // edge_update.4
-  WS_48_64 = 4,         // combine_future_past.4
-  WS_96_64 = 5,         // combine_future_past.0 (two column halves)
-  WS_SHAPES = 6
+  WS_96_48_32 = 0,      // P: 96-row stacks, columns of x[.] and e / e'
+  WS_96_48 = 1,         // P: 96-row stacks, columns of x[src] / x0[.]
+  WS_64_96 = 2,
+  WS_32_64 = 3,
+  WS_48_64 = 4,
+  WS_96_64 = 5,
+  WS_64_64 = 6,
+  WS_SHAPES = 7
 };
 
-__global__ __launch_bounds__(kWsWaves * 64, 1) void wstream_kernel(const WsArgs args) {
-  __shared__ WsJob sjobs[kWsMaxJobs];
-  for (int i = threadIdx.x; i < (int)(args.njobs * sizeof(WsJob) / 4); i += blockDim.x)
-    reinterpret_cast<int*>(sjobs)[i] = reinterpret_cast<const int*>(args.jobs)[i];
-  __syncthreads();
-  const int task = blockIdx.x * kWsWaves + (threadIdx.x >> 6);
-  if (task >= args.total_tasks) return;
-  int j = 0;
-#pragma unroll
-  for (int t = 1; t < kWsMaxJobs; ++t)
-    if (t < args.njobs && task >= sjobs[t].task_begin) j = t;
-  const WsJob& job = sjobs[j];
+__global__ void ws_table_kernel(const WsTableArgs a) {
+  const int j = blockIdx.x;
+  if (j >= a.n) return;
+  const int* srcw = reinterpret_cast<const int*>(&a.jobs[j]);
+  int* dstw = reinterpret_cast<int*>(&a.table[a.first + j]);
+  for (int i = threadIdx.x; i < (int)(sizeof(WsJob) / 4); i += blockDim.x) dstw[i] = srcw[i];
+  for (int t = threadIdx.x; t < a.jobs[j].ntasks; t += blockDim.x) a.task_job[a.jobs[j].task_begin + t] = a.first + j;
+}
+
+__global__ __launch_bounds__(kWsWaves * 64, 1) void wstream_kernel(const WsJob* __restrict__ table,
+                                                                   const int* __restrict__ task_job, int total_tasks,
+                                                                   const float* __restrict__ zero_row) {
+  __shared__ WsJob sj[kWsWaves];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int task = blockIdx.x * kWsWaves + wave;
+  if (task >= total_tasks) return;
+  {
+    const int* srcw = reinterpret_cast<const int*>(&table[task_job[task]]);
+    int* dstw = reinterpret_cast<int*>(&sj[wave]);
+    for (int i = lane; i < (int)(sizeof(WsJob) / 4); i += 64) dstw[i] = srcw[i];
+  }
+  __builtin_amdgcn_wave_barrier();
+  const WsJob& job = sj[wave];
   const int chunk = task - job.task_begin;
   switch (job.shape) {
-    case WS_96_48_32: ws_task<96, 48, 32>(job, chunk, args.zero_row); break;
-    case WS_96_48: ws_task<96, 48, 0>(job, chunk, args.zero_row); break;
-    case WS_64_96: ws_task<64, 96, 0>(job, chunk, args.zero_row); break;
-    case WS_32_64: ws_task<32, 64, 0>(job, chunk, args.zero_row); break;
-    case WS_48_64: ws_task<48, 64, 0>(job, chunk, args.zero_row); break;
-    case WS_96_64: ws_task<96, 64, 0>(job, chunk, args.zero_row); break;
+    case WS_96_48_32: ws_task<96, 48, 32>(job, chunk, zero_row); break;
+    case WS_96_48: ws_task<96, 48, 0>(job, chunk, zero_row); break;
+    case WS_64_96: ws_task<64, 96, 0>(job, chunk, zero_row); break;
+    case WS_32_64: ws_task<32, 64, 0>(job, chunk, zero_row); break;
+    case WS_48_64: ws_task<48, 64, 0>(job, chunk, zero_row); break;
+    case WS_96_64: ws_task<96, 64, 0>(job, chunk, zero_row); break;
+    case WS_64_64: ws_task<64, 64, 0>(job, chunk, zero_row); break;
     default: break;
   }
 }
 
 // blocks (MFMAs per 4-row step) of a shape: the unit of work used to balance tasks
 inline int ws_shape_blocks(int shape) {
-  static const int b[WS_SHAPES] = {6 * 5, 6 * 3, 4 * 6, 2 * 4, 3 * 4, 6 * 4};
+  static const int b[WS_SHAPES] = {6 * 5, 6 * 3, 4 * 6, 2 * 4, 3 * 4, 6 * 4, 4 * 4};
   return b[shape];
 }
+
+// Host side: collects jobs, uploads the table, launches.
+struct WsLauncher {
+  WsJob* table;          // device, capacity `cap`
+  int* task_job;         // device, capacity `task_cap`
+  int cap, task_cap;
+  int njobs, total_tasks;
+  WsTableArgs pending;
+  hipStream_t stream;
+  int status;
+  void begin(WsJob* t, int c, int* tj, int tc, hipStream_t s) {
+    table = t; cap = c; task_job = tj; task_cap = tc; njobs = 0; total_tasks = 0; stream = s; status = 0;
+    pending.n = 0; pending.first = 0; pending.table = t; pending.task_job = tj;
+  }
+  void flush() {
+    if (pending.n == 0) return;
+    hipLaunchKernelGGL(ws_table_kernel, dim3(pending.n), dim3(64), 0, stream, pending);
+    pending.first += pending.n;
+    pending.n = 0;
+  }
+  // job.task_begin / ntasks are filled here from rows / rows_per_task
+  void add(WsJob job) {
+    if (njobs >= cap || status) { status = -1; return; }
+    job.ntasks = (job.rows + job.rows_per_task - 1) / job.rows_per_task;
+    if (job.ntasks < 1) job.ntasks = 1;
+    job.task_begin = total_tasks;
+    if (total_tasks + job.ntasks > task_cap) { status = -1; return; }
+    total_tasks += job.ntasks;
+    pending.jobs[pending.n++] = job;
+    ++njobs;
+    if (pending.n == kWsMaxJobs) flush();
+  }
+  void launch(const float* zero_row, int family) {
+    flush();
+    if (total_tasks == 0 || status) return;
+    ProfScope ps(family, stream);
+    hipLaunchKernelGGL(wstream_kernel, dim3((total_tasks + kWsWaves - 1) / kWsWaves), dim3(kWsWaves * 64), 0, stream,
+                       table, task_job, total_tasks, zero_row);
+  }
+};
 
 }  // namespace b3d

@@ -123,6 +123,70 @@ int b3d_pose_backward(const b3d_pose_weights* w, const b3d_graph* g, const float
                       const float* d_logits, const float* d_x_enc, const b3d_pose_grads* grads /* host */,
                       b3d_stream stream);
 
+/* ---- GNN (camera + LiDAR + radar) forward / backward -- clr_att_gnn.py:16-188 -------------------
+ * The three frozen per-detection encoders (resnet.encode, pointnet.forward_feat,
+ * radarnet.forward_feat; clr_att_gnn.py:125,131,139) are ADJACENT to the path and stay with the
+ * caller: their outputs are inputs here.  Everything from the modality heads onwards runs in this
+ * library: fc_lidar / fc_radar heads on the rows that have the modality (:127-141), the cross-edge
+ * modality attention (:143-159; nn.MultiheadAttention with one query and one key is exactly
+ * out_proj(v_proj(value)), hoisted from per edge to per node), att_edge_encoder (:161-164),
+ * node / edge encoders, 6 CausalMessagePassing layers with att_edge_attr (:178-186), the sigmoid
+ * classifier (:49-58,188). */
+typedef struct b3d_mha {            /* nn.MultiheadAttention(D, 2 heads, batch_first) parameters */
+  const float* in_proj_weight;      /* [3D, D]  (q | k | v rows) */
+  const float* in_proj_bias;        /* [3D] */
+  const float* out_proj_weight;     /* [D, D] */
+  const float* out_proj_bias;       /* [D] */
+} b3d_mha;
+typedef struct b3d_mha_grad { float* in_proj_weight; float* in_proj_bias; float* out_proj_weight; float* out_proj_bias; } b3d_mha_grad;
+
+typedef struct b3d_clr_weights {
+  b3d_linear edge_encoder[3];       /* 4-16-32-64            clr_att_gnn.py:35-41 */
+  b3d_linear node_encoder[2];       /* 19-48-96              :43-47 */
+  b3d_linear edge_classifier[4];    /* 64-32-16-8-1 +Sigmoid :49-58 */
+  b3d_linear fc_lidar_encoder[2];   /* 256-192-128           :60-64 */
+  b3d_linear fc_radar_encoder[3];   /* 256-192-128-64        :66-72 */
+  b3d_mha c2c_att, l2l_att, r2r_att;/* D = 96, 128, 64       :77-79 */
+  b3d_linear att_edge_encoder[5];   /* 640-512-384-256-128-64 :81-91 */
+  b3d_mp_weights mp;                /* widths of clr_att_gnn.py:196-222 */
+  b3d_gat knn_conv;                 /* D = 96 */
+} b3d_clr_weights;
+typedef struct b3d_clr_grads {
+  b3d_linear_grad edge_encoder[3];
+  b3d_linear_grad node_encoder[2];
+  b3d_linear_grad edge_classifier[4];
+  b3d_linear_grad fc_lidar_encoder[2];
+  b3d_linear_grad fc_radar_encoder[3];
+  b3d_mha_grad c2c_att, l2l_att, r2r_att;   /* q / k thirds of in_proj receive exact zeros */
+  b3d_linear_grad att_edge_encoder[5];
+  b3d_mp_grads mp;
+} b3d_clr_grads;
+
+typedef struct b3d_clr_inputs {
+  const float* pose_feats;          /* [N,19] */
+  const double* edge_attr;          /* [E,4] float64 */
+  const int64_t* node_timestamps;   /* [N] (only with B3D_FLAG_RUN_DEAD_KNN) */
+  const float* x_img;               /* [N,96]   resnet.encode(img_feats) */
+  const float* pointnet_out;        /* [n_lidar,256] pointnet.forward_feat of the rows that have LiDAR */
+  const int32_t* lidar_nodes;       /* [n_lidar] their node ids, ascending */
+  int32_t n_lidar;
+  const float* radarnet_out;        /* [n_radar,256] */
+  const int32_t* radar_nodes;       /* [n_radar] */
+  int32_t n_radar;
+} b3d_clr_inputs;
+
+size_t b3d_clr_workspace_bytes(int32_t N, int32_t E, int32_t n_lidar, int32_t n_radar, int32_t depth, uint32_t flags);
+/* out_prob [E,1] (after the sigmoid); out_x_sens [N,288] = x_img | x_lidar | x_radar (:172). */
+int b3d_clr_forward(const b3d_clr_weights* w, const b3d_graph* g, const b3d_clr_inputs* in, int32_t depth,
+                    uint32_t flags, void* workspace, size_t workspace_bytes, float* out_prob,
+                    float* out_x_sens, b3d_stream stream);
+/* d_prob [E,1], d_x_sens [N,288] (either may be NULL). */
+int b3d_clr_backward(const b3d_clr_weights* w, const b3d_graph* g, const b3d_clr_inputs* in, int32_t depth,
+                     void* workspace, size_t workspace_bytes, const float* d_prob, const float* d_x_sens,
+                     const b3d_clr_grads* grads, b3d_stream stream);
+/* Modality presence (clr_att_gnn.py:107-121): has[n] = (sum of row n) != 0, rows of `width` floats. */
+int b3d_modality_mask(const float* feats, int32_t N, int32_t width, uint8_t* has /* [N] */, b3d_stream stream);
+
 /* ---- kernel-family timers (measurement aid for bench.py; off by default) --------------------
  * When enabled, every launch of the listed kernel families is bracketed by hipEventRecord on the
  * launch stream.  b3d_prof_read synchronises on the recorded events and returns the summed device
