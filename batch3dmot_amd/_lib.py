@@ -49,6 +49,31 @@ class b3d_pose_grads(C.Structure):       # same layout as the weights minus knn_
                 ("edge_classifier", b3d_linear * 4), ("mp", b3d_mp_weights)]
 
 
+class b3d_mha(C.Structure):
+    _fields_ = [("in_proj_weight", C.c_void_p), ("in_proj_bias", C.c_void_p), ("out_proj_weight", C.c_void_p),
+                ("out_proj_bias", C.c_void_p)]
+
+
+class b3d_clr_weights(C.Structure):
+    _fields_ = [("edge_encoder", b3d_linear * 3), ("node_encoder", b3d_linear * 2), ("edge_classifier", b3d_linear * 4),
+                ("fc_lidar_encoder", b3d_linear * 2), ("fc_radar_encoder", b3d_linear * 3),
+                ("c2c_att", b3d_mha), ("l2l_att", b3d_mha), ("r2r_att", b3d_mha),
+                ("att_edge_encoder", b3d_linear * 5), ("mp", b3d_mp_weights), ("knn_conv", b3d_gat)]
+
+
+class b3d_clr_grads(C.Structure):        # same layout minus knn_conv
+    _fields_ = [("edge_encoder", b3d_linear * 3), ("node_encoder", b3d_linear * 2), ("edge_classifier", b3d_linear * 4),
+                ("fc_lidar_encoder", b3d_linear * 2), ("fc_radar_encoder", b3d_linear * 3),
+                ("c2c_att", b3d_mha), ("l2l_att", b3d_mha), ("r2r_att", b3d_mha),
+                ("att_edge_encoder", b3d_linear * 5), ("mp", b3d_mp_weights)]
+
+
+class b3d_clr_inputs(C.Structure):
+    _fields_ = [("pose_feats", C.c_void_p), ("edge_attr", C.c_void_p), ("node_timestamps", C.c_void_p),
+                ("x_img", C.c_void_p), ("pointnet_out", C.c_void_p), ("lidar_nodes", C.c_void_p), ("n_lidar", C.c_int32),
+                ("radarnet_out", C.c_void_p), ("radar_nodes", C.c_void_p), ("n_radar", C.c_int32)]
+
+
 _lib: Optional[C.CDLL] = None
 
 
@@ -82,6 +107,20 @@ def load() -> C.CDLL:
     lib.b3d_pose_debug_layer_ptrs.restype = C.c_int
     lib.b3d_pose_debug_layer_ptrs.argtypes = [C.c_void_p, C.c_size_t, C.c_int32, C.c_int32, C.c_int32, C.c_uint32,
                                               C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    lib.b3d_clr_workspace_bytes.restype = C.c_size_t
+    lib.b3d_clr_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint32]
+    lib.b3d_clr_forward.restype = C.c_int
+    lib.b3d_clr_forward.argtypes = [C.POINTER(b3d_clr_weights), C.POINTER(b3d_graph), C.POINTER(b3d_clr_inputs), C.c_int32,
+                                    C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.b3d_clr_backward.restype = C.c_int
+    lib.b3d_clr_backward.argtypes = [C.POINTER(b3d_clr_weights), C.POINTER(b3d_graph), C.POINTER(b3d_clr_inputs), C.c_int32,
+                                     C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(b3d_clr_grads), C.c_void_p]
+    lib.b3d_clr_debug_ptrs.restype = C.c_int
+    lib.b3d_clr_debug_ptrs.argtypes = [C.c_void_p, C.c_size_t, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                       C.c_uint32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                       C.POINTER(C.c_void_p)]
+    lib.b3d_modality_mask.restype = C.c_int
+    lib.b3d_modality_mask.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     lib.b3d_prof_enable.argtypes = [C.c_int]
     lib.b3d_prof_read.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]
     _lib = lib

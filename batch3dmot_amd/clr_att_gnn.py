@@ -1,0 +1,242 @@
+"""Drop-in for the reference's ``batch_3dmot.models.clr_att_gnn`` (GNN, CausalMessagePassing).
+
+Same constructor signature, ``forward(data)`` contract and ``state_dict`` keys as
+``/root/reference/batch_3dmot/models/clr_att_gnn.py:16-356``.  The three frozen encoder modules
+are called as the reference calls them (``resnet.encode``, ``pointnet.forward_feat``,
+``radarnet.forward_feat``; they are adjacent to the hot path and stay on PyTorch-ROCm);
+everything downstream -- modality heads, the cross-edge modality attention, att_edge_encoder, the
+encoders, 6 message-passing layers and the sigmoid classifier, forward and backward -- runs in
+the HIP kernels of ``libb3d_hip.so``.
+
+The cross-edge attention calls ``nn.MultiheadAttention`` with ONE query and ONE key per edge
+(clr_att_gnn.py:144-155): the softmax over a single key is 1, so every call equals
+``out_proj(v_proj(value))`` exactly and the query / key projections are dead.  The kernels
+evaluate that affine map once per node and gather it per edge; the ``nn.MultiheadAttention``
+modules are kept as parameter holders so that checkpoints load unchanged.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List
+
+import torch
+from torch import nn
+
+from . import _lib
+from ._lib import B3D_FLAG_RUN_DEAD_KNN, B3D_FLAG_TRAINING
+from .pose_gnn import GATConvParams, _linears, _mlp
+
+
+class CausalMessagePassing(nn.Module):
+    """Parameters of reference clr_att_gnn.py:193-222 (aggr='add')."""
+
+    def __init__(self):
+        super().__init__()
+        self.edge_update = _mlp([320, 256, 128, 64])
+        self.create_past_msgs = _mlp([256, 192, 128])
+        self.create_future_msgs = _mlp([256, 192, 128])
+        self.combine_future_past = _mlp([256, 192, 128, 96])
+
+    def forward(self, x, edge_index, edge_attr, initial_x, att_edge_attr):
+        from .mp_layer import mp_layer_forward
+        return mp_layer_forward(self, "clr", x, edge_index, edge_attr, initial_x, att_edge_attr)
+
+
+def modality_present(feats: torch.Tensor) -> torch.Tensor:
+    """clr_att_gnn.py:107-121: node n has the modality iff the sum of its row is non-zero."""
+    n = feats.size(0)
+    f = feats.reshape(n, -1).contiguous()
+    _lib.require_cuda(f, "modality features", torch.float32)
+    has = torch.empty(n, dtype=torch.uint8, device=f.device)
+    _lib.check(_lib.load().b3d_modality_mask(f.data_ptr(), n, f.size(1), has.data_ptr(), _lib.current_stream(f.device)),
+               "b3d_modality_mask")
+    return has.bool()
+
+
+def _param_list(m: "GNN") -> List[torch.Tensor]:
+    out: List[torch.Tensor] = []
+    for seq in (m.edge_encoder, m.node_encoder, m.edge_classifier, m.fc_lidar_encoder, m.fc_radar_encoder):
+        for lin in _linears(seq):
+            out += [lin.weight, lin.bias]
+    for att in (m.c2c_att, m.l2l_att, m.r2r_att):
+        out += [att.in_proj_weight, att.in_proj_bias, att.out_proj.weight, att.out_proj.bias]
+    for seq in (m.att_edge_encoder, m.message_passing.edge_update, m.message_passing.create_past_msgs,
+                m.message_passing.create_future_msgs, m.message_passing.combine_future_past):
+        for lin in _linears(seq):
+            out += [lin.weight, lin.bias]
+    return out
+
+
+def _fill(dst, tensors, k):
+    for i in range(len(dst)):
+        dst[i].w = tensors[k + 2 * i].data_ptr()
+        dst[i].b = tensors[k + 2 * i + 1].data_ptr()
+    return k + 2 * len(dst)
+
+
+def _fill_mha(dst, tensors, k):
+    dst.in_proj_weight, dst.in_proj_bias, dst.out_proj_weight, dst.out_proj_bias = (tensors[k + i].data_ptr() for i in range(4))
+    return k + 4
+
+
+def _clr_struct(cls, t):
+    s = cls()
+    k = 0
+    k = _fill(s.edge_encoder, t, k)
+    k = _fill(s.node_encoder, t, k)
+    k = _fill(s.edge_classifier, t, k)
+    k = _fill(s.fc_lidar_encoder, t, k)
+    k = _fill(s.fc_radar_encoder, t, k)
+    k = _fill_mha(s.c2c_att, t, k)
+    k = _fill_mha(s.l2l_att, t, k)
+    k = _fill_mha(s.r2r_att, t, k)
+    k = _fill(s.att_edge_encoder, t, k)
+    k = _fill(s.mp.edge_update, t, k)
+    k = _fill(s.mp.create_past_msgs, t, k)
+    k = _fill(s.mp.create_future_msgs, t, k)
+    k = _fill(s.mp.combine_future_past, t, k)
+    assert k == len(t)
+    return s
+
+
+class _GNNFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, graph, pose_feats, edge_attr, node_timestamps, x_img, pointnet_out, lidar_nodes,
+                radarnet_out, radar_nodes, training, *params):
+        lib = _lib.load()
+        dev = pose_feats.device
+        N, E = graph.N, graph.E
+        nl, nr = int(lidar_nodes.numel()), int(radar_nodes.numel())
+        flags = (B3D_FLAG_TRAINING if training else 0) | (B3D_FLAG_RUN_DEAD_KNN if module.run_dead_knn else 0)
+        nbytes = lib.b3d_clr_workspace_bytes(N, E, nl, nr, module.depth, flags)
+        if nbytes == 0:
+            raise ValueError(f"unsupported gnn_depth {module.depth} (1..15)")
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        params = [p.detach() for p in params]
+        w = _clr_struct(_lib.b3d_clr_weights, params)
+        kc = module.knn_conv
+        gat = [kc.lin_src.weight.detach(), kc.att_src.detach().reshape(-1), kc.att_dst.detach().reshape(-1), kc.bias.detach()]
+        w.knn_conv.lin, w.knn_conv.att_src, w.knn_conv.att_dst, w.knn_conv.bias = (t.data_ptr() for t in gat)
+        inp = _lib.b3d_clr_inputs()
+        inp.pose_feats, inp.edge_attr, inp.node_timestamps = pose_feats.data_ptr(), edge_attr.data_ptr(), node_timestamps.data_ptr()
+        inp.x_img = x_img.data_ptr()
+        inp.pointnet_out, inp.lidar_nodes, inp.n_lidar = (pointnet_out.data_ptr() if nl else None), (lidar_nodes.data_ptr() if nl else None), nl
+        inp.radarnet_out, inp.radar_nodes, inp.n_radar = (radarnet_out.data_ptr() if nr else None), (radar_nodes.data_ptr() if nr else None), nr
+        prob = torch.empty((E, 1), dtype=torch.float32, device=dev)
+        x_sens = torch.empty((N, 288), dtype=torch.float32, device=dev)
+        _lib.check(lib.b3d_clr_forward(C.byref(w), C.byref(graph.c), C.byref(inp), module.depth, flags, ws.data_ptr(), nbytes,
+                                       prob.data_ptr(), x_sens.data_ptr(), _lib.current_stream(dev)), "b3d_clr_forward")
+        ctx.set_materialize_grads(False)
+        ctx.module, ctx.graph, ctx.ws, ctx.nbytes, ctx.flags = module, graph, ws, nbytes, flags
+        ctx.params, ctx.inp, ctx.keep = params, inp, (gat, pose_feats, edge_attr, node_timestamps, x_img, pointnet_out,
+                                                      lidar_nodes, radarnet_out, radar_nodes)
+        module._last_workspace = (ws, nbytes, flags, N, E, nl, nr) if module.keep_workspace else None
+        return prob, x_sens
+
+    @staticmethod
+    def backward(ctx, d_prob, d_x_sens):
+        lib = _lib.load()
+        if not (ctx.flags & B3D_FLAG_TRAINING):
+            raise RuntimeError("backward through a GNN forward that ran without gradient tracking")
+        params = ctx.params
+        dev = params[0].device
+        if d_prob is not None:
+            d_prob = d_prob.contiguous().float()
+        if d_x_sens is not None:
+            d_x_sens = d_x_sens.contiguous().float()
+        grads = [torch.empty_like(p) for p in params]
+        w = _clr_struct(_lib.b3d_clr_weights, params)
+        g = _clr_struct(_lib.b3d_clr_grads, grads)
+        _lib.check(lib.b3d_clr_backward(C.byref(w), C.byref(ctx.graph.c), C.byref(ctx.inp), ctx.module.depth, ctx.ws.data_ptr(),
+                                        ctx.nbytes, _lib.ptr(d_prob), _lib.ptr(d_x_sens), C.byref(g), _lib.current_stream(dev)),
+                   "b3d_clr_backward")
+        return (None,) * 11 + tuple(grads)
+
+
+class GNN(nn.Module):
+    """``GNN(img_encoder, lidar_encoder, radar_encoder, use_attention=True, gnn_depth=6, edge_dim=64,
+    node_dim=179)`` -- reference clr_att_gnn.py:16-188.
+
+    ``forward(data)`` reads ``pose_feats [N,19]``, ``img_feats [N,3,32,32]``, ``lidar_feats [N,128,3]``,
+    ``radar_feats [N,64,4]``, ``edge_index [2,E] i64``, ``edge_attr [E,4]``, ``node_timestamps [N]`` and
+    returns ``(edge_prob [E,1] after the sigmoid, x_sens [N,288] = x_img | x_lidar | x_radar)``.
+    The reference's ``use_attention=False`` branch is a shape error as shipped (clr_att_gnn.py:166-170
+    feeds 512 features into ``Linear(640, ...)``) and raises ``NotImplementedError`` here.
+    """
+
+    def __init__(self, img_encoder, lidar_encoder, radar_encoder, use_attention=True, gnn_depth=6, edge_dim=64,
+                 node_dim=179):
+        super().__init__()
+        self.depth = gnn_depth
+        self.use_attention = use_attention
+        self.resnet, self.pointnet, self.radarnet = img_encoder, lidar_encoder, radar_encoder
+        for enc in (self.resnet, self.pointnet, self.radarnet):          # clr_att_gnn.py:26-33
+            for p in enc.parameters():
+                p.requires_grad = False
+        self.edge_encoder = _mlp([4, 16, 32, 64], inplace_relu=True)
+        self.node_encoder = _mlp([19, 48, 96])
+        cls = list(_mlp([64, 32, 16, 8, 1])) + [nn.Sigmoid()]
+        self.edge_classifier = nn.Sequential(*cls)
+        self.fc_lidar_encoder = _mlp([256, 192, 128], inplace_relu=True)
+        self.fc_radar_encoder = _mlp([256, 192, 128, 64], inplace_relu=True)
+        self.message_passing = CausalMessagePassing()
+        self.c2c_att = nn.MultiheadAttention(embed_dim=96, num_heads=2, kdim=96, vdim=96, batch_first=True)
+        self.l2l_att = nn.MultiheadAttention(embed_dim=128, num_heads=2, kdim=128, vdim=128, batch_first=True)
+        self.r2r_att = nn.MultiheadAttention(embed_dim=64, num_heads=2, kdim=64, vdim=64, batch_first=True)
+        self.att_edge_encoder = _mlp([640, 512, 384, 256, 128, 64])
+        self.knn_conv = GATConvParams(96)
+        self.run_dead_knn = True
+        self.keep_workspace = False
+        self._last_workspace = None
+
+    def encode_modalities(self, data):
+        """The frozen, adjacent part (clr_att_gnn.py:107-141): presence masks, ResNet / PointNet /
+        RadarNet embeddings of the rows that have the modality, and the sticky ``.eval()`` switch
+        when fewer than two rows have it."""
+        img_feats, lidar_feats, radar_feats = data.img_feats, data.lidar_feats, data.radar_feats
+        pcl_nodes = modality_present(lidar_feats)
+        pr_nodes = modality_present(radar_feats)
+        with torch.no_grad():
+            x_img = self.resnet.encode(img_feats).float().contiguous()
+            lidar_nodes = torch.nonzero(pcl_nodes).squeeze(1)
+            if lidar_nodes.numel() < 2:
+                self.pointnet.eval()
+                self.fc_lidar_encoder.eval()
+            pointnet_out = self.pointnet.forward_feat(lidar_feats[lidar_nodes].view(-1, 3, 128)).float().contiguous()
+            radar_nodes = torch.nonzero(pr_nodes).squeeze(1)
+            if radar_nodes.numel() < 2:
+                self.radarnet.eval()
+                self.fc_radar_encoder.eval()
+            radarnet_out = self.radarnet.forward_feat(radar_feats[radar_nodes].view(-1, 4, 64)).float().contiguous()
+        return x_img, pointnet_out, lidar_nodes.to(torch.int32).contiguous(), radarnet_out, radar_nodes.to(torch.int32).contiguous()
+
+    def forward(self, data, encoded=None):
+        if not self.use_attention:
+            raise NotImplementedError("use_attention=False is a shape error in the reference "
+                                      "(clr_att_gnn.py:166-170 vs :82)")
+        pose_feats, edge_index, edge_attr, node_timestamps = (data.pose_feats, data.edge_index, data.edge_attr,
+                                                              data.node_timestamps)
+        _lib.require_cuda(pose_feats, "data.pose_feats", torch.float32)
+        if pose_feats.dim() != 2 or pose_feats.size(1) != 19:
+            raise ValueError(f"data.pose_feats must be [N, 19], got {tuple(pose_feats.shape)}")
+        if edge_attr.dim() != 2 or edge_attr.size(1) != 4 or edge_attr.size(0) != edge_index.size(1):
+            raise ValueError(f"data.edge_attr must be [E, 4], got {tuple(edge_attr.shape)}")
+        if edge_index.size(1) == 0 or pose_feats.size(0) == 0:
+            raise ValueError("empty graph: the reference's callers skip these (predict.py:179-180)")
+        edge_attr = edge_attr.to(torch.float64).contiguous()
+        node_timestamps = node_timestamps.to(torch.int64).contiguous()
+        x_img, pointnet_out, lidar_nodes, radarnet_out, radar_nodes = encoded if encoded is not None else self.encode_modalities(data)
+        graph = getattr(data, "_b3d_graph", None)
+        if graph is None or graph.N != pose_feats.size(0) or graph.E != edge_index.size(1) \
+                or graph._keep.data_ptr() != edge_index.data_ptr():
+            graph = _lib.Graph(edge_index.contiguous(), pose_feats.size(0))
+            try:
+                data._b3d_graph = graph
+            except Exception:
+                pass
+        params = _param_list(self)
+        for p in params:
+            _lib.require_cuda(p, "parameter", torch.float32)
+        training = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        return _GNNFunction.apply(self, graph, pose_feats, edge_attr, node_timestamps, x_img, pointnet_out, lidar_nodes,
+                                  radarnet_out, radar_nodes, training, *params)

@@ -98,6 +98,55 @@ struct LoadNodeEncGrad {
   }
 };
 
+// two aligned sources added together (optional row gather on both)
+template <int NB_>
+struct LoadAdd2 {
+  static constexpr int NB = NB_;
+  const float* p0; int stride0; int col0;
+  const float* p1; int stride1; int col1;     // p1 may be nullptr
+  const int* idx;                             // row gather applied to both sources, or nullptr
+  __device__ __forceinline__ void operator()(long row, bool valid, v4f* dst) const {
+    long r = row;
+    if (idx && valid) r = idx[row];
+    load_row<NB>(p0, r, stride0, col0, valid, dst);
+    if (p1) {
+      v4f t[NB];
+      load_row<NB>(p1, r, stride1, col1, valid, t);
+      add_blocks<NB>(dst, t);
+    }
+  }
+};
+
+// node gradient = per-edge rows summed over the node's CSR list (columns col_dst) plus over its CSC
+// list (columns col_src) -- the transpose of gathering node rows at both ends of every edge
+template <int NB_>
+struct LoadSegSum2 {
+  static constexpr int NB = NB_;
+  const float* base; int stride; int col_dst; int col_src;
+  const int* dst_ptr; const int* dst_perm; const int* src_ptr; const int* src_perm;
+  __device__ __forceinline__ void operator()(long row, bool valid, v4f* dst) const {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) dst[b] = v4f{0.f, 0.f, 0.f, 0.f};
+    if (valid) {
+      segment_sum<NB>(base, stride, col_dst, dst_perm, dst_ptr[row], dst_ptr[row + 1], dst);
+      segment_sum<NB>(base, stride, col_src, src_perm, src_ptr[row], src_ptr[row + 1], dst);
+    }
+  }
+};
+
+// d(pre-sigmoid) = d_prob * p * (1 - p)   (Sigmoid at clr_att_gnn.py:57)
+struct LoadSigmoidGrad {
+  static constexpr int NB = 1;
+  const float* d_prob;   // [rows,1] or nullptr
+  const float* prob;     // [rows,1]
+  __device__ __forceinline__ void operator()(long row, bool valid, v4f* dst) const {
+    const int q = (threadIdx.x & 63) >> 4;
+    v4f v = {0.f, 0.f, 0.f, 0.f};
+    if (valid && q == 0 && d_prob) { const float p = prob[row]; v.x = d_prob[row] * p * (1.f - p); }
+    dst[0] = v;
+  }
+};
+
 // ---- row storers ------------------------------------------------------------------------------
 template <int NB_>
 struct StoreAligned {

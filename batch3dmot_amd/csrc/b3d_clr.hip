@@ -1,0 +1,737 @@
+// GNN (camera + LiDAR + radar) forward / backward -- reference batch_3dmot/models/clr_att_gnn.py:16-188
+// -- as a sequence of gfx950 kernel launches on one stream.  All scratch lives in the caller's
+// workspace.  The frozen encoders are adjacent (their outputs are inputs here, see include/b3d.h).
+#include "b3d_launch.hpp"
+#include "b3d_knn.hpp"
+#include "b3d_wstream.hpp"
+
+namespace b3d {
+namespace clr {
+
+using D = DimsC;
+constexpr int XS = 288;                                                  // x_sens / s width (96 + 128 + 64)
+using SeqEE = LayerSeq<L<16, 16>, L<16, 32>, L<32, 64>>;                 // 4-16-32-64          :35-41
+using SeqNE = LayerSeq<L<32, 48>, L<48, 96>>;                            // 19-48-96            :43-47
+using SeqCls = LayerSeq<L<64, 32>, L<32, 16>, L<16, 16>, L<16, 16>>;     // 64-32-16-8-1        :49-58
+using SeqFL = LayerSeq<L<256, 192>, L<192, 128>>;                        // 256-192-128         :60-64
+using SeqFR = LayerSeq<L<256, 192>, L<192, 128>, L<128, 64>>;            // 256-192-128-64      :66-72
+template <int DD> using SeqAff = LayerSeq<L<DD, DD>, L<DD, DD>>;         // out_proj(v_proj(x)) :77-79,148-155
+using SeqAT0 = LayerSeq<L<640, 512>>;                                    // att_edge_encoder    :81-91
+using SeqAT1 = LayerSeq<L<512, 384>>;
+using SeqAT2 = LayerSeq<L<384, 256>>;
+using SeqAT3 = LayerSeq<L<256, 128>>;
+using SeqAT4 = LayerSeq<L<128, 64>>;
+// transposed (data gradient)
+using SeqClsT = LayerSeq<L<16, 16>, L<16, 16>, L<16, 32>, L<32, 64>>;
+using SeqEET = LayerSeq<L<64, 32>, L<32, 16>>;
+using SeqNET = LayerSeq<L<96, 48>>;
+using SeqFLT = LayerSeq<L<128, 192>>;
+using SeqFRT = LayerSeq<L<64, 128>, L<128, 192>>;
+template <int DD> using SeqAffT = LayerSeq<L<DD, DD>, L<DD, DD>>;
+using SeqAT4T = LayerSeq<L<64, 128>>;
+using SeqAT3T = LayerSeq<L<128, 256>>;
+using SeqAT2T = LayerSeq<L<256, 384>>;
+using SeqAT1T = LayerSeq<L<384, 512>>;
+using SeqAT0T = LayerSeq<L<512, 640>>;
+
+enum { EE0, EE1, EE2, NE0, NE1, C0, C1, C2, C3, FL0, FL1, FR0, FR1, FR2,
+       AVC, AOC, AVL, AOL, AVR, AOR, AT0, AT1, AT2, AT3, AT4,
+       EU0, EU1, EU2, PA0, PA1, FU0, FU1, CF0, CF1, CF2, LIN_COUNT };
+struct LinDim { int N, K; };
+static const LinDim kDims[LIN_COUNT] = {
+    {16, 4}, {32, 16}, {64, 32}, {48, 19}, {96, 48}, {32, 64}, {16, 32}, {8, 16}, {1, 8},
+    {192, 256}, {128, 192}, {192, 256}, {128, 192}, {64, 128},
+    {96, 96}, {96, 96}, {128, 128}, {128, 128}, {64, 64}, {64, 64},
+    {512, 640}, {384, 512}, {256, 384}, {128, 256}, {64, 128},
+    {256, 320}, {128, 256}, {64, 128}, {192, 256}, {128, 192}, {192, 256}, {128, 192}, {192, 256}, {128, 192}, {96, 128}};
+// rows the layer is applied to: 0 = edges, 1 = nodes, 2 = lidar rows, 3 = radar rows
+static const int kRowKind[LIN_COUNT] = {0, 0, 0, 1, 1, 0, 0, 0, 0, 2, 2, 3, 3, 3, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0,
+                                        0, 0, 0, 0, 0, 0, 0, 1, 1, 1};
+constexpr int kStreamRowsPerTask = 512;       // message-passing stacks (x up to 6 layer variants)
+constexpr int kStreamRowsPerTaskAtt = 1024;   // att_edge_encoder (one variant)
+
+struct Ws {
+  // forward images
+  float *wp_ee, *wp_ne, *wp_cls, *wp_fl, *wp_fr, *wp_aff[3], *wp_at[5], *wp_efwd, *wp_nfwd;
+  // backward images
+  float *wp_clsT, *wp_eeT, *wp_neT, *wp_flT, *wp_frT, *wp_affT[3], *wp_atT[5], *wp_ebwd, *wp_ebwd_nm, *wp_nbwd;
+  // activations
+  float *ea_pad, *ee_a1, *ee_a2, *pose_pad, *ne_a1, *xsens, *fl_a1, *fr_a1, *fr_a2, *aff_v[3], *s;
+  float *A[4], *att;                 // att_edge_encoder hidden [E,512/384/256/128], output [E,64]
+  float *x[16], *e[16];
+  float *sH1[16], *sH2[16], *sF1[16], *sP1[16], *M[16], *nH1[16], *nH2[16];
+  float *fut, *past, *c_a1, *c_a2, *c_a3, *prob;
+  // backward scratch
+  float *de[2], *da_acc, *gdst, *gsrc, *dx0_acc;
+  float *dM, *GdH1, *GdH2, *Gde, *GdF1, *GdP1, *Gdx, *GnH2, *GnH1;     // per layer, uniform stride
+  float *gc_top, *gc3, *gc2, *gc1, *ge_top, *ge2, *ge1, *gn_top, *gn1;
+  float *dA[4], *dIn;                // att backward: [E,128/256/384/512], [E,640]
+  float *gaff_top[3], *gaff_v[3], *dxs;   // affine backward; dxs [N,288] gradient of x_sens columns
+  float *gfl_top, *gfl1, *gfr_top, *gfr2, *gfr1;
+  float* zrow;
+  int* iota;
+  WsJob* ws_table;
+  int* ws_task_job;
+  LinSlab lin[LIN_COUNT];
+  KnnWs knn;
+  size_t bytes;
+  bool ok;
+};
+constexpr int kTableCap = 320, kTaskCap = 32768;
+
+static bool is_streamed(int lin) { return lin >= AT0; }
+
+static void carve(Ws& w, void* ws, size_t ws_bytes, int N, int E, int nl, int nr, int depth, uint32_t flags) {
+  Carver c(ws, ws_bytes);
+  const bool tr = flags & B3D_FLAG_TRAINING;
+  const size_t e_ = (size_t)(E > 0 ? E : 1), n_ = (size_t)(N > 0 ? N : 1);
+  const size_t l_ = (size_t)(nl > 0 ? nl : 1), r_ = (size_t)(nr > 0 ? nr : 1);
+  memset(&w, 0, sizeof(w));
+  w.wp_ee = c.take<float>(SeqEE::TOTAL_FLOATS);
+  w.wp_ne = c.take<float>(SeqNE::TOTAL_FLOATS);
+  w.wp_cls = c.take<float>(SeqCls::TOTAL_FLOATS);
+  w.wp_fl = c.take<float>(SeqFL::TOTAL_FLOATS);
+  w.wp_fr = c.take<float>(SeqFR::TOTAL_FLOATS);
+  w.wp_aff[0] = c.take<float>(SeqAff<96>::TOTAL_FLOATS);
+  w.wp_aff[1] = c.take<float>(SeqAff<128>::TOTAL_FLOATS);
+  w.wp_aff[2] = c.take<float>(SeqAff<64>::TOTAL_FLOATS);
+  w.wp_at[0] = c.take<float>(SeqAT0::TOTAL_FLOATS);
+  w.wp_at[1] = c.take<float>(SeqAT1::TOTAL_FLOATS);
+  w.wp_at[2] = c.take<float>(SeqAT2::TOTAL_FLOATS);
+  w.wp_at[3] = c.take<float>(SeqAT3::TOTAL_FLOATS);
+  w.wp_at[4] = c.take<float>(SeqAT4::TOTAL_FLOATS);
+  w.wp_efwd = c.take<float>(D::EdgeFwdSeq::TOTAL_FLOATS);
+  w.wp_nfwd = c.take<float>(D::NodeFwdSeq::TOTAL_FLOATS);
+  w.xsens = c.take<float>(n_ * XS);
+  w.s = c.take<float>(n_ * XS);
+  w.att = c.take<float>(e_ * 64);
+  w.fut = c.take<float>(e_ * D::DM);
+  w.past = c.take<float>(e_ * D::DM);
+  w.prob = c.take<float>(e_);
+  const int adims[4] = {512, 384, 256, 128};
+  const int affd[3] = {96, 128, 64};
+  if (!tr) {
+    // inference: hidden activations of the wide encoder ping-pong through two buffers
+    w.A[0] = c.take<float>(e_ * 512); w.A[1] = c.take<float>(e_ * 384); w.A[2] = w.A[0]; w.A[3] = w.A[1];
+    w.x[0] = c.take<float>(n_ * D::DX); w.x[1] = c.take<float>(n_ * D::DX); w.x[2] = c.take<float>(n_ * D::DX);
+    w.e[0] = c.take<float>(e_ * D::DE); w.e[1] = c.take<float>(e_ * D::DE); w.e[2] = c.take<float>(e_ * D::DE);
+    for (int l = 3; l <= depth; ++l) { w.x[l] = w.x[1 + (l - 1) % 2]; w.e[l] = w.e[1 + (l - 1) % 2]; }
+    for (int m = 0; m < 3; ++m) w.aff_v[m] = nullptr;
+  } else {
+    w.wp_clsT = c.take<float>(SeqClsT::TOTAL_FLOATS);
+    w.wp_eeT = c.take<float>(SeqEET::TOTAL_FLOATS);
+    w.wp_neT = c.take<float>(SeqNET::TOTAL_FLOATS);
+    w.wp_flT = c.take<float>(SeqFLT::TOTAL_FLOATS);
+    w.wp_frT = c.take<float>(SeqFRT::TOTAL_FLOATS);
+    w.wp_affT[0] = c.take<float>(SeqAffT<96>::TOTAL_FLOATS);
+    w.wp_affT[1] = c.take<float>(SeqAffT<128>::TOTAL_FLOATS);
+    w.wp_affT[2] = c.take<float>(SeqAffT<64>::TOTAL_FLOATS);
+    w.wp_atT[0] = c.take<float>(SeqAT0T::TOTAL_FLOATS);
+    w.wp_atT[1] = c.take<float>(SeqAT1T::TOTAL_FLOATS);
+    w.wp_atT[2] = c.take<float>(SeqAT2T::TOTAL_FLOATS);
+    w.wp_atT[3] = c.take<float>(SeqAT3T::TOTAL_FLOATS);
+    w.wp_atT[4] = c.take<float>(SeqAT4T::TOTAL_FLOATS);
+    w.wp_ebwd = c.take<float>(D::EdgeBwdSeq::TOTAL_FLOATS);
+    w.wp_ebwd_nm = c.take<float>(D::EdgeBwdSeqNoMsg::TOTAL_FLOATS);
+    w.wp_nbwd = c.take<float>(D::NodeBwdSeq::TOTAL_FLOATS);
+    w.ea_pad = c.take<float>(e_ * 16); w.ee_a1 = c.take<float>(e_ * 16); w.ee_a2 = c.take<float>(e_ * 32);
+    w.pose_pad = c.take<float>(n_ * 32); w.ne_a1 = c.take<float>(n_ * 48);
+    w.fl_a1 = c.take<float>(l_ * 192); w.fr_a1 = c.take<float>(r_ * 192); w.fr_a2 = c.take<float>(r_ * 128);
+    for (int m = 0; m < 3; ++m) w.aff_v[m] = c.take<float>(n_ * affd[m]);
+    for (int i = 0; i < 4; ++i) w.A[i] = c.take<float>(e_ * adims[i]);
+    {
+      float* xb = c.take<float>((size_t)(depth + 1) * n_ * D::DX);
+      float* eb = c.take<float>((size_t)(depth + 1) * e_ * D::DE);
+      for (int l = 0; l <= depth; ++l) {
+        w.x[l] = xb ? xb + (size_t)l * n_ * D::DX : nullptr;
+        w.e[l] = eb ? eb + (size_t)l * e_ * D::DE : nullptr;
+      }
+    }
+    auto per_layer = [&](float** arr, size_t per) {
+      float* b = c.take<float>((size_t)depth * per);
+      for (int l = 0; l < depth; ++l) arr[l] = b ? b + (size_t)l * per : nullptr;
+    };
+    per_layer(w.sH1, e_ * D::EH1); per_layer(w.sH2, e_ * D::EH2); per_layer(w.sF1, e_ * D::MH); per_layer(w.sP1, e_ * D::MH);
+    per_layer(w.M, n_ * D::NIN); per_layer(w.nH1, n_ * D::NH1); per_layer(w.nH2, n_ * D::NH2);
+    w.c_a1 = c.take<float>(e_ * 32); w.c_a2 = c.take<float>(e_ * 16); w.c_a3 = c.take<float>(e_ * 16);
+    w.de[0] = c.take<float>(e_ * D::DE); w.de[1] = c.take<float>(e_ * D::DE);
+    w.da_acc = c.take<float>(e_ * D::DA);
+    w.gdst = c.take<float>(e_ * 2 * D::DX); w.gsrc = c.take<float>(e_ * 2 * D::DX);
+    w.dx0_acc = c.take<float>(n_ * D::DX);
+    w.dM = c.take<float>((size_t)depth * n_ * D::NIN);
+    w.GdH1 = c.take<float>((size_t)depth * e_ * D::EH1);
+    w.GdH2 = c.take<float>((size_t)depth * e_ * D::EH2);
+    w.Gde = c.take<float>((size_t)depth * e_ * D::DE);
+    w.GdF1 = c.take<float>((size_t)depth * e_ * D::MH);
+    w.GdP1 = c.take<float>((size_t)depth * e_ * D::MH);
+    w.Gdx = c.take<float>((size_t)depth * n_ * D::DX);
+    w.GnH2 = c.take<float>((size_t)depth * n_ * D::NH2);
+    w.GnH1 = c.take<float>((size_t)depth * n_ * D::NH1);
+    w.gc_top = c.take<float>(e_ * 16); w.gc3 = c.take<float>(e_ * 16); w.gc2 = c.take<float>(e_ * 16); w.gc1 = c.take<float>(e_ * 32);
+    w.ge_top = c.take<float>(e_ * 64); w.ge2 = c.take<float>(e_ * 32); w.ge1 = c.take<float>(e_ * 16);
+    w.gn_top = c.take<float>(n_ * 96); w.gn1 = c.take<float>(n_ * 48);
+    w.dA[0] = c.take<float>(e_ * 128); w.dA[1] = c.take<float>(e_ * 256); w.dA[2] = c.take<float>(e_ * 384); w.dA[3] = c.take<float>(e_ * 512);
+    w.dIn = c.take<float>(e_ * 640);
+    for (int m = 0; m < 3; ++m) { w.gaff_top[m] = c.take<float>(n_ * affd[m]); w.gaff_v[m] = c.take<float>(n_ * affd[m]); }
+    w.dxs = c.take<float>(n_ * XS);
+    w.gfl_top = c.take<float>(l_ * 128); w.gfl1 = c.take<float>(l_ * 192);
+    w.gfr_top = c.take<float>(r_ * 64); w.gfr2 = c.take<float>(r_ * 128); w.gfr1 = c.take<float>(r_ * 192);
+    w.zrow = c.take<float>(256);
+    w.iota = c.take<int>((size_t)(E > N ? E : N) + 64);
+    w.ws_table = c.take<WsJob>(kTableCap);
+    w.ws_task_job = c.take<int>(kTaskCap);
+    for (int i = 0; i < LIN_COUNT; ++i) {
+      LinSlab& ls = w.lin[i];
+      ls.N = kDims[i].N; ls.K = kDims[i].K; ls.NP = pad16(ls.N); ls.KP = pad16(ls.K);
+      const long rows = kRowKind[i] == 0 ? E : kRowKind[i] == 1 ? N : kRowKind[i] == 2 ? nl : nr;
+      if (is_streamed(i)) {
+        const int rpt = (i <= AT4) ? kStreamRowsPerTaskAtt : kStreamRowsPerTask;
+        ls.nchunks = (int)((rows + rpt - 1) / rpt);
+        if (ls.nchunks < 1) ls.nchunks = 1;
+      } else {
+        ls.nchunks = wg_nchunks(rows, ls.NP, ls.KP, 0);
+      }
+      ls.slab = c.take<float>(wg_slab_floats(ls.nchunks, ls.NP, ls.KP));
+      ls.used = false;
+    }
+  }
+  if (flags & B3D_FLAG_RUN_DEAD_KNN) knn_carve(w.knn, c, N, D::DX);
+  w.bytes = c.off + 256;
+  w.ok = c.ok();
+}
+
+__global__ void iota_kernel(int* p, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = i;
+}
+
+// strided row copy: dst[r][dcol0 + c] = src[r][c]
+__global__ void copy_cols_kernel(const float* __restrict__ src, int sstride, float* __restrict__ dst, int dstride,
+                                 int dcol0, int rows, int width) {
+  const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= (long)rows * width) return;
+  const long r = id / width;
+  const int cc = (int)(id - r * width);
+  dst[r * dstride + dcol0 + cc] = src[r * sstride + cc];
+}
+
+// clr_att_gnn.py:107-121: has[n] = (sum of row n) != 0.  One wavefront per row.
+__global__ __launch_bounds__(256) void modality_mask_kernel(const float* __restrict__ f, int N, int width,
+                                                            uint8_t* __restrict__ has) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= N) return;
+  float s = 0.f;
+  for (int c = lane; c < width; c += 64) s += f[(size_t)row * width + c];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+  if (lane == 0) has[row] = (s != 0.f) ? 1 : 0;
+}
+
+struct LinPtrs { const float* w; const float* b; };
+static void gather_linears(const b3d_clr_weights* pw, LinPtrs* L) {
+  auto put = [&](int first, const b3d_linear* a, int n) { for (int i = 0; i < n; ++i) L[first + i] = LinPtrs{a[i].w, a[i].b}; };
+  put(EE0, pw->edge_encoder, 3); put(NE0, pw->node_encoder, 2); put(C0, pw->edge_classifier, 4);
+  put(FL0, pw->fc_lidar_encoder, 2); put(FR0, pw->fc_radar_encoder, 3); put(AT0, pw->att_edge_encoder, 5);
+  put(EU0, pw->mp.edge_update, 3); put(PA0, pw->mp.create_past_msgs, 2); put(FU0, pw->mp.create_future_msgs, 2);
+  put(CF0, pw->mp.combine_future_past, 3);
+  const b3d_mha* mh[3] = {&pw->c2c_att, &pw->l2l_att, &pw->r2r_att};
+  const int dd[3] = {96, 128, 64};
+  for (int m = 0; m < 3; ++m) {
+    // value projection = rows [2D, 3D) of in_proj (clr_att_gnn.py:148-155 with one key: softmax == 1)
+    L[AVC + 2 * m] = LinPtrs{mh[m]->in_proj_weight + (size_t)2 * dd[m] * dd[m], mh[m]->in_proj_bias + 2 * dd[m]};
+    L[AOC + 2 * m] = LinPtrs{mh[m]->out_proj_weight, mh[m]->out_proj_bias};
+  }
+}
+
+static int check_weights(const b3d_clr_weights* pw) {
+  B3D_REQUIRE(pw != nullptr, "weights struct is null");
+  LinPtrs L[LIN_COUNT];
+  gather_linears(pw, L);
+  for (int i = 0; i < LIN_COUNT; ++i) B3D_REQUIRE(L[i].w && L[i].b, "null weight/bias pointer (linear %d)", i);
+  return B3D_OK;
+}
+
+static int pack_all(const b3d_clr_weights* pw, Ws& w, bool training, hipStream_t stream) {
+  LinPtrs L[LIN_COUNT];
+  gather_linears(pw, L);
+  PackDesc d[96];
+  int n = 0;
+  auto F = [&](auto tag, int li, float* base, int lin) {
+    using S = decltype(tag);
+    d[n++] = pack_desc<S>(li, base, L[lin].w, L[lin].b, kDims[lin].N, kDims[lin].K, false);
+  };
+  auto T = [&](auto tag, int li, float* base, int lin) {
+    using S = decltype(tag);
+    d[n++] = pack_desc<S>(li, base, L[lin].w, nullptr, kDims[lin].K, kDims[lin].N, true);
+  };
+  for (int i = 0; i < 3; ++i) F(SeqEE{}, i, w.wp_ee, EE0 + i);
+  for (int i = 0; i < 2; ++i) F(SeqNE{}, i, w.wp_ne, NE0 + i);
+  for (int i = 0; i < 4; ++i) F(SeqCls{}, i, w.wp_cls, C0 + i);
+  for (int i = 0; i < 2; ++i) F(SeqFL{}, i, w.wp_fl, FL0 + i);
+  for (int i = 0; i < 3; ++i) F(SeqFR{}, i, w.wp_fr, FR0 + i);
+  F(SeqAff<96>{}, 0, w.wp_aff[0], AVC); F(SeqAff<96>{}, 1, w.wp_aff[0], AOC);
+  F(SeqAff<128>{}, 0, w.wp_aff[1], AVL); F(SeqAff<128>{}, 1, w.wp_aff[1], AOL);
+  F(SeqAff<64>{}, 0, w.wp_aff[2], AVR); F(SeqAff<64>{}, 1, w.wp_aff[2], AOR);
+  F(SeqAT0{}, 0, w.wp_at[0], AT0); F(SeqAT1{}, 0, w.wp_at[1], AT1); F(SeqAT2{}, 0, w.wp_at[2], AT2);
+  F(SeqAT3{}, 0, w.wp_at[3], AT3); F(SeqAT4{}, 0, w.wp_at[4], AT4);
+  using EF = D::EdgeFwdSeq;
+  for (int i = 0; i < 3; ++i) F(EF{}, i, w.wp_efwd, EU0 + i);
+  for (int i = 0; i < 2; ++i) F(EF{}, 3 + i, w.wp_efwd, FU0 + i);
+  for (int i = 0; i < 2; ++i) F(EF{}, 5 + i, w.wp_efwd, PA0 + i);
+  for (int i = 0; i < 3; ++i) F(D::NodeFwdSeq{}, i, w.wp_nfwd, CF0 + i);
+  if (training) {
+    T(SeqClsT{}, 0, w.wp_clsT, C3); T(SeqClsT{}, 1, w.wp_clsT, C2); T(SeqClsT{}, 2, w.wp_clsT, C1); T(SeqClsT{}, 3, w.wp_clsT, C0);
+    T(SeqEET{}, 0, w.wp_eeT, EE2); T(SeqEET{}, 1, w.wp_eeT, EE1);
+    T(SeqNET{}, 0, w.wp_neT, NE1);
+    T(SeqFLT{}, 0, w.wp_flT, FL1);
+    T(SeqFRT{}, 0, w.wp_frT, FR2); T(SeqFRT{}, 1, w.wp_frT, FR1);
+    T(SeqAffT<96>{}, 0, w.wp_affT[0], AOC); T(SeqAffT<96>{}, 1, w.wp_affT[0], AVC);
+    T(SeqAffT<128>{}, 0, w.wp_affT[1], AOL); T(SeqAffT<128>{}, 1, w.wp_affT[1], AVL);
+    T(SeqAffT<64>{}, 0, w.wp_affT[2], AOR); T(SeqAffT<64>{}, 1, w.wp_affT[2], AVR);
+    T(SeqAT0T{}, 0, w.wp_atT[0], AT0); T(SeqAT1T{}, 0, w.wp_atT[1], AT1); T(SeqAT2T{}, 0, w.wp_atT[2], AT2);
+    T(SeqAT3T{}, 0, w.wp_atT[3], AT3); T(SeqAT4T{}, 0, w.wp_atT[4], AT4);
+    using EB = D::EdgeBwdSeq;
+    T(EB{}, 0, w.wp_ebwd, PA1); T(EB{}, 1, w.wp_ebwd, PA0); T(EB{}, 2, w.wp_ebwd, FU1); T(EB{}, 3, w.wp_ebwd, FU0);
+    T(EB{}, 4, w.wp_ebwd, EU2); T(EB{}, 5, w.wp_ebwd, EU1); T(EB{}, 6, w.wp_ebwd, EU0);
+    using EN = D::EdgeBwdSeqNoMsg;
+    T(EN{}, 0, w.wp_ebwd_nm, EU2); T(EN{}, 1, w.wp_ebwd_nm, EU1); T(EN{}, 2, w.wp_ebwd_nm, EU0);
+    using NB = D::NodeBwdSeq;
+    T(NB{}, 0, w.wp_nbwd, CF2); T(NB{}, 1, w.wp_nbwd, CF1); T(NB{}, 2, w.wp_nbwd, CF0);
+  }
+  return pack_images(d, n, stream);
+}
+
+template <class Seq, bool RELU, bool BIAS, class In>
+static int wide(const char* name, const In& in, long rows, float* out, int ostride, int ocol0, const float* mask,
+                const float* wp, hipStream_t stream) {
+  WideArgs<In> a;
+  a.rows = (int)rows; a.in = in; a.out = out; a.out_stride = ostride; a.out_col0 = ocol0; a.mask = mask; a.wpack = wp;
+  return launch_rows<kNWEdge>(wide_linear_kernel<Seq, RELU, BIAS, In, kNWEdge>, name, a, rows, stream);
+}
+
+// One modality's out_proj(v_proj(x)) on all nodes: x = xsens[:, xc : xc+DD] -> s[:, sc : sc+DD]
+template <int DD>
+static int affine_fwd(Ws& w, int m, int N, int xc, int sc, hipStream_t stream) {
+  using In = LoadAligned<DD / 16>;
+  using Out = StoreAligned<DD / 16>;
+  ChainFwdArgs<In, Out> a;
+  memset(&a, 0, sizeof(a));
+  a.rows = N; a.in = In{w.xsens, nullptr, XS, xc}; a.out = Out{w.s, nullptr, XS, sc};
+  a.save[0] = w.aff_v[m];
+  a.wpack = w.wp_aff[m];
+  return launch_rows<kNWNode>(chain_fwd_kernel<SeqAff<DD>, 0u, In, Out, kNWNode>, "modality_affine", a, N, stream);
+}
+
+// backward of one modality: G_out = segment sums of d s_i / d s_j columns; d x_m -> dxs[:, xc : xc+DD]
+template <int DD>
+static int affine_bwd(Ws& w, const b3d_graph* g, int m, int N, int xc, int sc, hipStream_t stream) {
+  using In = LoadSegSum2<DD / 16>;
+  using Out = StoreAligned<DD / 16>;
+  ChainBwdArgs<In, Out> a;
+  memset(&a, 0, sizeof(a));
+  a.rows = N;
+  a.in = In{w.dIn, 640, sc, XS + sc, g->dst_ptr, g->dst_perm, g->src_ptr, g->src_perm};
+  a.out = Out{w.dxs, nullptr, XS, xc};
+  a.gtop = w.gaff_top[m];
+  a.gsave[0] = w.gaff_v[m];
+  a.wpack = w.wp_affT[m];
+  return launch_rows<kNWNode>(chain_bwd_kernel<SeqAffT<DD>, In, Out, kNWNode>, "modality_affine_bwd", a, N, stream);
+}
+
+}  // namespace clr
+}  // namespace b3d
+
+using namespace b3d;
+using namespace b3d::clr;
+
+extern "C" int b3d_modality_mask(const float* feats, int32_t N, int32_t width, uint8_t* has, b3d_stream stream_) {
+  B3D_REQUIRE(feats && has && N >= 0 && width > 0, "b3d_modality_mask: bad argument");
+  if (N == 0) return B3D_OK;
+  hipLaunchKernelGGL(modality_mask_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream_, feats, N, width, has);
+  return launch_check("modality_mask_kernel");
+}
+
+extern "C" size_t b3d_clr_workspace_bytes(int32_t N, int32_t E, int32_t n_lidar, int32_t n_radar, int32_t depth, uint32_t flags) {
+  if (depth < 1 || depth > 15) return 0;
+  Ws w;
+  carve(w, nullptr, 0, N, E, n_lidar, n_radar, depth, flags);
+  return w.bytes;
+}
+
+extern "C" int b3d_clr_debug_ptrs(void* workspace, size_t workspace_bytes, int32_t N, int32_t E, int32_t nl, int32_t nr,
+                                  int32_t depth, uint32_t flags, int32_t layer, float** x, float** e, float** att) {
+  B3D_REQUIRE(depth >= 1 && depth <= 15 && layer >= 0 && layer <= depth, "bad layer");
+  Ws w;
+  carve(w, workspace, workspace_bytes, N, E, nl, nr, depth, flags);
+  if (!w.ok) return fail(B3D_ERR_WORKSPACE, "workspace too small");
+  *x = w.x[layer]; *e = w.e[layer]; *att = w.att;
+  return B3D_OK;
+}
+
+extern "C" int b3d_clr_forward(const b3d_clr_weights* pw, const b3d_graph* g, const b3d_clr_inputs* in, int32_t depth,
+                               uint32_t flags, void* workspace, size_t workspace_bytes, float* out_prob,
+                               float* out_x_sens, b3d_stream stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  B3D_TRY(check_weights(pw));
+  B3D_REQUIRE(g && in && workspace && out_prob && out_x_sens, "b3d_clr_forward: null argument");
+  B3D_REQUIRE(in->pose_feats && in->edge_attr && in->x_img, "b3d_clr_forward: null input tensor");
+  B3D_REQUIRE(depth >= 1 && depth <= 15, "b3d_clr_forward: depth %d outside [1,15]", depth);
+  const int N = g->N, E = g->E, nl = in->n_lidar, nr = in->n_radar;
+  B3D_REQUIRE(N > 0 && E > 0, "b3d_clr_forward: empty graph (N=%d, E=%d)", N, E);
+  B3D_REQUIRE(nl >= 0 && nl <= N && nr >= 0 && nr <= N, "b3d_clr_forward: bad modality row counts");
+  B3D_REQUIRE(nl == 0 || (in->pointnet_out && in->lidar_nodes), "b3d_clr_forward: LiDAR rows without data");
+  B3D_REQUIRE(nr == 0 || (in->radarnet_out && in->radar_nodes), "b3d_clr_forward: radar rows without data");
+  const bool tr = flags & B3D_FLAG_TRAINING;
+  Ws w;
+  carve(w, workspace, workspace_bytes, N, E, nl, nr, depth, flags);
+  if (!w.ok) return fail(B3D_ERR_WORKSPACE, "b3d_clr_forward: workspace %zu < %zu bytes", workspace_bytes, w.bytes);
+  B3D_TRY(pack_all(pw, w, tr, stream));
+
+  // ---- x_sens = x_img | x_lidar | x_radar; rows without a modality stay zero (:127-141,172) ------
+  B3D_HIP_CHECK(hipMemsetAsync(w.xsens, 0, (size_t)N * XS * sizeof(float), stream));
+  hipLaunchKernelGGL(copy_cols_kernel, dim3(((long)N * 96 + 255) / 256), dim3(256), 0, stream, in->x_img, 96, w.xsens, XS, 0, N, 96);
+  B3D_TRY(launch_check("copy_cols_kernel"));
+  if (nl > 0) {  // fc_lidar_encoder 256-192-128 on the LiDAR rows, scattered to their nodes
+    using In = LoadAligned<16>;
+    using Out = StoreAligned<8>;
+    ChainFwdArgs<In, Out> a;
+    memset(&a, 0, sizeof(a));
+    a.rows = nl; a.in = In{in->pointnet_out, nullptr, 256, 0}; a.out = Out{w.xsens, in->lidar_nodes, XS, 96};
+    a.save[0] = w.fl_a1; a.wpack = w.wp_fl;
+    B3D_TRY(launch_rows<kNWNode>(chain_fwd_kernel<SeqFL, 0x1u, In, Out, kNWNode>, "fc_lidar_encoder", a, nl, stream));
+  }
+  if (nr > 0) {  // fc_radar_encoder 256-192-128-64
+    using In = LoadAligned<16>;
+    using Out = StoreAligned<4>;
+    ChainFwdArgs<In, Out> a;
+    memset(&a, 0, sizeof(a));
+    a.rows = nr; a.in = In{in->radarnet_out, nullptr, 256, 0}; a.out = Out{w.xsens, in->radar_nodes, XS, 224};
+    a.save[0] = w.fr_a1; a.save[1] = w.fr_a2; a.wpack = w.wp_fr;
+    B3D_TRY(launch_rows<kNWNode>(chain_fwd_kernel<SeqFR, 0x3u, In, Out, kNWNode>, "fc_radar_encoder", a, nr, stream));
+  }
+  B3D_HIP_CHECK(hipMemcpyAsync(out_x_sens, w.xsens, (size_t)N * XS * sizeof(float), hipMemcpyDeviceToDevice, stream));
+
+  // ---- cross-edge modality attention, hoisted to nodes: s = z_radar | z_lidar | z_img (:143-161) ----
+  B3D_TRY(affine_fwd<96>(w, 0, N, 0, 192, stream));
+  B3D_TRY(affine_fwd<128>(w, 1, N, 96, 64, stream));
+  B3D_TRY(affine_fwd<64>(w, 2, N, 224, 0, stream));
+
+  {  // edge encoder: edge_attr.float() -> 4-16-32-64 (:123)
+    ChainFwdArgs<LoadEdgeAttrF64, StoreAligned<4>> a;
+    memset(&a, 0, sizeof(a));
+    a.rows = E; a.in.ptr = in->edge_attr; a.out = StoreAligned<4>{w.e[0], nullptr, D::DE, 0};
+    a.save_in = w.ea_pad; a.save[0] = w.ee_a1; a.save[1] = w.ee_a2; a.wpack = w.wp_ee;
+    B3D_TRY(launch_rows<kNWEdge>(chain_fwd_kernel<SeqEE, 0x3u, LoadEdgeAttrF64, StoreAligned<4>, kNWEdge>, "edge_encoder", a, E, stream));
+  }
+  {  // att_edge_encoder( s[dst] | s[src] | e ) 640-512-384-256-128-64 (:161-164)
+    using In0 = LoadConcat3<18, 18, 4>;
+    In0 i0{LoadAligned<18>{w.s, g->dst, XS, 0}, LoadAligned<18>{w.s, g->src, XS, 0}, LoadAligned<4>{w.e[0], nullptr, D::DE, 0}};
+    B3D_TRY((wide<SeqAT0, true, true>("att_edge_encoder.0", i0, E, w.A[0], 512, 0, nullptr, w.wp_at[0], stream)));
+    B3D_TRY((wide<SeqAT1, true, true>("att_edge_encoder.2", LoadAligned<32>{w.A[0], nullptr, 512, 0}, E, w.A[1], 384, 0, nullptr, w.wp_at[1], stream)));
+    B3D_TRY((wide<SeqAT2, true, true>("att_edge_encoder.4", LoadAligned<24>{w.A[1], nullptr, 384, 0}, E, w.A[2], 256, 0, nullptr, w.wp_at[2], stream)));
+    B3D_TRY((wide<SeqAT3, true, true>("att_edge_encoder.6", LoadAligned<16>{w.A[2], nullptr, 256, 0}, E, w.A[3], 128, 0, nullptr, w.wp_at[3], stream)));
+    B3D_TRY((wide<SeqAT4, false, true>("att_edge_encoder.8", LoadAligned<8>{w.A[3], nullptr, 128, 0}, E, w.att, 64, 0, nullptr, w.wp_at[4], stream)));
+  }
+  {  // node encoder 19-48-96 (:174-176)
+    ChainFwdArgs<LoadUnaligned<19>, StoreAligned<6>> a;
+    memset(&a, 0, sizeof(a));
+    a.rows = N; a.in.ptr = in->pose_feats; a.out = StoreAligned<6>{w.x[0], nullptr, D::DX, 0};
+    a.save_in = w.pose_pad; a.save[0] = w.ne_a1; a.wpack = w.wp_ne;
+    B3D_TRY(launch_rows<kNWNode>(chain_fwd_kernel<SeqNE, 0x1u, LoadUnaligned<19>, StoreAligned<6>, kNWNode>, "node_encoder", a, N, stream));
+  }
+  for (int l = 0; l < depth; ++l) {
+    if ((flags & B3D_FLAG_RUN_DEAD_KNN) && (l % 2 == 0)) {
+      B3D_REQUIRE(in->node_timestamps != nullptr, "node_timestamps required with B3D_FLAG_RUN_DEAD_KNN");
+      B3D_TRY(knn_gat_block<D::DX>(w.knn, w.x[l], in->node_timestamps, N, pw->knn_conv, 20, stream));
+    }
+    EdgeFwdArgs ea;
+    memset(&ea, 0, sizeof(ea));
+    ea.E = E; ea.src = g->src; ea.dst = g->dst; ea.x = w.x[l]; ea.x0 = w.x[0]; ea.e_in = w.e[l]; ea.a_in = w.att;
+    ea.e_out = w.e[l + 1]; ea.fut = w.fut; ea.past = w.past;
+    ea.sH1 = w.sH1[l]; ea.sH2 = w.sH2[l]; ea.sF1 = w.sF1[l]; ea.sP1 = w.sP1[l]; ea.wpack = w.wp_efwd;
+    B3D_TRY(launch_rows<kNWEdge>(mp_edge_fwd_kernel<D, kNWEdge>, "mp_edge_fwd", ea, E, stream, B3D_K_EDGE_FWD));
+    NodeFwdArgs na;
+    memset(&na, 0, sizeof(na));
+    na.N = N; na.dst_ptr = g->dst_ptr; na.dst_perm = g->dst_perm; na.src_ptr = g->src_ptr; na.src_perm = g->src_perm;
+    na.past = w.past; na.fut = w.fut; na.M = w.M[l]; na.x_out = w.x[l + 1]; na.sH1 = w.nH1[l]; na.sH2 = w.nH2[l];
+    na.wpack = w.wp_nfwd;
+    B3D_TRY(launch_rows<kNWNode>(mp_node_fwd_kernel<D, kNWNode>, "mp_node_fwd", na, N, stream, B3D_K_NODE_FWD));
+  }
+  {  // edge classifier 64-32-16-8-1 + Sigmoid (:49-58,188)
+    ChainFwdArgs<LoadAligned<4>, StoreScalar> a;
+    memset(&a, 0, sizeof(a));
+    a.rows = E; a.in = LoadAligned<4>{w.e[depth], nullptr, D::DE, 0}; a.out = StoreScalar{w.prob, 1};
+    a.save[0] = w.c_a1; a.save[1] = w.c_a2; a.save[2] = w.c_a3; a.wpack = w.wp_cls;
+    B3D_TRY(launch_rows<kNWEdge>(chain_fwd_kernel<SeqCls, 0x7u, LoadAligned<4>, StoreScalar, kNWEdge>, "edge_classifier", a, E, stream));
+    B3D_HIP_CHECK(hipMemcpyAsync(out_prob, w.prob, (size_t)E * sizeof(float), hipMemcpyDeviceToDevice, stream));
+  }
+  return B3D_OK;
+}
+
+extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, const b3d_clr_inputs* in, int32_t depth,
+                                void* workspace, size_t workspace_bytes, const float* d_prob, const float* d_x_sens,
+                                const b3d_clr_grads* gr, b3d_stream stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  B3D_TRY(check_weights(pw));
+  B3D_REQUIRE(g && in && workspace && gr, "b3d_clr_backward: null argument");
+  B3D_REQUIRE(depth >= 1 && depth <= 15, "b3d_clr_backward: depth %d outside [1,15]", depth);
+  const int N = g->N, E = g->E, nl = in->n_lidar, nr = in->n_radar;
+  B3D_REQUIRE(N > 0 && E > 0, "b3d_clr_backward: empty graph");
+  Ws w;
+  carve(w, workspace, workspace_bytes, N, E, nl, nr, depth, B3D_FLAG_TRAINING);
+  if (!w.ok) return fail(B3D_ERR_WORKSPACE, "b3d_clr_backward: workspace %zu < %zu bytes", workspace_bytes, w.bytes);
+  const int* src = g->src;
+  const int* dst = g->dst;
+  const size_t eL1 = (size_t)E * D::EH1, eL2 = (size_t)E * D::EH2, eLe = (size_t)E * D::DE, eLm = (size_t)E * D::MH;
+  const size_t nLm = (size_t)N * D::NIN, nLx = (size_t)N * D::DX, nL1 = (size_t)N * D::NH1, nL2 = (size_t)N * D::NH2;
+  WgArgs smallE, smallN, fc;       // LDS-staged weight gradients of the narrow / unaligned layers
+  smallE.njobs = smallN.njobs = fc.njobs = 0;
+
+  // ---- classifier (with the sigmoid derivative) -> d e[depth] --------------------------------------
+  int cur = 0;
+  {
+    ChainBwdArgs<LoadSigmoidGrad, StoreAligned<4>> a;
+    memset(&a, 0, sizeof(a));
+    a.rows = E; a.in = LoadSigmoidGrad{d_prob, w.prob}; a.out = StoreAligned<4>{w.de[cur], nullptr, D::DE, 0};
+    a.gtop = w.gc_top;
+    a.act[0] = w.c_a3; a.act[1] = w.c_a2; a.act[2] = w.c_a1; a.act[3] = nullptr;
+    a.gsave[0] = w.gc3; a.gsave[1] = w.gc2; a.gsave[2] = w.gc1; a.gsave[3] = nullptr;
+    a.wpack = w.wp_clsT;
+    B3D_TRY(launch_rows<kNWEdge>(chain_bwd_kernel<SeqClsT, LoadSigmoidGrad, StoreAligned<4>, kNWEdge>, "edge_classifier_bwd", a, E, stream));
+    WgJob j3 = make_job(w.lin[C3], E, seg(w.gc_top, nullptr, 16, 0, 1)); add_act(j3, seg(w.c_a3, nullptr, 16, 0, 8)); smallE.jobs[smallE.njobs++] = j3;
+    WgJob j2 = make_job(w.lin[C2], E, seg(w.gc3, nullptr, 16, 0, 8)); add_act(j2, seg(w.c_a2, nullptr, 16, 0, 16)); smallE.jobs[smallE.njobs++] = j2;
+    WgJob j1 = make_job(w.lin[C1], E, seg(w.gc2, nullptr, 16, 0, 16)); add_act(j1, seg(w.c_a1, nullptr, 32, 0, 32)); smallE.jobs[smallE.njobs++] = j1;
+    WgJob j0 = make_job(w.lin[C0], E, seg(w.gc1, nullptr, 32, 0, 32)); add_act(j0, seg(w.e[depth], nullptr, D::DE, 0, D::DE)); smallE.jobs[smallE.njobs++] = j0;
+  }
+
+  // ---- message-passing layers, last to first (data gradients; G tensors kept per layer) -------------
+  bool dx0_first = true, da_first = true;
+  for (int l = depth - 1; l >= 0; --l) {
+    const bool msgs = (l < depth - 1);
+    if (msgs) {
+      NodeBwdArgs nb;
+      memset(&nb, 0, sizeof(nb));
+      nb.N = N; nb.dst_ptr = g->dst_ptr; nb.dst_perm = g->dst_perm; nb.src_ptr = g->src_ptr; nb.src_perm = g->src_perm;
+      nb.gdst = w.gdst; nb.gsrc = w.gsrc; nb.dx0_acc = w.dx0_acc; nb.dx0_first = dx0_first ? 1 : 0;
+      nb.sH1 = w.nH1[l]; nb.sH2 = w.nH2[l];
+      nb.dM = w.dM + l * nLm; nb.Gdx = w.Gdx + l * nLx; nb.GdH2 = w.GnH2 + l * nL2; nb.GdH1 = w.GnH1 + l * nL1;
+      nb.wpack = w.wp_nbwd;
+      B3D_TRY(launch_rows<kNWNode>(mp_node_bwd_kernel<D, kNWNode>, "mp_node_bwd", nb, N, stream, B3D_K_NODE_BWD));
+      dx0_first = false;
+    }
+    EdgeBwdArgs eb;
+    memset(&eb, 0, sizeof(eb));
+    eb.E = E; eb.src = src; eb.dst = dst;
+    eb.dM = msgs ? w.dM + l * nLm : nullptr;
+    eb.de_out = w.de[cur]; eb.de_in = w.de[cur ^ 1];
+    eb.sH1 = w.sH1[l]; eb.sH2 = w.sH2[l]; eb.sF1 = w.sF1[l]; eb.sP1 = w.sP1[l];
+    eb.da_acc = w.da_acc; eb.da_first = da_first ? 1 : 0;
+    eb.gdst = w.gdst; eb.gsrc = w.gsrc;
+    eb.GdH1 = w.GdH1 + l * eL1; eb.GdH2 = w.GdH2 + l * eL2; eb.Gde = w.Gde + l * eLe;
+    eb.GdF1 = w.GdF1 + l * eLm; eb.GdP1 = w.GdP1 + l * eLm;
+    if (msgs) {
+      eb.wpack = w.wp_ebwd;
+      B3D_TRY(launch_rows<kNWEdge>(mp_edge_bwd_kernel<D, true, kNWEdge>, "mp_edge_bwd", eb, E, stream, B3D_K_EDGE_BWD));
+    } else {
+      eb.wpack = w.wp_ebwd_nm;
+      B3D_TRY(launch_rows<kNWEdge>(mp_edge_bwd_kernel<D, false, kNWEdge>, "mp_edge_bwd_last", eb, E, stream, B3D_K_OTHER));
+    }
+    da_first = false;
+    cur ^= 1;
+  }
+
+  // ---- att_edge_encoder backward: d att (summed over the layers) -> d(s[dst] | s[src] | e) ------------
+  B3D_TRY((wide<SeqAT4T, false, false>("att_edge_encoder.8^T", LoadAligned<4>{w.da_acc, nullptr, 64, 0}, E, w.dA[0], 128, 0, w.A[3], w.wp_atT[4], stream)));
+  B3D_TRY((wide<SeqAT3T, false, false>("att_edge_encoder.6^T", LoadAligned<8>{w.dA[0], nullptr, 128, 0}, E, w.dA[1], 256, 0, w.A[2], w.wp_atT[3], stream)));
+  B3D_TRY((wide<SeqAT2T, false, false>("att_edge_encoder.4^T", LoadAligned<16>{w.dA[1], nullptr, 256, 0}, E, w.dA[2], 384, 0, w.A[1], w.wp_atT[2], stream)));
+  B3D_TRY((wide<SeqAT1T, false, false>("att_edge_encoder.2^T", LoadAligned<24>{w.dA[2], nullptr, 384, 0}, E, w.dA[3], 512, 0, w.A[0], w.wp_atT[1], stream)));
+  B3D_TRY((wide<SeqAT0T, false, false>("att_edge_encoder.0^T", LoadAligned<32>{w.dA[3], nullptr, 512, 0}, E, w.dIn, 640, 0, nullptr, w.wp_atT[0], stream)));
+
+  // ---- modality attention (per node) backward, then the modality heads -------------------------------
+  B3D_TRY(affine_bwd<96>(w, g, 0, N, 0, 192, stream));
+  B3D_TRY(affine_bwd<128>(w, g, 1, N, 96, 64, stream));
+  B3D_TRY(affine_bwd<64>(w, g, 2, N, 224, 0, stream));
+  {
+    const int affd[3] = {96, 128, 64}, xc[3] = {0, 96, 224};
+    for (int m = 0; m < 3; ++m) {
+      WgJob jo = make_job(w.lin[AOC + 2 * m], N, seg(w.gaff_top[m], nullptr, affd[m], 0, affd[m]));
+      add_act(jo, seg(w.aff_v[m], nullptr, affd[m], 0, affd[m]));
+      smallN.jobs[smallN.njobs++] = jo;
+      WgJob jv = make_job(w.lin[AVC + 2 * m], N, seg(w.gaff_v[m], nullptr, affd[m], 0, affd[m]));
+      add_act(jv, seg(w.xsens, nullptr, XS, xc[m], affd[m]));
+      smallN.jobs[smallN.njobs++] = jv;
+    }
+  }
+  if (nl > 0) {  // fc_lidar_encoder: gradient of x_lidar = attention path + upstream d x_sens
+    using In = LoadAdd2<8>;
+    ChainBwdArgs<In, StoreNone> a;
+    memset(&a, 0, sizeof(a));
+    a.rows = nl; a.in = In{w.dxs, XS, 96, d_x_sens, XS, 96, in->lidar_nodes};
+    a.gtop = w.gfl_top; a.act[0] = w.fl_a1; a.gsave[0] = w.gfl1; a.wpack = w.wp_flT;
+    B3D_TRY(launch_rows<kNWNode>(chain_bwd_kernel<SeqFLT, In, StoreNone, kNWNode>, "fc_lidar_encoder_bwd", a, nl, stream));
+    WgJob j1 = make_job(w.lin[FL1], nl, seg(w.gfl_top, nullptr, 128, 0, 128)); add_act(j1, seg(w.fl_a1, nullptr, 192, 0, 192)); fc.jobs[fc.njobs++] = j1;
+    WgJob j0 = make_job(w.lin[FL0], nl, seg(w.gfl1, nullptr, 192, 0, 192)); add_act(j0, seg(in->pointnet_out, nullptr, 256, 0, 256)); fc.jobs[fc.njobs++] = j0;
+  }
+  if (nr > 0) {  // fc_radar_encoder
+    using In = LoadAdd2<4>;
+    ChainBwdArgs<In, StoreNone> a;
+    memset(&a, 0, sizeof(a));
+    a.rows = nr; a.in = In{w.dxs, XS, 224, d_x_sens, XS, 224, in->radar_nodes};
+    a.gtop = w.gfr_top; a.act[0] = w.fr_a2; a.act[1] = w.fr_a1; a.gsave[0] = w.gfr2; a.gsave[1] = w.gfr1; a.wpack = w.wp_frT;
+    B3D_TRY(launch_rows<kNWNode>(chain_bwd_kernel<SeqFRT, In, StoreNone, kNWNode>, "fc_radar_encoder_bwd", a, nr, stream));
+    WgJob j2 = make_job(w.lin[FR2], nr, seg(w.gfr_top, nullptr, 64, 0, 64)); add_act(j2, seg(w.fr_a2, nullptr, 128, 0, 128)); fc.jobs[fc.njobs++] = j2;
+    WgJob j1 = make_job(w.lin[FR1], nr, seg(w.gfr2, nullptr, 128, 0, 128)); add_act(j1, seg(w.fr_a1, nullptr, 192, 0, 192)); fc.jobs[fc.njobs++] = j1;
+    WgJob j0 = make_job(w.lin[FR0], nr, seg(w.gfr1, nullptr, 192, 0, 192)); add_act(j0, seg(in->radarnet_out, nullptr, 256, 0, 256)); fc.jobs[fc.njobs++] = j0;
+  }
+
+  // ---- encoders ----------------------------------------------------------------------------------------
+  {  // node encoder (x = initial_x): running d initial_x + layer-0 scatter transposes
+    using In = LoadNodeEncGrad<6>;
+    ChainBwdArgs<In, StoreNone> a;
+    memset(&a, 0, sizeof(a));
+    a.rows = N;
+    a.in = In{nullptr, dx0_first ? nullptr : w.dx0_acc, w.gdst, w.gsrc, g->dst_ptr, g->dst_perm, g->src_ptr, g->src_perm};
+    a.gtop = w.gn_top; a.act[0] = w.ne_a1; a.gsave[0] = w.gn1; a.wpack = w.wp_neT;
+    B3D_TRY(launch_rows<kNWNode>(chain_bwd_kernel<SeqNET, In, StoreNone, kNWNode>, "node_encoder_bwd", a, N, stream));
+    WgJob n1 = make_job(w.lin[NE1], N, seg(w.gn_top, nullptr, 96, 0, 96)); add_act(n1, seg(w.ne_a1, nullptr, 48, 0, 48)); smallN.jobs[smallN.njobs++] = n1;
+    WgJob n0 = make_job(w.lin[NE0], N, seg(w.gn1, nullptr, 48, 0, 48)); add_act(n0, seg(w.pose_pad, nullptr, 32, 0, 19)); smallN.jobs[smallN.njobs++] = n0;
+  }
+  {  // edge encoder: e[0] feeds layer 0 AND att_edge_encoder (columns 576:640 of its input)
+    using In = LoadAdd2<4>;
+    ChainBwdArgs<In, StoreNone> a;
+    memset(&a, 0, sizeof(a));
+    a.rows = E; a.in = In{w.de[cur], D::DE, 0, w.dIn, 640, 576, nullptr};
+    a.gtop = w.ge_top; a.act[0] = w.ee_a2; a.act[1] = w.ee_a1; a.gsave[0] = w.ge2; a.gsave[1] = w.ge1; a.wpack = w.wp_eeT;
+    B3D_TRY(launch_rows<kNWEdge>(chain_bwd_kernel<SeqEET, In, StoreNone, kNWEdge>, "edge_encoder_bwd", a, E, stream));
+    WgJob e2 = make_job(w.lin[EE2], E, seg(w.ge_top, nullptr, 64, 0, 64)); add_act(e2, seg(w.ee_a2, nullptr, 32, 0, 32)); smallE.jobs[smallE.njobs++] = e2;
+    WgJob e1 = make_job(w.lin[EE1], E, seg(w.ge2, nullptr, 32, 0, 32)); add_act(e1, seg(w.ee_a1, nullptr, 16, 0, 16)); smallE.jobs[smallE.njobs++] = e1;
+    WgJob e0 = make_job(w.lin[EE0], E, seg(w.ge1, nullptr, 16, 0, 16)); add_act(e0, seg(w.ea_pad, nullptr, 16, 0, 4)); smallE.jobs[smallE.njobs++] = e0;
+  }
+  B3D_TRY((launch_wgrad<8, 1>(smallE, stream, B3D_K_WGRAD_OTHER)));
+  B3D_TRY((launch_wgrad<8, 1>(smallN, stream, B3D_K_WGRAD_OTHER)));
+  B3D_TRY((launch_wgrad<8, 2>(fc, stream, B3D_K_WGRAD_OTHER)));
+
+  // ---- streamed weight gradients: message-passing stacks (all layers) + att_edge_encoder -------------
+  {
+    WsLauncher wl;
+    wl.begin(w.ws_table, kTableCap, w.ws_task_job, kTaskCap, stream);
+    hipLaunchKernelGGL(iota_kernel, dim3(((E > N ? E : N) + 255) / 256), dim3(256), 0, stream, w.iota, E > N ? E : N);
+    B3D_TRY(launch_check("iota_kernel"));
+    B3D_HIP_CHECK(hipMemsetAsync(w.zrow, 0, 256 * sizeof(float), stream));
+    const int* iota = w.iota;
+    struct Col { const float* p; const int* idx; long vstride; int stride; int col0; int width; };   // activation columns
+    // Every (64-row group of G) x (<= 96-column group of an activation segment) pair is one job.
+    auto add_matrix = [&](int lin, long rows, int nvar, int rpt, const float* gp, const int* gidx, long gvs, int gstride, int gcol0,
+                          const Col* cols, int ncols) {
+      if (nvar <= 0) return;
+      LinSlab& ls = w.lin[lin];
+      ls.used = true;
+      bool first_job_of_group = true;
+      for (int g0 = 0; g0 < ls.N; g0 += 64) {
+        const int gw = (ls.N - g0 >= 64) ? 64 : ls.N - g0;       // 64, or the 32-row tail of a 96-row matrix
+        int wcol = 0;
+        first_job_of_group = true;
+        for (int ci = 0; ci < ncols; ++ci) {
+          for (int c0 = 0; c0 < cols[ci].width;) {
+            int cw = cols[ci].width - c0;           // column groups of 96 or 64: 128 -> 64+64, 256 -> 96+96+64
+            cw = (cw == 128 || cw < 96) ? 64 : 96;
+            WsJob jb;
+            memset(&jb, 0, sizeof(jb));
+            jb.g.ptr = gp; jb.g.idx = gidx ? gidx : iota; jb.g.vstride = gvs; jb.g.stride = gstride; jb.g.col0 = gcol0 + g0;
+            jb.act[0].ptr = cols[ci].p; jb.act[0].idx = cols[ci].idx ? cols[ci].idx : iota; jb.act[0].vstride = cols[ci].vstride;
+            jb.act[0].stride = cols[ci].stride; jb.act[0].col0 = cols[ci].col0 + c0;
+            jb.act[1] = jb.act[0];
+            jb.wcol[0] = wcol + c0; jb.wcol[1] = 0; jb.wrow = g0;
+            jb.write_bias = first_job_of_group ? 1 : 0;
+            first_job_of_group = false;
+            jb.shape = (gw == 64) ? (cw == 96 ? WS_64_96 : WS_64_64) : WS_32_64;   // 32-row tail only with 64-col groups
+            jb.rows = (int)rows; jb.nvar = nvar; jb.rows_per_task = rpt;
+            jb.NP = ls.NP; jb.KP = ls.KP; jb.slab = ls.slab;
+            wl.add(jb);
+            c0 += cw;
+          }
+          wcol += cols[ci].width;
+        }
+      }
+    };
+    const int rp = kStreamRowsPerTask, rpa = kStreamRowsPerTaskAtt;
+    {  // edge_update: x[l][dst] 96 | x[l][src] 96 | e[l] 64 | att 64
+      Col c[4] = {{w.x[0], dst, (long)nLx, D::DX, 0, 96}, {w.x[0], src, (long)nLx, D::DX, 0, 96},
+                  {w.e[0], nullptr, (long)eLe, D::DE, 0, 64}, {w.att, nullptr, 0, 64, 0, 64}};
+      add_matrix(EU0, E, depth, rp, w.GdH1, nullptr, eL1, D::EH1, 0, c, 4);
+      Col c1[1] = {{w.sH1[0], nullptr, (long)eL1, D::EH1, 0, 256}};
+      add_matrix(EU1, E, depth, rp, w.GdH2, nullptr, eL2, D::EH2, 0, c1, 1);
+      Col c2[1] = {{w.sH2[0], nullptr, (long)eL2, D::EH2, 0, 128}};
+      add_matrix(EU2, E, depth, rp, w.Gde, nullptr, eLe, D::DE, 0, c2, 1);
+    }
+    {  // message stacks (layers 0 .. depth-2): x[l][.] 96 | e[l+1] 64 | x0[.] 96
+      Col cp[3] = {{w.x[0], src, (long)nLx, D::DX, 0, 96}, {w.e[1], nullptr, (long)eLe, D::DE, 0, 64}, {w.x[0], src, 0, D::DX, 0, 96}};
+      add_matrix(PA0, E, depth - 1, rp, w.GdP1, nullptr, eLm, D::MH, 0, cp, 3);
+      Col cp1[1] = {{w.sP1[0], nullptr, (long)eLm, D::MH, 0, 192}};
+      add_matrix(PA1, E, depth - 1, rp, w.dM, dst, nLm, D::NIN, 0, cp1, 1);
+      Col cf[3] = {{w.x[0], dst, (long)nLx, D::DX, 0, 96}, {w.e[1], nullptr, (long)eLe, D::DE, 0, 64}, {w.x[0], dst, 0, D::DX, 0, 96}};
+      add_matrix(FU0, E, depth - 1, rp, w.GdF1, nullptr, eLm, D::MH, 0, cf, 3);
+      Col cf1[1] = {{w.sF1[0], nullptr, (long)eLm, D::MH, 0, 192}};
+      add_matrix(FU1, E, depth - 1, rp, w.dM, src, nLm, D::NIN, D::DM, cf1, 1);
+    }
+    {  // node update (layers 0 .. depth-2)
+      Col c0[1] = {{w.M[0], nullptr, (long)nLm, D::NIN, 0, 256}};
+      add_matrix(CF0, N, depth - 1, rp, w.GnH1, nullptr, nL1, D::NH1, 0, c0, 1);
+      Col c1[1] = {{w.nH1[0], nullptr, (long)nL1, D::NH1, 0, 192}};
+      add_matrix(CF1, N, depth - 1, rp, w.GnH2, nullptr, nL2, D::NH2, 0, c1, 1);
+      Col c2[1] = {{w.nH2[0], nullptr, (long)nL2, D::NH2, 0, 128}};
+      add_matrix(CF2, N, depth - 1, rp, w.Gdx, nullptr, nLx, D::DX, 0, c2, 1);
+    }
+    {  // att_edge_encoder
+      Col c0[3] = {{w.s, dst, 0, XS, 0, 288}, {w.s, src, 0, XS, 0, 288}, {w.e[0], nullptr, 0, D::DE, 0, 64}};
+      add_matrix(AT0, E, 1, rpa, w.dA[3], nullptr, 0, 512, 0, c0, 3);
+      Col c1[1] = {{w.A[0], nullptr, 0, 512, 0, 512}};
+      add_matrix(AT1, E, 1, rpa, w.dA[2], nullptr, 0, 384, 0, c1, 1);
+      Col c2[1] = {{w.A[1], nullptr, 0, 384, 0, 384}};
+      add_matrix(AT2, E, 1, rpa, w.dA[1], nullptr, 0, 256, 0, c2, 1);
+      Col c3[1] = {{w.A[2], nullptr, 0, 256, 0, 256}};
+      add_matrix(AT3, E, 1, rpa, w.dA[0], nullptr, 0, 128, 0, c3, 1);
+      Col c4[1] = {{w.A[3], nullptr, 0, 128, 0, 128}};
+      add_matrix(AT4, E, 1, rpa, w.da_acc, nullptr, 0, 64, 0, c4, 1);
+    }
+    wl.launch(w.zrow, B3D_K_WGRAD_EDGE);
+    B3D_REQUIRE(wl.status == 0, "streaming weight gradient: job table overflow (%d jobs, %d tasks)", wl.njobs, wl.total_tasks);
+    B3D_TRY(launch_check("wstream_kernel"));
+  }
+
+  // ---- slabs -> parameter gradients -----------------------------------------------------------------------
+  {
+    float* dw[LIN_COUNT];
+    float* db[LIN_COUNT];
+    auto put = [&](int first, const b3d_linear_grad* a, int n) { for (int i = 0; i < n; ++i) { dw[first + i] = a[i].w; db[first + i] = a[i].b; } };
+    put(EE0, gr->edge_encoder, 3); put(NE0, gr->node_encoder, 2); put(C0, gr->edge_classifier, 4);
+    put(FL0, gr->fc_lidar_encoder, 2); put(FR0, gr->fc_radar_encoder, 3); put(AT0, gr->att_edge_encoder, 5);
+    put(EU0, gr->mp.edge_update, 3); put(PA0, gr->mp.create_past_msgs, 2); put(FU0, gr->mp.create_future_msgs, 2);
+    put(CF0, gr->mp.combine_future_past, 3);
+    const b3d_mha_grad* mg[3] = {&gr->c2c_att, &gr->l2l_att, &gr->r2r_att};
+    const int dd[3] = {96, 128, 64};
+    for (int m = 0; m < 3; ++m) {
+      // q / k thirds of in_proj receive no gradient (softmax over one key is constant)
+      if (mg[m]->in_proj_weight) B3D_HIP_CHECK(hipMemsetAsync(mg[m]->in_proj_weight, 0, (size_t)3 * dd[m] * dd[m] * sizeof(float), stream));
+      if (mg[m]->in_proj_bias) B3D_HIP_CHECK(hipMemsetAsync(mg[m]->in_proj_bias, 0, (size_t)3 * dd[m] * sizeof(float), stream));
+      dw[AVC + 2 * m] = mg[m]->in_proj_weight ? mg[m]->in_proj_weight + (size_t)2 * dd[m] * dd[m] : nullptr;
+      db[AVC + 2 * m] = mg[m]->in_proj_bias ? mg[m]->in_proj_bias + 2 * dd[m] : nullptr;
+      dw[AOC + 2 * m] = mg[m]->out_proj_weight;
+      db[AOC + 2 * m] = mg[m]->out_proj_bias;
+    }
+    RedArgs ra;
+    ra.nentries = 0;
+    for (int i = 0; i < LIN_COUNT; ++i) {
+      LinSlab& ls = w.lin[i];
+      if (!ls.used) {
+        if (dw[i]) B3D_HIP_CHECK(hipMemsetAsync(dw[i], 0, (size_t)ls.N * ls.K * sizeof(float), stream));
+        if (db[i]) B3D_HIP_CHECK(hipMemsetAsync(db[i], 0, (size_t)ls.N * sizeof(float), stream));
+        continue;
+      }
+      ra.e[ra.nentries++] = red_entry(ls, dw[i], db[i]);
+      if (ra.nentries == kRedMaxEntries) { B3D_TRY(launch_reduce(ra, stream)); ra.nentries = 0; }
+    }
+    B3D_TRY(launch_reduce(ra, stream));
+  }
+  return B3D_OK;
+}

@@ -47,7 +47,7 @@ inline void knn_carve(KnnWs& k, Carver& c, int N, int D) {
 // (i, s) counts over slice s of the nodes (timestamps staged through LDS as 32-bit offsets from
 // ts[0]) and adds its partial counts with integer atomics (exact, order independent).
 constexpr int kRankSlices = 16;
-__global__ __launch_bounds__(256) void knn_rank_count_kernel(const int64_t* __restrict__ ts, int N,
+static __global__ __launch_bounds__(256) void knn_rank_count_kernel(const int64_t* __restrict__ ts, int N,
                                                              int* __restrict__ cnt /* [3][N] zeroed */) {
   __shared__ int tile[256];
   const int64_t t0 = ts[0];
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void knn_rank_count_kernel(const int64_t* __re
   }
 }
 
-__global__ void knn_rank_finish_kernel(const int* __restrict__ cnt, int N, int* __restrict__ rank,
+static __global__ void knn_rank_finish_kernel(const int* __restrict__ cnt, int N, int* __restrict__ rank,
                                        int* __restrict__ order, int* __restrict__ fbeg, int* __restrict__ fend) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;

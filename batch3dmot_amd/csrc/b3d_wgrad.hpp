@@ -289,7 +289,7 @@ struct RedArgs {
   RedEntry e[kRedMaxEntries];
 };
 
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedArgs a) {
+static __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedArgs a) {
   const int id = blockIdx.x * 256 + threadIdx.x;
   if (id >= a.total) return;
   int j = 0;

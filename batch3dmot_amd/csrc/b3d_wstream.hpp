@@ -239,7 +239,7 @@ enum {
   WS_SHAPES = 7
 };
 
-__global__ void ws_table_kernel(const WsTableArgs a) {
+static __global__ void ws_table_kernel(const WsTableArgs a) {
   const int j = blockIdx.x;
   if (j >= a.n) return;
   const int* srcw = reinterpret_cast<const int*>(&a.jobs[j]);
@@ -248,7 +248,7 @@ __global__ void ws_table_kernel(const WsTableArgs a) {
   for (int t = threadIdx.x; t < a.jobs[j].ntasks; t += blockDim.x) a.task_job[a.jobs[j].task_begin + t] = a.first + j;
 }
 
-__global__ __launch_bounds__(kWsWaves * 64, 1) void wstream_kernel(const WsJob* __restrict__ table,
+static __global__ __launch_bounds__(kWsWaves * 64, 1) void wstream_kernel(const WsJob* __restrict__ table,
                                                                    const int* __restrict__ task_job, int total_tasks,
                                                                    const float* __restrict__ zero_row) {
   __shared__ WsJob sj[kWsWaves];

@@ -1,0 +1,120 @@
+"""GPU: the HIP GNN (camera + LiDAR + radar) path against the golden vectors of the reference
+(clr_att_gnn.py executed verbatim, oracle/make_golden.py) and the CPU oracle."""
+import ctypes as C
+
+import pytest
+import torch
+
+from conftest import data_from, load_golden
+from oracle.seeded import grad_digest, seeded_fill_
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def _loss_weights(t, salt):
+    g = torch.Generator().manual_seed(1234 + salt)
+    return torch.randn(t.shape, generator=g)
+
+
+def _model(salt, dev):
+    from batch3dmot_amd import encoders
+    from batch3dmot_amd.clr_att_gnn import GNN
+    m = GNN(encoders.ResNetAE(), encoders.PointNetClassifier(k=7), encoders.RadarNetClassifier(k=7))
+    seeded_fill_(m, salt)
+    return m.to(dev).eval()
+
+
+def _digest_close(have, want, rtol=1e-4):
+    for n, w in want.items():
+        h = have[n]
+        if w is None:
+            assert h is None, n
+            continue
+        if n.endswith("in_proj_weight") or n.endswith("in_proj_bias"):
+            continue        # q / k thirds: reference holds ~1e-12 rounding noise, the kernels exact zeros
+        tol = rtol * max(w["norm"], 1e-6)
+        assert abs(h["norm"] - w["norm"]) <= tol, (n, h["norm"], w["norm"])
+        scale = max(w["norm"], 1e-6) * (torch.tensor(w["shape"]).prod().item() ** 0.5)
+        assert abs(h["proj"] - w["proj"]) <= rtol * scale, n
+        torch.testing.assert_close(h["head"], w["head"], rtol=1e-3, atol=tol)
+
+
+def test_state_dict_keys_match_reference():
+    g = load_golden("g2_clr.pt")
+    m = _model(g["salt"], "cpu")
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == g["state_keys"]
+
+
+@pytest.mark.parametrize("name", ["g2_clr.pt", "g2b_clr_one_lidar.pt"])
+def test_forward_backward_match_reference_golden(name):
+    from batch3dmot_amd import _lib
+    dev = torch.device("cuda:0")
+    g = load_golden(name)
+    data = data_from(g["data"]).to(dev)
+    m = _model(g["salt"], dev)
+    m.keep_workspace = True
+    out, x_sens = m(data)
+    assert rel(out, g["out"]) < TOL and rel(x_sens, g["x_sens"]) < TOL
+    ws, nbytes, flags, N, E, nl, nr = m._last_workspace
+    assert nl == int(g["encoder_out"]["has_lidar"].sum()) and nr == int(g["encoder_out"]["has_radar"].sum())
+    lib = _lib.load()
+    for l in range(1, m.depth + 1):
+        px, pe, pa = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _lib.check(lib.b3d_clr_debug_ptrs(ws.data_ptr(), nbytes, N, E, nl, nr, m.depth, flags, l,
+                                          C.byref(px), C.byref(pe), C.byref(pa)), "ptrs")
+        x = ws[px.value - ws.data_ptr():][:N * 96 * 4].view(torch.float32).view(N, 96)
+        e = ws[pe.value - ws.data_ptr():][:E * 64 * 4].view(torch.float32).view(E, 64)
+        gx, ge = g["layers"][l - 1]
+        assert rel(x, gx) < TOL and rel(e, ge) < TOL
+    loss = (out * _loss_weights(out, 0).to(dev)).sum() + (x_sens * _loss_weights(x_sens, 1).to(dev)).sum() * 0.1
+    loss.backward()
+    grads = {n: p.grad for n, p in m.named_parameters() if p.requires_grad}
+    assert all(v is None for k, v in grads.items() if k.startswith("knn_conv"))
+    for att in ("c2c_att", "l2l_att", "r2r_att"):         # dead query / key projections
+        gw = grads[att + ".in_proj_weight"]
+        assert float(gw[: 2 * gw.shape[0] // 3].abs().max()) == 0.0
+    _digest_close(grad_digest(grads), g["grad_digest"])
+
+
+def test_modality_masks_and_sticky_eval():
+    from batch3dmot_amd.clr_att_gnn import modality_present
+    dev = torch.device("cuda:0")
+    g = load_golden("g2b_clr_one_lidar.pt")
+    data = data_from(g["data"]).to(dev)
+    assert torch.equal(modality_present(data.lidar_feats).cpu(), g["encoder_out"]["has_lidar"])
+    assert torch.equal(modality_present(data.radar_feats).cpu(), g["encoder_out"]["has_radar"])
+    m = _model(g["salt"], dev).train()
+    m(data)
+    assert not m.pointnet.training and not m.fc_lidar_encoder.training      # < 2 LiDAR rows (clr_att_gnn.py:128-130)
+
+
+def test_train_step_matches_reference():
+    """H1 (train.py:124-160): loss, and every trainable weight after one Adam step."""
+    from batch3dmot_amd.train_step import make_optimizer, train_step
+    dev = torch.device("cuda:0")
+    g = load_golden("g3_train_step.pt")
+    data = data_from(g["data"]).to(dev)
+    m = _model(g["salt"], dev)
+    opt = make_optimizer(m)
+    loss, out, _ = train_step(m, data, opt, batch_size=2, loss_kind="cb", logits=False)
+    assert rel(out.reshape(-1), g["out"].reshape(-1)) < TOL
+    assert abs(float(loss) - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
+    after = {n: p.detach() for n, p in m.named_parameters() if p.requires_grad}
+    have, want = grad_digest(after), g["after_digest"]
+    for n, w in want.items():
+        assert abs(have[n]["norm"] - w["norm"]) <= 2e-6 * max(w["norm"], 1e-6), n
+        torch.testing.assert_close(have[n]["head"], w["head"], rtol=1e-5, atol=2e-7)
+
+
+def test_use_attention_false_is_rejected():
+    from batch3dmot_amd import encoders
+    from batch3dmot_amd.clr_att_gnn import GNN
+    m = GNN(encoders.ResNetAE(), encoders.PointNetClassifier(k=7), encoders.RadarNetClassifier(k=7), use_attention=False)
+    with pytest.raises(NotImplementedError):
+        m(data_from(load_golden("g2_clr.pt")["data"]))
