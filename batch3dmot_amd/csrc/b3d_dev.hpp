@@ -311,7 +311,8 @@ __device__ __forceinline__ void copy_blocks(v4f* __restrict__ a, const v4f* __re
 // Sum of rows listed in perm[beg..end) (a CSR / CSC segment), NBLK blocks starting at col0.
 // perm == nullptr means identity.  Rows are fetched four (two for wide rows) at a time so that
 // several independent loads are in flight per lane, and added in list order (fixed summation
-// order -> bitwise reproducible).
+// order -> bitwise reproducible).  (Measured on MI355X: deeper unrolling, index prefetch with
+// branch-free masked batches, and a fused two-list variant were all slower than this form.)
 template <int NBLK>
 __device__ __forceinline__ void segment_sum(const float* __restrict__ base, int stride, int col0,
                                             const int* __restrict__ perm, int beg, int end,

@@ -134,9 +134,17 @@ __global__ __launch_bounds__(256) void knn_select_kernel(const float* __restrict
   };
   const float INF = __builtin_inff();
   if (nt <= kKnnLdsCand) {
-    for (int p = lane; p < nt; p += 64) {
-      const int q = order[b + p];
-      dist[wave][p] = (q == c) ? INF : sqdist(q);
+    // four candidates per lane per trip: their 4 x D/4 row loads are independent and in flight together
+    for (int p0 = lane; p0 < nt; p0 += 256) {
+      int qq[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) qq[u] = (p0 + 64 * u < nt) ? order[b + p0 + 64 * u] : c;
+      float dd[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) dd[u] = sqdist(qq[u]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (p0 + 64 * u < nt) dist[wave][p0 + 64 * u] = (qq[u] == c) ? INF : dd[u];
     }
     for (int r = 0; r < kk; ++r) {
       float bd = INF; int bp = 0x7fffffff;

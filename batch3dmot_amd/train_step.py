@@ -43,4 +43,5 @@ def train_step(gnn, data, optimizer, batch_size: int = 2, loss_kind: str = "cb",
 
 def make_optimizer(gnn, lr: float = 1e-4, weight_decay: float = 1e-4, betas=(0.9, 0.999)):
     """Adam exactly as train.py:106-109 (``gnn.*`` keys of the YAML config)."""
-    return torch.optim.Adam(gnn.parameters(), lr=lr, weight_decay=weight_decay, betas=betas)
+    params = [p for p in gnn.parameters() if p.requires_grad]
+    return torch.optim.Adam(params, lr=lr, weight_decay=weight_decay, betas=betas)
