@@ -640,8 +640,8 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
             jb.g.ptr = gp; jb.g.idx = gidx ? gidx : iota; jb.g.vstride = gvs; jb.g.stride = gstride; jb.g.col0 = gcol0 + g0;
             jb.act[0].ptr = cols[ci].p; jb.act[0].idx = cols[ci].idx ? cols[ci].idx : iota; jb.act[0].vstride = cols[ci].vstride;
             jb.act[0].stride = cols[ci].stride; jb.act[0].col0 = cols[ci].col0 + c0;
-            jb.act[1] = jb.act[0];
-            jb.wcol[0] = wcol + c0; jb.wcol[1] = 0; jb.wrow = g0;
+            jb.act[1] = jb.act[0]; jb.act[2] = jb.act[0];
+            jb.wcol[0] = wcol + c0; jb.wcol[1] = 0; jb.wcol[2] = 0; jb.wrow = g0;
             jb.write_bias = first_job_of_group ? 1 : 0;
             first_job_of_group = false;
             jb.shape = (gw == 64) ? (cw == 96 ? WS_64_96 : WS_64_64) : WS_32_64;   // 32-row tail only with 64-col groups

@@ -24,9 +24,9 @@ static const LinDim kLinDims[LIN_COUNT] = {
     {96, 128}, {64, 96}, {32, 64}, {96, 128}, {64, 96}, {96, 128}, {64, 96}, {96, 128}, {64, 96}, {48, 64}};
 static const bool kLinOnEdges[LIN_COUNT] = {1, 1, 1, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0};
 
-// Task plan of the streaming weight gradient: 14 jobs over the 10 message-passing Linear layers
-// (96x128 matrices are split into two column groups that share a slab), a work-proportional
-// share of ~2048 wavefront tasks each.  Jobs that share a slab get the same task count.
+// Task plan of the streaming weight gradient: 14 jobs over the 10 message-passing Linear layers (a
+// 96x128 matrix is two 64-column jobs sharing a slab), a work-proportional share of ~2048 wavefront
+// tasks each (two resident wavefronts per SIMD).
 enum { WJ_EU0A, WJ_EU0B, WJ_EU1, WJ_EU2, WJ_PA0A, WJ_PA0B, WJ_PA1, WJ_FU0A, WJ_FU0B, WJ_FU1,
        WJ_CF0A, WJ_CF0B, WJ_CF1, WJ_CF2, WJ_COUNT };
 struct WsPlan {
@@ -41,8 +41,8 @@ __global__ void iota_kernel(int* p, int n) {
 
 static WsPlan ws_plan(int N, int E, int depth) {
   WsPlan p;
-  const int shp[WJ_COUNT] = {WS_96_48_32, WS_96_48, WS_64_96, WS_32_64, WS_96_48_32, WS_96_48, WS_64_96,
-                             WS_96_48_32, WS_96_48, WS_64_96, WS_96_64, WS_96_64, WS_64_96, WS_48_64};
+  const int shp[WJ_COUNT] = {WS_96_48_16, WS_96_32_32, WS_64_96, WS_32_64, WS_96_48_16, WS_96_48_16, WS_64_96,
+                             WS_96_48_16, WS_96_48_16, WS_64_96, WS_96_64, WS_96_64, WS_64_96, WS_48_64};
   const int lin[WJ_COUNT] = {LIN_EU0, LIN_EU0, LIN_EU1, LIN_EU2, LIN_PA0, LIN_PA0, LIN_PA1,
                              LIN_FU0, LIN_FU0, LIN_FU1, LIN_CF0, LIN_CF0, LIN_CF1, LIN_CF2};
   double total = 0;
@@ -54,10 +54,7 @@ static WsPlan ws_plan(int N, int E, int depth) {
     total += (double)p.rows[i] * ws_shape_blocks(shp[i]) * (p.nvar[i] > 0 ? p.nvar[i] : 0);
   }
   for (int i = 0; i < WJ_COUNT; ++i) {
-    // column groups of one matrix share the slab: size both by the larger group's work
-    int ref = i;
-    if (i == WJ_EU0B || i == WJ_PA0B || i == WJ_FU0B || i == WJ_CF0B) ref = i - 1;
-    const double work = (double)p.rows[ref] * ws_shape_blocks(shp[ref]) * (p.nvar[ref] > 0 ? p.nvar[ref] : 0);
+    const double work = (double)p.rows[i] * ws_shape_blocks(shp[i]) * (p.nvar[i] > 0 ? p.nvar[i] : 0);
     long t = (long)(2048.0 * work / (total > 0 ? total : 1) + 0.5);
     const long maxt = (p.rows[i] + 15) / 16;
     if (t > maxt) t = maxt;
@@ -500,31 +497,31 @@ extern "C" int b3d_pose_backward(const b3d_pose_weights* pw, const b3d_graph* g,
       const int lin = w.plan.lin[wj];
       WsJob jb;
       memset(&jb, 0, sizeof(jb));
-      jb.g = gseg; jb.act[0] = a0; jb.act[1] = a1; jb.wcol[0] = c0; jb.wcol[1] = c1; jb.write_bias = bias ? 1 : 0;
+      jb.g = gseg; jb.act[0] = a0; jb.act[1] = a1; jb.act[2] = a1;
+      jb.wcol[0] = c0; jb.wcol[1] = c1; jb.wcol[2] = 0; jb.wrow = 0; jb.write_bias = bias ? 1 : 0;
       jb.shape = w.plan.shape[wj]; jb.rows = w.plan.rows[wj]; jb.nvar = w.plan.nvar[wj];
       jb.rows_per_task = w.plan.rows_per_task[wj]; jb.ntasks = w.plan.ntasks[wj];
       jb.NP = w.lin[lin].NP; jb.KP = w.lin[lin].KP; jb.slab = w.lin[lin].slab;
-      jb.wrow = 0;
       wl.add(jb);
       w.lin[lin].used = true;
     };
     const float* x0 = w.x[0];
-    const WsSeg xd = sg(w.x[0], dst, nLx, D::DX, 0), xs = sg(w.x[0], src, nLx, D::DX, 0);
-    const WsSeg x0d = sg(x0, dst, 0, D::DX, 0), x0s = sg(x0, src, 0, D::DX, 0);
-    const WsSeg e_l = sg(w.e[0], nullptr, eLe, D::DE, 0), e_l1 = sg(w.e[1], nullptr, eLe, D::DE, 0);
+    auto xrow = [&](const int* idx, int c0) { return sg(w.x[0], idx, nLx, D::DX, c0); };      // x[l][idx], columns c0..
+    auto x0row = [&](const int* idx) { return sg(x0, idx, 0, D::DX, 0); };
+    auto erow = [&](int l0, int c0) { return sg(w.e[l0], nullptr, eLe, D::DE, c0); };         // e[l + l0], columns c0..
     // edge_update (every layer): dW columns [x[dst] 0:48 | x[src] 48:96 | e 96:128]
     const WsSeg gH1 = sg(w.GdH1, nullptr, eL1, D::EH1, 0);
-    add(WJ_EU0A, gH1, xd, 0, e_l, 2 * D::DX, true);
-    add(WJ_EU0B, gH1, xs, D::DX, none, 0, false);
+    add(WJ_EU0A, gH1, xrow(dst, 0), 0, xrow(src, 0), 48, true);            // [x[dst] | x[src][0:16]]
+    add(WJ_EU0B, gH1, xrow(src, 16), 64, erow(0, 0), 96, false);           // [x[src][16:48] | e]
     add(WJ_EU1, sg(w.GdH2, nullptr, eL2, D::EH2, 0), sg(w.sH1[0], nullptr, eL1, D::EH1, 0), 0, none, 0, true);
     add(WJ_EU2, sg(w.Gde, nullptr, eLe, D::DE, 0), sg(w.sH2[0], nullptr, eL2, D::EH2, 0), 0, none, 0, true);
     // message stacks (layers 0 .. depth-2): columns [x[.] 0:48 | e' 48:80 | x0[.] 80:128]
     const WsSeg gP1 = sg(w.GdP1, nullptr, eLm, D::MH, 0), gF1 = sg(w.GdF1, nullptr, eLm, D::MH, 0);
-    add(WJ_PA0A, gP1, xs, 0, e_l1, D::DX, true);
-    add(WJ_PA0B, gP1, x0s, D::DX + D::DE, none, 0, false);
+    add(WJ_PA0A, gP1, xrow(src, 0), 0, erow(1, 0), 48, true);              // [x[src] | e'[0:16]]
+    add(WJ_PA0B, gP1, x0row(src), 80, erow(1, 16), 64, false);             // [x0[src] | e'[16:32]]
     add(WJ_PA1, sg(w.dM, dst, nLm, D::NIN, 0), sg(w.sP1[0], nullptr, eLm, D::MH, 0), 0, none, 0, true);
-    add(WJ_FU0A, gF1, xd, 0, e_l1, D::DX, true);
-    add(WJ_FU0B, gF1, x0d, D::DX + D::DE, none, 0, false);
+    add(WJ_FU0A, gF1, xrow(dst, 0), 0, erow(1, 0), 48, true);
+    add(WJ_FU0B, gF1, x0row(dst), 80, erow(1, 16), 64, false);
     add(WJ_FU1, sg(w.dM, src, nLm, D::NIN, D::DM), sg(w.sF1[0], nullptr, eLm, D::MH, 0), 0, none, 0, true);
     // node update (layers 0 .. depth-2)
     const WsSeg gN1 = sg(w.GnH1, nullptr, nL1, D::NH1, 0);

@@ -37,8 +37,8 @@ struct WsSeg {
 
 struct WsJob {
   WsSeg g;               // gradient rows, width GW
-  WsSeg act[2];          // activation segments, widths S0, S1
-  int wcol[2];           // column of dW where each segment's features start
+  WsSeg act[3];          // activation segments, widths S0, S1, S2
+  int wcol[3];           // column of dW where each segment's features start
   int wrow;              // row of dW where this job's gradient features start
   int write_bias;        // exactly one of the jobs that share a slab writes the bias gradient
   int shape;             // index into the compiled shape list
@@ -94,10 +94,10 @@ __device__ __forceinline__ void seg_load(const float* __restrict__ p, int m, flo
     out[4 * M::n4 + 2 * M::n2] = p[64 * M::n4 + 32 * M::n2 + m];
   }
 }
-template <int GW, int S0, int S1>
+template <int GW, int S0, int S1, int S2>
 struct WsShape {
-  static constexpr int MB = GW / 16, K = S0 + S1, NB = K / 16;
-  static constexpr int B0 = S0 / 16, B1 = S1 / 16;
+  static constexpr int MB = GW / 16, K = S0 + S1 + S2, NB = K / 16;
+  static constexpr int B0 = S0 / 16, B1 = S1 / 16, B2 = S2 / 16;
 };
 
 template <class SH>
@@ -106,13 +106,14 @@ struct WsStage {
   float b[SH::NB];
 };
 
-// A wavefront never holds more than 30 accumulator blocks (120 VGPRs): wide matrices are split
-// into column groups handled by different jobs that share one slab.
-template <int GW, int S0, int S1>
+// Up to 48 accumulator blocks (192 registers, the MFMA accumulator file) per wavefront: a 96x128
+// matrix is owned whole, so its gradient rows are read once.  Wider matrices are split into
+// (row group x column group) jobs that share one slab.
+template <int GW, int S0, int S1, int S2>
 __device__ __forceinline__ void ws_task(const WsJob& job, int chunk, const float* __restrict__ zero_row) {
-  using SH = WsShape<GW, S0, S1>;
+  using SH = WsShape<GW, S0, S1, S2>;
   constexpr int MB = SH::MB, NB = SH::NB;
-  static_assert(MB * NB <= 30, "too many accumulator blocks for one wavefront");
+  static_assert(MB * NB <= 24, "too many accumulator blocks for one wavefront");
   const int lane = threadIdx.x & 63, m = lane & 15, q = lane >> 4;
   v4f acc[MB][NB];
 #pragma unroll
@@ -127,19 +128,22 @@ __device__ __forceinline__ void ws_task(const WsJob& job, int chunk, const float
   int r1 = r0 + job.rows_per_task;
   if (r1 > job.rows) r1 = job.rows;
   const int nsteps = (r1 > r0) ? (r1 - r0 + 3) / 4 : 0;
-  const int gstride = job.g.stride, s0stride = job.act[0].stride, s1stride = (S1 > 0) ? job.act[1].stride : 0;
+  const int gstride = job.g.stride, s0stride = job.act[0].stride, s1stride = (S1 > 0) ? job.act[1].stride : 0,
+            s2stride = (S2 > 0) ? job.act[2].stride : 0;
   // every segment carries an index array (identity segments point at an iota array), so the loop
   // body is straight-line code: loads, selects, MFMAs.
   const int* ig = job.g.idx;
   const int* i0 = job.act[0].idx;
   const int* i1 = (S1 > 0) ? job.act[1].idx : i0;
+  const int* i2 = (S2 > 0) ? job.act[2].idx : i0;
 
   for (int v = 0; v < job.nvar; ++v) {
     const float* gp = job.g.ptr + v * job.g.vstride + job.g.col0;
     const float* p0 = job.act[0].ptr + v * job.act[0].vstride + job.act[0].col0;
     const float* p1 = (S1 > 0) ? job.act[1].ptr + v * job.act[1].vstride + job.act[1].col0 : p0;
+    const float* p2 = (S2 > 0) ? job.act[2].ptr + v * job.act[2].vstride + job.act[2].col0 : p0;
 
-    struct Rows { int g, a0, a1; bool ok; };
+    struct Rows { int g, a0, a1, a2; bool ok; };
     auto rows_of = [&](int step) {
       Rows r;
       const int row = r0 + 4 * step + q;
@@ -148,6 +152,7 @@ __device__ __forceinline__ void ws_task(const WsJob& job, int chunk, const float
       r.g = ig[rr];
       r.a0 = i0[rr];
       r.a1 = (S1 > 0) ? i1[rr] : 0;
+      r.a2 = (S2 > 0) ? i2[rr] : 0;
       return r;
     };
     auto fetch = [&](const Rows& r, WsStage<SH>& st) {
@@ -155,6 +160,7 @@ __device__ __forceinline__ void ws_task(const WsJob& job, int chunk, const float
       seg_load<GW>(pg, m, st.a);
       seg_load<S0>(p0 + (long)r.a0 * s0stride, m, st.b);
       if constexpr (S1 > 0) seg_load<S1>(p1 + (long)r.a1 * s1stride, m, st.b + SH::B0);
+      if constexpr (S2 > 0) seg_load<S2>(p2 + (long)r.a2 * s2stride, m, st.b + SH::B0 + SH::B1);
     };
     auto compute = [&](const WsStage<SH>& st) {
 #pragma unroll
@@ -170,7 +176,7 @@ __device__ __forceinline__ void ws_task(const WsJob& job, int chunk, const float
     // block k+1 are in flight (issued right after the first step of block k) and the gather indices
     // of block k+2 are being fetched: the only wait on the critical path is the one in front of a
     // block's first step, BS-1 steps of MFMAs after its loads were issued.
-    constexpr int BS = 4;
+    constexpr int BS = (MB * NB >= 24) ? 2 : 4;
     WsStage<SH> SA[BS], SB[BS];
     Rows RA[BS], RB[BS];
     const int nblk = (nsteps + BS - 1) / BS;
@@ -208,7 +214,8 @@ __device__ __forceinline__ void ws_task(const WsJob& job, int chunk, const float
     for (int b = 0; b < NB; ++b) {
       const float* vv = reinterpret_cast<const float*>(&acc[a][b]);
       const int colf = (b < SH::B0) ? job.wcol[0] + SegMap<S0>::feat(b, m)
-                                    : job.wcol[1] + SegMap<(S1 > 0 ? S1 : 16)>::feat(b - SH::B0, m);
+                       : (b < SH::B0 + SH::B1) ? job.wcol[1] + SegMap<(S1 > 0 ? S1 : 16)>::feat(b - SH::B0, m)
+                                               : job.wcol[2] + SegMap<(S2 > 0 ? S2 : 16)>::feat(b - SH::B0 - SH::B1, m);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int rowf = job.wrow + SegMap<GW>::feat(a, 4 * q + j);
@@ -227,14 +234,16 @@ __device__ __forceinline__ void ws_task(const WsJob& job, int chunk, const float
   }
 }
 
-// compiled shapes (GW; S0, S1)
+// compiled shapes (GW; S0, S1, S2).  At most 24 accumulator blocks (96 VGPRs) per wavefront so that
+// two wavefronts fit a SIMD without touching the AGPR half of the register file (the compiler
+// otherwise shuttles accumulators through v_accvgpr moves that stall behind the MFMAs).
 enum {
-  WS_96_48_32 = 0,      // P: 96-row stacks, columns of x[.] and e / e'
-  WS_96_48 = 1,         // P: 96-row stacks, columns of x[src] / x0[.]
+  WS_96_48_16 = 0,      // P 96x128 stacks, columns [48-wide segment | 16 columns of the next]
+  WS_96_32_32 = 1,      // P edge_update.0, columns [x[src] 16:48 | e]
   WS_64_96 = 2,
   WS_32_64 = 3,
   WS_48_64 = 4,
-  WS_96_64 = 5,
+  WS_96_64 = 5,         // P combine_future_past.0 (two column halves)
   WS_64_64 = 6,
   WS_SHAPES = 7
 };
@@ -248,7 +257,7 @@ static __global__ void ws_table_kernel(const WsTableArgs a) {
   for (int t = threadIdx.x; t < a.jobs[j].ntasks; t += blockDim.x) a.task_job[a.jobs[j].task_begin + t] = a.first + j;
 }
 
-static __global__ __launch_bounds__(kWsWaves * 64, 1) void wstream_kernel(const WsJob* __restrict__ table,
+static __global__ __launch_bounds__(kWsWaves * 64, 2) void wstream_kernel(const WsJob* __restrict__ table,
                                                                    const int* __restrict__ task_job, int total_tasks,
                                                                    const float* __restrict__ zero_row) {
   __shared__ WsJob sj[kWsWaves];
@@ -264,20 +273,20 @@ static __global__ __launch_bounds__(kWsWaves * 64, 1) void wstream_kernel(const 
   const WsJob& job = sj[wave];
   const int chunk = task - job.task_begin;
   switch (job.shape) {
-    case WS_96_48_32: ws_task<96, 48, 32>(job, chunk, zero_row); break;
-    case WS_96_48: ws_task<96, 48, 0>(job, chunk, zero_row); break;
-    case WS_64_96: ws_task<64, 96, 0>(job, chunk, zero_row); break;
-    case WS_32_64: ws_task<32, 64, 0>(job, chunk, zero_row); break;
-    case WS_48_64: ws_task<48, 64, 0>(job, chunk, zero_row); break;
-    case WS_96_64: ws_task<96, 64, 0>(job, chunk, zero_row); break;
-    case WS_64_64: ws_task<64, 64, 0>(job, chunk, zero_row); break;
+    case WS_96_48_16: ws_task<96, 48, 16, 0>(job, chunk, zero_row); break;
+    case WS_96_32_32: ws_task<96, 32, 32, 0>(job, chunk, zero_row); break;
+    case WS_64_96: ws_task<64, 96, 0, 0>(job, chunk, zero_row); break;
+    case WS_32_64: ws_task<32, 64, 0, 0>(job, chunk, zero_row); break;
+    case WS_48_64: ws_task<48, 64, 0, 0>(job, chunk, zero_row); break;
+    case WS_96_64: ws_task<96, 64, 0, 0>(job, chunk, zero_row); break;
+    case WS_64_64: ws_task<64, 64, 0, 0>(job, chunk, zero_row); break;
     default: break;
   }
 }
 
 // blocks (MFMAs per 4-row step) of a shape: the unit of work used to balance tasks
 inline int ws_shape_blocks(int shape) {
-  static const int b[WS_SHAPES] = {6 * 5, 6 * 3, 4 * 6, 2 * 4, 3 * 4, 6 * 4, 4 * 4};
+  static const int b[WS_SHAPES] = {6 * 4, 6 * 4, 4 * 6, 2 * 4, 3 * 4, 6 * 4, 4 * 4};
   return b[shape];
 }
 
