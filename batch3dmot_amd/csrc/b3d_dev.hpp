@@ -201,8 +201,10 @@ __device__ __forceinline__ v4f relu4(v4f a) {
 // act(W . in + b) for layer LI of Seq.  in: KB feature blocks (layout L); every finished output
 // block is handed to emit(mb, value) -- either kept in registers (linear) or streamed to memory
 // (linear_emit, for layers whose input + output do not fit the register file together).
-template <class Seq, int LI, bool RELU, bool BIAS, int CH, class WS, class Emit>
-__device__ __forceinline__ void linear_chunk(WS& ws, bool more, const v4f* __restrict__ in, Emit& emit) {
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+
+template <class Seq, int LI, bool RELU, bool BIAS, int CH, class WS, class Emit, class Hook>
+__device__ __forceinline__ void linear_chunk(WS& ws, bool more, const v4f* __restrict__ in, Emit& emit, Hook& hook) {
   constexpr int KP = Seq::kp(LI), NP = Seq::np(LI);
   constexpr int KB = KP / 16, NB = NP / 16;
   constexpr int STRIDE = KP + 4;
@@ -213,51 +215,76 @@ __device__ __forceinline__ void linear_chunk(WS& ws, bool more, const v4f* __res
   const int lane = threadIdx.x & 63;
   const int m = lane & 15, q = lane >> 4;
   const float* w = ws.template acquire<Seq, C0 + CH>(more);
-  // two output blocks at a time: two independent accumulator chains hide the 40-cycle
-  // dependent latency of v_mfma_f32_16x16x4_f32 behind its 32-cycle issue interval.
+  // work that should overlap this layer's MFMAs instead of sitting in front of its barrier (the
+  // acquire above drains vmcnt, stores included): e.g. the previous layer's activation stores
+  if constexpr (CH == 0) hook();
+  // Two output blocks at a time (two independent accumulator chains hide the 40-cycle dependent
+  // latency of v_mfma_f32_16x16x4_f32 behind its 32-cycle issue interval).  The weight fragments
+  // (and the bias) of step t+1 are read from LDS BEFORE the 8 MFMAs of step t are issued, so the
+  // LDS latency is always covered by a full step of matrix work.
+  constexpr int NPAIR = (mbn - mb0 + 1) / 2;
+  const float* wrow = w + m * STRIDE + 4 * q;                 // A fragment: row m of a block, 4 consecutive k
+  const float* wbias = w + 4 * q * STRIDE + KP;               // bias of output rows 4q..4q+3
+  auto frag = [&](int pair, int half, int kb) -> v4f {
+    return *reinterpret_cast<const v4f*>(wrow + (pair * 2 + half) * 16 * STRIDE + 16 * kb);
+  };
+  auto bias = [&](int pair, int half) -> v4f {
+    const float* wb = wbias + (pair * 2 + half) * 16 * STRIDE;
+    return v4f{wb[0], wb[STRIDE], wb[2 * STRIDE], wb[3 * STRIDE]};
+  };
+  const v4f zero4 = {0.f, 0.f, 0.f, 0.f};
+  v4f fa0 = frag(0, 0, 0);
+  v4f fa1 = (mb0 + 1 < mbn) ? frag(0, 1, 0) : zero4;
+  v4f nb0 = BIAS ? bias(0, 0) : zero4;
+  v4f nb1 = (BIAS && mb0 + 1 < mbn) ? bias(0, 1) : zero4;
 #pragma unroll
-  for (int mb = mb0; mb < mbn; mb += 2) {
+  for (int pr = 0; pr < NPAIR; ++pr) {
+    const int mb = mb0 + 2 * pr;
     const bool two = (mb + 1 < mbn);
-    const float* wr0 = w + ((mb - mb0) * 16 + m) * STRIDE + 4 * q;
-    const float* wr1 = wr0 + 16 * STRIDE;
-    v4f acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    if constexpr (BIAS) {
-      const float* wb0 = w + ((mb - mb0) * 16 + 4 * q) * STRIDE + KP;
-      acc0.x = wb0[0]; acc0.y = wb0[STRIDE]; acc0.z = wb0[2 * STRIDE]; acc0.w = wb0[3 * STRIDE];
-      if (two) {
-        const float* wb1 = wb0 + 16 * STRIDE;
-        acc1.x = wb1[0]; acc1.y = wb1[STRIDE]; acc1.z = wb1[2 * STRIDE]; acc1.w = wb1[3 * STRIDE];
-      }
-    }
+    v4f acc0 = nb0, acc1 = nb1;
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
-      const v4f a0 = *reinterpret_cast<const v4f*>(wr0 + 16 * kb);
-      acc0 = mfma4(a0, in[kb], acc0);
-      if (two) {
-        const v4f a1 = *reinterpret_cast<const v4f*>(wr1 + 16 * kb);
-        acc1 = mfma4(a1, in[kb], acc1);
+      v4f na0 = zero4, na1 = zero4;
+      if (kb + 1 < KB) {
+        na0 = frag(pr, 0, kb + 1);
+        if (two) na1 = frag(pr, 1, kb + 1);
+      } else if (pr + 1 < NPAIR) {
+        const bool two_n = (mb + 3 < mbn);
+        na0 = frag(pr + 1, 0, 0);
+        if (two_n) na1 = frag(pr + 1, 1, 0);
+        if constexpr (BIAS) {
+          nb0 = bias(pr + 1, 0);
+          if (two_n) nb1 = bias(pr + 1, 1);
+        }
       }
+      // keep the LDS reads of the next step in front of this step's MFMAs (hipcc otherwise sinks
+      // them next to their use and every 8-MFMA group starts with an exposed lgkmcnt(0) wait)
+      __builtin_amdgcn_sched_barrier(0);
+      acc0 = mfma4(fa0, in[kb], acc0);
+      if (two) acc1 = mfma4(fa1, in[kb], acc1);
+      fa0 = na0; fa1 = na1;
     }
     emit(mb, RELU ? relu4(acc0) : acc0);
     if (two) emit(mb + 1, RELU ? relu4(acc1) : acc1);
   }
 }
 
-template <class Seq, int LI, bool RELU, bool BIAS, class WS, class Emit, int... CH>
-__device__ __forceinline__ void linear_impl(WS& ws, bool more, const v4f* __restrict__ in, Emit& emit,
+template <class Seq, int LI, bool RELU, bool BIAS, class WS, class Emit, class Hook, int... CH>
+__device__ __forceinline__ void linear_impl(WS& ws, bool more, const v4f* __restrict__ in, Emit& emit, Hook& hook,
                                             std::integer_sequence<int, CH...>) {
-  (linear_chunk<Seq, LI, RELU, BIAS, CH, WS, Emit>(ws, more, in, emit), ...);
+  (linear_chunk<Seq, LI, RELU, BIAS, CH, WS, Emit, Hook>(ws, more, in, emit, hook), ...);
 }
 
-template <class Seq, int LI, bool RELU, bool BIAS = true, class WS, class Emit>
-__device__ __forceinline__ void linear_emit(WS& ws, bool more, const v4f* __restrict__ in, Emit emit) {
-  linear_impl<Seq, LI, RELU, BIAS, WS, Emit>(ws, more, in, emit,
-                                             std::make_integer_sequence<int, n_chunks(Seq::kp(LI), Seq::np(LI))>{});
+template <class Seq, int LI, bool RELU, bool BIAS = true, class WS, class Emit, class Hook = NoHook>
+__device__ __forceinline__ void linear_emit(WS& ws, bool more, const v4f* __restrict__ in, Emit emit, Hook hook = Hook{}) {
+  linear_impl<Seq, LI, RELU, BIAS, WS, Emit, Hook>(ws, more, in, emit, hook,
+                                                   std::make_integer_sequence<int, n_chunks(Seq::kp(LI), Seq::np(LI))>{});
 }
 
-template <class Seq, int LI, bool RELU, bool BIAS = true, class WS>
-__device__ __forceinline__ void linear(WS& ws, bool more, const v4f* __restrict__ in, v4f* __restrict__ out) {
-  linear_emit<Seq, LI, RELU, BIAS>(ws, more, in, [out](int mb, v4f v) { out[mb] = v; });
+template <class Seq, int LI, bool RELU, bool BIAS = true, class WS, class Hook = NoHook>
+__device__ __forceinline__ void linear(WS& ws, bool more, const v4f* __restrict__ in, v4f* __restrict__ out,
+                                       Hook hook = Hook{}) {
+  linear_emit<Seq, LI, RELU, BIAS>(ws, more, in, [out](int mb, v4f v) { out[mb] = v; }, hook);
 }
 
 // ---- row <-> register helpers (layout L) -----------------------------------------------------

@@ -146,29 +146,25 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void mp_edge_fwd_kernel(c
     load_row<XB>(a.x0, d, D::DX, 0, valid, x0i);
     load_row<XB>(a.x0, s, D::DX, 0, valid, x0j);
 
+    // Every store is issued right AFTER the next layer's weight-chunk barrier (as that layer's hook):
+    // the barrier drains vmcnt, so a store placed in front of it would be waited for at once.
     v4f h1[H1B], h2[H2B], en[EB];
     linear<Seq, 0, true>(ws, more, in1, h1);
-    if (a.sH1) store_row<H1B>(a.sH1, row, D::EH1, 0, valid, h1);
-    linear<Seq, 1, true>(ws, more, h1, h2);
-    if (a.sH2) store_row<H2B>(a.sH2, row, D::EH2, 0, valid, h2);
-    linear<Seq, 2, false>(ws, more, h2, en);
-    store_row<EB>(a.e_out, row, D::DE, 0, valid, en);
+    linear<Seq, 1, true>(ws, more, h1, h2, [&]() { if (a.sH1) store_row<H1B>(a.sH1, row, D::EH1, 0, valid, h1); });
+    linear<Seq, 2, false>(ws, more, h2, en, [&]() { if (a.sH2) store_row<H2B>(a.sH2, row, D::EH2, 0, valid, h2); });
 
-    v4f inm[2 * XB + EB], m1[MHB], mo[DMB];
+    v4f inm[2 * XB + EB], m1[MHB], mo[DMB], mo2[DMB];
     copy_blocks<XB>(inm, in1);                 // x_i | e' | x0_i
     copy_blocks<EB>(inm + XB, en);
     copy_blocks<XB>(inm + XB + EB, x0i);
-    linear<Seq, 3, true>(ws, more, inm, m1);
-    if (a.sF1) store_row<MHB>(a.sF1, row, D::MH, 0, valid, m1);
-    linear<Seq, 4, false>(ws, more, m1, mo);
-    store_row<DMB>(a.fut, row, D::DM, 0, valid, mo);
+    linear<Seq, 3, true>(ws, more, inm, m1, [&]() { store_row<EB>(a.e_out, row, D::DE, 0, valid, en); });
+    linear<Seq, 4, false>(ws, more, m1, mo, [&]() { if (a.sF1) store_row<MHB>(a.sF1, row, D::MH, 0, valid, m1); });
 
     copy_blocks<XB>(inm, in1 + XB);            // x_j | e' | x0_j
     copy_blocks<XB>(inm + XB + EB, x0j);
-    linear<Seq, 5, true>(ws, more, inm, m1);
-    if (a.sP1) store_row<MHB>(a.sP1, row, D::MH, 0, valid, m1);
-    linear<Seq, 6, false>(ws, more, m1, mo);
-    store_row<DMB>(a.past, row, D::DM, 0, valid, mo);
+    linear<Seq, 5, true>(ws, more, inm, m1, [&]() { store_row<DMB>(a.fut, row, D::DM, 0, valid, mo); });
+    linear<Seq, 6, false>(ws, more, m1, mo2, [&]() { if (a.sP1) store_row<MHB>(a.sP1, row, D::MH, 0, valid, m1); });
+    store_row<DMB>(a.past, row, D::DM, 0, valid, mo2);
   }
 }
 
