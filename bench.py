@@ -127,15 +127,28 @@ def main():
     if rank == 0:
         e_avg = my_edges / args.steps
         # ---- per-family device time (HIP events on the launch stream, whole timed region) -----
+        depth = model.depth
+        mac_eu = 128 * 96 + 96 * 64 + 64 * 32                  # edge_update stack
+        mac_msg = 2 * (128 * 96 + 96 * 64)                     # create_past_msgs + create_future_msgs
+        # the weight gradient of ALL layers is one launch: edge_update in every layer, the message
+        # and node stacks in layers 0..depth-2 (the last layer's node update feeds nothing)
         flops = {"mp_edge_fwd": 2.0 * MAC_EDGE * e_avg, "mp_edge_bwd": 2.0 * MAC_EDGE * e_avg,
-                 "wgrad_edge": 2.0 * MAC_EDGE * e_avg,
+                 "wgrad_edge": 2.0 * (e_avg * (mac_eu * depth + mac_msg * (depth - 1)) + n_nodes * MAC_NODE * (depth - 1)),
                  "mp_node_fwd": 2.0 * MAC_NODE * n_nodes, "mp_node_bwd": 2.0 * MAC_NODE * n_nodes}
         # algorithmic bytes per launch (each logical tensor once, fp32, int32 indices)
         byts = {"mp_edge_fwd": e_avg * (8 + 4 * (32 + 32 + 64 + 64 + 352)),      # idx, e in/out, fut, past, saved hidden
                 "mp_edge_bwd": e_avg * (8 + 4 * (32 + 32 + 352 + 192 + 384)),    # de out/in, saved, per-edge node grads, G
-                "wgrad_edge": e_avg * 4 * (384 + 352 + 64),                      # G, saved hidden, e / e'
+                # G (dH1,dH2,de' every layer; dF1,dP1 + gathered dM in the message layers), saved hidden, e / e'
+                "wgrad_edge": e_avg * 4 * ((192 + 160 + 64) * depth + (192 + 128 + 192 + 32) * (depth - 1)),
                 "mp_node_fwd": e_avg * 4 * 128 + n_nodes * 4 * (128 + 48 + 160),
                 "mp_node_bwd": e_avg * 4 * 192 + n_nodes * 4 * (128 + 48 + 48 + 160 + 208)}
+        bound = {"mp_edge_fwd": "mfma", "mp_edge_bwd": "mfma", "wgrad_edge": "hbm", "mp_node_fwd": "hbm", "mp_node_bwd": "hbm"}
+        # HBM bytes per launch measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of
+        # this command (profiles/r01_c_pmc_traffic.txt), FETCH_SIZE doubled as MI355X_MICROARCH.md
+        # prescribes for wide coalesced reads on gfx950.  Valid for the default workload only.
+        traffic_pmc = {"wgrad_edge": 2 * 451.77e6 * 1.024 + 51.67e6 * 1.024, "mp_edge_fwd": 2 * 5.755e6 * 1.024 + 62.16e6 * 1.024,
+                       "mp_edge_bwd": 2 * 26.44e6 * 1.024 + 74.79e6 * 1.024, "mp_node_fwd": 2 * 8.416e6 * 1.024 + 3.94e6 * 1.024,
+                       "mp_node_bwd": 2 * 13.48e6 * 1.024 + 4.5e6 * 1.024}
         kernels = {}
         for name, (ms, n) in fam.items():
             if n == 0:
@@ -144,15 +157,22 @@ def main():
             k = {"launches_per_step": n / args.steps, "avg_us": round(avg_us, 2),
                  "us_per_step": round(1e3 * ms / args.steps, 1)}
             if name in flops:
+                k["bound"] = bound[name]
                 k["tflops"] = round(flops[name] / (avg_us * 1e-6) / 1e12, 2)
                 k["gbs"] = round(byts[name] / (avg_us * 1e-6) / 1e9, 1)
             kernels[name] = k
         dom = max((k for k in kernels if k in flops), key=lambda k: kernels[k]["us_per_step"])
-        achieved = kernels[dom]["tflops"]
-        roofline = {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+        default_workload = (depth == 6 and abs(e_avg - 31078) < 200 and not args.no_dead_knn)
+        if bound[dom] == "mfma":
+            achieved, peak, unit = kernels[dom]["tflops"], PEAK_FP32_MFMA_TFLOPS, "TFLOP/s"
+        else:
+            achieved, peak, unit = kernels[dom]["gbs"], PEAK_HBM_GBS, "GB/s"
+        roofline = {"kernel": dom, "bound": bound[dom], "achieved": achieved, "peak": peak, "unit": unit,
+                    "frac": round(achieved / peak, 4),
+                    "traffic": round(traffic_pmc[dom]) if default_workload else None,
                     "avg_launch_us": kernels[dom]["avg_us"],
-                    "algorithmic_flops_per_launch": flops[dom], "algorithmic_bytes_per_launch": byts[dom]}
+                    "algorithmic_flops_per_launch": flops[dom], "algorithmic_bytes_per_launch": byts[dom],
+                    "fp32_tflops": kernels[dom]["tflops"], "fp32_frac": round(kernels[dom]["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4)}
         ms_step = 1e3 * dt / args.steps
         step_bytes = algorithmic_bytes_step(n_nodes, e_avg)
         step_flops = algorithmic_flops_step(n_nodes, e_avg)
