@@ -121,6 +121,11 @@ def load() -> C.CDLL:
                                        C.POINTER(C.c_void_p)]
     lib.b3d_modality_mask.restype = C.c_int
     lib.b3d_modality_mask.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.b3d_knn_gat_workspace_bytes.restype = C.c_size_t
+    lib.b3d_knn_gat_workspace_bytes.argtypes = [C.c_int32, C.c_int32]
+    lib.b3d_knn_gat_forward.restype = C.c_int
+    lib.b3d_knn_gat_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(b3d_gat),
+                                        C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.b3d_prof_enable.argtypes = [C.c_int]
     lib.b3d_prof_read.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]
     _lib = lib
@@ -195,3 +200,24 @@ def prof_read() -> dict:
         check(load().b3d_prof_read(fam, C.byref(ms), C.byref(n)), "b3d_prof_read")
         out[name] = (ms.value, n.value)
     return out
+
+
+def knn_gat(x: torch.Tensor, node_timestamps: torch.Tensor, conv, k: int = 20):
+    """Frame-wise k-NN + GATConv as a standalone operator (reference pose_gnn.py:74-80).  ``conv`` is a
+    ``GATConvParams``.  Returns (nbr [N,32] int32, cnt [N] int32, y [N,D])."""
+    require_cuda(x, "x", torch.float32)
+    lib = load()
+    n, d = x.shape
+    ts = node_timestamps.to(torch.int64).contiguous()
+    g = b3d_gat()
+    keep = [conv.lin_src.weight.detach().contiguous(), conv.att_src.detach().reshape(-1).contiguous(),
+            conv.att_dst.detach().reshape(-1).contiguous(), conv.bias.detach().contiguous()]
+    g.lin, g.att_src, g.att_dst, g.bias = (t.data_ptr() for t in keep)
+    nbytes = lib.b3d_knn_gat_workspace_bytes(n, d)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    nbr = torch.empty((n, 32), dtype=torch.int32, device=x.device)
+    cnt = torch.empty(n, dtype=torch.int32, device=x.device)
+    y = torch.empty((n, d), dtype=torch.float32, device=x.device)
+    check(lib.b3d_knn_gat_forward(x.data_ptr(), ts.data_ptr(), n, d, k, C.byref(g), ws.data_ptr(), nbytes,
+                                  nbr.data_ptr(), cnt.data_ptr(), y.data_ptr(), current_stream(x.device)), "b3d_knn_gat_forward")
+    return nbr, cnt, y

@@ -25,7 +25,7 @@ struct KnnWs {
   int* fend;      // [N] one past the last
   int* nbr;       // [N, kKnnMaxK] neighbour node ids (-1 padded)
   int* cnt;       // [N] number of neighbours
-  int* rcnt;      // [3, N] rank counters
+  int* rcnt;      // [3, N] rank counters, then one overflow counter
   float* h;       // [N, D]
   float* s_src;   // [N]
   float* s_dst;   // [N]
@@ -37,7 +37,7 @@ struct KnnWs {
 inline void knn_carve(KnnWs& k, Carver& c, int N, int D) {
   const size_t n = (size_t)(N > 0 ? N : 1);
   k.rank = c.take<int>(n); k.order = c.take<int>(n); k.fbeg = c.take<int>(n); k.fend = c.take<int>(n);
-  k.nbr = c.take<int>(n * kKnnMaxK); k.cnt = c.take<int>(n); k.rcnt = c.take<int>(3 * n);
+  k.nbr = c.take<int>(n * kKnnMaxK); k.cnt = c.take<int>(n); k.rcnt = c.take<int>(3 * n + 64);
   k.h = c.take<float>(n * D); k.s_src = c.take<float>(n); k.s_dst = c.take<float>(n); k.y = c.take<float>(n * D);
   k.wp = c.take<float>(image_floats(D, D));
   k.ranked = false;
@@ -104,17 +104,92 @@ __device__ __forceinline__ void wave_argmin(float& d, int& j) {
   }
 }
 
-// one wavefront per centre
+// One wavefront per centre, 16 centres (consecutive in frame order) per workgroup.  Candidate rows
+// are staged through LDS in tiles of 64, so a candidate row is fetched from L2 once per 16 centres
+// instead of once per centre; each lane computes the squared distance of its candidate to the
+// wave's centre from LDS, the distances of the whole frame stay in a per-wave LDS list, and the k
+// nearest are extracted by k rounds of a wavefront arg-min.
+constexpr int kKnnCentres = 16;
+constexpr int kKnnList = 1024;        // frame sizes up to this use the tiled kernel
+template <int D>
+__global__ __launch_bounds__(kKnnCentres * 64) void knn_tile_kernel(const float* __restrict__ x, int N, int k,
+                                                                    const int* __restrict__ order,
+                                                                    const int* __restrict__ fbeg,
+                                                                    const int* __restrict__ fend,
+                                                                    int* __restrict__ nbr, int* __restrict__ cnt,
+                                                                    int* __restrict__ overflow) {
+  constexpr int TS = D + 1;                               // padded tile row (bank spread)
+  __shared__ float tile[64 * TS];
+  __shared__ float dist[kKnnCentres][kKnnList];
+  __shared__ int wb[kKnnCentres], we[kKnnCentres];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int pos = blockIdx.x * kKnnCentres + wave;        // position in frame order
+  const bool live = pos < N;
+  const int c = live ? order[pos] : 0;
+  const int b = live ? fbeg[c] : 0x7fffffff, e = live ? fend[c] : 0;
+  const int nt = live ? e - b : 0;
+  if (lane == 0) { wb[wave] = b; we[wave] = e; }
+  __syncthreads();
+  int ub = 0x7fffffff, ue = 0;                            // union of the candidate ranges of the workgroup
+#pragma unroll
+  for (int w = 0; w < kKnnCentres; ++w) { ub = min(ub, wb[w]); ue = max(ue, we[w]); }
+  const bool big = nt > kKnnList;                         // handled by the fallback kernel
+  if (live && big && lane == 0) atomicAdd(overflow, 1);
+  float xc[D];
+#pragma unroll
+  for (int d = 0; d < D; d += 4) {
+    const v4f v = *reinterpret_cast<const v4f*>(x + (size_t)c * D + d);
+    xc[d] = v.x; xc[d + 1] = v.y; xc[d + 2] = v.z; xc[d + 3] = v.w;
+  }
+  const float INF = __builtin_inff();
+  for (int t0 = ub; t0 < ue; t0 += 64) {
+    // stage 64 candidate rows (positions t0 .. t0+63 of the frame order)
+    for (int i = threadIdx.x; i < 64 * (D / 4); i += blockDim.x) {
+      const int r = i / (D / 4), c4 = i - r * (D / 4);
+      v4f v = {0.f, 0.f, 0.f, 0.f};
+      if (t0 + r < ue) v = *reinterpret_cast<const v4f*>(x + (size_t)order[t0 + r] * D + 4 * c4);
+      float* dst = tile + r * TS + 4 * c4;
+      dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+    }
+    __syncthreads();
+    const int p = t0 + lane;                              // this lane's candidate position
+    if (live && !big && p >= b && p < e) {
+      const float* row = tile + lane * TS;
+      float s2 = 0.f;
+#pragma unroll
+      for (int d = 0; d < D; ++d) { const float a = row[d] - xc[d]; s2 = fmaf(a, a, s2); }
+      dist[wave][p - b] = (p == pos) ? INF : s2;
+    }
+    __syncthreads();
+  }
+  if (!live || big) return;
+  const int kk = (k < nt - 1) ? k : (nt - 1);
+  for (int r = 0; r < kk; ++r) {
+    float bd = INF; int bp = 0x7fffffff;
+    for (int q = lane; q < nt; q += 64) {
+      const float dv = dist[wave][q];
+      if (dv < bd) { bd = dv; bp = q; }
+    }
+    wave_argmin(bd, bp);
+    if (lane == 0) nbr[(size_t)c * kKnnMaxK + r] = order[b + bp];
+    if ((bp & 63) == lane) dist[wave][bp] = INF;
+  }
+  if (lane == 0) cnt[c] = kk > 0 ? kk : 0;
+}
+
+// Fallback for frames larger than kKnnList: one wavefront per centre, distances recomputed from
+// global memory in every selection round.  Only centres of such frames do any work.
 template <int D>
 __global__ __launch_bounds__(256) void knn_select_kernel(const float* __restrict__ x, int N, int k,
                                                          const int* __restrict__ order, const int* __restrict__ fbeg,
                                                          const int* __restrict__ fend, int* __restrict__ nbr,
-                                                         int* __restrict__ cnt) {
-  __shared__ float dist[4][kKnnLdsCand];
+                                                         int* __restrict__ cnt, const int* __restrict__ overflow) {
+  if (*overflow == 0) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int c = blockIdx.x * 4 + wave;
   if (c >= N) return;
   const int b = fbeg[c], e = fend[c], nt = e - b;
+  if (nt <= kKnnList) return;
   const int kk = (k < nt - 1) ? k : (nt - 1);
   float xc[D];
 #pragma unroll
@@ -133,46 +208,20 @@ __global__ __launch_bounds__(256) void knn_select_kernel(const float* __restrict
     return s;
   };
   const float INF = __builtin_inff();
-  if (nt <= kKnnLdsCand) {
-    // four candidates per lane per trip: their 4 x D/4 row loads are independent and in flight together
-    for (int p0 = lane; p0 < nt; p0 += 256) {
-      int qq[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) qq[u] = (p0 + 64 * u < nt) ? order[b + p0 + 64 * u] : c;
-      float dd[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) dd[u] = sqdist(qq[u]);
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (p0 + 64 * u < nt) dist[wave][p0 + 64 * u] = (qq[u] == c) ? INF : dd[u];
+  // select the smallest (dist, pos) pair strictly greater than the previous pick, k times
+  float ld = -1.f; int lp = -1;
+  for (int r = 0; r < kk; ++r) {
+    float bd = INF; int bp = 0x7fffffff;
+    for (int p = lane; p < nt; p += 64) {
+      const int q = order[b + p];
+      if (q == c) continue;
+      const float dv = sqdist(q);
+      const bool after = (dv > ld) || (dv == ld && p > lp);
+      if (after && (dv < bd || (dv == bd && p < bp))) { bd = dv; bp = p; }
     }
-    for (int r = 0; r < kk; ++r) {
-      float bd = INF; int bp = 0x7fffffff;
-      for (int p = lane; p < nt; p += 64) {
-        const float dv = dist[wave][p];
-        if (dv < bd) { bd = dv; bp = p; }
-      }
-      wave_argmin(bd, bp);
-      if (lane == 0) nbr[(size_t)c * kKnnMaxK + r] = order[b + bp];
-      if ((bp & 63) == lane) dist[wave][bp] = INF;
-    }
-  } else {
-    // huge frame: re-evaluate distances every round, selecting the smallest (dist, pos) pair
-    // strictly greater than the previous pick
-    float ld = -1.f; int lp = -1;
-    for (int r = 0; r < kk; ++r) {
-      float bd = INF; int bp = 0x7fffffff;
-      for (int p = lane; p < nt; p += 64) {
-        const int q = order[b + p];
-        if (q == c) continue;
-        const float dv = sqdist(q);
-        const bool after = (dv > ld) || (dv == ld && p > lp);
-        if (after && (dv < bd || (dv == bd && p < bp))) { bd = dv; bp = p; }
-      }
-      wave_argmin(bd, bp);
-      if (lane == 0) nbr[(size_t)c * kKnnMaxK + r] = order[b + bp];
-      ld = bd; lp = bp;
-    }
+    wave_argmin(bd, bp);
+    if (lane == 0) nbr[(size_t)c * kKnnMaxK + r] = order[b + bp];
+    ld = bd; lp = bp;
   }
   if (lane == 0) cnt[c] = kk > 0 ? kk : 0;
 }
@@ -248,7 +297,7 @@ inline int knn_gat_block(KnnWs& ws, const float* x, const int64_t* ts, int N, co
   B3D_REQUIRE(k >= 1 && k <= kKnnMaxK, "k-NN k=%d outside [1,%d]", k, kKnnMaxK);
   if (N <= 0) return B3D_OK;
   if (!ws.ranked) {
-    B3D_HIP_CHECK(hipMemsetAsync(ws.rcnt, 0, 3 * (size_t)N * sizeof(int), stream));
+    B3D_HIP_CHECK(hipMemsetAsync(ws.rcnt, 0, (3 * (size_t)N + 64) * sizeof(int), stream));
     hipLaunchKernelGGL(knn_rank_count_kernel, dim3((N + 255) / 256, kRankSlices), dim3(256), 0, stream, ts, N, ws.rcnt);
     B3D_TRY(launch_check("knn_rank_count_kernel"));
     hipLaunchKernelGGL(knn_rank_finish_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, ws.rcnt, N, ws.rank, ws.order, ws.fbeg, ws.fend);
@@ -258,7 +307,12 @@ inline int knn_gat_block(KnnWs& ws, const float* x, const int64_t* ts, int N, co
     B3D_TRY(pack_images(&d, 1, stream));
     ws.ranked = true;
   }
-  hipLaunchKernelGGL(knn_select_kernel<D>, dim3((N + 3) / 4), dim3(256), 0, stream, x, N, k, ws.order, ws.fbeg, ws.fend, ws.nbr, ws.cnt);
+  int* overflow = ws.rcnt + 3 * (size_t)N;
+  hipLaunchKernelGGL(knn_tile_kernel<D>, dim3((N + kKnnCentres - 1) / kKnnCentres), dim3(kKnnCentres * 64), 0, stream,
+                     x, N, k, ws.order, ws.fbeg, ws.fend, ws.nbr, ws.cnt, overflow);
+  B3D_TRY(launch_check("knn_tile_kernel"));
+  hipLaunchKernelGGL(knn_select_kernel<D>, dim3((N + 3) / 4), dim3(256), 0, stream, x, N, k, ws.order, ws.fbeg, ws.fend,
+                     ws.nbr, ws.cnt, overflow);
   B3D_TRY(launch_check("knn_select_kernel"));
   {
     using S = LayerSeq<L<D, D>>;

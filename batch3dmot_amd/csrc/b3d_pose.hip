@@ -559,3 +559,30 @@ extern "C" int b3d_pose_backward(const b3d_pose_weights* pw, const b3d_graph* g,
   }
   return B3D_OK;
 }
+
+// ---- standalone k-NN + GAT operator ---------------------------------------------------------------
+extern "C" size_t b3d_knn_gat_workspace_bytes(int32_t N, int32_t Dm) {
+  Carver c(nullptr, 0);
+  KnnWs k;
+  knn_carve(k, c, N, Dm);
+  return c.off + 256;
+}
+
+extern "C" int b3d_knn_gat_forward(const float* x, const int64_t* ts, int32_t N, int32_t Dm, int32_t k, const b3d_gat* gat,
+                                   void* workspace, size_t workspace_bytes, int32_t* out_nbr, int32_t* out_cnt,
+                                   float* out_y, b3d_stream stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  B3D_REQUIRE(x && ts && gat && workspace && out_nbr && out_cnt && out_y, "b3d_knn_gat_forward: null argument");
+  B3D_REQUIRE(Dm == 48 || Dm == 96, "b3d_knn_gat_forward: D must be 48 or 96, got %d", Dm);
+  B3D_REQUIRE(N > 0, "b3d_knn_gat_forward: empty input");
+  Carver c(workspace, workspace_bytes);
+  KnnWs w;
+  knn_carve(w, c, N, Dm);
+  if (!c.ok()) return fail(B3D_ERR_WORKSPACE, "b3d_knn_gat_forward: workspace too small");
+  if (Dm == 48) B3D_TRY(knn_gat_block<48>(w, x, ts, N, *gat, k, stream));
+  else B3D_TRY(knn_gat_block<96>(w, x, ts, N, *gat, k, stream));
+  B3D_HIP_CHECK(hipMemcpyAsync(out_nbr, w.nbr, (size_t)N * kKnnMaxK * sizeof(int), hipMemcpyDeviceToDevice, stream));
+  B3D_HIP_CHECK(hipMemcpyAsync(out_cnt, w.cnt, (size_t)N * sizeof(int), hipMemcpyDeviceToDevice, stream));
+  B3D_HIP_CHECK(hipMemcpyAsync(out_y, w.y, (size_t)N * Dm * sizeof(float), hipMemcpyDeviceToDevice, stream));
+  return B3D_OK;
+}

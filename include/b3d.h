@@ -187,6 +187,18 @@ int b3d_clr_backward(const b3d_clr_weights* w, const b3d_graph* g, const b3d_clr
 /* Modality presence (clr_att_gnn.py:107-121): has[n] = (sum of row n) != 0, rows of `width` floats. */
 int b3d_modality_mask(const float* feats, int32_t N, int32_t width, uint8_t* has /* [N] */, b3d_stream stream);
 
+/* ---- frame-wise k-NN + GATConv (pose_gnn.py:74-80, clr_att_gnn.py:178-184) as a standalone operator --
+ * For every distinct timestamp value: k nearest neighbours (Euclidean, feature space, no self
+ * loops, fewer than k in frames of <= k nodes) among the nodes of that frame, then
+ * GATConv(D, D, heads=1, add_self_loops=False) on that graph.  D = 48 or 96, k <= 32.
+ * out_nbr [N,32] int32 (neighbour node ids by ascending distance, unspecified beyond out_cnt),
+ * out_cnt [N] int32, out_y [N,D].  The model forwards run exactly this when B3D_FLAG_RUN_DEAD_KNN
+ * is set and discard the result, as the reference does. */
+size_t b3d_knn_gat_workspace_bytes(int32_t N, int32_t D);
+int b3d_knn_gat_forward(const float* x, const int64_t* node_timestamps, int32_t N, int32_t D, int32_t k,
+                        const b3d_gat* gat /* host */, void* workspace, size_t workspace_bytes,
+                        int32_t* out_nbr, int32_t* out_cnt, float* out_y, b3d_stream stream);
+
 /* ---- kernel-family timers (measurement aid for bench.py; off by default) --------------------
  * When enabled, every launch of the listed kernel families is bracketed by hipEventRecord on the
  * launch stream.  b3d_prof_read synchronises on the recorded events and returns the summed device

@@ -1,0 +1,42 @@
+"""GPU: frame-wise k-NN + GAT kernels against the oracle's restatement (third-party semantics,
+"parity unpinned": SURVEY.md section 8c; the reference discards this block's result)."""
+import pytest
+import torch
+
+from oracle import ref_torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dim,frames", [(48, [130, 70, 19, 1, 300]), (96, [90, 21, 64])])
+def test_knn_gat_matches_oracle(dim, frames):
+    from batch3dmot_amd import _lib
+    from batch3dmot_amd.pose_gnn import GATConvParams
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    n = sum(frames)
+    x = torch.randn(n, dim, generator=g)
+    ts = torch.cat([torch.full((m,), 100 + 7 * i, dtype=torch.long) for i, m in enumerate(frames)])
+    perm = torch.randperm(n, generator=g)              # frames interleaved in node order
+    x, ts = x[perm].contiguous(), ts[perm].contiguous()
+    conv = GATConvParams(dim)
+    with torch.no_grad():
+        conv.bias.copy_(torch.randn(dim, generator=g) * 0.1)
+    ora = ref_torch.GATConv(dim)
+    ora.load_state_dict(conv.state_dict())
+    nbr, cnt, y = _lib.knn_gat(x.to(dev), ts.to(dev), conv.to(dev), k=20)
+    nbr, cnt, y = nbr.cpu().long(), cnt.cpu().long(), y.cpu()
+    for t in torch.unique(ts).tolist():
+        idx = torch.nonzero(ts == t).squeeze(1)
+        xt = x[idx]
+        ei = ref_torch.knn_graph(xt, 20)
+        kk = min(20, idx.numel() - 1)
+        assert torch.all(cnt[idx] == max(kk, 0))
+        if kk <= 0:
+            continue
+        ref_nbr = idx[ei[0]].view(idx.numel(), kk)      # neighbours of centre j, ascending distance
+        got = nbr[idx][:, :kk]
+        # identical neighbour SETS (ordering may differ on float ties only)
+        assert torch.equal(torch.sort(got, 1).values, torch.sort(ref_nbr, 1).values)
+        yt = ora(xt, ei)
+        torch.testing.assert_close(y[idx], yt, rtol=1e-4, atol=1e-5)
