@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libb3d_hip.so")
 
 B3D_FLAG_TRAINING = 1
 B3D_FLAG_RUN_DEAD_KNN = 2
+B3D_FLAG_SINGLE_STREAM = 4
 
 c_float_p = C.POINTER(C.c_float)
 
@@ -126,7 +127,17 @@ def load() -> C.CDLL:
     lib.b3d_knn_gat_forward.restype = C.c_int
     lib.b3d_knn_gat_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(b3d_gat),
                                         C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.b3d_edge_loss_workspace_bytes.restype = C.c_size_t
+    lib.b3d_edge_loss_workspace_bytes.argtypes = [C.c_int32]
+    lib.b3d_edge_loss.restype = C.c_int
+    lib.b3d_edge_loss.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int32, C.c_int, C.c_float,
+                                  C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.b3d_adam_step.restype = C.c_int
+    lib.b3d_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
+                                  C.c_float, C.c_float, C.c_float, C.c_int64, C.c_void_p]
     lib.b3d_prof_enable.argtypes = [C.c_int]
+    lib.b3d_prof_select.argtypes = [C.c_uint32]
+    lib.b3d_prof_select.restype = C.c_int
     lib.b3d_prof_read.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]
     _lib = lib
     return lib
@@ -187,7 +198,14 @@ KERNEL_FAMILIES = {"mp_edge_fwd": 0, "mp_edge_bwd": 1, "mp_node_fwd": 2, "mp_nod
                    "wgrad_other": 5, "other": 6}
 
 
-def prof_enable(on: bool) -> None:
+def prof_enable(on: bool, families=None) -> None:
+    """Time kernel families with HIP events; ``families`` (names) restricts the event pairs."""
+    mask = 0xFFFFFFFF
+    if families is not None:
+        mask = 0
+        for f in families:
+            mask |= 1 << KERNEL_FAMILIES[f]
+    check(load().b3d_prof_select(C.c_uint32(mask)), "b3d_prof_select")
     check(load().b3d_prof_enable(1 if on else 0), "b3d_prof_enable")
     check(load().b3d_prof_reset(), "b3d_prof_reset")
 

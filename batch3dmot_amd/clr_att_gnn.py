@@ -23,7 +23,7 @@ import torch
 from torch import nn
 
 from . import _lib
-from ._lib import B3D_FLAG_RUN_DEAD_KNN, B3D_FLAG_TRAINING
+from ._lib import B3D_FLAG_RUN_DEAD_KNN, B3D_FLAG_SINGLE_STREAM, B3D_FLAG_TRAINING
 from .pose_gnn import GATConvParams, _linears, _mlp
 
 
@@ -107,7 +107,8 @@ class _GNNFunction(torch.autograd.Function):
         dev = pose_feats.device
         N, E = graph.N, graph.E
         nl, nr = int(lidar_nodes.numel()), int(radar_nodes.numel())
-        flags = (B3D_FLAG_TRAINING if training else 0) | (B3D_FLAG_RUN_DEAD_KNN if module.run_dead_knn else 0)
+        flags = ((B3D_FLAG_TRAINING if training else 0) | (B3D_FLAG_RUN_DEAD_KNN if module.run_dead_knn else 0)
+                 | (B3D_FLAG_SINGLE_STREAM if module.single_stream else 0))
         nbytes = lib.b3d_clr_workspace_bytes(N, E, nl, nr, module.depth, flags)
         if nbytes == 0:
             raise ValueError(f"unsupported gnn_depth {module.depth} (1..15)")
@@ -144,12 +145,16 @@ class _GNNFunction(torch.autograd.Function):
             d_prob = d_prob.contiguous().float()
         if d_x_sens is not None:
             d_x_sens = d_x_sens.contiguous().float()
-        grads = [torch.empty_like(p) for p in params]
+        sink = getattr(ctx.module, "_grad_sink", None)      # optim.FlatAdam: gradients land in its flat buffer
+        grads = sink.targets() if sink is not None else [torch.empty_like(p) for p in params]
         w = _clr_struct(_lib.b3d_clr_weights, params)
         g = _clr_struct(_lib.b3d_clr_grads, grads)
         _lib.check(lib.b3d_clr_backward(C.byref(w), C.byref(ctx.graph.c), C.byref(ctx.inp), ctx.module.depth, ctx.ws.data_ptr(),
                                         ctx.nbytes, _lib.ptr(d_prob), _lib.ptr(d_x_sens), C.byref(g), _lib.current_stream(dev)),
                    "b3d_clr_backward")
+        if sink is not None:
+            sink.deposited()
+            return (None,) * (11 + len(params))
         return (None,) * 11 + tuple(grads)
 
 
@@ -186,8 +191,14 @@ class GNN(nn.Module):
         self.att_edge_encoder = _mlp([640, 512, 384, 256, 128, 64])
         self.knn_conv = GATConvParams(96)
         self.run_dead_knn = True
+        self.single_stream = False     # True: no library side stream (B3D_FLAG_SINGLE_STREAM)
         self.keep_workspace = False
         self._last_workspace = None
+        self._grad_sink = None          # set by optim.FlatAdam: backward writes gradients into its flat buffer
+
+    def _hip_params(self):
+        """Parameters whose gradients ``backward`` of the HIP path produces, in C-ABI struct order."""
+        return _param_list(self)
 
     def encode_modalities(self, data):
         """The frozen, adjacent part (clr_att_gnn.py:107-141): presence masks, ResNet / PointNet /

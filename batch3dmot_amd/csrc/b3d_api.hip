@@ -24,6 +24,7 @@ namespace {
 struct ProfState {
   std::mutex mu;
   bool on = false;
+  unsigned mask = ~0u;                   // families that get event pairs while `on`
   std::vector<hipEvent_t> pool;          // event pairs: 2*i, 2*i+1
   std::vector<int> fam;                  // family of pair i
   size_t used = 0;                       // pairs handed out since reset
@@ -32,7 +33,7 @@ struct ProfState {
 ProfState& prof() { static ProfState p; return p; }
 }  // namespace
 
-bool prof_on() { return prof().on; }
+bool prof_on(int family) { return prof().on && ((prof().mask >> family) & 1u); }
 
 void prof_begin(int family, hipStream_t stream) {
   ProfState& p = prof();
@@ -60,12 +61,61 @@ void prof_end(hipStream_t stream) {
   p.open = -1;
 }
 
+namespace {
+struct SideSet {
+  bool made[kSideStreams] = {};
+  Side sd[kSideStreams];
+};
+std::mutex g_side_mu;
+constexpr int kMaxDevices = 64;
+SideSet g_sides[kMaxDevices];
+}  // namespace
+
+int side_get(int idx, Side** out) {
+  B3D_REQUIRE(idx >= 0 && idx < kSideStreams, "side_get: bad index %d", idx);
+  int dev = 0;
+  B3D_HIP_CHECK(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(g_side_mu);
+  B3D_REQUIRE(dev >= 0 && dev < kMaxDevices, "side_get: device ordinal %d not supported", dev);
+  SideSet& set = g_sides[dev];
+  if (!set.made[idx]) {
+    Side n{};
+    int prio_low = 0, prio_high = 0;                       // background work: lowest priority
+    B3D_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+    B3D_HIP_CHECK(hipStreamCreateWithPriority(&n.s, hipStreamNonBlocking, prio_low));
+    B3D_HIP_CHECK(hipEventCreateWithFlags(&n.ev_fork, hipEventDisableTiming));
+    B3D_HIP_CHECK(hipEventCreateWithFlags(&n.ev_join, hipEventDisableTiming));
+    set.sd[idx] = n;
+    set.made[idx] = true;
+  }
+  *out = &set.sd[idx];
+  return B3D_OK;
+}
+
+int side_fork(hipStream_t main, Side* sd) {
+  B3D_HIP_CHECK(hipEventRecord(sd->ev_fork, main));
+  B3D_HIP_CHECK(hipStreamWaitEvent(sd->s, sd->ev_fork, 0));
+  return B3D_OK;
+}
+
+int side_join(Side* sd, hipStream_t main) {
+  B3D_HIP_CHECK(hipEventRecord(sd->ev_join, sd->s));
+  B3D_HIP_CHECK(hipStreamWaitEvent(main, sd->ev_join, 0));
+  return B3D_OK;
+}
+
 }  // namespace b3d
 
 extern "C" int b3d_prof_enable(int on) {
   auto& p = b3d::prof();
   std::lock_guard<std::mutex> lk(p.mu);
   p.on = on != 0;
+  return B3D_OK;
+}
+extern "C" int b3d_prof_select(uint32_t family_mask) {
+  auto& p = b3d::prof();
+  std::lock_guard<std::mutex> lk(p.mu);
+  p.mask = family_mask;
   return B3D_OK;
 }
 extern "C" int b3d_prof_reset(void) {

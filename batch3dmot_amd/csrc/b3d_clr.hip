@@ -439,10 +439,17 @@ extern "C" int b3d_clr_forward(const b3d_clr_weights* pw, const b3d_graph* g, co
     a.save_in = w.pose_pad; a.save[0] = w.ne_a1; a.wpack = w.wp_ne;
     B3D_TRY(launch_rows<kNWNode>(chain_fwd_kernel<SeqNE, 0x1u, LoadUnaligned<19>, StoreAligned<6>, kNWNode>, "node_encoder", a, N, stream));
   }
+  Side* knn_side = nullptr;
   for (int l = 0; l < depth; ++l) {
     if ((flags & B3D_FLAG_RUN_DEAD_KNN) && (l % 2 == 0)) {
       B3D_REQUIRE(in->node_timestamps != nullptr, "node_timestamps required with B3D_FLAG_RUN_DEAD_KNN");
-      B3D_TRY(knn_gat_block<D::DX>(w.knn, w.x[l], in->node_timestamps, N, pw->knn_conv, 20, stream));
+      hipStream_t ks = stream;
+      if (!(flags & B3D_FLAG_SINGLE_STREAM)) {
+        if (!knn_side) B3D_TRY(side_get(0, &knn_side));
+        B3D_TRY(side_fork(stream, knn_side));              // x[l] is complete on `stream` here
+        ks = knn_side->s;
+      }
+      B3D_TRY(knn_gat_block<D::DX>(w.knn, w.x[l], in->node_timestamps, N, pw->knn_conv, 20, ks));
     }
     EdgeFwdArgs ea;
     memset(&ea, 0, sizeof(ea));
@@ -465,6 +472,7 @@ extern "C" int b3d_clr_forward(const b3d_clr_weights* pw, const b3d_graph* g, co
     B3D_TRY(launch_rows<kNWEdge>(chain_fwd_kernel<SeqCls, 0x7u, LoadAligned<4>, StoreScalar, kNWEdge>, "edge_classifier", a, E, stream));
     B3D_HIP_CHECK(hipMemcpyAsync(out_prob, w.prob, (size_t)E * sizeof(float), hipMemcpyDeviceToDevice, stream));
   }
+  if (knn_side) B3D_TRY(side_join(knn_side, stream));
   return B3D_OK;
 }
 

@@ -47,15 +47,28 @@ inline int grid_for_tiles(long rows, int tile_rows, int cap = 2048) {
 }
 
 // Kernel-family timers (b3d_prof_*): records an event pair around a launch when enabled.
-bool prof_on();
+bool prof_on(int family);
 void prof_begin(int family, hipStream_t stream);
 void prof_end(hipStream_t stream);
 struct ProfScope {
   hipStream_t s;
   bool on;
-  ProfScope(int family, hipStream_t stream) : s(stream), on(prof_on()) { if (on) prof_begin(family, s); }
+  ProfScope(int family, hipStream_t stream) : s(stream), on(prof_on(family)) { if (on) prof_begin(family, s); }
   ~ProfScope() { if (on) prof_end(s); }
 };
+
+// Library-owned side streams (one set per device, created on first use, never destroyed): work
+// that has no consumer on the caller's stream until later (the discarded k-NN + GAT block, weight
+// gradients) is forked onto them and joined back before the entry point returns, so that from the
+// caller's point of view everything is still ordered on the stream it passed.
+struct Side {
+  hipStream_t s;
+  hipEvent_t ev_fork, ev_join;
+};
+int side_get(int idx, Side** out);             // idx < kSideStreams
+int side_fork(hipStream_t main, Side* sd);     // side waits for all work enqueued on main so far
+int side_join(Side* sd, hipStream_t main);     // main waits for all work enqueued on side so far
+constexpr int kSideStreams = 2;
 
 // Bump allocator over a caller-provided workspace (the library allocates nothing).
 struct Carver {

@@ -104,12 +104,15 @@ __device__ __forceinline__ void wave_argmin(float& d, int& j) {
   }
 }
 
-// One wavefront per centre, 16 centres (consecutive in frame order) per workgroup.  Candidate rows
-// are staged through LDS in tiles of 64, so a candidate row is fetched from L2 once per 16 centres
-// instead of once per centre; each lane computes the squared distance of its candidate to the
-// wave's centre from LDS, the distances of the whole frame stay in a per-wave LDS list, and the k
-// nearest are extracted by k rounds of a wavefront arg-min.
-constexpr int kKnnCentres = 16;
+// One wavefront per centre, kKnnCentres centres (consecutive in frame order) per workgroup.
+// Candidate rows are staged through LDS in tiles of kKnnTileRows, so a candidate row is fetched from
+// L2 once per workgroup instead of once per centre; each lane computes the squared distance of its
+// candidate to the wave's centre from LDS, the distances of the whole frame stay in a per-wave LDS
+// list, and the k nearest are extracted by k rounds of a wavefront arg-min.  The footprint (4 waves,
+// < 45 KB LDS) is chosen so that these workgroups fit on a CU NEXT to a resident edge-phase
+// workgroup (104 KB LDS, 8 waves): the block runs on a side stream underneath the layer it belongs to.
+constexpr int kKnnCentres = 4;
+constexpr int kKnnTileRows = 64;
 constexpr int kKnnList = 1024;        // frame sizes up to this use the tiled kernel
 template <int D>
 __global__ __launch_bounds__(kKnnCentres * 64) void knn_tile_kernel(const float* __restrict__ x, int N, int k,
@@ -119,7 +122,9 @@ __global__ __launch_bounds__(kKnnCentres * 64) void knn_tile_kernel(const float*
                                                                     int* __restrict__ nbr, int* __restrict__ cnt,
                                                                     int* __restrict__ overflow) {
   constexpr int TS = D + 1;                               // padded tile row (bank spread)
-  __shared__ float tile[64 * TS];
+  constexpr int TR = kKnnTileRows;                        // candidate rows per tile
+  constexpr int NT = kKnnCentres * 64;
+  __shared__ float tile[2][TR * TS];                      // double buffered: one barrier per tile
   __shared__ float dist[kKnnCentres][kKnnList];
   __shared__ int wb[kKnnCentres], we[kKnnCentres];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -142,28 +147,58 @@ __global__ __launch_bounds__(kKnnCentres * 64) void knn_tile_kernel(const float*
     xc[d] = v.x; xc[d + 1] = v.y; xc[d + 2] = v.z; xc[d + 3] = v.w;
   }
   const float INF = __builtin_inff();
-  for (int t0 = ub; t0 < ue; t0 += 64) {
-    // stage 64 candidate rows (positions t0 .. t0+63 of the frame order)
-    for (int i = threadIdx.x; i < 64 * (D / 4); i += blockDim.x) {
-      const int r = i / (D / 4), c4 = i - r * (D / 4);
-      v4f v = {0.f, 0.f, 0.f, 0.f};
-      if (t0 + r < ue) v = *reinterpret_cast<const v4f*>(x + (size_t)order[t0 + r] * D + 4 * c4);
-      float* dst = tile + r * TS + 4 * c4;
-      dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
-    }
-    __syncthreads();
-    const int p = t0 + lane;                              // this lane's candidate position
-    if (live && !big && p >= b && p < e) {
-      const float* row = tile + lane * TS;
-      float s2 = 0.f;
+  constexpr int PER = TR * (D / 4) / NT;                  // v4f staged per thread per tile
+  static_assert(PER * NT == TR * (D / 4), "tile must divide over the workgroup");
+  // Software pipeline: while tile i is evaluated from LDS, the rows of tile i+1 are in flight to
+  // registers and the gather indices of tile i+2 are being fetched.
+  int ridx[PER];
+  v4f v[PER];
+  auto load_idx = [&](int t0) {
 #pragma unroll
-      for (int d = 0; d < D; ++d) { const float a = row[d] - xc[d]; s2 = fmaf(a, a, s2); }
-      dist[wave][p - b] = (p == pos) ? INF : s2;
+    for (int j = 0; j < PER; ++j) {
+      const int r = (threadIdx.x + j * NT) / (D / 4);
+      ridx[j] = (t0 + r < ue) ? order[t0 + r] : -1;
+    }
+  };
+  auto load_rows = [&]() {
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int i = threadIdx.x + j * NT;
+      const int c4 = i % (D / 4);
+      v[j] = v4f{0.f, 0.f, 0.f, 0.f};
+      if (ridx[j] >= 0) v[j] = *reinterpret_cast<const v4f*>(x + (size_t)ridx[j] * D + 4 * c4);
+    }
+  };
+  load_idx(ub);
+  load_rows();
+  load_idx(ub + TR);
+  int cur = 0;
+  for (int t0 = ub; t0 < ue; t0 += TR, cur ^= 1) {
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int i = threadIdx.x + j * NT;
+      const int r = i / (D / 4), c4 = i - r * (D / 4);
+      float* dst = tile[cur] + r * TS + 4 * c4;
+      dst[0] = v[j].x; dst[1] = v[j].y; dst[2] = v[j].z; dst[3] = v[j].w;
     }
     __syncthreads();
+    load_rows();                                          // tile t0 + TR (indices fetched one tile ago)
+    load_idx(t0 + 2 * TR);
+#pragma unroll
+    for (int u = 0; u < TR / 64; ++u) {
+      const int p = t0 + 64 * u + lane;                   // this lane's candidate position
+      if (live && !big && p >= b && p < e) {
+        const float* row = tile[cur] + (64 * u + lane) * TS;
+        float s2 = 0.f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) { const float a = row[d] - xc[d]; s2 = fmaf(a, a, s2); }
+        dist[wave][p - b] = (p == pos) ? INF : s2;
+      }
+    }
   }
   if (!live || big) return;
   const int kk = (k < nt - 1) ? k : (nt - 1);
+  int mine = 0;
   for (int r = 0; r < kk; ++r) {
     float bd = INF; int bp = 0x7fffffff;
     for (int q = lane; q < nt; q += 64) {
@@ -171,9 +206,10 @@ __global__ __launch_bounds__(kKnnCentres * 64) void knn_tile_kernel(const float*
       if (dv < bd) { bd = dv; bp = q; }
     }
     wave_argmin(bd, bp);
-    if (lane == 0) nbr[(size_t)c * kKnnMaxK + r] = order[b + bp];
+    if (lane == r) mine = bp;                               // lane r keeps the r-th nearest
     if ((bp & 63) == lane) dist[wave][bp] = INF;
   }
+  if (lane < kk) nbr[(size_t)c * kKnnMaxK + lane] = order[b + mine];
   if (lane == 0) cnt[c] = kk > 0 ? kk : 0;
 }
 

@@ -318,11 +318,18 @@ extern "C" int b3d_pose_forward(const b3d_pose_weights* pw, const b3d_graph* g, 
   }
   B3D_HIP_CHECK(hipMemcpyAsync(out_x_enc, w.x[0], (size_t)N * D::DX * sizeof(float), hipMemcpyDeviceToDevice, stream));
 
+  Side* knn_side = nullptr;
   for (int l = 0; l < depth; ++l) {
     if ((flags & B3D_FLAG_RUN_DEAD_KNN) && (l % 2 == 0)) {
       // frame-wise k-NN + GAT whose result the reference discards          pose_gnn.py:74-80
       B3D_REQUIRE(node_timestamps != nullptr, "node_timestamps required with B3D_FLAG_RUN_DEAD_KNN");
-      B3D_TRY(knn_gat_block<D::DX>(w.knn, w.x[l], node_timestamps, N, pw->knn_conv, 20, stream));
+      hipStream_t ks = stream;
+      if (!(flags & B3D_FLAG_SINGLE_STREAM)) {
+        if (!knn_side) B3D_TRY(side_get(0, &knn_side));
+        B3D_TRY(side_fork(stream, knn_side));              // x[l] is complete on `stream` here
+        ks = knn_side->s;
+      }
+      B3D_TRY(knn_gat_block<D::DX>(w.knn, w.x[l], node_timestamps, N, pw->knn_conv, 20, ks));
     }
     EdgeFwdArgs ea;
     memset(&ea, 0, sizeof(ea));
@@ -348,6 +355,7 @@ extern "C" int b3d_pose_forward(const b3d_pose_weights* pw, const b3d_graph* g, 
     a.wpack = w.wp_cls;
     B3D_TRY(launch_rows<kNWEdge>(chain_fwd_kernel<SeqCls, 0x7u, LoadAligned<2>, StoreScalar, kNWEdge>, "edge_classifier", a, E, stream));
   }
+  if (knn_side) B3D_TRY(side_join(knn_side, stream));
   return B3D_OK;
 }
 

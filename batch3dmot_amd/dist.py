@@ -18,8 +18,14 @@ import torch.distributed as dist
 
 
 class FlatGradSync:
-    def __init__(self, params: Iterable[torch.nn.Parameter], group: Optional[dist.ProcessGroup] = None):
-        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+    """``FlatGradSync(params)`` or ``FlatGradSync(params, flat=optim.FlatAdam)``: with a FlatAdam the
+    gradients of its parameters already live in one buffer and are reduced in place; everything else
+    is packed into a second flat buffer."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], group: Optional[dist.ProcessGroup] = None, flat=None):
+        self.flat_opt = flat
+        skip = {id(p) for p in flat.params} if flat is not None else set()
+        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad and id(p) not in skip]
         self.group = group
         self._flat: Optional[torch.Tensor] = None
 
@@ -29,8 +35,14 @@ class FlatGradSync:
 
     def sync(self) -> None:
         """grad <- mean over ranks.  Call between backward() and optimizer.step()."""
+        if self.world_size == 1:
+            return
+        if self.flat_opt is not None and not self.flat_opt.fresh:
+            g = self.flat_opt.flat_grad
+            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+            g.mul_(1.0 / self.world_size)
         live = [p for p in self.params if p.grad is not None]
-        if not live or self.world_size == 1:
+        if not live:
             return
         n = sum(p.grad.numel() for p in live)
         if self._flat is None or self._flat.numel() != n or self._flat.device != live[0].grad.device:

@@ -13,7 +13,7 @@ import torch
 from torch import nn
 
 from . import _lib
-from ._lib import B3D_FLAG_RUN_DEAD_KNN, B3D_FLAG_TRAINING
+from ._lib import B3D_FLAG_RUN_DEAD_KNN, B3D_FLAG_SINGLE_STREAM, B3D_FLAG_TRAINING
 
 
 def _mlp(dims, inplace_relu=False):
@@ -108,7 +108,8 @@ class _PoseGNNFunction(torch.autograd.Function):
         lib = _lib.load()
         dev = pose_feats.device
         N, E = graph.N, graph.E
-        flags = (B3D_FLAG_TRAINING if training else 0) | (B3D_FLAG_RUN_DEAD_KNN if module.run_dead_knn else 0)
+        flags = ((B3D_FLAG_TRAINING if training else 0) | (B3D_FLAG_RUN_DEAD_KNN if module.run_dead_knn else 0)
+                 | (B3D_FLAG_SINGLE_STREAM if module.single_stream else 0))
         nbytes = lib.b3d_pose_workspace_bytes(N, E, module.depth, flags)
         if nbytes == 0:
             raise ValueError(f"unsupported gnn_depth {module.depth} (1..15)")
@@ -143,13 +144,17 @@ class _PoseGNNFunction(torch.autograd.Function):
             d_logits = d_logits.contiguous().float()
         if d_x_enc is not None:
             d_x_enc = d_x_enc.contiguous().float()
-        grads = [torch.empty_like(p) for p in params]
+        sink = getattr(ctx.module, "_grad_sink", None)      # optim.FlatAdam: gradients land in its flat buffer
+        grads = sink.targets() if sink is not None else [torch.empty_like(p) for p in params]
         w = _pose_struct(_lib.b3d_pose_weights, params)
         g = _pose_struct(_lib.b3d_pose_grads, grads)
         _lib.check(lib.b3d_pose_backward(C.byref(w), C.byref(ctx.graph.c), pose_feats.data_ptr(), edge_attr.data_ptr(),
                                          ctx.module.depth, ctx.ws.data_ptr(), ctx.nbytes, _lib.ptr(d_logits),
                                          _lib.ptr(d_x_enc), C.byref(g), _lib.current_stream(dev)),
                    "b3d_pose_backward")
+        if sink is not None:
+            sink.deposited()
+            return (None,) * (6 + len(params))
         return (None, None, None, None, None, None) + tuple(grads)
 
 
@@ -176,8 +181,14 @@ class PoseGNN(nn.Module):
         self.knn_conv = GATConvParams(48)
         self.message_passing = CausalMessagePassing()
         self.run_dead_knn = True
+        self.single_stream = False     # True: no library side stream (B3D_FLAG_SINGLE_STREAM)
         self.keep_workspace = False
         self._last_workspace = None
+        self._grad_sink = None          # set by optim.FlatAdam: backward writes gradients into its flat buffer
+
+    def _hip_params(self):
+        """Parameters whose gradients ``backward`` of the HIP path produces, in C-ABI struct order."""
+        return _param_list(self)
 
     def forward(self, data):
         pose_feats, edge_index, edge_attr, node_timestamps, _batch = (

@@ -4,9 +4,10 @@
     loss   = BCELoss(weight=data.edge_weights)(out, data.y.float()) / params.gnn.batch_size
     optimizer.zero_grad(); loss.backward(); optimizer.step()
 
-The loss itself is a handful of element-wise torch ops on an [E] vector (the fused loss kernel is
-a "next" row of SURVEY.md section 8f).  ``PoseGNN`` emits logits (pose_gnn.py:45-53; the release
-ships no trainer for it), so its step uses the numerically equivalent BCE-with-logits.
+``edge_loss`` is that loss as a handful of element-wise torch ops; ``fused_edge_loss`` is the same
+value and its gradient from one HIP kernel (``b3d_edge_loss``), which ``train_step`` uses on the
+GPU.  ``PoseGNN`` emits logits (pose_gnn.py:45-53; the release ships no trainer for it), so its step
+uses the numerically equivalent BCE-with-logits.
 """
 from __future__ import annotations
 
@@ -27,21 +28,66 @@ def edge_loss(out: torch.Tensor, data, batch_size: int, loss_kind: str = "cb", l
     return loss / batch_size                                       # train.py:141
 
 
+def fused_edge_loss(out: torch.Tensor, data, batch_size: int, loss_kind: str = "cb", logits: bool = False):
+    """(loss, d loss / d out) of ``edge_loss`` from one kernel launch.  ``out`` [E,1] or [E] on the GPU."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    o = out.detach().reshape(-1)
+    _lib.require_cuda(o, "out", torch.float32)
+    y = data.y.reshape(-1)
+    if y.dtype not in (torch.float32, torch.int64):
+        y = y.float()
+    y = y.contiguous()
+    w = data.edge_weights.reshape(-1).float().contiguous() if loss_kind == "cb" else None
+    n = o.numel()
+    if y.numel() != n or (w is not None and w.numel() != n):
+        raise ValueError(f"edge loss: out has {n} rows, y {y.numel()}, weights {None if w is None else w.numel()}")
+    loss = torch.empty((), dtype=torch.float32, device=o.device)
+    grad = torch.empty_like(o)
+    nbytes = lib.b3d_edge_loss_workspace_bytes(n)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=o.device)
+    _lib.check(lib.b3d_edge_loss(o.data_ptr(), y.data_ptr(), int(y.dtype == torch.int64),
+                                 w.data_ptr() if w is not None else None, n, int(bool(logits)),
+                                 C.c_float(1.0 / batch_size), ws.data_ptr(), nbytes, loss.data_ptr(), grad.data_ptr(),
+                                 _lib.current_stream(o.device)), "b3d_edge_loss")
+    return loss, grad.view_as(out)
+
+
 def train_step(gnn, data, optimizer, batch_size: int = 2, loss_kind: str = "cb", logits: bool = False,
-               grad_sync: Optional[object] = None):
+               grad_sync: Optional[object] = None, fused_loss: Optional[bool] = None):
     """One optimisation step; ``grad_sync`` (batch3dmot_amd.dist.FlatGradSync) averages gradients over
-    the ranks of a data-parallel job between backward and the optimizer step."""
+    the ranks of a data-parallel job between backward and the optimizer step.  ``fused_loss``
+    (default: on when the model output lives on the GPU) takes loss and d loss/d out from
+    ``b3d_edge_loss`` and seeds ``out.backward`` with it."""
     out, aux = gnn(data)
-    loss = edge_loss(out, data, batch_size, loss_kind, logits)
-    optimizer.zero_grad(set_to_none=True)
-    loss.backward()
+    if fused_loss is None:
+        fused_loss = out.is_cuda
+    if hasattr(optimizer, "flat_grad"):
+        optimizer.zero_grad()                   # optim.FlatAdam: lazy (the backward overwrites the flat buffer)
+    else:
+        optimizer.zero_grad(set_to_none=True)
+    if fused_loss:
+        loss, g = fused_edge_loss(out, data, batch_size, loss_kind, logits)
+        out.backward(g)
+    else:
+        loss = edge_loss(out, data, batch_size, loss_kind, logits)
+        loss.backward()
     if grad_sync is not None:
         grad_sync.sync()
     optimizer.step()
     return loss.detach(), out.detach(), aux
 
 
-def make_optimizer(gnn, lr: float = 1e-4, weight_decay: float = 1e-4, betas=(0.9, 0.999)):
-    """Adam exactly as train.py:106-109 (``gnn.*`` keys of the YAML config)."""
+def make_optimizer(gnn, lr: float = 1e-4, weight_decay: float = 1e-4, betas=(0.9, 0.999), flat: Optional[bool] = None):
+    """Adam exactly as train.py:106-109 (``gnn.*`` keys of the YAML config).  ``flat`` (default: on
+    for a GPU-resident PoseGNN / GNN whose Linear stacks are all trainable) returns
+    ``optim.FlatAdam``: same update, one kernel launch, gradients written in place by the backward."""
     params = [p for p in gnn.parameters() if p.requires_grad]
+    if flat is None:
+        hip = list(gnn._hip_params()) if hasattr(gnn, "_hip_params") else []
+        flat = bool(hip) and all(p.is_cuda and p.requires_grad for p in hip)
+    if flat:
+        from .optim import FlatAdam
+        return FlatAdam(gnn, lr=lr, weight_decay=weight_decay, betas=betas)
     return torch.optim.Adam(params, lr=lr, weight_decay=weight_decay, betas=betas)

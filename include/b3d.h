@@ -103,6 +103,11 @@ typedef struct b3d_pose_grads {
 #define B3D_FLAG_TRAINING      1u   /* keep what backward needs in the workspace            */
 #define B3D_FLAG_RUN_DEAD_KNN  2u   /* execute the frame-wise k-NN + GAT block whose result the
                                        reference discards (pose_gnn.py:74-80)                 */
+#define B3D_FLAG_SINGLE_STREAM 4u   /* enqueue every kernel on `stream` itself.  By default work with
+                                       no consumer until the end of the call (the discarded k-NN +
+                                       GAT block) runs on a library-owned side stream that is forked
+                                       from and joined back into `stream` inside the call; results
+                                       and ordering as seen from `stream` are the same either way  */
 
 /* ---- PoseGNN.forward / backward ------------------------------------------------------------ */
 size_t b3d_pose_workspace_bytes(int32_t N, int32_t E, int32_t depth, uint32_t flags);
@@ -199,6 +204,23 @@ int b3d_knn_gat_forward(const float* x, const int64_t* node_timestamps, int32_t 
                         const b3d_gat* gat /* host */, void* workspace, size_t workspace_bytes,
                         int32_t* out_nbr, int32_t* out_cnt, float* out_y, b3d_stream stream);
 
+/* ---- fused edge loss of the training loop (train.py:136-141) ----------------------------------------
+ *   loss = scale * mean_i( w_i * BCE(out_i, y_i) ),   d_out_i = d loss / d out_i,   scale = 1/batch_size
+ * out [E] float32: probabilities (torch.nn.BCELoss semantics incl. the -100 log clamp) or, with
+ * from_logits != 0, logits (BCEWithLogitsLoss).  y [E]: float32, or int64 when y_is_int64 != 0.
+ * weight [E] float32 or NULL (train.py:136-139, the class-balanced factors `data.edge_weights`).
+ * loss_out: device float[1].  d_out [E] or NULL.  E == 0 is an error.  Deterministic reduction. */
+size_t b3d_edge_loss_workspace_bytes(int32_t E);
+int b3d_edge_loss(const float* out, const void* y, int y_is_int64, const float* weight, int32_t E, int from_logits,
+                  float scale, void* workspace, size_t workspace_bytes, float* loss_out, float* d_out,
+                  b3d_stream stream);
+
+/* ---- Adam step of the training loop (train.py:106-109, 160) over one contiguous fp32 buffer --------
+ * torch.optim.Adam(lr, betas, eps, weight_decay) semantics (L2 decay added to the gradient, bias
+ * corrections from `step` = 1, 2, ...; amsgrad off).  All four arrays [n] on the device. */
+int b3d_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                  float beta1, float beta2, float eps, float weight_decay, int64_t step, b3d_stream stream);
+
 /* ---- kernel-family timers (measurement aid for bench.py; off by default) --------------------
  * When enabled, every launch of the listed kernel families is bracketed by hipEventRecord on the
  * launch stream.  b3d_prof_read synchronises on the recorded events and returns the summed device
@@ -214,6 +236,8 @@ typedef enum b3d_kernel_family {
   B3D_K_COUNT = 7
 } b3d_kernel_family;
 int b3d_prof_enable(int on);
+int b3d_prof_select(uint32_t family_mask);   /* bit f set: family f is timed while enabled (default: all).  Event
+                                               pairs cost device time; time one family to measure it undisturbed */
 int b3d_prof_reset(void);
 int b3d_prof_read(int family, double* total_ms /* host */, int* launches /* host */);
 

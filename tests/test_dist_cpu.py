@@ -35,6 +35,16 @@ def _worker(rank, world, port, ret):
     sync = FlatGradSync(m.parameters())
     sync.sync()
     ret[rank] = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    # flat-optimizer fast path (optim.FlatAdam keeps its gradients in one buffer): reduced in place,
+    # its parameters left out of the packed exchange
+    import types
+    flat_params = list(m.message_passing.parameters())
+    buf = torch.full((7,), float(rank + 1))
+    stub = types.SimpleNamespace(params=flat_params, fresh=False, flat_grad=buf)
+    before = {id(p): p.grad.clone() for p in flat_params}
+    FlatGradSync(m.parameters(), flat=stub).sync()
+    assert torch.equal(buf, torch.full((7,), 1.5))
+    assert all(torch.equal(p.grad, before[id(p)]) for p in flat_params)
     dist.destroy_process_group()
 
 

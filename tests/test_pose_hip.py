@@ -194,3 +194,65 @@ def test_invalid_inputs_raise():
     # out-of-range node ids are neutralised by the graph build (never dereferenced)
     m(data_from({**d.__dict__, "edge_index": oob}))
     torch.cuda.synchronize()
+
+
+def _tiny_batch(dev, idx=0):
+    from batch3dmot_amd import synth
+    return synth.make_batch(2, 60, None, first_graph_idx=700 + idx, k=6).to(dev)
+
+
+def test_flat_adam_matches_torch_adam():
+    """optim.FlatAdam (one b3d_adam_step launch, gradients written in place by backward) == torch.optim.Adam
+    (train.py:106-109) on the same model, data and hyper-parameters, step for step."""
+    import copy
+    from batch3dmot_amd.pose_gnn import PoseGNN
+    from batch3dmot_amd.optim import FlatAdam
+    from batch3dmot_amd.train_step import train_step
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    a = PoseGNN().to(dev)
+    b = copy.deepcopy(a)
+    hp = dict(lr=1e-3, weight_decay=1e-4, betas=(0.9, 0.999))
+    opt_a = torch.optim.Adam([p for p in a.parameters() if p.requires_grad], **hp)
+    opt_b = FlatAdam(b, **hp)
+    keys = list(a.state_dict().keys())
+    assert list(b.state_dict().keys()) == keys                      # re-pointing keeps names and shapes
+    for i in range(4):
+        data = _tiny_batch(dev, i)
+        la, _, _ = train_step(a, data, opt_a, logits=True, fused_loss=False)
+        lb, _, _ = train_step(b, data, opt_b, logits=True)
+        torch.testing.assert_close(lb, la, rtol=1e-5, atol=1e-7)
+    sa, sb = a.state_dict(), b.state_dict()
+    for k in keys:
+        torch.testing.assert_close(sb[k], sa[k], rtol=2e-5, atol=2e-7, msg=k)
+    assert opt_b.step_count == 4
+    # knn_conv never receives a gradient: untouched by both optimizers
+    assert torch.equal(sb["knn_conv.bias"], sa["knn_conv.bias"])
+
+
+def test_flat_adam_gradient_accumulation_and_zero_grad():
+    from batch3dmot_amd.pose_gnn import PoseGNN
+    from batch3dmot_amd.optim import FlatAdam
+    dev = torch.device("cuda:0")
+    torch.manual_seed(4)
+    m = PoseGNN().to(dev)
+    opt = FlatAdam(m, lr=1e-3)
+    d0, d1 = _tiny_batch(dev, 10), _tiny_batch(dev, 11)
+    m(d0)[0].sum().backward()
+    g0 = opt.flat_grad.clone()
+    assert m.edge_encoder[0].weight.grad.data_ptr() == opt.flat_grad.data_ptr()    # .grad is a view of the buffer
+    m(d1)[0].sum().backward()                                                     # no zero_grad: accumulates
+    g01 = opt.flat_grad.clone()
+    opt.zero_grad()
+    m(d1)[0].sum().backward()                                                     # lazy zero_grad: overwritten
+    g1 = opt.flat_grad.clone()
+    torch.testing.assert_close(g01, g0 + g1, rtol=1e-6, atol=1e-6)
+    before = opt.flat_param.clone()
+    opt.zero_grad()
+    opt.step()                                                                    # nothing deposited: no update
+    assert torch.equal(opt.flat_param, before)
+    opt.zero_grad(set_to_none=True)
+    assert m.edge_encoder[0].weight.grad is None
+    sd = opt.state_dict()
+    opt.load_state_dict(sd)
+    assert opt.step_count == sd["step"]
