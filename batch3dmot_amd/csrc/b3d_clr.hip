@@ -462,7 +462,7 @@ extern "C" int b3d_clr_forward(const b3d_clr_weights* pw, const b3d_graph* g, co
     na.N = N; na.dst_ptr = g->dst_ptr; na.dst_perm = g->dst_perm; na.src_ptr = g->src_ptr; na.src_perm = g->src_perm;
     na.past = w.past; na.fut = w.fut; na.M = w.M[l]; na.x_out = w.x[l + 1]; na.sH1 = w.nH1[l]; na.sH2 = w.nH2[l];
     na.wpack = w.wp_nfwd;
-    B3D_TRY(launch_rows<kNWNode>(mp_node_fwd_kernel<D, kNWNode>, "mp_node_fwd", na, N, stream, B3D_K_NODE_FWD));
+    B3D_TRY(launch_node_split<D>(mp_node_fwd_split_kernel<D>, "mp_node_fwd", na, N, stream, B3D_K_NODE_FWD));
   }
   {  // edge classifier 64-32-16-8-1 + Sigmoid (:49-58,188)
     ChainFwdArgs<LoadAligned<4>, StoreScalar> a;
@@ -524,7 +524,7 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
       nb.sH1 = w.nH1[l]; nb.sH2 = w.nH2[l];
       nb.dM = w.dM + l * nLm; nb.Gdx = w.Gdx + l * nLx; nb.GdH2 = w.GnH2 + l * nL2; nb.GdH1 = w.GnH1 + l * nL1;
       nb.wpack = w.wp_nbwd;
-      B3D_TRY(launch_rows<kNWNode>(mp_node_bwd_kernel<D, kNWNode>, "mp_node_bwd", nb, N, stream, B3D_K_NODE_BWD));
+      B3D_TRY(launch_node_split<D>(mp_node_bwd_split_kernel<D>, "mp_node_bwd", nb, N, stream, B3D_K_NODE_BWD));
       dx0_first = false;
     }
     EdgeBwdArgs eb;

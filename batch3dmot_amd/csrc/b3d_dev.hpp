@@ -372,4 +372,46 @@ __device__ __forceinline__ void segment_sum(const float* __restrict__ base, int 
   }
 }
 
+// Deep variant for kernels with few feature blocks per wavefront: U rows in flight per lane, the
+// gather indices of the next batch fetched while the rows of this one are in flight, slots beyond
+// the segment end masked (they re-read the segment's last row).  Same summation order as above.
+template <int NBLK, int U>
+__device__ __forceinline__ void segment_sum_deep(const float* __restrict__ base, int stride, int col0,
+                                                 const int* __restrict__ perm, int beg, int end,
+                                                 v4f* __restrict__ acc) {
+  const int q = (threadIdx.x & 63) >> 4;
+  const float* b0 = base + col0 + 4 * q;
+  if (beg >= end) return;
+  const int last = end - 1;
+  int r[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int kk = (beg + u < end) ? beg + u : last;
+    r[u] = perm ? perm[kk] : kk;
+  }
+  for (int k = beg; k < end; k += U) {
+    v4f t[U][NBLK];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float* p = b0 + (long)r[u] * stride;
+#pragma unroll
+      for (int b = 0; b < NBLK; ++b) t[u][b] = *reinterpret_cast<const v4f*>(p + 16 * b);
+    }
+    if (k + U < end) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int kk = (k + U + u < end) ? k + U + u : last;
+        r[u] = perm ? perm[kk] : kk;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (k + u < end) {
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) acc[b] += t[u][b];
+      }
+    }
+  }
+}
+
 }  // namespace b3d

@@ -4,6 +4,7 @@
 #include "b3d_common.hpp"
 #include "b3d_chain.hpp"
 #include "b3d_mp.hpp"
+#include "b3d_node.hpp"
 #include "b3d_pack.hpp"
 #include "b3d_wgrad.hpp"
 
@@ -31,6 +32,16 @@ inline int launch_rows(Kern kernel, const char* name, const Args& a, long rows, 
   return launch_check(name);
 }
 constexpr int kNWEdge = 8, kNWNode = 1;
+
+// Node phase of a message-passing layer: 4 wavefronts per 16-row tile (b3d_node.hpp).
+template <class D, class Kern, class Args>
+inline int launch_node_split(Kern kernel, const char* name, const Args& a, long rows, hipStream_t stream, int family) {
+  if (rows <= 0) return B3D_OK;
+  B3D_TRY(set_lds(kernel, NodeSplit<D>::LDS_BYTES));
+  ProfScope ps(family, stream);
+  hipLaunchKernelGGL(kernel, dim3((unsigned)((rows + 15) / 16)), dim3(kNodeWaves * 64), NodeSplit<D>::LDS_BYTES, stream, a);
+  return launch_check(name);
+}
 
 inline WgSeg seg(const float* p, const int* idx, int stride, int col0, int width) {
   WgSeg s;

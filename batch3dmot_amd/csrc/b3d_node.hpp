@@ -1,0 +1,246 @@
+// Node phase of CausalMessagePassing for node-sized inputs (a few thousand rows): FOUR wavefronts
+// share one 16-row tile.
+//
+// With one wavefront per tile (mp_node_*_kernel<D, 1>) a tile is a serial chain -- two gathered
+// segment sums, then three Linear layers whose MFMAs all sit on one SIMD -- and ~190 such chains
+// are all the parallelism a 3,000-node batch offers: the launch is latency bound at ~5 TFLOP/s.
+// Here the chain is cut across the 4 SIMDs of a CU:
+//   * segment sums: each wavefront sums a slice of the feature blocks of ONE of the two lists;
+//   * every Linear: wavefront w computes the output blocks mb with mb % 4 == w (same fmaf chain
+//     per output as the single-wave kernel, so results are bitwise those of mp_node_*_kernel for
+//     the forward; the backward adds the two list partials in a different, fixed, order);
+//   * activations travel between layers through a ping-pong LDS buffer in register ("layout L")
+//     image form: block b, lane l -> float4 at [b][l]; conflict-free b128 accesses.
+// Weights stream through the same two-slot LDS ring as everywhere else.
+#pragma once
+#include "b3d_mp.hpp"
+
+namespace b3d {
+
+constexpr int kNodeWaves = 4;
+
+template <class D>
+struct NodeSplit {
+  static constexpr int XB = D::DX / 16, DMB = D::DM / 16, H1B = D::NH1 / 16, H2B = D::NH2 / 16;
+  // exchange buffer: the widest thing that crosses waves (backward: two partial gradient rows)
+  static constexpr int XBUF_BLOCKS = 4 * XB > 2 * DMB ? (4 * XB > H1B ? 4 * XB : H1B) : (2 * DMB > H1B ? 2 * DMB : H1B);
+  static constexpr int LDS_BYTES = kLdsBytes + 2 * XBUF_BLOCKS * 64 * 16;
+};
+
+// One Linear layer, output blocks split over the NWS wavefronts of the workgroup.
+//   inload(): fills in[] -- called after the first chunk's barrier, i.e. when the previous layer's
+//             LDS writes of every wavefront are visible;
+//   emit(mb, v): called by the wavefront that owns output block mb.
+template <class Seq, int LI, bool RELU, bool BIAS, int NWS, int CH, class WS, class InLoad, class Emit>
+__device__ __forceinline__ void linear_split_chunk(WS& ws, bool more, const v4f* __restrict__ in, InLoad& inload, Emit& emit) {
+  constexpr int KP = Seq::kp(LI), NP = Seq::np(LI);
+  constexpr int KB = KP / 16, NB = NP / 16;
+  constexpr int STRIDE = KP + 4;
+  constexpr int CR = chunk_rows(KP, NP);
+  constexpr int C0 = Seq::first_chunk(LI);
+  constexpr int mb0 = CH * (CR / 16);
+  constexpr int mbn = (mb0 + CR / 16 < NB) ? mb0 + CR / 16 : NB;
+  constexpr int JMAX = (mbn - mb0 + NWS - 1) / NWS;          // owned blocks in this chunk (upper bound)
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int m = lane & 15, q = lane >> 4;
+  const float* w = ws.template acquire<Seq, C0 + CH>(more);
+  if constexpr (CH == 0) inload();
+  const int first = mb0 + ((wave - mb0 % NWS) + NWS) % NWS;   // first owned block of the chunk
+  const v4f zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < JMAX; j += 2) {
+    const int mbA = first + NWS * j, mbB = mbA + NWS;
+    const bool hasA = mbA < mbn, hasB = (j + 1 < JMAX) && (mbB < mbn);     // wave-uniform
+    if (!hasA) break;
+    const float* wa = w + ((mbA - mb0) * 16 + m) * STRIDE + 4 * q;
+    const float* wb = w + (((hasB ? mbB : mbA) - mb0) * 16 + m) * STRIDE + 4 * q;
+    v4f acc0 = zero4, acc1 = zero4;
+    if constexpr (BIAS) {
+      const float* ba = w + ((mbA - mb0) * 16 + 4 * q) * STRIDE + KP;
+      const float* bb = w + (((hasB ? mbB : mbA) - mb0) * 16 + 4 * q) * STRIDE + KP;
+      acc0 = v4f{ba[0], ba[STRIDE], ba[2 * STRIDE], ba[3 * STRIDE]};
+      acc1 = v4f{bb[0], bb[STRIDE], bb[2 * STRIDE], bb[3 * STRIDE]};
+    }
+    v4f fa = *reinterpret_cast<const v4f*>(wa), fb = *reinterpret_cast<const v4f*>(wb);
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      v4f na = zero4, nb = zero4;
+      if (kb + 1 < KB) {
+        na = *reinterpret_cast<const v4f*>(wa + 16 * (kb + 1));
+        nb = *reinterpret_cast<const v4f*>(wb + 16 * (kb + 1));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      acc0 = mfma4(fa, in[kb], acc0);
+      if (hasB) acc1 = mfma4(fb, in[kb], acc1);
+      fa = na; fb = nb;
+    }
+    emit(mbA, RELU ? relu4(acc0) : acc0);
+    if (hasB) emit(mbB, RELU ? relu4(acc1) : acc1);
+  }
+}
+
+template <class Seq, int LI, bool RELU, bool BIAS, int NWS, class WS, class InLoad, class Emit, int... CH>
+__device__ __forceinline__ void linear_split_impl(WS& ws, bool more, const v4f* __restrict__ in, InLoad& inload, Emit& emit,
+                                                  std::integer_sequence<int, CH...>) {
+  (linear_split_chunk<Seq, LI, RELU, BIAS, NWS, CH>(ws, more, in, inload, emit), ...);
+}
+
+template <class Seq, int LI, bool RELU, bool BIAS, int NWS, class WS, class InLoad, class Emit>
+__device__ __forceinline__ void linear_split(WS& ws, bool more, const v4f* __restrict__ in, InLoad inload, Emit emit) {
+  linear_split_impl<Seq, LI, RELU, BIAS, NWS>(ws, more, in, inload, emit,
+                                              std::make_integer_sequence<int, n_chunks(Seq::kp(LI), Seq::np(LI))>{});
+}
+
+// ------------------------------------------------------------------------------------------
+template <class D>
+__global__ __launch_bounds__(kNodeWaves * 64, 1) void mp_node_fwd_split_kernel(const NodeFwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  using Seq = typename D::NodeFwdSeq;
+  using NS = NodeSplit<D>;
+  constexpr int NWS = kNodeWaves;
+  constexpr int XB = NS::XB, DMB = NS::DMB, H1B = NS::H1B, H2B = NS::H2B;
+  constexpr int MB2 = 2 * DMB, BPW = MB2 / NWS;              // blocks of M per wavefront
+  static_assert(MB2 % NWS == 0 && DMB % BPW == 0, "message width must split over the wavefronts");
+  WStreamT<NWS * 64> ws;
+  ws.init(a.wpack, smem);
+  ws.template start<Seq>();
+  v4f* xb0 = reinterpret_cast<v4f*>(smem + 2 * kWBufFloats);
+  v4f* xb1 = xb0 + NS::XBUF_BLOCKS * 64;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 16 + (lane & 15);
+  const bool valid = row < a.N;
+
+  // ---- segment sums: waves [0, NWS/2) own the `past` half of M, the others the `fut` half ----
+  {
+    v4f part[BPW];
+#pragma unroll
+    for (int b = 0; b < BPW; ++b) part[b] = v4f{0.f, 0.f, 0.f, 0.f};
+    const int blk0 = wave * BPW;
+    if (valid) {
+      constexpr int U = BPW <= 3 ? 8 : 4;                    // rows in flight per lane (MI355X: 8 beats 4 and 16)
+      if (blk0 < DMB) segment_sum_deep<BPW, U>(a.past, D::DM, 16 * blk0, a.dst_perm, a.dst_ptr[row], a.dst_ptr[row + 1], part);
+      else segment_sum_deep<BPW, U>(a.fut, D::DM, 16 * (blk0 - DMB), a.src_perm, a.src_ptr[row], a.src_ptr[row + 1], part);
+    }
+#pragma unroll
+    for (int b = 0; b < BPW; ++b) xb0[(blk0 + b) * 64 + lane] = part[b];
+    if (a.M) store_row<BPW>(a.M, row, 2 * D::DM, 16 * blk0, valid, part);
+  }
+  v4f m[MB2], h1[H1B], h2[H2B];
+  linear_split<Seq, 0, true, true, NWS>(
+      ws, false, m,
+      [&]() {
+#pragma unroll
+        for (int b = 0; b < MB2; ++b) m[b] = xb0[b * 64 + lane];
+      },
+      [&](int mb, v4f v) {
+        xb1[mb * 64 + lane] = v;
+        if (a.sH1) store_row<1>(a.sH1, row, D::NH1, 16 * mb, valid, &v);
+      });
+  linear_split<Seq, 1, true, true, NWS>(
+      ws, false, h1,
+      [&]() {
+#pragma unroll
+        for (int b = 0; b < H1B; ++b) h1[b] = xb1[b * 64 + lane];
+      },
+      [&](int mb, v4f v) {
+        xb0[mb * 64 + lane] = v;
+        if (a.sH2) store_row<1>(a.sH2, row, D::NH2, 16 * mb, valid, &v);
+      });
+  linear_split<Seq, 2, false, true, NWS>(
+      ws, false, h2,
+      [&]() {
+#pragma unroll
+        for (int b = 0; b < H2B; ++b) h2[b] = xb0[b * 64 + lane];
+      },
+      [&](int mb, v4f v) { store_row<1>(a.x_out, row, D::DX, 16 * mb, valid, &v); });
+  (void)XB;
+}
+
+// ------------------------------------------------------------------------------------------
+template <class D>
+__global__ __launch_bounds__(kNodeWaves * 64, 1) void mp_node_bwd_split_kernel(const NodeBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  using Seq = typename D::NodeBwdSeq;
+  using NS = NodeSplit<D>;
+  constexpr int NWS = kNodeWaves;
+  constexpr int XB = NS::XB, DMB = NS::DMB, H1B = NS::H1B, H2B = NS::H2B;
+  constexpr int GB = 2 * XB;                                  // d x' | d x0 contribution
+  constexpr int GPW = GB / (NWS / 2);                         // gradient blocks per wavefront (one list each half)
+  static_assert(NWS % 2 == 0 && GB % (NWS / 2) == 0, "gradient width must split over half the wavefronts");
+  WStreamT<NWS * 64> ws;
+  ws.init(a.wpack, smem);
+  ws.template start<Seq>();
+  v4f* xb0 = reinterpret_cast<v4f*>(smem + 2 * kWBufFloats);
+  v4f* xb1 = xb0 + NS::XBUF_BLOCKS * 64;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 16 + (lane & 15);
+  const bool valid = row < a.N;
+
+  // saved activations of this layer (whole rows: every wavefront masks the full gradient it reads)
+  v4f act2[H2B], act1[H1B];
+  load_row<H2B>(a.sH2, row, D::NH2, 0, valid, act2);
+  load_row<H1B>(a.sH1, row, D::NH1, 0, valid, act1);
+
+  // ---- transposed gathers: waves [0, NWS/2) sum the by-destination list, the others by-source ----
+  {
+    v4f part[GPW];
+#pragma unroll
+    for (int b = 0; b < GPW; ++b) part[b] = v4f{0.f, 0.f, 0.f, 0.f};
+    const int half = wave / (NWS / 2), blk0 = (wave % (NWS / 2)) * GPW;
+    if (valid) {
+      constexpr int U = GPW <= 3 ? 8 : 4;
+      if (half == 0) segment_sum_deep<GPW, U>(a.gdst, 2 * D::DX, 16 * blk0, a.dst_perm, a.dst_ptr[row], a.dst_ptr[row + 1], part);
+      else segment_sum_deep<GPW, U>(a.gsrc, 2 * D::DX, 16 * blk0, a.src_perm, a.src_ptr[row], a.src_ptr[row + 1], part);
+    }
+#pragma unroll
+    for (int b = 0; b < GPW; ++b) xb0[(half * GB + blk0 + b) * 64 + lane] = part[b];
+  }
+  __syncthreads();
+  v4f g[GB];
+#pragma unroll
+  for (int b = 0; b < GB; ++b) g[b] = xb0[b * 64 + lane] + xb0[(GB + b) * 64 + lane];
+#pragma unroll
+  for (int b = 0; b < GB; ++b) {
+    if (b % NWS != wave) continue;                            // wave-uniform: one owner per block
+    if (b < XB) {
+      store_row<1>(a.Gdx, row, D::DX, 16 * b, valid, &g[b]);
+    } else {
+      v4f t = g[b];
+      if (!a.dx0_first) {
+        v4f prev;
+        load_row<1>(a.dx0_acc, row, D::DX, 16 * (b - XB), valid, &prev);
+        t += prev;
+      }
+      store_row<1>(a.dx0_acc, row, D::DX, 16 * (b - XB), valid, &t);
+    }
+  }
+
+  v4f d2[H2B], d1[H1B];
+  linear_split<Seq, 0, false, false, NWS>(
+      ws, false, g, [&]() {}, [&](int mb, v4f v) { xb1[mb * 64 + lane] = v; });
+  linear_split<Seq, 1, false, false, NWS>(
+      ws, false, d2,
+      [&]() {
+#pragma unroll
+        for (int b = 0; b < H2B; ++b) d2[b] = xb1[b * 64 + lane];
+        relu_bwd<H2B>(d2, act2);
+#pragma unroll
+        for (int b = 0; b < H2B; ++b)
+          if (b % NWS == wave) store_row<1>(a.GdH2, row, D::NH2, 16 * b, valid, &d2[b]);
+      },
+      [&](int mb, v4f v) { xb0[mb * 64 + lane] = v; });
+  linear_split<Seq, 2, false, false, NWS>(
+      ws, false, d1,
+      [&]() {
+#pragma unroll
+        for (int b = 0; b < H1B; ++b) d1[b] = xb0[b * 64 + lane];
+        relu_bwd<H1B>(d1, act1);
+#pragma unroll
+        for (int b = 0; b < H1B; ++b)
+          if (b % NWS == wave) store_row<1>(a.GdH1, row, D::NH1, 16 * b, valid, &d1[b]);
+      },
+      [&](int mb, v4f v) { store_row<1>(a.dM, row, 2 * D::DM, 16 * mb, valid, &v); });
+  (void)DMB;
+}
+
+}  // namespace b3d

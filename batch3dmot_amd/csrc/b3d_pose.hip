@@ -344,7 +344,7 @@ extern "C" int b3d_pose_forward(const b3d_pose_weights* pw, const b3d_graph* g, 
     na.N = N; na.dst_ptr = g->dst_ptr; na.dst_perm = g->dst_perm; na.src_ptr = g->src_ptr; na.src_perm = g->src_perm;
     na.past = w.past; na.fut = w.fut; na.M = w.M[l]; na.x_out = w.x[l + 1]; na.sH1 = w.nH1[l]; na.sH2 = w.nH2[l];
     na.wpack = w.wp_nfwd;
-    B3D_TRY(launch_rows<kNWNode>(mp_node_fwd_kernel<D, kNWNode>, "mp_node_fwd", na, N, stream, B3D_K_NODE_FWD));
+    B3D_TRY(launch_node_split<D>(mp_node_fwd_split_kernel<D>, "mp_node_fwd", na, N, stream, B3D_K_NODE_FWD));
   }
   {  // edge classifier 32-16-8-4-1 -> logits                                pose_gnn.py:86
     ChainFwdArgs<LoadAligned<2>, StoreScalar> a;
@@ -422,7 +422,7 @@ extern "C" int b3d_pose_backward(const b3d_pose_weights* pw, const b3d_graph* g,
       nb.sH1 = w.nH1[l]; nb.sH2 = w.nH2[l];
       nb.dM = w.dM + l * nLm; nb.Gdx = w.Gdx + l * nLx; nb.GdH2 = w.GnH2 + l * nL2; nb.GdH1 = w.GnH1 + l * nL1;
       nb.wpack = w.wp_nbwd;
-      B3D_TRY(launch_rows<kNWNode>(mp_node_bwd_kernel<D, kNWNode>, "mp_node_bwd", nb, N, stream, B3D_K_NODE_BWD));
+      B3D_TRY(launch_node_split<D>(mp_node_bwd_split_kernel<D>, "mp_node_bwd", nb, N, stream, B3D_K_NODE_BWD));
       dx0_first = false;
     }
     EdgeBwdArgs eb;
@@ -517,24 +517,25 @@ extern "C" int b3d_pose_backward(const b3d_pose_weights* pw, const b3d_graph* g,
     auto xrow = [&](const int* idx, int c0) { return sg(w.x[0], idx, nLx, D::DX, c0); };      // x[l][idx], columns c0..
     auto x0row = [&](const int* idx) { return sg(x0, idx, 0, D::DX, 0); };
     auto erow = [&](int l0, int c0) { return sg(w.e[l0], nullptr, eLe, D::DE, c0); };         // e[l + l0], columns c0..
-    // edge_update (every layer): dW columns [x[dst] 0:48 | x[src] 48:96 | e 96:128]
+    // edge_update.0 (every layer): dW columns [x[dst] 0:48 | x[src] 48:96 | e 96:128]
     const WsSeg gH1 = sg(w.GdH1, nullptr, eL1, D::EH1, 0);
-    add(WJ_EU0A, gH1, xrow(dst, 0), 0, xrow(src, 0), 48, true);            // [x[dst] | x[src][0:16]]
-    add(WJ_EU0B, gH1, xrow(src, 16), 64, erow(0, 0), 96, false);           // [x[src][16:48] | e]
-    add(WJ_EU1, sg(w.GdH2, nullptr, eL2, D::EH2, 0), sg(w.sH1[0], nullptr, eL1, D::EH1, 0), 0, none, 0, true);
-    add(WJ_EU2, sg(w.Gde, nullptr, eLe, D::DE, 0), sg(w.sH2[0], nullptr, eL2, D::EH2, 0), 0, none, 0, true);
-    // message stacks (layers 0 .. depth-2): columns [x[.] 0:48 | e' 48:80 | x0[.] 80:128]
+    add(WJ_EU0A, gH1, xrow(dst, 0), 0, xrow(src, 0), 48, true);         // [x[dst] | x[src][0:16]]
+    add(WJ_EU0B, gH1, xrow(src, 16), 64, erow(0, 0), 96, false);        // [x[src][16:48] | e]
+    // message stacks .0 (layers 0 .. depth-2): columns [x[.] 0:48 | e' 48:80 | x0[.] 80:128]
     const WsSeg gP1 = sg(w.GdP1, nullptr, eLm, D::MH, 0), gF1 = sg(w.GdF1, nullptr, eLm, D::MH, 0);
-    add(WJ_PA0A, gP1, xrow(src, 0), 0, erow(1, 0), 48, true);              // [x[src] | e'[0:16]]
-    add(WJ_PA0B, gP1, x0row(src), 80, erow(1, 16), 64, false);             // [x0[src] | e'[16:32]]
-    add(WJ_PA1, sg(w.dM, dst, nLm, D::NIN, 0), sg(w.sP1[0], nullptr, eLm, D::MH, 0), 0, none, 0, true);
+    add(WJ_PA0A, gP1, xrow(src, 0), 0, erow(1, 0), 48, true);           // [x[src] | e'[0:16]]
+    add(WJ_PA0B, gP1, x0row(src), 80, erow(1, 16), 64, false);          // [x0[src] | e'[16:32]]
     add(WJ_FU0A, gF1, xrow(dst, 0), 0, erow(1, 0), 48, true);
     add(WJ_FU0B, gF1, x0row(dst), 80, erow(1, 16), 64, false);
-    add(WJ_FU1, sg(w.dM, src, nLm, D::NIN, D::DM), sg(w.sF1[0], nullptr, eLm, D::MH, 0), 0, none, 0, true);
-    // node update (layers 0 .. depth-2)
+    // node update .0 (layers 0 .. depth-2)
     const WsSeg gN1 = sg(w.GnH1, nullptr, nL1, D::NH1, 0);
     add(WJ_CF0A, gN1, sg(w.M[0], nullptr, nLm, D::NIN, 0), 0, none, 0, true);
     add(WJ_CF0B, gN1, sg(w.M[0], nullptr, nLm, D::NIN, D::DM), D::DM, none, 0, false);
+    // single-job matrices
+    add(WJ_EU1, sg(w.GdH2, nullptr, eL2, D::EH2, 0), sg(w.sH1[0], nullptr, eL1, D::EH1, 0), 0, none, 0, true);
+    add(WJ_EU2, sg(w.Gde, nullptr, eLe, D::DE, 0), sg(w.sH2[0], nullptr, eL2, D::EH2, 0), 0, none, 0, true);
+    add(WJ_PA1, sg(w.dM, dst, nLm, D::NIN, 0), sg(w.sP1[0], nullptr, eLm, D::MH, 0), 0, none, 0, true);
+    add(WJ_FU1, sg(w.dM, src, nLm, D::NIN, D::DM), sg(w.sF1[0], nullptr, eLm, D::MH, 0), 0, none, 0, true);
     add(WJ_CF1, sg(w.GnH2, nullptr, nL2, D::NH2, 0), sg(w.nH1[0], nullptr, nL1, D::NH1, 0), 0, none, 0, true);
     add(WJ_CF2, sg(w.Gdx, nullptr, nLx, D::DX, 0), sg(w.nH2[0], nullptr, nL2, D::NH2, 0), 0, none, 0, true);
     wl.launch(w.zrow, B3D_K_WGRAD_EDGE);
