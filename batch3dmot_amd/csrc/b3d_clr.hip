@@ -743,3 +743,62 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
   }
   return B3D_OK;
 }
+
+// ---- standalone CausalMessagePassing layer, camera+LiDAR+radar widths (clr_att_gnn.py:227-356) --------------
+// Forward only: the layer-level backward is built for the poses-only widths (b3d_pose_layer_backward);
+// training of this model goes through b3d_clr_forward / b3d_clr_backward.
+namespace b3d {
+struct ClrLayerWs { float *wp_efwd, *wp_nfwd, *fut, *past; size_t bytes; bool ok; };
+static void carve_layer(ClrLayerWs& w, void* ws, size_t ws_bytes, int N, int E) {
+  Carver c(ws, ws_bytes);
+  (void)N;
+  w.wp_efwd = c.take<float>(D::EdgeFwdSeq::TOTAL_FLOATS);
+  w.wp_nfwd = c.take<float>(D::NodeFwdSeq::TOTAL_FLOATS);
+  w.fut = c.take<float>((size_t)(E > 0 ? E : 1) * D::DM);
+  w.past = c.take<float>((size_t)(E > 0 ? E : 1) * D::DM);
+  w.bytes = c.off + 256;
+  w.ok = c.ok();
+}
+}  // namespace b3d
+
+extern "C" size_t b3d_clr_layer_workspace_bytes(int32_t N, int32_t E) {
+  ClrLayerWs w;
+  carve_layer(w, nullptr, 0, N, E);
+  return w.bytes;
+}
+
+extern "C" int b3d_clr_layer_forward(const b3d_mp_weights* mw, const b3d_graph* g, const float* x, const float* x0,
+                                     const float* e, const float* att, void* workspace, size_t workspace_bytes,
+                                     float* x_new, float* e_new, b3d_stream stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  B3D_REQUIRE(mw && g && x && x0 && e && att && workspace && x_new && e_new, "b3d_clr_layer_forward: null argument");
+  const int N = g->N, E = g->E;
+  B3D_REQUIRE(N > 0 && E > 0, "b3d_clr_layer_forward: empty graph (N=%d, E=%d)", N, E);
+  ClrLayerWs w;
+  carve_layer(w, workspace, workspace_bytes, N, E);
+  if (!w.ok) return fail(B3D_ERR_WORKSPACE, "b3d_clr_layer_forward: workspace %zu < %zu bytes", workspace_bytes, w.bytes);
+  const b3d_linear* stacks[] = {mw->edge_update, mw->create_future_msgs, mw->create_past_msgs, mw->combine_future_past};
+  const int first[] = {EU0, FU0, PA0, CF0}, cnt[] = {3, 2, 2, 3};
+  PackDesc d[16];
+  int n = 0, li = 0;
+  for (int s = 0; s < 4; ++s)
+    for (int i = 0; i < cnt[s]; ++i) {
+      const b3d_linear& l = stacks[s][i];
+      B3D_REQUIRE(l.w && l.b, "b3d_clr_layer_forward: null weight/bias pointer (stack %d layer %d)", s, i);
+      const LinDim dim = kDims[first[s] + i];
+      if (s < 3) d[n++] = pack_desc<D::EdgeFwdSeq>(li++, w.wp_efwd, l.w, l.b, dim.N, dim.K, false);
+      else d[n++] = pack_desc<D::NodeFwdSeq>(i, w.wp_nfwd, l.w, l.b, dim.N, dim.K, false);
+    }
+  B3D_TRY(pack_images(d, n, stream));
+  EdgeFwdArgs ea;
+  memset(&ea, 0, sizeof(ea));
+  ea.E = E; ea.src = g->src; ea.dst = g->dst; ea.x = x; ea.x0 = x0; ea.e_in = e; ea.a_in = att;
+  ea.e_out = e_new; ea.fut = w.fut; ea.past = w.past; ea.wpack = w.wp_efwd;
+  B3D_TRY(launch_rows<kNWEdge>(mp_edge_fwd_kernel<D, kNWEdge>, "mp_edge_fwd", ea, E, stream, B3D_K_EDGE_FWD));
+  NodeFwdArgs na;
+  memset(&na, 0, sizeof(na));
+  na.N = N; na.dst_ptr = g->dst_ptr; na.dst_perm = g->dst_perm; na.src_ptr = g->src_ptr; na.src_perm = g->src_perm;
+  na.past = w.past; na.fut = w.fut; na.x_out = x_new; na.wpack = w.wp_nfwd;
+  B3D_TRY(launch_node_split<D>(mp_node_fwd_split_kernel<D>, "mp_node_fwd", na, N, stream, B3D_K_NODE_FWD));
+  return B3D_OK;
+}

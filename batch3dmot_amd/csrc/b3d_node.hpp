@@ -181,37 +181,44 @@ __global__ __launch_bounds__(kNodeWaves * 64, 1) void mp_node_bwd_split_kernel(c
   load_row<H2B>(a.sH2, row, D::NH2, 0, valid, act2);
   load_row<H1B>(a.sH1, row, D::NH1, 0, valid, act1);
 
-  // ---- transposed gathers: waves [0, NWS/2) sum the by-destination list, the others by-source ----
-  {
-    v4f part[GPW];
-#pragma unroll
-    for (int b = 0; b < GPW; ++b) part[b] = v4f{0.f, 0.f, 0.f, 0.f};
-    const int half = wave / (NWS / 2), blk0 = (wave % (NWS / 2)) * GPW;
-    if (valid) {
-      constexpr int U = GPW <= 3 ? 8 : 4;
-      if (half == 0) segment_sum_deep<GPW, U>(a.gdst, 2 * D::DX, 16 * blk0, a.dst_perm, a.dst_ptr[row], a.dst_ptr[row + 1], part);
-      else segment_sum_deep<GPW, U>(a.gsrc, 2 * D::DX, 16 * blk0, a.src_perm, a.src_ptr[row], a.src_ptr[row + 1], part);
-    }
-#pragma unroll
-    for (int b = 0; b < GPW; ++b) xb0[(half * GB + blk0 + b) * 64 + lane] = part[b];
-  }
-  __syncthreads();
   v4f g[GB];
+  if (a.g_direct) {
+    // standalone layer: d x' is given per node
+    load_row<XB>(a.g_direct, row, D::DX, 0, valid, g);
 #pragma unroll
-  for (int b = 0; b < GB; ++b) g[b] = xb0[b * 64 + lane] + xb0[(GB + b) * 64 + lane];
+    for (int b = XB; b < GB; ++b) g[b] = v4f{0.f, 0.f, 0.f, 0.f};
+  } else {
+    // ---- transposed gathers: waves [0, NWS/2) sum the by-destination list, the others by-source ----
+    {
+      v4f part[GPW];
 #pragma unroll
-  for (int b = 0; b < GB; ++b) {
-    if (b % NWS != wave) continue;                            // wave-uniform: one owner per block
-    if (b < XB) {
-      store_row<1>(a.Gdx, row, D::DX, 16 * b, valid, &g[b]);
-    } else {
-      v4f t = g[b];
-      if (!a.dx0_first) {
-        v4f prev;
-        load_row<1>(a.dx0_acc, row, D::DX, 16 * (b - XB), valid, &prev);
-        t += prev;
+      for (int b = 0; b < GPW; ++b) part[b] = v4f{0.f, 0.f, 0.f, 0.f};
+      const int half = wave / (NWS / 2), blk0 = (wave % (NWS / 2)) * GPW;
+      if (valid) {
+        constexpr int U = GPW <= 3 ? 8 : 4;
+        if (half == 0) segment_sum_deep<GPW, U>(a.gdst, 2 * D::DX, 16 * blk0, a.dst_perm, a.dst_ptr[row], a.dst_ptr[row + 1], part);
+        else segment_sum_deep<GPW, U>(a.gsrc, 2 * D::DX, 16 * blk0, a.src_perm, a.src_ptr[row], a.src_ptr[row + 1], part);
       }
-      store_row<1>(a.dx0_acc, row, D::DX, 16 * (b - XB), valid, &t);
+#pragma unroll
+      for (int b = 0; b < GPW; ++b) xb0[(half * GB + blk0 + b) * 64 + lane] = part[b];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < GB; ++b) g[b] = xb0[b * 64 + lane] + xb0[(GB + b) * 64 + lane];
+#pragma unroll
+    for (int b = 0; b < GB; ++b) {
+      if (b % NWS != wave) continue;                            // wave-uniform: one owner per block
+      if (b < XB) {
+        store_row<1>(a.Gdx, row, D::DX, 16 * b, valid, &g[b]);
+      } else {
+        v4f t = g[b];
+        if (!a.dx0_first) {
+          v4f prev;
+          load_row<1>(a.dx0_acc, row, D::DX, 16 * (b - XB), valid, &prev);
+          t += prev;
+        }
+        store_row<1>(a.dx0_acc, row, D::DX, 16 * (b - XB), valid, &t);
+      }
     }
   }
 

@@ -32,14 +32,14 @@ enum { WJ_EU0A, WJ_EU0B, WJ_EU1, WJ_EU2, WJ_PA0A, WJ_PA0B, WJ_PA1, WJ_FU0A, WJ_F
 struct WsPlan {
   int shape[WJ_COUNT], lin[WJ_COUNT], rows[WJ_COUNT], nvar[WJ_COUNT], rows_per_task[WJ_COUNT], ntasks[WJ_COUNT];
 };
-static WsPlan ws_plan(int N, int E, int depth);
+static WsPlan ws_plan(int N, int E, int depth, bool layer_mode);
 
 __global__ void iota_kernel(int* p, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = i;
 }
 
-static WsPlan ws_plan(int N, int E, int depth) {
+static WsPlan ws_plan(int N, int E, int depth, bool layer_mode) {
   WsPlan p;
   const int shp[WJ_COUNT] = {WS_96_48_16, WS_96_32_32, WS_64_96, WS_32_64, WS_96_48_16, WS_96_48_16, WS_64_96,
                              WS_96_48_16, WS_96_48_16, WS_64_96, WS_96_64, WS_96_64, WS_64_96, WS_48_64};
@@ -50,7 +50,7 @@ static WsPlan ws_plan(int N, int E, int depth) {
     p.shape[i] = shp[i];
     p.lin[i] = lin[i];
     p.rows[i] = (i < WJ_CF0A) ? E : N;
-    p.nvar[i] = (i <= WJ_EU2) ? depth : depth - 1;
+    p.nvar[i] = layer_mode ? 1 : (i <= WJ_EU2) ? depth : depth - 1;   // standalone layer: every stack once
     total += (double)p.rows[i] * ws_shape_blocks(shp[i]) * (p.nvar[i] > 0 ? p.nvar[i] : 0);
   }
   for (int i = 0; i < WJ_COUNT; ++i) {
@@ -67,6 +67,8 @@ static WsPlan ws_plan(int N, int E, int depth) {
   }
   return p;
 }
+
+constexpr uint32_t kFlagLayerMode = 0x80000000u;   // internal: workspace of the standalone layer operator
 
 struct PoseWs {
   // packed weight images
@@ -181,7 +183,7 @@ static void carve(PoseWs& w, void* ws, size_t ws_bytes, int N, int E, int depth,
     w.ws_table = c.take<WsJob>(32);
     w.ws_task_job = c.take<int>(8192);
     // weight-gradient slabs; chunk / task counts are a pure function of (N, E, depth)
-    w.plan = ws_plan(N, E, depth);
+    w.plan = ws_plan(N, E, depth, (flags & kFlagLayerMode) != 0);
     for (int i = 0; i < LIN_COUNT; ++i) {
       LinSlab& ls = w.lin[i];
       ls.N = kLinDims[i].N; ls.K = kLinDims[i].K;
@@ -247,6 +249,74 @@ static int pack_forward(const b3d_pose_weights* pw, PoseWs& w, bool training, hi
     T(SeqNodeEncT{}, 1, w.wp_neT, ne[1], LIN_NE1);
   }
   return pack_images(d, n, stream);
+}
+
+// Activation / gradient sources of the message-passing weight gradient.  In the whole-model backward
+// every pointer is layer 0 of a per-layer array (consecutive layers `*s` floats apart, see carve());
+// the standalone layer operator passes the caller's tensors (one variant, strides unused).
+struct MpGradSrc {
+  const float *x, *x0, *e_in, *e_out;
+  long xs, es;
+  const float *GdH1, *GdH2, *Gde, *GdP1, *GdF1, *dM, *GnH1, *GnH2, *Gdx;
+  const float *sH1, *sH2, *sP1, *sF1, *M, *nH1, *nH2;
+};
+
+static int mp_weight_grads(PoseWs& w, const MpGradSrc& ms, int N, int E, const int* src, const int* dst, hipStream_t stream) {
+  const size_t eL1 = (size_t)E * D::EH1, eL2 = (size_t)E * D::EH2, eLe = (size_t)E * D::DE, eLm = (size_t)E * D::MH;
+  const size_t nLm = (size_t)N * D::NIN, nLx = (size_t)N * D::DX, nL1 = (size_t)N * D::NH1, nL2 = (size_t)N * D::NH2;
+  (void)eLe; (void)nLx;
+    WsLauncher wl;
+    wl.begin(w.ws_table, 32, w.ws_task_job, 8192, stream);
+    hipLaunchKernelGGL(iota_kernel, dim3(((E > N ? E : N) + 255) / 256), dim3(256), 0, stream, w.iota, E > N ? E : N);
+    B3D_TRY(launch_check("iota_kernel"));
+    B3D_HIP_CHECK(hipMemsetAsync(w.zrow, 0, 256 * sizeof(float), stream));
+    const int* iota = w.iota;
+    auto sg = [iota](const float* p, const int* idx, long vstride, int stride, int col0) {
+      WsSeg s; s.ptr = p; s.idx = idx ? idx : iota; s.vstride = vstride; s.stride = stride; s.col0 = col0; return s;
+    };
+    const WsSeg none = sg(nullptr, nullptr, 0, 0, 0);
+    auto add = [&](int wj, const WsSeg& gseg, const WsSeg& a0, int c0, const WsSeg& a1, int c1, bool bias) {
+      if (w.plan.nvar[wj] <= 0) return;
+      const int lin = w.plan.lin[wj];
+      WsJob jb;
+      memset(&jb, 0, sizeof(jb));
+      jb.g = gseg; jb.act[0] = a0; jb.act[1] = a1; jb.act[2] = a1;
+      jb.wcol[0] = c0; jb.wcol[1] = c1; jb.wcol[2] = 0; jb.wrow = 0; jb.write_bias = bias ? 1 : 0;
+      jb.shape = w.plan.shape[wj]; jb.rows = w.plan.rows[wj]; jb.nvar = w.plan.nvar[wj];
+      jb.rows_per_task = w.plan.rows_per_task[wj]; jb.ntasks = w.plan.ntasks[wj];
+      jb.NP = w.lin[lin].NP; jb.KP = w.lin[lin].KP; jb.slab = w.lin[lin].slab;
+      wl.add(jb);
+      w.lin[lin].used = true;
+    };
+    const float* x0 = ms.x0;
+    auto xrow = [&](const int* idx, int c0) { return sg(ms.x, idx, ms.xs, D::DX, c0); };      // x[l][idx], columns c0..
+    auto x0row = [&](const int* idx) { return sg(x0, idx, 0, D::DX, 0); };
+    auto erow = [&](int l0, int c0) { return sg(l0 ? ms.e_out : ms.e_in, nullptr, ms.es, D::DE, c0); };         // e[l + l0], columns c0..
+    // edge_update.0 (every layer): dW columns [x[dst] 0:48 | x[src] 48:96 | e 96:128]
+    const WsSeg gH1 = sg(ms.GdH1, nullptr, eL1, D::EH1, 0);
+    add(WJ_EU0A, gH1, xrow(dst, 0), 0, xrow(src, 0), 48, true);         // [x[dst] | x[src][0:16]]
+    add(WJ_EU0B, gH1, xrow(src, 16), 64, erow(0, 0), 96, false);        // [x[src][16:48] | e]
+    // message stacks .0 (layers 0 .. depth-2): columns [x[.] 0:48 | e' 48:80 | x0[.] 80:128]
+    const WsSeg gP1 = sg(ms.GdP1, nullptr, eLm, D::MH, 0), gF1 = sg(ms.GdF1, nullptr, eLm, D::MH, 0);
+    add(WJ_PA0A, gP1, xrow(src, 0), 0, erow(1, 0), 48, true);           // [x[src] | e'[0:16]]
+    add(WJ_PA0B, gP1, x0row(src), 80, erow(1, 16), 64, false);          // [x0[src] | e'[16:32]]
+    add(WJ_FU0A, gF1, xrow(dst, 0), 0, erow(1, 0), 48, true);
+    add(WJ_FU0B, gF1, x0row(dst), 80, erow(1, 16), 64, false);
+    // node update .0 (layers 0 .. depth-2)
+    const WsSeg gN1 = sg(ms.GnH1, nullptr, nL1, D::NH1, 0);
+    add(WJ_CF0A, gN1, sg(ms.M, nullptr, nLm, D::NIN, 0), 0, none, 0, true);
+    add(WJ_CF0B, gN1, sg(ms.M, nullptr, nLm, D::NIN, D::DM), D::DM, none, 0, false);
+    // single-job matrices
+    add(WJ_EU1, sg(ms.GdH2, nullptr, eL2, D::EH2, 0), sg(ms.sH1, nullptr, eL1, D::EH1, 0), 0, none, 0, true);
+    add(WJ_EU2, sg(ms.Gde, nullptr, eLe, D::DE, 0), sg(ms.sH2, nullptr, eL2, D::EH2, 0), 0, none, 0, true);
+    add(WJ_PA1, sg(ms.dM, dst, nLm, D::NIN, 0), sg(ms.sP1, nullptr, eLm, D::MH, 0), 0, none, 0, true);
+    add(WJ_FU1, sg(ms.dM, src, nLm, D::NIN, D::DM), sg(ms.sF1, nullptr, eLm, D::MH, 0), 0, none, 0, true);
+    add(WJ_CF1, sg(ms.GnH2, nullptr, nL2, D::NH2, 0), sg(ms.nH1, nullptr, nL1, D::NH1, 0), 0, none, 0, true);
+    add(WJ_CF2, sg(ms.Gdx, nullptr, nLx, D::DX, 0), sg(ms.nH2, nullptr, nL2, D::NH2, 0), 0, none, 0, true);
+    wl.launch(w.zrow, B3D_K_WGRAD_EDGE);
+    B3D_REQUIRE(wl.status == 0, "streaming weight gradient: job table overflow");
+    B3D_TRY(launch_check("wstream_kernel"));
+  return B3D_OK;
 }
 
 static int check_weights(const b3d_pose_weights* pw) {
@@ -490,57 +560,12 @@ extern "C" int b3d_pose_backward(const b3d_pose_weights* pw, const b3d_graph* g,
 
   // ---- message-passing weight gradients: all layers, one streaming launch ---------------------
   {
-    WsLauncher wl;
-    wl.begin(w.ws_table, 32, w.ws_task_job, 8192, stream);
-    hipLaunchKernelGGL(iota_kernel, dim3(((E > N ? E : N) + 255) / 256), dim3(256), 0, stream, w.iota, E > N ? E : N);
-    B3D_TRY(launch_check("iota_kernel"));
-    B3D_HIP_CHECK(hipMemsetAsync(w.zrow, 0, 256 * sizeof(float), stream));
-    const int* iota = w.iota;
-    auto sg = [iota](const float* p, const int* idx, long vstride, int stride, int col0) {
-      WsSeg s; s.ptr = p; s.idx = idx ? idx : iota; s.vstride = vstride; s.stride = stride; s.col0 = col0; return s;
-    };
-    const WsSeg none = sg(nullptr, nullptr, 0, 0, 0);
-    auto add = [&](int wj, const WsSeg& gseg, const WsSeg& a0, int c0, const WsSeg& a1, int c1, bool bias) {
-      if (w.plan.nvar[wj] <= 0) return;
-      const int lin = w.plan.lin[wj];
-      WsJob jb;
-      memset(&jb, 0, sizeof(jb));
-      jb.g = gseg; jb.act[0] = a0; jb.act[1] = a1; jb.act[2] = a1;
-      jb.wcol[0] = c0; jb.wcol[1] = c1; jb.wcol[2] = 0; jb.wrow = 0; jb.write_bias = bias ? 1 : 0;
-      jb.shape = w.plan.shape[wj]; jb.rows = w.plan.rows[wj]; jb.nvar = w.plan.nvar[wj];
-      jb.rows_per_task = w.plan.rows_per_task[wj]; jb.ntasks = w.plan.ntasks[wj];
-      jb.NP = w.lin[lin].NP; jb.KP = w.lin[lin].KP; jb.slab = w.lin[lin].slab;
-      wl.add(jb);
-      w.lin[lin].used = true;
-    };
-    const float* x0 = w.x[0];
-    auto xrow = [&](const int* idx, int c0) { return sg(w.x[0], idx, nLx, D::DX, c0); };      // x[l][idx], columns c0..
-    auto x0row = [&](const int* idx) { return sg(x0, idx, 0, D::DX, 0); };
-    auto erow = [&](int l0, int c0) { return sg(w.e[l0], nullptr, eLe, D::DE, c0); };         // e[l + l0], columns c0..
-    // edge_update.0 (every layer): dW columns [x[dst] 0:48 | x[src] 48:96 | e 96:128]
-    const WsSeg gH1 = sg(w.GdH1, nullptr, eL1, D::EH1, 0);
-    add(WJ_EU0A, gH1, xrow(dst, 0), 0, xrow(src, 0), 48, true);         // [x[dst] | x[src][0:16]]
-    add(WJ_EU0B, gH1, xrow(src, 16), 64, erow(0, 0), 96, false);        // [x[src][16:48] | e]
-    // message stacks .0 (layers 0 .. depth-2): columns [x[.] 0:48 | e' 48:80 | x0[.] 80:128]
-    const WsSeg gP1 = sg(w.GdP1, nullptr, eLm, D::MH, 0), gF1 = sg(w.GdF1, nullptr, eLm, D::MH, 0);
-    add(WJ_PA0A, gP1, xrow(src, 0), 0, erow(1, 0), 48, true);           // [x[src] | e'[0:16]]
-    add(WJ_PA0B, gP1, x0row(src), 80, erow(1, 16), 64, false);          // [x0[src] | e'[16:32]]
-    add(WJ_FU0A, gF1, xrow(dst, 0), 0, erow(1, 0), 48, true);
-    add(WJ_FU0B, gF1, x0row(dst), 80, erow(1, 16), 64, false);
-    // node update .0 (layers 0 .. depth-2)
-    const WsSeg gN1 = sg(w.GnH1, nullptr, nL1, D::NH1, 0);
-    add(WJ_CF0A, gN1, sg(w.M[0], nullptr, nLm, D::NIN, 0), 0, none, 0, true);
-    add(WJ_CF0B, gN1, sg(w.M[0], nullptr, nLm, D::NIN, D::DM), D::DM, none, 0, false);
-    // single-job matrices
-    add(WJ_EU1, sg(w.GdH2, nullptr, eL2, D::EH2, 0), sg(w.sH1[0], nullptr, eL1, D::EH1, 0), 0, none, 0, true);
-    add(WJ_EU2, sg(w.Gde, nullptr, eLe, D::DE, 0), sg(w.sH2[0], nullptr, eL2, D::EH2, 0), 0, none, 0, true);
-    add(WJ_PA1, sg(w.dM, dst, nLm, D::NIN, 0), sg(w.sP1[0], nullptr, eLm, D::MH, 0), 0, none, 0, true);
-    add(WJ_FU1, sg(w.dM, src, nLm, D::NIN, D::DM), sg(w.sF1[0], nullptr, eLm, D::MH, 0), 0, none, 0, true);
-    add(WJ_CF1, sg(w.GnH2, nullptr, nL2, D::NH2, 0), sg(w.nH1[0], nullptr, nL1, D::NH1, 0), 0, none, 0, true);
-    add(WJ_CF2, sg(w.Gdx, nullptr, nLx, D::DX, 0), sg(w.nH2[0], nullptr, nL2, D::NH2, 0), 0, none, 0, true);
-    wl.launch(w.zrow, B3D_K_WGRAD_EDGE);
-    B3D_REQUIRE(wl.status == 0, "streaming weight gradient: job table overflow");
-    B3D_TRY(launch_check("wstream_kernel"));
+    MpGradSrc ms;
+    ms.x = w.x[0]; ms.xs = (long)nLx; ms.x0 = w.x[0]; ms.e_in = w.e[0]; ms.e_out = w.e[1]; ms.es = (long)eLe;
+    ms.GdH1 = w.GdH1; ms.GdH2 = w.GdH2; ms.Gde = w.Gde; ms.GdP1 = w.GdP1; ms.GdF1 = w.GdF1; ms.dM = w.dM;
+    ms.GnH1 = w.GnH1; ms.GnH2 = w.GnH2; ms.Gdx = w.Gdx;
+    ms.sH1 = w.sH1[0]; ms.sH2 = w.sH2[0]; ms.sP1 = w.sP1[0]; ms.sF1 = w.sF1[0]; ms.M = w.M[0]; ms.nH1 = w.nH1[0]; ms.nH2 = w.nH2[0];
+    B3D_TRY(mp_weight_grads(w, ms, N, E, src, dst, stream));
   }
 
   // ---- slabs -> parameter gradients -------------------------------------------------------------
@@ -593,5 +618,165 @@ extern "C" int b3d_knn_gat_forward(const float* x, const int64_t* ts, int32_t N,
   B3D_HIP_CHECK(hipMemcpyAsync(out_nbr, w.nbr, (size_t)N * kKnnMaxK * sizeof(int), hipMemcpyDeviceToDevice, stream));
   B3D_HIP_CHECK(hipMemcpyAsync(out_cnt, w.cnt, (size_t)N * sizeof(int), hipMemcpyDeviceToDevice, stream));
   B3D_HIP_CHECK(hipMemcpyAsync(out_y, w.y, (size_t)N * Dm * sizeof(float), hipMemcpyDeviceToDevice, stream));
+  return B3D_OK;
+}
+
+// ---- standalone CausalMessagePassing layer (pose_gnn.py:125-252) -----------------------------------------
+namespace b3d {
+
+static int check_mp_weights(const b3d_mp_weights* mw) {
+  B3D_REQUIRE(mw != nullptr, "message-passing weights struct is null");
+  const b3d_linear* all[] = {mw->edge_update, mw->create_past_msgs, mw->create_future_msgs, mw->combine_future_past};
+  const int cnt[] = {3, 2, 2, 3};
+  for (int g = 0; g < 4; ++g)
+    for (int i = 0; i < cnt[g]; ++i)
+      B3D_REQUIRE(all[g][i].w != nullptr && all[g][i].b != nullptr, "null weight/bias pointer (stack %d layer %d)", g, i);
+  return B3D_OK;
+}
+
+static int pack_layer(const b3d_mp_weights& mp, PoseWs& w, bool training, hipStream_t stream) {
+  PackDesc d[32];
+  int n = 0;
+  using EF = D::EdgeFwdSeq;
+  for (int i = 0; i < 3; ++i) d[n++] = pack_desc<EF>(i, w.wp_efwd, mp.edge_update[i].w, mp.edge_update[i].b, kLinDims[LIN_EU0 + i].N, kLinDims[LIN_EU0 + i].K, false);
+  for (int i = 0; i < 2; ++i) d[n++] = pack_desc<EF>(3 + i, w.wp_efwd, mp.create_future_msgs[i].w, mp.create_future_msgs[i].b, kLinDims[LIN_FU0 + i].N, kLinDims[LIN_FU0 + i].K, false);
+  for (int i = 0; i < 2; ++i) d[n++] = pack_desc<EF>(5 + i, w.wp_efwd, mp.create_past_msgs[i].w, mp.create_past_msgs[i].b, kLinDims[LIN_PA0 + i].N, kLinDims[LIN_PA0 + i].K, false);
+  for (int i = 0; i < 3; ++i) d[n++] = pack_desc<D::NodeFwdSeq>(i, w.wp_nfwd, mp.combine_future_past[i].w, mp.combine_future_past[i].b, kLinDims[LIN_CF0 + i].N, kLinDims[LIN_CF0 + i].K, false);
+  if (training) {
+    auto T = [&](auto seq_tag, int li, float* base, const b3d_linear& l, int lin) {
+      using S = decltype(seq_tag);
+      d[n++] = pack_desc<S>(li, base, l.w, nullptr, kLinDims[lin].K, kLinDims[lin].N, true);
+    };
+    using EB = D::EdgeBwdSeq;
+    T(EB{}, 0, w.wp_ebwd, mp.create_past_msgs[1], LIN_PA1);
+    T(EB{}, 1, w.wp_ebwd, mp.create_past_msgs[0], LIN_PA0);
+    T(EB{}, 2, w.wp_ebwd, mp.create_future_msgs[1], LIN_FU1);
+    T(EB{}, 3, w.wp_ebwd, mp.create_future_msgs[0], LIN_FU0);
+    T(EB{}, 4, w.wp_ebwd, mp.edge_update[2], LIN_EU2);
+    T(EB{}, 5, w.wp_ebwd, mp.edge_update[1], LIN_EU1);
+    T(EB{}, 6, w.wp_ebwd, mp.edge_update[0], LIN_EU0);
+    using NB = D::NodeBwdSeq;
+    T(NB{}, 0, w.wp_nbwd, mp.combine_future_past[2], LIN_CF2);
+    T(NB{}, 1, w.wp_nbwd, mp.combine_future_past[1], LIN_CF1);
+    T(NB{}, 2, w.wp_nbwd, mp.combine_future_past[0], LIN_CF0);
+  }
+  return pack_images(d, n, stream);
+}
+
+// d x[n] = sum over edges with dst == n of gdst[.,0:DX] + sum over edges with src == n of gsrc[.,0:DX];
+// d x0[n] likewise from columns DX:2DX -- the transpose of the four node-row gathers of the edge phase.
+struct NodeGradArgs {
+  int N;
+  const int *dst_ptr, *dst_perm, *src_ptr, *src_perm;
+  const float *gdst, *gsrc;
+  float *d_x, *d_x0;
+};
+__global__ __launch_bounds__(256) void node_grad_gather_kernel(const NodeGradArgs a) {
+  constexpr int XB = D::DX / 16;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long row = ((long)blockIdx.x * 4 + wave) * 16 + (lane & 15);
+  const bool valid = row < a.N;
+  v4f g[2 * XB];
+#pragma unroll
+  for (int b = 0; b < 2 * XB; ++b) g[b] = v4f{0.f, 0.f, 0.f, 0.f};
+  if (valid) {
+    segment_sum<2 * XB>(a.gdst, 2 * D::DX, 0, a.dst_perm, a.dst_ptr[row], a.dst_ptr[row + 1], g);
+    segment_sum<2 * XB>(a.gsrc, 2 * D::DX, 0, a.src_perm, a.src_ptr[row], a.src_ptr[row + 1], g);
+  }
+  if (a.d_x) store_row<XB>(a.d_x, row, D::DX, 0, valid, g);
+  if (a.d_x0) store_row<XB>(a.d_x0, row, D::DX, 0, valid, g + XB);
+}
+
+}  // namespace b3d
+
+extern "C" size_t b3d_pose_layer_workspace_bytes(int32_t N, int32_t E, uint32_t flags) {
+  PoseWs w;
+  carve(w, nullptr, 0, N, E, 1, (flags & B3D_FLAG_TRAINING) | kFlagLayerMode);
+  return w.bytes;
+}
+
+extern "C" int b3d_pose_layer_forward(const b3d_mp_weights* mw, const b3d_graph* g, const float* x, const float* x0,
+                                      const float* e, uint32_t flags, void* workspace, size_t workspace_bytes,
+                                      float* x_new, float* e_new, b3d_stream stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  B3D_TRY(check_mp_weights(mw));
+  B3D_REQUIRE(g && x && x0 && e && workspace && x_new && e_new, "b3d_pose_layer_forward: null argument");
+  const int N = g->N, E = g->E;
+  B3D_REQUIRE(N > 0 && E > 0, "b3d_pose_layer_forward: empty graph (N=%d, E=%d)", N, E);
+  const bool tr = flags & B3D_FLAG_TRAINING;
+  PoseWs w;
+  carve(w, workspace, workspace_bytes, N, E, 1, (flags & B3D_FLAG_TRAINING) | kFlagLayerMode);
+  if (!w.ok) return fail(B3D_ERR_WORKSPACE, "b3d_pose_layer_forward: workspace %zu < %zu bytes", workspace_bytes, w.bytes);
+  B3D_TRY(pack_layer(*mw, w, tr, stream));
+  EdgeFwdArgs ea;
+  memset(&ea, 0, sizeof(ea));
+  ea.E = E; ea.src = g->src; ea.dst = g->dst;
+  ea.x = x; ea.x0 = x0; ea.e_in = e; ea.a_in = nullptr;
+  ea.e_out = e_new; ea.fut = w.fut; ea.past = w.past;
+  if (tr) { ea.sH1 = w.sH1[0]; ea.sH2 = w.sH2[0]; ea.sF1 = w.sF1[0]; ea.sP1 = w.sP1[0]; }
+  ea.wpack = w.wp_efwd;
+  B3D_TRY(launch_rows<kNWEdge>(mp_edge_fwd_kernel<D, kNWEdge>, "mp_edge_fwd", ea, E, stream, B3D_K_EDGE_FWD));
+  NodeFwdArgs na;
+  memset(&na, 0, sizeof(na));
+  na.N = N; na.dst_ptr = g->dst_ptr; na.dst_perm = g->dst_perm; na.src_ptr = g->src_ptr; na.src_perm = g->src_perm;
+  na.past = w.past; na.fut = w.fut; na.x_out = x_new;
+  if (tr) { na.M = w.M[0]; na.sH1 = w.nH1[0]; na.sH2 = w.nH2[0]; }
+  na.wpack = w.wp_nfwd;
+  B3D_TRY(launch_node_split<D>(mp_node_fwd_split_kernel<D>, "mp_node_fwd", na, N, stream, B3D_K_NODE_FWD));
+  return B3D_OK;
+}
+
+extern "C" int b3d_pose_layer_backward(const b3d_mp_weights* mw, const b3d_graph* g, const float* x, const float* x0,
+                                       const float* e, const float* e_new, void* workspace, size_t workspace_bytes,
+                                       const float* d_x_new, const float* d_e_new, float* d_x, float* d_x0, float* d_e,
+                                       const b3d_mp_grads* gr, b3d_stream stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  B3D_TRY(check_mp_weights(mw));
+  B3D_REQUIRE(g && x && x0 && e && e_new && workspace && gr, "b3d_pose_layer_backward: null argument");
+  const int N = g->N, E = g->E;
+  B3D_REQUIRE(N > 0 && E > 0, "b3d_pose_layer_backward: empty graph");
+  PoseWs w;
+  carve(w, workspace, workspace_bytes, N, E, 1, B3D_FLAG_TRAINING | kFlagLayerMode);
+  if (!w.ok) return fail(B3D_ERR_WORKSPACE, "b3d_pose_layer_backward: workspace %zu < %zu bytes", workspace_bytes, w.bytes);
+  // missing upstream gradients are zeros
+  if (!d_x_new) { B3D_HIP_CHECK(hipMemsetAsync(w.dx0_acc, 0, (size_t)N * D::DX * sizeof(float), stream)); d_x_new = w.dx0_acc; }
+  if (!d_e_new) { B3D_HIP_CHECK(hipMemsetAsync(w.de[0], 0, (size_t)E * D::DE * sizeof(float), stream)); d_e_new = w.de[0]; }
+  NodeBwdArgs nb;
+  memset(&nb, 0, sizeof(nb));
+  nb.N = N; nb.dst_ptr = g->dst_ptr; nb.dst_perm = g->dst_perm; nb.src_ptr = g->src_ptr; nb.src_perm = g->src_perm;
+  nb.g_direct = d_x_new;
+  nb.sH1 = w.nH1[0]; nb.sH2 = w.nH2[0];
+  nb.dM = w.dM; nb.GdH2 = w.GnH2; nb.GdH1 = w.GnH1;
+  nb.wpack = w.wp_nbwd;
+  B3D_TRY(launch_node_split<D>(mp_node_bwd_split_kernel<D>, "mp_node_bwd", nb, N, stream, B3D_K_NODE_BWD));
+  EdgeBwdArgs eb;
+  memset(&eb, 0, sizeof(eb));
+  eb.E = E; eb.src = g->src; eb.dst = g->dst;
+  eb.dM = w.dM;
+  eb.de_out = d_e_new; eb.de_in = d_e ? d_e : w.de[1];
+  eb.sH1 = w.sH1[0]; eb.sH2 = w.sH2[0]; eb.sF1 = w.sF1[0]; eb.sP1 = w.sP1[0];
+  eb.gdst = w.gdst; eb.gsrc = w.gsrc;
+  eb.GdH1 = w.GdH1; eb.GdH2 = w.GdH2; eb.Gde = w.Gde; eb.GdF1 = w.GdF1; eb.GdP1 = w.GdP1;
+  eb.wpack = w.wp_ebwd;
+  B3D_TRY(launch_rows<kNWEdge>(mp_edge_bwd_kernel<D, true, kNWEdge>, "mp_edge_bwd", eb, E, stream, B3D_K_EDGE_BWD));
+  if (d_x || d_x0) {
+    NodeGradArgs na{N, g->dst_ptr, g->dst_perm, g->src_ptr, g->src_perm, w.gdst, w.gsrc, d_x, d_x0};
+    hipLaunchKernelGGL(node_grad_gather_kernel, dim3((N + 63) / 64), dim3(256), 0, stream, na);
+    B3D_TRY(launch_check("node_grad_gather_kernel"));
+  }
+  MpGradSrc ms;
+  ms.x = x; ms.xs = 0; ms.x0 = x0; ms.e_in = e; ms.e_out = e_new; ms.es = 0;
+  ms.GdH1 = w.GdH1; ms.GdH2 = w.GdH2; ms.Gde = w.Gde; ms.GdP1 = w.GdP1; ms.GdF1 = w.GdF1; ms.dM = w.dM;
+  ms.GnH1 = w.GnH1; ms.GnH2 = w.GnH2; ms.Gdx = d_x_new;
+  ms.sH1 = w.sH1[0]; ms.sH2 = w.sH2[0]; ms.sP1 = w.sP1[0]; ms.sF1 = w.sF1[0]; ms.M = w.M[0]; ms.nH1 = w.nH1[0]; ms.nH2 = w.nH2[0];
+  B3D_TRY(mp_weight_grads(w, ms, N, E, g->src, g->dst, stream));
+  RedArgs ra;
+  ra.nentries = 0;
+  const b3d_linear_grad* groups[] = {gr->edge_update, gr->create_past_msgs, gr->create_future_msgs, gr->combine_future_past};
+  const int first[] = {LIN_EU0, LIN_PA0, LIN_FU0, LIN_CF0};
+  const int cnt[] = {3, 2, 2, 3};
+  for (int gi = 0; gi < 4; ++gi)
+    for (int i = 0; i < cnt[gi]; ++i) ra.e[ra.nentries++] = red_entry(w.lin[first[gi] + i], groups[gi][i].w, groups[gi][i].b);
+  B3D_TRY(launch_reduce(ra, stream));
   return B3D_OK;
 }

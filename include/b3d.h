@@ -192,6 +192,28 @@ int b3d_clr_backward(const b3d_clr_weights* w, const b3d_graph* g, const b3d_clr
 /* Modality presence (clr_att_gnn.py:107-121): has[n] = (sum of row n) != 0, rows of `width` floats. */
 int b3d_modality_mask(const float* feats, int32_t N, int32_t width, uint8_t* has /* [N] */, b3d_stream stream);
 
+/* ---- one CausalMessagePassing layer as a standalone operator ------------------------------------------
+ * Replaces `CausalMessagePassing.forward(x, edge_index, edge_attr, initial_x[, att_edge_attr])`
+ * (pose_gnn.py:125-252 / clr_att_gnn.py:227-356): (x [N,DX], e [E,DE], x0 [N,DX]) -> (x' [N,DX], e' [E,DE]).
+ * Poses-only widths (DX 48, DE 32): forward and backward.  `flags`: B3D_FLAG_TRAINING keeps what
+ * backward needs in `workspace` (pass the same workspace, untouched, to backward).  Backward takes
+ * d x' / d e' (NULL = zero), the forward's inputs and its e' output, and fills d x, d x0, d e (NULL =
+ * not wanted) and all ten Linear gradients of `grads` (overwritten). */
+size_t b3d_pose_layer_workspace_bytes(int32_t N, int32_t E, uint32_t flags);
+int b3d_pose_layer_forward(const b3d_mp_weights* weights /* host */, const b3d_graph* g, const float* x, const float* x0,
+                           const float* e, uint32_t flags, void* workspace, size_t workspace_bytes, float* x_new,
+                           float* e_new, b3d_stream stream);
+int b3d_pose_layer_backward(const b3d_mp_weights* weights, const b3d_graph* g, const float* x, const float* x0,
+                            const float* e, const float* e_new, void* workspace, size_t workspace_bytes,
+                            const float* d_x_new, const float* d_e_new, float* d_x, float* d_x0, float* d_e,
+                            const b3d_mp_grads* grads /* host struct of device pointers */, b3d_stream stream);
+/* Camera+LiDAR+radar widths (DX 96, DE 64, att_edge_attr [E,64]): forward only -- training of that
+ * model goes through b3d_clr_forward / b3d_clr_backward. */
+size_t b3d_clr_layer_workspace_bytes(int32_t N, int32_t E);
+int b3d_clr_layer_forward(const b3d_mp_weights* weights, const b3d_graph* g, const float* x, const float* x0,
+                          const float* e, const float* att_edge_attr, void* workspace, size_t workspace_bytes,
+                          float* x_new, float* e_new, b3d_stream stream);
+
 /* ---- frame-wise k-NN + GATConv (pose_gnn.py:74-80, clr_att_gnn.py:178-184) as a standalone operator --
  * For every distinct timestamp value: k nearest neighbours (Euclidean, feature space, no self
  * loops, fewer than k in frames of <= k nodes) among the nodes of that frame, then

@@ -1,0 +1,135 @@
+"""GPU: CausalMessagePassing.forward as a standalone operator against the oracle's restatement of
+pose_gnn.py:125-252 / clr_att_gnn.py:227-356 (the oracle itself is pinned to the reference by the
+per-layer captures of tests/golden/g1_pose.pt and g2_clr.pt)."""
+import pytest
+import torch
+
+from oracle import ref_torch
+from oracle.seeded import seeded_fill_
+
+pytestmark = pytest.mark.gpu
+
+
+def _graph(n, k, seed):
+    from batch3dmot_amd import synth
+    return synth.make_graph(n, None, k=k, graph_idx=seed)
+
+
+def _defuse_relu_ties(ora, x, x0, e, edge_index, gen, margin=1e-4):
+    """Random inputs put ~1 in 10^7 ReLU pre-activations within fp32 rounding of zero; such a unit may
+    switch between two correct fp32 evaluations and move the gradients of its row by O(1).  Nudge the
+    edge features of the affected rows (float64 probe of every Linear that feeds a ReLU) until every
+    pre-activation is at least `margin` away from zero, so that the comparison below can be tight."""
+    import copy
+    o64 = copy.deepcopy(ora).double()
+    pre = []
+    hooks = []
+    for seq in (o64.edge_update, o64.create_past_msgs, o64.create_future_msgs, o64.combine_future_past):
+        mods = list(seq)
+        for a, b in zip(mods, mods[1:]):
+            if isinstance(a, torch.nn.Linear) and isinstance(b, torch.nn.ReLU):
+                hooks.append(a.register_forward_hook(lambda _m, _i, out: pre.append(out.detach())))
+    e = e.clone()
+    n = x.size(0)
+    for _ in range(20):
+        pre.clear()
+        with torch.no_grad():
+            o64(x.double(), edge_index, e.double(), x0.double())
+        bad_edges = torch.zeros(e.size(0), dtype=torch.bool)
+        for t in pre:
+            close = t.abs().min(dim=1).values < margin
+            if t.size(0) == e.size(0):
+                bad_edges |= close
+            else:                                   # node-level unit: move the messages that reach the node
+                assert t.size(0) == n
+                bad_edges |= close[edge_index[1]]
+        if not bad_edges.any():
+            break
+        e[bad_edges] += 0.05 * torch.randn(int(bad_edges.sum()), e.size(1), generator=gen)
+    else:
+        raise AssertionError("could not move the ReLU pre-activations away from zero")
+    for h in hooks:
+        h.remove()
+    return e
+
+
+@pytest.mark.parametrize("n,k", [(90, 6), (700, 12)])
+def test_pose_layer_forward_backward_match_oracle(n, k):
+    from batch3dmot_amd.pose_gnn import CausalMessagePassing
+    dev = torch.device("cuda:0")
+    d = _graph(n, k, 31)
+    ora = ref_torch.CausalMessagePassing("p")
+    seeded_fill_(ora, 5)
+    m = CausalMessagePassing()
+    m.load_state_dict(ora.state_dict())
+    m.to(dev)
+    g = torch.Generator().manual_seed(1)
+    N, E = d.pose_feats.size(0), d.edge_index.size(1)
+    x = torch.randn(N, 48, generator=g)
+    x0 = torch.randn(N, 48, generator=g)
+    e = torch.randn(E, 32, generator=g)
+    cx, ce = torch.randn(N, 48, generator=g), torch.randn(E, 32, generator=g)
+
+    e = _defuse_relu_ties(ora, x, x0, e, d.edge_index, g)
+
+    def run(mod, dev_):
+        xs = [t.clone().to(dev_).requires_grad_(True) for t in (x, x0, e)]
+        xn, en = mod(xs[0], d.edge_index.to(dev_), xs[2], xs[1])
+        ((xn * cx.to(dev_)).sum() + (en * ce.to(dev_)).sum()).backward()
+        return xn.detach().cpu(), en.detach().cpu(), [t.grad.cpu() for t in xs], \
+            {k_: p.grad.cpu() for k_, p in mod.named_parameters()}
+
+    ref = run(ora, torch.device("cpu"))
+    got = run(m, dev)
+    torch.testing.assert_close(got[0], ref[0], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(got[1], ref[1], rtol=1e-4, atol=1e-5)
+    for a, b, name in zip(got[2], ref[2], ("d x", "d initial_x", "d edge_attr")):
+        scale = b.abs().max().item()
+        assert (a - b).abs().max().item() <= 1e-4 * scale + 1e-6, name
+    for k_ in ref[3]:
+        scale = ref[3][k_].abs().max().item()
+        assert (got[3][k_] - ref[3][k_]).abs().max().item() <= 1e-4 * scale + 1e-6, k_
+
+
+def test_pose_layer_only_node_output_gradient():
+    """d e' absent (None): treated as zero."""
+    from batch3dmot_amd.pose_gnn import CausalMessagePassing
+    dev = torch.device("cuda:0")
+    d = _graph(120, 5, 77)
+    ora = ref_torch.CausalMessagePassing("p")
+    seeded_fill_(ora, 6)
+    m = CausalMessagePassing()
+    m.load_state_dict(ora.state_dict())
+    m.to(dev)
+    g = torch.Generator().manual_seed(2)
+    N, E = d.pose_feats.size(0), d.edge_index.size(1)
+    x, x0, e = torch.randn(N, 48, generator=g), torch.randn(N, 48, generator=g), torch.randn(E, 32, generator=g)
+    e = _defuse_relu_ties(ora, x, x0, e, d.edge_index, g)
+    xr = x.clone().requires_grad_(True)
+    ora(xr, d.edge_index, e, x0)[0].sum().backward()
+    xg = x.clone().to(dev).requires_grad_(True)
+    m(xg, d.edge_index.to(dev), e.to(dev), x0.to(dev))[0].sum().backward()
+    scale = xr.grad.abs().max().item()
+    assert (xg.grad.cpu() - xr.grad).abs().max().item() <= 1e-4 * scale
+
+
+def test_clr_layer_forward_matches_oracle_and_refuses_gradients():
+    from batch3dmot_amd.clr_att_gnn import CausalMessagePassing
+    dev = torch.device("cuda:0")
+    d = _graph(150, 7, 13)
+    ora = ref_torch.CausalMessagePassing("clr")
+    seeded_fill_(ora, 8)
+    m = CausalMessagePassing()
+    m.load_state_dict(ora.state_dict())
+    m.to(dev)
+    g = torch.Generator().manual_seed(3)
+    N, E = d.pose_feats.size(0), d.edge_index.size(1)
+    x, x0 = torch.randn(N, 96, generator=g), torch.randn(N, 96, generator=g)
+    e, att = torch.randn(E, 64, generator=g), torch.randn(E, 64, generator=g)
+    with torch.no_grad():
+        rx, re = ora(x, d.edge_index, e, x0, att)
+        gx, ge = m(x.to(dev), d.edge_index.to(dev), e.to(dev), x0.to(dev), att.to(dev))
+    torch.testing.assert_close(gx.cpu(), rx, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(ge.cpu(), re, rtol=1e-4, atol=1e-4)
+    with pytest.raises(NotImplementedError):
+        m(x.to(dev), d.edge_index.to(dev), e.to(dev), x0.to(dev), att.to(dev))
