@@ -186,6 +186,9 @@ def main():
                     "avg_launch_us": kernels[dom]["avg_us"],
                     "algorithmic_flops_per_launch": flops[dom], "algorithmic_bytes_per_launch": byts[dom],
                     "fp32_tflops": kernels[dom]["tflops"], "fp32_frac": round(kernels[dom]["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4)}
+        if model.run_dead_knn and not model.single_stream and dom in ("mp_edge_fwd", "mp_node_fwd"):
+            roofline["note"] = ("launch durations include CU sharing with the k-NN + GAT block that runs concurrently on "
+                                "the library's side stream; --no-dead-knn measures the kernel undisturbed")
         ms_step = 1e3 * dt / args.steps
         step_bytes = algorithmic_bytes_step(n_nodes, e_avg)
         step_flops = algorithmic_flops_step(n_nodes, e_avg)
