@@ -28,7 +28,12 @@ static const bool kLinOnEdges[LIN_COUNT] = {1, 1, 1, 0, 0, 0, 1, 1, 1, 1, 1, 1, 
 // 96x128 matrix is two 64-column jobs sharing a slab), a work-proportional share of ~2048 wavefront
 // tasks each (two resident wavefronts per SIMD).
 enum { WJ_EU0A, WJ_EU0B, WJ_EU1, WJ_EU2, WJ_PA0A, WJ_PA0B, WJ_PA1, WJ_FU0A, WJ_FU0B, WJ_FU1,
-       WJ_CF0A, WJ_CF0B, WJ_CF1, WJ_CF2, WJ_COUNT };
+       WJ_CF0A, WJ_CF0B, WJ_CF1, WJ_CF2,
+       // narrow stacks (one application each): classifier, node encoder, edge encoder
+       WJ_C3, WJ_C2, WJ_C1, WJ_C0, WJ_NE2, WJ_NE1, WJ_NE0, WJ_EE2, WJ_EE1, WJ_EE0, WJ_COUNT };
+constexpr int kWjBig = WJ_C3;              // jobs [0, kWjBig) share ~2048 tasks in proportion to their work
+constexpr int kNarrowRowsPerTask = 512;
+constexpr int kWsTaskCap = 65536;          // entries of the task -> job table in the workspace
 struct WsPlan {
   int shape[WJ_COUNT], lin[WJ_COUNT], rows[WJ_COUNT], nvar[WJ_COUNT], rows_per_task[WJ_COUNT], ntasks[WJ_COUNT];
 };
@@ -42,25 +47,34 @@ __global__ void iota_kernel(int* p, int n) {
 static WsPlan ws_plan(int N, int E, int depth, bool layer_mode) {
   WsPlan p;
   const int shp[WJ_COUNT] = {WS_96_48_16, WS_96_32_32, WS_64_96, WS_32_64, WS_96_48_16, WS_96_48_16, WS_64_96,
-                             WS_96_48_16, WS_96_48_16, WS_64_96, WS_96_64, WS_96_64, WS_64_96, WS_48_64};
+                             WS_96_48_16, WS_96_48_16, WS_64_96, WS_96_64, WS_96_64, WS_64_96, WS_48_64,
+                             WS_16_16, WS_16_16, WS_16_16, WS_16_32, WS_48_48, WS_48_32, WS_32_32, WS_32_16, WS_16_16, WS_16_16};
   const int lin[WJ_COUNT] = {LIN_EU0, LIN_EU0, LIN_EU1, LIN_EU2, LIN_PA0, LIN_PA0, LIN_PA1,
-                             LIN_FU0, LIN_FU0, LIN_FU1, LIN_CF0, LIN_CF0, LIN_CF1, LIN_CF2};
+                             LIN_FU0, LIN_FU0, LIN_FU1, LIN_CF0, LIN_CF0, LIN_CF1, LIN_CF2,
+                             LIN_C3, LIN_C2, LIN_C1, LIN_C0, LIN_NE2, LIN_NE1, LIN_NE0, LIN_EE2, LIN_EE1, LIN_EE0};
   double total = 0;
   for (int i = 0; i < WJ_COUNT; ++i) {
     p.shape[i] = shp[i];
     p.lin[i] = lin[i];
-    p.rows[i] = (i < WJ_CF0A) ? E : N;
-    p.nvar[i] = layer_mode ? 1 : (i <= WJ_EU2) ? depth : depth - 1;   // standalone layer: every stack once
-    total += (double)p.rows[i] * ws_shape_blocks(shp[i]) * (p.nvar[i] > 0 ? p.nvar[i] : 0);
+    const bool on_nodes = (i >= WJ_CF0A && i <= WJ_CF2) || (i >= WJ_NE2 && i <= WJ_NE0);
+    p.rows[i] = on_nodes ? N : E;
+    if (i >= kWjBig) p.nvar[i] = layer_mode ? 0 : 1;
+    else p.nvar[i] = layer_mode ? 1 : (i <= WJ_EU2) ? depth : depth - 1;   // standalone layer: every stack once
+    if (i < kWjBig) total += (double)p.rows[i] * ws_shape_blocks(shp[i]) * (p.nvar[i] > 0 ? p.nvar[i] : 0);
   }
   for (int i = 0; i < WJ_COUNT; ++i) {
-    const double work = (double)p.rows[i] * ws_shape_blocks(shp[i]) * (p.nvar[i] > 0 ? p.nvar[i] : 0);
-    long t = (long)(2048.0 * work / (total > 0 ? total : 1) + 0.5);
-    const long maxt = (p.rows[i] + 15) / 16;
-    if (t > maxt) t = maxt;
-    if (t < 1) t = 1;
-    long rpt = ((p.rows[i] + t - 1) / t + 3) / 4 * 4;
-    if (rpt < 4) rpt = 4;
+    long rpt;
+    if (i < kWjBig) {
+      const double work = (double)p.rows[i] * ws_shape_blocks(shp[i]) * (p.nvar[i] > 0 ? p.nvar[i] : 0);
+      long t = (long)(2048.0 * work / (total > 0 ? total : 1) + 0.5);
+      const long maxt = (p.rows[i] + 15) / 16;
+      if (t > maxt) t = maxt;
+      if (t < 1) t = 1;
+      rpt = ((p.rows[i] + t - 1) / t + 3) / 4 * 4;
+      if (rpt < 4) rpt = 4;
+    } else {
+      rpt = kNarrowRowsPerTask;              // load-latency bound tasks: a fixed, short row range each
+    }
     p.rows_per_task[i] = (int)rpt;
     p.ntasks[i] = (int)((p.rows[i] + rpt - 1) / rpt);
     if (p.ntasks[i] < 1) p.ntasks[i] = 1;
@@ -89,7 +103,7 @@ struct PoseWs {
   WsJob* ws_table;      // device job table of the streaming weight gradient
   int* ws_task_job;
   int* iota;            // 0, 1, 2, ... (identity gather for the streaming weight gradient)
-  float *gc3, *gc2, *gc1, *ge2, *ge1, *gn_top, *gn2, *gn1;
+  float *gc_top, *gc3, *gc2, *gc1, *ge2, *ge1, *gn_top, *gn2, *gn1;
   LinSlab lin[LIN_COUNT];
   KnnWs knn;
   size_t bytes;
@@ -170,6 +184,7 @@ static void carve(PoseWs& w, void* ws, size_t ws_bytes, int N, int E, int depth,
     w.Gdx = c.take<float>((size_t)depth * n_ * D::DX);
     w.GnH2 = c.take<float>((size_t)depth * n_ * D::NH2);
     w.GnH1 = c.take<float>((size_t)depth * n_ * D::NH1);
+    w.gc_top = c.take<float>(e_ * 16);
     w.gc3 = c.take<float>(e_ * 16);
     w.gc2 = c.take<float>(e_ * 16);
     w.gc1 = c.take<float>(e_ * 16);
@@ -181,7 +196,7 @@ static void carve(PoseWs& w, void* ws, size_t ws_bytes, int N, int E, int depth,
     w.iota = c.take<int>((size_t)(E > N ? E : N) + 64);
     w.zrow = c.take<float>(256);
     w.ws_table = c.take<WsJob>(32);
-    w.ws_task_job = c.take<int>(8192);
+    w.ws_task_job = c.take<int>(kWsTaskCap);
     // weight-gradient slabs; chunk / task counts are a pure function of (N, E, depth)
     w.plan = ws_plan(N, E, depth, (flags & kFlagLayerMode) != 0);
     for (int i = 0; i < LIN_COUNT; ++i) {
@@ -259,6 +274,9 @@ struct MpGradSrc {
   long xs, es;
   const float *GdH1, *GdH2, *Gde, *GdP1, *GdF1, *dM, *GnH1, *GnH2, *Gdx;
   const float *sH1, *sH2, *sP1, *sF1, *M, *nH1, *nH2;
+  const float* e_last;      // e[depth]: input of the classifier (whole model only)
+  const float* de0;         // gradient of e[0] = G of edge_encoder.4 (whole model only)
+  bool have_logit_grad;
 };
 
 static int mp_weight_grads(PoseWs& w, const MpGradSrc& ms, int N, int E, const int* src, const int* dst, hipStream_t stream) {
@@ -266,7 +284,7 @@ static int mp_weight_grads(PoseWs& w, const MpGradSrc& ms, int N, int E, const i
   const size_t nLm = (size_t)N * D::NIN, nLx = (size_t)N * D::DX, nL1 = (size_t)N * D::NH1, nL2 = (size_t)N * D::NH2;
   (void)eLe; (void)nLx;
     WsLauncher wl;
-    wl.begin(w.ws_table, 32, w.ws_task_job, 8192, stream);
+    wl.begin(w.ws_table, 32, w.ws_task_job, kWsTaskCap, stream);
     hipLaunchKernelGGL(iota_kernel, dim3(((E > N ? E : N) + 255) / 256), dim3(256), 0, stream, w.iota, E > N ? E : N);
     B3D_TRY(launch_check("iota_kernel"));
     B3D_HIP_CHECK(hipMemsetAsync(w.zrow, 0, 256 * sizeof(float), stream));
@@ -313,6 +331,21 @@ static int mp_weight_grads(PoseWs& w, const MpGradSrc& ms, int N, int E, const i
     add(WJ_FU1, sg(ms.dM, src, nLm, D::NIN, D::DM), sg(ms.sF1, nullptr, eLm, D::MH, 0), 0, none, 0, true);
     add(WJ_CF1, sg(ms.GnH2, nullptr, nL2, D::NH2, 0), sg(ms.nH1, nullptr, nL1, D::NH1, 0), 0, none, 0, true);
     add(WJ_CF2, sg(ms.Gdx, nullptr, nLx, D::DX, 0), sg(ms.nH2, nullptr, nL2, D::NH2, 0), 0, none, 0, true);
+    // narrow stacks (whole model only; nvar == 0 in layer mode).  Row strides pad every width to 16, the
+    // padding columns only reach slab entries outside [N, K], which the reduce never reads.
+    auto narrow = [&](int wj, const float* gp, int gstride, const float* ap, int astride) {
+      add(wj, sg(gp, nullptr, 0, gstride, 0), sg(ap, nullptr, 0, astride, 0), 0, none, 0, true);
+    };
+    if (ms.have_logit_grad) narrow(WJ_C3, w.gc_top, 16, w.c_a3, 16);       // edge_classifier.6  [1,4]
+    narrow(WJ_C2, w.gc3, 16, w.c_a2, 16);                                  // .4  [4,8]
+    narrow(WJ_C1, w.gc2, 16, w.c_a1, 16);                                  // .2  [8,16]
+    narrow(WJ_C0, w.gc1, 16, ms.e_last, D::DE);                            // .0  [16,32]
+    narrow(WJ_NE2, w.gn_top, 48, w.ne_a2, 48);                             // node_encoder.4  [48,36]
+    narrow(WJ_NE1, w.gn2, 48, w.ne_a1, 32);                                // .2  [36,24]
+    narrow(WJ_NE0, w.gn1, 32, w.pose_pad, 32);                             // .0  [24,19]
+    narrow(WJ_EE2, ms.de0, D::DE, w.ee_a2, 16);                            // edge_encoder.4  [32,16]
+    narrow(WJ_EE1, w.ge2, 16, w.ee_a1, 16);                                // .2  [16,8]
+    narrow(WJ_EE0, w.ge1, 16, w.ea_pad, 16);                               // .0  [8,4]
     wl.launch(w.zrow, B3D_K_WGRAD_EDGE);
     B3D_REQUIRE(wl.status == 0, "streaming weight gradient: job table overflow");
     B3D_TRY(launch_check("wstream_kernel"));
@@ -448,8 +481,6 @@ extern "C" int b3d_pose_backward(const b3d_pose_weights* pw, const b3d_graph* g,
 
   const size_t eL1 = (size_t)E * D::EH1, eL2 = (size_t)E * D::EH2, eLe = (size_t)E * D::DE, eLm = (size_t)E * D::MH;
   const size_t nLm = (size_t)N * D::NIN, nLx = (size_t)N * D::DX, nL1 = (size_t)N * D::NH1, nL2 = (size_t)N * D::NH2;
-  WgArgs small;                 // classifier + encoder weight gradients (tiny / unaligned layers)
-  small.njobs = 0;
 
   // ---- classifier: d_logits -> d e[depth] -------------------------------------------------------
   int cur = 0;
@@ -460,22 +491,9 @@ extern "C" int b3d_pose_backward(const b3d_pose_weights* pw, const b3d_graph* g,
     a.out = StoreAligned<2>{w.de[cur], nullptr, D::DE, 0};
     a.act[0] = w.c_a3; a.act[1] = w.c_a2; a.act[2] = w.c_a1; a.act[3] = nullptr;
     a.gsave[0] = w.gc3; a.gsave[1] = w.gc2; a.gsave[2] = w.gc1; a.gsave[3] = nullptr;
+    a.gtop = w.gc_top;                       // d_logits padded to 16 columns: G of edge_classifier.6
     a.wpack = w.wp_clsT;
     B3D_TRY(launch_rows<kNWEdge>(chain_bwd_kernel<SeqClsT, LoadScalar, StoreAligned<2>, kNWEdge>, "edge_classifier_bwd", a, E, stream));
-    if (d_logits) {
-      WgJob j3 = make_job(w.lin[LIN_C3], E, seg(d_logits, nullptr, 1, 0, 1));
-      add_act(j3, seg(w.c_a3, nullptr, 16, 0, 4));
-      small.jobs[small.njobs++] = j3;
-    }
-    WgJob j2 = make_job(w.lin[LIN_C2], E, seg(w.gc3, nullptr, 16, 0, 4));
-    add_act(j2, seg(w.c_a2, nullptr, 16, 0, 8));
-    small.jobs[small.njobs++] = j2;
-    WgJob j1 = make_job(w.lin[LIN_C1], E, seg(w.gc2, nullptr, 16, 0, 8));
-    add_act(j1, seg(w.c_a1, nullptr, 16, 0, 16));
-    small.jobs[small.njobs++] = j1;
-    WgJob j0 = make_job(w.lin[LIN_C0], E, seg(w.gc1, nullptr, 16, 0, 16));
-    add_act(j0, seg(w.e[depth], nullptr, D::DE, 0, D::DE));
-    small.jobs[small.njobs++] = j0;
   }
 
   // ---- message-passing layers, last to first: data gradients only; the G tensors of every layer
@@ -527,15 +545,6 @@ extern "C" int b3d_pose_backward(const b3d_pose_weights* pw, const b3d_graph* g,
     a.gsave[0] = w.gn2; a.gsave[1] = w.gn1;
     a.wpack = w.wp_neT;
     B3D_TRY(launch_rows<kNWNode>(chain_bwd_kernel<SeqNodeEncT, In, StoreNone, kNWNode>, "node_encoder_bwd", a, N, stream));
-    WgJob n2 = make_job(w.lin[LIN_NE2], N, seg(w.gn_top, nullptr, 48, 0, 48));
-    add_act(n2, seg(w.ne_a2, nullptr, 48, 0, 36));
-    small.jobs[small.njobs++] = n2;
-    WgJob n1 = make_job(w.lin[LIN_NE1], N, seg(w.gn2, nullptr, 48, 0, 36));
-    add_act(n1, seg(w.ne_a1, nullptr, 32, 0, 24));
-    small.jobs[small.njobs++] = n1;
-    WgJob n0 = make_job(w.lin[LIN_NE0], N, seg(w.gn1, nullptr, 32, 0, 24));
-    add_act(n0, seg(w.pose_pad, nullptr, 32, 0, 19));
-    small.jobs[small.njobs++] = n0;
   }
   {  // edge encoder: G_3 = d e[0]
     ChainBwdArgs<LoadAligned<2>, StoreNone> a;
@@ -546,17 +555,7 @@ extern "C" int b3d_pose_backward(const b3d_pose_weights* pw, const b3d_graph* g,
     a.gsave[0] = w.ge2; a.gsave[1] = w.ge1;
     a.wpack = w.wp_eeT;
     B3D_TRY(launch_rows<kNWEdge>(chain_bwd_kernel<SeqEdgeEncT, LoadAligned<2>, StoreNone, kNWEdge>, "edge_encoder_bwd", a, E, stream));
-    WgJob e2 = make_job(w.lin[LIN_EE2], E, seg(w.de[cur], nullptr, D::DE, 0, 32));
-    add_act(e2, seg(w.ee_a2, nullptr, 16, 0, 16));
-    small.jobs[small.njobs++] = e2;
-    WgJob e1 = make_job(w.lin[LIN_EE1], E, seg(w.ge2, nullptr, 16, 0, 16));
-    add_act(e1, seg(w.ee_a1, nullptr, 16, 0, 8));
-    small.jobs[small.njobs++] = e1;
-    WgJob e0 = make_job(w.lin[LIN_EE0], E, seg(w.ge1, nullptr, 16, 0, 8));
-    add_act(e0, seg(w.ea_pad, nullptr, 16, 0, 4));
-    small.jobs[small.njobs++] = e0;
   }
-  B3D_TRY((launch_wgrad<6, 1>(small, stream, B3D_K_WGRAD_OTHER)));
 
   // ---- message-passing weight gradients: all layers, one streaming launch ---------------------
   {
@@ -565,6 +564,7 @@ extern "C" int b3d_pose_backward(const b3d_pose_weights* pw, const b3d_graph* g,
     ms.GdH1 = w.GdH1; ms.GdH2 = w.GdH2; ms.Gde = w.Gde; ms.GdP1 = w.GdP1; ms.GdF1 = w.GdF1; ms.dM = w.dM;
     ms.GnH1 = w.GnH1; ms.GnH2 = w.GnH2; ms.Gdx = w.Gdx;
     ms.sH1 = w.sH1[0]; ms.sH2 = w.sH2[0]; ms.sP1 = w.sP1[0]; ms.sF1 = w.sF1[0]; ms.M = w.M[0]; ms.nH1 = w.nH1[0]; ms.nH2 = w.nH2[0];
+    ms.e_last = w.e[depth]; ms.de0 = w.de[cur]; ms.have_logit_grad = d_logits != nullptr;
     B3D_TRY(mp_weight_grads(w, ms, N, E, src, dst, stream));
   }
 
@@ -769,6 +769,7 @@ extern "C" int b3d_pose_layer_backward(const b3d_mp_weights* mw, const b3d_graph
   ms.GdH1 = w.GdH1; ms.GdH2 = w.GdH2; ms.Gde = w.Gde; ms.GdP1 = w.GdP1; ms.GdF1 = w.GdF1; ms.dM = w.dM;
   ms.GnH1 = w.GnH1; ms.GnH2 = w.GnH2; ms.Gdx = d_x_new;
   ms.sH1 = w.sH1[0]; ms.sH2 = w.sH2[0]; ms.sP1 = w.sP1[0]; ms.sF1 = w.sF1[0]; ms.M = w.M[0]; ms.nH1 = w.nH1[0]; ms.nH2 = w.nH2[0];
+  ms.e_last = nullptr; ms.de0 = nullptr; ms.have_logit_grad = false;
   B3D_TRY(mp_weight_grads(w, ms, N, E, g->src, g->dst, stream));
   RedArgs ra;
   ra.nentries = 0;

@@ -245,7 +245,14 @@ enum {
   WS_48_64 = 4,
   WS_96_64 = 5,         // P combine_future_past.0 (two column halves)
   WS_64_64 = 6,
-  WS_SHAPES = 7
+  // narrow stacks (encoders, classifier): widths padded to 16 by their row stride
+  WS_16_16 = 7,
+  WS_16_32 = 8,
+  WS_32_16 = 9,
+  WS_32_32 = 10,
+  WS_48_32 = 11,
+  WS_48_48 = 12,
+  WS_SHAPES = 13
 };
 
 static __global__ void ws_table_kernel(const WsTableArgs a) {
@@ -280,13 +287,19 @@ static __global__ __launch_bounds__(kWsWaves * 64, 2) void wstream_kernel(const 
     case WS_48_64: ws_task<48, 64, 0, 0>(job, chunk, zero_row); break;
     case WS_96_64: ws_task<96, 64, 0, 0>(job, chunk, zero_row); break;
     case WS_64_64: ws_task<64, 64, 0, 0>(job, chunk, zero_row); break;
+    case WS_16_16: ws_task<16, 16, 0, 0>(job, chunk, zero_row); break;
+    case WS_16_32: ws_task<16, 32, 0, 0>(job, chunk, zero_row); break;
+    case WS_32_16: ws_task<32, 16, 0, 0>(job, chunk, zero_row); break;
+    case WS_32_32: ws_task<32, 32, 0, 0>(job, chunk, zero_row); break;
+    case WS_48_32: ws_task<48, 32, 0, 0>(job, chunk, zero_row); break;
+    case WS_48_48: ws_task<48, 48, 0, 0>(job, chunk, zero_row); break;
     default: break;
   }
 }
 
 // blocks (MFMAs per 4-row step) of a shape: the unit of work used to balance tasks
 inline int ws_shape_blocks(int shape) {
-  static const int b[WS_SHAPES] = {6 * 4, 6 * 4, 4 * 6, 2 * 4, 3 * 4, 6 * 4, 4 * 4};
+  static const int b[WS_SHAPES] = {6 * 4, 6 * 4, 4 * 6, 2 * 4, 3 * 4, 6 * 4, 4 * 4, 1, 2, 2, 4, 6, 9};
   return b[shape];
 }
 
