@@ -25,10 +25,8 @@ struct KnnWs {
   int* fend;      // [N] one past the last
   int* nbr;       // [N, kKnnMaxK] neighbour node ids (-1 padded)
   int* cnt;       // [N] number of neighbours
-  int* rcnt;      // [3, N] rank counters, then one overflow counter
+  int* rcnt;      // [3, N] rank counters
   float* h;       // [N, D]
-  float* s_src;   // [N]
-  float* s_dst;   // [N]
   float* y;       // [N, D] GAT output
   float* wp;      // packed image of lin (L<D,D>)
   bool ranked;
@@ -38,7 +36,7 @@ inline void knn_carve(KnnWs& k, Carver& c, int N, int D) {
   const size_t n = (size_t)(N > 0 ? N : 1);
   k.rank = c.take<int>(n); k.order = c.take<int>(n); k.fbeg = c.take<int>(n); k.fend = c.take<int>(n);
   k.nbr = c.take<int>(n * kKnnMaxK); k.cnt = c.take<int>(n); k.rcnt = c.take<int>(3 * n + 64);
-  k.h = c.take<float>(n * D); k.s_src = c.take<float>(n); k.s_dst = c.take<float>(n); k.y = c.take<float>(n * D);
+  k.h = c.take<float>(n * D); k.y = c.take<float>(n * D);
   k.wp = c.take<float>(image_floats(D, D));
   k.ranked = false;
 }
@@ -104,6 +102,42 @@ __device__ __forceinline__ void wave_argmin(float& d, int& j) {
   }
 }
 
+// Frames larger than kKnnList (the per-wave LDS distance list): distances are recomputed from global
+// memory in every selection round -- the smallest (distance, position) pair strictly after the
+// previous pick, k times.  Rare (a frame of > 1,024 detections), slow, exact.
+template <int D>
+__device__ __forceinline__ void knn_select_big(const float* __restrict__ x, const float (&xc)[D], int c, int b, int nt, int kk,
+                                               const int* __restrict__ order, int* __restrict__ nbr) {
+  const int lane = threadIdx.x & 63;
+  auto sqdist = [&](int q) {
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < D; d += 4) {
+      const v4f v = *reinterpret_cast<const v4f*>(x + (size_t)q * D + d);
+      const float a0 = v.x - xc[d], a1 = v.y - xc[d + 1], a2 = v.z - xc[d + 2], a3 = v.w - xc[d + 3];
+      s = fmaf(a0, a0, s); s = fmaf(a1, a1, s); s = fmaf(a2, a2, s); s = fmaf(a3, a3, s);
+    }
+    return s;
+  };
+  const float INF = __builtin_inff();
+  float ld = -1.f; int lp = -1;
+  int mine = 0;
+  for (int r = 0; r < kk; ++r) {
+    float bd = INF; int bp = 0x7fffffff;
+    for (int p = lane; p < nt; p += 64) {
+      const int q = order[b + p];
+      if (q == c) continue;
+      const float dv = sqdist(q);
+      const bool after = (dv > ld) || (dv == ld && p > lp);
+      if (after && (dv < bd || (dv == bd && p < bp))) { bd = dv; bp = p; }
+    }
+    wave_argmin(bd, bp);
+    if (lane == r) mine = bp;
+    ld = bd; lp = bp;
+  }
+  if (lane < kk) nbr[(size_t)c * kKnnMaxK + lane] = order[b + mine];
+}
+
 // One wavefront per centre, kKnnCentres centres (consecutive in frame order) per workgroup.
 // Candidate rows are staged through LDS in tiles of kKnnTileRows, so a candidate row is fetched from
 // L2 once per workgroup instead of once per centre; each lane computes the squared distance of its
@@ -119,8 +153,7 @@ __global__ __launch_bounds__(kKnnCentres * 64) void knn_tile_kernel(const float*
                                                                     const int* __restrict__ order,
                                                                     const int* __restrict__ fbeg,
                                                                     const int* __restrict__ fend,
-                                                                    int* __restrict__ nbr, int* __restrict__ cnt,
-                                                                    int* __restrict__ overflow) {
+                                                                    int* __restrict__ nbr, int* __restrict__ cnt) {
   constexpr int TS = D + 1;                               // padded tile row (bank spread)
   constexpr int TR = kKnnTileRows;                        // candidate rows per tile
   constexpr int NT = kKnnCentres * 64;
@@ -138,8 +171,7 @@ __global__ __launch_bounds__(kKnnCentres * 64) void knn_tile_kernel(const float*
   int ub = 0x7fffffff, ue = 0;                            // union of the candidate ranges of the workgroup
 #pragma unroll
   for (int w = 0; w < kKnnCentres; ++w) { ub = min(ub, wb[w]); ue = max(ue, we[w]); }
-  const bool big = nt > kKnnList;                         // handled by the fallback kernel
-  if (live && big && lane == 0) atomicAdd(overflow, 1);
+  const bool big = nt > kKnnList;                         // does not fit the LDS list: knn_select_big
   float xc[D];
 #pragma unroll
   for (int d = 0; d < D; d += 4) {
@@ -196,8 +228,13 @@ __global__ __launch_bounds__(kKnnCentres * 64) void knn_tile_kernel(const float*
       }
     }
   }
-  if (!live || big) return;
+  if (!live) return;
   const int kk = (k < nt - 1) ? k : (nt - 1);
+  if (big) {
+    knn_select_big<D>(x, xc, c, b, nt, kk, order, nbr);
+    if (lane == 0) cnt[c] = kk;
+    return;
+  }
   int mine = 0;
   for (int r = 0; r < kk; ++r) {
     float bd = INF; int bp = 0x7fffffff;
@@ -213,78 +250,12 @@ __global__ __launch_bounds__(kKnnCentres * 64) void knn_tile_kernel(const float*
   if (lane == 0) cnt[c] = kk > 0 ? kk : 0;
 }
 
-// Fallback for frames larger than kKnnList: one wavefront per centre, distances recomputed from
-// global memory in every selection round.  Only centres of such frames do any work.
-template <int D>
-__global__ __launch_bounds__(256) void knn_select_kernel(const float* __restrict__ x, int N, int k,
-                                                         const int* __restrict__ order, const int* __restrict__ fbeg,
-                                                         const int* __restrict__ fend, int* __restrict__ nbr,
-                                                         int* __restrict__ cnt, const int* __restrict__ overflow) {
-  if (*overflow == 0) return;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int c = blockIdx.x * 4 + wave;
-  if (c >= N) return;
-  const int b = fbeg[c], e = fend[c], nt = e - b;
-  if (nt <= kKnnList) return;
-  const int kk = (k < nt - 1) ? k : (nt - 1);
-  float xc[D];
-#pragma unroll
-  for (int d = 0; d < D; d += 4) {
-    const v4f v = *reinterpret_cast<const v4f*>(x + (size_t)c * D + d);
-    xc[d] = v.x; xc[d + 1] = v.y; xc[d + 2] = v.z; xc[d + 3] = v.w;
-  }
-  auto sqdist = [&](int q) {
-    float s = 0.f;
-#pragma unroll
-    for (int d = 0; d < D; d += 4) {
-      const v4f v = *reinterpret_cast<const v4f*>(x + (size_t)q * D + d);
-      const float a0 = v.x - xc[d], a1 = v.y - xc[d + 1], a2 = v.z - xc[d + 2], a3 = v.w - xc[d + 3];
-      s = fmaf(a0, a0, s); s = fmaf(a1, a1, s); s = fmaf(a2, a2, s); s = fmaf(a3, a3, s);
-    }
-    return s;
-  };
-  const float INF = __builtin_inff();
-  // select the smallest (dist, pos) pair strictly greater than the previous pick, k times
-  float ld = -1.f; int lp = -1;
-  for (int r = 0; r < kk; ++r) {
-    float bd = INF; int bp = 0x7fffffff;
-    for (int p = lane; p < nt; p += 64) {
-      const int q = order[b + p];
-      if (q == c) continue;
-      const float dv = sqdist(q);
-      const bool after = (dv > ld) || (dv == ld && p > lp);
-      if (after && (dv < bd || (dv == bd && p < bp))) { bd = dv; bp = p; }
-    }
-    wave_argmin(bd, bp);
-    if (lane == 0) nbr[(size_t)c * kKnnMaxK + r] = order[b + bp];
-    ld = bd; lp = bp;
-  }
-  if (lane == 0) cnt[c] = kk > 0 ? kk : 0;
-}
-
-template <int D>
-__global__ void gat_scores_kernel(const float* __restrict__ h, int N, const float* __restrict__ att_src,
-                                  const float* __restrict__ att_dst, float* __restrict__ s_src,
-                                  float* __restrict__ s_dst) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
-  float a = 0.f, b = 0.f;
-#pragma unroll
-  for (int d = 0; d < D; d += 4) {
-    const v4f v = *reinterpret_cast<const v4f*>(h + (size_t)n * D + d);
-    a = fmaf(v.x, att_src[d], a); a = fmaf(v.y, att_src[d + 1], a); a = fmaf(v.z, att_src[d + 2], a); a = fmaf(v.w, att_src[d + 3], a);
-    b = fmaf(v.x, att_dst[d], b); b = fmaf(v.y, att_dst[d + 1], b); b = fmaf(v.z, att_dst[d + 2], b); b = fmaf(v.w, att_dst[d + 3], b);
-  }
-  s_src[n] = a;
-  s_dst[n] = b;
-}
-
 // one wavefront per destination: per-destination segmented softmax with wavefront shuffles,
 // attention-weighted sum of neighbour rows
 template <int D>
 __global__ __launch_bounds__(256) void gat_aggregate_kernel(const float* __restrict__ h, int N,
                                                             const int* __restrict__ nbr, const int* __restrict__ cnt,
-                                                            const float* __restrict__ s_src, const float* __restrict__ s_dst,
+                                                            const float* __restrict__ att_src, const float* __restrict__ att_dst,
                                                             const float* __restrict__ bias, float* __restrict__ y) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int c = blockIdx.x * 4 + wave;
@@ -293,8 +264,17 @@ __global__ __launch_bounds__(256) void gat_aggregate_kernel(const float* __restr
   int q = -1;
   float a = -__builtin_inff();
   if (lane < kk) {
+    // attention logit of edge (q -> c): leaky_relu(<h[q], att_src> + <h[c], att_dst>), GATConv heads = 1
     q = nbr[(size_t)c * kKnnMaxK + lane];
-    const float z = s_src[q] + s_dst[c];
+    float ss = 0.f, sd = 0.f;
+#pragma unroll
+    for (int d = 0; d < D; d += 4) {
+      const v4f vq = *reinterpret_cast<const v4f*>(h + (size_t)q * D + d);
+      const v4f vc = *reinterpret_cast<const v4f*>(h + (size_t)c * D + d);
+      ss = fmaf(vq.x, att_src[d], ss); ss = fmaf(vq.y, att_src[d + 1], ss); ss = fmaf(vq.z, att_src[d + 2], ss); ss = fmaf(vq.w, att_src[d + 3], ss);
+      sd = fmaf(vc.x, att_dst[d], sd); sd = fmaf(vc.y, att_dst[d + 1], sd); sd = fmaf(vc.z, att_dst[d + 2], sd); sd = fmaf(vc.w, att_dst[d + 3], sd);
+    }
+    const float z = ss + sd;
     a = z > 0.f ? z : 0.2f * z;
   }
   float m = a;
@@ -343,13 +323,9 @@ inline int knn_gat_block(KnnWs& ws, const float* x, const int64_t* ts, int N, co
     B3D_TRY(pack_images(&d, 1, stream));
     ws.ranked = true;
   }
-  int* overflow = ws.rcnt + 3 * (size_t)N;
   hipLaunchKernelGGL(knn_tile_kernel<D>, dim3((N + kKnnCentres - 1) / kKnnCentres), dim3(kKnnCentres * 64), 0, stream,
-                     x, N, k, ws.order, ws.fbeg, ws.fend, ws.nbr, ws.cnt, overflow);
+                     x, N, k, ws.order, ws.fbeg, ws.fend, ws.nbr, ws.cnt);
   B3D_TRY(launch_check("knn_tile_kernel"));
-  hipLaunchKernelGGL(knn_select_kernel<D>, dim3((N + 3) / 4), dim3(256), 0, stream, x, N, k, ws.order, ws.fbeg, ws.fend,
-                     ws.nbr, ws.cnt, overflow);
-  B3D_TRY(launch_check("knn_select_kernel"));
   {
     using S = LayerSeq<L<D, D>>;
     ChainFwdArgs<LoadAligned<D / 16>, StoreAligned<D / 16>> a;
@@ -360,9 +336,7 @@ inline int knn_gat_block(KnnWs& ws, const float* x, const int64_t* ts, int N, co
     a.wpack = ws.wp;
     B3D_TRY(launch_rows<kNWNode>(chain_fwd_kernel<S, 0u, LoadAligned<D / 16>, StoreAligned<D / 16>, kNWNode>, "gat_linear", a, N, stream));
   }
-  hipLaunchKernelGGL(gat_scores_kernel<D>, dim3((N + 255) / 256), dim3(256), 0, stream, ws.h, N, gat.att_src, gat.att_dst, ws.s_src, ws.s_dst);
-  B3D_TRY(launch_check("gat_scores_kernel"));
-  hipLaunchKernelGGL(gat_aggregate_kernel<D>, dim3((N + 3) / 4), dim3(256), 0, stream, ws.h, N, ws.nbr, ws.cnt, ws.s_src, ws.s_dst, gat.bias, ws.y);
+  hipLaunchKernelGGL(gat_aggregate_kernel<D>, dim3((N + 3) / 4), dim3(256), 0, stream, ws.h, N, ws.nbr, ws.cnt, gat.att_src, gat.att_dst, gat.bias, ws.y);
   return launch_check("gat_aggregate_kernel");
 }
 

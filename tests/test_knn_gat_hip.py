@@ -8,7 +8,8 @@ from oracle import ref_torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("dim,frames", [(48, [130, 70, 19, 1, 300]), (96, [90, 21, 64])])
+@pytest.mark.parametrize("dim,frames", [(48, [130, 70, 19, 1, 300]), (96, [90, 21, 64]),
+                                        (48, [1100, 40])])          # > 1,024 nodes: the global-memory selection path
 def test_knn_gat_matches_oracle(dim, frames):
     from batch3dmot_amd import _lib
     from batch3dmot_amd.pose_gnn import GATConvParams
