@@ -93,6 +93,28 @@ static __global__ void knn_rank_finish_kernel(const int* __restrict__ cnt, int N
   fend[i] = cnt[N + i];
 }
 
+// Wavefront minimum of 64-bit keys (hi, lo) with DPP row shifts / row broadcasts (GFX9 wave64
+// reduction; the result lands in lane 63 and is broadcast through an SGPR).  Distances are
+// non-negative floats, so their bit patterns order like unsigned integers.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void dpp_min_step(unsigned& hi, unsigned& lo) {
+  const unsigned th = (unsigned)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)hi, CTRL, ROW_MASK, 0xF, false);
+  const unsigned tl = (unsigned)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)lo, CTRL, ROW_MASK, 0xF, false);
+  const bool less = (th < hi) || (th == hi && tl < lo);
+  hi = less ? th : hi;
+  lo = less ? tl : lo;
+}
+__device__ __forceinline__ void wave_min_key(unsigned& hi, unsigned& lo) {
+  dpp_min_step<0x111, 0xF>(hi, lo);      // row_shr:1
+  dpp_min_step<0x112, 0xF>(hi, lo);      // row_shr:2
+  dpp_min_step<0x114, 0xF>(hi, lo);      // row_shr:4
+  dpp_min_step<0x118, 0xF>(hi, lo);      // row_shr:8   -> lane 15 of every row holds the row minimum
+  dpp_min_step<0x142, 0xA>(hi, lo);      // row_bcast:15 into rows 1 and 3
+  dpp_min_step<0x143, 0xC>(hi, lo);      // row_bcast:31 into rows 2 and 3 -> lane 63 holds the minimum
+  hi = (unsigned)__builtin_amdgcn_readlane((int)hi, 63);
+  lo = (unsigned)__builtin_amdgcn_readlane((int)lo, 63);
+}
+
 __device__ __forceinline__ void wave_argmin(float& d, int& j) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
@@ -235,16 +257,28 @@ __global__ __launch_bounds__(kKnnCentres * 64) void knn_tile_kernel(const float*
     if (lane == 0) cnt[c] = kk;
     return;
   }
+  // The lane's candidates (positions lane, lane + 64, ...) move to registers; each round is a
+  // register scan plus a DPP wavefront arg-min on (distance bits, position) keys.
+  constexpr int SL = kKnnList / 64;
+  float cd[SL];
+#pragma unroll
+  for (int j = 0; j < SL; ++j) cd[j] = (64 * j + lane < nt) ? dist[wave][64 * j + lane] : INF;
   int mine = 0;
   for (int r = 0; r < kk; ++r) {
-    float bd = INF; int bp = 0x7fffffff;
-    for (int q = lane; q < nt; q += 64) {
-      const float dv = dist[wave][q];
-      if (dv < bd) { bd = dv; bp = q; }
-    }
-    wave_argmin(bd, bp);
+    float bd = INF; int bj = 0;
+#pragma unroll
+    for (int j = 0; j < SL; ++j)
+      if (cd[j] < bd) { bd = cd[j]; bj = j; }
+    unsigned hi = __float_as_uint(bd), lo = (bd < INF) ? (unsigned)(64 * bj + lane) : 0x7fffffffu;
+    wave_min_key(hi, lo);                                   // smallest distance, then smallest position
+    const int bp = (int)lo;
     if (lane == r) mine = bp;                               // lane r keeps the r-th nearest
-    if ((bp & 63) == lane) dist[wave][bp] = INF;
+    if ((bp & 63) == lane) {
+      const int slot = bp >> 6;
+#pragma unroll
+      for (int j = 0; j < SL; ++j)
+        if (j == slot) cd[j] = INF;
+    }
   }
   if (lane < kk) nbr[(size_t)c * kKnnMaxK + lane] = order[b + mine];
   if (lane == 0) cnt[c] = kk > 0 ? kk : 0;
