@@ -87,8 +87,9 @@ struct LoadNodeEncGrad {
 #pragma unroll
     for (int b = 0; b < 2 * XB; ++b) g[b] = v4f{0.f, 0.f, 0.f, 0.f};
     if (valid) {
-      segment_sum<2 * XB>(gdst, 32 * XB, 0, dst_perm, dst_ptr[row], dst_ptr[row + 1], g);
-      segment_sum<2 * XB>(gsrc, 32 * XB, 0, src_perm, src_ptr[row], src_ptr[row + 1], g);
+      constexpr int U = XB <= 3 ? 4 : 2;          // rows in flight per lane
+      segment_sum_deep<2 * XB, U>(gdst, 32 * XB, 0, dst_perm, dst_ptr[row], dst_ptr[row + 1], g);
+      segment_sum_deep<2 * XB, U>(gsrc, 32 * XB, 0, src_perm, src_ptr[row], src_ptr[row + 1], g);
     }
     v4f t[XB];
     if (d_x_enc) { load_row<XB>(d_x_enc, row, 16 * XB, 0, valid, t); add_blocks<XB>(g, t); }
@@ -156,6 +157,16 @@ struct StoreAligned {
     long r = row;
     if (idx && valid) r = idx[row];
     if (ptr) store_row<NB>(ptr, r, stride, col0, valid, src);
+  }
+};
+
+template <int NB_>
+struct StoreTwo {                    // the same rows to two destinations (e.g. x[0] and the returned x_enc)
+  static constexpr int NB = NB_;
+  float* p0; float* p1; int stride;
+  __device__ __forceinline__ void operator()(long row, bool valid, const v4f* src) const {
+    store_row<NB>(p0, row, stride, 0, valid, src);
+    store_row<NB>(p1, row, stride, 0, valid, src);
   }
 };
 

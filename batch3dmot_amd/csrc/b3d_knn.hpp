@@ -30,6 +30,7 @@ struct KnnWs {
   float* y;       // [N, D] GAT output
   float* wp;      // packed image of lin (L<D,D>)
   bool ranked;
+  bool packed;    // wp already holds the image of `lin` (the model's own pack launch wrote it)
 };
 
 inline void knn_carve(KnnWs& k, Carver& c, int N, int D) {
@@ -39,6 +40,7 @@ inline void knn_carve(KnnWs& k, Carver& c, int N, int D) {
   k.h = c.take<float>(n * D); k.y = c.take<float>(n * D);
   k.wp = c.take<float>(image_floats(D, D));
   k.ranked = false;
+  k.packed = false;
 }
 
 // Rank by (timestamp, node id).  O(N^2) comparisons spread over N x kRankSlices threads: thread
@@ -352,9 +354,12 @@ inline int knn_gat_block(KnnWs& ws, const float* x, const int64_t* ts, int N, co
     B3D_TRY(launch_check("knn_rank_count_kernel"));
     hipLaunchKernelGGL(knn_rank_finish_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, ws.rcnt, N, ws.rank, ws.order, ws.fbeg, ws.fend);
     B3D_TRY(launch_check("knn_rank_finish_kernel"));
-    using S = LayerSeq<L<D, D>>;
-    PackDesc d = pack_desc<S>(0, ws.wp, gat.lin, nullptr, D, D, false);
-    B3D_TRY(pack_images(&d, 1, stream));
+    if (!ws.packed) {
+      using S = LayerSeq<L<D, D>>;
+      PackDesc d = pack_desc<S>(0, ws.wp, gat.lin, nullptr, D, D, false);
+      B3D_TRY(pack_images(&d, 1, stream));
+      ws.packed = true;
+    }
     ws.ranked = true;
   }
   hipLaunchKernelGGL(knn_tile_kernel<D>, dim3((N + kKnnCentres - 1) / kKnnCentres), dim3(kKnnCentres * 64), 0, stream,

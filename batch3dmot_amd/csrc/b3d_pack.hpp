@@ -10,10 +10,11 @@ struct PackDesc {
   float* dst;        // image base (chunked layout)
   int N, K;          // true rows / cols OF THE IMAGE (transposed: N = in, K = out of the forward layer)
   int NP, KP;        // padded to multiples of 16
-  int transposed;    // 1: image of W^T (data-gradient operand)
+  int transposed;    // 1: image of W^T (data-gradient operand); 2 / 3: not an image -- fill N ints at dst with
+                     // 0, 1, 2, ... / with zeros (index and zero rows of the streaming weight gradient)
 };
 
-constexpr int kPackMax = 24;
+constexpr int kPackMax = 64;      // 3 KB of kernel arguments: one launch packs a whole model's images
 struct PackArgs {
   int n;
   PackDesc d[kPackMax];
@@ -29,6 +30,14 @@ inline PackDesc pack_desc(int li, float* base, const float* w, const float* b, i
   d.dst = base + Seq::layer_off(li);
   d.N = N; d.K = K; d.NP = Seq::np(li); d.KP = Seq::kp(li);
   d.transposed = transposed ? 1 : 0;
+  return d;
+}
+
+inline PackDesc fill_desc(void* dst, int count, bool iota) {
+  PackDesc d;
+  d.w = nullptr; d.b = nullptr; d.dst = (float*)dst;
+  d.N = count; d.K = 0; d.NP = 0; d.KP = 0;
+  d.transposed = iota ? 2 : 3;
   return d;
 }
 

@@ -39,11 +39,6 @@ struct WsPlan {
 };
 static WsPlan ws_plan(int N, int E, int depth, bool layer_mode);
 
-__global__ void iota_kernel(int* p, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) p[i] = i;
-}
-
 static WsPlan ws_plan(int N, int E, int depth, bool layer_mode) {
   WsPlan p;
   const int shp[WJ_COUNT] = {WS_96_48_16, WS_96_32_32, WS_64_96, WS_32_64, WS_96_48_16, WS_96_48_16, WS_64_96,
@@ -103,6 +98,7 @@ struct PoseWs {
   WsJob* ws_table;      // device job table of the streaming weight gradient
   int* ws_task_job;
   int* iota;            // 0, 1, 2, ... (identity gather for the streaming weight gradient)
+  int iota_n;
   float *gc_top, *gc3, *gc2, *gc1, *ge2, *ge1, *gn_top, *gn2, *gn1;
   LinSlab lin[LIN_COUNT];
   KnnWs knn;
@@ -193,7 +189,8 @@ static void carve(PoseWs& w, void* ws, size_t ws_bytes, int N, int E, int depth,
     w.gn_top = c.take<float>(n_ * 48);
     w.gn2 = c.take<float>(n_ * 48);
     w.gn1 = c.take<float>(n_ * 32);
-    w.iota = c.take<int>((size_t)(E > N ? E : N) + 64);
+    w.iota_n = (E > N ? E : N) + 64;
+    w.iota = c.take<int>((size_t)w.iota_n);
     w.zrow = c.take<float>(256);
     w.ws_table = c.take<WsJob>(32);
     w.ws_task_job = c.take<int>(kWsTaskCap);
@@ -217,8 +214,8 @@ static void carve(PoseWs& w, void* ws, size_t ws_bytes, int N, int E, int depth,
 }
 
 // ---- forward ------------------------------------------------------------------------------------
-static int pack_forward(const b3d_pose_weights* pw, PoseWs& w, bool training, hipStream_t stream) {
-  PackDesc d[48];
+static int pack_forward(const b3d_pose_weights* pw, PoseWs& w, bool training, bool knn, hipStream_t stream) {
+  PackDesc d[64];
   int n = 0;
   const b3d_linear* ee = pw->edge_encoder;
   const b3d_linear* ne = pw->node_encoder;
@@ -232,7 +229,13 @@ static int pack_forward(const b3d_pose_weights* pw, PoseWs& w, bool training, hi
   for (int i = 0; i < 2; ++i) d[n++] = pack_desc<EF>(3 + i, w.wp_efwd, mp.create_future_msgs[i].w, mp.create_future_msgs[i].b, kLinDims[LIN_FU0 + i].N, kLinDims[LIN_FU0 + i].K, false);
   for (int i = 0; i < 2; ++i) d[n++] = pack_desc<EF>(5 + i, w.wp_efwd, mp.create_past_msgs[i].w, mp.create_past_msgs[i].b, kLinDims[LIN_PA0 + i].N, kLinDims[LIN_PA0 + i].K, false);
   for (int i = 0; i < 3; ++i) d[n++] = pack_desc<D::NodeFwdSeq>(i, w.wp_nfwd, mp.combine_future_past[i].w, mp.combine_future_past[i].b, kLinDims[LIN_CF0 + i].N, kLinDims[LIN_CF0 + i].K, false);
+  if (knn) {                              // GATConv lin of the discarded k-NN block (consumed on the side stream)
+    d[n++] = pack_desc<LayerSeq<L<D::DX, D::DX>>>(0, w.knn.wp, pw->knn_conv.lin, nullptr, D::DX, D::DX, false);
+    w.knn.packed = true;
+  }
   if (training) {
+    d[n++] = fill_desc(w.iota, w.iota_n, true);       // identity gather + zero row of the streaming weight gradient
+    d[n++] = fill_desc(w.zrow, 256, false);
     // transposed images: image rows = forward inputs (K), image cols = forward outputs (N)
     auto T = [&](auto seq_tag, int li, float* base, const b3d_linear& l, int lin) {
       using S = decltype(seq_tag);
@@ -285,9 +288,7 @@ static int mp_weight_grads(PoseWs& w, const MpGradSrc& ms, int N, int E, const i
   (void)eLe; (void)nLx;
     WsLauncher wl;
     wl.begin(w.ws_table, 32, w.ws_task_job, kWsTaskCap, stream);
-    hipLaunchKernelGGL(iota_kernel, dim3(((E > N ? E : N) + 255) / 256), dim3(256), 0, stream, w.iota, E > N ? E : N);
-    B3D_TRY(launch_check("iota_kernel"));
-    B3D_HIP_CHECK(hipMemsetAsync(w.zrow, 0, 256 * sizeof(float), stream));
+    // w.iota / w.zrow were filled by the forward's pack launch
     const int* iota = w.iota;
     auto sg = [iota](const float* p, const int* idx, long vstride, int stride, int col0) {
       WsSeg s; s.ptr = p; s.idx = idx ? idx : iota; s.vstride = vstride; s.stride = stride; s.col0 = col0; return s;
@@ -399,7 +400,10 @@ extern "C" int b3d_pose_forward(const b3d_pose_weights* pw, const b3d_graph* g, 
   PoseWs w;
   carve(w, workspace, workspace_bytes, N, E, depth, flags);
   if (!w.ok) return fail(B3D_ERR_WORKSPACE, "b3d_pose_forward: workspace %zu < %zu bytes", workspace_bytes, w.bytes);
-  B3D_TRY(pack_forward(pw, w, tr, stream));
+  if (flags & B3D_FLAG_RUN_DEAD_KNN)
+    B3D_REQUIRE(pw->knn_conv.lin && pw->knn_conv.att_src && pw->knn_conv.att_dst && pw->knn_conv.bias,
+                "b3d_pose_forward: knn_conv pointers are required with B3D_FLAG_RUN_DEAD_KNN");
+  B3D_TRY(pack_forward(pw, w, tr, (flags & B3D_FLAG_RUN_DEAD_KNN) != 0, stream));
 
   {  // edge encoder: edge_attr.float() -> 4-8-16-32                      pose_gnn.py:67
     ChainFwdArgs<LoadEdgeAttrF64, StoreAligned<2>> a;
@@ -411,15 +415,14 @@ extern "C" int b3d_pose_forward(const b3d_pose_weights* pw, const b3d_graph* g, 
     B3D_TRY(launch_rows<kNWEdge>(chain_fwd_kernel<SeqEdgeEnc, 0x3u, LoadEdgeAttrF64, StoreAligned<2>, kNWEdge>, "edge_encoder", a, E, stream));
   }
   {  // node encoder 19-24-36-48 (initial_x == x == x_enc)                  pose_gnn.py:68-71
-    ChainFwdArgs<LoadUnaligned<19>, StoreAligned<3>> a;
+    ChainFwdArgs<LoadUnaligned<19>, StoreTwo<3>> a;
     memset(&a, 0, sizeof(a));
     a.rows = N; a.in.ptr = pose_feats;
-    a.out = StoreAligned<3>{w.x[0], nullptr, D::DX, 0};
+    a.out = StoreTwo<3>{w.x[0], out_x_enc, D::DX};       // layer-0 input and the returned x_enc (pose_gnn.py:86)
     a.save_in = w.pose_pad; a.save[0] = w.ne_a1; a.save[1] = w.ne_a2;
     a.wpack = w.wp_ne;
-    B3D_TRY(launch_rows<kNWNode>(chain_fwd_kernel<SeqNodeEnc, 0x3u, LoadUnaligned<19>, StoreAligned<3>, kNWNode>, "node_encoder", a, N, stream));
+    B3D_TRY(launch_rows<kNWNode>(chain_fwd_kernel<SeqNodeEnc, 0x3u, LoadUnaligned<19>, StoreTwo<3>, kNWNode>, "node_encoder", a, N, stream));
   }
-  B3D_HIP_CHECK(hipMemcpyAsync(out_x_enc, w.x[0], (size_t)N * D::DX * sizeof(float), hipMemcpyDeviceToDevice, stream));
 
   Side* knn_side = nullptr;
   for (int l = 0; l < depth; ++l) {
@@ -643,6 +646,8 @@ static int pack_layer(const b3d_mp_weights& mp, PoseWs& w, bool training, hipStr
   for (int i = 0; i < 2; ++i) d[n++] = pack_desc<EF>(5 + i, w.wp_efwd, mp.create_past_msgs[i].w, mp.create_past_msgs[i].b, kLinDims[LIN_PA0 + i].N, kLinDims[LIN_PA0 + i].K, false);
   for (int i = 0; i < 3; ++i) d[n++] = pack_desc<D::NodeFwdSeq>(i, w.wp_nfwd, mp.combine_future_past[i].w, mp.combine_future_past[i].b, kLinDims[LIN_CF0 + i].N, kLinDims[LIN_CF0 + i].K, false);
   if (training) {
+    d[n++] = fill_desc(w.iota, w.iota_n, true);
+    d[n++] = fill_desc(w.zrow, 256, false);
     auto T = [&](auto seq_tag, int li, float* base, const b3d_linear& l, int lin) {
       using S = decltype(seq_tag);
       d[n++] = pack_desc<S>(li, base, l.w, nullptr, kLinDims[lin].K, kLinDims[lin].N, true);

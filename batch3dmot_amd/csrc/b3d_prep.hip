@@ -161,6 +161,12 @@ namespace b3d {
 __global__ void pack_kernel(const PackArgs a) {
   // one workgroup column per descriptor (blockIdx.y), grid-stride over the image's floats
   const PackDesc& d = a.d[blockIdx.y];
+  if (d.transposed >= 2) {                      // index / zero fill
+    int* p = reinterpret_cast<int*>(d.dst);
+    for (int id = blockIdx.x * blockDim.x + threadIdx.x; id < d.N; id += gridDim.x * blockDim.x)
+      p[id] = (d.transposed == 2) ? id : 0;
+    return;
+  }
   const int stride = d.KP + 4;
   const int cr = chunk_rows(d.KP, d.NP);
   const int total = d.NP * stride;
@@ -192,7 +198,7 @@ int pack_images(const PackDesc* descs, int n, hipStream_t stream) {
     int maxtot = 0;
     for (int i = 0; i < a.n; ++i) {
       a.d[i] = descs[i0 + i];
-      const int t = a.d[i].NP * (a.d[i].KP + 4);
+      const int t = (a.d[i].transposed >= 2) ? a.d[i].N : a.d[i].NP * (a.d[i].KP + 4);
       if (t > maxtot) maxtot = t;
     }
     int gx = (maxtot + 255) / 256;

@@ -1,0 +1,28 @@
+"""Per-kernel means of rocprofv3 --pmc counters: python tools/pmc_summary.py DIR [DIR...]"""
+import csv, glob, sys, collections
+agg = collections.defaultdict(lambda: collections.defaultdict(float))
+cnt = collections.defaultdict(lambda: collections.Counter())
+dur = collections.defaultdict(list)
+for d in sys.argv[1:]:
+    for f in glob.glob(d + '/*/*counter_collection.csv'):
+        for r in csv.DictReader(open(f)):
+            n = r['Kernel_Name'].replace('b3d::', '').replace('MPDims<48, 32, 0, 96, 64, 96, 64, 96, 64>', 'P').split('(')[0][:60]
+            agg[n][r['Counter_Name']] += float(r['Counter_Value'])
+            cnt[n][r['Counter_Name']] += 1
+            if 'Start_Timestamp' in r and r['Counter_Name'] == 'GRBM_GUI_ACTIVE':
+                dur[n].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+names = sorted(agg, key=lambda n: -sum(agg[n].values()))
+for n in names[:16]:
+    c = agg[n]
+    parts = [f"{k}={c[k] / cnt[n][k]:.4g}" for k in sorted(c)]
+    extra = ""
+    if dur[n] and 'GRBM_GUI_ACTIVE' in c:
+        us = sum(dur[n]) / len(dur[n]) / 1e3
+        clk = c['GRBM_GUI_ACTIVE'] / cnt[n]['GRBM_GUI_ACTIVE'] / 8 / (us * 1e-6) / 1e9
+        extra = f"  | avg {us:.1f} us, effective clock {clk:.2f} GHz"
+        if 'SQ_VALU_MFMA_BUSY_CYCLES' in c:
+            # MFMA busy cycles are summed over all SIMDs of the chip (256 CU x 4)
+            busy = c['SQ_VALU_MFMA_BUSY_CYCLES'] / cnt[n]['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024
+            act = c['GRBM_GUI_ACTIVE'] / cnt[n]['GRBM_GUI_ACTIVE'] / 8
+            extra += f", MFMA pipe busy {100 * busy / act:.0f}% of active cycles"
+    print(f"{n} (x{max(cnt[n].values())})\n    " + "  ".join(parts) + extra)
