@@ -306,7 +306,7 @@ static int wide(const char* name, const In& in, long rows, float* out, int ostri
                 const float* wp, hipStream_t stream) {
   WideArgs<In> a;
   a.rows = (int)rows; a.in = in; a.out = out; a.out_stride = ostride; a.out_col0 = ocol0; a.mask = mask; a.wpack = wp;
-  return launch_rows<kNWEdge>(wide_linear_kernel<Seq, RELU, BIAS, In, kNWEdge>, name, a, rows, stream);
+  return launch_rows<kNWEdge>(wide_linear_kernel<Seq, RELU, BIAS, In, kNWEdge>, name, a, rows, stream, B3D_K_OTHER, chain_lds<Seq>());
 }
 
 // One modality's out_proj(v_proj(x)) on all nodes: x = xsens[:, xc : xc+DD] -> s[:, sc : sc+DD]
@@ -319,7 +319,7 @@ static int affine_fwd(Ws& w, int m, int N, int xc, int sc, hipStream_t stream) {
   a.rows = N; a.in = In{w.xsens, nullptr, XS, xc}; a.out = Out{w.s, nullptr, XS, sc};
   a.save[0] = w.aff_v[m];
   a.wpack = w.wp_aff[m];
-  return launch_rows<kNWNode>(chain_fwd_kernel<SeqAff<DD>, 0u, In, Out, kNWNode>, "modality_affine", a, N, stream);
+  return launch_rows<kNWNode>(chain_fwd_kernel<SeqAff<DD>, 0u, In, Out, kNWNode>, "modality_affine", a, N, stream, B3D_K_OTHER, chain_lds<SeqAff<DD>>());
 }
 
 // backward of one modality: G_out = segment sums of d s_i / d s_j columns; d x_m -> dxs[:, xc : xc+DD]
@@ -335,7 +335,7 @@ static int affine_bwd(Ws& w, const b3d_graph* g, int m, int N, int xc, int sc, h
   a.gtop = w.gaff_top[m];
   a.gsave[0] = w.gaff_v[m];
   a.wpack = w.wp_affT[m];
-  return launch_rows<kNWNode>(chain_bwd_kernel<SeqAffT<DD>, In, Out, kNWNode>, "modality_affine_bwd", a, N, stream);
+  return launch_rows<kNWNode>(chain_bwd_kernel<SeqAffT<DD>, In, Out, kNWNode>, "modality_affine_bwd", a, N, stream, B3D_K_OTHER, chain_lds<SeqAffT<DD>>());
 }
 
 }  // namespace clr
@@ -398,7 +398,7 @@ extern "C" int b3d_clr_forward(const b3d_clr_weights* pw, const b3d_graph* g, co
     memset(&a, 0, sizeof(a));
     a.rows = nl; a.in = In{in->pointnet_out, nullptr, 256, 0}; a.out = Out{w.xsens, in->lidar_nodes, XS, 96};
     a.save[0] = w.fl_a1; a.wpack = w.wp_fl;
-    B3D_TRY(launch_rows<kNWNode>(chain_fwd_kernel<SeqFL, 0x1u, In, Out, kNWNode>, "fc_lidar_encoder", a, nl, stream));
+    B3D_TRY(launch_rows<kNWNode>(chain_fwd_kernel<SeqFL, 0x1u, In, Out, kNWNode>, "fc_lidar_encoder", a, nl, stream, B3D_K_OTHER, chain_lds<SeqFL>()));
   }
   if (nr > 0) {  // fc_radar_encoder 256-192-128-64
     using In = LoadAligned<16>;
@@ -407,7 +407,7 @@ extern "C" int b3d_clr_forward(const b3d_clr_weights* pw, const b3d_graph* g, co
     memset(&a, 0, sizeof(a));
     a.rows = nr; a.in = In{in->radarnet_out, nullptr, 256, 0}; a.out = Out{w.xsens, in->radar_nodes, XS, 224};
     a.save[0] = w.fr_a1; a.save[1] = w.fr_a2; a.wpack = w.wp_fr;
-    B3D_TRY(launch_rows<kNWNode>(chain_fwd_kernel<SeqFR, 0x3u, In, Out, kNWNode>, "fc_radar_encoder", a, nr, stream));
+    B3D_TRY(launch_rows<kNWNode>(chain_fwd_kernel<SeqFR, 0x3u, In, Out, kNWNode>, "fc_radar_encoder", a, nr, stream, B3D_K_OTHER, chain_lds<SeqFR>()));
   }
   B3D_HIP_CHECK(hipMemcpyAsync(out_x_sens, w.xsens, (size_t)N * XS * sizeof(float), hipMemcpyDeviceToDevice, stream));
 
@@ -421,7 +421,7 @@ extern "C" int b3d_clr_forward(const b3d_clr_weights* pw, const b3d_graph* g, co
     memset(&a, 0, sizeof(a));
     a.rows = E; a.in.ptr = in->edge_attr; a.out = StoreAligned<4>{w.e[0], nullptr, D::DE, 0};
     a.save_in = w.ea_pad; a.save[0] = w.ee_a1; a.save[1] = w.ee_a2; a.wpack = w.wp_ee;
-    B3D_TRY(launch_rows<kNWEdge>(chain_fwd_kernel<SeqEE, 0x3u, LoadEdgeAttrF64, StoreAligned<4>, kNWEdge>, "edge_encoder", a, E, stream));
+    B3D_TRY(launch_rows<kNWEdge>(chain_fwd_kernel<SeqEE, 0x3u, LoadEdgeAttrF64, StoreAligned<4>, kNWEdge>, "edge_encoder", a, E, stream, B3D_K_OTHER, chain_lds<SeqEE>()));
   }
   {  // att_edge_encoder( s[dst] | s[src] | e ) 640-512-384-256-128-64 (:161-164)
     using In0 = LoadConcat3<18, 18, 4>;
@@ -437,7 +437,7 @@ extern "C" int b3d_clr_forward(const b3d_clr_weights* pw, const b3d_graph* g, co
     memset(&a, 0, sizeof(a));
     a.rows = N; a.in.ptr = in->pose_feats; a.out = StoreAligned<6>{w.x[0], nullptr, D::DX, 0};
     a.save_in = w.pose_pad; a.save[0] = w.ne_a1; a.wpack = w.wp_ne;
-    B3D_TRY(launch_rows<kNWNode>(chain_fwd_kernel<SeqNE, 0x1u, LoadUnaligned<19>, StoreAligned<6>, kNWNode>, "node_encoder", a, N, stream));
+    B3D_TRY(launch_rows<kNWNode>(chain_fwd_kernel<SeqNE, 0x1u, LoadUnaligned<19>, StoreAligned<6>, kNWNode>, "node_encoder", a, N, stream, B3D_K_OTHER, chain_lds<SeqNE>()));
   }
   Side* knn_side = nullptr;
   for (int l = 0; l < depth; ++l) {
@@ -469,7 +469,7 @@ extern "C" int b3d_clr_forward(const b3d_clr_weights* pw, const b3d_graph* g, co
     memset(&a, 0, sizeof(a));
     a.rows = E; a.in = LoadAligned<4>{w.e[depth], nullptr, D::DE, 0}; a.out = StoreScalar{w.prob, 1};
     a.save[0] = w.c_a1; a.save[1] = w.c_a2; a.save[2] = w.c_a3; a.wpack = w.wp_cls;
-    B3D_TRY(launch_rows<kNWEdge>(chain_fwd_kernel<SeqCls, 0x7u, LoadAligned<4>, StoreScalar, kNWEdge>, "edge_classifier", a, E, stream));
+    B3D_TRY(launch_rows<kNWEdge>(chain_fwd_kernel<SeqCls, 0x7u, LoadAligned<4>, StoreScalar, kNWEdge>, "edge_classifier", a, E, stream, B3D_K_OTHER, chain_lds<SeqCls>()));
     B3D_HIP_CHECK(hipMemcpyAsync(out_prob, w.prob, (size_t)E * sizeof(float), hipMemcpyDeviceToDevice, stream));
   }
   if (knn_side) B3D_TRY(side_join(knn_side, stream));
@@ -505,7 +505,7 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
     a.act[0] = w.c_a3; a.act[1] = w.c_a2; a.act[2] = w.c_a1; a.act[3] = nullptr;
     a.gsave[0] = w.gc3; a.gsave[1] = w.gc2; a.gsave[2] = w.gc1; a.gsave[3] = nullptr;
     a.wpack = w.wp_clsT;
-    B3D_TRY(launch_rows<kNWEdge>(chain_bwd_kernel<SeqClsT, LoadSigmoidGrad, StoreAligned<4>, kNWEdge>, "edge_classifier_bwd", a, E, stream));
+    B3D_TRY(launch_rows<kNWEdge>(chain_bwd_kernel<SeqClsT, LoadSigmoidGrad, StoreAligned<4>, kNWEdge>, "edge_classifier_bwd", a, E, stream, B3D_K_OTHER, chain_lds<SeqClsT>()));
     WgJob j3 = make_job(w.lin[C3], E, seg(w.gc_top, nullptr, 16, 0, 1)); add_act(j3, seg(w.c_a3, nullptr, 16, 0, 8)); smallE.jobs[smallE.njobs++] = j3;
     WgJob j2 = make_job(w.lin[C2], E, seg(w.gc3, nullptr, 16, 0, 8)); add_act(j2, seg(w.c_a2, nullptr, 16, 0, 16)); smallE.jobs[smallE.njobs++] = j2;
     WgJob j1 = make_job(w.lin[C1], E, seg(w.gc2, nullptr, 16, 0, 16)); add_act(j1, seg(w.c_a1, nullptr, 32, 0, 32)); smallE.jobs[smallE.njobs++] = j1;
@@ -576,7 +576,7 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
     memset(&a, 0, sizeof(a));
     a.rows = nl; a.in = In{w.dxs, XS, 96, d_x_sens, XS, 96, in->lidar_nodes};
     a.gtop = w.gfl_top; a.act[0] = w.fl_a1; a.gsave[0] = w.gfl1; a.wpack = w.wp_flT;
-    B3D_TRY(launch_rows<kNWNode>(chain_bwd_kernel<SeqFLT, In, StoreNone, kNWNode>, "fc_lidar_encoder_bwd", a, nl, stream));
+    B3D_TRY(launch_rows<kNWNode>(chain_bwd_kernel<SeqFLT, In, StoreNone, kNWNode>, "fc_lidar_encoder_bwd", a, nl, stream, B3D_K_OTHER, chain_lds<SeqFLT>()));
     WgJob j1 = make_job(w.lin[FL1], nl, seg(w.gfl_top, nullptr, 128, 0, 128)); add_act(j1, seg(w.fl_a1, nullptr, 192, 0, 192)); fc.jobs[fc.njobs++] = j1;
     WgJob j0 = make_job(w.lin[FL0], nl, seg(w.gfl1, nullptr, 192, 0, 192)); add_act(j0, seg(in->pointnet_out, nullptr, 256, 0, 256)); fc.jobs[fc.njobs++] = j0;
   }
@@ -586,7 +586,7 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
     memset(&a, 0, sizeof(a));
     a.rows = nr; a.in = In{w.dxs, XS, 224, d_x_sens, XS, 224, in->radar_nodes};
     a.gtop = w.gfr_top; a.act[0] = w.fr_a2; a.act[1] = w.fr_a1; a.gsave[0] = w.gfr2; a.gsave[1] = w.gfr1; a.wpack = w.wp_frT;
-    B3D_TRY(launch_rows<kNWNode>(chain_bwd_kernel<SeqFRT, In, StoreNone, kNWNode>, "fc_radar_encoder_bwd", a, nr, stream));
+    B3D_TRY(launch_rows<kNWNode>(chain_bwd_kernel<SeqFRT, In, StoreNone, kNWNode>, "fc_radar_encoder_bwd", a, nr, stream, B3D_K_OTHER, chain_lds<SeqFRT>()));
     WgJob j2 = make_job(w.lin[FR2], nr, seg(w.gfr_top, nullptr, 64, 0, 64)); add_act(j2, seg(w.fr_a2, nullptr, 128, 0, 128)); fc.jobs[fc.njobs++] = j2;
     WgJob j1 = make_job(w.lin[FR1], nr, seg(w.gfr2, nullptr, 128, 0, 128)); add_act(j1, seg(w.fr_a1, nullptr, 192, 0, 192)); fc.jobs[fc.njobs++] = j1;
     WgJob j0 = make_job(w.lin[FR0], nr, seg(w.gfr1, nullptr, 192, 0, 192)); add_act(j0, seg(in->radarnet_out, nullptr, 256, 0, 256)); fc.jobs[fc.njobs++] = j0;
@@ -600,7 +600,7 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
     a.rows = N;
     a.in = In{nullptr, dx0_first ? nullptr : w.dx0_acc, w.gdst, w.gsrc, g->dst_ptr, g->dst_perm, g->src_ptr, g->src_perm};
     a.gtop = w.gn_top; a.act[0] = w.ne_a1; a.gsave[0] = w.gn1; a.wpack = w.wp_neT;
-    B3D_TRY(launch_rows<kNWNode>(chain_bwd_kernel<SeqNET, In, StoreNone, kNWNode>, "node_encoder_bwd", a, N, stream));
+    B3D_TRY(launch_rows<kNWNode>(chain_bwd_kernel<SeqNET, In, StoreNone, kNWNode>, "node_encoder_bwd", a, N, stream, B3D_K_OTHER, chain_lds<SeqNET>()));
     WgJob n1 = make_job(w.lin[NE1], N, seg(w.gn_top, nullptr, 96, 0, 96)); add_act(n1, seg(w.ne_a1, nullptr, 48, 0, 48)); smallN.jobs[smallN.njobs++] = n1;
     WgJob n0 = make_job(w.lin[NE0], N, seg(w.gn1, nullptr, 48, 0, 48)); add_act(n0, seg(w.pose_pad, nullptr, 32, 0, 19)); smallN.jobs[smallN.njobs++] = n0;
   }
@@ -610,7 +610,7 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
     memset(&a, 0, sizeof(a));
     a.rows = E; a.in = In{w.de[cur], D::DE, 0, w.dIn, 640, 576, nullptr};
     a.gtop = w.ge_top; a.act[0] = w.ee_a2; a.act[1] = w.ee_a1; a.gsave[0] = w.ge2; a.gsave[1] = w.ge1; a.wpack = w.wp_eeT;
-    B3D_TRY(launch_rows<kNWEdge>(chain_bwd_kernel<SeqEET, In, StoreNone, kNWEdge>, "edge_encoder_bwd", a, E, stream));
+    B3D_TRY(launch_rows<kNWEdge>(chain_bwd_kernel<SeqEET, In, StoreNone, kNWEdge>, "edge_encoder_bwd", a, E, stream, B3D_K_OTHER, chain_lds<SeqEET>()));
     WgJob e2 = make_job(w.lin[EE2], E, seg(w.ge_top, nullptr, 64, 0, 64)); add_act(e2, seg(w.ee_a2, nullptr, 32, 0, 32)); smallE.jobs[smallE.njobs++] = e2;
     WgJob e1 = make_job(w.lin[EE1], E, seg(w.ge2, nullptr, 32, 0, 32)); add_act(e1, seg(w.ee_a1, nullptr, 16, 0, 16)); smallE.jobs[smallE.njobs++] = e1;
     WgJob e0 = make_job(w.lin[EE0], E, seg(w.ge1, nullptr, 16, 0, 16)); add_act(e0, seg(w.ea_pad, nullptr, 16, 0, 4)); smallE.jobs[smallE.njobs++] = e0;

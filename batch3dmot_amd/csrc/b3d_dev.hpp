@@ -102,6 +102,14 @@ struct LayerSeq {
     int li = chunk_layer(ci);
     return chunk_floats(kp(li), chunk_nrows(kp(li), np(li), ci - first_chunk(li)));
   }
+  __host__ __device__ static constexpr int max_chunk() {           // floats of the largest chunk
+    int m = 0;
+    for (int ci = 0; ci < NCH; ++ci) m = chunk_size(ci) > m ? chunk_size(ci) : m;
+    return m;
+  }
+  // ring slot size for kernels that size their LDS by the sequence (narrow stacks); the message-passing
+  // kernels use the full kWBufFloats
+  static constexpr int SLOT = max_chunk();
 };
 
 // ---- weight stream: global -> LDS, two slots ----------------------------------------------
@@ -109,13 +117,13 @@ struct LayerSeq {
 #define B3D_USE_LDS_DMA 1
 #endif
 
-template <int NT>
+template <int NT, int SLOT = kWBufFloats>
 struct WStreamT {
   const float* g;      // packed images of this kernel (global)
-  float* lds;          // 2 * kWBufFloats
+  float* lds;          // 2 * SLOT floats
   int slot;            // slot that the NEXT acquire returns
 #if !B3D_USE_LDS_DMA
-  v4f pre[(kWBufFloats / 4 + NT - 1) / NT];
+  v4f pre[(SLOT / 4 + NT - 1) / NT];
 #endif
 
   __device__ __forceinline__ void init(const float* gw, float* l) { g = gw; lds = l; slot = 0; }
@@ -124,11 +132,11 @@ struct WStreamT {
   __device__ __forceinline__ void issue(int to_slot) {
     constexpr int off = Seq::chunk_off(CI);
     constexpr int n4 = Seq::chunk_size(CI) / 4;          // multiple of 64
-    static_assert(Seq::chunk_size(CI) <= kWBufFloats, "chunk larger than a ring slot");
+    static_assert(Seq::chunk_size(CI) <= SLOT, "chunk larger than a ring slot");
 #if B3D_USE_LDS_DMA
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float* src = g + off;
-    float* dst = lds + to_slot * kWBufFloats;
+    float* dst = lds + to_slot * SLOT;
 #pragma unroll
     for (int i0 = 0; i0 < n4; i0 += NT) {
       const int base = i0 + wave * 64;                   // wave-uniform
@@ -165,7 +173,7 @@ struct WStreamT {
 #else
     {
       constexpr int n4 = Seq::chunk_size(CI) / 4;
-      float* dst = lds + slot * kWBufFloats;
+      float* dst = lds + slot * SLOT;
 #pragma unroll
       for (int j = 0; j < (n4 + NT - 1) / NT; ++j) {
         const int i = j * NT + threadIdx.x;
@@ -175,7 +183,7 @@ struct WStreamT {
     __syncthreads();
     if (NXT != 0 || more) issue<Seq, NXT>(slot ^ 1);
 #endif
-    const float* cur = lds + slot * kWBufFloats;
+    const float* cur = lds + slot * SLOT;
     slot ^= 1;
     return cur;
   }

@@ -373,7 +373,7 @@ inline int knn_gat_block(KnnWs& ws, const float* x, const int64_t* ts, int N, co
     a.in = LoadAligned<D / 16>{x, nullptr, D, 0};
     a.out = StoreAligned<D / 16>{ws.h, nullptr, D, 0};
     a.wpack = ws.wp;
-    B3D_TRY(launch_rows<kNWNode>(chain_fwd_kernel<S, 0u, LoadAligned<D / 16>, StoreAligned<D / 16>, kNWNode>, "gat_linear", a, N, stream));
+    B3D_TRY(launch_rows<kNWNode>(chain_fwd_kernel<S, 0u, LoadAligned<D / 16>, StoreAligned<D / 16>, kNWNode>, "gat_linear", a, N, stream, B3D_K_OTHER, chain_lds<S>()));
   }
   hipLaunchKernelGGL(gat_aggregate_kernel<D>, dim3((N + 3) / 4), dim3(256), 0, stream, ws.h, N, ws.nbr, ws.cnt, gat.att_src, gat.att_dst, gat.bias, ws.y);
   return launch_check("gat_aggregate_kernel");

@@ -24,13 +24,17 @@ inline int set_lds(K kernel, int bytes) {
 // use 8; node-sized inputs (a few thousand rows) use 1 so the launch still covers ~200 CUs.
 template <int NW, class Kern, class Args>
 inline int launch_rows(Kern kernel, const char* name, const Args& a, long rows, hipStream_t stream,
-                       int family = B3D_K_OTHER) {
+                       int family = B3D_K_OTHER, int lds_bytes = kLdsBytes) {
   if (rows <= 0) return B3D_OK;
-  B3D_TRY(set_lds(kernel, kLdsBytes));
+  B3D_TRY(set_lds(kernel, lds_bytes));
   ProfScope ps(family, stream);
-  hipLaunchKernelGGL(kernel, dim3(grid_for_tiles(rows, NW * 16)), dim3(NW * 64), kLdsBytes, stream, a);
+  hipLaunchKernelGGL(kernel, dim3(grid_for_tiles(rows, NW * 16)), dim3(NW * 64), lds_bytes, stream, a);
   return launch_check(name);
 }
+// LDS of the chain / wide-linear kernels: two ring slots of the sequence's largest chunk (a 48x48 layer
+// needs 20 KB, not the 104 KB of the message-passing kernels -- it must not evict them from a CU).
+template <class Seq>
+constexpr int chain_lds() { return 2 * Seq::SLOT * 4; }
 constexpr int kNWEdge = 8, kNWNode = 1;
 
 // Node phase of a message-passing layer: 4 wavefronts per 16-row tile (b3d_node.hpp).

@@ -412,7 +412,7 @@ extern "C" int b3d_pose_forward(const b3d_pose_weights* pw, const b3d_graph* g, 
     a.out = StoreAligned<2>{w.e[0], nullptr, D::DE, 0};
     a.save_in = w.ea_pad; a.save[0] = w.ee_a1; a.save[1] = w.ee_a2;
     a.wpack = w.wp_ee;
-    B3D_TRY(launch_rows<kNWEdge>(chain_fwd_kernel<SeqEdgeEnc, 0x3u, LoadEdgeAttrF64, StoreAligned<2>, kNWEdge>, "edge_encoder", a, E, stream));
+    B3D_TRY(launch_rows<kNWEdge>(chain_fwd_kernel<SeqEdgeEnc, 0x3u, LoadEdgeAttrF64, StoreAligned<2>, kNWEdge>, "edge_encoder", a, E, stream, B3D_K_OTHER, chain_lds<SeqEdgeEnc>()));
   }
   {  // node encoder 19-24-36-48 (initial_x == x == x_enc)                  pose_gnn.py:68-71
     ChainFwdArgs<LoadUnaligned<19>, StoreTwo<3>> a;
@@ -421,7 +421,7 @@ extern "C" int b3d_pose_forward(const b3d_pose_weights* pw, const b3d_graph* g, 
     a.out = StoreTwo<3>{w.x[0], out_x_enc, D::DX};       // layer-0 input and the returned x_enc (pose_gnn.py:86)
     a.save_in = w.pose_pad; a.save[0] = w.ne_a1; a.save[1] = w.ne_a2;
     a.wpack = w.wp_ne;
-    B3D_TRY(launch_rows<kNWNode>(chain_fwd_kernel<SeqNodeEnc, 0x3u, LoadUnaligned<19>, StoreTwo<3>, kNWNode>, "node_encoder", a, N, stream));
+    B3D_TRY(launch_rows<kNWNode>(chain_fwd_kernel<SeqNodeEnc, 0x3u, LoadUnaligned<19>, StoreTwo<3>, kNWNode>, "node_encoder", a, N, stream, B3D_K_OTHER, chain_lds<SeqNodeEnc>()));
   }
 
   Side* knn_side = nullptr;
@@ -459,7 +459,7 @@ extern "C" int b3d_pose_forward(const b3d_pose_weights* pw, const b3d_graph* g, 
     a.out = StoreScalar{out_logits, 0};
     a.save[0] = w.c_a1; a.save[1] = w.c_a2; a.save[2] = w.c_a3;
     a.wpack = w.wp_cls;
-    B3D_TRY(launch_rows<kNWEdge>(chain_fwd_kernel<SeqCls, 0x7u, LoadAligned<2>, StoreScalar, kNWEdge>, "edge_classifier", a, E, stream));
+    B3D_TRY(launch_rows<kNWEdge>(chain_fwd_kernel<SeqCls, 0x7u, LoadAligned<2>, StoreScalar, kNWEdge>, "edge_classifier", a, E, stream, B3D_K_OTHER, chain_lds<SeqCls>()));
   }
   if (knn_side) B3D_TRY(side_join(knn_side, stream));
   return B3D_OK;
@@ -496,7 +496,7 @@ extern "C" int b3d_pose_backward(const b3d_pose_weights* pw, const b3d_graph* g,
     a.gsave[0] = w.gc3; a.gsave[1] = w.gc2; a.gsave[2] = w.gc1; a.gsave[3] = nullptr;
     a.gtop = w.gc_top;                       // d_logits padded to 16 columns: G of edge_classifier.6
     a.wpack = w.wp_clsT;
-    B3D_TRY(launch_rows<kNWEdge>(chain_bwd_kernel<SeqClsT, LoadScalar, StoreAligned<2>, kNWEdge>, "edge_classifier_bwd", a, E, stream));
+    B3D_TRY(launch_rows<kNWEdge>(chain_bwd_kernel<SeqClsT, LoadScalar, StoreAligned<2>, kNWEdge>, "edge_classifier_bwd", a, E, stream, B3D_K_OTHER, chain_lds<SeqClsT>()));
   }
 
   // ---- message-passing layers, last to first: data gradients only; the G tensors of every layer
@@ -547,7 +547,7 @@ extern "C" int b3d_pose_backward(const b3d_pose_weights* pw, const b3d_graph* g,
     a.act[0] = w.ne_a2; a.act[1] = w.ne_a1;
     a.gsave[0] = w.gn2; a.gsave[1] = w.gn1;
     a.wpack = w.wp_neT;
-    B3D_TRY(launch_rows<kNWNode>(chain_bwd_kernel<SeqNodeEncT, In, StoreNone, kNWNode>, "node_encoder_bwd", a, N, stream));
+    B3D_TRY(launch_rows<kNWNode>(chain_bwd_kernel<SeqNodeEncT, In, StoreNone, kNWNode>, "node_encoder_bwd", a, N, stream, B3D_K_OTHER, chain_lds<SeqNodeEncT>()));
   }
   {  // edge encoder: G_3 = d e[0]
     ChainBwdArgs<LoadAligned<2>, StoreNone> a;
@@ -557,7 +557,7 @@ extern "C" int b3d_pose_backward(const b3d_pose_weights* pw, const b3d_graph* g,
     a.act[0] = w.ee_a2; a.act[1] = w.ee_a1;
     a.gsave[0] = w.ge2; a.gsave[1] = w.ge1;
     a.wpack = w.wp_eeT;
-    B3D_TRY(launch_rows<kNWEdge>(chain_bwd_kernel<SeqEdgeEncT, LoadAligned<2>, StoreNone, kNWEdge>, "edge_encoder_bwd", a, E, stream));
+    B3D_TRY(launch_rows<kNWEdge>(chain_bwd_kernel<SeqEdgeEncT, LoadAligned<2>, StoreNone, kNWEdge>, "edge_encoder_bwd", a, E, stream, B3D_K_OTHER, chain_lds<SeqEdgeEncT>()));
   }
 
   // ---- message-passing weight gradients: all layers, one streaming launch ---------------------
