@@ -212,7 +212,8 @@ __device__ __forceinline__ v4f relu4(v4f a) {
 struct NoHook { __device__ __forceinline__ void operator()() const {} };
 
 template <class Seq, int LI, bool RELU, bool BIAS, int CH, class WS, class Emit, class Hook>
-__device__ __forceinline__ void linear_chunk(WS& ws, bool more, const v4f* __restrict__ in, Emit& emit, Hook& hook) {
+__device__ __forceinline__ void linear_chunk(WS& ws, bool more, const v4f* __restrict__ in, Emit& emit, Hook& hook,
+                                             const v4f* init = nullptr) {
   constexpr int KP = Seq::kp(LI), NP = Seq::np(LI);
   constexpr int KB = KP / 16, NB = NP / 16;
   constexpr int STRIDE = KP + 4;
@@ -250,6 +251,10 @@ __device__ __forceinline__ void linear_chunk(WS& ws, bool more, const v4f* __res
     const int mb = mb0 + 2 * pr;
     const bool two = (mb + 1 < mbn);
     v4f acc0 = nb0, acc1 = nb1;
+    if (init) {                                  // accumulators start from a caller-provided partial result
+      acc0 += init[mb];
+      if (two) acc1 += init[mb + 1];
+    }
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
       v4f na0 = zero4, na1 = zero4;
@@ -279,8 +284,8 @@ __device__ __forceinline__ void linear_chunk(WS& ws, bool more, const v4f* __res
 
 template <class Seq, int LI, bool RELU, bool BIAS, class WS, class Emit, class Hook, int... CH>
 __device__ __forceinline__ void linear_impl(WS& ws, bool more, const v4f* __restrict__ in, Emit& emit, Hook& hook,
-                                            std::integer_sequence<int, CH...>) {
-  (linear_chunk<Seq, LI, RELU, BIAS, CH, WS, Emit, Hook>(ws, more, in, emit, hook), ...);
+                                            std::integer_sequence<int, CH...>, const v4f* init = nullptr) {
+  (linear_chunk<Seq, LI, RELU, BIAS, CH, WS, Emit, Hook>(ws, more, in, emit, hook, init), ...);
 }
 
 template <class Seq, int LI, bool RELU, bool BIAS = true, class WS, class Emit, class Hook = NoHook>
@@ -293,6 +298,16 @@ template <class Seq, int LI, bool RELU, bool BIAS = true, class WS, class Hook =
 __device__ __forceinline__ void linear(WS& ws, bool more, const v4f* __restrict__ in, v4f* __restrict__ out,
                                        Hook hook = Hook{}) {
   linear_emit<Seq, LI, RELU, BIAS>(ws, more, in, [out](int mb, v4f v) { out[mb] = v; }, hook);
+}
+
+// out = act(W . in (+ b) + init): the accumulators start from `init` (e.g. the per-node part of a
+// Linear over a concatenation, gathered per edge).  out may alias init.
+template <class Seq, int LI, bool RELU, bool BIAS, class WS, class Hook = NoHook>
+__device__ __forceinline__ void linear_init(WS& ws, bool more, const v4f* __restrict__ in, const v4f* init, v4f* out,
+                                            Hook hook = Hook{}) {
+  auto emit = [out](int mb, v4f v) { out[mb] = v; };
+  linear_impl<Seq, LI, RELU, BIAS, WS, decltype(emit), Hook>(ws, more, in, emit, hook,
+                                                             std::make_integer_sequence<int, n_chunks(Seq::kp(LI), Seq::np(LI))>{}, init);
 }
 
 // ---- row <-> register helpers (layout L) -----------------------------------------------------

@@ -1,0 +1,185 @@
+// Hoisted first layers of the three edge stacks.
+//
+// Every stack of CausalMessagePassing starts with a Linear over a CONCATENATION of gathered node rows
+// and the edge row (pose_gnn.py:205-226):
+//     edge_update.0        ( x[dst] | x[src] | e  )
+//     create_future_msgs.0 ( x[dst] | e' | x0[dst] )
+//     create_past_msgs.0   ( x[src] | e' | x0[src] )
+// W . (u | v | w) = W_u u + W_v v + W_w w, and the node parts depend on the NODE only.  They are
+// evaluated once per node (N = 3,000 rows) instead of once per edge (E = 30,000 rows):
+//     T[n] = ( W_eu[:, x_i] x[n] + b_eu | W_eu[:, x_j] x[n] | W_fu[:, x] x[n] + W_fu[:, x0] x0[n] + b_fu |
+//              W_pa[:, x] x[n] + W_pa[:, x0] x0[n] + b_pa )                       [N, 2 EH1 + 2 MH]
+// and the edge kernel starts its accumulators from the gathered rows T[dst] / T[src] and multiplies
+// only the 32 edge columns.  Per edge and layer 29,696 MAC instead of 57,344; the same split runs
+// through the data gradient (per-node segment sums of the first-layer gradients, then one per-node
+// product with the transposed node columns) and the weight gradient (node columns contract over
+// nodes).  The x0 terms are layer-invariant and computed once per forward.  Summation order differs
+// from the unsplit Linear by fp32 rounding only.
+#pragma once
+#include "b3d_mp.hpp"
+#include "b3d_node.hpp"
+#include "b3d_chain.hpp"
+
+namespace b3d {
+
+template <class D>
+struct Hoist {
+  static constexpr int TW = 2 * D::EH1 + 2 * D::MH;        // width of the per-node table
+  static constexpr int OA = 0, OB = D::EH1, OF = 2 * D::EH1, OP = 2 * D::EH1 + D::MH;
+  static constexpr int KE = D::DE + D::DA;                  // per-edge input columns of edge_update.0
+  using ProjSeq = LayerSeq<L<D::DX, TW>>;                   // x[l]  -> T (without the x0 terms)
+  using Proj0Seq = LayerSeq<L<D::DX, 2 * D::MH>>;           // x0    -> x0 terms of the F | P columns
+  using EdgeFwdSeq = LayerSeq<L<KE, D::EH1>, L<D::EH1, D::EH2>, L<D::EH2, D::DE>,     // edge_update (.0: edge columns)
+                              L<D::DE, D::MH>, L<D::MH, D::DM>,                       // create_future_msgs
+                              L<D::DE, D::MH>, L<D::MH, D::DM>>;                      // create_past_msgs
+  // transposed images, data-gradient order; the .0 layers keep their edge columns only
+  using EdgeBwdSeq = LayerSeq<L<D::DM, D::MH>, L<D::MH, D::DE>,                       // past.2^T, past.0[e']^T
+                              L<D::DM, D::MH>, L<D::MH, D::DE>,                       // future.2^T, future.0[e']^T
+                              L<D::DE, D::EH2>, L<D::EH2, D::EH1>, L<D::EH1, KE>>;    // edge_update.4^T/.2^T/.0[e]^T
+  using EdgeBwdSeqNoMsg = LayerSeq<L<D::DE, D::EH2>, L<D::EH2, D::EH1>, L<D::EH1, KE>>;
+  // per-node gradient of (x | x0) from the gradient of T: [W_eu_i^T | W_eu_j^T | W_fu_x^T | W_pa_x^T ; 0 | 0 | W_fu_x0^T | W_pa_x0^T]
+  using GradProjSeq = LayerSeq<L<TW, 2 * D::DX>>;
+};
+
+// Storer of the projection chain: the F | P columns receive the layer-invariant x0 terms.
+template <class D>
+struct StoreProj {
+  using H = Hoist<D>;
+  static constexpr int NB = H::TW / 16;
+  float* T;            // [rows, TW]
+  const float* T0;     // [rows, 2 MH]
+  __device__ __forceinline__ void operator()(long row, bool valid, const v4f* src) const {
+    constexpr int FB = H::OF / 16;
+    v4f t0[NB - FB];
+    load_row<NB - FB>(T0, row, 2 * D::MH, 0, valid, t0);
+    store_row<FB>(T, row, H::TW, 0, valid, src);
+    v4f out[NB - FB];
+#pragma unroll
+    for (int b = 0; b < NB - FB; ++b) out[b] = src[FB + b] + t0[b];
+    store_row<NB - FB>(T, row, H::TW, H::OF, valid, out);
+  }
+};
+
+struct EdgeFwdHArgs {
+  int E;
+  const int* src;
+  const int* dst;
+  const float* T;      // [N, TW] per-node parts of the three first layers (this layer's x)
+  const float* e_in;   // [E, DE]
+  const float* a_in;   // [E, DA] or nullptr
+  float* e_out;
+  float* fut;
+  float* past;
+  float* sH1;
+  float* sH2;
+  float* sF1;
+  float* sP1;
+  const float* wpack;  // Hoist::EdgeFwdSeq images
+};
+
+template <class D, int NW>
+__global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void mp_edge_fwd_h_kernel(const EdgeFwdHArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  using H = Hoist<D>;
+  using Seq = typename H::EdgeFwdSeq;
+  constexpr int EB = D::DE / 16, AB = D::DA / 16;
+  constexpr int H1B = D::EH1 / 16, H2B = D::EH2 / 16, MHB = D::MH / 16, DMB = D::DM / 16;
+  WStreamT<NW * 64> ws;
+  ws.init(a.wpack, smem);
+  ws.template start<Seq>();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int ntiles = (a.E + NW * 16 - 1) / (NW * 16);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const bool more = tile + (int)gridDim.x < ntiles;
+    const long row = (long)tile * (NW * 16) + wave * kRowsPerWave + (lane & 15);
+    const bool valid = row < a.E;
+    int s = 0, d = 0;
+    if (valid) { s = a.src[row]; d = a.dst[row]; }
+
+    v4f ein[EB + AB];
+    load_row<EB>(a.e_in, row, D::DE, 0, valid, ein);
+    if constexpr (AB > 0) load_row<AB>(a.a_in, row, D::DA, 0, valid, ein + EB);
+    v4f h1[H1B], tb[H1B], fi[MHB], pi[MHB];
+    load_row<H1B>(a.T, d, H::TW, H::OA, valid, h1);
+    load_row<H1B>(a.T, s, H::TW, H::OB, valid, tb);
+    load_row<MHB>(a.T, d, H::TW, H::OF, valid, fi);
+    load_row<MHB>(a.T, s, H::TW, H::OP, valid, pi);
+    add_blocks<H1B>(h1, tb);
+
+    v4f h2[H2B], en[EB];
+    linear_init<Seq, 0, true, false>(ws, more, ein, h1, h1);
+    linear<Seq, 1, true>(ws, more, h1, h2, [&]() { if (a.sH1) store_row<H1B>(a.sH1, row, D::EH1, 0, valid, h1); });
+    linear<Seq, 2, false>(ws, more, h2, en, [&]() { if (a.sH2) store_row<H2B>(a.sH2, row, D::EH2, 0, valid, h2); });
+
+    v4f mo[DMB], mo2[DMB];
+    linear_init<Seq, 3, true, false>(ws, more, en, fi, fi, [&]() { store_row<EB>(a.e_out, row, D::DE, 0, valid, en); });
+    linear<Seq, 4, false>(ws, more, fi, mo, [&]() { if (a.sF1) store_row<MHB>(a.sF1, row, D::MH, 0, valid, fi); });
+    linear_init<Seq, 5, true, false>(ws, more, en, pi, pi, [&]() { store_row<DMB>(a.fut, row, D::DM, 0, valid, mo); });
+    linear<Seq, 6, false>(ws, more, pi, mo2, [&]() { if (a.sP1) store_row<MHB>(a.sP1, row, D::MH, 0, valid, pi); });
+    store_row<DMB>(a.past, row, D::DM, 0, valid, mo2);
+  }
+}
+
+// Node update + the per-node table of the NEXT layer in one launch (b3d_node.hpp, PROJ stage).
+template <class D>
+using NodeFwdHSeq = LayerSeq<L<D::NIN, D::NH1>, L<D::NH1, D::NH2>, L<D::NH2, D::DX>, L<D::DX, Hoist<D>::TW>>;
+
+template <class D>
+__global__ __launch_bounds__(kNodeWaves * 64, 1) void mp_node_fwd_split_h_kernel(const NodeFwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  node_fwd_split_body<D, NodeFwdHSeq<D>, true>(a, smem);
+}
+
+// Node encoder (three Linear layers) + x0 terms + the table of layer 0, one wavefront per 16 rows.
+// Seq = encoder layers 0..2, then L<DX, 2 MH> (x0 terms, no bias), then L<DX, TW> (projection).
+template <class In>
+struct NodeEncProjArgs {
+  int rows;
+  In in;
+  float* save_in;       // padded input rows (training) or nullptr
+  float* save[2];       // hidden activations (training) or nullptr
+  float* x0;            // [rows, DX]  layer-0 node features (= initial_x)
+  float* x_enc;         // [rows, DX]  second copy, returned to the caller (pose_gnn.py:86)
+  float* T0;            // [rows, 2 MH]
+  float* T;             // [rows, TW]
+  const float* wpack;
+};
+
+template <class D, class Seq, class In, int NW>
+__global__ __launch_bounds__(NW * 64, 1) void node_enc_proj_kernel(const NodeEncProjArgs<In> a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  using H = Hoist<D>;
+  static_assert(Seq::NL == 5 && Seq::np(2) == D::DX && Seq::np(3) == 2 * D::MH && Seq::np(4) == H::TW, "sequence layout");
+  constexpr int XB = D::DX / 16, A1B = Seq::np(0) / 16, A2B = Seq::np(1) / 16, T0B = 2 * D::MH / 16, TB = H::TW / 16;
+  constexpr int FB = H::OF / 16;
+  WStreamT<NW * 64, Seq::SLOT> ws;
+  ws.init(a.wpack, smem);
+  ws.template start<Seq>();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int ntiles = (a.rows + NW * 16 - 1) / (NW * 16);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const bool more = tile + (int)gridDim.x < ntiles;
+    const long row = (long)tile * (NW * 16) + wave * kRowsPerWave + (lane & 15);
+    const bool valid = row < a.rows;
+    v4f in[In::NB];
+    a.in(row, valid, in);
+    if (a.save_in) store_row<In::NB>(a.save_in, row, 16 * In::NB, 0, valid, in);
+    v4f a1[A1B], a2[A2B], x[XB];
+    linear<Seq, 0, true>(ws, more, in, a1);
+    if (a.save[0]) store_row<A1B>(a.save[0], row, 16 * A1B, 0, valid, a1);
+    linear<Seq, 1, true>(ws, more, a1, a2);
+    if (a.save[1]) store_row<A2B>(a.save[1], row, 16 * A2B, 0, valid, a2);
+    linear<Seq, 2, false>(ws, more, a2, x);
+    store_row<XB>(a.x0, row, D::DX, 0, valid, x);
+    store_row<XB>(a.x_enc, row, D::DX, 0, valid, x);
+    v4f t0[T0B], t[TB];
+    linear<Seq, 3, false, false>(ws, more, x, t0);
+    store_row<T0B>(a.T0, row, 2 * D::MH, 0, valid, t0);
+    linear<Seq, 4, false, true>(ws, more, x, t);
+#pragma unroll
+    for (int b = 0; b < T0B; ++b) t[FB + b] += t0[b];
+    store_row<TB>(a.T, row, H::TW, 0, valid, t);
+  }
+}
+
+}  // namespace b3d

@@ -134,7 +134,7 @@ inline void add_act(WgJob& j, const WgSeg& s) { j.act[j.nact++] = s; }
 inline RedEntry red_entry(const LinSlab& ls, float* dw, float* db) {
   RedEntry e;
   e.slab = ls.slab; e.nchunks = ls.nchunks; e.NP = ls.NP; e.KP = ls.KP; e.N = ls.N; e.K = ls.K;
-  e.dw = dw; e.db = db; e.begin = 0;
+  e.dw = dw; e.db = db; e.begin = 0; e.ld = ls.K;
   return e;
 }
 

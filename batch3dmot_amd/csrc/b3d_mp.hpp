@@ -73,7 +73,9 @@ struct NodeFwdArgs {
   float* x_out;         // [N, DX]
   float* sH1;           // [N, NH1] or nullptr
   float* sH2;           // [N, NH2] or nullptr
-  const float* wpack;   // NodeFwdSeq images
+  const float* wpack;   // NodeFwdSeq images (+ the projection image for the hoisted variant)
+  float* T;             // hoisted variant: [N, TW] per-node table of the next layer
+  const float* T0;      //                  [N, 2 MH] x0 terms
 };
 
 struct NodeBwdArgs {

@@ -74,8 +74,16 @@ __device__ __forceinline__ void linear_split_chunk(WS& ws, bool more, const v4f*
       if (hasB) acc1 = mfma4(fb, in[kb], acc1);
       fa = na; fb = nb;
     }
-    emit(mbA, RELU ? relu4(acc0) : acc0);
-    if (hasB) emit(mbB, RELU ? relu4(acc1) : acc1);
+    // emit(mb, v) or emit(mb, v, slot): slot = mb / NWS, the index of the block among those this
+    // wavefront owns -- a compile-time constant after unrolling (for per-wave register arrays)
+    if constexpr (requires { emit(0, zero4, 0); }) {
+      static_assert(mb0 % NWS == 0, "slot numbering needs chunk boundaries on multiples of the wave count");
+      emit(mbA, RELU ? relu4(acc0) : acc0, mb0 / NWS + j);
+      if (hasB) emit(mbB, RELU ? relu4(acc1) : acc1, mb0 / NWS + j + 1);
+    } else {
+      emit(mbA, RELU ? relu4(acc0) : acc0);
+      if (hasB) emit(mbB, RELU ? relu4(acc1) : acc1);
+    }
   }
 }
 
@@ -92,10 +100,8 @@ __device__ __forceinline__ void linear_split(WS& ws, bool more, const v4f* __res
 }
 
 // ------------------------------------------------------------------------------------------
-template <class D>
-__global__ __launch_bounds__(kNodeWaves * 64, 1) void mp_node_fwd_split_kernel(const NodeFwdArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  using Seq = typename D::NodeFwdSeq;
+template <class D, class Seq, bool PROJ>
+__device__ __forceinline__ void node_fwd_split_body(const NodeFwdArgs& a, float* smem) {
   using NS = NodeSplit<D>;
   constexpr int NWS = kNodeWaves;
   constexpr int XB = NS::XB, DMB = NS::DMB, H1B = NS::H1B, H2B = NS::H2B;
@@ -152,8 +158,37 @@ __global__ __launch_bounds__(kNodeWaves * 64, 1) void mp_node_fwd_split_kernel(c
 #pragma unroll
         for (int b = 0; b < H2B; ++b) h2[b] = xb0[b * 64 + lane];
       },
-      [&](int mb, v4f v) { store_row<1>(a.x_out, row, D::DX, 16 * mb, valid, &v); });
+      [&](int mb, v4f v) {
+        store_row<1>(a.x_out, row, D::DX, 16 * mb, valid, &v);
+        if constexpr (PROJ) xb1[mb * 64 + lane] = v;
+      });
+  if constexpr (PROJ) {
+    // per-node parts of the NEXT layer's three first Linear layers (b3d_hoist.hpp): T = Wp x' + bp (+ x0 terms)
+    constexpr int TB = (2 * D::EH1 + 2 * D::MH) / 16, FB = 2 * D::EH1 / 16, TW = 16 * TB;
+    static_assert(FB % NWS == 0 && (TB - FB) % NWS == 0, "table columns must split over the wavefronts");
+    constexpr int T0N = (TB - FB) / NWS;
+    v4f t0[T0N];                                 // this wavefront's blocks of the x0 terms
+#pragma unroll
+    for (int i = 0; i < T0N; ++i) load_row<1>(a.T0, row, 16 * (TB - FB), 16 * (wave + NWS * i), valid, &t0[i]);
+    v4f xn[XB];
+    linear_split<Seq, 3, false, true, NWS>(
+        ws, false, xn,
+        [&]() {
+#pragma unroll
+          for (int b = 0; b < XB; ++b) xn[b] = xb1[b * 64 + lane];
+        },
+        [&](int mb, v4f v, int slot) {
+          if (mb >= FB) v += t0[slot - FB / NWS];
+          store_row<1>(a.T, row, TW, 16 * mb, valid, &v);
+        });
+  }
   (void)XB;
+}
+
+template <class D>
+__global__ __launch_bounds__(kNodeWaves * 64, 1) void mp_node_fwd_split_kernel(const NodeFwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  node_fwd_split_body<D, typename D::NodeFwdSeq, false>(a, smem);
 }
 
 // ------------------------------------------------------------------------------------------

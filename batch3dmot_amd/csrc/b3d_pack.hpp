@@ -12,9 +12,14 @@ struct PackDesc {
   int NP, KP;        // padded to multiples of 16
   int transposed;    // 1: image of W^T (data-gradient operand); 2 / 3: not an image -- fill N ints at dst with
                      // 0, 1, 2, ... / with zeros (index and zero rows of the streaming weight gradient)
+  // A descriptor may cover only image rows [row0, row0 + nrows) (several slices of different weight
+  // matrices stacked into one image) and read a column slice of its source: element (r, c) of the
+  // slice is w[r * ld + c] (transposed: w[c * ld + r]).  N counts the slice's valid rows.
+  int ld;            // leading dimension of the source matrix
+  int row0, nrows;   // image rows covered (multiples of 16)
 };
 
-constexpr int kPackMax = 64;      // 3 KB of kernel arguments: one launch packs a whole model's images
+constexpr int kPackMax = 56;      // 3.5 KB of kernel arguments: one launch packs a whole model's images
 struct PackArgs {
   int n;
   PackDesc d[kPackMax];
@@ -30,6 +35,18 @@ inline PackDesc pack_desc(int li, float* base, const float* w, const float* b, i
   d.dst = base + Seq::layer_off(li);
   d.N = N; d.K = K; d.NP = Seq::np(li); d.KP = Seq::kp(li);
   d.transposed = transposed ? 1 : 0;
+  d.ld = transposed ? N : K;
+  d.row0 = 0; d.nrows = d.NP;
+  return d;
+}
+
+// Slice descriptor: rows [row0, row0 + nrows) of layer LI's image <- the [N, K] slice of a forward
+// weight starting at `w` with leading dimension ld (transposed: the slice is [K, N] in the source).
+template <class Seq>
+inline PackDesc pack_slice(int li, float* base, const float* w, const float* b, int N, int K, int ld, int row0, int nrows,
+                           bool transposed) {
+  PackDesc d = pack_desc<Seq>(li, base, w, b, N, K, transposed);
+  d.ld = ld; d.row0 = row0; d.nrows = nrows;
   return d;
 }
 
@@ -38,6 +55,7 @@ inline PackDesc fill_desc(void* dst, int count, bool iota) {
   d.w = nullptr; d.b = nullptr; d.dst = (float*)dst;
   d.N = count; d.K = 0; d.NP = 0; d.KP = 0;
   d.transposed = iota ? 2 : 3;
+  d.ld = 0; d.row0 = 0; d.nrows = 0;
   return d;
 }
 

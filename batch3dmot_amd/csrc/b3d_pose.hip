@@ -3,13 +3,22 @@
 #include "b3d_launch.hpp"
 #include "b3d_knn.hpp"
 #include "b3d_wstream.hpp"
+#include "b3d_hoist.hpp"
 
 namespace b3d {
 
 using D = DimsP;
+using HP = Hoist<DimsP>;
+
+// Hoisted first layers (b3d_hoist.hpp).  B3D_HOIST=0 selects the unsplit kernels (A/B comparisons).
+static bool hoist_enabled() {
+  static const bool on = [] { const char* e = getenv("B3D_HOIST"); return e ? atoi(e) != 0 : true; }();
+  return on;
+}
 // encoders / classifier, widths padded to multiples of 16
 using SeqEdgeEnc = LayerSeq<L<16, 16>, L<16, 16>, L<16, 32>>;            // 4-8-16-32    pose_gnn.py:29-35
 using SeqNodeEnc = LayerSeq<L<32, 32>, L<32, 48>, L<48, 48>>;            // 19-24-36-48  :37-43
+using SeqNodeEncH = LayerSeq<L<32, 32>, L<32, 48>, L<48, 48>, L<48, 192>, L<48, 384>>;   // + x0 terms + layer-0 table
 using SeqCls = LayerSeq<L<32, 16>, L<16, 16>, L<16, 16>, L<16, 16>>;     // 32-16-8-4-1  :45-53
 using SeqClsT = LayerSeq<L<16, 16>, L<16, 16>, L<16, 16>, L<16, 32>>;    // W4^T, W3^T, W2^T, W1^T
 using SeqEdgeEncT = LayerSeq<L<32, 16>, L<16, 16>>;                      // W3^T, W2^T
@@ -82,6 +91,10 @@ constexpr uint32_t kFlagLayerMode = 0x80000000u;   // internal: workspace of the
 struct PoseWs {
   // packed weight images
   float *wp_ee, *wp_ne, *wp_cls, *wp_efwd, *wp_nfwd, *wp_ebwd, *wp_ebwd_nm, *wp_nbwd, *wp_clsT, *wp_eeT, *wp_neT;
+  // hoisted first layers: projection images, per-node tables
+  bool hoist;
+  float *wp_ne_h, *wp_nfwd_h, *wp_efwd_h;
+  float *T, *T0;        // [N, TW] (current layer), [N, 2 MH] (x0 terms, whole forward)
   // encoder / classifier activations
   float *ea_pad, *ee_a1, *ee_a2, *pose_pad, *ne_a1, *ne_a2, *c_a1, *c_a2, *c_a3;
   float* x[16];      // x[0] = x_enc ... x[depth]
@@ -116,6 +129,14 @@ static void carve(PoseWs& w, void* ws, size_t ws_bytes, int N, int E, int depth,
   w.wp_cls = c.take<float>(SeqCls::TOTAL_FLOATS);
   w.wp_efwd = c.take<float>(D::EdgeFwdSeq::TOTAL_FLOATS);
   w.wp_nfwd = c.take<float>(D::NodeFwdSeq::TOTAL_FLOATS);
+  w.hoist = hoist_enabled() && !(flags & kFlagLayerMode);
+  if (w.hoist) {
+    w.wp_ne_h = c.take<float>(SeqNodeEncH::TOTAL_FLOATS);
+    w.wp_nfwd_h = c.take<float>(NodeFwdHSeq<D>::TOTAL_FLOATS);
+    w.wp_efwd_h = c.take<float>(HP::EdgeFwdSeq::TOTAL_FLOATS);
+    w.T = c.take<float>(n_ * HP::TW);
+    w.T0 = c.take<float>(n_ * 2 * D::MH);
+  }
   if (!tr) {
     w.x[0] = c.take<float>(n_ * D::DX);
     w.e[0] = c.take<float>(e_ * D::DE);
@@ -215,7 +236,7 @@ static void carve(PoseWs& w, void* ws, size_t ws_bytes, int N, int E, int depth,
 
 // ---- forward ------------------------------------------------------------------------------------
 static int pack_forward(const b3d_pose_weights* pw, PoseWs& w, bool training, bool knn, hipStream_t stream) {
-  PackDesc d[64];
+  PackDesc d[96];
   int n = 0;
   const b3d_linear* ee = pw->edge_encoder;
   const b3d_linear* ne = pw->node_encoder;
@@ -229,6 +250,31 @@ static int pack_forward(const b3d_pose_weights* pw, PoseWs& w, bool training, bo
   for (int i = 0; i < 2; ++i) d[n++] = pack_desc<EF>(3 + i, w.wp_efwd, mp.create_future_msgs[i].w, mp.create_future_msgs[i].b, kLinDims[LIN_FU0 + i].N, kLinDims[LIN_FU0 + i].K, false);
   for (int i = 0; i < 2; ++i) d[n++] = pack_desc<EF>(5 + i, w.wp_efwd, mp.create_past_msgs[i].w, mp.create_past_msgs[i].b, kLinDims[LIN_PA0 + i].N, kLinDims[LIN_PA0 + i].K, false);
   for (int i = 0; i < 3; ++i) d[n++] = pack_desc<D::NodeFwdSeq>(i, w.wp_nfwd, mp.combine_future_past[i].w, mp.combine_future_past[i].b, kLinDims[LIN_CF0 + i].N, kLinDims[LIN_CF0 + i].K, false);
+  if (w.hoist) {
+    constexpr int DX = D::DX, DE = D::DE, EIN = D::EIN, MIN = D::MIN, H1 = D::EH1, MH = D::MH;
+    const b3d_linear &eu0 = mp.edge_update[0], &fu0 = mp.create_future_msgs[0], &pa0 = mp.create_past_msgs[0];
+    // the projection image sits behind the node encoder (layer 0) and behind the node update (layers 1..)
+    auto proj = [&](auto tag, int li, float* base) {
+      using S = decltype(tag);
+      d[n++] = pack_slice<S>(li, base, eu0.w, eu0.b, H1, DX, EIN, HP::OA, H1, false);             // x[dst] columns + bias
+      d[n++] = pack_slice<S>(li, base, eu0.w + DX, nullptr, H1, DX, EIN, HP::OB, H1, false);     // x[src] columns
+      d[n++] = pack_slice<S>(li, base, fu0.w, fu0.b, MH, DX, MIN, HP::OF, MH, false);             // future: x[dst]
+      d[n++] = pack_slice<S>(li, base, pa0.w, pa0.b, MH, DX, MIN, HP::OP, MH, false);             // past:   x[src]
+    };
+    for (int i = 0; i < 3; ++i) d[n++] = pack_desc<SeqNodeEncH>(i, w.wp_ne_h, ne[i].w, ne[i].b, kLinDims[LIN_NE0 + i].N, kLinDims[LIN_NE0 + i].K, false);
+    d[n++] = pack_slice<SeqNodeEncH>(3, w.wp_ne_h, fu0.w + DX + DE, nullptr, MH, DX, MIN, 0, MH, false);    // x0 columns
+    d[n++] = pack_slice<SeqNodeEncH>(3, w.wp_ne_h, pa0.w + DX + DE, nullptr, MH, DX, MIN, MH, MH, false);
+    proj(SeqNodeEncH{}, 4, w.wp_ne_h);
+    for (int i = 0; i < 3; ++i) d[n++] = pack_desc<NodeFwdHSeq<D>>(i, w.wp_nfwd_h, mp.combine_future_past[i].w, mp.combine_future_past[i].b, kLinDims[LIN_CF0 + i].N, kLinDims[LIN_CF0 + i].K, false);
+    proj(NodeFwdHSeq<D>{}, 3, w.wp_nfwd_h);
+    using EH = HP::EdgeFwdSeq;
+    d[n++] = pack_slice<EH>(0, w.wp_efwd_h, eu0.w + 2 * DX, nullptr, H1, DE, EIN, 0, H1, false);    // edge columns of edge_update.0
+    for (int i = 1; i < 3; ++i) d[n++] = pack_desc<EH>(i, w.wp_efwd_h, mp.edge_update[i].w, mp.edge_update[i].b, kLinDims[LIN_EU0 + i].N, kLinDims[LIN_EU0 + i].K, false);
+    d[n++] = pack_slice<EH>(3, w.wp_efwd_h, fu0.w + DX, nullptr, MH, DE, MIN, 0, MH, false);         // e' columns
+    d[n++] = pack_desc<EH>(4, w.wp_efwd_h, mp.create_future_msgs[1].w, mp.create_future_msgs[1].b, kLinDims[LIN_FU1].N, kLinDims[LIN_FU1].K, false);
+    d[n++] = pack_slice<EH>(5, w.wp_efwd_h, pa0.w + DX, nullptr, MH, DE, MIN, 0, MH, false);
+    d[n++] = pack_desc<EH>(6, w.wp_efwd_h, mp.create_past_msgs[1].w, mp.create_past_msgs[1].b, kLinDims[LIN_PA1].N, kLinDims[LIN_PA1].K, false);
+  }
   if (knn) {                              // GATConv lin of the discarded k-NN block (consumed on the side stream)
     d[n++] = pack_desc<LayerSeq<L<D::DX, D::DX>>>(0, w.knn.wp, pw->knn_conv.lin, nullptr, D::DX, D::DX, false);
     w.knn.packed = true;
@@ -414,7 +460,17 @@ extern "C" int b3d_pose_forward(const b3d_pose_weights* pw, const b3d_graph* g, 
     a.wpack = w.wp_ee;
     B3D_TRY(launch_rows<kNWEdge>(chain_fwd_kernel<SeqEdgeEnc, 0x3u, LoadEdgeAttrF64, StoreAligned<2>, kNWEdge>, "edge_encoder", a, E, stream, B3D_K_OTHER, chain_lds<SeqEdgeEnc>()));
   }
-  {  // node encoder 19-24-36-48 (initial_x == x == x_enc)                  pose_gnn.py:68-71
+  if (w.hoist) {  // node encoder 19-24-36-48 + x0 terms + table of layer 0            pose_gnn.py:68-71
+    using In = LoadUnaligned<19>;
+    NodeEncProjArgs<In> a;
+    memset(&a, 0, sizeof(a));
+    a.rows = N; a.in.ptr = pose_feats;
+    a.save_in = w.pose_pad; a.save[0] = w.ne_a1; a.save[1] = w.ne_a2;
+    a.x0 = w.x[0]; a.x_enc = out_x_enc; a.T0 = w.T0; a.T = w.T;
+    a.wpack = w.wp_ne_h;
+    B3D_TRY(launch_rows<kNWNode>(node_enc_proj_kernel<D, SeqNodeEncH, In, kNWNode>, "node_encoder", a, N, stream, B3D_K_OTHER,
+                                 chain_lds<SeqNodeEncH>()));
+  } else {  // node encoder 19-24-36-48 (initial_x == x == x_enc)                  pose_gnn.py:68-71
     ChainFwdArgs<LoadUnaligned<19>, StoreTwo<3>> a;
     memset(&a, 0, sizeof(a));
     a.rows = N; a.in.ptr = pose_feats;
@@ -423,7 +479,6 @@ extern "C" int b3d_pose_forward(const b3d_pose_weights* pw, const b3d_graph* g, 
     a.wpack = w.wp_ne;
     B3D_TRY(launch_rows<kNWNode>(chain_fwd_kernel<SeqNodeEnc, 0x3u, LoadUnaligned<19>, StoreTwo<3>, kNWNode>, "node_encoder", a, N, stream, B3D_K_OTHER, chain_lds<SeqNodeEnc>()));
   }
-
   Side* knn_side = nullptr;
   for (int l = 0; l < depth; ++l) {
     if ((flags & B3D_FLAG_RUN_DEAD_KNN) && (l % 2 == 0)) {
@@ -437,6 +492,16 @@ extern "C" int b3d_pose_forward(const b3d_pose_weights* pw, const b3d_graph* g, 
       }
       B3D_TRY(knn_gat_block<D::DX>(w.knn, w.x[l], node_timestamps, N, pw->knn_conv, 20, ks));
     }
+    if (w.hoist) {
+      EdgeFwdHArgs ea;
+      memset(&ea, 0, sizeof(ea));
+      ea.E = E; ea.src = g->src; ea.dst = g->dst;
+      ea.T = w.T; ea.e_in = w.e[l]; ea.a_in = nullptr;
+      ea.e_out = w.e[l + 1]; ea.fut = w.fut; ea.past = w.past;
+      ea.sH1 = w.sH1[l]; ea.sH2 = w.sH2[l]; ea.sF1 = w.sF1[l]; ea.sP1 = w.sP1[l];
+      ea.wpack = w.wp_efwd_h;
+      B3D_TRY(launch_rows<kNWEdge>(mp_edge_fwd_h_kernel<D, kNWEdge>, "mp_edge_fwd", ea, E, stream, B3D_K_EDGE_FWD));
+    } else {
     EdgeFwdArgs ea;
     memset(&ea, 0, sizeof(ea));
     ea.E = E; ea.src = g->src; ea.dst = g->dst;
@@ -445,12 +510,18 @@ extern "C" int b3d_pose_forward(const b3d_pose_weights* pw, const b3d_graph* g, 
     ea.sH1 = w.sH1[l]; ea.sH2 = w.sH2[l]; ea.sF1 = w.sF1[l]; ea.sP1 = w.sP1[l];
     ea.wpack = w.wp_efwd;
     B3D_TRY(launch_rows<kNWEdge>(mp_edge_fwd_kernel<D, kNWEdge>, "mp_edge_fwd", ea, E, stream, B3D_K_EDGE_FWD));
+    }
     NodeFwdArgs na;
     memset(&na, 0, sizeof(na));
     na.N = N; na.dst_ptr = g->dst_ptr; na.dst_perm = g->dst_perm; na.src_ptr = g->src_ptr; na.src_perm = g->src_perm;
     na.past = w.past; na.fut = w.fut; na.M = w.M[l]; na.x_out = w.x[l + 1]; na.sH1 = w.nH1[l]; na.sH2 = w.nH2[l];
-    na.wpack = w.wp_nfwd;
-    B3D_TRY(launch_node_split<D>(mp_node_fwd_split_kernel<D>, "mp_node_fwd", na, N, stream, B3D_K_NODE_FWD));
+    if (w.hoist && l + 1 < depth) {            // + the per-node table the next layer's edge phase gathers
+      na.wpack = w.wp_nfwd_h; na.T = w.T; na.T0 = w.T0;
+      B3D_TRY(launch_node_split<D>(mp_node_fwd_split_h_kernel<D>, "mp_node_fwd", na, N, stream, B3D_K_NODE_FWD));
+    } else {
+      na.wpack = w.wp_nfwd;
+      B3D_TRY(launch_node_split<D>(mp_node_fwd_split_kernel<D>, "mp_node_fwd", na, N, stream, B3D_K_NODE_FWD));
+    }
   }
   {  // edge classifier 32-16-8-4-1 -> logits                                pose_gnn.py:86
     ChainFwdArgs<LoadAligned<2>, StoreScalar> a;

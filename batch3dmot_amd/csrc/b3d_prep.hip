@@ -169,25 +169,25 @@ __global__ void pack_kernel(const PackArgs a) {
   }
   const int stride = d.KP + 4;
   const int cr = chunk_rows(d.KP, d.NP);
-  const int total = d.NP * stride;
+  const int total = d.nrows * stride;
   for (int id = blockIdx.x * blockDim.x + threadIdx.x; id < total; id += gridDim.x * blockDim.x) {
-    const int r = id / stride, c = id - r * stride;
+    const int rl = id / stride, c = id - rl * stride;        // row within the slice
     float v = 0.f;
-    if (!d.transposed) {
-      if (r < d.N) {
-        if (c < d.K) v = d.w[(size_t)r * d.K + c];
-        else if (c == d.KP && d.b) v = d.b[r];
+    if (rl < d.N) {
+      if (!d.transposed) {
+        if (c < d.K) v = d.w[(size_t)rl * d.ld + c];
+        else if (c == d.KP && d.b) v = d.b[rl];
+      } else if (c < d.K) {
+        // image of W^T: rows = input features of the forward layer, cols = its outputs
+        v = d.w[(size_t)c * d.ld + rl];
       }
-    } else {
-      // image of W^T: rows = input features of the forward layer (K_fwd = d.N here), cols = outputs
-      // d.N / d.K describe the IMAGE (N rows, K cols); the source is [K, N] row-major.
-      if (r < d.N && c < d.K) v = d.w[(size_t)c * d.N + r];
     }
-    // chunked placement: chunk ch holds rows [ch*cr, ...), each chunk padded to 1 KB
-    const int ch = r / cr, rl = r - ch * cr;
+    // chunked placement: chunk ch holds image rows [ch*cr, ...), each chunk padded to 1 KB
+    const int r = d.row0 + rl;
+    const int ch = r / cr, rc = r - ch * cr;
     size_t off = 0;
     for (int i = 0; i < ch; ++i) off += chunk_floats(d.KP, chunk_nrows(d.KP, d.NP, i));
-    d.dst[off + (size_t)rl * stride + c] = v;
+    d.dst[off + (size_t)rc * stride + c] = v;
   }
 }
 
@@ -198,7 +198,7 @@ int pack_images(const PackDesc* descs, int n, hipStream_t stream) {
     int maxtot = 0;
     for (int i = 0; i < a.n; ++i) {
       a.d[i] = descs[i0 + i];
-      const int t = (a.d[i].transposed >= 2) ? a.d[i].N : a.d[i].NP * (a.d[i].KP + 4);
+      const int t = (a.d[i].transposed >= 2) ? a.d[i].N : a.d[i].nrows * (a.d[i].KP + 4);
       if (t > maxtot) maxtot = t;
     }
     int gx = (maxtot + 255) / 256;

@@ -279,7 +279,8 @@ constexpr int kRedMaxEntries = 32;
 struct RedEntry {
   const float* slab;
   int nchunks, NP, KP, N, K;
-  float* dw;   // [N, K] or nullptr
+  float* dw;   // [N, K] block with leading dimension ld (a column slice of a wider gradient), or nullptr
+  int ld;
   float* db;   // [N] or nullptr
   int begin;   // first flat element id of this entry in the launch
 };
@@ -303,7 +304,7 @@ static __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedArgs 
   if (l < e.N * e.K) {
     const int n = l / e.K, k = l - n * e.K;
     off = (size_t)n * e.KP + k;
-    out = e.dw ? e.dw + l : nullptr;
+    out = e.dw ? e.dw + (size_t)n * e.ld + k : nullptr;
   } else {
     const int n = l - e.N * e.K;
     off = (size_t)e.NP * e.KP + n;

@@ -252,7 +252,10 @@ enum {
   WS_32_32 = 10,
   WS_48_32 = 11,
   WS_48_48 = 12,
-  WS_SHAPES = 13
+  // hoisted first layers (per-node and per-edge parts of a Linear over a concatenation)
+  WS_96_32 = 13,
+  WS_96_48 = 14,
+  WS_SHAPES = 15
 };
 
 static __global__ void ws_table_kernel(const WsTableArgs a) {
@@ -293,13 +296,15 @@ static __global__ __launch_bounds__(kWsWaves * 64, 2) void wstream_kernel(const 
     case WS_32_32: ws_task<32, 32, 0, 0>(job, chunk, zero_row); break;
     case WS_48_32: ws_task<48, 32, 0, 0>(job, chunk, zero_row); break;
     case WS_48_48: ws_task<48, 48, 0, 0>(job, chunk, zero_row); break;
+    case WS_96_32: ws_task<96, 32, 0, 0>(job, chunk, zero_row); break;
+    case WS_96_48: ws_task<96, 48, 0, 0>(job, chunk, zero_row); break;
     default: break;
   }
 }
 
 // blocks (MFMAs per 4-row step) of a shape: the unit of work used to balance tasks
 inline int ws_shape_blocks(int shape) {
-  static const int b[WS_SHAPES] = {6 * 4, 6 * 4, 4 * 6, 2 * 4, 3 * 4, 6 * 4, 4 * 4, 1, 2, 2, 4, 6, 9};
+  static const int b[WS_SHAPES] = {6 * 4, 6 * 4, 4 * 6, 2 * 4, 3 * 4, 6 * 4, 4 * 4, 1, 2, 2, 4, 6, 9, 6 * 2, 6 * 3};
   return b[shape];
 }
 
