@@ -182,4 +182,172 @@ __global__ __launch_bounds__(NW * 64, 1) void node_enc_proj_kernel(const NodeEnc
   }
 }
 
+// ---- backward -------------------------------------------------------------------------------------
+struct EdgeBwdHArgs {
+  int E;
+  const int* src;
+  const int* dst;
+  const float* dM;      // [N, 2 DM] (past | future) or nullptr when MSGS == false
+  const float* de_out;  // [E, DE] gradient of this layer's e'
+  const float* sH1;
+  const float* sH2;
+  const float* sF1;
+  const float* sP1;
+  float* de_in;         // [E, DE] gradient of this layer's input e
+  float* da_acc;        // [E, DA] running gradient of att_edge_attr or nullptr
+  int da_first;
+  float* GdH1;          // [E, EH1]  G tensors: weight gradient AND per-node sums of the first layers
+  float* GdH2;
+  float* Gde;
+  float* GdF1;
+  float* GdP1;
+  const float* wpack;   // Hoist::EdgeBwdSeq / EdgeBwdSeqNoMsg images
+};
+
+// Data gradient of the edge phase without the node columns of the three first layers: those are
+// contracted per NODE from the segment sums of GdH1 / GdF1 / GdP1 (node_gradproj_kernel).
+template <class D, bool MSGS, int NW>
+__global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void mp_edge_bwd_h_kernel(const EdgeBwdHArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  using H = Hoist<D>;
+  using Seq = typename std::conditional<MSGS, typename H::EdgeBwdSeq, typename H::EdgeBwdSeqNoMsg>::type;
+  constexpr int L0 = MSGS ? 4 : 0;
+  constexpr int EB = D::DE / 16, AB = D::DA / 16;
+  constexpr int H1B = D::EH1 / 16, H2B = D::EH2 / 16, MHB = D::MH / 16, DMB = D::DM / 16;
+  WStreamT<NW * 64> ws;
+  ws.init(a.wpack, smem);
+  ws.template start<Seq>();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int ntiles = (a.E + NW * 16 - 1) / (NW * 16);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const bool more = tile + (int)gridDim.x < ntiles;
+    const long row = (long)tile * (NW * 16) + wave * kRowsPerWave + (lane & 15);
+    const bool valid = row < a.E;
+    int s = 0, d = 0;
+    if (valid) { s = a.src[row]; d = a.dst[row]; }
+    v4f de[EB];
+    load_row<EB>(a.de_out, row, D::DE, 0, valid, de);
+    if constexpr (MSGS) {
+      v4f dmsg[DMB], act[MHB], dh[MHB], dee[EB];
+      load_row<DMB>(a.dM, d, 2 * D::DM, 0, valid, dmsg);           // past messages were summed at dst
+      load_row<MHB>(a.sP1, row, D::MH, 0, valid, act);
+      linear<Seq, 0, false, false>(ws, more, dmsg, dh);
+      relu_bwd<MHB>(dh, act);
+      store_row<MHB>(a.GdP1, row, D::MH, 0, valid, dh);
+      linear<Seq, 1, false, false>(ws, more, dh, dee);
+      add_blocks<EB>(de, dee);
+      load_row<DMB>(a.dM, s, 2 * D::DM, D::DM, valid, dmsg);       // future messages were summed at src
+      load_row<MHB>(a.sF1, row, D::MH, 0, valid, act);
+      linear<Seq, 2, false, false>(ws, more, dmsg, dh);
+      relu_bwd<MHB>(dh, act);
+      store_row<MHB>(a.GdF1, row, D::MH, 0, valid, dh);
+      linear<Seq, 3, false, false>(ws, more, dh, dee);
+      add_blocks<EB>(de, dee);
+    }
+    store_row<EB>(a.Gde, row, D::DE, 0, valid, de);
+    v4f act2[H2B], d2[H2B];
+    load_row<H2B>(a.sH2, row, D::EH2, 0, valid, act2);
+    linear<Seq, L0 + 0, false, false>(ws, more, de, d2);
+    relu_bwd<H2B>(d2, act2);
+    store_row<H2B>(a.GdH2, row, D::EH2, 0, valid, d2);
+    v4f act1[H1B], d1[H1B];
+    load_row<H1B>(a.sH1, row, D::EH1, 0, valid, act1);
+    linear<Seq, L0 + 1, false, false>(ws, more, d2, d1);
+    relu_bwd<H1B>(d1, act1);
+    store_row<H1B>(a.GdH1, row, D::EH1, 0, valid, d1);
+    v4f dein[EB + AB];
+    linear<Seq, L0 + 2, false, false>(ws, more, d1, dein);
+    store_row<EB>(a.de_in, row, D::DE, 0, valid, dein);
+    if constexpr (AB > 0) {
+      if (!a.da_first) {
+        v4f prev[AB];
+        load_row<AB>(a.da_acc, row, D::DA, 0, valid, prev);
+        add_blocks<AB>(dein + EB, prev);
+      }
+      store_row<AB>(a.da_acc, row, D::DA, 0, valid, dein + EB);
+    }
+  }
+}
+
+// Per-node gradient of the table T and of (x | x0), 4 wavefronts per 16-row tile:
+//   dT[n] = ( sum_{dst=n} dH1 | sum_{src=n} dH1 | sum_{dst=n} dF1 | sum_{src=n} dP1 )      (kept: weight gradient)
+//   gx[n] = ( dx | dx0 contribution ) = GradProj . dT[n]
+struct NodeGradProjArgs {
+  int N;
+  const int* dst_ptr;
+  const int* dst_perm;
+  const int* src_ptr;
+  const int* src_perm;
+  const float* GdH1;    // [E, EH1]
+  const float* GdF1;    // [E, MH] or nullptr (last layer: the message stacks carry no gradient)
+  const float* GdP1;
+  float* dT;            // [N, TW]
+  float* gx;            // [N, 2 DX]
+  const float* wpack;   // Hoist::GradProjSeq image
+};
+
+template <class D>
+struct GradProjLds {
+  static constexpr int TB = Hoist<D>::TW / 16;
+  static constexpr int BYTES = kLdsBytes + TB * 64 * 16;
+};
+
+template <class D>
+__global__ __launch_bounds__(kNodeWaves * 64, 1) void node_gradproj_kernel(const NodeGradProjArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  using H = Hoist<D>;
+  using Seq = typename H::GradProjSeq;
+  constexpr int NWS = kNodeWaves;
+  static_assert(NWS == 4 && D::EH1 == D::MH, "one list per wavefront, equal widths");
+  constexpr int LB = D::EH1 / 16, TB = H::TW / 16;
+  WStreamT<NWS * 64> ws;
+  ws.init(a.wpack, smem);
+  ws.template start<Seq>();
+  v4f* xb = reinterpret_cast<v4f*>(smem + 2 * kWBufFloats);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 16 + (lane & 15);
+  const bool valid = row < a.N;
+  {
+    v4f part[LB];
+#pragma unroll
+    for (int b = 0; b < LB; ++b) part[b] = v4f{0.f, 0.f, 0.f, 0.f};
+    const float* base = (wave < 2) ? a.GdH1 : (wave == 2 ? a.GdF1 : a.GdP1);
+    const bool by_dst = (wave == 0 || wave == 2);
+    if (valid && base) {
+      constexpr int U = LB <= 6 ? 4 : 2;
+      if (by_dst) segment_sum_deep<LB, U>(base, 16 * LB, 0, a.dst_perm, a.dst_ptr[row], a.dst_ptr[row + 1], part);
+      else segment_sum_deep<LB, U>(base, 16 * LB, 0, a.src_perm, a.src_ptr[row], a.src_ptr[row + 1], part);
+    }
+#pragma unroll
+    for (int b = 0; b < LB; ++b) xb[(wave * LB + b) * 64 + lane] = part[b];
+    store_row<LB>(a.dT, row, H::TW, 16 * LB * wave, valid, part);
+  }
+  v4f dt[TB];
+  linear_split<Seq, 0, false, false, NWS>(
+      ws, false, dt,
+      [&]() {
+#pragma unroll
+        for (int b = 0; b < TB; ++b) dt[b] = xb[b * 64 + lane];
+      },
+      [&](int mb, v4f v) { store_row<1>(a.gx, row, 2 * D::DX, 16 * mb, valid, &v); });
+}
+
+// Loader of the node-encoder backward: gradient at x_enc = upstream + running d initial_x + layer 0's (dx | dx0).
+template <int XB>
+struct LoadNodeEncGradH {
+  static constexpr int NB = XB;
+  const float* d_x_enc;   // [N, DX] or nullptr
+  const float* dx0_acc;   // [N, DX] or nullptr
+  const float* gx;        // [N, 2 DX]
+  __device__ __forceinline__ void operator()(long row, bool valid, v4f* dst) const {
+    v4f g[2 * XB];
+    load_row<2 * XB>(gx, row, 32 * XB, 0, valid, g);
+    v4f t[XB];
+    if (d_x_enc) { load_row<XB>(d_x_enc, row, 16 * XB, 0, valid, t); add_blocks<XB>(g, t); }
+    if (dx0_acc) { load_row<XB>(dx0_acc, row, 16 * XB, 0, valid, t); add_blocks<XB>(g, t); }
+#pragma unroll
+    for (int b = 0; b < XB; ++b) dst[b] = g[b] + g[XB + b];
+  }
+};
+
 }  // namespace b3d

@@ -86,8 +86,10 @@ struct NodeBwdArgs {
   const int* src_perm;
   const float* gdst;    // [E, 2 DX]  (d x[dst] | d x0[dst]) per edge, from the next layer
   const float* gsrc;    // [E, 2 DX]  (d x[src] | d x0[src]) per edge
-  const float* g_direct; // [N, DX] gradient of x' given per NODE (standalone layer operator): replaces the
-                         // two per-edge lists; dx0_acc / Gdx are not touched
+  const float* g_direct; // gradient given per NODE instead of the two per-edge lists: [N, DX] = d x' (standalone
+                         // layer operator; dx0_acc / Gdx are not touched) or, with g_direct_wide, [N, 2 DX] =
+                         // (d x' | d x0 contribution) from node_gradproj_kernel (hoisted first layers)
+  int g_direct_wide;
   float* dx0_acc;       // [N, DX] running gradient of initial_x
   int dx0_first;        // 1: overwrite dx0_acc, 0: accumulate
   const float* sH1;     // saved activations of THIS layer's node MLP

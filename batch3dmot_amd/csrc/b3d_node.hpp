@@ -217,12 +217,15 @@ __global__ __launch_bounds__(kNodeWaves * 64, 1) void mp_node_bwd_split_kernel(c
   load_row<H1B>(a.sH1, row, D::NH1, 0, valid, act1);
 
   v4f g[GB];
-  if (a.g_direct) {
+  if (a.g_direct && !a.g_direct_wide) {
     // standalone layer: d x' is given per node
     load_row<XB>(a.g_direct, row, D::DX, 0, valid, g);
 #pragma unroll
     for (int b = XB; b < GB; ++b) g[b] = v4f{0.f, 0.f, 0.f, 0.f};
   } else {
+    if (a.g_direct) {
+      load_row<GB>(a.g_direct, row, 2 * D::DX, 0, valid, g);     // (d x' | d x0 contribution) per node
+    } else {
     // ---- transposed gathers: waves [0, NWS/2) sum the by-destination list, the others by-source ----
     {
       v4f part[GPW];
@@ -240,6 +243,7 @@ __global__ __launch_bounds__(kNodeWaves * 64, 1) void mp_node_bwd_split_kernel(c
     __syncthreads();
 #pragma unroll
     for (int b = 0; b < GB; ++b) g[b] = xb0[b * 64 + lane] + xb0[(GB + b) * 64 + lane];
+    }
 #pragma unroll
     for (int b = 0; b < GB; ++b) {
       if (b % NWS != wave) continue;                            // wave-uniform: one owner per block

@@ -17,6 +17,9 @@ struct PackDesc {
   // slice is w[r * ld + c] (transposed: w[c * ld + r]).  N counts the slice's valid rows.
   int ld;            // leading dimension of the source matrix
   int row0, nrows;   // image rows covered (multiples of 16)
+  int col0;          // >= 0 with `partial`: the slice lands at image columns [col0, col0 + K)
+  int partial;       // 1: write only the slice's nrows x K cells (w == nullptr: zeros); other cells belong to other
+                     //    descriptors of the same image
 };
 
 constexpr int kPackMax = 56;      // 3.5 KB of kernel arguments: one launch packs a whole model's images
@@ -24,6 +27,7 @@ struct PackArgs {
   int n;
   PackDesc d[kPackMax];
 };
+static_assert(sizeof(PackArgs) <= 4096, "kernel argument block limit");
 
 int pack_images(const PackDesc* descs, int n, hipStream_t stream);
 
@@ -37,6 +41,7 @@ inline PackDesc pack_desc(int li, float* base, const float* w, const float* b, i
   d.transposed = transposed ? 1 : 0;
   d.ld = transposed ? N : K;
   d.row0 = 0; d.nrows = d.NP;
+  d.col0 = 0; d.partial = 0;
   return d;
 }
 
@@ -50,12 +55,22 @@ inline PackDesc pack_slice(int li, float* base, const float* w, const float* b, 
   return d;
 }
 
+// Block of an image assembled from several weight slices: rows [row0, row0 + nrows), columns
+// [col0, col0 + K); w == nullptr writes zeros.
+template <class Seq>
+inline PackDesc pack_block(int li, float* base, const float* w, int N, int K, int ld, int row0, int nrows, int col0,
+                           bool transposed) {
+  PackDesc d = pack_slice<Seq>(li, base, w, nullptr, N, K, ld, row0, nrows, transposed);
+  d.col0 = col0; d.partial = 1;
+  return d;
+}
+
 inline PackDesc fill_desc(void* dst, int count, bool iota) {
   PackDesc d;
   d.w = nullptr; d.b = nullptr; d.dst = (float*)dst;
   d.N = count; d.K = 0; d.NP = 0; d.KP = 0;
   d.transposed = iota ? 2 : 3;
-  d.ld = 0; d.row0 = 0; d.nrows = 0;
+  d.ld = 0; d.row0 = 0; d.nrows = 0; d.col0 = 0; d.partial = 0;
   return d;
 }
 

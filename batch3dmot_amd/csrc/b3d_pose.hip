@@ -93,7 +93,8 @@ struct PoseWs {
   float *wp_ee, *wp_ne, *wp_cls, *wp_efwd, *wp_nfwd, *wp_ebwd, *wp_ebwd_nm, *wp_nbwd, *wp_clsT, *wp_eeT, *wp_neT;
   // hoisted first layers: projection images, per-node tables
   bool hoist;
-  float *wp_ne_h, *wp_nfwd_h, *wp_efwd_h;
+  float *wp_ne_h, *wp_nfwd_h, *wp_efwd_h, *wp_ebwd_h, *wp_ebwd_nm_h, *wp_gproj;
+  float *dT, *gx;       // [depth][N, TW] gradient of T per layer (kept for the weight gradient), [N, 2 DX] scratch
   float *T, *T0;        // [N, TW] (current layer), [N, 2 MH] (x0 terms, whole forward)
   // encoder / classifier activations
   float *ea_pad, *ee_a1, *ee_a2, *pose_pad, *ne_a1, *ne_a2, *c_a1, *c_a2, *c_a3;
@@ -154,6 +155,13 @@ static void carve(PoseWs& w, void* ws, size_t ws_bytes, int N, int E, int depth,
     w.wp_ebwd = c.take<float>(D::EdgeBwdSeq::TOTAL_FLOATS);
     w.wp_ebwd_nm = c.take<float>(D::EdgeBwdSeqNoMsg::TOTAL_FLOATS);
     w.wp_nbwd = c.take<float>(D::NodeBwdSeq::TOTAL_FLOATS);
+    if (w.hoist) {
+      w.wp_ebwd_h = c.take<float>(HP::EdgeBwdSeq::TOTAL_FLOATS);
+      w.wp_ebwd_nm_h = c.take<float>(HP::EdgeBwdSeqNoMsg::TOTAL_FLOATS);
+      w.wp_gproj = c.take<float>(HP::GradProjSeq::TOTAL_FLOATS);
+      w.dT = c.take<float>((size_t)depth * n_ * HP::TW);
+      w.gx = c.take<float>(n_ * 2 * D::DX);
+    }
     w.wp_clsT = c.take<float>(SeqClsT::TOTAL_FLOATS);
     w.wp_eeT = c.take<float>(SeqEdgeEncT::TOTAL_FLOATS);
     w.wp_neT = c.take<float>(SeqNodeEncT::TOTAL_FLOATS);
@@ -236,7 +244,7 @@ static void carve(PoseWs& w, void* ws, size_t ws_bytes, int N, int E, int depth,
 
 // ---- forward ------------------------------------------------------------------------------------
 static int pack_forward(const b3d_pose_weights* pw, PoseWs& w, bool training, bool knn, hipStream_t stream) {
-  PackDesc d[96];
+  PackDesc d[128];
   int n = 0;
   const b3d_linear* ee = pw->edge_encoder;
   const b3d_linear* ne = pw->node_encoder;
@@ -311,6 +319,39 @@ static int pack_forward(const b3d_pose_weights* pw, PoseWs& w, bool training, bo
     T(SeqEdgeEncT{}, 1, w.wp_eeT, ee[1], LIN_EE1);
     T(SeqNodeEncT{}, 0, w.wp_neT, ne[2], LIN_NE2);
     T(SeqNodeEncT{}, 1, w.wp_neT, ne[1], LIN_NE1);
+    if (w.hoist) {
+      constexpr int DX = D::DX, DE = D::DE, EIN = D::EIN, MIN = D::MIN, H1 = D::EH1;
+      const b3d_linear &eu0 = mp.edge_update[0], &fu0 = mp.create_future_msgs[0], &pa0 = mp.create_past_msgs[0];
+      // data-gradient images: full transposes, except the .0 layers, which keep their edge columns
+      auto TS = [&](auto tag, int li, float* base, const float* wcol, int ld) {      // [DE rows (inputs), 96 cols (outputs)]
+        using S = decltype(tag);
+        d[n++] = pack_slice<S>(li, base, wcol, nullptr, DE, H1, ld, 0, S::np(li), true);
+      };
+      using EB2 = HP::EdgeBwdSeq;
+      T(EB2{}, 0, w.wp_ebwd_h, mp.create_past_msgs[1], LIN_PA1);
+      TS(EB2{}, 1, w.wp_ebwd_h, pa0.w + DX, MIN);
+      T(EB2{}, 2, w.wp_ebwd_h, mp.create_future_msgs[1], LIN_FU1);
+      TS(EB2{}, 3, w.wp_ebwd_h, fu0.w + DX, MIN);
+      T(EB2{}, 4, w.wp_ebwd_h, mp.edge_update[2], LIN_EU2);
+      T(EB2{}, 5, w.wp_ebwd_h, mp.edge_update[1], LIN_EU1);
+      TS(EB2{}, 6, w.wp_ebwd_h, eu0.w + 2 * DX, EIN);
+      using EN2 = HP::EdgeBwdSeqNoMsg;
+      T(EN2{}, 0, w.wp_ebwd_nm_h, mp.edge_update[2], LIN_EU2);
+      T(EN2{}, 1, w.wp_ebwd_nm_h, mp.edge_update[1], LIN_EU1);
+      TS(EN2{}, 2, w.wp_ebwd_nm_h, eu0.w + 2 * DX, EIN);
+      // (dx | dx0) = GradProj . dT: rows 0:DX from the x columns, rows DX:2DX from the x0 columns
+      using GP = HP::GradProjSeq;
+      auto B = [&](const float* wcol, int ld, int row0, int col0) {
+        d[n++] = pack_block<GP>(0, w.wp_gproj, wcol, DX, H1, ld, row0, DX, col0, true);
+      };
+      B(eu0.w, EIN, 0, HP::OA);
+      B(eu0.w + DX, EIN, 0, HP::OB);
+      B(fu0.w, MIN, 0, HP::OF);
+      B(pa0.w, MIN, 0, HP::OP);
+      d[n++] = pack_block<GP>(0, w.wp_gproj, nullptr, DX, 2 * H1, 0, DX, DX, 0, true);       // dx0 rows: no edge_update columns
+      B(fu0.w + DX + DE, MIN, DX, HP::OF);
+      B(pa0.w + DX + DE, MIN, DX, HP::OP);
+    }
   }
   return pack_images(d, n, stream);
 }
@@ -573,20 +614,59 @@ extern "C" int b3d_pose_backward(const b3d_pose_weights* pw, const b3d_graph* g,
   // ---- message-passing layers, last to first: data gradients only; the G tensors of every layer
   //      are kept for ONE streaming weight-gradient launch after the sweep -------------------------
   bool dx0_first = true;
+  // hoisted first layers: per-node gradient of T (kept per layer) and of (x | x0) from layer `lay`'s G tensors
+  auto gradproj = [&](int lay) -> int {
+    NodeGradProjArgs ga;
+    memset(&ga, 0, sizeof(ga));
+    ga.N = N; ga.dst_ptr = g->dst_ptr; ga.dst_perm = g->dst_perm; ga.src_ptr = g->src_ptr; ga.src_perm = g->src_perm;
+    ga.GdH1 = w.GdH1 + lay * eL1;
+    const bool lay_msgs = lay < depth - 1;
+    ga.GdF1 = lay_msgs ? w.GdF1 + lay * eLm : nullptr;
+    ga.GdP1 = lay_msgs ? w.GdP1 + lay * eLm : nullptr;
+    ga.dT = w.dT + (size_t)lay * N * HP::TW; ga.gx = w.gx;
+    ga.wpack = w.wp_gproj;
+    B3D_TRY(set_lds(node_gradproj_kernel<D>, GradProjLds<D>::BYTES));
+    ProfScope ps(B3D_K_NODE_BWD, stream);
+    hipLaunchKernelGGL(node_gradproj_kernel<D>, dim3((N + 15) / 16), dim3(kNodeWaves * 64), GradProjLds<D>::BYTES, stream, ga);
+    return launch_check("node_gradproj_kernel");
+  };
   for (int l = depth - 1; l >= 0; --l) {
     const bool msgs = (l < depth - 1);   // the last layer's node update feeds nothing (pose_gnn.py:86)
     if (msgs) {
-      // node backward of layer l consumes the per-edge node gradients written by layer l+1
+      // node backward of layer l consumes the node gradients of layer l+1's edge phase
       NodeBwdArgs nb;
       memset(&nb, 0, sizeof(nb));
       nb.N = N; nb.dst_ptr = g->dst_ptr; nb.dst_perm = g->dst_perm; nb.src_ptr = g->src_ptr; nb.src_perm = g->src_perm;
-      nb.gdst = w.gdst; nb.gsrc = w.gsrc; nb.dx0_acc = w.dx0_acc; nb.dx0_first = dx0_first ? 1 : 0;
+      if (w.hoist) {
+        B3D_TRY(gradproj(l + 1));
+        nb.g_direct = w.gx; nb.g_direct_wide = 1;
+      } else {
+        nb.gdst = w.gdst; nb.gsrc = w.gsrc;
+      }
+      nb.dx0_acc = w.dx0_acc; nb.dx0_first = dx0_first ? 1 : 0;
       nb.sH1 = w.nH1[l]; nb.sH2 = w.nH2[l];
       nb.dM = w.dM + l * nLm; nb.Gdx = w.Gdx + l * nLx; nb.GdH2 = w.GnH2 + l * nL2; nb.GdH1 = w.GnH1 + l * nL1;
       nb.wpack = w.wp_nbwd;
       B3D_TRY(launch_node_split<D>(mp_node_bwd_split_kernel<D>, "mp_node_bwd", nb, N, stream, B3D_K_NODE_BWD));
       dx0_first = false;
     }
+    if (w.hoist) {
+      EdgeBwdHArgs eb;
+      memset(&eb, 0, sizeof(eb));
+      eb.E = E; eb.src = src; eb.dst = dst;
+      eb.dM = msgs ? w.dM + l * nLm : nullptr;
+      eb.de_out = w.de[cur]; eb.de_in = w.de[cur ^ 1];
+      eb.sH1 = w.sH1[l]; eb.sH2 = w.sH2[l]; eb.sF1 = w.sF1[l]; eb.sP1 = w.sP1[l];
+      eb.GdH1 = w.GdH1 + l * eL1; eb.GdH2 = w.GdH2 + l * eL2; eb.Gde = w.Gde + l * eLe;
+      eb.GdF1 = w.GdF1 + l * eLm; eb.GdP1 = w.GdP1 + l * eLm;
+      if (msgs) {
+        eb.wpack = w.wp_ebwd_h;
+        B3D_TRY(launch_rows<kNWEdge>(mp_edge_bwd_h_kernel<D, true, kNWEdge>, "mp_edge_bwd", eb, E, stream, B3D_K_EDGE_BWD));
+      } else {
+        eb.wpack = w.wp_ebwd_nm_h;
+        B3D_TRY(launch_rows<kNWEdge>(mp_edge_bwd_h_kernel<D, false, kNWEdge>, "mp_edge_bwd_last", eb, E, stream, B3D_K_OTHER));
+      }
+    } else {
     EdgeBwdArgs eb;
     memset(&eb, 0, sizeof(eb));
     eb.E = E; eb.src = src; eb.dst = dst;
@@ -604,11 +684,24 @@ extern "C" int b3d_pose_backward(const b3d_pose_weights* pw, const b3d_graph* g,
       eb.wpack = w.wp_ebwd_nm;
       B3D_TRY(launch_rows<kNWEdge>(mp_edge_bwd_kernel<D, false, kNWEdge>, "mp_edge_bwd_last", eb, E, stream, B3D_K_OTHER));
     }
+    }
     cur ^= 1;
   }
 
   // ---- encoders ---------------------------------------------------------------------------------
-  {  // node encoder: gradient at x_enc = upstream + running d initial_x + layer-0 scatter transposes
+  if (w.hoist) {  // node encoder: gradient at x_enc = upstream + running d initial_x + layer 0's (dx | dx0)
+    B3D_TRY(gradproj(0));
+    using In = LoadNodeEncGradH<3>;
+    ChainBwdArgs<In, StoreNone> a;
+    memset(&a, 0, sizeof(a));
+    a.rows = N;
+    a.in = In{d_x_enc, dx0_first ? nullptr : w.dx0_acc, w.gx};
+    a.gtop = w.gn_top;
+    a.act[0] = w.ne_a2; a.act[1] = w.ne_a1;
+    a.gsave[0] = w.gn2; a.gsave[1] = w.gn1;
+    a.wpack = w.wp_neT;
+    B3D_TRY(launch_rows<kNWNode>(chain_bwd_kernel<SeqNodeEncT, In, StoreNone, kNWNode>, "node_encoder_bwd", a, N, stream, B3D_K_OTHER, chain_lds<SeqNodeEncT>()));
+  } else {  // node encoder: gradient at x_enc = upstream + running d initial_x + layer-0 scatter transposes
     using In = LoadNodeEncGrad<3>;
     ChainBwdArgs<In, StoreNone> a;
     memset(&a, 0, sizeof(a));

@@ -169,11 +169,12 @@ __global__ void pack_kernel(const PackArgs a) {
   }
   const int stride = d.KP + 4;
   const int cr = chunk_rows(d.KP, d.NP);
-  const int total = d.nrows * stride;
+  const int span = d.partial ? d.K : stride;                 // columns this descriptor writes per row
+  const int total = d.nrows * span;
   for (int id = blockIdx.x * blockDim.x + threadIdx.x; id < total; id += gridDim.x * blockDim.x) {
-    const int rl = id / stride, c = id - rl * stride;        // row within the slice
+    const int rl = id / span, c = id - rl * span;            // row / column within the slice
     float v = 0.f;
-    if (rl < d.N) {
+    if (rl < d.N && d.w) {
       if (!d.transposed) {
         if (c < d.K) v = d.w[(size_t)rl * d.ld + c];
         else if (c == d.KP && d.b) v = d.b[rl];
@@ -187,7 +188,7 @@ __global__ void pack_kernel(const PackArgs a) {
     const int ch = r / cr, rc = r - ch * cr;
     size_t off = 0;
     for (int i = 0; i < ch; ++i) off += chunk_floats(d.KP, chunk_nrows(d.KP, d.NP, i));
-    d.dst[off + (size_t)rc * stride + c] = v;
+    d.dst[off + (size_t)rc * stride + d.col0 + c] = v;
   }
 }
 
@@ -198,7 +199,7 @@ int pack_images(const PackDesc* descs, int n, hipStream_t stream) {
     int maxtot = 0;
     for (int i = 0; i < a.n; ++i) {
       a.d[i] = descs[i0 + i];
-      const int t = (a.d[i].transposed >= 2) ? a.d[i].N : a.d[i].nrows * (a.d[i].KP + 4);
+      const int t = (a.d[i].transposed >= 2) ? a.d[i].N : a.d[i].nrows * (a.d[i].partial ? a.d[i].K : a.d[i].KP + 4);
       if (t > maxtot) maxtot = t;
     }
     int gx = (maxtot + 255) / 256;
