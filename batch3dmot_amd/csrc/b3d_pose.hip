@@ -39,36 +39,51 @@ static const bool kLinOnEdges[LIN_COUNT] = {1, 1, 1, 0, 0, 0, 1, 1, 1, 1, 1, 1, 
 enum { WJ_EU0A, WJ_EU0B, WJ_EU1, WJ_EU2, WJ_PA0A, WJ_PA0B, WJ_PA1, WJ_FU0A, WJ_FU0B, WJ_FU1,
        WJ_CF0A, WJ_CF0B, WJ_CF1, WJ_CF2,
        // narrow stacks (one application each): classifier, node encoder, edge encoder
-       WJ_C3, WJ_C2, WJ_C1, WJ_C0, WJ_NE2, WJ_NE1, WJ_NE0, WJ_EE2, WJ_EE1, WJ_EE0, WJ_COUNT };
-constexpr int kWjBig = WJ_C3;              // jobs [0, kWjBig) share ~2048 tasks in proportion to their work
+       WJ_C3, WJ_C2, WJ_C1, WJ_C0, WJ_NE2, WJ_NE1, WJ_NE0, WJ_EE2, WJ_EE1, WJ_EE0,
+       // hoisted first layers (replace WJ_*0A / WJ_*0B): edge columns contract over edges ...
+       WJ_HEU0E, WJ_HFU0E, WJ_HPA0E,
+       // ... node columns over nodes (G = column blocks of dT)
+       WJ_HEU0XI, WJ_HEU0XJ, WJ_HFU0X, WJ_HFU0X0, WJ_HPA0X, WJ_HPA0X0, WJ_COUNT };
+constexpr int kWjBig = WJ_C3;              // jobs [0, kWjBig) and the WJ_H*E jobs share ~2048 tasks in proportion to their work
+constexpr int kHoistNodeRowsPerTask = 64;
+// Column blocks of edge_update.0 / create_*_msgs.0 gradients that the hoisted jobs produce separately
+// (own slab each: node- and edge-level jobs have different task counts)
+enum { VL_EU0E, VL_FU0E, VL_PA0E, VL_EU0XI, VL_EU0XJ, VL_FU0X, VL_FU0X0, VL_PA0X, VL_PA0X0, VL_COUNT };
 constexpr int kNarrowRowsPerTask = 512;
 constexpr int kWsTaskCap = 65536;          // entries of the task -> job table in the workspace
 struct WsPlan {
   int shape[WJ_COUNT], lin[WJ_COUNT], rows[WJ_COUNT], nvar[WJ_COUNT], rows_per_task[WJ_COUNT], ntasks[WJ_COUNT];
 };
-static WsPlan ws_plan(int N, int E, int depth, bool layer_mode);
+static WsPlan ws_plan(int N, int E, int depth, bool layer_mode, bool hoist);
 
-static WsPlan ws_plan(int N, int E, int depth, bool layer_mode) {
+static WsPlan ws_plan(int N, int E, int depth, bool layer_mode, bool hoist) {
   WsPlan p;
   const int shp[WJ_COUNT] = {WS_96_48_16, WS_96_32_32, WS_64_96, WS_32_64, WS_96_48_16, WS_96_48_16, WS_64_96,
                              WS_96_48_16, WS_96_48_16, WS_64_96, WS_96_64, WS_96_64, WS_64_96, WS_48_64,
-                             WS_16_16, WS_16_16, WS_16_16, WS_16_32, WS_48_48, WS_48_32, WS_32_32, WS_32_16, WS_16_16, WS_16_16};
+                             WS_16_16, WS_16_16, WS_16_16, WS_16_32, WS_48_48, WS_48_32, WS_32_32, WS_32_16, WS_16_16, WS_16_16,
+                             WS_96_32, WS_96_32, WS_96_32, WS_96_48, WS_96_48, WS_96_48, WS_96_48, WS_96_48, WS_96_48};
+  // lin: index into PoseWs::lin for [0, WJ_HEU0E), into PoseWs::vlin for the hoisted jobs
   const int lin[WJ_COUNT] = {LIN_EU0, LIN_EU0, LIN_EU1, LIN_EU2, LIN_PA0, LIN_PA0, LIN_PA1,
                              LIN_FU0, LIN_FU0, LIN_FU1, LIN_CF0, LIN_CF0, LIN_CF1, LIN_CF2,
-                             LIN_C3, LIN_C2, LIN_C1, LIN_C0, LIN_NE2, LIN_NE1, LIN_NE0, LIN_EE2, LIN_EE1, LIN_EE0};
+                             LIN_C3, LIN_C2, LIN_C1, LIN_C0, LIN_NE2, LIN_NE1, LIN_NE0, LIN_EE2, LIN_EE1, LIN_EE0,
+                             VL_EU0E, VL_FU0E, VL_PA0E, VL_EU0XI, VL_EU0XJ, VL_FU0X, VL_FU0X0, VL_PA0X, VL_PA0X0};
+  auto proportional = [](int i) { return i < kWjBig || (i >= WJ_HEU0E && i <= WJ_HPA0E); };
   double total = 0;
   for (int i = 0; i < WJ_COUNT; ++i) {
     p.shape[i] = shp[i];
     p.lin[i] = lin[i];
-    const bool on_nodes = (i >= WJ_CF0A && i <= WJ_CF2) || (i >= WJ_NE2 && i <= WJ_NE0);
+    const bool on_nodes = (i >= WJ_CF0A && i <= WJ_CF2) || (i >= WJ_NE2 && i <= WJ_NE0) || i >= WJ_HEU0XI;
     p.rows[i] = on_nodes ? N : E;
-    if (i >= kWjBig) p.nvar[i] = layer_mode ? 0 : 1;
+    const bool first_layer_unsplit = i == WJ_EU0A || i == WJ_EU0B || i == WJ_PA0A || i == WJ_PA0B || i == WJ_FU0A || i == WJ_FU0B;
+    if (i >= WJ_HEU0E) p.nvar[i] = !hoist ? 0 : (i == WJ_HEU0E || i == WJ_HEU0XI || i == WJ_HEU0XJ) ? depth : depth - 1;
+    else if (i >= kWjBig) p.nvar[i] = layer_mode ? 0 : 1;
+    else if (hoist && first_layer_unsplit) p.nvar[i] = 0;
     else p.nvar[i] = layer_mode ? 1 : (i <= WJ_EU2) ? depth : depth - 1;   // standalone layer: every stack once
-    if (i < kWjBig) total += (double)p.rows[i] * ws_shape_blocks(shp[i]) * (p.nvar[i] > 0 ? p.nvar[i] : 0);
+    if (proportional(i)) total += (double)p.rows[i] * ws_shape_blocks(shp[i]) * (p.nvar[i] > 0 ? p.nvar[i] : 0);
   }
   for (int i = 0; i < WJ_COUNT; ++i) {
     long rpt;
-    if (i < kWjBig) {
+    if (proportional(i)) {
       const double work = (double)p.rows[i] * ws_shape_blocks(shp[i]) * (p.nvar[i] > 0 ? p.nvar[i] : 0);
       long t = (long)(2048.0 * work / (total > 0 ? total : 1) + 0.5);
       const long maxt = (p.rows[i] + 15) / 16;
@@ -76,6 +91,8 @@ static WsPlan ws_plan(int N, int E, int depth, bool layer_mode) {
       if (t < 1) t = 1;
       rpt = ((p.rows[i] + t - 1) / t + 3) / 4 * 4;
       if (rpt < 4) rpt = 4;
+    } else if (i >= WJ_HEU0XI) {
+      rpt = kHoistNodeRowsPerTask;           // N rows x depth layers per task
     } else {
       rpt = kNarrowRowsPerTask;              // load-latency bound tasks: a fixed, short row range each
     }
@@ -115,6 +132,7 @@ struct PoseWs {
   int iota_n;
   float *gc_top, *gc3, *gc2, *gc1, *ge2, *ge1, *gn_top, *gn2, *gn1;
   LinSlab lin[LIN_COUNT];
+  LinSlab vlin[VL_COUNT];   // hoisted first layers: column blocks of edge_update.0 / create_*_msgs.0
   KnnWs knn;
   size_t bytes;
   bool ok;
@@ -221,10 +239,10 @@ static void carve(PoseWs& w, void* ws, size_t ws_bytes, int N, int E, int depth,
     w.iota_n = (E > N ? E : N) + 64;
     w.iota = c.take<int>((size_t)w.iota_n);
     w.zrow = c.take<float>(256);
-    w.ws_table = c.take<WsJob>(32);
+    w.ws_table = c.take<WsJob>(48);
     w.ws_task_job = c.take<int>(kWsTaskCap);
     // weight-gradient slabs; chunk / task counts are a pure function of (N, E, depth)
-    w.plan = ws_plan(N, E, depth, (flags & kFlagLayerMode) != 0);
+    w.plan = ws_plan(N, E, depth, (flags & kFlagLayerMode) != 0, w.hoist);
     for (int i = 0; i < LIN_COUNT; ++i) {
       LinSlab& ls = w.lin[i];
       ls.N = kLinDims[i].N; ls.K = kLinDims[i].K;
@@ -234,6 +252,14 @@ static void carve(PoseWs& w, void* ws, size_t ws_bytes, int N, int E, int depth,
       for (int jx = WJ_COUNT - 1; jx >= 0; --jx)
         if (w.plan.lin[jx] == i) ls.nchunks = w.plan.ntasks[jx];
       ls.slab = c.take<float>(wg_slab_floats(ls.nchunks, ls.NP, ls.KP));
+      ls.used = false;
+    }
+    for (int v = 0; v < VL_COUNT; ++v) {
+      LinSlab& ls = w.vlin[v];
+      ls.N = D::EH1; ls.K = (v <= VL_PA0E) ? D::DE : D::DX;
+      ls.NP = pad16(ls.N); ls.KP = pad16(ls.K);
+      ls.nchunks = w.plan.ntasks[WJ_HEU0E + v];
+      ls.slab = w.hoist ? c.take<float>(wg_slab_floats(ls.nchunks, ls.NP, ls.KP)) : nullptr;
       ls.used = false;
     }
   }
@@ -364,6 +390,7 @@ struct MpGradSrc {
   long xs, es;
   const float *GdH1, *GdH2, *Gde, *GdP1, *GdF1, *dM, *GnH1, *GnH2, *Gdx;
   const float *sH1, *sH2, *sP1, *sF1, *M, *nH1, *nH2;
+  const float* dT;          // hoisted first layers: [depth][N, TW] per-node gradient of T
   const float* e_last;      // e[depth]: input of the classifier (whole model only)
   const float* de0;         // gradient of e[0] = G of edge_encoder.4 (whole model only)
   bool have_logit_grad;
@@ -374,7 +401,7 @@ static int mp_weight_grads(PoseWs& w, const MpGradSrc& ms, int N, int E, const i
   const size_t nLm = (size_t)N * D::NIN, nLx = (size_t)N * D::DX, nL1 = (size_t)N * D::NH1, nL2 = (size_t)N * D::NH2;
   (void)eLe; (void)nLx;
     WsLauncher wl;
-    wl.begin(w.ws_table, 32, w.ws_task_job, kWsTaskCap, stream);
+    wl.begin(w.ws_table, 48, w.ws_task_job, kWsTaskCap, stream);
     // w.iota / w.zrow were filled by the forward's pack launch
     const int* iota = w.iota;
     auto sg = [iota](const float* p, const int* idx, long vstride, int stride, int col0) {
@@ -383,16 +410,16 @@ static int mp_weight_grads(PoseWs& w, const MpGradSrc& ms, int N, int E, const i
     const WsSeg none = sg(nullptr, nullptr, 0, 0, 0);
     auto add = [&](int wj, const WsSeg& gseg, const WsSeg& a0, int c0, const WsSeg& a1, int c1, bool bias) {
       if (w.plan.nvar[wj] <= 0) return;
-      const int lin = w.plan.lin[wj];
+      LinSlab& ls = (wj >= WJ_HEU0E) ? w.vlin[w.plan.lin[wj]] : w.lin[w.plan.lin[wj]];
       WsJob jb;
       memset(&jb, 0, sizeof(jb));
       jb.g = gseg; jb.act[0] = a0; jb.act[1] = a1; jb.act[2] = a1;
       jb.wcol[0] = c0; jb.wcol[1] = c1; jb.wcol[2] = 0; jb.wrow = 0; jb.write_bias = bias ? 1 : 0;
       jb.shape = w.plan.shape[wj]; jb.rows = w.plan.rows[wj]; jb.nvar = w.plan.nvar[wj];
       jb.rows_per_task = w.plan.rows_per_task[wj]; jb.ntasks = w.plan.ntasks[wj];
-      jb.NP = w.lin[lin].NP; jb.KP = w.lin[lin].KP; jb.slab = w.lin[lin].slab;
+      jb.NP = ls.NP; jb.KP = ls.KP; jb.slab = ls.slab;
       wl.add(jb);
-      w.lin[lin].used = true;
+      ls.used = true;
     };
     const float* x0 = ms.x0;
     auto xrow = [&](const int* idx, int c0) { return sg(ms.x, idx, ms.xs, D::DX, c0); };      // x[l][idx], columns c0..
@@ -419,6 +446,20 @@ static int mp_weight_grads(PoseWs& w, const MpGradSrc& ms, int N, int E, const i
     add(WJ_FU1, sg(ms.dM, src, nLm, D::NIN, D::DM), sg(ms.sF1, nullptr, eLm, D::MH, 0), 0, none, 0, true);
     add(WJ_CF1, sg(ms.GnH2, nullptr, nL2, D::NH2, 0), sg(ms.nH1, nullptr, nL1, D::NH1, 0), 0, none, 0, true);
     add(WJ_CF2, sg(ms.Gdx, nullptr, nLx, D::DX, 0), sg(ms.nH2, nullptr, nL2, D::NH2, 0), 0, none, 0, true);
+    // hoisted first layers (nvar == 0 otherwise): edge columns over edges, node columns over nodes
+    {
+      const long tLs = (long)N * HP::TW;
+      auto tcol = [&](int off) { return sg(ms.dT, nullptr, tLs, HP::TW, off); };
+      add(WJ_HEU0E, gH1, erow(0, 0), 0, none, 0, true);
+      add(WJ_HFU0E, gF1, erow(1, 0), 0, none, 0, true);
+      add(WJ_HPA0E, gP1, erow(1, 0), 0, none, 0, true);
+      add(WJ_HEU0XI, tcol(HP::OA), xrow(nullptr, 0), 0, none, 0, false);
+      add(WJ_HEU0XJ, tcol(HP::OB), xrow(nullptr, 0), 0, none, 0, false);
+      add(WJ_HFU0X, tcol(HP::OF), xrow(nullptr, 0), 0, none, 0, false);
+      add(WJ_HFU0X0, tcol(HP::OF), x0row(nullptr), 0, none, 0, false);
+      add(WJ_HPA0X, tcol(HP::OP), xrow(nullptr, 0), 0, none, 0, false);
+      add(WJ_HPA0X0, tcol(HP::OP), x0row(nullptr), 0, none, 0, false);
+    }
     // narrow stacks (whole model only; nvar == 0 in layer mode).  Row strides pad every width to 16, the
     // padding columns only reach slab entries outside [N, K], which the reduce never reads.
     auto narrow = [&](int wj, const float* gp, int gstride, const float* ap, int astride) {
@@ -731,7 +772,7 @@ extern "C" int b3d_pose_backward(const b3d_pose_weights* pw, const b3d_graph* g,
     ms.GdH1 = w.GdH1; ms.GdH2 = w.GdH2; ms.Gde = w.Gde; ms.GdP1 = w.GdP1; ms.GdF1 = w.GdF1; ms.dM = w.dM;
     ms.GnH1 = w.GnH1; ms.GnH2 = w.GnH2; ms.Gdx = w.Gdx;
     ms.sH1 = w.sH1[0]; ms.sH2 = w.sH2[0]; ms.sP1 = w.sP1[0]; ms.sF1 = w.sF1[0]; ms.M = w.M[0]; ms.nH1 = w.nH1[0]; ms.nH2 = w.nH2[0];
-    ms.e_last = w.e[depth]; ms.de0 = w.de[cur]; ms.have_logit_grad = d_logits != nullptr;
+    ms.e_last = w.e[depth]; ms.de0 = w.de[cur]; ms.have_logit_grad = d_logits != nullptr; ms.dT = w.dT;
     B3D_TRY(mp_weight_grads(w, ms, N, E, src, dst, stream));
   }
 
@@ -748,6 +789,26 @@ extern "C" int b3d_pose_backward(const b3d_pose_weights* pw, const b3d_graph* g,
         LinSlab& ls = w.lin[first[gi] + i];
         float* dw = groups[gi][i].w;
         float* db = groups[gi][i].b;
+        const int li = first[gi] + i;
+        if (w.hoist && (li == LIN_EU0 || li == LIN_PA0 || li == LIN_FU0)) {
+          // the gradient of a hoisted first layer arrives as three column blocks with slabs of their own
+          struct Part { int vl, col; bool bias; };
+          const Part eu[3] = {{VL_EU0XI, 0, false}, {VL_EU0XJ, D::DX, false}, {VL_EU0E, 2 * D::DX, true}};
+          const Part fu[3] = {{VL_FU0X, 0, false}, {VL_FU0E, D::DX, true}, {VL_FU0X0, D::DX + D::DE, false}};
+          const Part pa[3] = {{VL_PA0X, 0, false}, {VL_PA0E, D::DX, true}, {VL_PA0X0, D::DX + D::DE, false}};
+          const Part* parts = (li == LIN_EU0) ? eu : (li == LIN_FU0) ? fu : pa;
+          if (!w.vlin[parts[0].vl].used) {       // depth == 1: the message stacks receive no gradient
+            if (dw) B3D_HIP_CHECK(hipMemsetAsync(dw, 0, (size_t)ls.N * ls.K * sizeof(float), stream));
+            if (db) B3D_HIP_CHECK(hipMemsetAsync(db, 0, (size_t)ls.N * sizeof(float), stream));
+            continue;
+          }
+          for (int k = 0; k < 3; ++k) {
+            RedEntry e = red_entry(w.vlin[parts[k].vl], dw ? dw + parts[k].col : nullptr, parts[k].bias ? db : nullptr);
+            e.ld = ls.K;
+            ra.e[ra.nentries++] = e;
+          }
+          continue;
+        }
         if (!ls.used) {
           // no gradient reached this layer (e.g. d_logits == NULL, or depth == 1 for the message stacks)
           if (dw) B3D_HIP_CHECK(hipMemsetAsync(dw, 0, (size_t)ls.N * ls.K * sizeof(float), stream));
@@ -938,7 +999,7 @@ extern "C" int b3d_pose_layer_backward(const b3d_mp_weights* mw, const b3d_graph
   ms.GdH1 = w.GdH1; ms.GdH2 = w.GdH2; ms.Gde = w.Gde; ms.GdP1 = w.GdP1; ms.GdF1 = w.GdF1; ms.dM = w.dM;
   ms.GnH1 = w.GnH1; ms.GnH2 = w.GnH2; ms.Gdx = d_x_new;
   ms.sH1 = w.sH1[0]; ms.sH2 = w.sH2[0]; ms.sP1 = w.sP1[0]; ms.sF1 = w.sF1[0]; ms.M = w.M[0]; ms.nH1 = w.nH1[0]; ms.nH2 = w.nH2[0];
-  ms.e_last = nullptr; ms.de0 = nullptr; ms.have_logit_grad = false;
+  ms.e_last = nullptr; ms.de0 = nullptr; ms.have_logit_grad = false; ms.dT = nullptr;
   B3D_TRY(mp_weight_grads(w, ms, N, E, g->src, g->dst, stream));
   RedArgs ra;
   ra.nentries = 0;
