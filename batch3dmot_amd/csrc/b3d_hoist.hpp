@@ -292,14 +292,17 @@ struct GradProjLds {
   static constexpr int BYTES = kLdsBytes + TB * 64 * 16;
 };
 
+constexpr int kGradProjWaves = 8;      // two wavefronts per list (three feature blocks each): the by-source lists of a
+                                       // tracking graph reach 40+ entries and set the kernel's critical path
+
 template <class D>
-__global__ __launch_bounds__(kNodeWaves * 64, 1) void node_gradproj_kernel(const NodeGradProjArgs a) {
+__global__ __launch_bounds__(kGradProjWaves * 64, 1) void node_gradproj_kernel(const NodeGradProjArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   using H = Hoist<D>;
   using Seq = typename H::GradProjSeq;
-  constexpr int NWS = kNodeWaves;
-  static_assert(NWS == 4 && D::EH1 == D::MH, "one list per wavefront, equal widths");
-  constexpr int LB = D::EH1 / 16, TB = H::TW / 16;
+  constexpr int NWS = kGradProjWaves;
+  static_assert(NWS == 8 && D::EH1 == D::MH && (D::EH1 / 16) % 2 == 0, "two wavefronts per list, equal widths");
+  constexpr int LB = D::EH1 / 16, HB = LB / 2, TB = H::TW / 16;
   WStreamT<NWS * 64> ws;
   ws.init(a.wpack, smem);
   ws.template start<Seq>();
@@ -308,19 +311,20 @@ __global__ __launch_bounds__(kNodeWaves * 64, 1) void node_gradproj_kernel(const
   const long row = (long)blockIdx.x * 16 + (lane & 15);
   const bool valid = row < a.N;
   {
-    v4f part[LB];
+    const int list = wave & 3, half = wave >> 2;             // list: dH1 by dst, dH1 by src, dF1 by dst, dP1 by src
+    v4f part[HB];
 #pragma unroll
-    for (int b = 0; b < LB; ++b) part[b] = v4f{0.f, 0.f, 0.f, 0.f};
-    const float* base = (wave < 2) ? a.GdH1 : (wave == 2 ? a.GdF1 : a.GdP1);
-    const bool by_dst = (wave == 0 || wave == 2);
+    for (int b = 0; b < HB; ++b) part[b] = v4f{0.f, 0.f, 0.f, 0.f};
+    const float* base = (list < 2) ? a.GdH1 : (list == 2 ? a.GdF1 : a.GdP1);
+    const bool by_dst = (list == 0 || list == 2);
     if (valid && base) {
-      constexpr int U = LB <= 6 ? 4 : 2;
-      if (by_dst) segment_sum_deep<LB, U>(base, 16 * LB, 0, a.dst_perm, a.dst_ptr[row], a.dst_ptr[row + 1], part);
-      else segment_sum_deep<LB, U>(base, 16 * LB, 0, a.src_perm, a.src_ptr[row], a.src_ptr[row + 1], part);
+      constexpr int U = HB <= 3 ? 8 : 4;
+      if (by_dst) segment_sum_deep<HB, U>(base, 16 * LB, 16 * HB * half, a.dst_perm, a.dst_ptr[row], a.dst_ptr[row + 1], part);
+      else segment_sum_deep<HB, U>(base, 16 * LB, 16 * HB * half, a.src_perm, a.src_ptr[row], a.src_ptr[row + 1], part);
     }
 #pragma unroll
-    for (int b = 0; b < LB; ++b) xb[(wave * LB + b) * 64 + lane] = part[b];
-    store_row<LB>(a.dT, row, H::TW, 16 * LB * wave, valid, part);
+    for (int b = 0; b < HB; ++b) xb[(list * LB + half * HB + b) * 64 + lane] = part[b];
+    store_row<HB>(a.dT, row, H::TW, 16 * (LB * list + HB * half), valid, part);
   }
   v4f dt[TB];
   linear_split<Seq, 0, false, false, NWS>(
