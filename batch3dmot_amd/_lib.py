@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libb3d_hip.so")
 B3D_FLAG_TRAINING = 1
 B3D_FLAG_RUN_DEAD_KNN = 2
 B3D_FLAG_SINGLE_STREAM = 4
+B3D_FLAG_DEFER_SIDE_JOIN = 8
 
 c_float_p = C.POINTER(C.c_float)
 
@@ -151,6 +152,8 @@ def load() -> C.CDLL:
     lib.b3d_clr_layer_forward.argtypes = [C.POINTER(b3d_mp_weights), C.POINTER(b3d_graph), C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
                                           C.c_void_p]
+    lib.b3d_side_join.restype = C.c_int
+    lib.b3d_side_join.argtypes = [C.c_void_p]
     lib.b3d_prof_enable.argtypes = [C.c_int]
     lib.b3d_prof_select.argtypes = [C.c_uint32]
     lib.b3d_prof_select.restype = C.c_int
@@ -255,3 +258,24 @@ def knn_gat(x: torch.Tensor, node_timestamps: torch.Tensor, conv, k: int = 20):
     check(lib.b3d_knn_gat_forward(x.data_ptr(), ts.data_ptr(), n, d, k, C.byref(g), ws.data_ptr(), nbytes,
                                   nbr.data_ptr(), cnt.data_ptr(), y.data_ptr(), current_stream(x.device)), "b3d_knn_gat_forward")
     return nbr, cnt, y
+
+
+class Workspace:
+    """Owner of a forward's workspace tensor.  A training forward may return while the discarded k-NN
+    block is still running on the library's side stream (B3D_FLAG_DEFER_SIDE_JOIN); backward joins
+    it.  If backward never runs, the join happens here, BEFORE the tensor goes back to the caching
+    allocator, so the block can never write into memory that has been handed to someone else."""
+
+    def __init__(self, tensor: torch.Tensor, pending: bool):
+        self.tensor = tensor
+        self.pending = pending
+
+    def joined(self) -> None:
+        self.pending = False
+
+    def __del__(self):
+        if getattr(self, "pending", False):
+            try:
+                check(load().b3d_side_join(current_stream(self.tensor.device)), "b3d_side_join")
+            except Exception:
+                torch.cuda.synchronize(self.tensor.device)

@@ -106,6 +106,22 @@ int side_join(Side* sd, hipStream_t main) {
 
 }  // namespace b3d
 
+extern "C" int b3d_side_join(b3d_stream stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int dev = 0;
+  B3D_HIP_CHECK(hipGetDevice(&dev));
+  for (int i = 0; i < b3d::kSideStreams; ++i) {
+    b3d::Side* sd = nullptr;
+    {
+      std::lock_guard<std::mutex> lk(b3d::g_side_mu);
+      if (dev < 0 || dev >= b3d::kMaxDevices || !b3d::g_sides[dev].made[i]) continue;
+      sd = &b3d::g_sides[dev].sd[i];
+    }
+    B3D_TRY(b3d::side_join(sd, stream));
+  }
+  return B3D_OK;
+}
+
 extern "C" int b3d_prof_enable(int on) {
   auto& p = b3d::prof();
   std::lock_guard<std::mutex> lk(p.mu);

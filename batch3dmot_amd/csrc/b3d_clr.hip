@@ -472,7 +472,7 @@ extern "C" int b3d_clr_forward(const b3d_clr_weights* pw, const b3d_graph* g, co
     B3D_TRY(launch_rows<kNWEdge>(chain_fwd_kernel<SeqCls, 0x7u, LoadAligned<4>, StoreScalar, kNWEdge>, "edge_classifier", a, E, stream, B3D_K_OTHER, chain_lds<SeqCls>()));
     B3D_HIP_CHECK(hipMemcpyAsync(out_prob, w.prob, (size_t)E * sizeof(float), hipMemcpyDeviceToDevice, stream));
   }
-  if (knn_side) B3D_TRY(side_join(knn_side, stream));
+  if (knn_side && !((flags & B3D_FLAG_DEFER_SIDE_JOIN) && (flags & B3D_FLAG_TRAINING))) B3D_TRY(side_join(knn_side, stream));
   return B3D_OK;
 }
 
@@ -741,6 +741,7 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
     }
     B3D_TRY(launch_reduce(ra, stream));
   }
+  B3D_TRY(b3d_side_join(stream_));
   return B3D_OK;
 }
 

@@ -614,7 +614,7 @@ extern "C" int b3d_pose_forward(const b3d_pose_weights* pw, const b3d_graph* g, 
     a.wpack = w.wp_cls;
     B3D_TRY(launch_rows<kNWEdge>(chain_fwd_kernel<SeqCls, 0x7u, LoadAligned<2>, StoreScalar, kNWEdge>, "edge_classifier", a, E, stream, B3D_K_OTHER, chain_lds<SeqCls>()));
   }
-  if (knn_side) B3D_TRY(side_join(knn_side, stream));
+  if (knn_side && !((flags & B3D_FLAG_DEFER_SIDE_JOIN) && (flags & B3D_FLAG_TRAINING))) B3D_TRY(side_join(knn_side, stream));
   return B3D_OK;
 }
 
@@ -819,6 +819,7 @@ extern "C" int b3d_pose_backward(const b3d_pose_weights* pw, const b3d_graph* g,
       }
     B3D_TRY(launch_reduce(ra, stream));
   }
+  B3D_TRY(b3d_side_join(stream_));      // a B3D_FLAG_DEFER_SIDE_JOIN forward left the k-NN block running under this sweep
   return B3D_OK;
 }
 

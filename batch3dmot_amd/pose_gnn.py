@@ -13,7 +13,7 @@ import torch
 from torch import nn
 
 from . import _lib
-from ._lib import B3D_FLAG_RUN_DEAD_KNN, B3D_FLAG_SINGLE_STREAM, B3D_FLAG_TRAINING
+from ._lib import B3D_FLAG_DEFER_SIDE_JOIN, B3D_FLAG_RUN_DEAD_KNN, B3D_FLAG_SINGLE_STREAM, B3D_FLAG_TRAINING
 
 
 def _mlp(dims, inplace_relu=False):
@@ -110,6 +110,11 @@ class _PoseGNNFunction(torch.autograd.Function):
         N, E = graph.N, graph.E
         flags = ((B3D_FLAG_TRAINING if training else 0) | (B3D_FLAG_RUN_DEAD_KNN if module.run_dead_knn else 0)
                  | (B3D_FLAG_SINGLE_STREAM if module.single_stream else 0))
+        # optional: let the discarded k-NN block run on under the loss and the backward sweep (measured on
+        # MI355X: 4 % slower than joining at the end of forward -- it delays the start of every backward kernel)
+        defer = bool(training and module.run_dead_knn and not module.single_stream and module.defer_knn_join)
+        if defer:
+            flags |= B3D_FLAG_DEFER_SIDE_JOIN
         nbytes = lib.b3d_pose_workspace_bytes(N, E, module.depth, flags)
         if nbytes == 0:
             raise ValueError(f"unsupported gnn_depth {module.depth} (1..15)")
@@ -128,6 +133,7 @@ class _PoseGNNFunction(torch.autograd.Function):
                    "b3d_pose_forward")
         ctx.set_materialize_grads(False)
         ctx.module, ctx.graph, ctx.ws, ctx.nbytes, ctx.flags = module, graph, ws, nbytes, flags
+        ctx.ws_owner = _lib.Workspace(ws, defer)
         ctx.params, ctx.inputs, ctx.keep = params, (pose_feats, edge_attr), gat
         module._last_workspace = (ws, nbytes, flags, N, E) if module.keep_workspace else None
         return logits, x_enc
@@ -152,6 +158,7 @@ class _PoseGNNFunction(torch.autograd.Function):
                                          ctx.module.depth, ctx.ws.data_ptr(), ctx.nbytes, _lib.ptr(d_logits),
                                          _lib.ptr(d_x_enc), C.byref(g), _lib.current_stream(dev)),
                    "b3d_pose_backward")
+        ctx.ws_owner.joined()              # backward joined the library's side stream into this stream
         if sink is not None:
             sink.deposited()
             return (None,) * (6 + len(params))
@@ -182,6 +189,7 @@ class PoseGNN(nn.Module):
         self.message_passing = CausalMessagePassing()
         self.run_dead_knn = True
         self.single_stream = False     # True: no library side stream (B3D_FLAG_SINGLE_STREAM)
+        self.defer_knn_join = False    # True: B3D_FLAG_DEFER_SIDE_JOIN in training forwards
         self.keep_workspace = False
         self._last_workspace = None
         self._grad_sink = None          # set by optim.FlatAdam: backward writes gradients into its flat buffer

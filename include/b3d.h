@@ -103,6 +103,11 @@ typedef struct b3d_pose_grads {
 #define B3D_FLAG_TRAINING      1u   /* keep what backward needs in the workspace            */
 #define B3D_FLAG_RUN_DEAD_KNN  2u   /* execute the frame-wise k-NN + GAT block whose result the
                                        reference discards (pose_gnn.py:74-80)                 */
+#define B3D_FLAG_DEFER_SIDE_JOIN 8u  /* training forwards only: return while the discarded k-NN + GAT block may still be
+                                       running on the library's side stream, so that it overlaps the loss and the
+                                       backward sweep.  The caller MUST keep `workspace` alive and untouched until
+                                       b3d_pose_backward / b3d_clr_backward on it has been enqueued (it joins the side
+                                       stream into its `stream`), or call b3d_side_join(stream) before releasing it */
 #define B3D_FLAG_SINGLE_STREAM 4u   /* enqueue every kernel on `stream` itself.  By default work with
                                        no consumer until the end of the call (the discarded k-NN +
                                        GAT block) runs on a library-owned side stream that is forked
@@ -242,6 +247,10 @@ int b3d_edge_loss(const float* out, const void* y, int y_is_int64, const float* 
  * corrections from `step` = 1, 2, ...; amsgrad off).  All four arrays [n] on the device. */
 int b3d_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                   float beta1, float beta2, float eps, float weight_decay, int64_t step, b3d_stream stream);
+
+/* Make `stream` wait for everything the library has enqueued on its side streams of the current device
+ * (pending work of a B3D_FLAG_DEFER_SIDE_JOIN forward).  Cheap when nothing is pending. */
+int b3d_side_join(b3d_stream stream);
 
 /* ---- kernel-family timers (measurement aid for bench.py; off by default) --------------------
  * When enabled, every launch of the listed kernel families is bracketed by hipEventRecord on the
