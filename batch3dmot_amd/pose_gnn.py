@@ -188,7 +188,9 @@ class PoseGNN(nn.Module):
         self.knn_conv = GATConvParams(48)
         self.message_passing = CausalMessagePassing()
         self.run_dead_knn = True
-        self.single_stream = False     # True: no library side stream (B3D_FLAG_SINGLE_STREAM)
+        # True (default): every kernel on the caller's stream.  False: the discarded k-NN block runs on the
+        # library's side stream (worth ~4 % before the first layers were hoisted; now it only adds jitter)
+        self.single_stream = True
         self.defer_knn_join = False    # True: B3D_FLAG_DEFER_SIDE_JOIN in training forwards
         self.keep_workspace = False
         self._last_workspace = None

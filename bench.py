@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-dead-knn", action="store_true",
                     help="skip the k-NN + GAT block whose result the reference discards (secondary figure)")
+    ap.add_argument("--side-stream", action="store_true", help="run the discarded k-NN block on the library's side stream (diagnostic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=50)
     args = ap.parse_args()
@@ -80,6 +81,7 @@ def main():
     torch.manual_seed(5621)                      # gnn.manual_seed, pose_config.yaml:96
     model = PoseGNN().to(dev)
     model.run_dead_knn = not args.no_dead_knn
+    model.single_stream = not args.side_stream
     model.train()
     opt = make_optimizer(model)                  # Adam(lr 1e-4, wd 1e-4, betas .9/.999): train.py:106-109 (optim.FlatAdam)
     sync = FlatGradSync(model.parameters(), flat=opt if hasattr(opt, "flat_grad") else None) if world > 1 else None
@@ -144,6 +146,17 @@ def main():
         flops = {"mp_edge_fwd": 2.0 * MAC_EDGE * e_avg, "mp_edge_bwd": 2.0 * MAC_EDGE * e_avg,
                  "wgrad_edge": 2.0 * (e_avg * (mac_eu * depth + mac_msg * (depth - 1)) + n_nodes * MAC_NODE * (depth - 1)),
                  "mp_node_fwd": 2.0 * MAC_NODE * n_nodes, "mp_node_bwd": 2.0 * MAC_NODE * n_nodes}
+        # FLOPs the kernels actually execute: the three first layers are hoisted (csrc/b3d_hoist.hpp): their
+        # node columns are multiplied per node (N rows) instead of per edge, 29,696 MAC/edge/layer remain
+        mac_eu_x = 32 * 96 + 96 * 64 + 64 * 32
+        mac_msg_x = 2 * (32 * 96 + 96 * 64)
+        mac_node_tab = 48 * 384                                   # per-node table of the next layer
+        mac_node_gp = 384 * 96                                    # per-node (dx | dx0) from the gradient of the table
+        executed = {"mp_edge_fwd": 2.0 * (mac_eu_x + mac_msg_x) * e_avg, "mp_edge_bwd": 2.0 * (mac_eu_x + mac_msg_x) * e_avg,
+                    "wgrad_edge": 2.0 * (e_avg * (mac_eu_x * depth + mac_msg_x * (depth - 1))
+                                         + n_nodes * (MAC_NODE * (depth - 1) + 2 * 96 * 48 * depth + 4 * 96 * 48 * (depth - 1))),
+                    "mp_node_fwd": 2.0 * (MAC_NODE + mac_node_tab) * n_nodes,
+                    "mp_node_bwd": 2.0 * (MAC_NODE + mac_node_gp) * n_nodes / 2.0}   # two launches per layer
         # algorithmic bytes per launch (each logical tensor once, fp32, int32 indices)
         byts = {"mp_edge_fwd": e_avg * (8 + 4 * (32 + 32 + 64 + 64 + 352)),      # idx, e in/out, fut, past, saved hidden
                 "mp_edge_bwd": e_avg * (8 + 4 * (32 + 32 + 352 + 192 + 384)),    # de out/in, saved, per-edge node grads, G
@@ -153,11 +166,10 @@ def main():
                 "mp_node_bwd": e_avg * 4 * 192 + n_nodes * 4 * (128 + 48 + 48 + 160 + 208)}
         bound = {"mp_edge_fwd": "mfma", "mp_edge_bwd": "mfma", "wgrad_edge": "hbm", "mp_node_fwd": "hbm", "mp_node_bwd": "hbm"}
         # HBM bytes per launch measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of
-        # this command (profiles/r01_c_pmc_traffic.txt), FETCH_SIZE doubled as MI355X_MICROARCH.md
+        # this command (profiles/r01_e_pmc_traffic.txt), FETCH_SIZE doubled as MI355X_MICROARCH.md
         # prescribes for wide coalesced reads on gfx950.  Valid for the default workload only.
-        traffic_pmc = {"wgrad_edge": 2 * 451.77e6 * 1.024 + 51.67e6 * 1.024, "mp_edge_fwd": 2 * 5.755e6 * 1.024 + 62.16e6 * 1.024,
-                       "mp_edge_bwd": 2 * 26.44e6 * 1.024 + 74.79e6 * 1.024, "mp_node_fwd": 2 * 8.416e6 * 1.024 + 3.94e6 * 1.024,
-                       "mp_node_bwd": 2 * 13.48e6 * 1.024 + 4.5e6 * 1.024}
+        traffic_pmc = {"wgrad_edge": 776.2e6, "mp_edge_fwd": 81.0e6, "mp_edge_bwd": 104.9e6, "mp_node_fwd": 28.7e6,
+                       "mp_node_bwd": 31.9e6}
         def table(famd, steps):
             out = {}
             for name, (ms, n) in famd.items():
@@ -185,7 +197,12 @@ def main():
                     "traffic": round(traffic_pmc[dom]) if default_workload else None,
                     "avg_launch_us": kernels[dom]["avg_us"],
                     "algorithmic_flops_per_launch": flops[dom], "algorithmic_bytes_per_launch": byts[dom],
-                    "fp32_tflops": kernels[dom]["tflops"], "fp32_frac": round(kernels[dom]["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4)}
+                    "fp32_tflops": kernels[dom]["tflops"], "fp32_frac": round(kernels[dom]["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4),
+                    "executed_flops_per_launch": executed[dom],
+                    "executed_fp32_tflops": round(executed[dom] / (kernels[dom]["avg_us"] * 1e-6) / 1e12, 2),
+                    "flops_note": "achieved / fp32_tflops count the reference's ALGORITHMIC FLOPs (57,344 MAC per edge and layer); "
+                                  "the kernels execute fewer (executed_*): the node columns of the first layer of every "
+                                  "edge stack are evaluated per node instead of per edge"}
         if model.run_dead_knn and not model.single_stream and dom in ("mp_edge_fwd", "mp_node_fwd"):
             roofline["note"] = ("launch durations include CU sharing with the k-NN + GAT block that runs concurrently on "
                                 "the library's side stream; --no-dead-knn measures the kernel undisturbed")
