@@ -38,7 +38,9 @@ struct Hoist {
                               L<D::DE, D::EH2>, L<D::EH2, D::EH1>, L<D::EH1, KE>>;    // edge_update.4^T/.2^T/.0[e]^T
   using EdgeBwdSeqNoMsg = LayerSeq<L<D::DE, D::EH2>, L<D::EH2, D::EH1>, L<D::EH1, KE>>;
   // per-node gradient of (x | x0) from the gradient of T: [W_eu_i^T | W_eu_j^T | W_fu_x^T | W_pa_x^T ; 0 | 0 | W_fu_x0^T | W_pa_x0^T]
-  using GradProjSeq = LayerSeq<L<TW, 2 * D::DX>>;
+  // ... as four accumulating products, one per list (all output blocks of a product sit in one weight chunk,
+  // so every owning wavefront works at once): dH1-by-dst and dH1-by-src reach dx only
+  using GradProjSeq = LayerSeq<L<D::EH1, D::DX>, L<D::EH1, D::DX>, L<D::MH, 2 * D::DX>, L<D::MH, 2 * D::DX>>;
 };
 
 // Storer of the projection chain: the F | P columns receive the layer-invariant x0 terms.
@@ -292,6 +294,32 @@ struct GradProjLds {
   static constexpr int BYTES = kLdsBytes + TB * 64 * 16;
 };
 
+// (dx | dx0) = sum over the four lists of (node columns)^T . dT_list: layers LI0 .. LI0+3 of Seq.  The wavefront
+// that owns output block mb (mb % NWS == wave, the same in all four products) keeps its partial in `keep`.
+template <class Seq, int LI0, int NWS, int LB, class WS>
+__device__ __forceinline__ v4f gradproj_products(WS& ws, const v4f* __restrict__ xt, int lane) {
+  v4f keep = {0.f, 0.f, 0.f, 0.f};
+  v4f dt[LB];
+  auto acc = [&](int, v4f v) { keep += v; };
+  linear_split<Seq, LI0 + 0, false, false, NWS>(ws, false, dt, [&]() {
+#pragma unroll
+    for (int b = 0; b < LB; ++b) dt[b] = xt[(0 * LB + b) * 64 + lane];
+  }, acc);
+  linear_split<Seq, LI0 + 1, false, false, NWS>(ws, false, dt, [&]() {
+#pragma unroll
+    for (int b = 0; b < LB; ++b) dt[b] = xt[(1 * LB + b) * 64 + lane];
+  }, acc);
+  linear_split<Seq, LI0 + 2, false, false, NWS>(ws, false, dt, [&]() {
+#pragma unroll
+    for (int b = 0; b < LB; ++b) dt[b] = xt[(2 * LB + b) * 64 + lane];
+  }, acc);
+  linear_split<Seq, LI0 + 3, false, false, NWS>(ws, false, dt, [&]() {
+#pragma unroll
+    for (int b = 0; b < LB; ++b) dt[b] = xt[(3 * LB + b) * 64 + lane];
+  }, acc);
+  return keep;
+}
+
 constexpr int kGradProjWaves = 8;      // two wavefronts per list (three feature blocks each): the by-source lists of a
                                        // tracking graph reach 40+ entries and set the kernel's critical path
 
@@ -326,14 +354,120 @@ __global__ __launch_bounds__(kGradProjWaves * 64, 1) void node_gradproj_kernel(c
     for (int b = 0; b < HB; ++b) xb[(list * LB + half * HB + b) * 64 + lane] = part[b];
     store_row<HB>(a.dT, row, H::TW, 16 * (LB * list + HB * half), valid, part);
   }
-  v4f dt[TB];
-  linear_split<Seq, 0, false, false, NWS>(
-      ws, false, dt,
+  const v4f keep = gradproj_products<Seq, 0, NWS, LB>(ws, xb, lane);
+  if (wave < 2 * D::DX / 16) store_row<1>(a.gx, row, 2 * D::DX, 16 * wave, valid, &keep);
+  (void)TB;
+}
+
+// node_gradproj + the node update's data gradient in ONE launch (layers 0 .. depth-2): the per-node
+// (dx | dx0) never leaves the CU.  8 wavefronts per 16-row tile throughout.
+template <class D>
+using NodeBwdHSeq = LayerSeq<L<D::EH1, D::DX>, L<D::EH1, D::DX>, L<D::MH, 2 * D::DX>, L<D::MH, 2 * D::DX>,   // GradProj
+                             L<D::DX, D::NH2>, L<D::NH2, D::NH1>, L<D::NH1, D::NIN>>;          // combine_future_past^T
+struct NodeBwdHArgs {
+  NodeGradProjArgs gp;  // lists of layer l+1, dT of layer l+1 (gp.gx unused)
+  float* dx0_acc;       // [N, DX] running gradient of initial_x
+  int dx0_first;
+  const float* sH1;     // saved activations of layer l's node MLP
+  const float* sH2;
+  float* dM;            // [N, 2 DM]
+  float* Gdx;           // [N, DX]  G tensors of layer l's node MLP
+  float* GdH2;
+  float* GdH1;
+  const float* wpack;   // NodeBwdHSeq images
+};
+
+template <class D>
+struct NodeBwdHLds {
+  static constexpr int TB = Hoist<D>::TW / 16, PB = (D::NH1 > 2 * D::DX ? D::NH1 : 2 * D::DX) / 16;
+  static constexpr int BYTES = kLdsBytes + (TB + 2 * PB) * 64 * 16;
+};
+
+template <class D>
+__global__ __launch_bounds__(kGradProjWaves * 64, 1) void node_bwd_h_kernel(const NodeBwdHArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  using H = Hoist<D>;
+  using Seq = NodeBwdHSeq<D>;
+  constexpr int NWS = kGradProjWaves;
+  static_assert(NWS == 8 && D::EH1 == D::MH && (D::EH1 / 16) % 2 == 0, "two wavefronts per list, equal widths");
+  constexpr int LB = D::EH1 / 16, HB = LB / 2, TB = H::TW / 16;
+  constexpr int XB = D::DX / 16, GB = 2 * XB, H1B = D::NH1 / 16, H2B = D::NH2 / 16;
+  static_assert(GB <= NWS, "one output block of (dx | dx0) per wavefront");
+  constexpr int PB = NodeBwdHLds<D>::PB;
+  WStreamT<NWS * 64> ws;
+  ws.init(a.wpack, smem);
+  ws.template start<Seq>();
+  v4f* xt = reinterpret_cast<v4f*>(smem + 2 * kWBufFloats);   // dT tile
+  v4f* xb0 = xt + TB * 64;                                     // ping-pong for the stages behind it
+  v4f* xb1 = xb0 + PB * 64;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 16 + (lane & 15);
+  const bool valid = row < a.gp.N;
+  v4f act2[H2B], act1[H1B];
+  load_row<H2B>(a.sH2, row, D::NH2, 0, valid, act2);
+  load_row<H1B>(a.sH1, row, D::NH1, 0, valid, act1);
+  {
+    const int list = wave & 3, half = wave >> 2;
+    v4f part[HB];
+#pragma unroll
+    for (int b = 0; b < HB; ++b) part[b] = v4f{0.f, 0.f, 0.f, 0.f};
+    const float* base = (list < 2) ? a.gp.GdH1 : (list == 2 ? a.gp.GdF1 : a.gp.GdP1);
+    const bool by_dst = (list == 0 || list == 2);
+    if (valid && base) {
+      constexpr int U = HB <= 3 ? 8 : 4;
+      if (by_dst) segment_sum_deep<HB, U>(base, 16 * LB, 16 * HB * half, a.gp.dst_perm, a.gp.dst_ptr[row], a.gp.dst_ptr[row + 1], part);
+      else segment_sum_deep<HB, U>(base, 16 * LB, 16 * HB * half, a.gp.src_perm, a.gp.src_ptr[row], a.gp.src_ptr[row + 1], part);
+    }
+#pragma unroll
+    for (int b = 0; b < HB; ++b) xt[(list * LB + half * HB + b) * 64 + lane] = part[b];
+    store_row<HB>(a.gp.dT, row, H::TW, 16 * (LB * list + HB * half), valid, part);
+  }
+  {
+    v4f v = gradproj_products<Seq, 0, NWS, LB>(ws, xt, lane);
+    const int mb = wave;                                      // output block this wavefront owns (mb < 2 XB)
+    if (mb < XB) {                                            // d x' : G of combine_future_past.4, input of the next stage
+      store_row<1>(a.Gdx, row, D::DX, 16 * mb, valid, &v);
+      xb0[mb * 64 + lane] = v;
+    } else if (mb < GB) {                                     // d x0 contribution
+      if (!a.dx0_first) {
+        v4f prev;
+        load_row<1>(a.dx0_acc, row, D::DX, 16 * (mb - XB), valid, &prev);
+        v += prev;
+      }
+      store_row<1>(a.dx0_acc, row, D::DX, 16 * (mb - XB), valid, &v);
+    }
+  }
+  (void)GB;
+  v4f g[XB], d2[H2B], d1[H1B];
+  linear_split<Seq, 4, false, false, NWS>(
+      ws, false, g,
       [&]() {
 #pragma unroll
-        for (int b = 0; b < TB; ++b) dt[b] = xb[b * 64 + lane];
+        for (int b = 0; b < XB; ++b) g[b] = xb0[b * 64 + lane];
       },
-      [&](int mb, v4f v) { store_row<1>(a.gx, row, 2 * D::DX, 16 * mb, valid, &v); });
+      [&](int mb, v4f v) { xb1[mb * 64 + lane] = v; });
+  linear_split<Seq, 5, false, false, NWS>(
+      ws, false, d2,
+      [&]() {
+#pragma unroll
+        for (int b = 0; b < H2B; ++b) d2[b] = xb1[b * 64 + lane];
+        relu_bwd<H2B>(d2, act2);
+#pragma unroll
+        for (int b = 0; b < H2B; ++b)
+          if (b % NWS == wave) store_row<1>(a.GdH2, row, D::NH2, 16 * b, valid, &d2[b]);
+      },
+      [&](int mb, v4f v) { xb0[mb * 64 + lane] = v; });
+  linear_split<Seq, 6, false, false, NWS>(
+      ws, false, d1,
+      [&]() {
+#pragma unroll
+        for (int b = 0; b < H1B; ++b) d1[b] = xb0[b * 64 + lane];
+        relu_bwd<H1B>(d1, act1);
+#pragma unroll
+        for (int b = 0; b < H1B; ++b)
+          if (b % NWS == wave) store_row<1>(a.GdH1, row, D::NH1, 16 * b, valid, &d1[b]);
+      },
+      [&](int mb, v4f v) { store_row<1>(a.dM, row, 2 * D::DM, 16 * mb, valid, &v); });
 }
 
 // Loader of the node-encoder backward: gradient at x_enc = upstream + running d initial_x + layer 0's (dx | dx0).

@@ -110,7 +110,7 @@ struct PoseWs {
   float *wp_ee, *wp_ne, *wp_cls, *wp_efwd, *wp_nfwd, *wp_ebwd, *wp_ebwd_nm, *wp_nbwd, *wp_clsT, *wp_eeT, *wp_neT;
   // hoisted first layers: projection images, per-node tables
   bool hoist;
-  float *wp_ne_h, *wp_nfwd_h, *wp_efwd_h, *wp_ebwd_h, *wp_ebwd_nm_h, *wp_gproj;
+  float *wp_ne_h, *wp_nfwd_h, *wp_efwd_h, *wp_ebwd_h, *wp_ebwd_nm_h, *wp_gproj, *wp_nbwd_h;
   float *dT, *gx;       // [depth][N, TW] gradient of T per layer (kept for the weight gradient), [N, 2 DX] scratch
   float *T, *T0;        // [N, TW] (current layer), [N, 2 MH] (x0 terms, whole forward)
   // encoder / classifier activations
@@ -177,6 +177,7 @@ static void carve(PoseWs& w, void* ws, size_t ws_bytes, int N, int E, int depth,
       w.wp_ebwd_h = c.take<float>(HP::EdgeBwdSeq::TOTAL_FLOATS);
       w.wp_ebwd_nm_h = c.take<float>(HP::EdgeBwdSeqNoMsg::TOTAL_FLOATS);
       w.wp_gproj = c.take<float>(HP::GradProjSeq::TOTAL_FLOATS);
+      w.wp_nbwd_h = c.take<float>(NodeBwdHSeq<D>::TOTAL_FLOATS);
       w.dT = c.take<float>((size_t)depth * n_ * HP::TW);
       w.gx = c.take<float>(n_ * 2 * D::DX);
     }
@@ -270,7 +271,7 @@ static void carve(PoseWs& w, void* ws, size_t ws_bytes, int N, int E, int depth,
 
 // ---- forward ------------------------------------------------------------------------------------
 static int pack_forward(const b3d_pose_weights* pw, PoseWs& w, bool training, bool knn, hipStream_t stream) {
-  PackDesc d[128];
+  PackDesc d[160];
   int n = 0;
   const b3d_linear* ee = pw->edge_encoder;
   const b3d_linear* ne = pw->node_encoder;
@@ -365,18 +366,22 @@ static int pack_forward(const b3d_pose_weights* pw, PoseWs& w, bool training, bo
       T(EN2{}, 0, w.wp_ebwd_nm_h, mp.edge_update[2], LIN_EU2);
       T(EN2{}, 1, w.wp_ebwd_nm_h, mp.edge_update[1], LIN_EU1);
       TS(EN2{}, 2, w.wp_ebwd_nm_h, eu0.w + 2 * DX, EIN);
-      // (dx | dx0) = GradProj . dT: rows 0:DX from the x columns, rows DX:2DX from the x0 columns
-      using GP = HP::GradProjSeq;
-      auto B = [&](const float* wcol, int ld, int row0, int col0) {
-        d[n++] = pack_block<GP>(0, w.wp_gproj, wcol, DX, H1, ld, row0, DX, col0, true);
+      // (dx | dx0) = sum over the four lists of (node columns)^T . dT_list; rows 0:DX from the x columns,
+      // rows DX:2DX (future / past only) from the x0 columns.  Standalone (layer 0) and in front of the node MLP.
+      auto gp = [&](auto tag, int li0, float* base) {
+        using S = decltype(tag);
+        d[n++] = pack_slice<S>(li0 + 0, base, eu0.w, nullptr, DX, H1, EIN, 0, DX, true);
+        d[n++] = pack_slice<S>(li0 + 1, base, eu0.w + DX, nullptr, DX, H1, EIN, 0, DX, true);
+        d[n++] = pack_slice<S>(li0 + 2, base, fu0.w, nullptr, DX, H1, MIN, 0, DX, true);
+        d[n++] = pack_slice<S>(li0 + 2, base, fu0.w + DX + DE, nullptr, DX, H1, MIN, DX, DX, true);
+        d[n++] = pack_slice<S>(li0 + 3, base, pa0.w, nullptr, DX, H1, MIN, 0, DX, true);
+        d[n++] = pack_slice<S>(li0 + 3, base, pa0.w + DX + DE, nullptr, DX, H1, MIN, DX, DX, true);
       };
-      B(eu0.w, EIN, 0, HP::OA);
-      B(eu0.w + DX, EIN, 0, HP::OB);
-      B(fu0.w, MIN, 0, HP::OF);
-      B(pa0.w, MIN, 0, HP::OP);
-      d[n++] = pack_block<GP>(0, w.wp_gproj, nullptr, DX, 2 * H1, 0, DX, DX, 0, true);       // dx0 rows: no edge_update columns
-      B(fu0.w + DX + DE, MIN, DX, HP::OF);
-      B(pa0.w + DX + DE, MIN, DX, HP::OP);
+      gp(HP::GradProjSeq{}, 0, w.wp_gproj);
+      gp(NodeBwdHSeq<D>{}, 0, w.wp_nbwd_h);
+      T(NodeBwdHSeq<D>{}, 4, w.wp_nbwd_h, mp.combine_future_past[2], LIN_CF2);
+      T(NodeBwdHSeq<D>{}, 5, w.wp_nbwd_h, mp.combine_future_past[1], LIN_CF1);
+      T(NodeBwdHSeq<D>{}, 6, w.wp_nbwd_h, mp.combine_future_past[0], LIN_CF0);
     }
   }
   return pack_images(d, n, stream);
@@ -679,16 +684,33 @@ extern "C" int b3d_pose_backward(const b3d_pose_weights* pw, const b3d_graph* g,
       memset(&nb, 0, sizeof(nb));
       nb.N = N; nb.dst_ptr = g->dst_ptr; nb.dst_perm = g->dst_perm; nb.src_ptr = g->src_ptr; nb.src_perm = g->src_perm;
       if (w.hoist) {
-        B3D_TRY(gradproj(l + 1));
-        nb.g_direct = w.gx; nb.g_direct_wide = 1;
+        // per-node gradient of T from layer l+1's first-layer gradients, (dx | dx0), node MLP: one launch
+        NodeBwdHArgs hb;
+        memset(&hb, 0, sizeof(hb));
+        const int lay = l + 1;
+        hb.gp.N = N; hb.gp.dst_ptr = g->dst_ptr; hb.gp.dst_perm = g->dst_perm; hb.gp.src_ptr = g->src_ptr; hb.gp.src_perm = g->src_perm;
+        hb.gp.GdH1 = w.GdH1 + lay * eL1;
+        hb.gp.GdF1 = (lay < depth - 1) ? w.GdF1 + lay * eLm : nullptr;
+        hb.gp.GdP1 = (lay < depth - 1) ? w.GdP1 + lay * eLm : nullptr;
+        hb.gp.dT = w.dT + (size_t)lay * N * HP::TW;
+        hb.dx0_acc = w.dx0_acc; hb.dx0_first = dx0_first ? 1 : 0;
+        hb.sH1 = w.nH1[l]; hb.sH2 = w.nH2[l];
+        hb.dM = w.dM + l * nLm; hb.Gdx = w.Gdx + l * nLx; hb.GdH2 = w.GnH2 + l * nL2; hb.GdH1 = w.GnH1 + l * nL1;
+        hb.wpack = w.wp_nbwd_h;
+        B3D_TRY(set_lds(node_bwd_h_kernel<D>, NodeBwdHLds<D>::BYTES));
+        {
+          ProfScope ps(B3D_K_NODE_BWD, stream);
+          hipLaunchKernelGGL(node_bwd_h_kernel<D>, dim3((N + 15) / 16), dim3(kGradProjWaves * 64), NodeBwdHLds<D>::BYTES, stream, hb);
+        }
+        B3D_TRY(launch_check("node_bwd_h_kernel"));
       } else {
         nb.gdst = w.gdst; nb.gsrc = w.gsrc;
+        nb.dx0_acc = w.dx0_acc; nb.dx0_first = dx0_first ? 1 : 0;
+        nb.sH1 = w.nH1[l]; nb.sH2 = w.nH2[l];
+        nb.dM = w.dM + l * nLm; nb.Gdx = w.Gdx + l * nLx; nb.GdH2 = w.GnH2 + l * nL2; nb.GdH1 = w.GnH1 + l * nL1;
+        nb.wpack = w.wp_nbwd;
+        B3D_TRY(launch_node_split<D>(mp_node_bwd_split_kernel<D>, "mp_node_bwd", nb, N, stream, B3D_K_NODE_BWD));
       }
-      nb.dx0_acc = w.dx0_acc; nb.dx0_first = dx0_first ? 1 : 0;
-      nb.sH1 = w.nH1[l]; nb.sH2 = w.nH2[l];
-      nb.dM = w.dM + l * nLm; nb.Gdx = w.Gdx + l * nLx; nb.GdH2 = w.GnH2 + l * nL2; nb.GdH1 = w.GnH1 + l * nL1;
-      nb.wpack = w.wp_nbwd;
-      B3D_TRY(launch_node_split<D>(mp_node_bwd_split_kernel<D>, "mp_node_bwd", nb, N, stream, B3D_K_NODE_BWD));
       dx0_first = false;
     }
     if (w.hoist) {
