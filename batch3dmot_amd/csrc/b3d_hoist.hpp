@@ -24,7 +24,9 @@ namespace b3d {
 
 template <class D>
 struct Hoist {
-  static constexpr int TW = 2 * D::EH1 + 2 * D::MH;        // width of the per-node table
+  static constexpr int GW = 2 * D::EH1 + 2 * D::MH;        // per-node parts of the three first layers (and width of dT)
+  static constexpr int OG = GW;                             // + GATConv.lin(x) of the discarded k-NN block (pose_gnn.py:79)
+  static constexpr int TW = GW + D::DX;                     // width of the per-node table
   static constexpr int OA = 0, OB = D::EH1, OF = 2 * D::EH1, OP = 2 * D::EH1 + D::MH;
   static constexpr int KE = D::DE + D::DA;                  // per-edge input columns of edge_update.0
   using ProjSeq = LayerSeq<L<D::DX, TW>>;                   // x[l]  -> T (without the x0 terms)
@@ -51,14 +53,15 @@ struct StoreProj {
   float* T;            // [rows, TW]
   const float* T0;     // [rows, 2 MH]
   __device__ __forceinline__ void operator()(long row, bool valid, const v4f* src) const {
-    constexpr int FB = H::OF / 16;
-    v4f t0[NB - FB];
-    load_row<NB - FB>(T0, row, 2 * D::MH, 0, valid, t0);
+    constexpr int FB = H::OF / 16, T0B = 2 * D::MH / 16, GB = H::OG / 16;
+    v4f t0[T0B];
+    load_row<T0B>(T0, row, 2 * D::MH, 0, valid, t0);
     store_row<FB>(T, row, H::TW, 0, valid, src);
-    v4f out[NB - FB];
+    v4f out[T0B];
 #pragma unroll
-    for (int b = 0; b < NB - FB; ++b) out[b] = src[FB + b] + t0[b];
-    store_row<NB - FB>(T, row, H::TW, H::OF, valid, out);
+    for (int b = 0; b < T0B; ++b) out[b] = src[FB + b] + t0[b];
+    store_row<T0B>(T, row, H::TW, H::OF, valid, out);
+    store_row<NB - GB>(T, row, H::TW, H::OG, valid, src + GB);
   }
 };
 
@@ -283,14 +286,14 @@ struct NodeGradProjArgs {
   const float* GdH1;    // [E, EH1]
   const float* GdF1;    // [E, MH] or nullptr (last layer: the message stacks carry no gradient)
   const float* GdP1;
-  float* dT;            // [N, TW]
+  float* dT;            // [N, GW]
   float* gx;            // [N, 2 DX]
   const float* wpack;   // Hoist::GradProjSeq image
 };
 
 template <class D>
 struct GradProjLds {
-  static constexpr int TB = Hoist<D>::TW / 16;
+  static constexpr int TB = Hoist<D>::GW / 16;
   static constexpr int BYTES = kLdsBytes + TB * 64 * 16;
 };
 
@@ -330,7 +333,7 @@ __global__ __launch_bounds__(kGradProjWaves * 64, 1) void node_gradproj_kernel(c
   using Seq = typename H::GradProjSeq;
   constexpr int NWS = kGradProjWaves;
   static_assert(NWS == 8 && D::EH1 == D::MH && (D::EH1 / 16) % 2 == 0, "two wavefronts per list, equal widths");
-  constexpr int LB = D::EH1 / 16, HB = LB / 2, TB = H::TW / 16;
+  constexpr int LB = D::EH1 / 16, HB = LB / 2, TB = H::GW / 16;
   WStreamT<NWS * 64> ws;
   ws.init(a.wpack, smem);
   ws.template start<Seq>();
@@ -352,7 +355,7 @@ __global__ __launch_bounds__(kGradProjWaves * 64, 1) void node_gradproj_kernel(c
     }
 #pragma unroll
     for (int b = 0; b < HB; ++b) xb[(list * LB + half * HB + b) * 64 + lane] = part[b];
-    store_row<HB>(a.dT, row, H::TW, 16 * (LB * list + HB * half), valid, part);
+    store_row<HB>(a.dT, row, H::GW, 16 * (LB * list + HB * half), valid, part);
   }
   const v4f keep = gradproj_products<Seq, 0, NWS, LB>(ws, xb, lane);
   if (wave < 2 * D::DX / 16) store_row<1>(a.gx, row, 2 * D::DX, 16 * wave, valid, &keep);
@@ -379,7 +382,7 @@ struct NodeBwdHArgs {
 
 template <class D>
 struct NodeBwdHLds {
-  static constexpr int TB = Hoist<D>::TW / 16, PB = (D::NH1 > 2 * D::DX ? D::NH1 : 2 * D::DX) / 16;
+  static constexpr int TB = Hoist<D>::GW / 16, PB = (D::NH1 > 2 * D::DX ? D::NH1 : 2 * D::DX) / 16;
   static constexpr int BYTES = kLdsBytes + (TB + 2 * PB) * 64 * 16;
 };
 
@@ -390,7 +393,7 @@ __global__ __launch_bounds__(kGradProjWaves * 64, 1) void node_bwd_h_kernel(cons
   using Seq = NodeBwdHSeq<D>;
   constexpr int NWS = kGradProjWaves;
   static_assert(NWS == 8 && D::EH1 == D::MH && (D::EH1 / 16) % 2 == 0, "two wavefronts per list, equal widths");
-  constexpr int LB = D::EH1 / 16, HB = LB / 2, TB = H::TW / 16;
+  constexpr int LB = D::EH1 / 16, HB = LB / 2, TB = H::GW / 16;
   constexpr int XB = D::DX / 16, GB = 2 * XB, H1B = D::NH1 / 16, H2B = D::NH2 / 16;
   static_assert(GB <= NWS, "one output block of (dx | dx0) per wavefront");
   constexpr int PB = NodeBwdHLds<D>::PB;
@@ -420,7 +423,7 @@ __global__ __launch_bounds__(kGradProjWaves * 64, 1) void node_bwd_h_kernel(cons
     }
 #pragma unroll
     for (int b = 0; b < HB; ++b) xt[(list * LB + half * HB + b) * 64 + lane] = part[b];
-    store_row<HB>(a.gp.dT, row, H::TW, 16 * (LB * list + HB * half), valid, part);
+    store_row<HB>(a.gp.dT, row, H::GW, 16 * (LB * list + HB * half), valid, part);
   }
   {
     v4f v = gradproj_products<Seq, 0, NWS, LB>(ws, xt, lane);

@@ -289,7 +289,7 @@ __global__ __launch_bounds__(kKnnCentres * 64) void knn_tile_kernel(const float*
 // one wavefront per destination: per-destination segmented softmax with wavefront shuffles,
 // attention-weighted sum of neighbour rows
 template <int D>
-__global__ __launch_bounds__(256) void gat_aggregate_kernel(const float* __restrict__ h, int N,
+__global__ __launch_bounds__(256) void gat_aggregate_kernel(const float* __restrict__ h, int hs, int N,
                                                             const int* __restrict__ nbr, const int* __restrict__ cnt,
                                                             const float* __restrict__ att_src, const float* __restrict__ att_dst,
                                                             const float* __restrict__ bias, float* __restrict__ y) {
@@ -305,8 +305,8 @@ __global__ __launch_bounds__(256) void gat_aggregate_kernel(const float* __restr
     float ss = 0.f, sd = 0.f;
 #pragma unroll
     for (int d = 0; d < D; d += 4) {
-      const v4f vq = *reinterpret_cast<const v4f*>(h + (size_t)q * D + d);
-      const v4f vc = *reinterpret_cast<const v4f*>(h + (size_t)c * D + d);
+      const v4f vq = *reinterpret_cast<const v4f*>(h + (size_t)q * hs + d);
+      const v4f vc = *reinterpret_cast<const v4f*>(h + (size_t)c * hs + d);
       ss = fmaf(vq.x, att_src[d], ss); ss = fmaf(vq.y, att_src[d + 1], ss); ss = fmaf(vq.z, att_src[d + 2], ss); ss = fmaf(vq.w, att_src[d + 3], ss);
       sd = fmaf(vc.x, att_dst[d], sd); sd = fmaf(vc.y, att_dst[d + 1], sd); sd = fmaf(vc.z, att_dst[d + 2], sd); sd = fmaf(vc.w, att_dst[d + 3], sd);
     }
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256) void gat_aggregate_kernel(const float* __restr
 #pragma unroll
     for (int p = 0; p < PER; ++p) {
       const int d = lane + 64 * p;
-      if (d < D) acc[p] = fmaf(aj, h[(size_t)qj * D + d], acc[p]);
+      if (d < D) acc[p] = fmaf(aj, h[(size_t)qj * hs + d], acc[p]);
     }
   }
 #pragma unroll
@@ -344,7 +344,8 @@ __global__ __launch_bounds__(256) void gat_aggregate_kernel(const float* __restr
 // x [N, D]; result left in ws.y / ws.nbr / ws.cnt
 template <int D>
 inline int knn_gat_block(KnnWs& ws, const float* x, const int64_t* ts, int N, const b3d_gat& gat, int k,
-                         hipStream_t stream) {
+                         hipStream_t stream, const float* h_pre = nullptr, int h_stride = 0) {
+  // h_pre: GATConv.lin(x) already computed by the caller ([N, h_stride] rows, D valid columns)
   B3D_REQUIRE(gat.lin && gat.att_src && gat.att_dst && gat.bias, "knn_conv parameters are null");
   B3D_REQUIRE(k >= 1 && k <= kKnnMaxK, "k-NN k=%d outside [1,%d]", k, kKnnMaxK);
   if (N <= 0) return B3D_OK;
@@ -365,7 +366,9 @@ inline int knn_gat_block(KnnWs& ws, const float* x, const int64_t* ts, int N, co
   hipLaunchKernelGGL(knn_tile_kernel<D>, dim3((N + kKnnCentres - 1) / kKnnCentres), dim3(kKnnCentres * 64), 0, stream,
                      x, N, k, ws.order, ws.fbeg, ws.fend, ws.nbr, ws.cnt);
   B3D_TRY(launch_check("knn_tile_kernel"));
-  {
+  const float* h = h_pre ? h_pre : ws.h;
+  const int hs = h_pre ? h_stride : D;
+  if (!h_pre) {
     using S = LayerSeq<L<D, D>>;
     ChainFwdArgs<LoadAligned<D / 16>, StoreAligned<D / 16>> a;
     memset(&a, 0, sizeof(a));
@@ -375,7 +378,7 @@ inline int knn_gat_block(KnnWs& ws, const float* x, const int64_t* ts, int N, co
     a.wpack = ws.wp;
     B3D_TRY(launch_rows<kNWNode>(chain_fwd_kernel<S, 0u, LoadAligned<D / 16>, StoreAligned<D / 16>, kNWNode>, "gat_linear", a, N, stream, B3D_K_OTHER, chain_lds<S>()));
   }
-  hipLaunchKernelGGL(gat_aggregate_kernel<D>, dim3((N + 3) / 4), dim3(256), 0, stream, ws.h, N, ws.nbr, ws.cnt, gat.att_src, gat.att_dst, gat.bias, ws.y);
+  hipLaunchKernelGGL(gat_aggregate_kernel<D>, dim3((N + 3) / 4), dim3(256), 0, stream, h, hs, N, ws.nbr, ws.cnt, gat.att_src, gat.att_dst, gat.bias, ws.y);
   return launch_check("gat_aggregate_kernel");
 }
 

@@ -104,7 +104,7 @@ inline int launch_reduce(RedArgs& a, hipStream_t stream) {
   }
   a.total = total;
   if (total == 0) return B3D_OK;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + kRedElems - 1) / kRedElems), dim3(kRedElems * kRedParts), 0, stream, a);
   return launch_check("wgrad_reduce_kernel");
 }
 

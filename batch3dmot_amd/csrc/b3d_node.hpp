@@ -164,12 +164,14 @@ __device__ __forceinline__ void node_fwd_split_body(const NodeFwdArgs& a, float*
       });
   if constexpr (PROJ) {
     // per-node parts of the NEXT layer's three first Linear layers (b3d_hoist.hpp): T = Wp x' + bp (+ x0 terms)
-    constexpr int TB = (2 * D::EH1 + 2 * D::MH) / 16, FB = 2 * D::EH1 / 16, TW = 16 * TB;
-    static_assert(FB % NWS == 0 && (TB - FB) % NWS == 0, "table columns must split over the wavefronts");
-    constexpr int T0N = (TB - FB) / NWS;
+    // columns: first-layer parts (A | B | F | P), then GATConv.lin(x) of the discarded k-NN block; only F | P
+    // carry x0 terms
+    constexpr int FB = 2 * D::EH1 / 16, T0B = 2 * D::MH / 16, TB = FB + T0B + D::DX / 16, TW = 16 * TB;
+    static_assert(FB % NWS == 0 && T0B % NWS == 0, "table columns must split over the wavefronts");
+    constexpr int T0N = T0B / NWS;
     v4f t0[T0N];                                 // this wavefront's blocks of the x0 terms
 #pragma unroll
-    for (int i = 0; i < T0N; ++i) load_row<1>(a.T0, row, 16 * (TB - FB), 16 * (wave + NWS * i), valid, &t0[i]);
+    for (int i = 0; i < T0N; ++i) load_row<1>(a.T0, row, 16 * T0B, 16 * (wave + NWS * i), valid, &t0[i]);
     v4f xn[XB];
     linear_split<Seq, 3, false, true, NWS>(
         ws, false, xn,
@@ -178,7 +180,7 @@ __device__ __forceinline__ void node_fwd_split_body(const NodeFwdArgs& a, float*
           for (int b = 0; b < XB; ++b) xn[b] = xb1[b * 64 + lane];
         },
         [&](int mb, v4f v, int slot) {
-          if (mb >= FB) v += t0[slot - FB / NWS];
+          if (mb >= FB && mb < FB + T0B) v += t0[slot - FB / NWS];
           store_row<1>(a.T, row, TW, 16 * mb, valid, &v);
         });
   }

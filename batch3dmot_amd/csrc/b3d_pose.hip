@@ -18,7 +18,7 @@ static bool hoist_enabled() {
 // encoders / classifier, widths padded to multiples of 16
 using SeqEdgeEnc = LayerSeq<L<16, 16>, L<16, 16>, L<16, 32>>;            // 4-8-16-32    pose_gnn.py:29-35
 using SeqNodeEnc = LayerSeq<L<32, 32>, L<32, 48>, L<48, 48>>;            // 19-24-36-48  :37-43
-using SeqNodeEncH = LayerSeq<L<32, 32>, L<32, 48>, L<48, 48>, L<48, 192>, L<48, 384>>;   // + x0 terms + layer-0 table
+using SeqNodeEncH = LayerSeq<L<32, 32>, L<32, 48>, L<48, 48>, L<48, 192>, L<48, 432>>;   // + x0 terms + layer-0 table
 using SeqCls = LayerSeq<L<32, 16>, L<16, 16>, L<16, 16>, L<16, 16>>;     // 32-16-8-4-1  :45-53
 using SeqClsT = LayerSeq<L<16, 16>, L<16, 16>, L<16, 16>, L<16, 32>>;    // W4^T, W3^T, W2^T, W1^T
 using SeqEdgeEncT = LayerSeq<L<32, 16>, L<16, 16>>;                      // W3^T, W2^T
@@ -178,7 +178,7 @@ static void carve(PoseWs& w, void* ws, size_t ws_bytes, int N, int E, int depth,
       w.wp_ebwd_nm_h = c.take<float>(HP::EdgeBwdSeqNoMsg::TOTAL_FLOATS);
       w.wp_gproj = c.take<float>(HP::GradProjSeq::TOTAL_FLOATS);
       w.wp_nbwd_h = c.take<float>(NodeBwdHSeq<D>::TOTAL_FLOATS);
-      w.dT = c.take<float>((size_t)depth * n_ * HP::TW);
+      w.dT = c.take<float>((size_t)depth * n_ * HP::GW);
       w.gx = c.take<float>(n_ * 2 * D::DX);
     }
     w.wp_clsT = c.take<float>(SeqClsT::TOTAL_FLOATS);
@@ -295,6 +295,7 @@ static int pack_forward(const b3d_pose_weights* pw, PoseWs& w, bool training, bo
       d[n++] = pack_slice<S>(li, base, eu0.w + DX, nullptr, H1, DX, EIN, HP::OB, H1, false);     // x[src] columns
       d[n++] = pack_slice<S>(li, base, fu0.w, fu0.b, MH, DX, MIN, HP::OF, MH, false);             // future: x[dst]
       d[n++] = pack_slice<S>(li, base, pa0.w, pa0.b, MH, DX, MIN, HP::OP, MH, false);             // past:   x[src]
+      d[n++] = pack_slice<S>(li, base, knn ? pw->knn_conv.lin : nullptr, nullptr, DX, DX, DX, HP::OG, DX, false);   // GATConv.lin
     };
     for (int i = 0; i < 3; ++i) d[n++] = pack_desc<SeqNodeEncH>(i, w.wp_ne_h, ne[i].w, ne[i].b, kLinDims[LIN_NE0 + i].N, kLinDims[LIN_NE0 + i].K, false);
     d[n++] = pack_slice<SeqNodeEncH>(3, w.wp_ne_h, fu0.w + DX + DE, nullptr, MH, DX, MIN, 0, MH, false);    // x0 columns
@@ -453,8 +454,8 @@ static int mp_weight_grads(PoseWs& w, const MpGradSrc& ms, int N, int E, const i
     add(WJ_CF2, sg(ms.Gdx, nullptr, nLx, D::DX, 0), sg(ms.nH2, nullptr, nL2, D::NH2, 0), 0, none, 0, true);
     // hoisted first layers (nvar == 0 otherwise): edge columns over edges, node columns over nodes
     {
-      const long tLs = (long)N * HP::TW;
-      auto tcol = [&](int off) { return sg(ms.dT, nullptr, tLs, HP::TW, off); };
+      const long tLs = (long)N * HP::GW;
+      auto tcol = [&](int off) { return sg(ms.dT, nullptr, tLs, HP::GW, off); };
       add(WJ_HEU0E, gH1, erow(0, 0), 0, none, 0, true);
       add(WJ_HFU0E, gF1, erow(1, 0), 0, none, 0, true);
       add(WJ_HPA0E, gP1, erow(1, 0), 0, none, 0, true);
@@ -577,7 +578,10 @@ extern "C" int b3d_pose_forward(const b3d_pose_weights* pw, const b3d_graph* g, 
         B3D_TRY(side_fork(stream, knn_side));              // x[l] is complete on `stream` here
         ks = knn_side->s;
       }
-      B3D_TRY(knn_gat_block<D::DX>(w.knn, w.x[l], node_timestamps, N, pw->knn_conv, 20, ks));
+      // on the launch stream the block reads GATConv.lin(x[l]) from the per-node table (T is rewritten by the
+      // next node update, so a side stream computes its own copy)
+      const bool pre = w.hoist && ks == stream;
+      B3D_TRY(knn_gat_block<D::DX>(w.knn, w.x[l], node_timestamps, N, pw->knn_conv, 20, ks, pre ? w.T + HP::OG : nullptr, HP::TW));
     }
     if (w.hoist) {
       EdgeFwdHArgs ea;
@@ -669,7 +673,7 @@ extern "C" int b3d_pose_backward(const b3d_pose_weights* pw, const b3d_graph* g,
     const bool lay_msgs = lay < depth - 1;
     ga.GdF1 = lay_msgs ? w.GdF1 + lay * eLm : nullptr;
     ga.GdP1 = lay_msgs ? w.GdP1 + lay * eLm : nullptr;
-    ga.dT = w.dT + (size_t)lay * N * HP::TW; ga.gx = w.gx;
+    ga.dT = w.dT + (size_t)lay * N * HP::GW; ga.gx = w.gx;
     ga.wpack = w.wp_gproj;
     B3D_TRY(set_lds(node_gradproj_kernel<D>, GradProjLds<D>::BYTES));
     ProfScope ps(B3D_K_NODE_BWD, stream);
@@ -692,7 +696,7 @@ extern "C" int b3d_pose_backward(const b3d_pose_weights* pw, const b3d_graph* g,
         hb.gp.GdH1 = w.GdH1 + lay * eL1;
         hb.gp.GdF1 = (lay < depth - 1) ? w.GdF1 + lay * eLm : nullptr;
         hb.gp.GdP1 = (lay < depth - 1) ? w.GdP1 + lay * eLm : nullptr;
-        hb.gp.dT = w.dT + (size_t)lay * N * HP::TW;
+        hb.gp.dT = w.dT + (size_t)lay * N * HP::GW;
         hb.dx0_acc = w.dx0_acc; hb.dx0_first = dx0_first ? 1 : 0;
         hb.sH1 = w.nH1[l]; hb.sH2 = w.nH2[l];
         hb.dM = w.dM + l * nLm; hb.Gdx = w.Gdx + l * nLx; hb.GdH2 = w.GnH2 + l * nL2; hb.GdH1 = w.GnH1 + l * nL1;

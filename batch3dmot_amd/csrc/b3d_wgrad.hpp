@@ -290,14 +290,21 @@ struct RedArgs {
   RedEntry e[kRedMaxEntries];
 };
 
-static __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedArgs a) {
-  const int id = blockIdx.x * 256 + threadIdx.x;
-  if (id >= a.total) return;
+// A workgroup reduces kRedElems consecutive output elements; kRedParts threads share one element:
+// each sums every kRedParts-th slab (8 loads in flight per thread, 128-byte runs per half wave), the
+// partials meet in LDS and are added in a fixed order -- the slab count (~150-200 tasks per big
+// matrix) is walked by 8 threads in parallel instead of one.  Bitwise reproducible.
+constexpr int kRedElems = 32, kRedParts = 8;
+static __global__ __launch_bounds__(kRedElems * kRedParts) void wgrad_reduce_kernel(const RedArgs a) {
+  __shared__ float part[kRedParts][kRedElems];
+  const int el = threadIdx.x % kRedElems, sub = threadIdx.x / kRedElems;
+  const int id = blockIdx.x * kRedElems + el;
+  const bool live = id < a.total;
   int j = 0;
   for (int t = 1; t < a.nentries; ++t)
-    if (id >= a.e[t].begin) j = t;
+    if (live && id >= a.e[t].begin) j = t;
   const RedEntry& e = a.e[j];
-  const int l = id - e.begin;                   // [0, N*K + N)
+  const int l = live ? id - e.begin : 0;         // [0, N*K + N)
   const size_t cs = (size_t)e.NP * e.KP + e.NP;
   size_t off;
   float* out;
@@ -310,18 +317,26 @@ static __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedArgs 
     off = (size_t)e.NP * e.KP + n;
     out = e.db ? e.db + n : nullptr;
   }
-  if (!out) return;
   float s = 0.f;
-  int c = 0;
-  for (; c + 8 <= e.nchunks; c += 8) {
-    float t[8];
+  if (live && out) {
+    int c = sub;
+    for (; c + 7 * kRedParts < e.nchunks; c += 8 * kRedParts) {
+      float t[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) t[u] = e.slab[(size_t)(c + u) * cs + off];
+      for (int u = 0; u < 8; ++u) t[u] = e.slab[(size_t)(c + u * kRedParts) * cs + off];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) s += t[u];
+      for (int u = 0; u < 8; ++u) s += t[u];
+    }
+    for (; c < e.nchunks; c += kRedParts) s += e.slab[(size_t)c * cs + off];
   }
-  for (; c < e.nchunks; ++c) s += e.slab[(size_t)c * cs + off];
-  *out = s;
+  part[sub][el] = s;
+  __syncthreads();
+  if (sub == 0 && live && out) {
+    float t = part[0][el];
+#pragma unroll
+    for (int p = 1; p < kRedParts; ++p) t += part[p][el];
+    *out = t;
+  }
 }
 
 }  // namespace b3d
