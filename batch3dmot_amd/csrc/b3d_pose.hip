@@ -520,6 +520,16 @@ extern "C" int b3d_pose_debug_layer_ptrs(void* workspace, size_t workspace_bytes
   return B3D_OK;
 }
 
+extern "C" int b3d_pose_debug_knn_ptrs(void* workspace, size_t workspace_bytes, int32_t N, int32_t E, int32_t depth,
+                                       uint32_t flags, float** y, int32_t** nbr, int32_t** cnt) {
+  B3D_REQUIRE(depth >= 1 && depth <= 15 && (flags & B3D_FLAG_RUN_DEAD_KNN), "no k-NN block in this workspace");
+  PoseWs w;
+  carve(w, workspace, workspace_bytes, N, E, depth, flags);
+  if (!w.ok) return fail(B3D_ERR_WORKSPACE, "workspace too small");
+  *y = w.knn.y; *nbr = w.knn.nbr; *cnt = w.knn.cnt;
+  return B3D_OK;
+}
+
 extern "C" int b3d_pose_forward(const b3d_pose_weights* pw, const b3d_graph* g, const float* pose_feats,
                                 const double* edge_attr, const int64_t* node_timestamps, int32_t depth,
                                 uint32_t flags, void* workspace, size_t workspace_bytes, float* out_logits,

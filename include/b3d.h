@@ -252,6 +252,13 @@ int b3d_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
  * (pending work of a B3D_FLAG_DEFER_SIDE_JOIN forward).  Cheap when nothing is pending. */
 int b3d_side_join(b3d_stream stream);
 
+/* ---- test hooks: addresses of intermediate tensors inside a workspace a forward has filled ---------------- */
+int b3d_pose_debug_layer_ptrs(void* workspace, size_t workspace_bytes, int32_t N, int32_t E, int32_t depth,
+                              uint32_t flags, int32_t layer, float** x /* [N,48] */, float** e /* [E,32] */);
+/* outputs of the LAST executed k-NN + GAT block (layer 2*floor((depth-1)/2)): y [N,48], nbr [N,32], cnt [N] */
+int b3d_pose_debug_knn_ptrs(void* workspace, size_t workspace_bytes, int32_t N, int32_t E, int32_t depth, uint32_t flags,
+                            float** y, int32_t** nbr, int32_t** cnt);
+
 /* ---- kernel-family timers (measurement aid for bench.py; off by default) --------------------
  * When enabled, every launch of the listed kernel families is bracketed by hipEventRecord on the
  * launch stream.  b3d_prof_read synchronises on the recorded events and returns the summed device

@@ -256,3 +256,37 @@ def test_flat_adam_gradient_accumulation_and_zero_grad():
     sd = opt.state_dict()
     opt.load_state_dict(sd)
     assert opt.step_count == sd["step"]
+
+
+@pytest.mark.parametrize("side_stream", [False, True])
+def test_dead_knn_block_inside_the_model_matches_oracle(side_stream):
+    """The reference discards this block's result (pose_gnn.py:80), so nothing downstream can notice a wrong
+    one: check the last executed block (layer 4, input x[4]) inside the workspace against the oracle's GATConv
+    on the oracle's k-NN graph -- both the path that reads GATConv.lin(x) from the per-node table and the
+    side-stream path that computes it itself."""
+    from batch3dmot_amd import _lib, synth
+    from oracle import ref_torch
+    from oracle.seeded import seeded_fill_
+    dev = torch.device("cuda:0")
+    d = synth.make_graph(240, None, k=6, graph_idx=77)
+    ora = ref_torch.PoseGNN(run_dead_knn=False)
+    seeded_fill_(ora, 21)
+    with torch.no_grad():
+        for p in ora.knn_conv.parameters():
+            p.copy_(torch.randn(p.shape, generator=torch.Generator().manual_seed(p.numel())) * 0.3)
+    m = _model(ora.state_dict(), dev)
+    m.run_dead_knn, m.single_stream, m.keep_workspace = True, not side_stream, True
+    m(d.to(dev))
+    torch.cuda.synchronize()
+    N, E = d.pose_feats.size(0), d.edge_index.size(1)
+    x4 = _layer_tensors(m, N, E)[4][0].cpu()
+    ws, nbytes, flags, _, _ = m._last_workspace
+    py, pn, pc = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    _lib.check(_lib.load().b3d_pose_debug_knn_ptrs(ws.data_ptr(), nbytes, N, E, m.depth, flags, C.byref(py), C.byref(pn),
+                                                   C.byref(pc)), "knn ptrs")
+    y = ws[py.value - ws.data_ptr():][:N * 48 * 4].view(torch.float32).view(N, 48).cpu()
+    ts = d.node_timestamps
+    for t in torch.unique(ts).tolist():
+        idx = torch.nonzero(ts == t).squeeze(1)
+        ei = ref_torch.knn_graph(x4[idx], 20)
+        torch.testing.assert_close(y[idx], ora.knn_conv(x4[idx], ei), rtol=1e-4, atol=1e-5)
