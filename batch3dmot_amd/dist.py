@@ -39,8 +39,11 @@ class FlatGradSync:
             return
         if self.flat_opt is not None and not self.flat_opt.fresh:
             g = self.flat_opt.flat_grad
-            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
-            g.mul_(1.0 / self.world_size)
+            if dist.get_backend(self.group) == "nccl":       # RCCL averages inside the collective: no extra launch
+                dist.all_reduce(g, op=dist.ReduceOp.AVG, group=self.group)
+            else:
+                dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+                g.mul_(1.0 / self.world_size)
         live = [p for p in self.params if p.grad is not None]
         if not live:
             return

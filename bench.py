@@ -57,6 +57,8 @@ def main():
                     help="skip the k-NN + GAT block whose result the reference discards (secondary figure)")
     ap.add_argument("--side-stream", action="store_true", help="run the discarded k-NN block on the library's side stream (diagnostic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to exercise the N > 1 path on one GPU)")
+    ap.add_argument("--all-ranks-on-device-0", action="store_true", help="testing aid for the N > 1 path on a 1-GPU box (with --backend gloo)")
     ap.add_argument("--cpu-steps", type=int, default=50)
     args = ap.parse_args()
 
@@ -67,11 +69,14 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     import torch.distributed as dist
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", 0 if args.all_ranks_on_device_0 else local_rank)
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
 
     from batch3dmot_amd import _lib, synth
     from batch3dmot_amd.dist import FlatGradSync
