@@ -28,6 +28,7 @@ class FlatGradSync:
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad and id(p) not in skip]
         self.group = group
         self._flat: Optional[torch.Tensor] = None
+        self._avg: Optional[bool] = None
 
     @property
     def world_size(self) -> int:
@@ -39,9 +40,14 @@ class FlatGradSync:
             return
         if self.flat_opt is not None and not self.flat_opt.fresh:
             g = self.flat_opt.flat_grad
-            if dist.get_backend(self.group) == "nccl":       # RCCL averages inside the collective: no extra launch
-                dist.all_reduce(g, op=dist.ReduceOp.AVG, group=self.group)
-            else:
+            if self._avg is None:
+                self._avg = dist.get_backend(self.group) == "nccl"   # RCCL averages inside the collective
+            if self._avg:
+                try:
+                    dist.all_reduce(g, op=dist.ReduceOp.AVG, group=self.group)
+                except Exception:                                  # backend without AVG: sum, then scale
+                    self._avg = False
+            if not self._avg:
                 dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
                 g.mul_(1.0 / self.world_size)
         live = [p for p in self.params if p.grad is not None]
