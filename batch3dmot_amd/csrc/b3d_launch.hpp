@@ -21,7 +21,7 @@ inline int set_lds(K kernel, int bytes) {
 }
 
 // Row-tiled MLP kernels.  NW = wavefronts per workgroup (each owns 16 rows).  Edge-sized inputs
-// use 8; node-sized inputs (a few thousand rows) use 1 so the launch still covers ~200 CUs.
+// use 8; node-sized chain kernels (encoders) use 1 so the launch still covers ~200 CUs.
 template <int NW, class Kern, class Args>
 inline int launch_rows(Kern kernel, const char* name, const Args& a, long rows, hipStream_t stream,
                        int family = B3D_K_OTHER, int lds_bytes = kLdsBytes) {

