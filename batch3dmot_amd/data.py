@@ -76,3 +76,32 @@ def collate(graphs: Iterable[Data]) -> Data:
             setattr(out, k, torch.cat(vals, dim=0))
     out.num_graphs = len(graphs)
     return out
+
+
+def class_balanced_edge_weights(edge_index: torch.Tensor, node_class: torch.Tensor, class_freq: torch.Tensor,
+                                num_edges: int = 5):
+    """Vectorised form of the loader's per-edge Python loop (reference utils/graph_data.py:126-138,
+    194-228): ``edge_weights``, ``edge_classes`` and ``node_classes`` of a window in three tensor ops.
+
+    ``edge_index`` [2,E] (row 0 past / source, row 1 current / destination), ``node_class`` [N] integer
+    class id of every node (the reference's ``class_dict`` value, ids >= 1), ``class_freq`` [C+1] the
+    relative training frequency per class id (``rel_freq_train``; index 0 unused).  Works on any device.
+
+    weight_e = (1 - beta) / (1 - beta ** (num_edges * freq[class])), beta = (num_edges - 1) / num_edges,
+    for an edge whose two nodes share a class.  The reference's branch for edges between different
+    classes reads an attribute it never defines (graph_data.py:223) -- its graphs only link detections
+    of one class -- so such an edge raises here as it does there.
+    """
+    src, dst = edge_index[0], edge_index[1]
+    ca, cb = node_class[src], node_class[dst]
+    if bool((ca != cb).any()):
+        raise ValueError("edge between nodes of different classes: undefined in the reference (graph_data.py:223)")
+    beta = (num_edges - 1) / num_edges
+    factor = (1.0 - beta) / (1.0 - torch.pow(torch.full_like(class_freq, beta, dtype=torch.float64),
+                                              num_edges * class_freq.double()))
+    weights = factor[ca.long()].float()
+    edge_classes = ca.float()
+    node_classes = torch.zeros(node_class.numel(), dtype=torch.float32, device=node_class.device)
+    node_classes[src] = ca.float()
+    node_classes[dst] = cb.float()
+    return weights, edge_classes, node_classes

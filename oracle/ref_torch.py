@@ -327,3 +327,30 @@ def greedy_flux(num_nodes: int, edges, scores, thresholds):
     pred = [max(d, key=d.get) if d else -1 for d in incoming]
     succ = [max(d, key=d.get) if d else -1 for d in outgoing]
     return kept, pred, succ
+
+
+# --------------------------------------------------------------------------------------
+# Loader-side edge weighting (utils/graph_data.py:126-138, 194-228), restated loop for loop
+# --------------------------------------------------------------------------------------
+def edge_weights_loop(edges: torch.Tensor, category_names, rel_freq_train: dict, class_dict: dict, num_nodes: int):
+    """``edges`` [E,2] (row = (past, current) node ids), ``category_names[n]`` the node's class name.
+    Returns (weights [E], edge_classes [E], node_classes [N]) exactly as the reference's per-edge loop
+    builds them.  The mixed-class branch of the reference reads ``self.rel_freq``, an attribute it never
+    defines (graph_data.py:223): it raises AttributeError there, and ValueError here."""
+    num_edges = 5                                              # graph_data.py:132
+    beta = (num_edges - 1) / num_edges
+    weights = torch.zeros(edges.shape[0])
+    edge_classes = torch.zeros(edges.shape[0])
+    node_classes = torch.zeros(num_nodes)
+    for row_idx, edge in enumerate(edges):
+        class_a = category_names[int(edge[0].item())]
+        class_b = category_names[int(edge[1].item())]
+        if class_a == class_b:
+            edges_per_cls = num_edges * rel_freq_train[class_a]
+            weights[row_idx] = (1 - beta) / (1 - beta ** edges_per_cls)
+            edge_classes[row_idx] = class_dict[class_a]
+            node_classes[edge[0]] = class_dict[class_a]
+            node_classes[edge[1]] = class_dict[class_a]
+        else:
+            raise ValueError("mixed-class edge: the reference fails here (graph_data.py:223)")
+    return weights, edge_classes, node_classes
