@@ -3,6 +3,7 @@
 #include "b3d_launch.hpp"
 #include "b3d_knn.hpp"
 #include "b3d_wstream.hpp"
+#include "b3d_wstream2.hpp"
 #include "b3d_hoist.hpp"
 
 namespace b3d {
@@ -481,7 +482,12 @@ static int mp_weight_grads(PoseWs& w, const MpGradSrc& ms, int N, int E, const i
     narrow(WJ_EE2, ms.de0, D::DE, w.ee_a2, 16);                            // edge_encoder.4  [32,16]
     narrow(WJ_EE1, w.ge2, 16, w.ee_a1, 16);                                // .2  [16,8]
     narrow(WJ_EE0, w.ge1, 16, w.ea_pad, 16);                               // .0  [8,4]
-    wl.launch(w.zrow, B3D_K_WGRAD_EDGE);
+    static const bool ws2 = [] { const char* e = getenv("B3D_WS2"); return e ? atoi(e) != 0 : true; }();   // B3D_WS2=0: register-staged form
+    if (ws2 && w.hoist) {      // every job of the hoisted plan has one activation segment: LDS-DMA ring form
+      B3D_REQUIRE(wl.launch2(wstream2_kernel, kWs2LdsBytes, w.zrow, w.iota, B3D_K_WGRAD_EDGE) == 0, "wstream2: LDS attribute");
+    } else {
+      wl.launch(w.zrow, B3D_K_WGRAD_EDGE);
+    }
     B3D_REQUIRE(wl.status == 0, "streaming weight gradient: job table overflow");
     B3D_TRY(launch_check("wstream_kernel"));
   return B3D_OK;

@@ -294,7 +294,7 @@ struct RedArgs {
 // each sums every kRedParts-th slab (8 loads in flight per thread, 128-byte runs per half wave), the
 // partials meet in LDS and are added in a fixed order -- the slab count (~150-200 tasks per big
 // matrix) is walked by 8 threads in parallel instead of one.  Bitwise reproducible.
-constexpr int kRedElems = 32, kRedParts = 8;
+constexpr int kRedElems = 64, kRedParts = 8;
 static __global__ __launch_bounds__(kRedElems * kRedParts) void wgrad_reduce_kernel(const RedArgs a) {
   __shared__ float part[kRedParts][kRedElems];
   const int el = threadIdx.x % kRedElems, sub = threadIdx.x / kRedElems;

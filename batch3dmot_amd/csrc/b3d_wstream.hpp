@@ -346,6 +346,20 @@ struct WsLauncher {
     hipLaunchKernelGGL(wstream_kernel, dim3((total_tasks + kWsWaves - 1) / kWsWaves), dim3(kWsWaves * 64), 0, stream,
                        table, task_job, total_tasks, zero_row);
   }
+  // LDS-DMA form (b3d_wstream2.hpp): single-segment jobs only
+  template <class Kern>
+  int launch2(Kern kernel, int lds_bytes, const float* zero_row, const int* iota, int family) {
+    flush();
+    if (total_tasks == 0 || status) return 0;
+    if (lds_bytes > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+      if (e != hipSuccess) return -1;
+    }
+    ProfScope ps(family, stream);
+    hipLaunchKernelGGL(kernel, dim3((total_tasks + kWsWaves - 1) / kWsWaves), dim3(kWsWaves * 64), lds_bytes, stream,
+                       table, task_job, total_tasks, zero_row, iota);
+    return 0;
+  }
 };
 
 }  // namespace b3d
