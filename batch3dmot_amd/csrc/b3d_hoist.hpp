@@ -135,56 +135,46 @@ __global__ __launch_bounds__(kNodeWaves * 64, 1) void mp_node_fwd_split_h_kernel
   node_fwd_split_body<D, NodeFwdHSeq<D>, true>(a, smem);
 }
 
-// Node encoder (three Linear layers) + x0 terms + the table of layer 0, one wavefront per 16 rows.
-// Seq = encoder layers 0..2, then L<DX, 2 MH> (x0 terms, no bias), then L<DX, TW> (projection).
-template <class In>
-struct NodeEncProjArgs {
-  int rows;
-  In in;
-  float* save_in;       // padded input rows (training) or nullptr
-  float* save[2];       // hidden activations (training) or nullptr
-  float* x0;            // [rows, DX]  layer-0 node features (= initial_x)
-  float* x_enc;         // [rows, DX]  second copy, returned to the caller (pose_gnn.py:86)
-  float* T0;            // [rows, 2 MH]
-  float* T;             // [rows, TW]
-  const float* wpack;
+// x0 terms + the table of layer 0 from the node encoder's output, four wavefronts per 16-row tile (the
+// 48 -> 192 and 48 -> 432 products are 468 MFMAs: too long a chain for one wavefront).
+template <class D>
+using Proj0Seq2 = LayerSeq<L<D::DX, 2 * D::MH>, L<D::DX, Hoist<D>::TW>>;
+struct NodeProj0Args {
+  int N;
+  const float* x0;      // [N, DX]
+  float* T0;            // [N, 2 MH]
+  float* T;             // [N, TW]
+  const float* wpack;   // Proj0Seq2 images
 };
-
-template <class D, class Seq, class In, int NW>
-__global__ __launch_bounds__(NW * 64, 1) void node_enc_proj_kernel(const NodeEncProjArgs<In> a) {
+template <class D>
+__global__ __launch_bounds__(kNodeWaves * 64, 1) void node_proj0_split_kernel(const NodeProj0Args a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   using H = Hoist<D>;
-  static_assert(Seq::NL == 5 && Seq::np(2) == D::DX && Seq::np(3) == 2 * D::MH && Seq::np(4) == H::TW, "sequence layout");
-  constexpr int XB = D::DX / 16, A1B = Seq::np(0) / 16, A2B = Seq::np(1) / 16, T0B = 2 * D::MH / 16, TB = H::TW / 16;
-  constexpr int FB = H::OF / 16;
-  WStreamT<NW * 64, Seq::SLOT> ws;
+  using Seq = Proj0Seq2<D>;
+  constexpr int NWS = kNodeWaves;
+  constexpr int XB = D::DX / 16, FB = H::OF / 16, T0B = 2 * D::MH / 16;
+  static_assert(FB % NWS == 0 && T0B % NWS == 0, "table columns must split over the wavefronts");
+  WStreamT<NWS * 64> ws;
   ws.init(a.wpack, smem);
   ws.template start<Seq>();
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int ntiles = (a.rows + NW * 16 - 1) / (NW * 16);
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const bool more = tile + (int)gridDim.x < ntiles;
-    const long row = (long)tile * (NW * 16) + wave * kRowsPerWave + (lane & 15);
-    const bool valid = row < a.rows;
-    v4f in[In::NB];
-    a.in(row, valid, in);
-    if (a.save_in) store_row<In::NB>(a.save_in, row, 16 * In::NB, 0, valid, in);
-    v4f a1[A1B], a2[A2B], x[XB];
-    linear<Seq, 0, true>(ws, more, in, a1);
-    if (a.save[0]) store_row<A1B>(a.save[0], row, 16 * A1B, 0, valid, a1);
-    linear<Seq, 1, true>(ws, more, a1, a2);
-    if (a.save[1]) store_row<A2B>(a.save[1], row, 16 * A2B, 0, valid, a2);
-    linear<Seq, 2, false>(ws, more, a2, x);
-    store_row<XB>(a.x0, row, D::DX, 0, valid, x);
-    store_row<XB>(a.x_enc, row, D::DX, 0, valid, x);
-    v4f t0[T0B], t[TB];
-    linear<Seq, 3, false, false>(ws, more, x, t0);
-    store_row<T0B>(a.T0, row, 2 * D::MH, 0, valid, t0);
-    linear<Seq, 4, false, true>(ws, more, x, t);
-#pragma unroll
-    for (int b = 0; b < T0B; ++b) t[FB + b] += t0[b];
-    store_row<TB>(a.T, row, H::TW, 0, valid, t);
-  }
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 16 + (lane & 15);
+  const bool valid = row < a.N;
+  v4f x[XB];
+  load_row<XB>(a.x0, row, D::DX, 0, valid, x);
+  v4f t0[T0B / NWS];                          // this wavefront's blocks of the x0 terms (block j <-> table block FB + j)
+  linear_split<Seq, 0, false, false, NWS>(
+      ws, false, x, [&]() {},
+      [&](int mb, v4f v, int slot) {
+        t0[slot] = v;
+        store_row<1>(a.T0, row, 2 * D::MH, 16 * mb, valid, &v);
+      });
+  linear_split<Seq, 1, false, true, NWS>(
+      ws, false, x, [&]() {},
+      [&](int mb, v4f v, int slot) {
+        if (mb >= FB && mb < FB + T0B) v += t0[slot - FB / NWS];
+        store_row<1>(a.T, row, H::TW, 16 * mb, valid, &v);
+      });
 }
 
 // ---- backward -------------------------------------------------------------------------------------

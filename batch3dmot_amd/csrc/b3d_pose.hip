@@ -19,7 +19,7 @@ static bool hoist_enabled() {
 // encoders / classifier, widths padded to multiples of 16
 using SeqEdgeEnc = LayerSeq<L<16, 16>, L<16, 16>, L<16, 32>>;            // 4-8-16-32    pose_gnn.py:29-35
 using SeqNodeEnc = LayerSeq<L<32, 32>, L<32, 48>, L<48, 48>>;            // 19-24-36-48  :37-43
-using SeqNodeEncH = LayerSeq<L<32, 32>, L<32, 48>, L<48, 48>, L<48, 192>, L<48, 432>>;   // + x0 terms + layer-0 table
+using SeqNodeEncH = LayerSeq<L<32, 32>, L<32, 48>, L<48, 48>, L<48, 192>, L<48, 432>>;   // layers 3, 4: x0 terms + layer-0 table (node_proj0_split_kernel)
 using SeqCls = LayerSeq<L<32, 16>, L<16, 16>, L<16, 16>, L<16, 16>>;     // 32-16-8-4-1  :45-53
 using SeqClsT = LayerSeq<L<16, 16>, L<16, 16>, L<16, 16>, L<16, 32>>;    // W4^T, W3^T, W2^T, W1^T
 using SeqEdgeEncT = LayerSeq<L<32, 16>, L<16, 16>>;                      // W3^T, W2^T
@@ -298,7 +298,6 @@ static int pack_forward(const b3d_pose_weights* pw, PoseWs& w, bool training, bo
       d[n++] = pack_slice<S>(li, base, pa0.w, pa0.b, MH, DX, MIN, HP::OP, MH, false);             // past:   x[src]
       d[n++] = pack_slice<S>(li, base, knn ? pw->knn_conv.lin : nullptr, nullptr, DX, DX, DX, HP::OG, DX, false);   // GATConv.lin
     };
-    for (int i = 0; i < 3; ++i) d[n++] = pack_desc<SeqNodeEncH>(i, w.wp_ne_h, ne[i].w, ne[i].b, kLinDims[LIN_NE0 + i].N, kLinDims[LIN_NE0 + i].K, false);
     d[n++] = pack_slice<SeqNodeEncH>(3, w.wp_ne_h, fu0.w + DX + DE, nullptr, MH, DX, MIN, 0, MH, false);    // x0 columns
     d[n++] = pack_slice<SeqNodeEncH>(3, w.wp_ne_h, pa0.w + DX + DE, nullptr, MH, DX, MIN, MH, MH, false);
     proj(SeqNodeEncH{}, 4, w.wp_ne_h);
@@ -564,17 +563,7 @@ extern "C" int b3d_pose_forward(const b3d_pose_weights* pw, const b3d_graph* g, 
     a.wpack = w.wp_ee;
     B3D_TRY(launch_rows<kNWEdge>(chain_fwd_kernel<SeqEdgeEnc, 0x3u, LoadEdgeAttrF64, StoreAligned<2>, kNWEdge>, "edge_encoder", a, E, stream, B3D_K_OTHER, chain_lds<SeqEdgeEnc>()));
   }
-  if (w.hoist) {  // node encoder 19-24-36-48 + x0 terms + table of layer 0            pose_gnn.py:68-71
-    using In = LoadUnaligned<19>;
-    NodeEncProjArgs<In> a;
-    memset(&a, 0, sizeof(a));
-    a.rows = N; a.in.ptr = pose_feats;
-    a.save_in = w.pose_pad; a.save[0] = w.ne_a1; a.save[1] = w.ne_a2;
-    a.x0 = w.x[0]; a.x_enc = out_x_enc; a.T0 = w.T0; a.T = w.T;
-    a.wpack = w.wp_ne_h;
-    B3D_TRY(launch_rows<kNWNode>(node_enc_proj_kernel<D, SeqNodeEncH, In, kNWNode>, "node_encoder", a, N, stream, B3D_K_OTHER,
-                                 chain_lds<SeqNodeEncH>()));
-  } else {  // node encoder 19-24-36-48 (initial_x == x == x_enc)                  pose_gnn.py:68-71
+  {  // node encoder 19-24-36-48 (initial_x == x == x_enc)                          pose_gnn.py:68-71
     ChainFwdArgs<LoadUnaligned<19>, StoreTwo<3>> a;
     memset(&a, 0, sizeof(a));
     a.rows = N; a.in.ptr = pose_feats;
@@ -582,6 +571,12 @@ extern "C" int b3d_pose_forward(const b3d_pose_weights* pw, const b3d_graph* g, 
     a.save_in = w.pose_pad; a.save[0] = w.ne_a1; a.save[1] = w.ne_a2;
     a.wpack = w.wp_ne;
     B3D_TRY(launch_rows<kNWNode>(chain_fwd_kernel<SeqNodeEnc, 0x3u, LoadUnaligned<19>, StoreTwo<3>, kNWNode>, "node_encoder", a, N, stream, B3D_K_OTHER, chain_lds<SeqNodeEnc>()));
+  }
+  if (w.hoist) {  // x0 terms of the future / past columns (once per forward) + the per-node table of layer 0
+    NodeProj0Args a;
+    a.N = N; a.x0 = w.x[0]; a.T0 = w.T0; a.T = w.T;
+    a.wpack = w.wp_ne_h + SeqNodeEncH::layer_off(3);
+    B3D_TRY(launch_node_split<D>(node_proj0_split_kernel<D>, "node_proj0", a, N, stream, B3D_K_OTHER));
   }
   Side* knn_side = nullptr;
   for (int l = 0; l < depth; ++l) {
