@@ -406,89 +406,89 @@ static int mp_weight_grads(PoseWs& w, const MpGradSrc& ms, int N, int E, const i
   const size_t eL1 = (size_t)E * D::EH1, eL2 = (size_t)E * D::EH2, eLe = (size_t)E * D::DE, eLm = (size_t)E * D::MH;
   const size_t nLm = (size_t)N * D::NIN, nLx = (size_t)N * D::DX, nL1 = (size_t)N * D::NH1, nL2 = (size_t)N * D::NH2;
   (void)eLe; (void)nLx;
-    WsLauncher wl;
-    wl.begin(w.ws_table, 48, w.ws_task_job, kWsTaskCap, stream);
-    // w.iota / w.zrow were filled by the forward's pack launch
-    const int* iota = w.iota;
-    auto sg = [iota](const float* p, const int* idx, long vstride, int stride, int col0) {
-      WsSeg s; s.ptr = p; s.idx = idx ? idx : iota; s.vstride = vstride; s.stride = stride; s.col0 = col0; return s;
-    };
-    const WsSeg none = sg(nullptr, nullptr, 0, 0, 0);
-    auto add = [&](int wj, const WsSeg& gseg, const WsSeg& a0, int c0, const WsSeg& a1, int c1, bool bias) {
-      if (w.plan.nvar[wj] <= 0) return;
-      LinSlab& ls = (wj >= WJ_HEU0E) ? w.vlin[w.plan.lin[wj]] : w.lin[w.plan.lin[wj]];
-      WsJob jb;
-      memset(&jb, 0, sizeof(jb));
-      jb.g = gseg; jb.act[0] = a0; jb.act[1] = a1; jb.act[2] = a1;
-      jb.wcol[0] = c0; jb.wcol[1] = c1; jb.wcol[2] = 0; jb.wrow = 0; jb.write_bias = bias ? 1 : 0;
-      jb.shape = w.plan.shape[wj]; jb.rows = w.plan.rows[wj]; jb.nvar = w.plan.nvar[wj];
-      jb.rows_per_task = w.plan.rows_per_task[wj]; jb.ntasks = w.plan.ntasks[wj];
-      jb.NP = ls.NP; jb.KP = ls.KP; jb.slab = ls.slab;
-      wl.add(jb);
-      ls.used = true;
-    };
-    const float* x0 = ms.x0;
-    auto xrow = [&](const int* idx, int c0) { return sg(ms.x, idx, ms.xs, D::DX, c0); };      // x[l][idx], columns c0..
-    auto x0row = [&](const int* idx) { return sg(x0, idx, 0, D::DX, 0); };
-    auto erow = [&](int l0, int c0) { return sg(l0 ? ms.e_out : ms.e_in, nullptr, ms.es, D::DE, c0); };         // e[l + l0], columns c0..
-    // edge_update.0 (every layer): dW columns [x[dst] 0:48 | x[src] 48:96 | e 96:128]
-    const WsSeg gH1 = sg(ms.GdH1, nullptr, eL1, D::EH1, 0);
-    add(WJ_EU0A, gH1, xrow(dst, 0), 0, xrow(src, 0), 48, true);         // [x[dst] | x[src][0:16]]
-    add(WJ_EU0B, gH1, xrow(src, 16), 64, erow(0, 0), 96, false);        // [x[src][16:48] | e]
-    // message stacks .0 (layers 0 .. depth-2): columns [x[.] 0:48 | e' 48:80 | x0[.] 80:128]
-    const WsSeg gP1 = sg(ms.GdP1, nullptr, eLm, D::MH, 0), gF1 = sg(ms.GdF1, nullptr, eLm, D::MH, 0);
-    add(WJ_PA0A, gP1, xrow(src, 0), 0, erow(1, 0), 48, true);           // [x[src] | e'[0:16]]
-    add(WJ_PA0B, gP1, x0row(src), 80, erow(1, 16), 64, false);          // [x0[src] | e'[16:32]]
-    add(WJ_FU0A, gF1, xrow(dst, 0), 0, erow(1, 0), 48, true);
-    add(WJ_FU0B, gF1, x0row(dst), 80, erow(1, 16), 64, false);
-    // node update .0 (layers 0 .. depth-2)
-    const WsSeg gN1 = sg(ms.GnH1, nullptr, nL1, D::NH1, 0);
-    add(WJ_CF0A, gN1, sg(ms.M, nullptr, nLm, D::NIN, 0), 0, none, 0, true);
-    add(WJ_CF0B, gN1, sg(ms.M, nullptr, nLm, D::NIN, D::DM), D::DM, none, 0, false);
-    // single-job matrices
-    add(WJ_EU1, sg(ms.GdH2, nullptr, eL2, D::EH2, 0), sg(ms.sH1, nullptr, eL1, D::EH1, 0), 0, none, 0, true);
-    add(WJ_EU2, sg(ms.Gde, nullptr, eLe, D::DE, 0), sg(ms.sH2, nullptr, eL2, D::EH2, 0), 0, none, 0, true);
-    add(WJ_PA1, sg(ms.dM, dst, nLm, D::NIN, 0), sg(ms.sP1, nullptr, eLm, D::MH, 0), 0, none, 0, true);
-    add(WJ_FU1, sg(ms.dM, src, nLm, D::NIN, D::DM), sg(ms.sF1, nullptr, eLm, D::MH, 0), 0, none, 0, true);
-    add(WJ_CF1, sg(ms.GnH2, nullptr, nL2, D::NH2, 0), sg(ms.nH1, nullptr, nL1, D::NH1, 0), 0, none, 0, true);
-    add(WJ_CF2, sg(ms.Gdx, nullptr, nLx, D::DX, 0), sg(ms.nH2, nullptr, nL2, D::NH2, 0), 0, none, 0, true);
-    // hoisted first layers (nvar == 0 otherwise): edge columns over edges, node columns over nodes
-    {
-      const long tLs = (long)N * HP::GW;
-      auto tcol = [&](int off) { return sg(ms.dT, nullptr, tLs, HP::GW, off); };
-      add(WJ_HEU0E, gH1, erow(0, 0), 0, none, 0, true);
-      add(WJ_HFU0E, gF1, erow(1, 0), 0, none, 0, true);
-      add(WJ_HPA0E, gP1, erow(1, 0), 0, none, 0, true);
-      add(WJ_HEU0XI, tcol(HP::OA), xrow(nullptr, 0), 0, none, 0, false);
-      add(WJ_HEU0XJ, tcol(HP::OB), xrow(nullptr, 0), 0, none, 0, false);
-      add(WJ_HFU0X, tcol(HP::OF), xrow(nullptr, 0), 0, none, 0, false);
-      add(WJ_HFU0X0, tcol(HP::OF), x0row(nullptr), 0, none, 0, false);
-      add(WJ_HPA0X, tcol(HP::OP), xrow(nullptr, 0), 0, none, 0, false);
-      add(WJ_HPA0X0, tcol(HP::OP), x0row(nullptr), 0, none, 0, false);
-    }
-    // narrow stacks (whole model only; nvar == 0 in layer mode).  Row strides pad every width to 16, the
-    // padding columns only reach slab entries outside [N, K], which the reduce never reads.
-    auto narrow = [&](int wj, const float* gp, int gstride, const float* ap, int astride) {
-      add(wj, sg(gp, nullptr, 0, gstride, 0), sg(ap, nullptr, 0, astride, 0), 0, none, 0, true);
-    };
-    if (ms.have_logit_grad) narrow(WJ_C3, w.gc_top, 16, w.c_a3, 16);       // edge_classifier.6  [1,4]
-    narrow(WJ_C2, w.gc3, 16, w.c_a2, 16);                                  // .4  [4,8]
-    narrow(WJ_C1, w.gc2, 16, w.c_a1, 16);                                  // .2  [8,16]
-    narrow(WJ_C0, w.gc1, 16, ms.e_last, D::DE);                            // .0  [16,32]
-    narrow(WJ_NE2, w.gn_top, 48, w.ne_a2, 48);                             // node_encoder.4  [48,36]
-    narrow(WJ_NE1, w.gn2, 48, w.ne_a1, 32);                                // .2  [36,24]
-    narrow(WJ_NE0, w.gn1, 32, w.pose_pad, 32);                             // .0  [24,19]
-    narrow(WJ_EE2, ms.de0, D::DE, w.ee_a2, 16);                            // edge_encoder.4  [32,16]
-    narrow(WJ_EE1, w.ge2, 16, w.ee_a1, 16);                                // .2  [16,8]
-    narrow(WJ_EE0, w.ge1, 16, w.ea_pad, 16);                               // .0  [8,4]
-    static const bool ws2 = [] { const char* e = getenv("B3D_WS2"); return e ? atoi(e) != 0 : true; }();   // B3D_WS2=0: register-staged form
-    if (ws2 && w.hoist) {      // every job of the hoisted plan has one activation segment: LDS-DMA ring form
-      B3D_REQUIRE(wl.launch2(wstream2_kernel, kWs2LdsBytes, w.zrow, w.iota, B3D_K_WGRAD_EDGE) == 0, "wstream2: LDS attribute");
-    } else {
-      wl.launch(w.zrow, B3D_K_WGRAD_EDGE);
-    }
-    B3D_REQUIRE(wl.status == 0, "streaming weight gradient: job table overflow");
-    B3D_TRY(launch_check("wstream_kernel"));
+  WsLauncher wl;
+  wl.begin(w.ws_table, 48, w.ws_task_job, kWsTaskCap, stream);
+  // w.iota / w.zrow were filled by the forward's pack launch
+  const int* iota = w.iota;
+  auto sg = [iota](const float* p, const int* idx, long vstride, int stride, int col0) {
+    WsSeg s; s.ptr = p; s.idx = idx ? idx : iota; s.vstride = vstride; s.stride = stride; s.col0 = col0; return s;
+  };
+  const WsSeg none = sg(nullptr, nullptr, 0, 0, 0);
+  auto add = [&](int wj, const WsSeg& gseg, const WsSeg& a0, int c0, const WsSeg& a1, int c1, bool bias) {
+    if (w.plan.nvar[wj] <= 0) return;
+    LinSlab& ls = (wj >= WJ_HEU0E) ? w.vlin[w.plan.lin[wj]] : w.lin[w.plan.lin[wj]];
+    WsJob jb;
+    memset(&jb, 0, sizeof(jb));
+    jb.g = gseg; jb.act[0] = a0; jb.act[1] = a1; jb.act[2] = a1;
+    jb.wcol[0] = c0; jb.wcol[1] = c1; jb.wcol[2] = 0; jb.wrow = 0; jb.write_bias = bias ? 1 : 0;
+    jb.shape = w.plan.shape[wj]; jb.rows = w.plan.rows[wj]; jb.nvar = w.plan.nvar[wj];
+    jb.rows_per_task = w.plan.rows_per_task[wj]; jb.ntasks = w.plan.ntasks[wj];
+    jb.NP = ls.NP; jb.KP = ls.KP; jb.slab = ls.slab;
+    wl.add(jb);
+    ls.used = true;
+  };
+  const float* x0 = ms.x0;
+  auto xrow = [&](const int* idx, int c0) { return sg(ms.x, idx, ms.xs, D::DX, c0); };      // x[l][idx], columns c0..
+  auto x0row = [&](const int* idx) { return sg(x0, idx, 0, D::DX, 0); };
+  auto erow = [&](int l0, int c0) { return sg(l0 ? ms.e_out : ms.e_in, nullptr, ms.es, D::DE, c0); };         // e[l + l0], columns c0..
+  // edge_update.0 (every layer): dW columns [x[dst] 0:48 | x[src] 48:96 | e 96:128]
+  const WsSeg gH1 = sg(ms.GdH1, nullptr, eL1, D::EH1, 0);
+  add(WJ_EU0A, gH1, xrow(dst, 0), 0, xrow(src, 0), 48, true);         // [x[dst] | x[src][0:16]]
+  add(WJ_EU0B, gH1, xrow(src, 16), 64, erow(0, 0), 96, false);        // [x[src][16:48] | e]
+  // message stacks .0 (layers 0 .. depth-2): columns [x[.] 0:48 | e' 48:80 | x0[.] 80:128]
+  const WsSeg gP1 = sg(ms.GdP1, nullptr, eLm, D::MH, 0), gF1 = sg(ms.GdF1, nullptr, eLm, D::MH, 0);
+  add(WJ_PA0A, gP1, xrow(src, 0), 0, erow(1, 0), 48, true);           // [x[src] | e'[0:16]]
+  add(WJ_PA0B, gP1, x0row(src), 80, erow(1, 16), 64, false);          // [x0[src] | e'[16:32]]
+  add(WJ_FU0A, gF1, xrow(dst, 0), 0, erow(1, 0), 48, true);
+  add(WJ_FU0B, gF1, x0row(dst), 80, erow(1, 16), 64, false);
+  // node update .0 (layers 0 .. depth-2)
+  const WsSeg gN1 = sg(ms.GnH1, nullptr, nL1, D::NH1, 0);
+  add(WJ_CF0A, gN1, sg(ms.M, nullptr, nLm, D::NIN, 0), 0, none, 0, true);
+  add(WJ_CF0B, gN1, sg(ms.M, nullptr, nLm, D::NIN, D::DM), D::DM, none, 0, false);
+  // single-job matrices
+  add(WJ_EU1, sg(ms.GdH2, nullptr, eL2, D::EH2, 0), sg(ms.sH1, nullptr, eL1, D::EH1, 0), 0, none, 0, true);
+  add(WJ_EU2, sg(ms.Gde, nullptr, eLe, D::DE, 0), sg(ms.sH2, nullptr, eL2, D::EH2, 0), 0, none, 0, true);
+  add(WJ_PA1, sg(ms.dM, dst, nLm, D::NIN, 0), sg(ms.sP1, nullptr, eLm, D::MH, 0), 0, none, 0, true);
+  add(WJ_FU1, sg(ms.dM, src, nLm, D::NIN, D::DM), sg(ms.sF1, nullptr, eLm, D::MH, 0), 0, none, 0, true);
+  add(WJ_CF1, sg(ms.GnH2, nullptr, nL2, D::NH2, 0), sg(ms.nH1, nullptr, nL1, D::NH1, 0), 0, none, 0, true);
+  add(WJ_CF2, sg(ms.Gdx, nullptr, nLx, D::DX, 0), sg(ms.nH2, nullptr, nL2, D::NH2, 0), 0, none, 0, true);
+  // hoisted first layers (nvar == 0 otherwise): edge columns over edges, node columns over nodes
+  {
+    const long tLs = (long)N * HP::GW;
+    auto tcol = [&](int off) { return sg(ms.dT, nullptr, tLs, HP::GW, off); };
+    add(WJ_HEU0E, gH1, erow(0, 0), 0, none, 0, true);
+    add(WJ_HFU0E, gF1, erow(1, 0), 0, none, 0, true);
+    add(WJ_HPA0E, gP1, erow(1, 0), 0, none, 0, true);
+    add(WJ_HEU0XI, tcol(HP::OA), xrow(nullptr, 0), 0, none, 0, false);
+    add(WJ_HEU0XJ, tcol(HP::OB), xrow(nullptr, 0), 0, none, 0, false);
+    add(WJ_HFU0X, tcol(HP::OF), xrow(nullptr, 0), 0, none, 0, false);
+    add(WJ_HFU0X0, tcol(HP::OF), x0row(nullptr), 0, none, 0, false);
+    add(WJ_HPA0X, tcol(HP::OP), xrow(nullptr, 0), 0, none, 0, false);
+    add(WJ_HPA0X0, tcol(HP::OP), x0row(nullptr), 0, none, 0, false);
+  }
+  // narrow stacks (whole model only; nvar == 0 in layer mode).  Row strides pad every width to 16, the
+  // padding columns only reach slab entries outside [N, K], which the reduce never reads.
+  auto narrow = [&](int wj, const float* gp, int gstride, const float* ap, int astride) {
+    add(wj, sg(gp, nullptr, 0, gstride, 0), sg(ap, nullptr, 0, astride, 0), 0, none, 0, true);
+  };
+  if (ms.have_logit_grad) narrow(WJ_C3, w.gc_top, 16, w.c_a3, 16);       // edge_classifier.6  [1,4]
+  narrow(WJ_C2, w.gc3, 16, w.c_a2, 16);                                  // .4  [4,8]
+  narrow(WJ_C1, w.gc2, 16, w.c_a1, 16);                                  // .2  [8,16]
+  narrow(WJ_C0, w.gc1, 16, ms.e_last, D::DE);                            // .0  [16,32]
+  narrow(WJ_NE2, w.gn_top, 48, w.ne_a2, 48);                             // node_encoder.4  [48,36]
+  narrow(WJ_NE1, w.gn2, 48, w.ne_a1, 32);                                // .2  [36,24]
+  narrow(WJ_NE0, w.gn1, 32, w.pose_pad, 32);                             // .0  [24,19]
+  narrow(WJ_EE2, ms.de0, D::DE, w.ee_a2, 16);                            // edge_encoder.4  [32,16]
+  narrow(WJ_EE1, w.ge2, 16, w.ee_a1, 16);                                // .2  [16,8]
+  narrow(WJ_EE0, w.ge1, 16, w.ea_pad, 16);                               // .0  [8,4]
+  static const bool ws2 = [] { const char* e = getenv("B3D_WS2"); return e ? atoi(e) != 0 : true; }();   // B3D_WS2=0: register-staged form
+  if (ws2 && w.hoist) {      // every job of the hoisted plan has one activation segment: LDS-DMA ring form
+    B3D_REQUIRE(wl.launch2(wstream2_kernel, kWs2LdsBytes, w.zrow, w.iota, B3D_K_WGRAD_EDGE) == 0, "wstream2: LDS attribute");
+  } else {
+    wl.launch(w.zrow, B3D_K_WGRAD_EDGE);
+  }
+  B3D_REQUIRE(wl.status == 0, "streaming weight gradient: job table overflow");
+  B3D_TRY(launch_check("wstream_kernel"));
   return B3D_OK;
 }
 
