@@ -83,13 +83,13 @@ struct EdgeFwdHArgs {
 };
 
 template <class D, int NW>
-__global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void mp_edge_fwd_h_kernel(const EdgeFwdHArgs a) {
+__global__ __launch_bounds__(NW * 64, 16 / NW) void mp_edge_fwd_h_kernel(const EdgeFwdHArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   using H = Hoist<D>;
   using Seq = typename H::EdgeFwdSeq;
   constexpr int EB = D::DE / 16, AB = D::DA / 16;
   constexpr int H1B = D::EH1 / 16, H2B = D::EH2 / 16, MHB = D::MH / 16, DMB = D::DM / 16;
-  WStreamT<NW * 64> ws;
+  WStreamT<NW * 64, Seq::max_chunk()> ws;     // hoisted stacks: every chunk is <= 26 KB, the ring takes 52 KB
   ws.init(a.wpack, smem);
   ws.template start<Seq>();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -202,14 +202,14 @@ struct EdgeBwdHArgs {
 // Data gradient of the edge phase without the node columns of the three first layers: those are
 // contracted per NODE from the segment sums of GdH1 / GdF1 / GdP1 (node_gradproj_kernel).
 template <class D, bool MSGS, int NW>
-__global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void mp_edge_bwd_h_kernel(const EdgeBwdHArgs a) {
+__global__ __launch_bounds__(NW * 64, 16 / NW) void mp_edge_bwd_h_kernel(const EdgeBwdHArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   using H = Hoist<D>;
   using Seq = typename std::conditional<MSGS, typename H::EdgeBwdSeq, typename H::EdgeBwdSeqNoMsg>::type;
   constexpr int L0 = MSGS ? 4 : 0;
   constexpr int EB = D::DE / 16, AB = D::DA / 16;
   constexpr int H1B = D::EH1 / 16, H2B = D::EH2 / 16, MHB = D::MH / 16, DMB = D::DM / 16;
-  WStreamT<NW * 64> ws;
+  WStreamT<NW * 64, Seq::max_chunk()> ws;     // hoisted stacks: every chunk is <= 26 KB, the ring takes 52 KB
   ws.init(a.wpack, smem);
   ws.template start<Seq>();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;

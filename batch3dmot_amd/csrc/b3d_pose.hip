@@ -10,6 +10,10 @@ namespace b3d {
 
 using D = DimsP;
 using HP = Hoist<DimsP>;
+#ifndef B3D_NW_EDGE_H
+#define B3D_NW_EDGE_H 8
+#endif
+constexpr int kNWEdgeH = B3D_NW_EDGE_H;   // wavefronts per workgroup of the hoisted edge kernels (4 = two workgroups per CU: measured 1.6x slower, the LDS-DMA weight stream per CU doubles)
 
 // Hoisted first layers (b3d_hoist.hpp).  B3D_HOIST=0 selects the unsplit kernels (A/B comparisons).
 static bool hoist_enabled() {
@@ -602,7 +606,7 @@ extern "C" int b3d_pose_forward(const b3d_pose_weights* pw, const b3d_graph* g, 
       ea.e_out = w.e[l + 1]; ea.fut = w.fut; ea.past = w.past;
       ea.sH1 = w.sH1[l]; ea.sH2 = w.sH2[l]; ea.sF1 = w.sF1[l]; ea.sP1 = w.sP1[l];
       ea.wpack = w.wp_efwd_h;
-      B3D_TRY(launch_rows<kNWEdge>(mp_edge_fwd_h_kernel<D, kNWEdge>, "mp_edge_fwd", ea, E, stream, B3D_K_EDGE_FWD));
+      B3D_TRY(launch_rows<kNWEdgeH>(mp_edge_fwd_h_kernel<D, kNWEdgeH>, "mp_edge_fwd", ea, E, stream, B3D_K_EDGE_FWD, 2 * HP::EdgeFwdSeq::max_chunk() * 4));
     } else {
     EdgeFwdArgs ea;
     memset(&ea, 0, sizeof(ea));
@@ -739,10 +743,10 @@ extern "C" int b3d_pose_backward(const b3d_pose_weights* pw, const b3d_graph* g,
       eb.GdF1 = w.GdF1 + l * eLm; eb.GdP1 = w.GdP1 + l * eLm;
       if (msgs) {
         eb.wpack = w.wp_ebwd_h;
-        B3D_TRY(launch_rows<kNWEdge>(mp_edge_bwd_h_kernel<D, true, kNWEdge>, "mp_edge_bwd", eb, E, stream, B3D_K_EDGE_BWD));
+        B3D_TRY(launch_rows<kNWEdgeH>(mp_edge_bwd_h_kernel<D, true, kNWEdgeH>, "mp_edge_bwd", eb, E, stream, B3D_K_EDGE_BWD, 2 * HP::EdgeBwdSeq::max_chunk() * 4));
       } else {
         eb.wpack = w.wp_ebwd_nm_h;
-        B3D_TRY(launch_rows<kNWEdge>(mp_edge_bwd_h_kernel<D, false, kNWEdge>, "mp_edge_bwd_last", eb, E, stream, B3D_K_OTHER));
+        B3D_TRY(launch_rows<kNWEdgeH>(mp_edge_bwd_h_kernel<D, false, kNWEdgeH>, "mp_edge_bwd_last", eb, E, stream, B3D_K_OTHER, 2 * HP::EdgeBwdSeqNoMsg::max_chunk() * 4));
       }
     } else {
     EdgeBwdArgs eb;
