@@ -220,38 +220,42 @@ __global__ __launch_bounds__(NW * 64, 16 / NW) void mp_edge_bwd_h_kernel(const E
     const bool valid = row < a.E;
     int s = 0, d = 0;
     if (valid) { s = a.src[row]; d = a.dst[row]; }
+    // Every weight-chunk acquire drains vmcnt (the LDS-DMA shares the counter with loads and stores), so a load
+    // issued right in front of one is waited for at once and a store in front of one is flushed at once.
+    // Loads are therefore issued a whole layer before their use and stores right AFTER the next layer's
+    // barrier (as that layer's hook): both then have a layer of MFMAs to complete under.
     v4f de[EB];
     load_row<EB>(a.de_out, row, D::DE, 0, valid, de);
+    v4f act2[H2B], act1[H1B], d2[H2B], d1[H1B];
     if constexpr (MSGS) {
-      v4f dmsg[DMB], act[MHB], dh[MHB], dee[EB];
-      load_row<DMB>(a.dM, d, 2 * D::DM, 0, valid, dmsg);           // past messages were summed at dst
-      load_row<MHB>(a.sP1, row, D::MH, 0, valid, act);
-      linear<Seq, 0, false, false>(ws, more, dmsg, dh);
-      relu_bwd<MHB>(dh, act);
-      store_row<MHB>(a.GdP1, row, D::MH, 0, valid, dh);
-      linear<Seq, 1, false, false>(ws, more, dh, dee);
+      v4f dmp[DMB], dmf[DMB], actp[MHB], actf[MHB], dh[MHB], dh2[MHB], dee[EB];
+      load_row<DMB>(a.dM, d, 2 * D::DM, 0, valid, dmp);            // past messages were summed at dst
+      load_row<MHB>(a.sP1, row, D::MH, 0, valid, actp);
+      load_row<DMB>(a.dM, s, 2 * D::DM, D::DM, valid, dmf);        // future messages were summed at src
+      linear<Seq, 0, false, false>(ws, more, dmp, dh, [&]() { load_row<MHB>(a.sF1, row, D::MH, 0, valid, actf); });
+      relu_bwd<MHB>(dh, actp);
+      linear<Seq, 1, false, false>(ws, more, dh, dee, [&]() {
+        store_row<MHB>(a.GdP1, row, D::MH, 0, valid, dh);
+        load_row<H2B>(a.sH2, row, D::EH2, 0, valid, act2);
+      });
       add_blocks<EB>(de, dee);
-      load_row<DMB>(a.dM, s, 2 * D::DM, D::DM, valid, dmsg);       // future messages were summed at src
-      load_row<MHB>(a.sF1, row, D::MH, 0, valid, act);
-      linear<Seq, 2, false, false>(ws, more, dmsg, dh);
-      relu_bwd<MHB>(dh, act);
-      store_row<MHB>(a.GdF1, row, D::MH, 0, valid, dh);
-      linear<Seq, 3, false, false>(ws, more, dh, dee);
+      linear<Seq, 2, false, false>(ws, more, dmf, dh2);
+      relu_bwd<MHB>(dh2, actf);
+      linear<Seq, 3, false, false>(ws, more, dh2, dee, [&]() {
+        store_row<MHB>(a.GdF1, row, D::MH, 0, valid, dh2);
+        load_row<H1B>(a.sH1, row, D::EH1, 0, valid, act1);
+      });
       add_blocks<EB>(de, dee);
+    } else {
+      load_row<H2B>(a.sH2, row, D::EH2, 0, valid, act2);
+      load_row<H1B>(a.sH1, row, D::EH1, 0, valid, act1);
     }
-    store_row<EB>(a.Gde, row, D::DE, 0, valid, de);
-    v4f act2[H2B], d2[H2B];
-    load_row<H2B>(a.sH2, row, D::EH2, 0, valid, act2);
-    linear<Seq, L0 + 0, false, false>(ws, more, de, d2);
+    linear<Seq, L0 + 0, false, false>(ws, more, de, d2, [&]() { store_row<EB>(a.Gde, row, D::DE, 0, valid, de); });
     relu_bwd<H2B>(d2, act2);
-    store_row<H2B>(a.GdH2, row, D::EH2, 0, valid, d2);
-    v4f act1[H1B], d1[H1B];
-    load_row<H1B>(a.sH1, row, D::EH1, 0, valid, act1);
-    linear<Seq, L0 + 1, false, false>(ws, more, d2, d1);
+    linear<Seq, L0 + 1, false, false>(ws, more, d2, d1, [&]() { store_row<H2B>(a.GdH2, row, D::EH2, 0, valid, d2); });
     relu_bwd<H1B>(d1, act1);
-    store_row<H1B>(a.GdH1, row, D::EH1, 0, valid, d1);
     v4f dein[EB + AB];
-    linear<Seq, L0 + 2, false, false>(ws, more, d1, dein);
+    linear<Seq, L0 + 2, false, false>(ws, more, d1, dein, [&]() { store_row<H1B>(a.GdH1, row, D::EH1, 0, valid, d1); });
     store_row<EB>(a.de_in, row, D::DE, 0, valid, dein);
     if constexpr (AB > 0) {
       if (!a.da_first) {
