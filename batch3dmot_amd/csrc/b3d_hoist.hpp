@@ -293,12 +293,13 @@ struct GradProjLds {
 
 // (dx | dx0) = sum over the four lists of (node columns)^T . dT_list: layers LI0 .. LI0+3 of Seq.  The wavefront
 // that owns output block mb (mb % NWS == wave, the same in all four products) keeps its partial in `keep`.
-template <class Seq, int LI0, int NWS, int LB, class WS>
-__device__ __forceinline__ v4f gradproj_products(WS& ws, const v4f* __restrict__ xt, int lane) {
+template <class Seq, int LI0, int NWS, int LB, class WS, class Hook>
+__device__ __forceinline__ v4f gradproj_products(WS& ws, const v4f* __restrict__ xt, int lane, Hook first) {
   v4f keep = {0.f, 0.f, 0.f, 0.f};
   v4f dt[LB];
   auto acc = [&](int, v4f v) { keep += v; };
   linear_split<Seq, LI0 + 0, false, false, NWS>(ws, false, dt, [&]() {
+    first();                                   // work that must sit BEHIND the first barrier (stores of the list sums)
 #pragma unroll
     for (int b = 0; b < LB; ++b) dt[b] = xt[(0 * LB + b) * 64 + lane];
   }, acc);
@@ -335,9 +336,9 @@ __global__ __launch_bounds__(kGradProjWaves * 64, 1) void node_gradproj_kernel(c
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 16 + (lane & 15);
   const bool valid = row < a.N;
+  v4f part[HB];
   {
     const int list = wave & 3, half = wave >> 2;             // list: dH1 by dst, dH1 by src, dF1 by dst, dP1 by src
-    v4f part[HB];
 #pragma unroll
     for (int b = 0; b < HB; ++b) part[b] = v4f{0.f, 0.f, 0.f, 0.f};
     const float* base = (list < 2) ? a.GdH1 : (list == 2 ? a.GdF1 : a.GdP1);
@@ -349,9 +350,10 @@ __global__ __launch_bounds__(kGradProjWaves * 64, 1) void node_gradproj_kernel(c
     }
 #pragma unroll
     for (int b = 0; b < HB; ++b) xb[(list * LB + half * HB + b) * 64 + lane] = part[b];
-    store_row<HB>(a.dT, row, H::GW, 16 * (LB * list + HB * half), valid, part);
   }
-  const v4f keep = gradproj_products<Seq, 0, NWS, LB>(ws, xb, lane);
+  const v4f keep = gradproj_products<Seq, 0, NWS, LB>(ws, xb, lane, [&]() {
+    store_row<HB>(a.dT, row, H::GW, 16 * (LB * (wave & 3) + HB * (wave >> 2)), valid, part);
+  });
   if (wave < 2 * D::DX / 16) store_row<1>(a.gx, row, 2 * D::DX, 16 * wave, valid, &keep);
   (void)TB;
 }
@@ -403,9 +405,12 @@ __global__ __launch_bounds__(kGradProjWaves * 64, 1) void node_bwd_h_kernel(cons
   v4f act2[H2B], act1[H1B];
   load_row<H2B>(a.sH2, row, D::NH2, 0, valid, act2);
   load_row<H1B>(a.sH1, row, D::NH1, 0, valid, act1);
+  // running d initial_x of the block this wavefront will own (loaded now: the acquire in front of its use would expose it)
+  v4f prev0 = {0.f, 0.f, 0.f, 0.f};
+  if (!a.dx0_first && wave >= XB && wave < GB) load_row<1>(a.dx0_acc, row, D::DX, 16 * (wave - XB), valid, &prev0);
+  v4f part[HB];
   {
     const int list = wave & 3, half = wave >> 2;
-    v4f part[HB];
 #pragma unroll
     for (int b = 0; b < HB; ++b) part[b] = v4f{0.f, 0.f, 0.f, 0.f};
     const float* base = (list < 2) ? a.gp.GdH1 : (list == 2 ? a.gp.GdF1 : a.gp.GdP1);
@@ -417,28 +422,19 @@ __global__ __launch_bounds__(kGradProjWaves * 64, 1) void node_bwd_h_kernel(cons
     }
 #pragma unroll
     for (int b = 0; b < HB; ++b) xt[(list * LB + half * HB + b) * 64 + lane] = part[b];
-    store_row<HB>(a.gp.dT, row, H::GW, 16 * (LB * list + HB * half), valid, part);
   }
-  {
-    v4f v = gradproj_products<Seq, 0, NWS, LB>(ws, xt, lane);
-    const int mb = wave;                                      // output block this wavefront owns (mb < 2 XB)
-    if (mb < XB) {                                            // d x' : G of combine_future_past.4, input of the next stage
-      store_row<1>(a.Gdx, row, D::DX, 16 * mb, valid, &v);
-      xb0[mb * 64 + lane] = v;
-    } else if (mb < GB) {                                     // d x0 contribution
-      if (!a.dx0_first) {
-        v4f prev;
-        load_row<1>(a.dx0_acc, row, D::DX, 16 * (mb - XB), valid, &prev);
-        v += prev;
-      }
-      store_row<1>(a.dx0_acc, row, D::DX, 16 * (mb - XB), valid, &v);
-    }
-  }
-  (void)GB;
+  // this wavefront's block of (dx | dx0): block `wave` (< 2 XB); stored behind the next barrier
+  v4f own = gradproj_products<Seq, 0, NWS, LB>(ws, xt, lane, [&]() {
+    store_row<HB>(a.gp.dT, row, H::GW, 16 * (LB * (wave & 3) + HB * (wave >> 2)), valid, part);
+  });
+  if (wave < XB) xb0[wave * 64 + lane] = own;                 // d x': input of the node MLP's data gradient
+  else if (wave < GB) own += prev0;
   v4f g[XB], d2[H2B], d1[H1B];
   linear_split<Seq, 4, false, false, NWS>(
       ws, false, g,
       [&]() {
+        if (wave < XB) store_row<1>(a.Gdx, row, D::DX, 16 * wave, valid, &own);            // G of combine_future_past.4
+        else if (wave < GB) store_row<1>(a.dx0_acc, row, D::DX, 16 * (wave - XB), valid, &own);
 #pragma unroll
         for (int b = 0; b < XB; ++b) g[b] = xb0[b * 64 + lane];
       },

@@ -116,12 +116,21 @@ __device__ __forceinline__ void node_fwd_split_body(const NodeFwdArgs& a, float*
   const long row = (long)blockIdx.x * 16 + (lane & 15);
   const bool valid = row < a.N;
 
+  // Every weight-chunk acquire drains vmcnt: stores are issued right AFTER the next layer's barrier (by the
+  // block's owner, from the values every wavefront reads back), loads a stage ahead of their use.
+  constexpr int PFB = 2 * D::EH1 / 16, PT0B = 2 * D::MH / 16, PT0N = PT0B / NWS;
+  v4f t0[PROJ ? PT0N : 1];                       // PROJ: this wavefront's blocks of the x0 terms
+  if constexpr (PROJ) {
+    static_assert(PFB % NWS == 0 && PT0B % NWS == 0, "table columns must split over the wavefronts");
+#pragma unroll
+    for (int i = 0; i < PT0N; ++i) load_row<1>(a.T0, row, 16 * PT0B, 16 * (wave + NWS * i), valid, &t0[i]);
+  }
   // ---- segment sums: waves [0, NWS/2) own the `past` half of M, the others the `fut` half ----
+  v4f part[BPW];
+  const int blk0 = wave * BPW;
   {
-    v4f part[BPW];
 #pragma unroll
     for (int b = 0; b < BPW; ++b) part[b] = v4f{0.f, 0.f, 0.f, 0.f};
-    const int blk0 = wave * BPW;
     if (valid) {
       constexpr int U = BPW <= 3 ? 8 : 4;                    // rows in flight per lane (MI355X: 8 beats 4 and 16)
       if (blk0 < DMB) segment_sum_deep<BPW, U>(a.past, D::DM, 16 * blk0, a.dst_perm, a.dst_ptr[row], a.dst_ptr[row + 1], part);
@@ -129,55 +138,57 @@ __device__ __forceinline__ void node_fwd_split_body(const NodeFwdArgs& a, float*
     }
 #pragma unroll
     for (int b = 0; b < BPW; ++b) xb0[(blk0 + b) * 64 + lane] = part[b];
-    if (a.M) store_row<BPW>(a.M, row, 2 * D::DM, 16 * blk0, valid, part);
   }
   v4f m[MB2], h1[H1B], h2[H2B];
   linear_split<Seq, 0, true, true, NWS>(
       ws, false, m,
       [&]() {
+        if (a.M) store_row<BPW>(a.M, row, 2 * D::DM, 16 * blk0, valid, part);
 #pragma unroll
         for (int b = 0; b < MB2; ++b) m[b] = xb0[b * 64 + lane];
       },
-      [&](int mb, v4f v) {
-        xb1[mb * 64 + lane] = v;
-        if (a.sH1) store_row<1>(a.sH1, row, D::NH1, 16 * mb, valid, &v);
-      });
+      [&](int mb, v4f v) { xb1[mb * 64 + lane] = v; });
   linear_split<Seq, 1, true, true, NWS>(
       ws, false, h1,
       [&]() {
 #pragma unroll
         for (int b = 0; b < H1B; ++b) h1[b] = xb1[b * 64 + lane];
+        if (a.sH1) {
+#pragma unroll
+          for (int b = 0; b < H1B; ++b)
+            if (b % NWS == wave) store_row<1>(a.sH1, row, D::NH1, 16 * b, valid, &h1[b]);
+        }
       },
-      [&](int mb, v4f v) {
-        xb0[mb * 64 + lane] = v;
-        if (a.sH2) store_row<1>(a.sH2, row, D::NH2, 16 * mb, valid, &v);
-      });
+      [&](int mb, v4f v) { xb0[mb * 64 + lane] = v; });
   linear_split<Seq, 2, false, true, NWS>(
       ws, false, h2,
       [&]() {
 #pragma unroll
         for (int b = 0; b < H2B; ++b) h2[b] = xb0[b * 64 + lane];
+        if (a.sH2) {
+#pragma unroll
+          for (int b = 0; b < H2B; ++b)
+            if (b % NWS == wave) store_row<1>(a.sH2, row, D::NH2, 16 * b, valid, &h2[b]);
+        }
       },
       [&](int mb, v4f v) {
-        store_row<1>(a.x_out, row, D::DX, 16 * mb, valid, &v);
-        if constexpr (PROJ) xb1[mb * 64 + lane] = v;
+        if constexpr (PROJ) xb1[mb * 64 + lane] = v;                  // stored behind the projection's barrier
+        else store_row<1>(a.x_out, row, D::DX, 16 * mb, valid, &v);
       });
   if constexpr (PROJ) {
     // per-node parts of the NEXT layer's three first Linear layers (b3d_hoist.hpp): T = Wp x' + bp (+ x0 terms)
     // columns: first-layer parts (A | B | F | P), then GATConv.lin(x) of the discarded k-NN block; only F | P
     // carry x0 terms
-    constexpr int FB = 2 * D::EH1 / 16, T0B = 2 * D::MH / 16, TB = FB + T0B + D::DX / 16, TW = 16 * TB;
-    static_assert(FB % NWS == 0 && T0B % NWS == 0, "table columns must split over the wavefronts");
-    constexpr int T0N = T0B / NWS;
-    v4f t0[T0N];                                 // this wavefront's blocks of the x0 terms
-#pragma unroll
-    for (int i = 0; i < T0N; ++i) load_row<1>(a.T0, row, 16 * T0B, 16 * (wave + NWS * i), valid, &t0[i]);
+    constexpr int FB = PFB, T0B = PT0B, TB = FB + T0B + D::DX / 16, TW = 16 * TB;
     v4f xn[XB];
     linear_split<Seq, 3, false, true, NWS>(
         ws, false, xn,
         [&]() {
 #pragma unroll
           for (int b = 0; b < XB; ++b) xn[b] = xb1[b * 64 + lane];
+#pragma unroll
+          for (int b = 0; b < XB; ++b)
+            if (b % NWS == wave) store_row<1>(a.x_out, row, D::DX, 16 * b, valid, &xn[b]);
         },
         [&](int mb, v4f v, int slot) {
           if (mb >= FB && mb < FB + T0B) v += t0[slot - FB / NWS];
