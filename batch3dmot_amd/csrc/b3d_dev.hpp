@@ -323,6 +323,30 @@ __device__ __forceinline__ void load_row(const float* __restrict__ base, long ro
   }
 }
 
+// Unconditional form: the caller guarantees a readable row (out-of-range tile rows are clamped to a valid
+// row; their results are never stored).  A predicated load makes hipcc stage the result through temporaries
+// and wait for every pair of loads before reusing them -- the gathers of a prologue then run serially.
+template <int NBLK>
+__device__ __forceinline__ void load_row_u(const float* __restrict__ base, long row, int stride, int col0,
+                                           v4f* __restrict__ dst) {
+  const int q = (threadIdx.x & 63) >> 4;
+  const float* p = base + row * (long)stride + col0 + 4 * q;
+#pragma unroll
+  for (int b = 0; b < NBLK; ++b) dst[b] = *reinterpret_cast<const v4f*>(p + 16 * b);
+}
+
+// Make the compiler wait for a loaded value HERE.  While an LDS-DMA is pending hipcc waits vmcnt(0) (not a
+// counted vmcnt) at the first use of any ordinary load result; if that first use sits behind the issue of
+// the next weight chunk, the wavefront waits for that chunk before computing on the current one and the
+// ring overlaps nothing.  Touching the value right in front of an acquire (which waits vmcnt(0) anyway)
+// moves the wait to where it is free.
+__device__ __forceinline__ void wait_for(const v4f& v) { asm volatile("" ::"v"(v.x)); }
+template <int N>
+__device__ __forceinline__ void wait_for(const v4f (&a)[N]) {      // every block: hipcc reorders the loads
+#pragma unroll
+  for (int b = 0; b < N; ++b) wait_for(a[b]);
+}
+
 template <int NBLK>
 __device__ __forceinline__ void store_row(float* __restrict__ base, long row, int stride, int col0,
                                           bool valid, const v4f* __restrict__ src) {

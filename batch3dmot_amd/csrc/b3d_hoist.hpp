@@ -98,27 +98,36 @@ __global__ __launch_bounds__(NW * 64, 16 / NW) void mp_edge_fwd_h_kernel(const E
     const bool more = tile + (int)gridDim.x < ntiles;
     const long row = (long)tile * (NW * 16) + wave * kRowsPerWave + (lane & 15);
     const bool valid = row < a.E;
-    int s = 0, d = 0;
-    if (valid) { s = a.src[row]; d = a.dst[row]; }
+    const long rc = valid ? row : (long)a.E - 1;             // rows past the end read the last edge (never stored)
+    const int s = a.src[rc], d = a.dst[rc];
 
+    // gathers: unconditional loads straight into their registers, all in flight together; the future / past
+    // rows are fetched a layer ahead of their use (as hooks, behind a barrier) to keep the prologue light
     v4f ein[EB + AB];
-    load_row<EB>(a.e_in, row, D::DE, 0, valid, ein);
-    if constexpr (AB > 0) load_row<AB>(a.a_in, row, D::DA, 0, valid, ein + EB);
+    load_row_u<EB>(a.e_in, rc, D::DE, 0, ein);
+    if constexpr (AB > 0) load_row_u<AB>(a.a_in, rc, D::DA, 0, ein + EB);
     v4f h1[H1B], tb[H1B], fi[MHB], pi[MHB];
-    load_row<H1B>(a.T, d, H::TW, H::OA, valid, h1);
-    load_row<H1B>(a.T, s, H::TW, H::OB, valid, tb);
-    load_row<MHB>(a.T, d, H::TW, H::OF, valid, fi);
-    load_row<MHB>(a.T, s, H::TW, H::OP, valid, pi);
+    load_row_u<H1B>(a.T, d, H::TW, H::OA, h1);
+    load_row_u<H1B>(a.T, s, H::TW, H::OB, tb);
+    wait_for(ein); wait_for(h1); wait_for(tb);             // every prologue load has landed before the first acquire
     add_blocks<H1B>(h1, tb);
 
     v4f h2[H2B], en[EB];
     linear_init<Seq, 0, true, false>(ws, more, ein, h1, h1);
-    linear<Seq, 1, true>(ws, more, h1, h2, [&]() { if (a.sH1) store_row<H1B>(a.sH1, row, D::EH1, 0, valid, h1); });
-    linear<Seq, 2, false>(ws, more, h2, en, [&]() { if (a.sH2) store_row<H2B>(a.sH2, row, D::EH2, 0, valid, h2); });
+    linear<Seq, 1, true>(ws, more, h1, h2, [&]() {
+      if (a.sH1) store_row<H1B>(a.sH1, row, D::EH1, 0, valid, h1);
+      load_row_u<MHB>(a.T, d, H::TW, H::OF, fi);
+    });
+    linear<Seq, 2, false>(ws, more, h2, en, [&]() {
+      if (a.sH2) store_row<H2B>(a.sH2, row, D::EH2, 0, valid, h2);
+      load_row_u<MHB>(a.T, s, H::TW, H::OP, pi);
+    });
 
     v4f mo[DMB], mo2[DMB];
+    wait_for(fi);
     linear_init<Seq, 3, true, false>(ws, more, en, fi, fi, [&]() { store_row<EB>(a.e_out, row, D::DE, 0, valid, en); });
     linear<Seq, 4, false>(ws, more, fi, mo, [&]() { if (a.sF1) store_row<MHB>(a.sF1, row, D::MH, 0, valid, fi); });
+    wait_for(pi);
     linear_init<Seq, 5, true, false>(ws, more, en, pi, pi, [&]() { store_row<DMB>(a.fut, row, D::DM, 0, valid, mo); });
     linear<Seq, 6, false>(ws, more, pi, mo2, [&]() { if (a.sP1) store_row<MHB>(a.sP1, row, D::MH, 0, valid, pi); });
     store_row<DMB>(a.past, row, D::DM, 0, valid, mo2);
@@ -232,6 +241,7 @@ __global__ __launch_bounds__(NW * 64, 16 / NW) void mp_edge_bwd_h_kernel(const E
       load_row<DMB>(a.dM, d, 2 * D::DM, 0, valid, dmp);            // past messages were summed at dst
       load_row<MHB>(a.sP1, row, D::MH, 0, valid, actp);
       load_row<DMB>(a.dM, s, 2 * D::DM, D::DM, valid, dmf);        // future messages were summed at src
+      wait_for(de); wait_for(dmp); wait_for(actp); wait_for(dmf);   // the prologue's loads have landed
       linear<Seq, 0, false, false>(ws, more, dmp, dh, [&]() { load_row<MHB>(a.sF1, row, D::MH, 0, valid, actf); });
       relu_bwd<MHB>(dh, actp);
       linear<Seq, 1, false, false>(ws, more, dh, dee, [&]() {
@@ -239,6 +249,7 @@ __global__ __launch_bounds__(NW * 64, 16 / NW) void mp_edge_bwd_h_kernel(const E
         load_row<H2B>(a.sH2, row, D::EH2, 0, valid, act2);
       });
       add_blocks<EB>(de, dee);
+      wait_for(actf);
       linear<Seq, 2, false, false>(ws, more, dmf, dh2);
       relu_bwd<MHB>(dh2, actf);
       linear<Seq, 3, false, false>(ws, more, dh2, dee, [&]() {
@@ -249,9 +260,12 @@ __global__ __launch_bounds__(NW * 64, 16 / NW) void mp_edge_bwd_h_kernel(const E
     } else {
       load_row<H2B>(a.sH2, row, D::EH2, 0, valid, act2);
       load_row<H1B>(a.sH1, row, D::EH1, 0, valid, act1);
+      wait_for(de);
     }
+    wait_for(act2);
     linear<Seq, L0 + 0, false, false>(ws, more, de, d2, [&]() { store_row<EB>(a.Gde, row, D::DE, 0, valid, de); });
     relu_bwd<H2B>(d2, act2);
+    wait_for(act1);
     linear<Seq, L0 + 1, false, false>(ws, more, d2, d1, [&]() { store_row<H2B>(a.GdH2, row, D::EH2, 0, valid, d2); });
     relu_bwd<H1B>(d1, act1);
     v4f dein[EB + AB];
