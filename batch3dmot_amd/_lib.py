@@ -157,6 +157,9 @@ def load() -> C.CDLL:
     lib.b3d_pose_debug_knn_ptrs.restype = C.c_int
     lib.b3d_pose_debug_knn_ptrs.argtypes = [C.c_void_p, C.c_size_t, C.c_int32, C.c_int32, C.c_int32, C.c_uint32,
                                             C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.b3d_adam_step_dev.restype = C.c_int
+    lib.b3d_adam_step_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
+                                      C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
     lib.b3d_prof_enable.argtypes = [C.c_int]
     lib.b3d_prof_select.argtypes = [C.c_uint32]
     lib.b3d_prof_select.restype = C.c_int

@@ -2,6 +2,7 @@
 #include "b3d_common.hpp"
 
 #include <mutex>
+#include <utility>
 #include <vector>
 
 namespace b3d {
@@ -70,6 +71,26 @@ std::mutex g_side_mu;
 constexpr int kMaxDevices = 64;
 SideSet g_sides[kMaxDevices];
 }  // namespace
+
+int set_lds_cached(const void* kernel, int bytes) {
+  struct Done { const void* kernel; int dev, bytes; };
+  static std::mutex mu;
+  static std::vector<Done> done;                              // largest size granted per (kernel, device)
+  int dev = 0;
+  B3D_HIP_CHECK(hipGetDevice(&dev));
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto& d : done)
+      if (d.kernel == kernel && d.dev == dev && d.bytes >= bytes) return B3D_OK;
+  }
+  hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return fail(B3D_ERR_HIP, "hipFuncSetAttribute(%d B LDS): %s", bytes, hipGetErrorString(e));
+  std::lock_guard<std::mutex> lk(mu);
+  for (auto& d : done)
+    if (d.kernel == kernel && d.dev == dev) { if (d.bytes < bytes) d.bytes = bytes; return B3D_OK; }
+  done.push_back(Done{kernel, dev, bytes});
+  return B3D_OK;
+}
 
 int side_get(int idx, Side** out) {
   B3D_REQUIRE(idx >= 0 && idx < kSideStreams, "side_get: bad index %d", idx);

@@ -57,6 +57,10 @@ struct ProfScope {
   ~ProfScope() { if (on) prof_end(s); }
 };
 
+// Raise a kernel's dynamic-LDS limit once per (kernel, device): hipFuncSetAttribute costs ~2 us of host time
+// and a training step launches ~45 kernels.
+int set_lds_cached(const void* kernel, int bytes);
+
 // Library-owned side streams (one set per device, created on first use, never destroyed): work
 // that has no consumer on the caller's stream until later (the discarded k-NN + GAT block, weight
 // gradients) is forked onto them and joined back before the entry point returns, so that from the

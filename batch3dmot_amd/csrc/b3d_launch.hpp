@@ -12,12 +12,8 @@ namespace b3d {
 
 template <class K>
 inline int set_lds(K kernel, int bytes) {
-  if (bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (e != hipSuccess) return fail(B3D_ERR_HIP, "hipFuncSetAttribute(%d B LDS): %s", bytes, hipGetErrorString(e));
-  }
-  return B3D_OK;
+  if (bytes <= 64 * 1024) return B3D_OK;
+  return set_lds_cached(reinterpret_cast<const void*>(kernel), bytes);
 }
 
 // Row-tiled MLP kernels.  NW = wavefronts per workgroup (each owns 16 rows).  Edge-sized inputs

@@ -35,6 +35,26 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a) {
   a.p[i] = p; a.m[i] = m; a.v[i] = v;
 }
 
+// Step counter on the device (for hipGraph-captured training steps: a captured launch replays its arguments,
+// so the bias corrections cannot come from a host integer).
+__global__ __launch_bounds__(256) void adam_dev_kernel(AdamArgs a, const long long* __restrict__ step, float lr) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  const double t = (double)(*step + 1);
+  const double bc1 = 1.0 - pow((double)a.beta1, t), bc2 = 1.0 - pow((double)a.beta2, t);
+  const float step_size = (float)((double)lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+  float p = a.p[i];
+  float g = a.g[i];
+  if (a.weight_decay != 0.f) g = __fmaf_rn(p, a.weight_decay, g);
+  float m = a.m[i], v = a.v[i];
+  m = __fmaf_rn(a.one_minus_beta1, g - m, m);
+  v = __fmaf_rn(a.one_minus_beta2 * g, g, v * a.beta2);
+  const float denom = __fsqrt_rn(v) / bc2_sqrt + a.eps;
+  p = p - step_size * (m / denom);
+  a.p[i] = p; a.m[i] = m; a.v[i] = v;
+}
+__global__ void adam_tick_kernel(long long* step) { *step += 1; }
+
 }  // namespace
 }  // namespace b3d
 
@@ -55,6 +75,25 @@ extern "C" int b3d_adam_step(float* param, const float* grad, float* exp_avg, fl
   a.step_size = (float)((double)lr / bc1);
   a.bc2_sqrt = (float)sqrt(bc2);
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a);
+  B3D_HIP_CHECK(hipGetLastError());
+  return B3D_OK;
+}
+
+extern "C" int b3d_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                                 float beta1, float beta2, float eps, float weight_decay, int64_t* step_dev,
+                                 b3d_stream stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  B3D_REQUIRE(param && grad && exp_avg && exp_avg_sq && step_dev, "b3d_adam_step_dev: null argument");
+  B3D_REQUIRE(n >= 0, "b3d_adam_step_dev: n %lld", (long long)n);
+  AdamArgs a;
+  a.p = param; a.g = grad; a.m = exp_avg; a.v = exp_avg_sq; a.n = (long)n;
+  a.beta1 = beta1; a.beta2 = beta2; a.one_minus_beta1 = 1.f - beta1; a.one_minus_beta2 = 1.f - beta2;
+  a.eps = eps; a.weight_decay = weight_decay; a.step_size = 0.f; a.bc2_sqrt = 0.f;
+  if (n > 0) {
+    hipLaunchKernelGGL(adam_dev_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a, (const long long*)step_dev, lr);
+    B3D_HIP_CHECK(hipGetLastError());
+  }
+  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, stream, (long long*)step_dev);
   B3D_HIP_CHECK(hipGetLastError());
   return B3D_OK;
 }

@@ -351,10 +351,7 @@ struct WsLauncher {
   int launch2(Kern kernel, int lds_bytes, const float* zero_row, const int* iota, int family) {
     flush();
     if (total_tasks == 0 || status) return 0;
-    if (lds_bytes > 64 * 1024) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-      if (e != hipSuccess) return -1;
-    }
+    if (lds_bytes > 64 * 1024 && set_lds_cached(reinterpret_cast<const void*>(kernel), lds_bytes) != 0) return -1;
     ProfScope ps(family, stream);
     hipLaunchKernelGGL(kernel, dim3((total_tasks + kWsWaves - 1) / kWsWaves), dim3(kWsWaves * 64), lds_bytes, stream,
                        table, task_job, total_tasks, zero_row, iota);

@@ -27,7 +27,7 @@ from . import _lib
 
 class FlatAdam:
     def __init__(self, gnn: torch.nn.Module, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
-                 weight_decay: float = 0.0):
+                 weight_decay: float = 0.0, capturable: bool = False):
         if not hasattr(gnn, "_hip_params"):
             raise TypeError("FlatAdam needs a batch3dmot_amd PoseGNN / GNN (module with _hip_params())")
         hip: List[torch.nn.Parameter] = list(gnn._hip_params())
@@ -48,6 +48,10 @@ class FlatAdam:
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
         self.step_count = 0
+        # capturable: the step counter lives on the device (b3d_adam_step_dev), so a step captured into a hipGraph
+        # (torch.cuda.graph) replays correctly; step_count then only counts eager calls
+        self.capturable = capturable
+        self.step_dev = torch.zeros((), dtype=torch.int64, device=dev) if capturable else None
         self.grad_views: List[torch.Tensor] = []
         off = 0
         with torch.no_grad():
@@ -112,11 +116,18 @@ class FlatAdam:
             g = self.param_groups[0]
             self.step_count += 1
             lib = _lib.load()
-            _lib.check(lib.b3d_adam_step(self.flat_param.data_ptr(), self.flat_grad.data_ptr(), self.exp_avg.data_ptr(),
-                                         self.exp_avg_sq.data_ptr(), self.numel, C.c_float(g["lr"]),
-                                         C.c_float(g["betas"][0]), C.c_float(g["betas"][1]), C.c_float(g["eps"]),
-                                         C.c_float(g["weight_decay"]), self.step_count,
-                                         _lib.current_stream(self.flat_param.device)), "b3d_adam_step")
+            if self.capturable:
+                _lib.check(lib.b3d_adam_step_dev(self.flat_param.data_ptr(), self.flat_grad.data_ptr(),
+                                                 self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.numel,
+                                                 C.c_float(g["lr"]), C.c_float(g["betas"][0]), C.c_float(g["betas"][1]),
+                                                 C.c_float(g["eps"]), C.c_float(g["weight_decay"]), self.step_dev.data_ptr(),
+                                                 _lib.current_stream(self.flat_param.device)), "b3d_adam_step_dev")
+            else:
+                _lib.check(lib.b3d_adam_step(self.flat_param.data_ptr(), self.flat_grad.data_ptr(), self.exp_avg.data_ptr(),
+                                             self.exp_avg_sq.data_ptr(), self.numel, C.c_float(g["lr"]),
+                                             C.c_float(g["betas"][0]), C.c_float(g["betas"][1]), C.c_float(g["eps"]),
+                                             C.c_float(g["weight_decay"]), self.step_count,
+                                             _lib.current_stream(self.flat_param.device)), "b3d_adam_step")
         if self.inner is not None and any(p.grad is not None for p in self.rest):
             for grp in self.inner.param_groups:
                 grp["lr"] = self.param_groups[0]["lr"]

@@ -79,7 +79,8 @@ def train_step(gnn, data, optimizer, batch_size: int = 2, loss_kind: str = "cb",
     return loss.detach(), out.detach(), aux
 
 
-def make_optimizer(gnn, lr: float = 1e-4, weight_decay: float = 1e-4, betas=(0.9, 0.999), flat: Optional[bool] = None):
+def make_optimizer(gnn, lr: float = 1e-4, weight_decay: float = 1e-4, betas=(0.9, 0.999), flat: Optional[bool] = None,
+                   capturable: bool = False):
     """Adam exactly as train.py:106-109 (``gnn.*`` keys of the YAML config).  ``flat`` (default: on
     for a GPU-resident PoseGNN / GNN whose Linear stacks are all trainable) returns
     ``optim.FlatAdam``: same update, one kernel launch, gradients written in place by the backward."""
@@ -89,5 +90,5 @@ def make_optimizer(gnn, lr: float = 1e-4, weight_decay: float = 1e-4, betas=(0.9
         flat = bool(hip) and all(p.is_cuda and p.requires_grad for p in hip)
     if flat:
         from .optim import FlatAdam
-        return FlatAdam(gnn, lr=lr, weight_decay=weight_decay, betas=betas)
+        return FlatAdam(gnn, lr=lr, weight_decay=weight_decay, betas=betas, capturable=capturable)
     return torch.optim.Adam(params, lr=lr, weight_decay=weight_decay, betas=betas)

@@ -15,6 +15,12 @@ Prints ONE JSON line (rank 0).  `roofline` describes the kernel family with the 
 device time, measured with HIP events on the launch stream (b3d_prof_*); `kernels` lists every
 instrumented family; `cpu_baseline` times the CPU oracle (the restated reference path) on the
 host cores, rank 0, N = 1 only.
+
+At N = 1 the timed region replays hipGraph-captured steps (one graph per pool batch, each holding the
+whole step): the device step takes ~1.0 ms while enqueueing it eagerly takes 0.5-0.7 ms of host time --
+1.6 ms on a busy host, which then throttles the GPU.  Event records cannot be captured, so the kernel
+families are timed in an eager pass of the same K steps right after the timed region (`timed_region` in
+the output says which mode ran; `--no-graph` keeps everything eager and inside the timed region).
 """
 from __future__ import annotations
 
@@ -56,6 +62,9 @@ def main():
     ap.add_argument("--no-dead-knn", action="store_true",
                     help="skip the k-NN + GAT block whose result the reference discards (secondary figure)")
     ap.add_argument("--side-stream", action="store_true", help="run the discarded k-NN block on the library's side stream (diagnostic)")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="enqueue every step eagerly (always so for N > 1); by default at N = 1 the whole training step of "
+                         "each of the 4 pool batches is captured into a hipGraph once and the timed region replays them")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to exercise the N > 1 path on one GPU)")
     ap.add_argument("--all-ranks-on-device-0", action="store_true", help="testing aid for the N > 1 path on a 1-GPU box (with --backend gloo)")
@@ -88,7 +97,7 @@ def main():
     model.run_dead_knn = not args.no_dead_knn
     model.single_stream = not args.side_stream
     model.train()
-    opt = make_optimizer(model)                  # Adam(lr 1e-4, wd 1e-4, betas .9/.999): train.py:106-109 (optim.FlatAdam)
+    opt = make_optimizer(model, capturable=True)  # Adam(lr 1e-4, wd 1e-4, betas .9/.999): train.py:106-109 (optim.FlatAdam)
     sync = FlatGradSync(model.parameters(), flat=opt if hasattr(opt, "flat_grad") else None) if world > 1 else None
 
     pool_cpu = [synth.make_batch(2, 1500, 15000, first_graph_idx=rank * 1000 + 2 * i) for i in range(4)]
@@ -113,19 +122,57 @@ def main():
     fam_all = _lib.prof_read() if args.warmup > 0 else None
     measured = [k for k in ("mp_edge_fwd", "mp_edge_bwd", "wgrad_edge", "mp_node_fwd", "mp_node_bwd")]
     dom = max(measured, key=lambda k: fam_all[k][0]) if fam_all else None
-    _lib.prof_enable(True, families=[dom] if dom else None)
+    # ---- hipGraph capture (N = 1): one graph per pool batch holds the WHOLE step (CSR/CSC build, forward, loss,
+    #      backward, Adam).  The timed region then costs one graph launch of host time per step, so a slow or
+    #      noisy host cannot throttle a ~1.1 ms device step that otherwise needs ~0.6 ms of enqueueing.  Kernel
+    #      families are timed with HIP events in an eager pass of the same K steps right after the timed region
+    #      (event records cannot be captured); eager mode (--no-graph, N > 1) times them inside the timed region.
+    graphs = None
+    graph_note = None
+    if world == 1 and not args.no_graph:
+        _lib.prof_enable(False)
+        try:
+            graphs = []
+            cap_stream = torch.cuda.Stream()
+            cap_stream.wait_stream(torch.cuda.current_stream())
+            for i in range(len(pool)):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=cap_stream):
+                    step(i)
+                graphs.append(g)
+            torch.cuda.current_stream().wait_stream(cap_stream)
+            torch.cuda.synchronize()
+        except Exception as exc:                                   # capture unsupported here: eager timed region
+            graphs = None
+            graph_note = f"hipGraph capture failed ({type(exc).__name__}: {exc}); eager timed region"
+            torch.cuda.synchronize()
+
+    def timed_step(i):
+        if graphs is not None:
+            graphs[i % len(pool)].replay()
+        else:
+            step(i)
+
+    if graphs is None:
+        _lib.prof_enable(True, families=[dom] if dom else None)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(args.warmup + i)
+        timed_step(args.warmup + i)
     t_enqueue = time.perf_counter() - t0          # host time to enqueue the K steps (diagnostic)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if graphs is not None:
+        # the same K steps again, eagerly, with event pairs on the dominant family only
+        _lib.prof_enable(True, families=[dom] if dom else None)
+        for i in range(args.steps):
+            step(args.warmup + i)
+        torch.cuda.synchronize()
     fam = _lib.prof_read()
     _lib.prof_enable(False)
 
@@ -235,7 +282,10 @@ def main():
                            "frames": 5, "dead_knn_gat_block_executed": bool(model.run_dead_knn),
                            "parallelism": f"graph-batch sharding x{world}"},
                 "roofline": roofline, "whole_step": whole, "kernels_instrumented_warmup": kernels_warmup,
-                "host_enqueue_ms_per_step": round(1e3 * t_enqueue / args.steps, 4), "kernels": kernels, "cpu_baseline": cpu}
+                "host_enqueue_ms_per_step": round(1e3 * t_enqueue / args.steps, 4),
+                "timed_region": ("hipGraph replay (one captured training step per pool batch); roofline / kernels timed with HIP "
+                                 "events in an eager pass of the same K steps right after it") if graphs is not None
+                                else ("eager" + (f" ({graph_note})" if graph_note else "")), "kernels": kernels, "cpu_baseline": cpu}
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -219,6 +219,11 @@ int b3d_clr_layer_forward(const b3d_mp_weights* weights, const b3d_graph* g, con
                           const float* e, const float* att_edge_attr, void* workspace, size_t workspace_bytes,
                           float* x_new, float* e_new, b3d_stream stream);
 
+/* Same update with the step counter on the device (`*step_dev` = number of steps taken so far, incremented by
+ * the call): for training steps captured into a hipGraph, where a by-value `step` would be replayed. */
+int b3d_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                      float beta1, float beta2, float eps, float weight_decay, int64_t* step_dev, b3d_stream stream);
+
 /* ---- frame-wise k-NN + GATConv (pose_gnn.py:74-80, clr_att_gnn.py:178-184) as a standalone operator --
  * For every distinct timestamp value: k nearest neighbours (Euclidean, feature space, no self
  * loops, fewer than k in frames of <= k nodes) among the nodes of that frame, then

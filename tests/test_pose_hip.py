@@ -290,3 +290,41 @@ def test_dead_knn_block_inside_the_model_matches_oracle(side_stream):
         idx = torch.nonzero(ts == t).squeeze(1)
         ei = ref_torch.knn_graph(x4[idx], 20)
         torch.testing.assert_close(y[idx], ora.knn_conv(x4[idx], ei), rtol=1e-4, atol=1e-5)
+
+
+def test_training_step_captured_into_a_hip_graph_replays_exactly():
+    """bench.py's timed region replays hipGraph-captured training steps.  A captured step (graph build, forward,
+    fused loss, backward, Adam with the step counter on the device) replayed N times must leave the same
+    parameters as N eager steps."""
+    import copy
+    from batch3dmot_amd.pose_gnn import PoseGNN
+    from batch3dmot_amd.train_step import make_optimizer, train_step
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)
+    a = PoseGNN().to(dev)
+    b = copy.deepcopy(a)
+    opt_a = make_optimizer(a, lr=1e-3, capturable=True)
+    opt_b = make_optimizer(b, lr=1e-3, capturable=True)
+    data = _tiny_batch(dev, 30)
+
+    def step(m, opt):
+        if hasattr(data, "_b3d_graph"):
+            del data._b3d_graph
+        return train_step(m, data, opt, logits=True)
+
+    for _ in range(4):
+        step(a, opt_a)
+    step(b, opt_b)                                   # eager warm-up, then capture one step and replay it 3 times
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.graph(g, stream=s):
+        step(b, opt_b)                               # capture does not execute
+    torch.cuda.current_stream().wait_stream(s)
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    assert int(opt_a.step_dev) == 4 and int(opt_b.step_dev) == 4
+    for (n, p), (_, q) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert torch.equal(p, q), n
