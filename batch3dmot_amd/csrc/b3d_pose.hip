@@ -691,7 +691,7 @@ extern "C" int b3d_pose_backward(const b3d_pose_weights* pw, const b3d_graph* g,
     ga.dT = w.dT + (size_t)lay * N * HP::GW; ga.gx = w.gx;
     ga.wpack = w.wp_gproj;
     B3D_TRY(set_lds(node_gradproj_kernel<D>, GradProjLds<D>::BYTES));
-    ProfScope ps(B3D_K_NODE_BWD, stream);
+    ProfScope ps(B3D_K_OTHER, stream);          // layer 0 only: a different kernel from the mp_node_bwd family
     hipLaunchKernelGGL(node_gradproj_kernel<D>, dim3((N + 15) / 16), dim3(kGradProjWaves * 64), GradProjLds<D>::BYTES, stream, ga);
     return launch_check("node_gradproj_kernel");
   };
