@@ -160,6 +160,11 @@ def load() -> C.CDLL:
     lib.b3d_adam_step_dev.restype = C.c_int
     lib.b3d_adam_step_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
                                       C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+    lib.b3d_post_workspace_bytes.restype = C.c_size_t
+    lib.b3d_post_workspace_bytes.argtypes = [C.c_int64, C.c_int64]
+    lib.b3d_post_greedy.restype = C.c_int
+    lib.b3d_post_greedy.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                    C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.b3d_prof_enable.argtypes = [C.c_int]
     lib.b3d_prof_select.argtypes = [C.c_uint32]
     lib.b3d_prof_select.restype = C.c_int

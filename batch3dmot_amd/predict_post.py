@@ -67,3 +67,29 @@ def greedy_edges(pairs: torch.Tensor, scores: torch.Tensor, node_class: torch.Te
     pred = _segmented_first_argmax(kp[:, 1], kp[:, 0], ks, n)       # incoming: keyed by destination
     succ = _segmented_first_argmax(kp[:, 0], kp[:, 1], ks, n)       # outgoing: keyed by source
     return {"kept_pairs": kp, "kept_scores": ks, "pred": pred, "succ": succ}
+
+
+def greedy_edges_hip(pairs: torch.Tensor, scores: torch.Tensor, node_class: torch.Tensor,
+                     class_names: Sequence[str], thresholds: Dict[str, float] = EDGE_SCORE_THRESHOLDS):
+    """``greedy_edges`` on the GPU in one C-ABI call (``b3d_post_greedy``: stable device sort by global edge id,
+    means in order of appearance, threshold, segmented first-arg-max).  Same outputs, same order, same ties."""
+    from . import _lib
+    lib = _lib.load()
+    _lib.require_cuda(pairs, "pairs", torch.int64)
+    dev = pairs.device
+    m, n = int(pairs.size(0)), int(node_class.numel())
+    sc = scores.reshape(-1).float().contiguous()
+    nc = node_class.to(device=dev, dtype=torch.int64).contiguous()
+    thr = torch.tensor([thresholds[c] for c in class_names], dtype=torch.float64, device=dev)
+    nbytes = lib.b3d_post_workspace_bytes(m, n)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    kept_pairs = torch.empty((max(m, 1), 2), dtype=torch.int64, device=dev)
+    kept_scores = torch.empty(max(m, 1), dtype=torch.float64, device=dev)
+    pred = torch.empty(n, dtype=torch.int64, device=dev)
+    succ = torch.empty(n, dtype=torch.int64, device=dev)
+    counts = torch.empty(2, dtype=torch.int32, device=dev)
+    _lib.check(lib.b3d_post_greedy(pairs.contiguous().data_ptr(), sc.data_ptr(), m, nc.data_ptr(), n, thr.data_ptr(),
+                                   ws.data_ptr(), nbytes, kept_pairs.data_ptr(), kept_scores.data_ptr(), pred.data_ptr(),
+                                   succ.data_ptr(), counts.data_ptr(), _lib.current_stream(dev)), "b3d_post_greedy")
+    k = int(counts[1])                                      # the only host read: the size of the kept-edge list
+    return {"kept_pairs": kept_pairs[:k], "kept_scores": kept_scores[:k], "pred": pred, "succ": succ}

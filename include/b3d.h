@@ -257,6 +257,19 @@ int b3d_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
  * (pending work of a B3D_FLAG_DEFER_SIDE_JOIN forward).  Cheap when nothing is pending. */
 int b3d_side_join(b3d_stream stream);
 
+/* ---- post-processing of per-window edge scores (predict.py:199-233, 92-124) -----------------------------
+ * pairs [M,2] int64: (global source id, global destination id) of every scored edge of every window, in
+ * processing order; scores [M] float32.  Mean score per distinct pair (float64 sum in order of appearance /
+ * count), kept iff mean > class_threshold[node_class[source]], kept edges in first-appearance order; per node
+ * the best incoming edge's source (pred) and the best outgoing edge's destination (succ), ties to the edge that
+ * appeared first, -1 if none.  node_class [N] int64 (index into class_threshold [C] float64).
+ * Outputs: kept_pairs [M,2] int64 / kept_scores [M] float64 (first counts[1] rows valid), pred / succ [N] int64,
+ * counts: device int32[2] = {distinct edges, kept edges}.  Deterministic; no host synchronisation. */
+size_t b3d_post_workspace_bytes(int64_t M, int64_t N);
+int b3d_post_greedy(const int64_t* pairs, const float* scores, int64_t M, const int64_t* node_class, int64_t N,
+                    const double* class_threshold, void* workspace, size_t workspace_bytes, int64_t* kept_pairs,
+                    double* kept_scores, int64_t* pred, int64_t* succ, int32_t* counts, b3d_stream stream);
+
 /* ---- test hooks: addresses of intermediate tensors inside a workspace a forward has filled ---------------- */
 int b3d_pose_debug_layer_ptrs(void* workspace, size_t workspace_bytes, int32_t N, int32_t E, int32_t depth,
                               uint32_t flags, int32_t layer, float** x /* [N,48] */, float** e /* [E,32] */);
