@@ -112,6 +112,14 @@ struct LayerSeq {
   static constexpr int SLOT = max_chunk();
 };
 
+// ---- experiment support: per-workgroup phase time stamps (off unless built with -DB3D_EXP_STAMPS) ----
+#ifdef B3D_EXP_STAMPS
+extern __device__ long long g_stamps[2][512 * 16];
+#define B3D_STAMP(k, i) do { if (threadIdx.x == 0 && blockIdx.x < 512) b3d::g_stamps[k][blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
+#else
+#define B3D_STAMP(k, i) do {} while (0)
+#endif
+
 // ---- weight stream: global -> LDS, two slots ----------------------------------------------
 #ifndef B3D_USE_LDS_DMA
 #define B3D_USE_LDS_DMA 1
@@ -421,12 +429,17 @@ __device__ __forceinline__ void segment_sum(const float* __restrict__ base, int 
 
 // Deep variant for kernels with few feature blocks per wavefront: U rows in flight per lane, the
 // gather indices of the next batch fetched while the rows of this one are in flight, slots beyond
-// the segment end masked (they re-read the segment's last row).  Same summation order as above.
+// the segment end masked off.  Same summation order as above.
+//
+// `q` is the 16-byte piece of every 64-byte feature block this lane reads.  In the register layout the MFMAs
+// want ("L": lane = row + 16 q) the four pieces of a block sit 16 lanes apart and neighbouring lanes read
+// different rows: the texture path then looks up one cache line per lane and a gather moves ~20 B/clk/CU.
+// With "Q" (lane = 4 row + q) each lane quad reads one contiguous 64-byte block: ~36-43 B/clk/CU measured on
+// MI355X (tools/micro/gather_pattern.hip).  Sums taken in Q go through LDS (slot row + 16 q) to reach L.
 template <int NBLK, int U>
-__device__ __forceinline__ void segment_sum_deep(const float* __restrict__ base, int stride, int col0,
-                                                 const int* __restrict__ perm, int beg, int end,
-                                                 v4f* __restrict__ acc) {
-  const int q = (threadIdx.x & 63) >> 4;
+__device__ __forceinline__ void segment_sum_deep_q(const float* __restrict__ base, int stride, int col0,
+                                                   const int* __restrict__ perm, int beg, int end,
+                                                   v4f* __restrict__ acc, int q) {
   const float* b0 = base + col0 + 4 * q;
   if (beg >= end) return;
   const int last = end - 1;
@@ -437,12 +450,18 @@ __device__ __forceinline__ void segment_sum_deep(const float* __restrict__ base,
     r[u] = perm ? perm[kk] : kk;
   }
   for (int k = beg; k < end; k += U) {
+    // slots beyond the segment end are NOT loaded (lanes masked off: in layout Q a row is a lane quad, and the
+    // texture path skips idle quads); they contribute zeros
     v4f t[U][NBLK];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const float* p = b0 + (long)r[u] * stride;
 #pragma unroll
-      for (int b = 0; b < NBLK; ++b) t[u][b] = *reinterpret_cast<const v4f*>(p + 16 * b);
+      for (int b = 0; b < NBLK; ++b) t[u][b] = v4f{0.f, 0.f, 0.f, 0.f};
+      if (k + u < end) {
+        const float* p = b0 + (long)r[u] * stride;
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) t[u][b] = *reinterpret_cast<const v4f*>(p + 16 * b);
+      }
     }
     if (k + U < end) {
 #pragma unroll
@@ -453,11 +472,29 @@ __device__ __forceinline__ void segment_sum_deep(const float* __restrict__ base,
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      if (k + u < end) {
 #pragma unroll
-        for (int b = 0; b < NBLK; ++b) acc[b] += t[u][b];
-      }
+      for (int b = 0; b < NBLK; ++b) acc[b] += t[u][b];
     }
+  }
+}
+template <int NBLK, int U>
+__device__ __forceinline__ void segment_sum_deep(const float* __restrict__ base, int stride, int col0,
+                                                 const int* __restrict__ perm, int beg, int end,
+                                                 v4f* __restrict__ acc) {
+  segment_sum_deep_q<NBLK, U>(base, stride, col0, perm, beg, end, acc, (threadIdx.x & 63) >> 4);
+}
+
+// Layout Q helpers: lane = 4 * (row in tile) + q.
+__device__ __forceinline__ int q_row(int lane) { return lane >> 2; }
+__device__ __forceinline__ int q_piece(int lane) { return lane & 3; }
+__device__ __forceinline__ int q_slot(int lane) { return (lane >> 2) + 16 * (lane & 3); }   // lane of layout L holding the same data
+template <int NBLK>
+__device__ __forceinline__ void store_row_q(float* __restrict__ base, long row, int stride, int col0, bool valid,
+                                            const v4f* __restrict__ src) {
+  float* p = base + row * (long)stride + col0 + 4 * (threadIdx.x & 3);
+  if (valid) {
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b) *reinterpret_cast<v4f*>(p + 16 * b) = src[b];
   }
 }
 

@@ -20,6 +20,13 @@
 #include "b3d_node.hpp"
 #include "b3d_chain.hpp"
 
+// wavefronts per by-source list half in the per-node gradient kernels (1..3) and gather depth
+#ifndef B3D_SRC_PARTS
+#define B3D_SRC_PARTS 3
+#endif
+#ifndef B3D_SEG_U
+#define B3D_SEG_U (B3D_SRC_PARTS == 3 ? 6 : 8)
+#endif
 namespace b3d {
 
 template <class D>
@@ -139,9 +146,9 @@ template <class D>
 using NodeFwdHSeq = LayerSeq<L<D::NIN, D::NH1>, L<D::NH1, D::NH2>, L<D::NH2, D::DX>, L<D::DX, Hoist<D>::TW>>;
 
 template <class D>
-__global__ __launch_bounds__(kNodeWaves * 64, 1) void mp_node_fwd_split_h_kernel(const NodeFwdArgs a) {
+__global__ __launch_bounds__(kNodeWavesWide * 64, 1) void mp_node_fwd_split_h_kernel(const NodeFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  node_fwd_split_body<D, NodeFwdHSeq<D>, true>(a, smem);
+  node_fwd_split_body<D, NodeFwdHSeq<D>, true, kNodeWavesWide>(a, smem);
 }
 
 // x0 terms + the table of layer 0 from the node encoder's output, four wavefronts per 16-row tile (the
@@ -302,7 +309,8 @@ struct NodeGradProjArgs {
 template <class D>
 struct GradProjLds {
   static constexpr int TB = Hoist<D>::GW / 16;
-  static constexpr int BYTES = kLdsBytes + TB * 64 * 16;
+  static constexpr int PARTB = (B3D_SRC_PARTS - 1) * 2 * (D::EH1 / 16);       // partial sums of the by-source lists (kSrcParts - 1 each)
+  static constexpr int BYTES = kLdsBytes + (TB + PARTB) * 64 * 16;
 };
 
 // (dx | dx0) = sum over the four lists of (node columns)^T . dT_list: layers LI0 .. LI0+3 of Seq.  The wavefront
@@ -332,8 +340,72 @@ __device__ __forceinline__ v4f gradproj_products(WS& ws, const v4f* __restrict__
   return keep;
 }
 
-constexpr int kGradProjWaves = 8;      // two wavefronts per list (three feature blocks each): the by-source lists of a
-                                       // tracking graph reach 40+ entries and set the kernel's critical path
+constexpr int kSrcParts = B3D_SRC_PARTS;
+constexpr int kGradProjWaves = 4 + 4 * kSrcParts;
+// Sixteen wavefronts sum the four lists (dH1 by dst, dH1 by src, dF1 by dst, dP1 by src) of a 16-row tile.  Fewer
+// than 256 tiles make a batch, so the launch lasts as long as its WORST tile: the by-destination lists are short
+// (in-degree: the few frames behind a detection), the by-source lists of a tracking graph reach 40+ entries.
+//   waves 0..3  : by-destination lists, one wavefront per half of the feature blocks;
+//   waves 4..15 : by-source lists, kSrcParts wavefronts per half, each a contiguous third of the list; the
+//                 partial sums meet in LDS and are added in a fixed order by the wavefront of the first third.
+// The owner wavefronts leave the list sums in xt[(list * LB + block)] and in `part`.
+struct ListRole { int list, half, third; bool owner; };
+
+template <class D>
+__device__ __forceinline__ ListRole gradproj_list_sums(const NodeGradProjArgs& gp, v4f* __restrict__ xt, v4f* __restrict__ xp,
+                                                       v4f* __restrict__ part) {
+  static_assert(kGradProjWaves == 4 + 4 * kSrcParts && D::EH1 == D::MH && (D::EH1 / 16) % 2 == 0, "two halves per list, equal widths");
+  constexpr int LB = D::EH1 / 16, HB = LB / 2;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // gathers run in layout Q (lane = 4 row + q: b3d_dev.hpp); the sums reach layout L through their LDS slot
+  const long row = (long)blockIdx.x * 16 + q_row(lane);
+  const bool valid = row < gp.N;
+  const int slot = q_slot(lane);
+  ListRole r;
+  if (wave < 4) { r.list = (wave & 1) * 2; r.half = wave >> 1; r.third = 0; }
+  else { const int j = wave - 4; r.list = 1 + (j & 1) * 2; r.half = (j >> 1) & 1; r.third = j >> 2; }
+  r.owner = r.third == 0;
+#pragma unroll
+  for (int b = 0; b < HB; ++b) part[b] = v4f{0.f, 0.f, 0.f, 0.f};
+  const float* base = (r.list < 2) ? gp.GdH1 : (r.list == 2 ? gp.GdF1 : gp.GdP1);
+  const bool by_dst = !(r.list & 1);
+  if (valid && base) {
+    constexpr int U = B3D_SEG_U;
+    if (by_dst) {
+      segment_sum_deep_q<HB, U>(base, 16 * LB, 16 * HB * r.half, gp.dst_perm, gp.dst_ptr[row], gp.dst_ptr[row + 1], part, q_piece(lane));
+    } else {
+      const int beg = gp.src_ptr[row], len = gp.src_ptr[row + 1] - beg;
+      segment_sum_deep_q<HB, U>(base, 16 * LB, 16 * HB * r.half, gp.src_perm, beg + len * r.third / kSrcParts,
+                                beg + len * (r.third + 1) / kSrcParts, part, q_piece(lane));
+    }
+  }
+  v4f* own = xt + (r.list * LB + r.half * HB) * 64 + slot;
+  {
+    v4f* dstp = r.owner ? own : xp + (((r.third - 1) * 2 + (r.list >> 1)) * LB + r.half * HB) * 64 + slot;
+#pragma unroll
+    for (int b = 0; b < HB; ++b) dstp[b * 64] = part[b];
+  }
+  if constexpr (kSrcParts > 1) {
+    const v4f* others = xp + ((r.list >> 1) * LB + r.half * HB) * 64 + slot;     // + (third - 1) * 2 LB blocks
+    __syncthreads();
+    if (!by_dst && r.owner) {
+#pragma unroll
+      for (int b = 0; b < HB; ++b) {
+#pragma unroll
+        for (int t = 1; t < kSrcParts; ++t) part[b] += others[((t - 1) * 2 * LB + b) * 64];
+        own[b * 64] = part[b];
+      }
+    }
+  }
+  return r;
+}
+// the owner's store of its list sums (held in layout Q) into dT
+template <class D>
+__device__ __forceinline__ void gradproj_store_sums(const ListRole& r, float* __restrict__ dT, int N, const v4f* __restrict__ part) {
+  constexpr int LB = D::EH1 / 16, HB = LB / 2;
+  const long row = (long)blockIdx.x * 16 + q_row(threadIdx.x & 63);
+  if (r.owner) store_row_q<HB>(dT, row, Hoist<D>::GW, 16 * (LB * r.list + HB * r.half), row < N, part);
+}
 
 template <class D>
 __global__ __launch_bounds__(kGradProjWaves * 64, 1) void node_gradproj_kernel(const NodeGradProjArgs a) {
@@ -341,7 +413,6 @@ __global__ __launch_bounds__(kGradProjWaves * 64, 1) void node_gradproj_kernel(c
   using H = Hoist<D>;
   using Seq = typename H::GradProjSeq;
   constexpr int NWS = kGradProjWaves;
-  static_assert(NWS == 8 && D::EH1 == D::MH && (D::EH1 / 16) % 2 == 0, "two wavefronts per list, equal widths");
   constexpr int LB = D::EH1 / 16, HB = LB / 2, TB = H::GW / 16;
   WStreamT<NWS * 64> ws;
   ws.init(a.wpack, smem);
@@ -351,23 +422,8 @@ __global__ __launch_bounds__(kGradProjWaves * 64, 1) void node_gradproj_kernel(c
   const long row = (long)blockIdx.x * 16 + (lane & 15);
   const bool valid = row < a.N;
   v4f part[HB];
-  {
-    const int list = wave & 3, half = wave >> 2;             // list: dH1 by dst, dH1 by src, dF1 by dst, dP1 by src
-#pragma unroll
-    for (int b = 0; b < HB; ++b) part[b] = v4f{0.f, 0.f, 0.f, 0.f};
-    const float* base = (list < 2) ? a.GdH1 : (list == 2 ? a.GdF1 : a.GdP1);
-    const bool by_dst = (list == 0 || list == 2);
-    if (valid && base) {
-      constexpr int U = HB <= 3 ? 8 : 4;
-      if (by_dst) segment_sum_deep<HB, U>(base, 16 * LB, 16 * HB * half, a.dst_perm, a.dst_ptr[row], a.dst_ptr[row + 1], part);
-      else segment_sum_deep<HB, U>(base, 16 * LB, 16 * HB * half, a.src_perm, a.src_ptr[row], a.src_ptr[row + 1], part);
-    }
-#pragma unroll
-    for (int b = 0; b < HB; ++b) xb[(list * LB + half * HB + b) * 64 + lane] = part[b];
-  }
-  const v4f keep = gradproj_products<Seq, 0, NWS, LB>(ws, xb, lane, [&]() {
-    store_row<HB>(a.dT, row, H::GW, 16 * (LB * (wave & 3) + HB * (wave >> 2)), valid, part);
-  });
+  const ListRole r = gradproj_list_sums<D>(a, xb, xb + TB * 64, part);
+  const v4f keep = gradproj_products<Seq, 0, NWS, LB>(ws, xb, lane, [&]() { gradproj_store_sums<D>(r, a.dT, a.N, part); });
   if (wave < 2 * D::DX / 16) store_row<1>(a.gx, row, 2 * D::DX, 16 * wave, valid, &keep);
   (void)TB;
 }
@@ -393,7 +449,10 @@ struct NodeBwdHArgs {
 template <class D>
 struct NodeBwdHLds {
   static constexpr int TB = Hoist<D>::GW / 16, PB = (D::NH1 > 2 * D::DX ? D::NH1 : 2 * D::DX) / 16;
-  static constexpr int BYTES = kLdsBytes + (TB + 2 * PB) * 64 * 16;
+  static constexpr int PARTB = GradProjLds<D>::PARTB;
+  static constexpr int XBB = 2 * PB > PARTB ? 2 * PB : PARTB;     // the ping-pong buffers start life as the partial-sum area
+  static constexpr int BYTES = kLdsBytes + (TB + XBB) * 64 * 16;
+  static_assert(BYTES <= 160 * 1024, "LDS of one CU");
 };
 
 template <class D>
@@ -401,11 +460,11 @@ __global__ __launch_bounds__(kGradProjWaves * 64, 1) void node_bwd_h_kernel(cons
   extern __shared__ __attribute__((aligned(16))) float smem[];
   using H = Hoist<D>;
   using Seq = NodeBwdHSeq<D>;
+  B3D_STAMP(1, 0);
   constexpr int NWS = kGradProjWaves;
-  static_assert(NWS == 8 && D::EH1 == D::MH && (D::EH1 / 16) % 2 == 0, "two wavefronts per list, equal widths");
   constexpr int LB = D::EH1 / 16, HB = LB / 2, TB = H::GW / 16;
   constexpr int XB = D::DX / 16, GB = 2 * XB, H1B = D::NH1 / 16, H2B = D::NH2 / 16;
-  static_assert(GB <= NWS, "one output block of (dx | dx0) per wavefront");
+  static_assert(GB <= NWS && H1B <= NWS && H2B <= NWS, "at most one output block per wavefront and layer");
   constexpr int PB = NodeBwdHLds<D>::PB;
   WStreamT<NWS * 64> ws;
   ws.init(a.wpack, smem);
@@ -416,34 +475,27 @@ __global__ __launch_bounds__(kGradProjWaves * 64, 1) void node_bwd_h_kernel(cons
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 16 + (lane & 15);
   const bool valid = row < a.gp.N;
-  v4f act2[H2B], act1[H1B];
-  load_row<H2B>(a.sH2, row, D::NH2, 0, valid, act2);
-  load_row<H1B>(a.sH1, row, D::NH1, 0, valid, act1);
-  // running d initial_x of the block this wavefront will own (loaded now: the acquire in front of its use would expose it)
+  // saved activations: only the block this wavefront owns in the masked layer (the owner masks what it emits);
+  // loaded now, in the shadow of the list sums: an acquire in front of their use would expose them
+  v4f act2 = {0.f, 0.f, 0.f, 0.f}, act1 = {0.f, 0.f, 0.f, 0.f};
+  if (wave < H2B) load_row<1>(a.sH2, row, D::NH2, 16 * wave, valid, &act2);
+  if (wave < H1B) load_row<1>(a.sH1, row, D::NH1, 16 * wave, valid, &act1);
+  // running d initial_x of the block this wavefront will own
   v4f prev0 = {0.f, 0.f, 0.f, 0.f};
   if (!a.dx0_first && wave >= XB && wave < GB) load_row<1>(a.dx0_acc, row, D::DX, 16 * (wave - XB), valid, &prev0);
   v4f part[HB];
-  {
-    const int list = wave & 3, half = wave >> 2;
-#pragma unroll
-    for (int b = 0; b < HB; ++b) part[b] = v4f{0.f, 0.f, 0.f, 0.f};
-    const float* base = (list < 2) ? a.gp.GdH1 : (list == 2 ? a.gp.GdF1 : a.gp.GdP1);
-    const bool by_dst = (list == 0 || list == 2);
-    if (valid && base) {
-      constexpr int U = HB <= 3 ? 8 : 4;
-      if (by_dst) segment_sum_deep<HB, U>(base, 16 * LB, 16 * HB * half, a.gp.dst_perm, a.gp.dst_ptr[row], a.gp.dst_ptr[row + 1], part);
-      else segment_sum_deep<HB, U>(base, 16 * LB, 16 * HB * half, a.gp.src_perm, a.gp.src_ptr[row], a.gp.src_ptr[row + 1], part);
-    }
-#pragma unroll
-    for (int b = 0; b < HB; ++b) xt[(list * LB + half * HB + b) * 64 + lane] = part[b];
-  }
+  B3D_STAMP(1, 1);
+  const ListRole r = gradproj_list_sums<D>(a.gp, xt, xb0, part);
+  B3D_STAMP(1, 2);
   // this wavefront's block of (dx | dx0): block `wave` (< 2 XB); stored behind the next barrier
-  v4f own = gradproj_products<Seq, 0, NWS, LB>(ws, xt, lane, [&]() {
-    store_row<HB>(a.gp.dT, row, H::GW, 16 * (LB * (wave & 3) + HB * (wave >> 2)), valid, part);
-  });
+  v4f own = gradproj_products<Seq, 0, NWS, LB>(ws, xt, lane, [&]() { gradproj_store_sums<D>(r, a.gp.dT, a.gp.N, part); });
+  B3D_STAMP(1, 3);
   if (wave < XB) xb0[wave * 64 + lane] = own;                 // d x': input of the node MLP's data gradient
   else if (wave < GB) own += prev0;
   v4f g[XB], d2[H2B], d1[H1B];
+  auto mask = [](v4f v, v4f act) {
+    return v4f{act.x > 0.f ? v.x : 0.f, act.y > 0.f ? v.y : 0.f, act.z > 0.f ? v.z : 0.f, act.w > 0.f ? v.w : 0.f};
+  };
   linear_split<Seq, 4, false, false, NWS>(
       ws, false, g,
       [&]() {
@@ -452,29 +504,26 @@ __global__ __launch_bounds__(kGradProjWaves * 64, 1) void node_bwd_h_kernel(cons
 #pragma unroll
         for (int b = 0; b < XB; ++b) g[b] = xb0[b * 64 + lane];
       },
-      [&](int mb, v4f v) { xb1[mb * 64 + lane] = v; });
+      [&](int mb, v4f v) { act2 = mask(v, act2); xb1[mb * 64 + lane] = act2; });          // mb == wave: act2 now holds d H2
+  B3D_STAMP(1, 4);
   linear_split<Seq, 5, false, false, NWS>(
       ws, false, d2,
       [&]() {
+        if (wave < H2B) store_row<1>(a.GdH2, row, D::NH2, 16 * wave, valid, &act2);
 #pragma unroll
         for (int b = 0; b < H2B; ++b) d2[b] = xb1[b * 64 + lane];
-        relu_bwd<H2B>(d2, act2);
-#pragma unroll
-        for (int b = 0; b < H2B; ++b)
-          if (b % NWS == wave) store_row<1>(a.GdH2, row, D::NH2, 16 * b, valid, &d2[b]);
       },
-      [&](int mb, v4f v) { xb0[mb * 64 + lane] = v; });
+      [&](int mb, v4f v) { act1 = mask(v, act1); xb0[mb * 64 + lane] = act1; });
+  B3D_STAMP(1, 5);
   linear_split<Seq, 6, false, false, NWS>(
       ws, false, d1,
       [&]() {
+        if (wave < H1B) store_row<1>(a.GdH1, row, D::NH1, 16 * wave, valid, &act1);
 #pragma unroll
         for (int b = 0; b < H1B; ++b) d1[b] = xb0[b * 64 + lane];
-        relu_bwd<H1B>(d1, act1);
-#pragma unroll
-        for (int b = 0; b < H1B; ++b)
-          if (b % NWS == wave) store_row<1>(a.GdH1, row, D::NH1, 16 * b, valid, &d1[b]);
       },
       [&](int mb, v4f v) { store_row<1>(a.dM, row, 2 * D::DM, 16 * mb, valid, &v); });
+  B3D_STAMP(1, 6);
 }
 
 // Loader of the node-encoder backward: gradient at x_enc = upstream + running d initial_x + layer 0's (dx | dx0).

@@ -34,12 +34,12 @@ constexpr int chain_lds() { return 2 * Seq::SLOT * 4; }
 constexpr int kNWEdge = 8, kNWNode = 1;
 
 // Node phase of a message-passing layer: 4 wavefronts per 16-row tile (b3d_node.hpp).
-template <class D, class Kern, class Args>
+template <class D, int NW = kNodeWaves, class Kern, class Args>
 inline int launch_node_split(Kern kernel, const char* name, const Args& a, long rows, hipStream_t stream, int family) {
   if (rows <= 0) return B3D_OK;
   B3D_TRY(set_lds(kernel, NodeSplit<D>::LDS_BYTES));
   ProfScope ps(family, stream);
-  hipLaunchKernelGGL(kernel, dim3((unsigned)((rows + 15) / 16)), dim3(kNodeWaves * 64), NodeSplit<D>::LDS_BYTES, stream, a);
+  hipLaunchKernelGGL(kernel, dim3((unsigned)((rows + 15) / 16)), dim3(NW * 64), NodeSplit<D>::LDS_BYTES, stream, a);
   return launch_check(name);
 }
 

@@ -100,13 +100,21 @@ __device__ __forceinline__ void linear_split(WS& ws, bool more, const v4f* __res
 }
 
 // ------------------------------------------------------------------------------------------
-template <class D, class Seq, bool PROJ>
+// NWS == 4: two wavefronts per list.  NWS == 8 (kNodeWavesWide): two for the by-destination list (`past`: the
+// in-degree is a handful of frames) and six for the by-source list (`fut`), three per feature half, each a
+// contiguous third of the list -- a launch lasts as long as its worst tile, and the out-degree of a tracking
+// graph reaches 40+.
+constexpr int kNodeWavesWide = 8;
+template <class D, class Seq, bool PROJ, int NWS = kNodeWaves>
 __device__ __forceinline__ void node_fwd_split_body(const NodeFwdArgs& a, float* smem) {
   using NS = NodeSplit<D>;
-  constexpr int NWS = kNodeWaves;
+  static_assert(NWS == kNodeWaves || NWS == kNodeWavesWide, "four or eight wavefronts per tile");
   constexpr int XB = NS::XB, DMB = NS::DMB, H1B = NS::H1B, H2B = NS::H2B;
-  constexpr int MB2 = 2 * DMB, BPW = MB2 / NWS;              // blocks of M per wavefront
-  static_assert(MB2 % NWS == 0 && DMB % BPW == 0, "message width must split over the wavefronts");
+  constexpr int FP = NWS == kNodeWavesWide ? 3 : 1;          // wavefronts per half of the by-source list
+  constexpr int MB2 = 2 * DMB, BPW = DMB / 2;                // blocks of M per gathering wavefront
+  static_assert(DMB % 2 == 0 && 2 + 2 * FP == NWS, "message width must split over the wavefronts");
+  static_assert(FP == 1 || (FP - 1) * DMB <= NS::XBUF_BLOCKS, "partial sums live in the second exchange buffer");
+  if constexpr (PROJ) B3D_STAMP(0, 0);
   WStreamT<NWS * 64> ws;
   ws.init(a.wpack, smem);
   ws.template start<Seq>();
@@ -118,36 +126,67 @@ __device__ __forceinline__ void node_fwd_split_body(const NodeFwdArgs& a, float*
 
   // Every weight-chunk acquire drains vmcnt: stores are issued right AFTER the next layer's barrier (by the
   // block's owner, from the values every wavefront reads back), loads a stage ahead of their use.
-  constexpr int PFB = 2 * D::EH1 / 16, PT0B = 2 * D::MH / 16, PT0N = PT0B / NWS;
-  v4f t0[PROJ ? PT0N : 1];                       // PROJ: this wavefront's blocks of the x0 terms
+  // PROJ: the x0 terms of the table blocks this wavefront will own (block mb = wave + NWS * slot, columns F | P only)
+  constexpr int PFB = 2 * D::EH1 / 16, PT0B = 2 * D::MH / 16;
+  constexpr int PS0 = PFB / NWS, PS1 = (PFB + PT0B - 1) / NWS;       // first and last slot that can hold such a block
+  v4f t0[PROJ ? PS1 - PS0 + 1 : 1];
   if constexpr (PROJ) {
-    static_assert(PFB % NWS == 0 && PT0B % NWS == 0, "table columns must split over the wavefronts");
 #pragma unroll
-    for (int i = 0; i < PT0N; ++i) load_row<1>(a.T0, row, 16 * PT0B, 16 * (wave + NWS * i), valid, &t0[i]);
+    for (int s = PS0; s <= PS1; ++s) {
+      const int mb = wave + NWS * s;                                   // wave-uniform
+      t0[s - PS0] = v4f{0.f, 0.f, 0.f, 0.f};
+      if (mb >= PFB && mb < PFB + PT0B) load_row<1>(a.T0, row, 16 * PT0B, 16 * (mb - PFB), valid, &t0[s - PS0]);
+    }
   }
   // ---- segment sums: waves [0, NWS/2) own the `past` half of M, the others the `fut` half ----
+  // The gathers run in layout Q (lane = 4 row + q: contiguous 64-byte reads per lane quad, b3d_dev.hpp); the
+  // sums reach the MFMA layout through their LDS slot.
   v4f part[BPW];
-  const int blk0 = wave * BPW;
+  const bool is_fut = wave >= 2;
+  const int fpart = is_fut ? (wave - 2) >> 1 : 0;            // which third of the by-source list
+  const int blk0 = is_fut ? DMB + ((wave - 2) & 1) * BPW : wave * BPW;
+  const bool owner = fpart == 0;                             // holds the finished sums of its blocks
+  const long rowq = (long)blockIdx.x * 16 + q_row(lane);
+  const bool validq = rowq < a.N;
   {
 #pragma unroll
     for (int b = 0; b < BPW; ++b) part[b] = v4f{0.f, 0.f, 0.f, 0.f};
-    if (valid) {
+    if (validq) {
       constexpr int U = BPW <= 3 ? 8 : 4;                    // rows in flight per lane (MI355X: 8 beats 4 and 16)
-      if (blk0 < DMB) segment_sum_deep<BPW, U>(a.past, D::DM, 16 * blk0, a.dst_perm, a.dst_ptr[row], a.dst_ptr[row + 1], part);
-      else segment_sum_deep<BPW, U>(a.fut, D::DM, 16 * (blk0 - DMB), a.src_perm, a.src_ptr[row], a.src_ptr[row + 1], part);
+      if (!is_fut) {
+        segment_sum_deep_q<BPW, U>(a.past, D::DM, 16 * blk0, a.dst_perm, a.dst_ptr[rowq], a.dst_ptr[rowq + 1], part, q_piece(lane));
+      } else {
+        const int beg = a.src_ptr[rowq], len = a.src_ptr[rowq + 1] - beg;
+        segment_sum_deep_q<BPW, U>(a.fut, D::DM, 16 * (blk0 - DMB), a.src_perm, beg + len * fpart / FP, beg + len * (fpart + 1) / FP, part,
+                                   q_piece(lane));
+      }
     }
+    v4f* dstp = owner ? xb0 + blk0 * 64 : xb1 + ((fpart - 1) * DMB + blk0 - DMB) * 64;
 #pragma unroll
-    for (int b = 0; b < BPW; ++b) xb0[(blk0 + b) * 64 + lane] = part[b];
+    for (int b = 0; b < BPW; ++b) dstp[b * 64 + q_slot(lane)] = part[b];
+    if constexpr (FP > 1) {
+      __syncthreads();
+      if (is_fut && owner) {
+#pragma unroll
+        for (int b = 0; b < BPW; ++b) {
+#pragma unroll
+          for (int t = 1; t < FP; ++t) part[b] += xb1[((t - 1) * DMB + blk0 - DMB + b) * 64 + q_slot(lane)];
+          xb0[(blk0 + b) * 64 + q_slot(lane)] = part[b];
+        }
+      }
+    }
   }
+  if constexpr (PROJ) B3D_STAMP(0, 1);
   v4f m[MB2], h1[H1B], h2[H2B];
   linear_split<Seq, 0, true, true, NWS>(
       ws, false, m,
       [&]() {
-        if (a.M) store_row<BPW>(a.M, row, 2 * D::DM, 16 * blk0, valid, part);
+        if (a.M && owner) store_row_q<BPW>(a.M, rowq, 2 * D::DM, 16 * blk0, validq, part);
 #pragma unroll
         for (int b = 0; b < MB2; ++b) m[b] = xb0[b * 64 + lane];
       },
       [&](int mb, v4f v) { xb1[mb * 64 + lane] = v; });
+  if constexpr (PROJ) B3D_STAMP(0, 2);
   linear_split<Seq, 1, true, true, NWS>(
       ws, false, h1,
       [&]() {
@@ -160,6 +199,7 @@ __device__ __forceinline__ void node_fwd_split_body(const NodeFwdArgs& a, float*
         }
       },
       [&](int mb, v4f v) { xb0[mb * 64 + lane] = v; });
+  if constexpr (PROJ) B3D_STAMP(0, 3);
   linear_split<Seq, 2, false, true, NWS>(
       ws, false, h2,
       [&]() {
@@ -175,6 +215,7 @@ __device__ __forceinline__ void node_fwd_split_body(const NodeFwdArgs& a, float*
         if constexpr (PROJ) xb1[mb * 64 + lane] = v;                  // stored behind the projection's barrier
         else store_row<1>(a.x_out, row, D::DX, 16 * mb, valid, &v);
       });
+  if constexpr (PROJ) B3D_STAMP(0, 4);
   if constexpr (PROJ) {
     // per-node parts of the NEXT layer's three first Linear layers (b3d_hoist.hpp): T = Wp x' + bp (+ x0 terms)
     // columns: first-layer parts (A | B | F | P), then GATConv.lin(x) of the discarded k-NN block; only F | P
@@ -191,17 +232,18 @@ __device__ __forceinline__ void node_fwd_split_body(const NodeFwdArgs& a, float*
             if (b % NWS == wave) store_row<1>(a.x_out, row, D::DX, 16 * b, valid, &xn[b]);
         },
         [&](int mb, v4f v, int slot) {
-          if (mb >= FB && mb < FB + T0B) v += t0[slot - FB / NWS];
+          if (mb >= FB && mb < FB + T0B) v += t0[slot - PS0];
           store_row<1>(a.T, row, TW, 16 * mb, valid, &v);
         });
   }
+  if constexpr (PROJ) B3D_STAMP(0, 5);
   (void)XB;
 }
 
-template <class D>
-__global__ __launch_bounds__(kNodeWaves * 64, 1) void mp_node_fwd_split_kernel(const NodeFwdArgs a) {
+template <class D, int NWS = kNodeWaves>
+__global__ __launch_bounds__(NWS * 64, 1) void mp_node_fwd_split_kernel(const NodeFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  node_fwd_split_body<D, typename D::NodeFwdSeq, false>(a, smem);
+  node_fwd_split_body<D, typename D::NodeFwdSeq, false, NWS>(a, smem);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -245,13 +287,14 @@ __global__ __launch_bounds__(kNodeWaves * 64, 1) void mp_node_bwd_split_kernel(c
 #pragma unroll
       for (int b = 0; b < GPW; ++b) part[b] = v4f{0.f, 0.f, 0.f, 0.f};
       const int half = wave / (NWS / 2), blk0 = (wave % (NWS / 2)) * GPW;
-      if (valid) {
+      const long rowq = (long)blockIdx.x * 16 + q_row(lane);       // gathers in layout Q (b3d_dev.hpp)
+      if (rowq < a.N) {
         constexpr int U = GPW <= 3 ? 8 : 4;
-        if (half == 0) segment_sum_deep<GPW, U>(a.gdst, 2 * D::DX, 16 * blk0, a.dst_perm, a.dst_ptr[row], a.dst_ptr[row + 1], part);
-        else segment_sum_deep<GPW, U>(a.gsrc, 2 * D::DX, 16 * blk0, a.src_perm, a.src_ptr[row], a.src_ptr[row + 1], part);
+        if (half == 0) segment_sum_deep_q<GPW, U>(a.gdst, 2 * D::DX, 16 * blk0, a.dst_perm, a.dst_ptr[rowq], a.dst_ptr[rowq + 1], part, q_piece(lane));
+        else segment_sum_deep_q<GPW, U>(a.gsrc, 2 * D::DX, 16 * blk0, a.src_perm, a.src_ptr[rowq], a.src_ptr[rowq + 1], part, q_piece(lane));
       }
 #pragma unroll
-      for (int b = 0; b < GPW; ++b) xb0[(half * GB + blk0 + b) * 64 + lane] = part[b];
+      for (int b = 0; b < GPW; ++b) xb0[(half * GB + blk0 + b) * 64 + q_slot(lane)] = part[b];
     }
     __syncthreads();
 #pragma unroll

@@ -529,6 +529,13 @@ extern "C" int b3d_pose_debug_layer_ptrs(void* workspace, size_t workspace_bytes
   return B3D_OK;
 }
 
+#ifdef B3D_EXP_STAMPS
+namespace b3d { __device__ long long g_stamps[2][512 * 16]; }
+extern "C" int b3d_debug_stamps(long long* host_dst) {
+  return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(b3d::g_stamps), sizeof(long long) * 2 * 512 * 16) == hipSuccess ? 0 : 1;
+}
+#endif
+
 extern "C" int b3d_pose_debug_knn_ptrs(void* workspace, size_t workspace_bytes, int32_t N, int32_t E, int32_t depth,
                                        uint32_t flags, float** y, int32_t** nbr, int32_t** cnt) {
   B3D_REQUIRE(depth >= 1 && depth <= 15 && (flags & B3D_FLAG_RUN_DEAD_KNN), "no k-NN block in this workspace");
@@ -623,10 +630,10 @@ extern "C" int b3d_pose_forward(const b3d_pose_weights* pw, const b3d_graph* g, 
     na.past = w.past; na.fut = w.fut; na.M = w.M[l]; na.x_out = w.x[l + 1]; na.sH1 = w.nH1[l]; na.sH2 = w.nH2[l];
     if (w.hoist && l + 1 < depth) {            // + the per-node table the next layer's edge phase gathers
       na.wpack = w.wp_nfwd_h; na.T = w.T; na.T0 = w.T0;
-      B3D_TRY(launch_node_split<D>(mp_node_fwd_split_h_kernel<D>, "mp_node_fwd", na, N, stream, B3D_K_NODE_FWD));
+      B3D_TRY((launch_node_split<D, kNodeWavesWide>(mp_node_fwd_split_h_kernel<D>, "mp_node_fwd", na, N, stream, B3D_K_NODE_FWD)));
     } else {
       na.wpack = w.wp_nfwd;
-      B3D_TRY(launch_node_split<D>(mp_node_fwd_split_kernel<D>, "mp_node_fwd", na, N, stream, B3D_K_NODE_FWD));
+      B3D_TRY((launch_node_split<D, kNodeWavesWide>(mp_node_fwd_split_kernel<D, kNodeWavesWide>, "mp_node_fwd", na, N, stream, B3D_K_NODE_FWD)));
     }
   }
   {  // edge classifier 32-16-8-4-1 -> logits                                pose_gnn.py:86
@@ -994,7 +1001,7 @@ extern "C" int b3d_pose_layer_forward(const b3d_mp_weights* mw, const b3d_graph*
   na.past = w.past; na.fut = w.fut; na.x_out = x_new;
   if (tr) { na.M = w.M[0]; na.sH1 = w.nH1[0]; na.sH2 = w.nH2[0]; }
   na.wpack = w.wp_nfwd;
-  B3D_TRY(launch_node_split<D>(mp_node_fwd_split_kernel<D>, "mp_node_fwd", na, N, stream, B3D_K_NODE_FWD));
+  B3D_TRY((launch_node_split<D, kNodeWavesWide>(mp_node_fwd_split_kernel<D, kNodeWavesWide>, "mp_node_fwd", na, N, stream, B3D_K_NODE_FWD)));
   return B3D_OK;
 }
 

@@ -1,0 +1,49 @@
+"""Gradient error of the HIP path and of the fp32 oracle against a float64 evaluation (full-size batch)."""
+import copy, os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from batch3dmot_amd import synth
+from batch3dmot_amd.data import Data
+from batch3dmot_amd.pose_gnn import PoseGNN
+from oracle import ref_torch
+from oracle.seeded import seeded_fill_
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+def rel2(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+dev = torch.device("cuda:0")
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+big = synth.make_batch(2, 1500, 15000, first_graph_idx=seed)
+ora = ref_torch.PoseGNN(run_dead_knn=False)
+seeded_fill_(ora, 5)
+m = PoseGNN().to(dev); m.load_state_dict(ora.state_dict(), strict=True)
+lw = torch.randn(big.edge_index.size(1), 1, generator=torch.Generator().manual_seed(1237))
+out, x_enc = m(big.to(dev))
+(out * lw.to(dev)).sum().backward()
+o32, x32 = ora(big)
+(o32 * lw).sum().backward()
+ora64 = copy.deepcopy(ora).double(); ora64.zero_grad()
+big64 = Data(**{k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in big.__dict__.items()})
+big64.edge_attr = big.edge_attr.float().double()
+e64 = ora64.edge_encoder(big64.edge_attr); x64 = ora64.node_encoder(big64.pose_feats); x0 = x64
+for _ in range(6):
+    x64, e64 = ora64.message_passing(x64, big64.edge_index, e64, x0)
+o64 = ora64.edge_classifier(e64)
+(o64 * lw.double()).sum().backward()
+print(f"out: hip {rel(out, o64):.2e} cpu {rel(o32, o64):.2e}")
+worst = 0
+for (n, p), (_, q), (_, r) in zip(m.named_parameters(), ora.named_parameters(), ora64.named_parameters()):
+    if r.grad is None: continue
+    eh, ec = rel(p.grad, r.grad), rel(q.grad, r.grad)
+    flag = "  <-- FAIL" if eh >= max(3 * ec, 1e-4) else ""
+    if eh > 5e-5 or flag:
+        print(f"{n:44s} max-rel hip {eh:.2e} cpu {ec:.2e} | l2-rel hip {rel2(p.grad, r.grad):.2e} cpu {rel2(q.grad, r.grad):.2e}{flag}")
+import numpy as np
+eh = [rel2(p.grad, r.grad) for (n, p), (_, r) in zip(m.named_parameters(), ora64.named_parameters()) if r.grad is not None]
+ec = [rel2(q.grad, r.grad) for (n, q), (_, r) in zip(ora.named_parameters(), ora64.named_parameters()) if r.grad is not None]
+print(f"SUMMARY seed {seed}: l2-rel over parameters: hip median {np.median(eh):.2e} max {max(eh):.2e} | cpu median {np.median(ec):.2e} max {max(ec):.2e}")
