@@ -96,6 +96,7 @@ __global__ __launch_bounds__(NW * 64, 16 / NW) void mp_edge_fwd_h_kernel(const E
   using Seq = typename H::EdgeFwdSeq;
   constexpr int EB = D::DE / 16, AB = D::DA / 16;
   constexpr int H1B = D::EH1 / 16, H2B = D::EH2 / 16, MHB = D::MH / 16, DMB = D::DM / 16;
+  B3D_STAMP(2, 0);
   WStreamT<NW * 64, Seq::max_chunk()> ws;     // hoisted stacks: every chunk is <= 26 KB, the ring takes 52 KB
   ws.init(a.wpack, smem);
   ws.template start<Seq>();
@@ -118,26 +119,35 @@ __global__ __launch_bounds__(NW * 64, 16 / NW) void mp_edge_fwd_h_kernel(const E
     load_row_u<H1B>(a.T, s, H::TW, H::OB, tb);
     wait_for(ein); wait_for(h1); wait_for(tb);             // every prologue load has landed before the first acquire
     add_blocks<H1B>(h1, tb);
+    B3D_STAMP(2, 1);
 
     v4f h2[H2B], en[EB];
     linear_init<Seq, 0, true, false>(ws, more, ein, h1, h1);
+    B3D_STAMP(2, 2);
     linear<Seq, 1, true>(ws, more, h1, h2, [&]() {
       if (a.sH1) store_row<H1B>(a.sH1, row, D::EH1, 0, valid, h1);
       load_row_u<MHB>(a.T, d, H::TW, H::OF, fi);
     });
+    B3D_STAMP(2, 3);
     linear<Seq, 2, false>(ws, more, h2, en, [&]() {
       if (a.sH2) store_row<H2B>(a.sH2, row, D::EH2, 0, valid, h2);
       load_row_u<MHB>(a.T, s, H::TW, H::OP, pi);
     });
+    B3D_STAMP(2, 4);
 
     v4f mo[DMB], mo2[DMB];
     wait_for(fi);
     linear_init<Seq, 3, true, false>(ws, more, en, fi, fi, [&]() { store_row<EB>(a.e_out, row, D::DE, 0, valid, en); });
+    B3D_STAMP(2, 5);
     linear<Seq, 4, false>(ws, more, fi, mo, [&]() { if (a.sF1) store_row<MHB>(a.sF1, row, D::MH, 0, valid, fi); });
+    B3D_STAMP(2, 6);
     wait_for(pi);
     linear_init<Seq, 5, true, false>(ws, more, en, pi, pi, [&]() { store_row<DMB>(a.fut, row, D::DM, 0, valid, mo); });
+    B3D_STAMP(2, 7);
     linear<Seq, 6, false>(ws, more, pi, mo2, [&]() { if (a.sP1) store_row<MHB>(a.sP1, row, D::MH, 0, valid, pi); });
+    B3D_STAMP(2, 8);
     store_row<DMB>(a.past, row, D::DM, 0, valid, mo2);
+    B3D_STAMP(2, 9);
   }
 }
 
@@ -222,6 +232,7 @@ __global__ __launch_bounds__(NW * 64, 16 / NW) void mp_edge_bwd_h_kernel(const E
   extern __shared__ __attribute__((aligned(16))) float smem[];
   using H = Hoist<D>;
   using Seq = typename std::conditional<MSGS, typename H::EdgeBwdSeq, typename H::EdgeBwdSeqNoMsg>::type;
+  if constexpr (MSGS) B3D_STAMP(3, 0);
   constexpr int L0 = MSGS ? 4 : 0;
   constexpr int EB = D::DE / 16, AB = D::DA / 16;
   constexpr int H1B = D::EH1 / 16, H2B = D::EH2 / 16, MHB = D::MH / 16, DMB = D::DM / 16;
@@ -249,20 +260,25 @@ __global__ __launch_bounds__(NW * 64, 16 / NW) void mp_edge_bwd_h_kernel(const E
       load_row<MHB>(a.sP1, row, D::MH, 0, valid, actp);
       load_row<DMB>(a.dM, s, 2 * D::DM, D::DM, valid, dmf);        // future messages were summed at src
       wait_for(de); wait_for(dmp); wait_for(actp); wait_for(dmf);   // the prologue's loads have landed
+      B3D_STAMP(3, 1);
       linear<Seq, 0, false, false>(ws, more, dmp, dh, [&]() { load_row<MHB>(a.sF1, row, D::MH, 0, valid, actf); });
+      B3D_STAMP(3, 2);
       relu_bwd<MHB>(dh, actp);
       linear<Seq, 1, false, false>(ws, more, dh, dee, [&]() {
         store_row<MHB>(a.GdP1, row, D::MH, 0, valid, dh);
         load_row<H2B>(a.sH2, row, D::EH2, 0, valid, act2);
       });
+      B3D_STAMP(3, 3);
       add_blocks<EB>(de, dee);
       wait_for(actf);
       linear<Seq, 2, false, false>(ws, more, dmf, dh2);
+      B3D_STAMP(3, 4);
       relu_bwd<MHB>(dh2, actf);
       linear<Seq, 3, false, false>(ws, more, dh2, dee, [&]() {
         store_row<MHB>(a.GdF1, row, D::MH, 0, valid, dh2);
         load_row<H1B>(a.sH1, row, D::EH1, 0, valid, act1);
       });
+      B3D_STAMP(3, 5);
       add_blocks<EB>(de, dee);
     } else {
       load_row<H2B>(a.sH2, row, D::EH2, 0, valid, act2);
@@ -271,12 +287,15 @@ __global__ __launch_bounds__(NW * 64, 16 / NW) void mp_edge_bwd_h_kernel(const E
     }
     wait_for(act2);
     linear<Seq, L0 + 0, false, false>(ws, more, de, d2, [&]() { store_row<EB>(a.Gde, row, D::DE, 0, valid, de); });
+    if constexpr (MSGS) B3D_STAMP(3, 6);
     relu_bwd<H2B>(d2, act2);
     wait_for(act1);
     linear<Seq, L0 + 1, false, false>(ws, more, d2, d1, [&]() { store_row<H2B>(a.GdH2, row, D::EH2, 0, valid, d2); });
+    if constexpr (MSGS) B3D_STAMP(3, 7);
     relu_bwd<H1B>(d1, act1);
     v4f dein[EB + AB];
     linear<Seq, L0 + 2, false, false>(ws, more, d1, dein, [&]() { store_row<H1B>(a.GdH1, row, D::EH1, 0, valid, d1); });
+    if constexpr (MSGS) B3D_STAMP(3, 8);
     store_row<EB>(a.de_in, row, D::DE, 0, valid, dein);
     if constexpr (AB > 0) {
       if (!a.da_first) {

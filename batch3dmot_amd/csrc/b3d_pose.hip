@@ -530,9 +530,9 @@ extern "C" int b3d_pose_debug_layer_ptrs(void* workspace, size_t workspace_bytes
 }
 
 #ifdef B3D_EXP_STAMPS
-namespace b3d { __device__ long long g_stamps[2][512 * 16]; }
+namespace b3d { __device__ long long g_stamps[4][512 * 16]; }
 extern "C" int b3d_debug_stamps(long long* host_dst) {
-  return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(b3d::g_stamps), sizeof(long long) * 2 * 512 * 16) == hipSuccess ? 0 : 1;
+  return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(b3d::g_stamps), sizeof(long long) * 4 * 512 * 16) == hipSuccess ? 0 : 1;
 }
 #endif
 

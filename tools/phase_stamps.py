@@ -20,15 +20,18 @@ for it in range(5):
     (out * lw).sum().backward()
 torch.cuda.synchronize()
 lib = _lib.load()
-buf = np.zeros((2, 512, 16), dtype=np.int64)
+buf = np.zeros((4, 512, 16), dtype=np.int64)
 assert lib.b3d_debug_stamps(buf.ctypes.data_as(C.c_void_p)) == 0
-nwg = (big.x.size(0) + 15) // 16 if hasattr(big, "x") else 188
 names = {0: ["start", "segsum", "L0 128>96", "L1 96>64", "L2 64>48", "proj 48>432"],
-         1: ["start", "act loads", "list sums", "4 products", "L4 48>64", "L5 64>96", "L6 96>128"]}
-for k in (0, 1):
+         1: ["start", "act loads", "list sums", "4 products", "L4 48>64", "L5 64>96", "L6 96>128"],
+         2: ["start", "gathers", "L0 32>96", "L1 96>64", "L2 64>32", "L3 32>96", "L4 96>64", "L5 32>96", "L6 96>64", "last store"],
+         3: ["start", "loads", "L0 64>96", "L1 96>32", "L2 64>96", "L3 96>32", "L4 32>64", "L5 64>96", "L6 96>32+"]}
+E_tiles = (E + 127) // 128
+for k in (0, 1, 2, 3):
+    nwg = ((big.pose_feats.size(0) + 15) // 16) if k < 2 else E_tiles
     s = buf[k, :nwg, :len(names[k])].astype(np.float64) * 0.01          # 100 MHz -> us
     t0 = s[:, 0].min()
-    print(["node_fwd_h", "node_bwd_h"][k], f"workgroups {nwg}: start spread {s[:,0].max()-t0:.2f} us, end: mean {(s[:,-1]-t0).mean():.2f} max {(s[:,-1]-t0).max():.2f} us")
+    print(["node_fwd_h", "node_bwd_h", "edge_fwd_h", "edge_bwd_h"][k], f"workgroups {nwg}: start spread {s[:,0].max()-t0:.2f} us, end: mean {(s[:,-1]-t0).mean():.2f} max {(s[:,-1]-t0).max():.2f} us")
     d = np.diff(s, axis=1)
     for i, n in enumerate(names[k][1:]):
         print(f"   {n:14s} mean {d[:, i].mean():6.2f}  p50 {np.median(d[:, i]):6.2f}  max {d[:, i].max():6.2f} us")
