@@ -354,3 +354,49 @@ def edge_weights_loop(edges: torch.Tensor, category_names, rel_freq_train: dict,
         else:
             raise ValueError("mixed-class edge: the reference fails here (graph_data.py:223)")
     return weights, edge_classes, node_classes
+
+
+# --------------------------------------------------------------------------------------
+# Window loader (utils/graph_data.py:152-257), restated loop for loop.  TEST INFRASTRUCTURE ONLY.
+# --------------------------------------------------------------------------------------
+def window_getitem_loop(stem: str, inference: bool, rel_freq_train: dict, class_dict: dict):
+    """What ``GraphDataset.__getitem__`` builds for the window whose files start with ``stem``: the eight
+    ``torch.load``s and the JSON (:162-175), the per-edge global-id loop and the per-node timestamp loop of the
+    inference branch (:177-192), the per-edge weighting loop (:194-228, via ``edge_weights_loop``) and the
+    field names of the returned ``Data`` (:230-242) / the inference extras and the metadata string (:244-255).
+    Returns a dict of those fields (and the string, for inference)."""
+    import json
+    pose_features = torch.load(stem + '_pose_features.pth')
+    img_features = torch.load(stem + '_img_features.pth')
+    lidar_features = torch.load(stem + '_lidar_features.pth')
+    radar_features = torch.load(stem + '_radar_features.pth')
+    node_timestamps = torch.load(stem + '_node_timestamps.pth')
+    edge_features = torch.load(stem + '_edge_features.pth')
+    edges = torch.load(stem + '_edges.pth')
+    gt = torch.load(stem + '_gt.pth')
+    if inference:
+        boxes = torch.load(stem + '_node_boxes.pth')
+    with open(stem + '_node_metadata.json', 'r') as file:
+        node_metadata = json.load(file)
+    if inference:
+        global_edge_index = torch.zeros_like(edges)
+        global_node_timestamps = torch.zeros((node_timestamps.shape[0], 2))
+        for row_idx, edge in enumerate(edges):
+            global_node_j = node_metadata[str(edge[0].item())]['global_node_id']
+            global_node_i = node_metadata[str(edge[1].item())]['global_node_id']
+            global_edge_index[row_idx] = torch.tensor([global_node_j, global_node_i])
+        for node_idx, node_time in enumerate(node_timestamps):
+            global_node_timestamps[node_idx] = torch.tensor([node_metadata[str(node_idx)]['global_node_id'], node_time])
+    names = [node_metadata[str(i)]['category_name'] for i in range(pose_features.shape[0])]
+    weights, edge_classes, node_classes = edge_weights_loop(edges, names, rel_freq_train, class_dict, pose_features.shape[0])
+    out = dict(pose_feats=pose_features, img_feats=img_features, lidar_feats=lidar_features, radar_feats=radar_features,
+               edge_index=edges.t().contiguous(), edge_attr=edge_features, y=gt.t().contiguous(),
+               node_timestamps=node_timestamps, edge_weights=weights, edge_classes=edge_classes,
+               node_classes=node_classes, num_nodes=pose_features.shape[0])
+    if not inference:
+        return out
+    out.update(global_edge_index=global_edge_index.t().contiguous(), global_node_timestamps=global_node_timestamps, boxes=boxes)
+    global_node_metadata = dict()
+    for node_id in range(pose_features.shape[0]):
+        global_node_metadata[node_metadata[str(node_id)]['global_node_id']] = node_metadata[str(node_id)]
+    return out, str(global_node_metadata)

@@ -1,0 +1,142 @@
+"""Window loader: files in the reference's on-disk format
+(construct_detection_graphs_parallel.py:623-650) are read by ``graph_data.GraphDataset`` and by the oracle's
+loop-for-loop restatement of ``GraphDataset.__getitem__`` (utils/graph_data.py:152-257); every field must match.
+Then the batch iterator against a plain collate."""
+import json
+import types
+
+import pytest
+import torch
+
+from batch3dmot_amd import synth
+from batch3dmot_amd.data import collate
+from batch3dmot_amd.graph_data import CLASS_DICT, REL_FREQ_TRAIN, GraphDataset, iterate_batches
+from oracle.ref_torch import window_getitem_loop
+
+INV_CLASS = {v: k for k, v in CLASS_DICT.items()}
+
+
+def _write_window(stem, seed, n_per_frame=12, global_offset=1000):
+    """One synthetic window in the reference's file layout (plus one isolated node, which no edge touches)."""
+    g = synth.make_graph(5 * n_per_frame, 40 * n_per_frame, graph_idx=seed, modalities=True)
+    n = g.pose_feats.size(0)
+    cls = g.node_classes.long().clone()
+    # append an isolated node: its class never reaches node_classes in the reference's loop
+    pose = torch.cat([g.pose_feats, g.pose_feats[:1]])
+    ts = torch.cat([g.node_timestamps, g.node_timestamps[:1]])
+    torch.save(pose, stem + "_pose_features.pth")
+    torch.save(torch.cat([g.img_feats, g.img_feats[:1]]), stem + "_img_features.pth")
+    torch.save(torch.cat([g.lidar_feats, g.lidar_feats[:1]]), stem + "_lidar_features.pth")
+    torch.save(torch.cat([g.radar_feats, g.radar_feats[:1]]), stem + "_radar_features.pth")
+    torch.save(ts, stem + "_node_timestamps.pth")
+    torch.save(g.edge_attr, stem + "_edge_features.pth")
+    torch.save(g.edge_index.t().contiguous(), stem + "_edges.pth")
+    torch.save(g.y.reshape(1, -1), stem + "_gt.pth")
+    torch.save(torch.arange((n + 1) * 7, dtype=torch.float32).reshape(n + 1, 7), stem + "_node_boxes.pth")
+    gen = torch.Generator().manual_seed(seed)
+    gids = (torch.randperm(5 * (n + 1), generator=gen)[: n + 1] + global_offset).tolist()
+    meta = {}
+    for i in range(n + 1):
+        c = int(cls[i]) if i < n and int(cls[i]) > 0 else 1
+        meta[str(i)] = {"category_name": INV_CLASS[c], "global_node_id": gids[i], "score": 0.5, "token": f"t{i}"}
+    with open(stem + "_node_metadata.json", "w") as fh:
+        json.dump(meta, fh)
+    return n + 1
+
+
+@pytest.fixture()
+def window_dir(tmp_path):
+    d = str(tmp_path) + "/"
+    scenes = [{"token": "sceneA", "nbr_samples": 8}, {"token": "sceneB", "nbr_samples": 7}]
+    k = 0
+    for sc in scenes:
+        for b in range(int(sc["nbr_samples"]) - 5):
+            _write_window(d + f"{sc['token']}_len5_{b}", seed=10 + k)
+            k += 1
+    return d, scenes
+
+
+def _same(a, b):
+    if a.dtype.is_floating_point:
+        torch.testing.assert_close(a, b, rtol=1e-6, atol=0)
+    else:
+        assert torch.equal(a, b)
+    assert a.dtype == b.dtype and a.shape == b.shape
+
+
+@pytest.mark.parametrize("inference", [False, True])
+def test_every_field_equals_the_reference_loops(window_dir, inference):
+    d, scenes = window_dir
+    params = types.SimpleNamespace(main=types.SimpleNamespace(slice_factor=1, class_dict="nuscenes_tracking_eval"),
+                                   gnn=types.SimpleNamespace(batch_size_graph=5),
+                                   classes=types.SimpleNamespace(nuscenes_tracking_eval=CLASS_DICT))
+    ds = GraphDataset(params, scenes, d, 5, inference)
+    assert len(ds) == 3 + 2 and ds.batches[0] == d + "sceneA_len5_0" and ds.batches[-1] == d + "sceneB_len5_1"
+    assert ds.get_metadata() == (ds.batches, scenes)
+    for idx in range(len(ds)):
+        got = ds[idx]
+        ref = window_getitem_loop(ds.batches[idx], inference, REL_FREQ_TRAIN, CLASS_DICT)
+        if inference:
+            (got, got_meta), (ref, ref_meta) = got, ref
+            assert got_meta == ref_meta
+        for key, val in ref.items():
+            if torch.is_tensor(val):
+                _same(getattr(got, key), val)
+            else:
+                assert getattr(got, key) == val, key
+        assert got.batch_idx == idx
+        assert float(got.node_classes[-1]) == 0.0                   # the isolated node keeps class 0, as in the loop
+        for e in range(0, got.edge_index.size(1), 41):
+            name = INV_CLASS[int(got.edge_classes[e])]
+            assert abs(float(got.edge_weights[e]) - ds.cb_scaling_factor(name)) < 1e-6
+
+
+def test_params_may_be_a_dict_or_absent_and_modalities_can_be_skipped(window_dir):
+    d, scenes = window_dir
+    a = GraphDataset(None, scenes, d, 5, False, modalities=())
+    b = GraphDataset({"main": {"slice_factor": 2}, "gnn": {"batch_size_graph": 5}}, scenes, d, 5, False)
+    assert len(a) == 5 and len(b) == 3                            # every second scene
+    w = a[1]
+    assert w.img_feats is None and w.lidar_feats is None and w.radar_feats is None and w.pose_feats.size(1) == 19
+
+
+@pytest.mark.parametrize("shuffle", [False, True])
+def test_batch_iterator_yields_the_collated_windows(window_dir, shuffle):
+    d, scenes = window_dir
+    ds = GraphDataset(None, scenes, d, 5, False)
+    gen = torch.Generator().manual_seed(3)
+    order = torch.randperm(len(ds), generator=torch.Generator().manual_seed(3)).tolist() if shuffle else list(range(len(ds)))
+    batches = list(iterate_batches(ds, 2, shuffle=shuffle, generator=gen, prefetch=2))
+    assert len(batches) == 3
+    for k, b in enumerate(batches):
+        want = collate([ds[i] for i in order[2 * k: 2 * k + 2]])
+        for key in ("pose_feats", "edge_index", "edge_attr", "y", "edge_weights", "node_timestamps", "batch"):
+            assert torch.equal(getattr(b, key), getattr(want, key)), key
+    assert len(list(iterate_batches(ds, 2, drop_last=True))) == 2
+
+
+def test_loader_errors_surface_in_the_consumer(window_dir):
+    d, scenes = window_dir
+    ds = GraphDataset(None, [{"token": "missing", "nbr_samples": 6}], d, 5, False)
+    with pytest.raises(FileNotFoundError):
+        list(iterate_batches(ds, 1))
+
+
+@pytest.mark.gpu
+def test_prefetched_batches_on_the_gpu_feed_the_model(window_dir):
+    """Pinned + copy-stream delivery: tensors arrive on the device bit-identical, and the path consumes them."""
+    from batch3dmot_amd.pose_gnn import PoseGNN
+    d, scenes = window_dir
+    ds = GraphDataset(None, scenes, d, 5, False, modalities=())
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    m = PoseGNN().to(dev).eval()
+    outs = []
+    for b in iterate_batches(ds, 2, device=dev, prefetch=2):
+        assert b.pose_feats.is_cuda and b.edge_index.is_cuda
+        with torch.no_grad():
+            outs.append(m(b)[0].cpu())
+    for k, o in enumerate(outs):
+        want = collate([ds[i] for i in range(2 * k, min(2 * k + 2, len(ds)))]).to(dev)
+        with torch.no_grad():
+            assert torch.equal(m(want)[0].cpu(), o)
