@@ -160,6 +160,11 @@ def load() -> C.CDLL:
     lib.b3d_adam_step_dev.restype = C.c_int
     lib.b3d_adam_step_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
                                       C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+    lib.b3d_average_precision_workspace_bytes.restype = C.c_size_t
+    lib.b3d_average_precision_workspace_bytes.argtypes = [C.c_int64, C.c_int32]
+    lib.b3d_average_precision.restype = C.c_int
+    lib.b3d_average_precision.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p,
+                                          C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.b3d_post_workspace_bytes.restype = C.c_size_t
     lib.b3d_post_workspace_bytes.argtypes = [C.c_int64, C.c_int64]
     lib.b3d_post_greedy.restype = C.c_int

@@ -270,6 +270,18 @@ int b3d_post_greedy(const int64_t* pairs, const float* scores, int64_t M, const 
                     const double* class_threshold, void* workspace, size_t workspace_bytes, int64_t* kept_pairs,
                     double* kept_scores, int64_t* pred, int64_t* succ, int32_t* counts, b3d_stream stream);
 
+/* ---- average precision of the edge scores (train.py:18,143-150,188-196) -----------------------------------
+ * torchmetrics.functional average_precision(out, gt, pos_label=1) of the whole batch (ap[0]) and of the edges of
+ * every class c in 1..num_classes (ap[c], the reference's out[edge_classes == c]); count[s] = edges in the set
+ * (the reference skips classes with none).  scores [E] float32; y [E] float32 or int64 (positive iff == 1);
+ * edge_classes [E] float32 class ids or NULL (overall only).  ap: device float64[num_classes + 1] (NaN for a set
+ * without positives, as torchmetrics' 0/0), count: device int32[num_classes + 1].  One curve point per distinct
+ * score; float64; deterministic; no host synchronisation. */
+size_t b3d_average_precision_workspace_bytes(int64_t E, int32_t num_classes);
+int b3d_average_precision(const float* scores, const void* y, int32_t y_is_int64, const float* edge_classes, int64_t E,
+                          int32_t num_classes, void* workspace, size_t workspace_bytes, double* ap, int32_t* count,
+                          b3d_stream stream);
+
 /* ---- test hooks: addresses of intermediate tensors inside a workspace a forward has filled ---------------- */
 int b3d_pose_debug_layer_ptrs(void* workspace, size_t workspace_bytes, int32_t N, int32_t E, int32_t depth,
                               uint32_t flags, int32_t layer, float** x /* [N,48] */, float** e /* [E,32] */);

@@ -400,3 +400,29 @@ def window_getitem_loop(stem: str, inference: bool, rel_freq_train: dict, class_
     for node_id in range(pose_features.shape[0]):
         global_node_metadata[node_metadata[str(node_id)]['global_node_id']] = node_metadata[str(node_id)]
     return out, str(global_node_metadata)
+
+
+# --------------------------------------------------------------------------------------
+# Average precision (train.py:18,143-150).  torchmetrics is not vendored by the reference and not installed here:
+# this restates its published binary algorithm (_binary_clf_curve + _average_precision_compute_with_precision_recall)
+# in numpy.  Pinned in tests against sklearn.metrics.average_precision_score (the same step-wise sum), not against
+# torchmetrics itself.  TEST INFRASTRUCTURE ONLY.
+# --------------------------------------------------------------------------------------
+def average_precision_np(preds, target, pos_label=1):
+    import numpy as np
+    preds = np.asarray(preds, dtype=np.float32).reshape(-1)
+    target = (np.asarray(target).reshape(-1) == pos_label)
+    order = np.argsort(-preds, kind="stable")                       # descending score
+    preds, target = preds[order], target[order]
+    distinct = np.where(preds[1:] - preds[:-1])[0]                   # a tie group ends at its last element
+    threshold_idxs = np.concatenate([distinct, [target.size - 1]]) if target.size else np.zeros(0, dtype=np.int64)
+    tps = np.cumsum(target.astype(np.float64))[threshold_idxs]
+    fps = 1 + threshold_idxs - tps
+    if tps.size == 0 or tps[-1] == 0:
+        return float("nan")                                          # recall = tps / 0
+    precision = tps / (tps + fps)
+    recall = tps / tps[-1]
+    last_ind = np.where(tps == tps[-1])[0][0]                        # stop once full recall is attained
+    precision = np.concatenate([precision[:last_ind + 1][::-1], [1.0]])
+    recall = np.concatenate([recall[:last_ind + 1][::-1], [0.0]])
+    return float(-np.sum((recall[1:] - recall[:-1]) * precision[:-1]))
