@@ -17,7 +17,7 @@ modules are kept as parameter holders so that checkpoints load unchanged.
 from __future__ import annotations
 
 import ctypes as C
-from typing import List
+from typing import List, Optional
 
 import torch
 from torch import nn
@@ -165,6 +165,54 @@ class _GNNFunction(torch.autograd.Function):
         return (None,) * 11 + tuple(grads)
 
 
+class EmbeddingCache:
+    """Encoder outputs of the detections seen so far, keyed by global node id.  Device
+    tables that grow by doubling; ``clear()`` between scenes (ids are per scene, predict.py:595-611)."""
+
+    def __init__(self, capacity: int = 4096):
+        self.capacity = capacity
+        self.clear()
+
+    def clear(self):
+        self.rows = {}
+        self.img = self.lidar = self.radar = self.has_lidar = self.has_radar = None
+        self.hits = self.misses = 0
+
+    def __len__(self):
+        return len(self.rows)
+
+    def _reserve(self, n, like_img, dev):
+        if self.img is None:
+            cap = max(self.capacity, n)
+            self.img = torch.zeros(cap, like_img.size(1), device=dev)
+            self.lidar = torch.zeros(cap, 256, device=dev)
+            self.radar = torch.zeros(cap, 256, device=dev)
+            self.has_lidar = torch.zeros(cap, dtype=torch.bool, device=dev)
+            self.has_radar = torch.zeros(cap, dtype=torch.bool, device=dev)
+        need = len(self.rows) + n
+        if need > self.img.size(0):
+            cap = max(need, 2 * self.img.size(0))
+            for name in ("img", "lidar", "radar", "has_lidar", "has_radar"):
+                old = getattr(self, name)
+                new = torch.zeros((cap,) + tuple(old.shape[1:]), dtype=old.dtype, device=old.device)
+                new[: old.size(0)] = old
+                setattr(self, name, new)
+
+    def append(self, ids, x_img, has_l, li, l_out, has_r, ri, r_out):
+        n0 = len(self.rows)
+        self._reserve(len(ids), x_img, x_img.device)
+        sl = slice(n0, n0 + len(ids))
+        self.img[sl] = x_img
+        self.has_lidar[sl] = has_l
+        self.has_radar[sl] = has_r
+        if l_out is not None:
+            self.lidar[n0 + li] = l_out
+        if r_out is not None:
+            self.radar[n0 + ri] = r_out
+        for k, gid in enumerate(ids):
+            self.rows[gid] = n0 + k
+
+
 class GNN(nn.Module):
     """``GNN(img_encoder, lidar_encoder, radar_encoder, use_attention=True, gnn_depth=6, edge_dim=64,
     node_dim=179)`` -- reference clr_att_gnn.py:16-188.
@@ -210,10 +258,17 @@ class GNN(nn.Module):
         """Parameters whose gradients ``backward`` of the HIP path produces, in C-ABI struct order."""
         return _param_list(self)
 
-    def encode_modalities(self, data):
+    def encode_modalities(self, data, cache: "Optional[EmbeddingCache]" = None, node_ids=None):
         """The frozen, adjacent part (clr_att_gnn.py:107-141): presence masks, ResNet / PointNet /
         RadarNet embeddings of the rows that have the modality, and the sticky ``.eval()`` switch
-        when fewer than two rows have it."""
+        when fewer than two rows have it.
+
+        With ``cache`` (inference: every encoder in eval mode) a detection is encoded once per scene instead of
+        once per window it appears in -- with the reference's stride-1 windows of ``batch_size_graph`` frames
+        (predict.py:172) that is up to 5x fewer encoder rows.  ``node_ids`` are the detections' global ids
+        (default: ``data.global_node_timestamps[:, 0]``, graph_data.py:190)."""
+        if cache is not None:
+            return self._encode_cached(data, cache, node_ids)
         img_feats, lidar_feats, radar_feats = data.img_feats, data.lidar_feats, data.radar_feats
         pcl_nodes = modality_present(lidar_feats)
         pr_nodes = modality_present(radar_feats)
@@ -230,6 +285,33 @@ class GNN(nn.Module):
                 self.fc_radar_encoder.eval()
             radarnet_out = self.radarnet.forward_feat(radar_feats[radar_nodes].view(-1, 4, 64)).float().contiguous()
         return x_img, pointnet_out, lidar_nodes.to(torch.int32).contiguous(), radarnet_out, radar_nodes.to(torch.int32).contiguous()
+
+    def _encode_cached(self, data, cache: "EmbeddingCache", node_ids):
+        if self.resnet.training or self.pointnet.training or self.radarnet.training:
+            raise RuntimeError("the embedding cache needs the encoders in eval mode: in train mode their BatchNorm "
+                               "statistics depend on which rows share a batch")
+        if node_ids is None:
+            node_ids = data.global_node_timestamps[:, 0]
+        ids = [int(v) for v in node_ids.tolist()]
+        dev = data.pose_feats.device
+        new_local = [i for i, gid in enumerate(ids) if gid not in cache.rows]
+        if new_local:
+            sel = torch.tensor(new_local, dtype=torch.long, device=dev)
+            lidar_new, radar_new = data.lidar_feats[sel], data.radar_feats[sel]
+            has_l, has_r = modality_present(lidar_new), modality_present(radar_new)
+            with torch.no_grad():
+                x_img = self.resnet.encode(data.img_feats[sel]).float()
+                li, ri = torch.nonzero(has_l).squeeze(1), torch.nonzero(has_r).squeeze(1)
+                l_out = self.pointnet.forward_feat(lidar_new[li].view(-1, 3, 128)).float() if li.numel() else None
+                r_out = self.radarnet.forward_feat(radar_new[ri].view(-1, 4, 64)).float() if ri.numel() else None
+            cache.append([ids[i] for i in new_local], x_img, has_l, li, l_out, has_r, ri, r_out)
+        cache.hits += len(ids) - len(new_local)
+        cache.misses += len(new_local)
+        rows = torch.tensor([cache.rows[g] for g in ids], dtype=torch.long, device=dev)
+        lidar_nodes = torch.nonzero(cache.has_lidar[rows]).squeeze(1)
+        radar_nodes = torch.nonzero(cache.has_radar[rows]).squeeze(1)
+        return (cache.img[rows].contiguous(), cache.lidar[rows[lidar_nodes]].contiguous(), lidar_nodes.to(torch.int32).contiguous(),
+                cache.radar[rows[radar_nodes]].contiguous(), radar_nodes.to(torch.int32).contiguous())
 
     def forward(self, data, encoded=None):
         if not self.use_attention:

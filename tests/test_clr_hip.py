@@ -170,3 +170,42 @@ def test_modality_configurations_against_oracle(case):
             assert rel(p.grad, q.grad) < 1e-2, (name, rel(p.grad, q.grad))
         else:
             assert rel(p.grad, q.grad) < 5 * TOL, (name, rel(p.grad, q.grad))
+
+
+def test_embedding_cache_encodes_each_detection_once():
+    """SURVEY section 8f #1 (cache half): overlapping windows re-use the encoder outputs of the detections they share;
+    the model's outputs are those of the uncached path."""
+    from batch3dmot_amd import synth
+    from batch3dmot_amd.clr_att_gnn import EmbeddingCache
+    from batch3dmot_amd.data import Data
+    dev = torch.device("cuda:0")
+    m = _model(11, dev)
+    pool = synth.make_graph(200, 2000, graph_idx=3, modalities=True)      # a "scene": 200 detections
+    n = pool.pose_feats.size(0)
+
+    def window(lo, hi):
+        keep = (pool.edge_index[0] >= lo) & (pool.edge_index[0] < hi) & (pool.edge_index[1] >= lo) & (pool.edge_index[1] < hi)
+        w = Data(pose_feats=pool.pose_feats[lo:hi], img_feats=pool.img_feats[lo:hi], lidar_feats=pool.lidar_feats[lo:hi],
+                 radar_feats=pool.radar_feats[lo:hi], edge_index=(pool.edge_index[:, keep] - lo).contiguous(),
+                 edge_attr=pool.edge_attr[keep], node_timestamps=pool.node_timestamps[lo:hi])
+        gid = torch.arange(lo, hi) + 7000
+        w.global_node_timestamps = torch.stack([gid.float(), pool.node_timestamps[lo:hi].float()], 1)
+        return w.to(dev)
+
+    cache = EmbeddingCache(capacity=64)                                    # forces the tables to grow
+    spans = [(0, 120), (40, 160), (80, n)]
+    for lo, hi in spans:
+        w = window(lo, hi)
+        plain = m.encode_modalities(w)
+        cached = m.encode_modalities(w, cache=cache)
+        assert torch.equal(plain[2], cached[2]) and torch.equal(plain[4], cached[4])          # the same rows have LiDAR / radar
+        for a, b in ((plain[0], cached[0]), (plain[1], cached[1]), (plain[3], cached[3])):
+            assert a.shape == b.shape and rel(b, a) < 1e-5                 # batch-size dependent GEMM/conv rounding only
+        with torch.no_grad():
+            out_plain, _ = m(w, encoded=plain)
+            out_cached, _ = m(w, encoded=cached)
+        assert rel(out_cached, out_plain) < TOL
+    assert len(cache) == n and cache.misses == n and cache.hits == (120 + 120 + (n - 80)) - n
+    m.pointnet.train()
+    with pytest.raises(RuntimeError):
+        m.encode_modalities(window(0, 50), cache=cache)
