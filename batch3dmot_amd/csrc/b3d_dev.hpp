@@ -114,8 +114,8 @@ struct LayerSeq {
 
 // ---- experiment support: per-workgroup phase time stamps (off unless built with -DB3D_EXP_STAMPS) ----
 #ifdef B3D_EXP_STAMPS
-extern __device__ long long g_stamps[4][512 * 16];
-#define B3D_STAMP(k, i) do { if (threadIdx.x == 0 && blockIdx.x < 512) b3d::g_stamps[k][blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
+extern __device__ long long g_stamps[4][512 * 32];
+#define B3D_STAMP(k, i) do { if (threadIdx.x == 0 && blockIdx.x < 512) b3d::g_stamps[k][blockIdx.x * 32 + (i)] = wall_clock64(); } while (0)
 #else
 #define B3D_STAMP(k, i) do {} while (0)
 #endif

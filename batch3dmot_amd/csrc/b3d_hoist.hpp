@@ -90,7 +90,7 @@ struct EdgeFwdHArgs {
 };
 
 template <class D, int NW>
-__global__ __launch_bounds__(NW * 64, 16 / NW) void mp_edge_fwd_h_kernel(const EdgeFwdHArgs a) {
+__global__ __launch_bounds__(NW * 64, 2) void mp_edge_fwd_h_kernel(const EdgeFwdHArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   using H = Hoist<D>;
   using Seq = typename H::EdgeFwdSeq;
@@ -125,26 +125,30 @@ __global__ __launch_bounds__(NW * 64, 16 / NW) void mp_edge_fwd_h_kernel(const E
     linear_init<Seq, 0, true, false>(ws, more, ein, h1, h1);
     B3D_STAMP(2, 2);
     linear<Seq, 1, true>(ws, more, h1, h2, [&]() {
+      B3D_STAMP(2, 10);
       if (a.sH1) store_row<H1B>(a.sH1, row, D::EH1, 0, valid, h1);
       load_row_u<MHB>(a.T, d, H::TW, H::OF, fi);
+      B3D_STAMP(2, 11);
     });
     B3D_STAMP(2, 3);
     linear<Seq, 2, false>(ws, more, h2, en, [&]() {
+      B3D_STAMP(2, 12);
       if (a.sH2) store_row<H2B>(a.sH2, row, D::EH2, 0, valid, h2);
       load_row_u<MHB>(a.T, s, H::TW, H::OP, pi);
+      B3D_STAMP(2, 13);
     });
     B3D_STAMP(2, 4);
 
     v4f mo[DMB], mo2[DMB];
     wait_for(fi);
-    linear_init<Seq, 3, true, false>(ws, more, en, fi, fi, [&]() { store_row<EB>(a.e_out, row, D::DE, 0, valid, en); });
+    linear_init<Seq, 3, true, false>(ws, more, en, fi, fi, [&]() { B3D_STAMP(2, 14); store_row<EB>(a.e_out, row, D::DE, 0, valid, en); B3D_STAMP(2, 15); });
     B3D_STAMP(2, 5);
-    linear<Seq, 4, false>(ws, more, fi, mo, [&]() { if (a.sF1) store_row<MHB>(a.sF1, row, D::MH, 0, valid, fi); });
+    linear<Seq, 4, false>(ws, more, fi, mo, [&]() { B3D_STAMP(2, 16); if (a.sF1) store_row<MHB>(a.sF1, row, D::MH, 0, valid, fi); B3D_STAMP(2, 17); });
     B3D_STAMP(2, 6);
     wait_for(pi);
-    linear_init<Seq, 5, true, false>(ws, more, en, pi, pi, [&]() { store_row<DMB>(a.fut, row, D::DM, 0, valid, mo); });
+    linear_init<Seq, 5, true, false>(ws, more, en, pi, pi, [&]() { B3D_STAMP(2, 18); store_row<DMB>(a.fut, row, D::DM, 0, valid, mo); B3D_STAMP(2, 19); });
     B3D_STAMP(2, 7);
-    linear<Seq, 6, false>(ws, more, pi, mo2, [&]() { if (a.sP1) store_row<MHB>(a.sP1, row, D::MH, 0, valid, pi); });
+    linear<Seq, 6, false>(ws, more, pi, mo2, [&]() { B3D_STAMP(2, 20); if (a.sP1) store_row<MHB>(a.sP1, row, D::MH, 0, valid, pi); B3D_STAMP(2, 21); });
     B3D_STAMP(2, 8);
     store_row<DMB>(a.past, row, D::DM, 0, valid, mo2);
     B3D_STAMP(2, 9);
@@ -228,7 +232,7 @@ struct EdgeBwdHArgs {
 // Data gradient of the edge phase without the node columns of the three first layers: those are
 // contracted per NODE from the segment sums of GdH1 / GdF1 / GdP1 (node_gradproj_kernel).
 template <class D, bool MSGS, int NW>
-__global__ __launch_bounds__(NW * 64, 16 / NW) void mp_edge_bwd_h_kernel(const EdgeBwdHArgs a) {
+__global__ __launch_bounds__(NW * 64, 2) void mp_edge_bwd_h_kernel(const EdgeBwdHArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   using H = Hoist<D>;
   using Seq = typename std::conditional<MSGS, typename H::EdgeBwdSeq, typename H::EdgeBwdSeqNoMsg>::type;

@@ -13,7 +13,7 @@ using HP = Hoist<DimsP>;
 #ifndef B3D_NW_EDGE_H
 #define B3D_NW_EDGE_H 8
 #endif
-constexpr int kNWEdgeH = B3D_NW_EDGE_H;   // wavefronts per workgroup of the hoisted edge kernels (4 = two workgroups per CU: measured 1.6x slower, the LDS-DMA weight stream per CU doubles)
+constexpr int kNWEdgeH = B3D_NW_EDGE_H;   // wavefronts per workgroup of the hoisted edge kernels (4 = two independent workgroups per CU: measured the same 26 / 30 us per launch)
 
 // Hoisted first layers (b3d_hoist.hpp).  B3D_HOIST=0 selects the unsplit kernels (A/B comparisons).
 static bool hoist_enabled() {
@@ -530,9 +530,9 @@ extern "C" int b3d_pose_debug_layer_ptrs(void* workspace, size_t workspace_bytes
 }
 
 #ifdef B3D_EXP_STAMPS
-namespace b3d { __device__ long long g_stamps[4][512 * 16]; }
+namespace b3d { __device__ long long g_stamps[4][512 * 32]; }
 extern "C" int b3d_debug_stamps(long long* host_dst) {
-  return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(b3d::g_stamps), sizeof(long long) * 4 * 512 * 16) == hipSuccess ? 0 : 1;
+  return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(b3d::g_stamps), sizeof(long long) * 4 * 512 * 32) == hipSuccess ? 0 : 1;
 }
 #endif
 

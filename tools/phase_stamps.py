@@ -20,7 +20,7 @@ for it in range(5):
     (out * lw).sum().backward()
 torch.cuda.synchronize()
 lib = _lib.load()
-buf = np.zeros((4, 512, 16), dtype=np.int64)
+buf = np.zeros((4, 512, 32), dtype=np.int64)
 assert lib.b3d_debug_stamps(buf.ctypes.data_as(C.c_void_p)) == 0
 names = {0: ["start", "segsum", "L0 128>96", "L1 96>64", "L2 64>48", "proj 48>432"],
          1: ["start", "act loads", "list sums", "4 products", "L4 48>64", "L5 64>96", "L6 96>128"],
@@ -35,3 +35,10 @@ for k in (0, 1, 2, 3):
     d = np.diff(s, axis=1)
     for i, n in enumerate(names[k][1:]):
         print(f"   {n:14s} mean {d[:, i].mean():6.2f}  p50 {np.median(d[:, i]):6.2f}  max {d[:, i].max():6.2f} us")
+
+# inside the layers of edge_fwd_h: [previous layer done] -> acquire (vmcnt + barrier) -> hook -> MFMAs
+s = buf[2, :E_tiles].astype(np.float64) * 0.01
+print("edge_fwd_h, layers 1..6: acquire wait | hook issue | MFMAs (us, mean over workgroups)")
+for li, (h0, h1) in enumerate([(10, 11), (12, 13), (14, 15), (16, 17), (18, 19), (20, 21)], start=1):
+    prev, nxt = s[:, 1 + li], s[:, 2 + li]
+    print(f"   L{li}: {np.mean(s[:, h0] - prev):5.2f} | {np.mean(s[:, h1] - s[:, h0]):5.2f} | {np.mean(nxt - s[:, h1]):5.2f}")
