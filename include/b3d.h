@@ -270,6 +270,16 @@ int b3d_post_greedy(const int64_t* pairs, const float* scores, int64_t M, const 
                     const double* class_threshold, void* workspace, size_t workspace_bytes, int64_t* kept_pairs,
                     double* kept_scores, int64_t* pred, int64_t* succ, int32_t* counts, b3d_stream stream);
 
+/* ---- point-cloud feature stacks of the frozen LiDAR / radar encoders, eval mode ------------------------------
+ * (models/pointnet.py:9-57 STN3d and :111-165 PointNetfeat, models/radarnet.py:9-37 RadarNetfeat)
+ * out[b, :] = max over the P points of  L3(relu(L2(relu(L1(x'[b, :, p])))))  (+ ReLU if relu_last), where L1..L3 are
+ * the three conv1d(kernel 1) layers WITH their eval-mode BatchNorm folded in by the caller: conv[i].w [out, in]
+ * (64 x C, 128 x 64, 1024 x 128), conv[i].b [out]; x [B, C, P] float32 (C <= 4, P = 128 or 64);
+ * trans [B, 3, 3] or NULL: x'[b, :, p] = x[b, :, p]^T . trans[b]  (the bmm of pointnet.py:137).  out [B, 1024]. */
+size_t b3d_point_feat_workspace_bytes(void);
+int b3d_point_feat(const b3d_linear* conv, const float* x, const float* trans, int32_t B, int32_t C, int32_t P,
+                   int32_t relu_last, void* workspace, size_t workspace_bytes, float* out, b3d_stream stream);
+
 /* ---- average precision of the edge scores (train.py:18,143-150,188-196) -----------------------------------
  * torchmetrics.functional average_precision(out, gt, pos_label=1) of the whole batch (ap[0]) and of the edges of
  * every class c in 1..num_classes (ap[c], the reference's out[edge_classes == c]); count[s] = edges in the set

@@ -1,0 +1,88 @@
+"""``b3d_point_feat``: the point-wise conv-BN-ReLU stacks + max-pool of PointNet / RadarNet in
+eval mode against the same modules on the PyTorch path (the restatement of models/pointnet.py / radarnet.py that the
+golden CLR vectors pin, tests/test_oracle_golden.py)."""
+import pytest
+import torch
+
+from oracle.seeded import seeded_fill_
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def _randomise_bn(m, seed):
+    g = torch.Generator().manual_seed(seed)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.modules.batchnorm._BatchNorm):
+            mod.running_mean.copy_(torch.randn(mod.num_features, generator=g) * 0.1)
+            mod.running_var.copy_(torch.rand(mod.num_features, generator=g) + 0.5)
+
+
+def _clouds(b, c, p, seed, dev):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(b, c, p, generator=g)
+    npts = torch.randint(6, p + 1, (b,), generator=g)
+    x = x * (torch.arange(p)[None, None, :] < npts[:, None, None])       # zero-padded clouds, as the dataset stores them
+    return x.to(dev)
+
+
+@pytest.mark.parametrize("b", [1, 2, 7, 300, 2100])
+def test_pointnet_forward_feat(b):
+    from batch3dmot_amd import encoders
+    dev = torch.device("cuda:0")
+    m = encoders.PointNetClassifier(k=7)
+    seeded_fill_(m, 3)
+    _randomise_bn(m, 4)
+    m = m.to(dev).eval()
+    x = _clouds(b, 3, 128, 10 + b, dev)
+    with torch.no_grad():
+        got = m.forward_feat(x)
+        for mod in m.modules():
+            mod.use_hip = False
+        want = m.forward_feat(x)
+    assert got.shape == want.shape == (b, 256)
+    assert rel(got, want) < TOL
+    # the trunk alone (STN transform applied inside the kernel; no ReLU after the last layer)
+    with torch.no_grad():
+        want_feat = m.feat(x)
+        for mod in m.modules():
+            mod.use_hip = True
+        got_feat = m.feat(x)
+    assert rel(got_feat, want_feat) < TOL and float(got_feat.min()) < 0.0
+
+
+@pytest.mark.parametrize("b", [1, 3, 500])
+def test_radarnet_forward_feat(b):
+    from batch3dmot_amd import encoders
+    dev = torch.device("cuda:0")
+    m = encoders.RadarNetClassifier(k=7)
+    seeded_fill_(m, 5)
+    _randomise_bn(m, 6)
+    m = m.to(dev).eval()
+    x = _clouds(b, 4, 64, 20 + b, dev)
+    with torch.no_grad():
+        got = m.forward_feat(x)
+        for mod in m.modules():
+            mod.use_hip = False
+        want = m.forward_feat(x)
+    assert rel(got, want) < TOL
+
+
+def test_train_mode_keeps_the_batch_statistics_path_and_bad_shapes_are_rejected():
+    from batch3dmot_amd import encoders
+    dev = torch.device("cuda:0")
+    m = encoders.RadarNetClassifier(k=7).to(dev).train()
+    x = _clouds(4, 4, 64, 1, dev)
+    out = m.forward_feat(x)                                              # batch statistics: PyTorch path, no error
+    assert out.shape == (4, 256)
+    with pytest.raises(RuntimeError):
+        encoders.point_feat_hip((m.feat.conv1, m.feat.conv2, m.feat.conv3), (m.feat.bn1, m.feat.bn2, m.feat.bn3), x)
+    m.eval()
+    with pytest.raises(Exception):
+        encoders.point_feat_hip((m.feat.conv1, m.feat.conv2, m.feat.conv3), (m.feat.bn1, m.feat.bn2, m.feat.bn3),
+                                torch.zeros(2, 4, 100, device=dev))
