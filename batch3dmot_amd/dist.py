@@ -34,11 +34,12 @@ class FlatGradSync:
     def world_size(self) -> int:
         return dist.get_world_size(self.group) if dist.is_initialized() else 1
 
-    def sync(self) -> None:
-        """grad <- mean over ranks.  Call between backward() and optimizer.step()."""
+    def sync(self, force: bool = False) -> None:
+        """grad <- mean over ranks.  Call between backward() and optimizer.step().  ``force``: reduce the flat buffer
+        even if no backward has been seen to write it (the backward ran inside a replayed hipGraph)."""
         if self.world_size == 1:
             return
-        if self.flat_opt is not None and not self.flat_opt.fresh:
+        if self.flat_opt is not None and (force or not self.flat_opt.fresh):
             g = self.flat_opt.flat_grad
             if self._avg is None:
                 self._avg = dist.get_backend(self.group) == "nccl"   # RCCL averages inside the collective

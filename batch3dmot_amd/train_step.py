@@ -54,12 +54,11 @@ def fused_edge_loss(out: torch.Tensor, data, batch_size: int, loss_kind: str = "
     return loss, grad.view_as(out)
 
 
-def train_step(gnn, data, optimizer, batch_size: int = 2, loss_kind: str = "cb", logits: bool = False,
-               grad_sync: Optional[object] = None, fused_loss: Optional[bool] = None):
-    """One optimisation step; ``grad_sync`` (batch3dmot_amd.dist.FlatGradSync) averages gradients over
-    the ranks of a data-parallel job between backward and the optimizer step.  ``fused_loss``
-    (default: on when the model output lives on the GPU) takes loss and d loss/d out from
-    ``b3d_edge_loss`` and seeds ``out.backward`` with it."""
+def forward_backward(gnn, data, optimizer, batch_size: int = 2, loss_kind: str = "cb", logits: bool = False,
+                     fused_loss: Optional[bool] = None):
+    """The part of a step in front of the gradient exchange: forward, ``zero_grad``, loss, backward.  Split out so
+    that a data-parallel loop can capture it (and ``optimizer.step()``) into hipGraphs and keep only the all-reduce
+    eager between the two replays."""
     out, aux = gnn(data)
     if fused_loss is None:
         fused_loss = out.is_cuda
@@ -73,10 +72,20 @@ def train_step(gnn, data, optimizer, batch_size: int = 2, loss_kind: str = "cb",
     else:
         loss = edge_loss(out, data, batch_size, loss_kind, logits)
         loss.backward()
+    return loss.detach(), out.detach(), aux
+
+
+def train_step(gnn, data, optimizer, batch_size: int = 2, loss_kind: str = "cb", logits: bool = False,
+               grad_sync: Optional[object] = None, fused_loss: Optional[bool] = None):
+    """One optimisation step; ``grad_sync`` (batch3dmot_amd.dist.FlatGradSync) averages gradients over
+    the ranks of a data-parallel job between backward and the optimizer step.  ``fused_loss``
+    (default: on when the model output lives on the GPU) takes loss and d loss/d out from
+    ``b3d_edge_loss`` and seeds ``out.backward`` with it."""
+    loss, out, aux = forward_backward(gnn, data, optimizer, batch_size, loss_kind, logits, fused_loss)
     if grad_sync is not None:
         grad_sync.sync()
     optimizer.step()
-    return loss.detach(), out.detach(), aux
+    return loss, out, aux
 
 
 def make_optimizer(gnn, lr: float = 1e-4, weight_decay: float = 1e-4, betas=(0.9, 0.999), flat: Optional[bool] = None,

@@ -21,6 +21,8 @@ whole step): the device step takes ~1.0 ms while enqueueing it eagerly takes 0.5
 1.6 ms on a busy host, which then throttles the GPU.  Event records cannot be captured, so the kernel
 families are timed in an eager pass of the same K steps right after the timed region (`timed_region` in
 the output says which mode ran; `--no-graph` keeps everything eager and inside the timed region).
+At N > 1 the steps are enqueued eagerly (the all-reduce sits inside the step); `--split-graph` replays two graphs
+per step (forward..backward; Adam) around the eager flat all-reduce -- validated at N = 1 only, hence opt-in.
 """
 from __future__ import annotations
 
@@ -63,8 +65,11 @@ def main():
                     help="skip the k-NN + GAT block whose result the reference discards (secondary figure)")
     ap.add_argument("--side-stream", action="store_true", help="run the discarded k-NN block on the library's side stream (diagnostic)")
     ap.add_argument("--no-graph", action="store_true",
-                    help="enqueue every step eagerly (always so for N > 1); by default at N = 1 the whole training step of "
+                    help="enqueue every step eagerly (the default for N > 1, see --split-graph); by default at N = 1 the whole training step of "
                          "each of the 4 pool batches is captured into a hipGraph once and the timed region replays them")
+    ap.add_argument("--split-graph", action="store_true",
+                    help="capture forward..backward and Adam as two graphs with the gradient all-reduce eager between their replays "
+                         "(opt-in for N > 1, where the default is eager: not yet validated on a multi-GPU node; at N = 1 a testing aid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to exercise the N > 1 path on one GPU)")
     ap.add_argument("--all-ranks-on-device-0", action="store_true", help="testing aid for the N > 1 path on a 1-GPU box (with --backend gloo)")
@@ -90,7 +95,7 @@ def main():
     from batch3dmot_amd import _lib, synth
     from batch3dmot_amd.dist import FlatGradSync
     from batch3dmot_amd.pose_gnn import PoseGNN
-    from batch3dmot_amd.train_step import make_optimizer, train_step
+    from batch3dmot_amd.train_step import forward_backward, make_optimizer, train_step
 
     torch.manual_seed(5621)                      # gnn.manual_seed, pose_config.yaml:96
     model = PoseGNN().to(dev)
@@ -126,30 +131,59 @@ def main():
     #      backward, Adam).  The timed region then costs one graph launch of host time per step, so a slow or
     #      noisy host cannot throttle a ~1.1 ms device step that otherwise needs ~0.6 ms of enqueueing.  Kernel
     #      families are timed with HIP events in an eager pass of the same K steps right after the timed region
-    #      (event records cannot be captured); eager mode (--no-graph, N > 1) times them inside the timed region.
+    #      (event records cannot be captured); eager mode (--no-graph) times them inside the timed region.
+    #      --split-graph: forward..backward and Adam are two graphs, the flat gradient all-reduce between them stays eager.
     graphs = None
     graph_note = None
-    if world == 1 and not args.no_graph:
+    opt_graph = None                              # N > 1: graphs[i] = forward..backward of pool batch i, opt_graph = Adam
+    if not args.no_graph and (world == 1 or args.split_graph):
         _lib.prof_enable(False)
         try:
             graphs = []
+            if world > 1:
+                dist.barrier()                    # no collective may be pending while this rank captures
+            torch.cuda.synchronize()
             cap_stream = torch.cuda.Stream()
             cap_stream.wait_stream(torch.cuda.current_stream())
             for i in range(len(pool)):
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=cap_stream):
-                    step(i)
+                with torch.cuda.graph(g, stream=cap_stream, capture_error_mode="thread_local"):
+                    if world == 1 and not args.split_graph:
+                        step(i)
+                    else:
+                        b = pool[i]
+                        if hasattr(b, "_b3d_graph"):
+                            del b._b3d_graph
+                        forward_backward(model, b, opt, batch_size=2, loss_kind="cb", logits=True)
                 graphs.append(g)
+            if world > 1 or args.split_graph:
+                # the flat all-reduce of the gradients stays eager between the two replays of a step: no collective
+                # inside a graph, one graph launch + one RCCL enqueue + one graph launch of host time per step
+                opt_graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(opt_graph, stream=cap_stream, capture_error_mode="thread_local"):
+                    opt.step()
             torch.cuda.current_stream().wait_stream(cap_stream)
             torch.cuda.synchronize()
         except Exception as exc:                                   # capture unsupported here: eager timed region
             graphs = None
+            opt_graph = None
             graph_note = f"hipGraph capture failed ({type(exc).__name__}: {exc}); eager timed region"
             torch.cuda.synchronize()
+        if world > 1:
+            # every rank must run the same mode: a rank that fell back to eager would still match (same kernels,
+            # same collective), but say so in the output
+            ok = torch.tensor([1.0 if graphs is not None else 0.0], device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if float(ok) == 0.0 and graphs is not None:
+                graph_note = "another rank could not capture; this rank replays graphs"
 
     def timed_step(i):
         if graphs is not None:
             graphs[i % len(pool)].replay()
+            if opt_graph is not None:
+                if sync is not None:
+                    sync.sync(force=True)         # the backward ran inside a graph: Python-side freshness flags did not move
+                opt_graph.replay()
         else:
             step(i)
 
@@ -283,8 +317,10 @@ def main():
                            "parallelism": f"graph-batch sharding x{world}"},
                 "roofline": roofline, "whole_step": whole, "kernels_instrumented_warmup": kernels_warmup,
                 "host_enqueue_ms_per_step": round(1e3 * t_enqueue / args.steps, 4),
-                "timed_region": ("hipGraph replay (one captured training step per pool batch); roofline / kernels timed with HIP "
-                                 "events in an eager pass of the same K steps right after it") if graphs is not None
+                "timed_region": (("hipGraph replay (one captured training step per pool batch)" if world == 1 else
+                                  "hipGraph replay of forward..backward, eager flat RCCL all-reduce, hipGraph replay of Adam") +
+                                 "; roofline / kernels timed with HIP events in an eager pass of the same K steps right after it")
+                                if graphs is not None
                                 else ("eager" + (f" ({graph_note})" if graph_note else "")), "kernels": kernels, "cpu_baseline": cpu}
         print(json.dumps(line))
     if world > 1:

@@ -336,3 +336,59 @@ def test_training_step_captured_into_a_hip_graph_replays_exactly():
     assert int(opt_a.step_dev) == 4 and int(opt_b.step_dev) == 4
     for (n, p), (_, q) in zip(a.state_dict().items(), b.state_dict().items()):
         assert torch.equal(p, q), n
+
+
+def test_split_capture_for_data_parallel_steps_replays_exactly():
+    """bench.py at N > 1: forward..backward of every pool batch is one hipGraph, Adam another, the gradient all-reduce
+    stays eager between the two replays.  Two batches, captured back to back, replayed alternately with an eager
+    in-place operation on the flat gradient buffer in between (the all-reduce's place): same parameters as eager."""
+    import copy
+    from batch3dmot_amd.pose_gnn import PoseGNN
+    from batch3dmot_amd.train_step import forward_backward, make_optimizer, train_step
+    dev = torch.device("cuda:0")
+    torch.manual_seed(12)
+    a = PoseGNN().to(dev)
+    b = copy.deepcopy(a)
+    opt_a = make_optimizer(a, lr=1e-3, capturable=True)
+    opt_b = make_optimizer(b, lr=1e-3, capturable=True)
+    batches = [_tiny_batch(dev, 30), _tiny_batch(dev, 31)]
+
+    class Halve:                                        # stands in for FlatGradSync: an eager op on the flat gradients
+        def __init__(self, opt):
+            self.opt = opt
+        def sync(self):
+            self.opt.flat_grad.mul_(0.5)
+
+    def fresh(d):
+        if hasattr(d, "_b3d_graph"):
+            del d._b3d_graph
+
+    for k in range(5):                                  # eager reference: 1 warm-up + 4 steps
+        d = batches[k % 2]
+        fresh(d)
+        train_step(a, d, opt_a, logits=True, grad_sync=Halve(opt_a))
+    fresh(batches[0])
+    train_step(b, batches[0], opt_b, logits=True, grad_sync=Halve(opt_b))      # warm-up
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    graphs = []
+    for d in batches:
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local"):
+            fresh(d)
+            forward_backward(b, d, opt_b, logits=True)
+        graphs.append(g)
+    g_opt = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g_opt, stream=s, capture_error_mode="thread_local"):
+        opt_b.step()
+    torch.cuda.current_stream().wait_stream(s)
+    sync_b = Halve(opt_b)
+    for k in range(1, 5):
+        graphs[k % 2].replay()
+        sync_b.sync()
+        g_opt.replay()
+    torch.cuda.synchronize()
+    assert int(opt_a.step_dev) == 5 and int(opt_b.step_dev) == 5
+    for (n, p), (_, q) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert torch.equal(p, q), n
