@@ -22,12 +22,12 @@ struct PackDesc {
                      //    descriptors of the same image
 };
 
-constexpr int kPackMax = 56;      // 3.5 KB of kernel arguments: one launch packs a whole model's images
+constexpr int kPackMax = 120;     // 8.5 KB of kernel arguments (the kernarg segment is plain memory on AMD): one launch packs a whole model's images
 struct PackArgs {
   int n;
   PackDesc d[kPackMax];
 };
-static_assert(sizeof(PackArgs) <= 4096, "kernel argument block limit");
+static_assert(sizeof(PackArgs) <= 16384, "kernel argument block");
 
 int pack_images(const PackDesc* descs, int n, hipStream_t stream);
 

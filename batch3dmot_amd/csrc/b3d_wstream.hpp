@@ -24,7 +24,7 @@ namespace b3d {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-constexpr int kWsMaxJobs = 16;
+constexpr int kWsMaxJobs = 40;
 constexpr int kWsWaves = 4;            // tasks per workgroup
 
 struct WsSeg {
