@@ -203,6 +203,10 @@ class GNN(nn.Module):
         self.run_dead_knn = run_dead_knn
         self.loop_masks = loop_masks
         self.resnet, self.pointnet, self.radarnet = img_encoder, lidar_encoder, radar_encoder
+        for enc in (self.resnet, self.pointnet, self.radarnet):          # the oracle keeps the reference's operation order:
+            for mod in enc.modules():                                    # no BatchNorm folding, no HIP kernels
+                mod.use_hip = False
+                mod.fold_bn = False
         for enc in (self.resnet, self.pointnet, self.radarnet):          # :26-33
             for p in enc.parameters():
                 p.requires_grad = False

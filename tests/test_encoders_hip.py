@@ -86,3 +86,31 @@ def test_train_mode_keeps_the_batch_statistics_path_and_bad_shapes_are_rejected(
     with pytest.raises(Exception):
         encoders.point_feat_hip((m.feat.conv1, m.feat.conv2, m.feat.conv3), (m.feat.bn1, m.feat.bn2, m.feat.bn3),
                                 torch.zeros(2, 4, 100, device=dev))
+
+
+def test_folded_batchnorm_paths_equal_the_reference_operation_order():
+    """Eval mode folds BatchNorm into the conv / linear in front of it (MIOpen's inference BatchNorm is the slow part
+    of the PyTorch path); ``reference_order_`` turns folding and the HIP kernels off -- what the CPU oracle runs."""
+    import copy
+    from batch3dmot_amd import encoders
+    dev = torch.device("cuda:0")
+    for ctor, shape in ((encoders.ResNetAE, (300, 3, 32, 32)), (lambda: encoders.PointNetClassifier(k=7), (64, 3, 128)),
+                        (lambda: encoders.RadarNetClassifier(k=7), (64, 4, 64))):
+        m = ctor()
+        seeded_fill_(m, 8)
+        _randomise_bn(m, 9)
+        m = m.to(dev).eval()
+        ref = encoders.reference_order_(copy.deepcopy(m))
+        x = torch.rand(*shape, device=dev)
+        with torch.no_grad():
+            got = m.encode(x) if hasattr(m, "encode") else m.forward_feat(x)
+            want = ref.encode(x) if hasattr(ref, "encode") else ref.forward_feat(x)
+        assert rel(got, want) < 1e-5
+    # the fold cache follows in-place updates of the statistics
+    bn = m.bn1
+    with torch.no_grad():
+        a = m.forward_feat(x)
+        bn.running_var.mul_(4.0)
+        b = m.forward_feat(x)
+        want = encoders.reference_order_(copy.deepcopy(m)).forward_feat(x)
+    assert rel(b, want) < 1e-5 and rel(a, want) > 1e-3

@@ -1,0 +1,13 @@
+import os, sys, time, torch
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+from batch3dmot_amd import encoders
+dev = torch.device("cuda:0"); torch.manual_seed(0)
+m = encoders.ResNetAE().to(dev).eval()
+x = torch.rand(2000, 3, 32, 32, device=dev)
+bench = len(sys.argv) > 1
+torch.backends.cudnn.benchmark = bench
+with torch.no_grad():
+    for _ in range(5): m.encode(x)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(20): m.encode(x)
+    torch.cuda.synchronize(); print("benchmark" if bench else "default", round(1e3 * (time.perf_counter() - t0) / 20, 3), "ms")
