@@ -27,7 +27,7 @@ import torch.nn.functional as F
 def _fold(layer: nn.Module, bn: nn.Module):
     """(W', b') of eval-mode ``bn(layer(x))`` for a Linear / ConvNd ``layer``: BatchNorm with running statistics is a
     per-channel affine map.  Folding is not only fewer launches: MIOpen's inference BatchNorm takes ~0.5 ms per call
-    at these shapes on MI355X (90 % of ``ResNetAE.encode`` before folding: 4.9 ms -> see tools/enc_parts2.py).
+    at these shapes on MI355X (90 % of ``ResNetAE.encode`` before folding: 4.9 ms -> see tools/bench_resnet_encode.py).
     Cached on the BatchNorm module, keyed by the versions of everything it depends on."""
     srcs = (layer.weight, layer.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var)
     key = tuple((t.data_ptr(), t._version) for t in srcs)

@@ -1,3 +1,5 @@
+"""ResNetAE.encode on 2,000 crops (eval mode): python tools/bench_resnet_encode.py [1 = cudnn.benchmark].  Run under rocprofv3
+--kernel-trace --stats to see the split (before the BatchNorm folding: 90 % MIOpenBatchNormFwdInferSpatialEst)."""
 import os, sys, time, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from batch3dmot_amd import encoders
