@@ -270,7 +270,7 @@ def main():
                 "mp_node_bwd": e_avg * 4 * 192 + n_nodes * 4 * (128 + 48 + 48 + 160 + 208)}
         bound = {"mp_edge_fwd": "mfma", "mp_edge_bwd": "mfma", "wgrad_edge": "hbm", "mp_node_fwd": "hbm", "mp_node_bwd": "hbm"}
         # HBM bytes per launch measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of
-        # this command (profiles/r01_g_pmc_traffic.txt), FETCH_SIZE doubled as MI355X_MICROARCH.md
+        # this command (profiles/r01_j_pmc_traffic.txt), FETCH_SIZE doubled as MI355X_MICROARCH.md
         # prescribes for wide coalesced reads on gfx950.  Valid for the default workload only.
         traffic_pmc = {"wgrad_edge": 764.0e6, "mp_edge_fwd": 82.7e6, "mp_edge_bwd": 104.9e6, "mp_node_fwd": 29.4e6,
                        "mp_node_bwd": 57.3e6}
