@@ -8,8 +8,10 @@ from batch3dmot_amd.train_step import forward_backward, make_optimizer, train_st
 rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
 mode = sys.argv[1] if len(sys.argv) > 1 else "all"
 dev = torch.device("cuda:0"); torch.cuda.set_device(dev)
-if world > 1:
-    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+backend = os.environ.get("B3D_DEBUG_BACKEND", "gloo")
+if world > 1 or backend == "nccl":
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group(backend=backend, rank=rank, world_size=world, **({"device_id": dev} if backend == "nccl" else {}))
 def say(*a):
     torch.cuda.synchronize(); print(f"[rank {rank}]", *a, flush=True)
 torch.manual_seed(5621)
@@ -40,6 +42,8 @@ say("captured")
 for k in range(4):
     graphs[k % 2].replay(); say("replayed fwd/bwd", k)
     if sync is not None and "noreplaysync" not in mode:
-        sync.sync(); say("synced", k)
+        sync.sync(force=True); say("synced", k)
+    elif backend == "nccl" and world == 1:
+        dist.all_reduce(opt.flat_grad); say("nccl all_reduce (1 rank)", k)     # an eager RCCL call between the replays
     g_opt.replay(); say("replayed adam", k)
 say("OK")
