@@ -51,18 +51,25 @@ inline WgSeg seg(const float* p, const int* idx, int stride, int col0, int width
 }
 
 // Chunk geometry of a weight-gradient job.  A workgroup's time is dominated by per-tile latency,
-// not by the matrix size, so the chunk length depends on the row count only: ~128 chunks per
-// matrix, between 1 and 8 tiles of 32 rows each.
-inline int wg_rows_per_chunk(long rows, int /*nchunks*/ = 0) {
+// not by the matrix size, so the chunk length depends first on the row count: ~128 chunks per
+// matrix, between 1 and 8 tiles of 32 rows each.  Every chunk writes a whole partial matrix (NP x KP floats), so a
+// wide matrix additionally gets at least as many rows per chunk as make that slab no larger than the rows it
+// reads (NP KP / (NP + KP)): 128 for the 192 x 256 fc heads of the camera+LiDAR+radar model, where 32-row chunks
+// spent more on slabs than on inputs (0.70 -> 0.49 ms of LDS-staged weight gradients per step).
+inline int wg_rows_per_chunk(long rows, int NP, int KP) {
   long rpc = ((rows + 127) / 128 + kWgRT - 1) / kWgRT * kWgRT;
   if (rpc < kWgRT) rpc = kWgRT;
+  if (NP > 0 && KP > 0) {
+    const long bal = ((long)NP * KP / (NP + KP) + kWgRT - 1) / kWgRT * kWgRT;
+    if (bal > rpc) rpc = bal;
+  }
   if (rpc > 8 * kWgRT) rpc = 8 * kWgRT;
   if (const char* ev = getenv("B3D_WG_RPC")) { long v = atol(ev); if (v >= kWgRT && rows > 4096) rpc = v / kWgRT * kWgRT; }
   return (int)rpc;
 }
-inline int wg_nchunks(long rows, int /*NP*/, int /*KP*/, long /*launch_weight*/) {
+inline int wg_nchunks(long rows, int NP, int KP, long /*launch_weight*/) {
   if (rows <= 0) return 1;
-  const int rpc = wg_rows_per_chunk(rows);
+  const int rpc = wg_rows_per_chunk(rows, NP, KP);
   return (int)((rows + rpc - 1) / rpc);
 }
 inline size_t wg_slab_floats(int nchunks, int NP, int KP) { return (size_t)nchunks * ((size_t)NP * KP + NP); }
@@ -119,7 +126,7 @@ inline WgJob make_job(LinSlab& ls, long rows, const WgSeg& g) {
   j.NP = ls.NP; j.KP = ls.KP;
   j.rows = (int)rows;
   j.nchunks = ls.nchunks;
-  j.rows_per_chunk = wg_rows_per_chunk(rows, ls.nchunks);
+  j.rows_per_chunk = wg_rows_per_chunk(rows, ls.NP, ls.KP);
   j.slab = ls.slab;
   j.accumulate = ls.used ? 1 : 0;
   ls.used = true;
