@@ -167,6 +167,9 @@ def load() -> C.CDLL:
                                           C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.b3d_point_feat_workspace_bytes.restype = C.c_size_t
     lib.b3d_point_feat_workspace_bytes.argtypes = []
+    lib.b3d_point_feat_stats.restype = C.c_int
+    lib.b3d_point_feat_stats.argtypes = [C.POINTER(b3d_linear), C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                         C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.b3d_point_feat.restype = C.c_int
     lib.b3d_point_feat.argtypes = [C.POINTER(b3d_linear), C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                    C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]

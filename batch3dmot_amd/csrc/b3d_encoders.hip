@@ -27,12 +27,23 @@ struct PointFeatArgs {
   const float* trans;   // [B, 3, 3] or nullptr
   int B, C, relu_last;
   float* out;           // [B, 1024]
+  float* out_min;       // STATS only: per-cloud minimum, sum and sum of squares of the last layer's output
+  float* out_sum;
+  float* out_sq;
   const float* wpack;   // PointSeq images
 };
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <class Op>
+__device__ __forceinline__ float row_reduce16(float v, Op op) {
+  v = op(v, dpp_f<0x128>(v));
+  v = op(v, dpp_f<0x124>(v));
+  v = op(v, dpp_f<0x122>(v));
+  v = op(v, dpp_f<0x121>(v));
+  return v;
 }
 // maximum over the 16 lanes of a DPP row (= the 16 points of a tile that share feature piece q); every lane gets it
 __device__ __forceinline__ float row_max16(float v) {
@@ -43,7 +54,14 @@ __device__ __forceinline__ float row_max16(float v) {
   return v;
 }
 
-template <int P>
+// STATS (train mode: the last BatchNorm uses the statistics of THIS batch, so it cannot be folded before its input
+// exists): the last layer is evaluated raw (conv bias only) and every cloud's per-feature maximum, minimum, sum and
+// sum of squares over its points are written; the caller derives mean / variance per feature from the sums and
+// applies the now-known affine map to the maximum (positive scale) or the minimum (negative scale) -- the [points,
+// 1024] activation is never stored.  Per weight chunk the 8 tile partials meet in a double-buffered LDS area and are
+// combined behind the NEXT chunk's barrier (no extra barrier per chunk).
+constexpr int kStatChunkFeat = 96;                              // features of one weight chunk of the 128 -> 1024 layer
+template <int P, bool STATS>
 __global__ __launch_bounds__(512, 1) void point_feat_kernel(const PointFeatArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int TPC = P / 16, CPW = 8 / TPC;                   // tiles per cloud, clouds per workgroup
@@ -78,6 +96,53 @@ __global__ __launch_bounds__(512, 1) void point_feat_kernel(const PointFeatArgs 
     v4f h1[4], h2[8];
     linear<PointSeq, 0, true>(ws, more, in, h1);
     linear<PointSeq, 1, true>(ws, more, h1, h2);
+    if constexpr (STATS) {
+      // xpart as [2 parities][4 quantities][8 wavefronts][96 features]
+      constexpr int CB = kStatChunkFeat / 16;                  // output blocks per weight chunk
+      static_assert(chunk_rows(128, 1024) == kStatChunkFeat, "chunk geometry of the 128 -> 1024 layer");
+      auto fmax_ = [](float x, float y) { return fmaxf(x, y); };
+      auto fmin_ = [](float x, float y) { return fminf(x, y); };
+      auto fadd_ = [](float x, float y) { return x + y; };
+      auto combine = [&](int chunk) {                          // all wavefronts: tile partials of `chunk` -> global
+        const float* buf = xpart + (chunk & 1) * 4 * 8 * kStatChunkFeat;
+        const int nfeat = min(kStatChunkFeat, kPointFeat - chunk * kStatChunkFeat);
+        for (int f = threadIdx.x; f < CPW * nfeat; f += 512) {
+          const int cl = f / nfeat, feat = f - cl * nfeat;
+          const float* src = buf + (cl * TPC) * kStatChunkFeat + feat;
+          float vmax = src[0], vmin = src[8 * kStatChunkFeat], vsum = src[16 * kStatChunkFeat], vsq = src[24 * kStatChunkFeat];
+#pragma unroll
+          for (int t = 1; t < TPC; ++t) {
+            vmax = fmaxf(vmax, src[t * kStatChunkFeat]);
+            vmin = fminf(vmin, src[(8 + t) * kStatChunkFeat]);
+            vsum += src[(16 + t) * kStatChunkFeat];
+            vsq += src[(24 + t) * kStatChunkFeat];
+          }
+          const int c = g * CPW + cl;
+          if (c < a.B) {
+            const long o = (long)c * kPointFeat + chunk * kStatChunkFeat + feat;
+            a.out[o] = vmax; a.out_min[o] = vmin; a.out_sum[o] = vsum; a.out_sq[o] = vsq;
+          }
+        }
+      };
+      linear_emit<PointSeq, 2, false>(ws, more, h2, [&](int mb, v4f v) {
+        const int chunk = mb / CB, lb = mb - chunk * CB;
+        if (lb == 0 && chunk > 0) combine(chunk - 1);          // behind this chunk's barrier: every tile partial is there
+        float* buf = xpart + (chunk & 1) * 4 * 8 * kStatChunkFeat + wave * kStatChunkFeat + lb * 16 + 4 * q;
+        v4f t;
+        t.x = row_reduce16(v.x, fmax_); t.y = row_reduce16(v.y, fmax_); t.z = row_reduce16(v.z, fmax_); t.w = row_reduce16(v.w, fmax_);
+        if (m == 0) *reinterpret_cast<v4f*>(buf) = t;
+        t.x = row_reduce16(v.x, fmin_); t.y = row_reduce16(v.y, fmin_); t.z = row_reduce16(v.z, fmin_); t.w = row_reduce16(v.w, fmin_);
+        if (m == 0) *reinterpret_cast<v4f*>(buf + 8 * kStatChunkFeat) = t;
+        t.x = row_reduce16(v.x, fadd_); t.y = row_reduce16(v.y, fadd_); t.z = row_reduce16(v.z, fadd_); t.w = row_reduce16(v.w, fadd_);
+        if (m == 0) *reinterpret_cast<v4f*>(buf + 16 * kStatChunkFeat) = t;
+        t.x = row_reduce16(v.x * v.x, fadd_); t.y = row_reduce16(v.y * v.y, fadd_); t.z = row_reduce16(v.z * v.z, fadd_);
+        t.w = row_reduce16(v.w * v.w, fadd_);
+        if (m == 0) *reinterpret_cast<v4f*>(buf + 24 * kStatChunkFeat) = t;
+      });
+      __syncthreads();
+      combine((kPointFeat + kStatChunkFeat - 1) / kStatChunkFeat - 1);
+      continue;                                                // next group: its first xpart write is 3 barriers away
+    }
     float* mine = xpart + wave * kPointFeat;
     linear_emit<PointSeq, 2, false>(ws, more, h2, [&](int mb, v4f v) {
       v.x = row_max16(v.x); v.y = row_max16(v.y); v.z = row_max16(v.z); v.w = row_max16(v.w);
@@ -105,9 +170,27 @@ using namespace b3d;
 
 extern "C" size_t b3d_point_feat_workspace_bytes(void) { return (size_t)PointSeq::TOTAL_FLOATS * sizeof(float) + 256; }
 
+static int point_feat_launch(const b3d_linear* conv, const float* x, const float* trans, int32_t B, int32_t C, int32_t P,
+                             int32_t relu_last, void* workspace, size_t workspace_bytes, float* out, float* out_min,
+                             float* out_sum, float* out_sq, hipStream_t stream);
+
 extern "C" int b3d_point_feat(const b3d_linear* conv, const float* x, const float* trans, int32_t B, int32_t C, int32_t P,
                               int32_t relu_last, void* workspace, size_t workspace_bytes, float* out, b3d_stream stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+  return point_feat_launch(conv, x, trans, B, C, P, relu_last, workspace, workspace_bytes, out, nullptr, nullptr, nullptr,
+                           (hipStream_t)stream_);
+}
+
+extern "C" int b3d_point_feat_stats(const b3d_linear* conv, const float* x, const float* trans, int32_t B, int32_t C, int32_t P,
+                                    void* workspace, size_t workspace_bytes, float* out_max, float* out_min, float* out_sum,
+                                    float* out_sq, b3d_stream stream_) {
+  B3D_REQUIRE(B == 0 || (out_min && out_sum && out_sq), "b3d_point_feat_stats: null output");
+  return point_feat_launch(conv, x, trans, B, C, P, 0, workspace, workspace_bytes, out_max, out_min, out_sum, out_sq,
+                           (hipStream_t)stream_);
+}
+
+static int point_feat_launch(const b3d_linear* conv, const float* x, const float* trans, int32_t B, int32_t C, int32_t P,
+                             int32_t relu_last, void* workspace, size_t workspace_bytes, float* out, float* out_min,
+                             float* out_sum, float* out_sq, hipStream_t stream) {
   B3D_REQUIRE(conv && workspace && (B == 0 || (x && out)), "b3d_point_feat: null argument");
   B3D_REQUIRE(conv[0].w && conv[1].w && conv[2].w && conv[0].b && conv[1].b && conv[2].b, "b3d_point_feat: null layer");
   B3D_REQUIRE(B >= 0 && C >= 1 && C <= 4 && (P == 64 || P == 128), "b3d_point_feat: B %d, C %d, P %d (C <= 4, P 64 or 128)", B, C, P);
@@ -122,15 +205,20 @@ extern "C" int b3d_point_feat(const b3d_linear* conv, const float* x, const floa
   B3D_TRY(pack_images(d, 3, stream));
   PointFeatArgs a;
   a.x = x; a.trans = trans; a.B = B; a.C = C; a.relu_last = relu_last; a.out = out; a.wpack = wp;
+  a.out_min = out_min; a.out_sum = out_sum; a.out_sq = out_sq;
+  const bool stats = out_min != nullptr;
   const int cpw = P == 128 ? 1 : 2;
   int groups = (B + cpw - 1) / cpw;
   if (groups > 1024) groups = 1024;                            // persistent: <= 4 groups per CU in flight order
-  if (P == 128) {
-    B3D_TRY(set_lds(point_feat_kernel<128>, kPointLds));
-    hipLaunchKernelGGL(point_feat_kernel<128>, dim3(groups), dim3(512), kPointLds, stream, a);
-  } else {
-    B3D_TRY(set_lds(point_feat_kernel<64>, kPointLds));
-    hipLaunchKernelGGL(point_feat_kernel<64>, dim3(groups), dim3(512), kPointLds, stream, a);
-  }
+#define B3D_POINT_LAUNCH(PP, ST)                                                                      \
+  do {                                                                                                \
+    B3D_TRY(set_lds(point_feat_kernel<PP, ST>, kPointLds));                                           \
+    hipLaunchKernelGGL((point_feat_kernel<PP, ST>), dim3(groups), dim3(512), kPointLds, stream, a);   \
+  } while (0)
+  if (P == 128 && stats) B3D_POINT_LAUNCH(128, true);
+  else if (P == 128) B3D_POINT_LAUNCH(128, false);
+  else if (stats) B3D_POINT_LAUNCH(64, true);
+  else B3D_POINT_LAUNCH(64, false);
+#undef B3D_POINT_LAUNCH
   return launch_check("point_feat_kernel");
 }

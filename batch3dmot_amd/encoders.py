@@ -96,8 +96,75 @@ def point_feat_hip(convs, bns, x: torch.Tensor, trans=None, relu_last: bool = Fa
     return out
 
 
+def _bn_batch_stats_(bn: nn.BatchNorm1d, mean: torch.Tensor, var_biased: torch.Tensor, count: int):
+    """What a train-mode BatchNorm forward does besides normalising: the running-statistics update
+    (torch.nn.modules.batchnorm: unbiased variance, momentum, num_batches_tracked)."""
+    if not bn.track_running_stats or bn.running_mean is None:
+        return
+    bn.num_batches_tracked += 1
+    mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+    unbiased = var_biased * (count / max(count - 1, 1))
+    bn.running_mean.mul_(1.0 - mom).add_(mean.to(bn.running_mean.dtype), alpha=mom)
+    bn.running_var.mul_(1.0 - mom).add_(unbiased.to(bn.running_var.dtype), alpha=mom)
+
+
+def point_feat_train_hip(convs, bns, x: torch.Tensor, trans=None, relu_last: bool = False) -> torch.Tensor:
+    """Train-mode (batch-statistics BatchNorm) form of ``point_feat_hip``.  The first two layers are narrow: their
+    pre-activations and statistics come from PyTorch ops (0.1 % / 6 % of the stack's arithmetic); the 128 -> 1024
+    layer -- 94 % -- runs in ``b3d_point_feat_stats``, which never stores its [points, 1024] output: per cloud it
+    returns max / min / sum / sum of squares per feature, enough for the batch statistics and for
+    max_p BN(z) = scale * (max_p z if scale > 0 else min_p z) + shift.  Running statistics are updated as
+    ``nn.BatchNorm1d`` would."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    x = x.float().contiguous()
+    _lib.require_cuda(x, "point cloud", torch.float32)
+    b, c, p = x.shape
+    n = b * p
+    with torch.no_grad():
+        xin = torch.bmm(x.transpose(2, 1), trans).transpose(2, 1) if trans is not None else x
+        folded = []
+        h = xin
+        for cv, bn in zip(convs[:2], bns[:2]):
+            z = F.conv1d(h, cv.weight, cv.bias)
+            var, mean = torch.var_mean(z, dim=(0, 2), unbiased=False)
+            _bn_batch_stats_(bn, mean, var, n)
+            scale = bn.weight / torch.sqrt(var + bn.eps)
+            shift = bn.bias - mean * scale
+            folded.append(((cv.weight.squeeze(-1) * scale[:, None]).float().contiguous(),
+                           (cv.bias * scale + shift).float().contiguous()))
+            h = torch.relu(z * scale[None, :, None] + shift[None, :, None])
+        folded.append((convs[2].weight.squeeze(-1).float().contiguous(), convs[2].bias.float().contiguous()))
+        layers = (_lib.b3d_linear * 3)()
+        for i, (w, bias) in enumerate(folded):
+            layers[i].w, layers[i].b = w.data_ptr(), bias.data_ptr()
+        outs = torch.empty(4, b, 1024, dtype=torch.float32, device=x.device)
+        nbytes = lib.b3d_point_feat_workspace_bytes()
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        t = trans.float().contiguous() if trans is not None else None
+        _lib.check(lib.b3d_point_feat_stats(layers, x.data_ptr(), t.data_ptr() if t is not None else None, b, c, p,
+                                            ws.data_ptr(), nbytes, outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(),
+                                            outs[3].data_ptr(), _lib.current_stream(x.device)), "b3d_point_feat_stats")
+        bn3 = bns[2]
+        mean = outs[2].double().sum(0) / n
+        var = (outs[3].double().sum(0) / n - mean * mean).clamp_min(0.0)
+        _bn_batch_stats_(bn3, mean.float(), var.float(), n)
+        scale = bn3.weight.double() / torch.sqrt(var + bn3.eps)
+        shift = bn3.bias.double() - mean * scale
+        ext = torch.where(scale[None, :] > 0, outs[0].double(), outs[1].double())
+        y = (ext * scale[None, :] + shift[None, :]).float()
+        return torch.relu(y) if relu_last else y
+
+
 def _use_hip(module: nn.Module, x: torch.Tensor) -> bool:
     return x.is_cuda and not module.training and getattr(module, "use_hip", True)
+
+
+def _use_hip_train(module: nn.Module, x: torch.Tensor) -> bool:
+    """Train mode with frozen parameters (how the GNN holds its encoders, clr_att_gnn.py:26-33): no autograd needed."""
+    return (x.is_cuda and module.training and getattr(module, "use_hip", True) and x.size(0) * x.size(2) > 1
+            and not any(p.requires_grad for p in module.parameters()) and not x.requires_grad)
 
 
 def reference_order_(module: nn.Module) -> nn.Module:
@@ -170,6 +237,8 @@ class _STN3d(nn.Module):
         b = x.size(0)
         if _use_hip(self, x) and b > 0:
             x = point_feat_hip((self.conv1, self.conv2, self.conv3), (self.bn1, self.bn2, self.bn3), x, relu_last=True)
+        elif _use_hip_train(self, x):
+            x = point_feat_train_hip((self.conv1, self.conv2, self.conv3), (self.bn1, self.bn2, self.bn3), x, relu_last=True)
         else:
             x = F.relu(self.bn1(self.conv1(x)))
             x = F.relu(self.bn2(self.conv2(x)))
@@ -193,6 +262,8 @@ class _PointNetFeat(nn.Module):
         trans = self.stn(x)
         if _use_hip(self, x) and x.size(0) > 0:          # the bmm is applied while the kernel loads the points
             return point_feat_hip((self.conv1, self.conv2, self.conv3), (self.bn1, self.bn2, self.bn3), x, trans=trans)
+        if _use_hip_train(self, x):
+            return point_feat_train_hip((self.conv1, self.conv2, self.conv3), (self.bn1, self.bn2, self.bn3), x, trans=trans)
         x = torch.bmm(x.transpose(2, 1), trans).transpose(2, 1)
         x = F.relu(self.bn1(self.conv1(x)))
         x = F.relu(self.bn2(self.conv2(x)))
@@ -227,6 +298,8 @@ class _RadarNetFeat(nn.Module):
     def forward(self, x):
         if _use_hip(self, x) and x.size(0) > 0:
             return point_feat_hip((self.conv1, self.conv2, self.conv3), (self.bn1, self.bn2, self.bn3), x)
+        if _use_hip_train(self, x):
+            return point_feat_train_hip((self.conv1, self.conv2, self.conv3), (self.bn1, self.bn2, self.bn3), x)
         x = F.relu(self.bn1(self.conv1(x)))
         x = F.relu(self.bn2(self.conv2(x)))
         x = self.bn3(self.conv3(x))

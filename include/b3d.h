@@ -277,6 +277,13 @@ int b3d_post_greedy(const int64_t* pairs, const float* scores, int64_t M, const 
  * (64 x C, 128 x 64, 1024 x 128), conv[i].b [out]; x [B, C, P] float32 (C <= 4, P = 128 or 64);
  * trans [B, 3, 3] or NULL: x'[b, :, p] = x[b, :, p]^T . trans[b]  (the bmm of pointnet.py:137).  out [B, 1024]. */
 size_t b3d_point_feat_workspace_bytes(void);
+/* Train-mode form (BatchNorm with the statistics of this batch): conv[0], conv[1] carry their BatchNorm folded with
+ * the batch statistics the caller has computed for them, conv[2] is the raw last conv; per cloud and feature the
+ * maximum, minimum, sum and sum of squares of conv[2]'s output over the points are returned ([B, 1024] each), from
+ * which the caller forms the last BatchNorm's statistics and applies it to the maximum (scale > 0) or minimum. */
+int b3d_point_feat_stats(const b3d_linear* conv, const float* x, const float* trans, int32_t B, int32_t C, int32_t P,
+                         void* workspace, size_t workspace_bytes, float* out_max, float* out_min, float* out_sum,
+                         float* out_sq, b3d_stream stream);
 int b3d_point_feat(const b3d_linear* conv, const float* x, const float* trans, int32_t B, int32_t C, int32_t P,
                    int32_t relu_last, void* workspace, size_t workspace_bytes, float* out, b3d_stream stream);
 

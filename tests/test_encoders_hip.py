@@ -114,3 +114,40 @@ def test_folded_batchnorm_paths_equal_the_reference_operation_order():
         b = m.forward_feat(x)
         want = encoders.reference_order_(copy.deepcopy(m)).forward_feat(x)
     assert rel(b, want) < 1e-5 and rel(a, want) > 1e-3
+
+
+@pytest.mark.parametrize("kind,b", [("pointnet", 300), ("pointnet", 3), ("radarnet", 200), ("radarnet", 5)])
+def test_train_mode_with_frozen_parameters_uses_batch_statistics(kind, b):
+    """How the GNN holds its encoders during training (clr_att_gnn.py:26-33: frozen, but in train mode): BatchNorm
+    normalises with the statistics of the batch and updates its running statistics.  HIP path (last layer's
+    statistics from per-cloud sums, max / min selected by the sign of the scale) against the PyTorch modules."""
+    import copy
+    from batch3dmot_amd import encoders
+    dev = torch.device("cuda:0")
+    m = encoders.PointNetClassifier(k=7) if kind == "pointnet" else encoders.RadarNetClassifier(k=7)
+    seeded_fill_(m, 13)
+    _randomise_bn(m, 14)
+    with torch.no_grad():                                   # negative BatchNorm scales exercise the min branch
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm1d):
+                mod.weight.mul_(torch.where(torch.arange(mod.num_features) % 3 == 0, -1.0, 1.0))
+    for p in m.parameters():
+        p.requires_grad = False
+    m = m.to(dev).train()
+    ref = copy.deepcopy(m)
+    for mod in ref.modules():
+        mod.use_hip = False
+    x = _clouds(b, 3 if kind == "pointnet" else 4, 128 if kind == "pointnet" else 64, 40 + b, dev)
+    if b < 16:
+        # BatchNorm1d over a handful of rows in the fc heads is ill-conditioned (it amplifies 1e-6 input differences
+        # by 1 / std of 3 samples): compare the point stack alone
+        got, want = m.feat(x), ref.feat(x)
+    else:
+        torch.manual_seed(0); got = m.forward_feat(x)       # same dropout mask on both paths
+        torch.manual_seed(0); want = ref.forward_feat(x)
+    assert rel(got, want) < TOL
+    for (n1, b1), (_, b2) in zip(m.feat.named_buffers(), ref.feat.named_buffers()):
+        if b1.dtype.is_floating_point:
+            assert rel(b1, b2) < TOL, n1
+        else:
+            assert torch.equal(b1, b2), n1                  # num_batches_tracked
