@@ -17,6 +17,7 @@
 //
 // No CUDA compatibility layer, no multi-backend dispatch: this file only builds for gfx950.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <utility>
@@ -194,6 +195,114 @@ struct WStreamT {
     const float* cur = lds + slot * SLOT;
     slot ^= 1;
     return cur;
+  }
+};
+
+// ---- grouped weight stream: consecutive chunks that fit one slot together travel under ONE barrier ----------
+// A Linear of the hoisted edge stacks is 9-25 KB of weights and 32-96 MFMAs per wavefront: with one barrier per
+// layer a tile spends about as long in barriers (~0.7 us each: drain, rendezvous, first LDS fragment) as in some of
+// its layers.  Chunks are grouped greedily in sequence order up to GSLOT floats; the group leader's acquire waits,
+// synchronises and prefetches the next group, the other chunks of the group only compute their address.
+template <class Seq, int GSLOT, int FIRST = GSLOT>
+struct ChunkGroups {                                          // FIRST: cap of the first group (a short one starts the MFMAs early)
+  __host__ __device__ static constexpr int leader(int ci) {
+    int lead = 0, acc = 0;
+    for (int c = 0; c <= ci; ++c) {
+      const int sz = Seq::chunk_size(c);
+      if (c == 0 || acc + sz > (lead == 0 ? FIRST : GSLOT)) { lead = c; acc = sz; } else acc += sz;
+    }
+    return lead;
+  }
+  __host__ __device__ static constexpr int next_leader(int ci) {     // first chunk of the following group (NCH: none)
+    int c = ci + 1;
+    while (c < Seq::NCH && leader(c) != c) ++c;
+    return c;
+  }
+  __host__ __device__ static constexpr int group_floats(int lead) {
+    const int nl = next_leader(lead);
+    return (nl < Seq::NCH ? Seq::chunk_off(nl) : Seq::TOTAL_FLOATS) - Seq::chunk_off(lead);
+  }
+  __host__ __device__ static constexpr int group_index(int ci) {
+    int k = 0;
+    for (int c = 1; c <= ci; ++c) k += (leader(c) == c) ? 1 : 0;
+    return k;
+  }
+};
+
+// RESIDENT (the whole sequence fits LDS next to nothing else): the image sits in LDS at its global offsets and is
+// loaded ONCE per workgroup, in front of the first layer (under the tile's gather prologue); one barrier per
+// kernel, none between layers, and later tiles of the workgroup find everything in place.
+// Otherwise: a two-slot ring of GSLOT floats, one group per slot.
+constexpr int kResidentMaxFloats = 35 * 1024;                 // 140 KB of the CU's 160 KB
+template <class Seq>
+__host__ __device__ constexpr bool stream_resident() { return Seq::TOTAL_FLOATS <= kResidentMaxFloats; }
+template <class Seq>
+__host__ __device__ constexpr int stream_lds_bytes() { return (stream_resident<Seq>() ? Seq::TOTAL_FLOATS : 2 * kWBufFloats) * 4; }
+
+template <int NT, class SeqT>
+struct WStreamG {
+  static constexpr bool RESIDENT = stream_resident<SeqT>();
+  static constexpr int GSLOT = RESIDENT ? SeqT::TOTAL_FLOATS : kWBufFloats;
+  // One group when resident: a short first group (MFMAs start earlier, the rest streams underneath) was measured
+  // SLOWER, 27.9 vs 24.5 us -- while any LDS-DMA is pending hipcc drains vmcnt(0) at every use of a load result.
+  static constexpr int FIRST = GSLOT;
+  using G = ChunkGroups<SeqT, GSLOT, FIRST>;
+  const float* g;
+  float* lds;
+  const float* base;   // start of the group being consumed
+  int slot;            // ring form: slot that the next leader acquire returns
+  int loaded;          // resident form: groups already in place
+
+  __device__ __forceinline__ void init(const float* gw, float* l) { g = gw; lds = l; slot = 0; base = l; loaded = 0; }
+
+  template <int LEAD>
+  __device__ __forceinline__ void issue(float* dst) {
+    constexpr int off = SeqT::chunk_off(LEAD);
+    constexpr int n4 = G::group_floats(LEAD) / 4;
+    static_assert(G::group_floats(LEAD) <= GSLOT && n4 % 64 == 0, "group larger than a slot");
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float* src = g + off;
+#pragma unroll
+    for (int i0 = 0; i0 < n4; i0 += NT) {
+      const int b = i0 + wave * 64;
+      if (b < n4) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)(b + lane) * 4),
+                                         (__attribute__((address_space(3))) void*)(dst + (size_t)b * 4), 16, 0, 0);
+      }
+    }
+  }
+  template <class Seq>
+  __device__ __forceinline__ void start() {
+    static_assert(std::is_same<Seq, SeqT>::value, "stream bound to another sequence");
+    issue<0>(lds);
+  }
+
+  template <class Seq, int CI>
+  __device__ __forceinline__ const float* acquire(bool more) {
+    static_assert(std::is_same<Seq, SeqT>::value, "stream bound to another sequence");
+    constexpr int LEAD = G::leader(CI);
+    if constexpr (LEAD != CI) {
+      constexpr int OFF = SeqT::chunk_off(CI) - SeqT::chunk_off(LEAD);    // forced constant: the offset functions loop
+      return base + OFF;
+    } else if constexpr (RESIDENT) {
+      constexpr int K = G::group_index(CI), NXT = G::next_leader(CI), OFF = SeqT::chunk_off(CI);
+      if (loaded <= K) {                                       // wave-uniform; false on every tile after the first
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if constexpr (NXT < SeqT::NCH) issue<NXT>(lds + SeqT::chunk_off(NXT));
+        loaded = K + 1;
+      }
+      base = lds + OFF;
+      return base;
+    } else {
+      constexpr int NXT = G::next_leader(CI) % SeqT::NCH;     // NCH -> 0: the next tile's first group
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (NXT != 0 || more) issue<NXT>(lds + (slot ^ 1) * GSLOT);
+      base = lds + slot * GSLOT;
+      slot ^= 1;
+      return base;
+    }
   }
 };
 

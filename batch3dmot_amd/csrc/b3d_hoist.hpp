@@ -97,7 +97,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mp_edge_fwd_h_kernel(const EdgeFwd
   constexpr int EB = D::DE / 16, AB = D::DA / 16;
   constexpr int H1B = D::EH1 / 16, H2B = D::EH2 / 16, MHB = D::MH / 16, DMB = D::DM / 16;
   B3D_STAMP(2, 0);
-  WStreamT<NW * 64, Seq::max_chunk()> ws;     // hoisted stacks: every chunk is <= 26 KB, the ring takes 52 KB
+  WStreamG<NW * 64, Seq> ws;                  // hoisted stacks: 126 KB of weights, resident in LDS
   ws.init(a.wpack, smem);
   ws.template start<Seq>();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mp_edge_bwd_h_kernel(const EdgeBwd
   constexpr int L0 = MSGS ? 4 : 0;
   constexpr int EB = D::DE / 16, AB = D::DA / 16;
   constexpr int H1B = D::EH1 / 16, H2B = D::EH2 / 16, MHB = D::MH / 16, DMB = D::DM / 16;
-  WStreamT<NW * 64, Seq::max_chunk()> ws;     // hoisted stacks: every chunk is <= 26 KB, the ring takes 52 KB
+  WStreamG<NW * 64, Seq> ws;                  // resident weights (128 KB) or a two-slot ring
   ws.init(a.wpack, smem);
   ws.template start<Seq>();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;

@@ -613,7 +613,7 @@ extern "C" int b3d_pose_forward(const b3d_pose_weights* pw, const b3d_graph* g, 
       ea.e_out = w.e[l + 1]; ea.fut = w.fut; ea.past = w.past;
       ea.sH1 = w.sH1[l]; ea.sH2 = w.sH2[l]; ea.sF1 = w.sF1[l]; ea.sP1 = w.sP1[l];
       ea.wpack = w.wp_efwd_h;
-      B3D_TRY(launch_rows<kNWEdgeH>(mp_edge_fwd_h_kernel<D, kNWEdgeH>, "mp_edge_fwd", ea, E, stream, B3D_K_EDGE_FWD, 2 * HP::EdgeFwdSeq::max_chunk() * 4));
+            B3D_TRY(launch_rows<kNWEdgeH>(mp_edge_fwd_h_kernel<D, kNWEdgeH>, "mp_edge_fwd", ea, E, stream, B3D_K_EDGE_FWD, stream_lds_bytes<HP::EdgeFwdSeq>()));
     } else {
     EdgeFwdArgs ea;
     memset(&ea, 0, sizeof(ea));
@@ -750,10 +750,10 @@ extern "C" int b3d_pose_backward(const b3d_pose_weights* pw, const b3d_graph* g,
       eb.GdF1 = w.GdF1 + l * eLm; eb.GdP1 = w.GdP1 + l * eLm;
       if (msgs) {
         eb.wpack = w.wp_ebwd_h;
-        B3D_TRY(launch_rows<kNWEdgeH>(mp_edge_bwd_h_kernel<D, true, kNWEdgeH>, "mp_edge_bwd", eb, E, stream, B3D_K_EDGE_BWD, 2 * HP::EdgeBwdSeq::max_chunk() * 4));
+        B3D_TRY(launch_rows<kNWEdgeH>(mp_edge_bwd_h_kernel<D, true, kNWEdgeH>, "mp_edge_bwd", eb, E, stream, B3D_K_EDGE_BWD, stream_lds_bytes<HP::EdgeBwdSeq>()));
       } else {
         eb.wpack = w.wp_ebwd_nm_h;
-        B3D_TRY(launch_rows<kNWEdgeH>(mp_edge_bwd_h_kernel<D, false, kNWEdgeH>, "mp_edge_bwd_last", eb, E, stream, B3D_K_OTHER, 2 * HP::EdgeBwdSeqNoMsg::max_chunk() * 4));
+        B3D_TRY(launch_rows<kNWEdgeH>(mp_edge_bwd_h_kernel<D, false, kNWEdgeH>, "mp_edge_bwd_last", eb, E, stream, B3D_K_OTHER, stream_lds_bytes<HP::EdgeBwdSeqNoMsg>()));
       }
     } else {
     EdgeBwdArgs eb;
