@@ -217,7 +217,7 @@ template <class Seq, unsigned RELU_MASK, class In, class Out, int NW>
 __global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void chain_fwd_kernel(const ChainFwdArgs<In, Out> a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   static_assert(In::NB == Seq::kp(0) / 16, "loader width != first layer input width");
-  WStreamT<NW * 64, Seq::SLOT> ws;
+  WStreamG<NW * 64, Seq, Seq::SLOT, 2 * Seq::SLOT> ws;       // narrow stacks: the whole image usually fits where the ring was
   ws.init(a.wpack, smem);
   ws.template start<Seq>();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -273,7 +273,7 @@ template <class SeqT, class In, class Out, int NW>
 __global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void chain_bwd_kernel(const ChainBwdArgs<In, Out> a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   static_assert(In::NB == SeqT::kp(0) / 16, "loader width != top gradient width");
-  WStreamT<NW * 64, SeqT::SLOT> ws;
+  WStreamG<NW * 64, SeqT, SeqT::SLOT, 2 * SeqT::SLOT> ws;
   ws.init(a.wpack, smem);
   ws.template start<SeqT>();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;

@@ -234,15 +234,14 @@ struct ChunkGroups {                                          // FIRST: cap of t
 // kernel, none between layers, and later tiles of the workgroup find everything in place.
 // Otherwise: a two-slot ring of GSLOT floats, one group per slot.
 constexpr int kResidentMaxFloats = 35 * 1024;                 // 140 KB of the CU's 160 KB
-template <class Seq>
-__host__ __device__ constexpr bool stream_resident() { return Seq::TOTAL_FLOATS <= kResidentMaxFloats; }
-template <class Seq>
-__host__ __device__ constexpr int stream_lds_bytes() { return (stream_resident<Seq>() ? Seq::TOTAL_FLOATS : 2 * kWBufFloats) * 4; }
+template <class Seq, int RING_SLOT = kWBufFloats, int RES_MAX = kResidentMaxFloats>
+__host__ __device__ constexpr int stream_lds_bytes() { return (Seq::TOTAL_FLOATS <= RES_MAX ? Seq::TOTAL_FLOATS : 2 * RING_SLOT) * 4; }
 
-template <int NT, class SeqT>
+// RING_SLOT: slot size of the ring form; RES_MAX: the sequence is kept resident if it is no larger than this.
+template <int NT, class SeqT, int RING_SLOT = kWBufFloats, int RES_MAX = kResidentMaxFloats>
 struct WStreamG {
-  static constexpr bool RESIDENT = stream_resident<SeqT>();
-  static constexpr int GSLOT = RESIDENT ? SeqT::TOTAL_FLOATS : kWBufFloats;
+  static constexpr bool RESIDENT = SeqT::TOTAL_FLOATS <= RES_MAX;
+  static constexpr int GSLOT = RESIDENT ? SeqT::TOTAL_FLOATS : RING_SLOT;
   // One group when resident: a short first group (MFMAs start earlier, the rest streams underneath) was measured
   // SLOWER, 27.9 vs 24.5 us -- while any LDS-DMA is pending hipcc drains vmcnt(0) at every use of a load result.
   static constexpr int FIRST = GSLOT;

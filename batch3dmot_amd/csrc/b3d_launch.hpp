@@ -30,7 +30,7 @@ inline int launch_rows(Kern kernel, const char* name, const Args& a, long rows, 
 // LDS of the chain / wide-linear kernels: two ring slots of the sequence's largest chunk (a 48x48 layer
 // needs 20 KB, not the 104 KB of the message-passing kernels -- it must not evict them from a CU).
 template <class Seq>
-constexpr int chain_lds() { return 2 * Seq::SLOT * 4; }
+constexpr int chain_lds() { return 2 * Seq::SLOT * 4; }     // ring of the largest chunk; a resident image (WStreamG) is never larger
 constexpr int kNWEdge = 8, kNWNode = 1;
 
 // Node phase of a message-passing layer: 4 wavefronts per 16-row tile (b3d_node.hpp).

@@ -115,7 +115,7 @@ __device__ __forceinline__ void node_fwd_split_body(const NodeFwdArgs& a, float*
   static_assert(DMB % 2 == 0 && 2 + 2 * FP == NWS, "message width must split over the wavefronts");
   static_assert(FP == 1 || (FP - 1) * DMB <= NS::XBUF_BLOCKS, "partial sums live in the second exchange buffer");
   if constexpr (PROJ) B3D_STAMP(0, 0);
-  WStreamT<NWS * 64> ws;
+  WStreamT<NWS * 64> ws;      // one barrier per weight chunk: it is also what publishes the previous layer's LDS activations
   ws.init(a.wpack, smem);
   ws.template start<Seq>();
   v4f* xb0 = reinterpret_cast<v4f*>(smem + 2 * kWBufFloats);
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(kNodeWaves * 64, 1) void mp_node_bwd_split_kernel(c
   constexpr int GB = 2 * XB;                                  // d x' | d x0 contribution
   constexpr int GPW = GB / (NWS / 2);                         // gradient blocks per wavefront (one list each half)
   static_assert(NWS % 2 == 0 && GB % (NWS / 2) == 0, "gradient width must split over half the wavefronts");
-  WStreamT<NWS * 64> ws;
+  WStreamT<NWS * 64> ws;      // one barrier per weight chunk: it is also what publishes the previous layer's LDS activations
   ws.init(a.wpack, smem);
   ws.template start<Seq>();
   v4f* xb0 = reinterpret_cast<v4f*>(smem + 2 * kWBufFloats);
