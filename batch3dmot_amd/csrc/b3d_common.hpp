@@ -1,5 +1,6 @@
 // Host-side helpers shared by the translation units of libb3d_hip.so.
 #pragma once
+#include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -43,6 +44,10 @@ inline int launch_check(const char* what) {
 inline int grid_for_tiles(long rows, int tile_rows, int cap = 2048) {
   long t = (rows + tile_rows - 1) / tile_rows;
   if (t < 1) t = 1;
+  if (const char* ev = getenv("B3D_GRID_CAP")) {          // testing aid: force the grid-stride (several tiles per workgroup) path
+    const int v = atoi(ev);
+    if (v >= 1) cap = v;
+  }
   return (int)(t < cap ? t : cap);
 }
 

@@ -99,3 +99,38 @@ def test_single_frame_and_frames_smaller_than_k():
     ts[0] = 5; ts[1:3] = 6; ts[3:24] = 7
     d.node_timestamps = ts
     _check(d, dead_knn=True)
+
+
+@pytest.mark.gpu
+def test_several_tiles_per_workgroup_give_the_same_bits():
+    """Row-tiled kernels grid-stride once an input exceeds 2,048 tiles (262,144 edges); the weights of the hoisted edge
+    kernels then stay resident in LDS across the tiles of a workgroup.  B3D_GRID_CAP forces that path at test size:
+    outputs and gradients must be bitwise those of the one-tile-per-workgroup launch."""
+    import copy, os
+    from batch3dmot_amd import synth
+    from batch3dmot_amd.pose_gnn import PoseGNN
+    dev = torch.device("cuda:0")
+    torch.manual_seed(21)
+    a = PoseGNN().to(dev)
+    b = copy.deepcopy(a)
+    d = synth.make_graph(900, None, k=12, graph_idx=321).to(dev)
+    assert d.edge_index.size(1) > 5 * 3 * 128                    # > 5 tiles per workgroup at cap 3
+    lw = torch.randn(d.edge_index.size(1), 1, device=dev)
+
+    def run(m):
+        if hasattr(d, "_b3d_graph"):
+            del d._b3d_graph
+        out, x = m(d)
+        (out * lw).sum().backward()
+        return out.detach(), x.detach()
+
+    ref = run(a)
+    os.environ["B3D_GRID_CAP"] = "3"
+    try:
+        got = run(b)
+    finally:
+        del os.environ["B3D_GRID_CAP"]
+    assert torch.equal(ref[0], got[0]) and torch.equal(ref[1], got[1])
+    for (n, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+        if p.grad is not None:
+            assert torch.equal(p.grad, q.grad), n
