@@ -126,7 +126,7 @@ def point_feat_train_hip(convs, bns, x: torch.Tensor, trans=None, relu_last: boo
         xin = torch.bmm(x.transpose(2, 1), trans).transpose(2, 1) if trans is not None else x
         folded = []
         h = xin
-        for cv, bn in zip(convs[:2], bns[:2]):
+        for li, (cv, bn) in enumerate(zip(convs[:2], bns[:2])):
             z = F.conv1d(h, cv.weight, cv.bias)
             var, mean = torch.var_mean(z, dim=(0, 2), unbiased=False)
             _bn_batch_stats_(bn, mean, var, n)
@@ -134,7 +134,8 @@ def point_feat_train_hip(convs, bns, x: torch.Tensor, trans=None, relu_last: boo
             shift = bn.bias - mean * scale
             folded.append(((cv.weight.squeeze(-1) * scale[:, None]).float().contiguous(),
                            (cv.bias * scale + shift).float().contiguous()))
-            h = torch.relu(z * scale[None, :, None] + shift[None, :, None])
+            if li == 0:                                       # the kernel recomputes the activations itself; only the
+                h = torch.relu(z * scale[None, :, None] + shift[None, :, None])   # next layer's statistics need them here
         folded.append((convs[2].weight.squeeze(-1).float().contiguous(), convs[2].bias.float().contiguous()))
         layers = (_lib.b3d_linear * 3)()
         for i, (w, bias) in enumerate(folded):
