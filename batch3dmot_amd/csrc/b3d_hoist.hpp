@@ -110,7 +110,8 @@ __global__ __launch_bounds__(NW * 64, 2) void mp_edge_fwd_h_kernel(const EdgeFwd
     const int s = a.src[rc], d = a.dst[rc];
 
     // gathers: unconditional loads straight into their registers, all in flight together; the future / past
-    // rows are fetched a layer ahead of their use (as hooks, behind a barrier) to keep the prologue light
+    // rows are fetched a layer ahead of their use (as hooks) to keep the prologue light.  The weights are resident
+    // in LDS (WStreamG): one barrier in front of the first layer of the first tile, none afterwards.
     v4f ein[EB + AB];
     load_row_u<EB>(a.e_in, rc, D::DE, 0, ein);
     if constexpr (AB > 0) load_row_u<AB>(a.a_in, rc, D::DA, 0, ein + EB);
@@ -251,10 +252,9 @@ __global__ __launch_bounds__(NW * 64, 2) void mp_edge_bwd_h_kernel(const EdgeBwd
     const bool valid = row < a.E;
     int s = 0, d = 0;
     if (valid) { s = a.src[row]; d = a.dst[row]; }
-    // Every weight-chunk acquire drains vmcnt (the LDS-DMA shares the counter with loads and stores), so a load
-    // issued right in front of one is waited for at once and a store in front of one is flushed at once.
-    // Loads are therefore issued a whole layer before their use and stores right AFTER the next layer's
-    // barrier (as that layer's hook): both then have a layer of MFMAs to complete under.
+    // Loads are issued a whole layer before their use and stores as the next layer's hook: both have a layer of
+    // MFMAs to complete under.  (With a weight RING every chunk acquire drained vmcnt -- the LDS-DMA shares the
+    // counter with loads and stores; with the weights resident only the first acquire of the first tile does.)
     v4f de[EB];
     load_row<EB>(a.de_out, row, D::DE, 0, valid, de);
     v4f act2[H2B], act1[H1B], d2[H2B], d1[H1B];
