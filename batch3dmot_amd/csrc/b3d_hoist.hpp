@@ -260,8 +260,8 @@ __global__ __launch_bounds__(NW * 64, 2) void mp_edge_bwd_h_kernel(const EdgeBwd
     v4f act2[H2B], act1[H1B], d2[H2B], d1[H1B];
     if constexpr (MSGS) {
       v4f dmp[DMB], dmf[DMB], actp[MHB], actf[MHB], dh[MHB], dh2[MHB], dee[EB];
+      load_row<MHB>(a.sP1, row, D::MH, 0, valid, actp);            // needs no index: issued under the index fetch
       load_row<DMB>(a.dM, d, 2 * D::DM, 0, valid, dmp);            // past messages were summed at dst
-      load_row<MHB>(a.sP1, row, D::MH, 0, valid, actp);
       load_row<DMB>(a.dM, s, 2 * D::DM, D::DM, valid, dmf);        // future messages were summed at src
       wait_for(de); wait_for(dmp); wait_for(actp); wait_for(dmf);   // the prologue's loads have landed
       B3D_STAMP(3, 1);
