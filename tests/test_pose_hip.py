@@ -114,7 +114,7 @@ def test_full_size_against_oracle_and_float64():
 
     Through six ReLU layers the fp32 gradient of this model is chaotic at the 1e-4 .. 1e-3 level: a
     pre-activation that rounds to the other side of zero flips a unit.  Against float64, over eight
-    synthetic batches (tools/grad_error_seeds.py, MI355X) the l2-relative gradient error per parameter is
+    synthetic batches (tests/tools/grad_error_seeds.py, MI355X) the l2-relative gradient error per parameter is
     1e-5 .. 1.0e-3 for the fp32 CPU oracle and 3e-5 .. 1.1e-3 for the HIP path, neither consistently
     ahead -- while the forward outputs of both sit at 1.5e-6.  GRAD_TOL bounds that range; the small-graph
     tests hold the gradients to 1e-4 against the oracle where no unit sits near a tie."""

@@ -1,5 +1,5 @@
 import os, sys, time, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 from batch3dmot_amd import synth
 from oracle import ref_torch
 th = int(sys.argv[1]); torch.set_num_threads(th)

@@ -1,7 +1,7 @@
 """GPU diagnostic: GNN (CLR) HIP path vs the golden fixtures / oracle."""
 import ctypes as C, os, sys, time
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 from batch3dmot_amd import _lib, encoders
 from batch3dmot_amd.data import Data
 from batch3dmot_amd.clr_att_gnn import GNN

@@ -1,5 +1,5 @@
 import os, sys, copy
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from oracle import ref_torch
 from oracle.seeded import seeded_fill_

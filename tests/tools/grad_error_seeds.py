@@ -1,7 +1,7 @@
 """Gradient error of the HIP path and of the fp32 oracle against a float64 evaluation (full-size batch)."""
 import copy, os, sys
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from batch3dmot_amd import synth
 from batch3dmot_amd.data import Data
