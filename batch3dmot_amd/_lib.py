@@ -25,7 +25,7 @@ c_float_p = C.POINTER(C.c_float)
 class b3d_graph(C.Structure):
     _fields_ = [("N", C.c_int32), ("E", C.c_int32), ("src", C.c_void_p), ("dst", C.c_void_p),
                 ("dst_ptr", C.c_void_p), ("dst_perm", C.c_void_p), ("src_ptr", C.c_void_p),
-                ("src_perm", C.c_void_p)]
+                ("src_perm", C.c_void_p), ("invalid_edges", C.c_void_p)]
 
 
 class b3d_linear(C.Structure):
@@ -176,8 +176,8 @@ def load() -> C.CDLL:
     lib.b3d_post_workspace_bytes.restype = C.c_size_t
     lib.b3d_post_workspace_bytes.argtypes = [C.c_int64, C.c_int64]
     lib.b3d_post_greedy.restype = C.c_int
-    lib.b3d_post_greedy.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
-                                    C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.b3d_post_greedy.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32,
+                                    C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.b3d_prof_enable.argtypes = [C.c_int]
     lib.b3d_prof_select.argtypes = [C.c_uint32]
     lib.b3d_prof_select.restype = C.c_int
@@ -212,7 +212,12 @@ def require_cuda(t: torch.Tensor, name: str, dtype=None) -> None:
 class Graph:
     """Device-side graph structure built once per batch and reused by all layers and by backward."""
 
-    def __init__(self, edge_index: torch.Tensor, num_nodes: int):
+    def __init__(self, edge_index: torch.Tensor, num_nodes: int, validated: bool = False):
+        """``validated``: the caller has already checked that every endpoint lies in [0, num_nodes) (``Data.to`` does
+        so on the CPU copy).  Otherwise the build's counter of out-of-range edges is read back (one 4-byte copy, a
+        host synchronisation) and a ``ValueError`` is raised, where the reference raises an index error
+        (pose_gnn.py:180); during stream capture the read is impossible and skipped -- the build has rewritten such
+        edges to the self loop (0, 0), so nothing indexes out of bounds, and ``invalid_edges()`` reports them later."""
         require_cuda(edge_index, "edge_index", torch.int64)
         if edge_index.dim() != 2 or edge_index.size(0) != 2:
             raise ValueError(f"edge_index must be [2, E], got {tuple(edge_index.shape)}")
@@ -224,6 +229,14 @@ class Graph:
         check(lib.b3d_graph_build(edge_index.data_ptr(), self.N, self.E, self.ws.data_ptr(), nbytes,
                                   C.byref(self.c), current_stream(edge_index.device)), "b3d_graph_build")
         self._keep = edge_index
+        if not validated and not torch.cuda.is_current_stream_capturing():
+            bad = self.invalid_edges()
+            if bad:
+                raise ValueError(f"edge_index has {bad} edge(s) with an endpoint outside [0, {self.N})")
+
+    def invalid_edges(self) -> int:
+        """Number of edges with an endpoint outside [0, N) (synchronises)."""
+        return int(self._view(self.c.invalid_edges, 1).item())
 
     def _view(self, p, n):
         off = (p - self.ws.data_ptr())

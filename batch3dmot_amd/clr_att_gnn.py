@@ -118,6 +118,7 @@ class _GNNFunction(torch.autograd.Function):
         if nbytes == 0:
             raise ValueError(f"unsupported gnn_depth {module.depth} (1..15)")
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        ctx.save_for_backward(*params)                           # version-checked: in-place edits before backward are errors
         params = [p.detach() for p in params]
         w = _clr_struct(_lib.b3d_clr_weights, params)
         kc = module.knn_conv
@@ -135,7 +136,7 @@ class _GNNFunction(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         ctx.module, ctx.graph, ctx.ws, ctx.nbytes, ctx.flags = module, graph, ws, nbytes, flags
         ctx.ws_owner = _lib.Workspace(ws, defer)
-        ctx.params, ctx.inp, ctx.keep = params, inp, (gat, pose_feats, edge_attr, node_timestamps, x_img, pointnet_out,
+        ctx.inp, ctx.keep = inp, (gat, pose_feats, edge_attr, node_timestamps, x_img, pointnet_out,
                                                       lidar_nodes, radarnet_out, radar_nodes)
         module._last_workspace = (ws, nbytes, flags, N, E, nl, nr) if module.keep_workspace else None
         return prob, x_sens
@@ -145,7 +146,7 @@ class _GNNFunction(torch.autograd.Function):
         lib = _lib.load()
         if not (ctx.flags & B3D_FLAG_TRAINING):
             raise RuntimeError("backward through a GNN forward that ran without gradient tracking")
-        params = ctx.params
+        params = [p.detach() for p in ctx.saved_tensors]
         dev = params[0].device
         if d_prob is not None:
             d_prob = d_prob.contiguous().float()
@@ -332,7 +333,7 @@ class GNN(nn.Module):
         graph = getattr(data, "_b3d_graph", None)
         if graph is None or graph.N != pose_feats.size(0) or graph.E != edge_index.size(1) \
                 or graph._keep.data_ptr() != edge_index.data_ptr():
-            graph = _lib.Graph(edge_index.contiguous(), pose_feats.size(0))
+            graph = _lib.Graph(edge_index.contiguous(), pose_feats.size(0), validated=getattr(data, "_b3d_valid_edge_index", None) is edge_index)
             try:
                 data._b3d_graph = graph
             except Exception:

@@ -12,11 +12,28 @@
 namespace b3d {
 namespace {
 
-__global__ void post_keys_kernel(const long long* __restrict__ pairs, long long M, long long N, long long* key, int* pos) {
+// Order-preserving map of a double onto an unsigned integer (any sign; 0 is below every value and means "none").
+__device__ __forceinline__ unsigned long long ordered_bits(double v) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+// A node id outside [0, N) or a class id outside [0, C) is counted in *invalid (the caller raises on it) and
+// clamped, so that nothing below indexes out of bounds.
+__global__ void post_keys_kernel(const long long* __restrict__ pairs, long long M, long long N, long long* key, int* pos, int* invalid) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= M) return;
-  key[i] = pairs[2 * i] * N + pairs[2 * i + 1];
+  long long s = pairs[2 * i], d = pairs[2 * i + 1];
+  if (s < 0 || s >= N || d < 0 || d >= N) {
+    atomicAdd(invalid, 1);
+    s = s < 0 ? 0 : (s >= N ? N - 1 : s);
+    d = d < 0 ? 0 : (d >= N ? N - 1 : d);
+  }
+  key[i] = s * N + d;
   pos[i] = (int)i;
+}
+__global__ void post_check_classes_kernel(const long long* __restrict__ node_class, long long N, int C, int* invalid) {
+  const long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n < N && (node_class[n] < 0 || node_class[n] >= C)) atomicAdd(invalid, 1);
 }
 __global__ void post_heads_kernel(const long long* __restrict__ skey, long long M, int* head) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -54,14 +71,16 @@ __global__ void post_pad_kernel(const int* __restrict__ U, long long M, int* fir
 }
 // uniques in first-appearance order -> keep flag by the class threshold of the SOURCE node
 __global__ void post_keep_kernel(const int* __restrict__ order, const long long* __restrict__ ukey, const double* __restrict__ mean,
-                                 const long long* __restrict__ node_class, const double* __restrict__ thr, long long N,
+                                 const long long* __restrict__ node_class, const double* __restrict__ thr, int C, long long N,
                                  const int* __restrict__ U, long long M, int* keep) {
   const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (r > M) return;
   if (r >= *U) { keep[r] = 0; return; }
   const int u = order[r];
   const long long src = ukey[u] / N;
-  keep[r] = mean[u] > thr[node_class[src]] ? 1 : 0;
+  long long c = node_class[src];
+  c = c < 0 ? 0 : (c >= C ? C - 1 : c);                  // counted by post_check_classes_kernel
+  keep[r] = mean[u] > thr[c] ? 1 : 0;
 }
 __global__ void post_emit_kernel(const int* __restrict__ order, const long long* __restrict__ ukey, const double* __restrict__ mean,
                                  const int* __restrict__ keep, const int* __restrict__ slot, long long N,
@@ -73,8 +92,7 @@ __global__ void post_emit_kernel(const int* __restrict__ order, const long long*
   const long long src = ukey[u] / N, dst = ukey[u] - src * N;
   kept_pairs[2 * k] = src; kept_pairs[2 * k + 1] = dst;
   kept_scores[k] = mean[u];
-  // scores are > threshold >= 0: the bit pattern of a non-negative double orders like an unsigned integer
-  const unsigned long long bits = (unsigned long long)__double_as_longlong(mean[u]);
+  const unsigned long long bits = ordered_bits(mean[u]);
   atomicMax(best_in + dst, bits);
   atomicMax(best_out + src, bits);
 }
@@ -86,7 +104,7 @@ __global__ void post_first_kernel(const long long* __restrict__ kept_pairs, cons
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= *Kp) return;
   const long long src = kept_pairs[2 * k], dst = kept_pairs[2 * k + 1];
-  const unsigned long long bits = (unsigned long long)__double_as_longlong(kept_scores[k]);
+  const unsigned long long bits = ordered_bits(kept_scores[k]);
   if (bits == best_in[dst]) atomicMin(first_in + dst, k);
   if (bits == best_out[src]) atomicMin(first_out + src, k);
 }
@@ -145,26 +163,29 @@ extern "C" size_t b3d_post_workspace_bytes(int64_t M, int64_t N) {
   return w.bytes;
 }
 
-// The number of kept edges is data dependent: counts[0] = distinct edges, counts[1] = kept edges (device int32[2]);
-// kept_pairs [M,2] / kept_scores [M] are filled for the first counts[1] rows.  The caller reads the counts when
-// it needs the size (one 8-byte copy), exactly as torch's boolean indexing would.
+// The number of kept edges is data dependent: counts[0] = distinct edges, counts[1] = kept edges, counts[2] = entries
+// of `pairs` / `node_class` outside their range (device int32[3]); kept_pairs [M,2] / kept_scores [M] are filled for
+// the first counts[1] rows.  The caller reads the counts when it needs the size (one 12-byte copy), exactly as
+// torch's boolean indexing would, and treats counts[2] != 0 as the index error the reference's dictionaries raise.
 extern "C" int b3d_post_greedy(const int64_t* pairs, const float* scores, int64_t M, const int64_t* node_class, int64_t N,
-                               const double* class_threshold, void* workspace, size_t workspace_bytes, int64_t* kept_pairs,
+                               const double* class_threshold, int32_t num_classes, void* workspace, size_t workspace_bytes, int64_t* kept_pairs,
                                double* kept_scores, int64_t* pred, int64_t* succ, int32_t* counts, b3d_stream stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   B3D_REQUIRE(node_class && class_threshold && workspace && kept_pairs && kept_scores && pred && succ && counts,
               "b3d_post_greedy: null argument");
   B3D_REQUIRE(M == 0 || (pairs && scores), "b3d_post_greedy: null edge list");
   B3D_REQUIRE(M >= 0 && N > 0 && M < (1ll << 31) && N < (1ll << 31), "b3d_post_greedy: M %lld, N %lld", (long long)M, (long long)N);
+  B3D_REQUIRE(num_classes > 0, "b3d_post_greedy: num_classes %d", (int)num_classes);
   PostWs w;
   post_carve(w, workspace, workspace_bytes, M, N);
   if (!w.ok) return fail(B3D_ERR_WORKSPACE, "b3d_post_greedy: workspace %zu < %zu bytes", workspace_bytes, w.bytes);
   const unsigned nb = (unsigned)((N + 255) / 256);
   hipLaunchKernelGGL(post_init_kernel, dim3(nb), dim3(256), 0, stream, (long long)N, w.best_in, w.best_out, w.first_in, w.first_out);
-  B3D_HIP_CHECK(hipMemsetAsync(counts, 0, 2 * sizeof(int32_t), stream));
+  B3D_HIP_CHECK(hipMemsetAsync(counts, 0, 3 * sizeof(int32_t), stream));
+  hipLaunchKernelGGL(post_check_classes_kernel, dim3(nb), dim3(256), 0, stream, (const long long*)node_class, (long long)N, (int)num_classes, counts + 2);
   if (M > 0) {
     const unsigned mb = (unsigned)((M + 256) / 256);       // covers M + 1 items where a scan total is written
-    hipLaunchKernelGGL(post_keys_kernel, dim3(mb), dim3(256), 0, stream, (const long long*)pairs, (long long)M, (long long)N, w.key, w.pos);
+    hipLaunchKernelGGL(post_keys_kernel, dim3(mb), dim3(256), 0, stream, (const long long*)pairs, (long long)M, (long long)N, w.key, w.pos, counts + 2);
     size_t tb = w.tmp_bytes;
     B3D_HIP_CHECK(rocprim::radix_sort_pairs(w.tmp, tb, w.key, w.skey, w.pos, w.spos, (size_t)M, 0, 64, stream));
     hipLaunchKernelGGL(post_heads_kernel, dim3(mb), dim3(256), 0, stream, w.skey, (long long)M, w.head);
@@ -180,7 +201,7 @@ extern "C" int b3d_post_greedy(const int64_t* pairs, const float* scores, int64_
     tb = w.tmp_bytes;
     B3D_HIP_CHECK(rocprim::radix_sort_pairs(w.tmp, tb, w.first_pos, w.sfirst, w.uid, w.order, (size_t)M, 0, 32, stream));
     hipLaunchKernelGGL(post_keep_kernel, dim3(mb), dim3(256), 0, stream, w.order, w.ukey, w.mean, (const long long*)node_class,
-                       class_threshold, (long long)N, U, (long long)M, w.keep);
+                       class_threshold, (int)num_classes, (long long)N, U, (long long)M, w.keep);
     tb = w.tmp_bytes;
     B3D_HIP_CHECK(rocprim::exclusive_scan(w.tmp, tb, w.keep, w.slot, 0, (size_t)M + 1, rocprim::plus<int>(), stream));
     const int* K = w.slot + M;                              // number of kept edges

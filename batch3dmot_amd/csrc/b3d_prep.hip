@@ -13,11 +13,19 @@ __global__ void graph_convert_count(const int64_t* __restrict__ ei, int E, int N
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= E) return;
   const long s = ei[k], d = ei[(long)E + k];
-  if (s < 0 || s >= N || d < 0 || d >= N) { atomicAdd(bad, 1); src[k] = 0; dst[k] = 0; return; }
-  src[k] = (int)s;
-  dst[k] = (int)d;
-  atomicAdd(&cnt_dst[d], 1);
-  atomicAdd(&cnt_src[s], 1);
+  long ss = s, dd = d;
+  if (s < 0 || s >= N || d < 0 || d >= N) {
+    // the reference raises an index error for this input (pose_gnn.py:180); here the edge is counted in `bad`
+    // (b3d_graph.invalid_edges, which the caller turns into that error) and rewritten to the self loop (0, 0), which
+    // keeps CSR / CSC consistent: nothing downstream can index out of bounds before the caller has looked
+    atomicAdd(bad, 1);
+    ss = 0; dd = 0;
+    if (N <= 0) { src[k] = 0; dst[k] = 0; return; }
+  }
+  src[k] = (int)ss;
+  dst[k] = (int)dd;
+  atomicAdd(&cnt_dst[dd], 1);
+  atomicAdd(&cnt_src[ss], 1);
 }
 
 // Exclusive scan of two count arrays (one workgroup each): ptr[0..N], cursor copy for the fill.
@@ -49,11 +57,12 @@ __global__ __launch_bounds__(1024) void graph_scan(const int* __restrict__ cnt_d
   if (threadIdx.x == 1023) ptr[N] = part[1023];
 }
 
-__global__ void graph_fill(const int* __restrict__ src, const int* __restrict__ dst, int E,
+__global__ void graph_fill(const int* __restrict__ src, const int* __restrict__ dst, int E, int N,
                            int* __restrict__ cur_dst, int* __restrict__ cur_src,
                            int* __restrict__ dst_perm, int* __restrict__ src_perm) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= E) return;
+  if (N <= 0) { dst_perm[k] = k; src_perm[k] = k; return; }        // every edge invalid: identity, flagged in `bad`
   dst_perm[atomicAdd(&cur_dst[dst[k]], 1)] = k;
   src_perm[atomicAdd(&cur_src[src[k]], 1)] = k;
 }
@@ -137,7 +146,7 @@ extern "C" int b3d_graph_build(const int64_t* edge_index, int32_t N, int32_t E, 
                      g.src_ptr, g.cur_dst, g.cur_src);
   B3D_TRY(launch_check("graph_scan"));
   if (E > 0) {
-    hipLaunchKernelGGL(graph_fill, dim3((E + 255) / 256), dim3(256), 0, stream, g.src, g.dst, E, g.cur_dst,
+    hipLaunchKernelGGL(graph_fill, dim3((E + 255) / 256), dim3(256), 0, stream, g.src, g.dst, E, N, g.cur_dst,
                        g.cur_src, g.dst_perm, g.src_perm);
     B3D_TRY(launch_check("graph_fill"));
     hipLaunchKernelGGL(graph_sort_segments, dim3((2 * N + 3) / 4), dim3(256), 0, stream, g.dst_ptr,
@@ -152,6 +161,7 @@ extern "C" int b3d_graph_build(const int64_t* edge_index, int32_t N, int32_t E, 
   out->dst_perm = g.dst_perm;
   out->src_ptr = g.src_ptr;
   out->src_perm = g.src_perm;
+  out->invalid_edges = g.bad;
   return B3D_OK;
 }
 

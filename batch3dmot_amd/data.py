@@ -32,6 +32,15 @@ class Data:
         out = Data()
         for k, v in self.__dict__.items():
             setattr(out, k, v.to(device, non_blocking=non_blocking) if torch.is_tensor(v) else v)
+        ei = self.__dict__.get("edge_index")
+        pf = self.__dict__.get("pose_feats")
+        if torch.is_tensor(ei) and torch.is_tensor(pf) and not ei.is_cuda and ei.numel() and torch.device(device).type == "cuda":
+            # the reference fails with an index error on an edge whose endpoint is not a node (pose_gnn.py:180); checking
+            # the CPU copy here costs microseconds and spares the GPU graph build its read-back of the error counter
+            lo, hi = int(ei.min()), int(ei.max())
+            if lo < 0 or hi >= pf.size(0):
+                raise ValueError(f"edge_index has endpoints outside [0, {pf.size(0)}): min {lo}, max {hi}")
+            out._b3d_valid_edge_index = out.edge_index      # identity-checked by the models: valid for THIS tensor only
         return out
 
     @property

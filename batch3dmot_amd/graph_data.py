@@ -188,7 +188,14 @@ def iterate_batches(dataset, batch_size: int, shuffle: bool = False, generator: 
                 raise item
             batch, ev, _keep = item
             if ev is not None:
-                torch.cuda.current_stream(dev).wait_event(ev)
+                cur = torch.cuda.current_stream(dev)
+                cur.wait_event(ev)
+                # The batch was allocated on the copy stream: without this the caching allocator would hand its blocks
+                # back to the copy stream the moment the consumer drops the batch, and the worker's next H2D copy could
+                # overwrite them while kernels of the consumer's (asynchronously enqueued) step are still reading.
+                for v in batch.__dict__.values():
+                    if torch.is_tensor(v) and v.is_cuda:
+                        v.record_stream(cur)
             yield batch
     finally:
         stop.set()

@@ -67,7 +67,9 @@ class _MPLayerFunction(torch.autograd.Function):
                                                  stream), "b3d_clr_layer_forward")
         ctx.set_materialize_grads(False)
         ctx.kind, ctx.graph, ctx.training, ctx.ws, ctx.nbytes = kind, graph, training, ws, nbytes
-        ctx.saved = (x, x0, e, e_new, params)
+        # save_for_backward: no reference cycle through the output e_new, and in-place edits of x / e between forward
+        # and backward are detected by autograd's version counters
+        ctx.save_for_backward(x, x0, e, e_new, *params)
         return x_new, e_new
 
     @staticmethod
@@ -75,7 +77,7 @@ class _MPLayerFunction(torch.autograd.Function):
         if ctx.kind != "p" or not ctx.training:
             raise RuntimeError("backward through a CausalMessagePassing layer whose forward kept no state")
         lib = _lib.load()
-        x, x0, e, e_new, params = ctx.saved
+        x, x0, e, e_new, *params = ctx.saved_tensors
         dev = x.device
         if d_x_new is not None:
             d_x_new = d_x_new.contiguous().float()

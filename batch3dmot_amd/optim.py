@@ -134,12 +134,16 @@ class FlatAdam:
             self.inner.step()
 
     def state_dict(self) -> dict:
-        return {"step": self.step_count, "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(),
+        # capturable: the counter that the bias corrections read lives on the device and advances on graph replays
+        step = int(self.step_dev.item()) if self.capturable else self.step_count
+        return {"step": step, "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(),
                 "param_groups": [{k: v for k, v in self.param_groups[0].items() if k != "params"}],
                 "inner": self.inner.state_dict() if self.inner is not None else None}
 
     def load_state_dict(self, sd: dict) -> None:
         self.step_count = int(sd["step"])
+        if self.capturable:
+            self.step_dev.fill_(self.step_count)
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         self.param_groups[0].update(sd["param_groups"][0])

@@ -119,6 +119,7 @@ class _PoseGNNFunction(torch.autograd.Function):
         if nbytes == 0:
             raise ValueError(f"unsupported gnn_depth {module.depth} (1..15)")
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        ctx.save_for_backward(pose_feats, edge_attr, *params)     # version-checked: in-place edits before backward are errors
         params = [p.detach() for p in params]
         w = _pose_struct(_lib.b3d_pose_weights, params)
         kc = module.knn_conv
@@ -134,7 +135,7 @@ class _PoseGNNFunction(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         ctx.module, ctx.graph, ctx.ws, ctx.nbytes, ctx.flags = module, graph, ws, nbytes, flags
         ctx.ws_owner = _lib.Workspace(ws, defer)
-        ctx.params, ctx.inputs, ctx.keep = params, (pose_feats, edge_attr), gat
+        ctx.keep = gat
         module._last_workspace = (ws, nbytes, flags, N, E) if module.keep_workspace else None
         return logits, x_enc
 
@@ -143,8 +144,8 @@ class _PoseGNNFunction(torch.autograd.Function):
         lib = _lib.load()
         if not (ctx.flags & B3D_FLAG_TRAINING):
             raise RuntimeError("backward through a PoseGNN forward that ran without gradient tracking")
-        params = ctx.params
-        pose_feats, edge_attr = ctx.inputs
+        pose_feats, edge_attr, *params = ctx.saved_tensors
+        params = [p.detach() for p in params]
         dev = pose_feats.device
         if d_logits is not None:
             d_logits = d_logits.contiguous().float()
@@ -220,7 +221,7 @@ class PoseGNN(nn.Module):
         graph = getattr(data, "_b3d_graph", None)
         if graph is None or graph.N != pose_feats.size(0) or graph.E != edge_index.size(1) \
                 or graph._keep.data_ptr() != edge_index.data_ptr():
-            graph = _lib.Graph(edge_index.contiguous(), pose_feats.size(0))
+            graph = _lib.Graph(edge_index.contiguous(), pose_feats.size(0), validated=getattr(data, "_b3d_valid_edge_index", None) is edge_index)
             try:
                 data._b3d_graph = graph
             except Exception:

@@ -87,9 +87,12 @@ def greedy_edges_hip(pairs: torch.Tensor, scores: torch.Tensor, node_class: torc
     kept_scores = torch.empty(max(m, 1), dtype=torch.float64, device=dev)
     pred = torch.empty(n, dtype=torch.int64, device=dev)
     succ = torch.empty(n, dtype=torch.int64, device=dev)
-    counts = torch.empty(2, dtype=torch.int32, device=dev)
+    counts = torch.empty(3, dtype=torch.int32, device=dev)
     _lib.check(lib.b3d_post_greedy(pairs.contiguous().data_ptr(), sc.data_ptr(), m, nc.data_ptr(), n, thr.data_ptr(),
-                                   ws.data_ptr(), nbytes, kept_pairs.data_ptr(), kept_scores.data_ptr(), pred.data_ptr(),
+                                   len(class_names), ws.data_ptr(), nbytes, kept_pairs.data_ptr(), kept_scores.data_ptr(), pred.data_ptr(),
                                    succ.data_ptr(), counts.data_ptr(), _lib.current_stream(dev)), "b3d_post_greedy")
-    k = int(counts[1])                                      # the only host read: the size of the kept-edge list
+    _, k, invalid = counts.tolist()                         # the only host read: the size of the kept-edge list
+    if invalid:
+        raise ValueError(f"{invalid} entries of pairs / node_class lie outside [0, {n}) / [0, {len(class_names)}) "
+                         "(the reference's dictionaries raise a KeyError for them, predict.py:92-117)")
     return {"kept_pairs": kept_pairs[:k], "kept_scores": kept_scores[:k], "pred": pred, "succ": succ}

@@ -52,6 +52,10 @@ typedef struct b3d_graph {
   const int32_t* dst_perm;   /* [E] edge ids grouped by destination, ascending   */
   const int32_t* src_ptr;    /* [N+1] CSC by source                              */
   const int32_t* src_perm;   /* [E] edge ids grouped by source, ascending        */
+  const int32_t* invalid_edges; /* device int32[1]: edges with an endpoint outside [0, N).  The reference raises an
+                                   index error for them (pose_gnn.py:180); the build rewrites each to the self loop
+                                   (0, 0) so that no kernel can index out of bounds, and the caller reads this counter
+                                   (one 4-byte copy) to raise the error -- batch3dmot_amd._lib.Graph does            */
 } b3d_graph;
 
 size_t b3d_graph_workspace_bytes(int32_t N, int32_t E);
@@ -264,10 +268,14 @@ int b3d_side_join(b3d_stream stream);
  * the best incoming edge's source (pred) and the best outgoing edge's destination (succ), ties to the edge that
  * appeared first, -1 if none.  node_class [N] int64 (index into class_threshold [C] float64).
  * Outputs: kept_pairs [M,2] int64 / kept_scores [M] float64 (first counts[1] rows valid), pred / succ [N] int64,
- * counts: device int32[2] = {distinct edges, kept edges}.  Deterministic; no host synchronisation. */
+ * counts: device int32[3] = {distinct edges, kept edges, entries of pairs / node_class outside [0,N) / [0,C)}.
+ * Out-of-range entries are clamped (nothing indexes out of bounds) and counted; a caller treats counts[2] != 0 as
+ * the KeyError / IndexError the reference's dictionaries raise.  Scores of any sign.  Deterministic; no host
+ * synchronisation. */
 size_t b3d_post_workspace_bytes(int64_t M, int64_t N);
 int b3d_post_greedy(const int64_t* pairs, const float* scores, int64_t M, const int64_t* node_class, int64_t N,
-                    const double* class_threshold, void* workspace, size_t workspace_bytes, int64_t* kept_pairs,
+                    const double* class_threshold, int32_t num_classes, void* workspace, size_t workspace_bytes,
+                    int64_t* kept_pairs,
                     double* kept_scores, int64_t* pred, int64_t* succ, int32_t* counts, b3d_stream stream);
 
 /* ---- point-cloud feature stacks of the frozen LiDAR / radar encoders, eval mode ------------------------------

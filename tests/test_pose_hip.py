@@ -199,9 +199,26 @@ def test_invalid_inputs_raise():
         m(empty)
     oob = d.edge_index.clone()
     oob[0, 0] = 10 ** 6
-    # out-of-range node ids are neutralised by the graph build (never dereferenced)
-    m(data_from({**d.__dict__, "edge_index": oob}))
+    # an endpoint that is not a node: the reference raises an index error (pose_gnn.py:180); here a ValueError, from the
+    # graph build's counter for tensors that are already on the GPU ...
+    with pytest.raises(ValueError, match="outside"):
+        m(data_from({**d.__dict__, "edge_index": oob}))
     torch.cuda.synchronize()
+    # ... the build itself stays consistent (the edge becomes the self loop (0, 0), nothing indexes out of bounds)
+    from batch3dmot_amd import _lib
+    gr = _lib.Graph(oob, 50, validated=True)
+    a = {k: v.cpu().long() for k, v in gr.arrays().items()}
+    assert gr.invalid_edges() == 1 and int(a["src"][0]) == 0 and int(a["dst"][0]) == 0
+    assert int(a["dst_ptr"][-1]) == oob.size(1) and int(a["src_ptr"][-1]) == oob.size(1)
+    assert sorted(a["dst_perm"].tolist()) == list(range(oob.size(1))) and sorted(a["src_perm"].tolist()) == list(range(oob.size(1)))
+    # ... and from Data.to() for a batch that comes from the host (no GPU read-back)
+    cpu = data_from({**{k: (v.cpu() if torch.is_tensor(v) else v) for k, v in d.__dict__.items()}, "edge_index": oob.cpu()})
+    with pytest.raises(ValueError, match="outside"):
+        cpu.to(dev)
+    neg = d.edge_index.clone()
+    neg[1, 3] = -1
+    with pytest.raises(ValueError, match="outside"):
+        m(data_from({**d.__dict__, "edge_index": neg}))
 
 
 def _tiny_batch(dev, idx=0):
