@@ -140,3 +140,26 @@ def test_prefetched_batches_on_the_gpu_feed_the_model(window_dir):
         want = collate([ds[i] for i in range(2 * k, min(2 * k + 2, len(ds)))]).to(dev)
         with torch.no_grad():
             assert torch.equal(m(want)[0].cpu(), o)
+
+
+@pytest.mark.gpu
+def test_prefetched_batches_stay_intact_under_a_long_running_consumer(window_dir):
+    """The worker allocates batch k+1 on its copy stream while the consumer's kernels on batch k may still be queued:
+    the consumer's stream is recorded on every tensor, so the allocator cannot hand batch k's blocks to the next
+    copy early.  A long-running kernel between taking a batch and reading it makes the race window wide."""
+    d, scenes = window_dir
+    ds = GraphDataset(None, scenes, d, 5, False, modalities=())
+    dev = torch.device("cuda:0")
+    want = [collate([ds[i] for i in range(2 * k, min(2 * k + 2, len(ds)))]) for k in range(3)]
+    spin = torch.randn(4096, 4096, device=dev)
+    sums = []
+    for rep in range(3):
+        for b in iterate_batches(ds, 2, device=dev, prefetch=2):
+            for _ in range(6):
+                spin = (spin @ spin).clamp_(-1.0, 1.0)            # ~tens of ms of queued device work
+            sums.append((b.pose_feats.clone(), b.edge_attr.clone(), b.edge_index.clone()))   # read BEHIND the queued work
+            del b                                                  # blocks go back to the allocator while work is queued
+    torch.cuda.synchronize()
+    for i, (pf, ea, ei) in enumerate(sums):
+        w = want[i % 3]
+        assert torch.equal(pf.cpu(), w.pose_feats) and torch.equal(ea.cpu(), w.edge_attr) and torch.equal(ei.cpu(), w.edge_index), i

@@ -255,6 +255,33 @@ def test_flat_adam_matches_torch_adam():
     assert torch.equal(sb["knn_conv.bias"], sa["knn_conv.bias"])
 
 
+def test_flat_adam_capturable_state_round_trip():
+    """capturable=True keeps the step counter on the device (it advances on hipGraph replays): state_dict / load_state_dict
+    must carry it, or the bias corrections restart at t = 1 against warm moments."""
+    import copy
+    from batch3dmot_amd.pose_gnn import PoseGNN
+    from batch3dmot_amd.optim import FlatAdam
+    from batch3dmot_amd.train_step import train_step
+    dev = torch.device("cuda:0")
+    torch.manual_seed(8)
+    a = PoseGNN().to(dev)
+    b = copy.deepcopy(a)
+    hp = dict(lr=1e-3, weight_decay=1e-4, betas=(0.9, 0.999))
+    opt_a = FlatAdam(a, capturable=True, **hp)
+    for i in range(3):
+        train_step(a, _tiny_batch(dev, 20 + i), opt_a, logits=True)
+    sd = opt_a.state_dict()
+    assert sd["step"] == 3
+    b.load_state_dict(a.state_dict())
+    opt_b = FlatAdam(b, capturable=True, **hp)
+    opt_b.load_state_dict(copy.deepcopy(sd))
+    assert int(opt_b.step_dev) == 3 and opt_b.step_count == 3
+    d = _tiny_batch(dev, 30)
+    train_step(a, d, opt_a, logits=True)
+    train_step(b, d, opt_b, logits=True)
+    assert torch.equal(opt_a.flat_param, opt_b.flat_param)          # the resumed run takes the identical 4th step
+
+
 def test_flat_adam_gradient_accumulation_and_zero_grad():
     from batch3dmot_amd.pose_gnn import PoseGNN
     from batch3dmot_amd.optim import FlatAdam
