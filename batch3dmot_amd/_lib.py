@@ -182,6 +182,10 @@ def load() -> C.CDLL:
     lib.b3d_prof_select.argtypes = [C.c_uint32]
     lib.b3d_prof_select.restype = C.c_int
     lib.b3d_prof_read.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    lib.b3d_prof_pair_overhead_us.restype = C.c_int
+    lib.b3d_prof_pair_overhead_us.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
+    lib.b3d_features.restype = C.c_uint32
+    lib.b3d_features.argtypes = []
     _lib = lib
     return lib
 
@@ -251,7 +255,7 @@ class Graph:
 
 
 KERNEL_FAMILIES = {"mp_edge_fwd": 0, "mp_edge_bwd": 1, "mp_node_fwd": 2, "mp_node_bwd": 3, "wgrad_edge": 4,
-                   "wgrad_other": 5, "other": 6}
+                   "wgrad_other": 5, "other": 6, "att_fwd": 7, "att_bwd": 8, "knn_gat": 9, "point_feat": 10}
 
 
 def prof_enable(on: bool, families=None) -> None:
@@ -274,6 +278,19 @@ def prof_read() -> dict:
         check(load().b3d_prof_read(fam, C.byref(ms), C.byref(n)), "b3d_prof_read")
         out[name] = (ms.value, n.value)
     return out
+
+
+def prof_pair_overhead_us(stream: int, reps: int = 256) -> float:
+    """Average elapsed time of an empty HIP event pair on ``stream`` (us): what a pair adds to the kernel it brackets."""
+    out = C.c_double()
+    check(load().b3d_prof_pair_overhead_us(stream, reps, C.byref(out)), "b3d_prof_pair_overhead_us")
+    return out.value
+
+
+def features() -> dict:
+    """Execution plans of this build (which first layers are evaluated per node): for FLOP accounting."""
+    f = int(load().b3d_features())
+    return {"pose_hoist": bool(f & 1), "clr_hoist_mp": bool(f & 2), "clr_hoist_att": bool(f & 4)}
 
 
 def knn_gat(x: torch.Tensor, node_timestamps: torch.Tensor, conv, k: int = 20):

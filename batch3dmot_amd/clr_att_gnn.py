@@ -253,16 +253,41 @@ class GNN(nn.Module):
         self.defer_knn_join = False    # True: B3D_FLAG_DEFER_SIDE_JOIN in training forwards
         self.keep_workspace = False
         self._last_workspace = None
+        self.mask_stream = None         # see modality_rows()
         self._grad_sink = None          # set by optim.FlatAdam: backward writes gradients into its flat buffer
 
     def _hip_params(self):
         """Parameters whose gradients ``backward`` of the HIP path produces, in C-ABI struct order."""
         return _param_list(self)
 
-    def encode_modalities(self, data, cache: "Optional[EmbeddingCache]" = None, node_ids=None):
+    def modality_rows(self, data):
+        """clr_att_gnn.py:107-121 as two launches (``b3d_modality_mask``) and two compactions: the node ids
+        (int64, ascending) of the rows that carry LiDAR / radar points.  The row COUNTS are shapes downstream
+        (the encoders run on the compacted rows, :131,139), so they must reach the host: one synchronisation.
+
+        With ``self.mask_stream`` set (a ``torch.cuda.Stream``) the masks run there and only that stream is
+        waited for, so the caller's stream keeps its queue -- the host can enqueue step k+1 while step k runs.
+        The caller then guarantees that ``lidar_feats`` / ``radar_feats`` are complete when this is called (resident
+        inputs, or a loader that has already made the caller's stream wait for its copy)."""
+        lidar_feats, radar_feats = data.lidar_feats, data.radar_feats
+        ms = self.mask_stream
+        if ms is None or torch.cuda.is_current_stream_capturing():
+            return (torch.nonzero(modality_present(lidar_feats)).squeeze(1),
+                    torch.nonzero(modality_present(radar_feats)).squeeze(1))
+        cur = torch.cuda.current_stream(lidar_feats.device)
+        with torch.cuda.stream(ms):
+            li = torch.nonzero(modality_present(lidar_feats)).squeeze(1)      # nonzero() waits for `ms` only
+            ri = torch.nonzero(modality_present(radar_feats)).squeeze(1)
+        cur.wait_stream(ms)
+        li.record_stream(cur)
+        ri.record_stream(cur)
+        return li, ri
+
+    def encode_modalities(self, data, cache: "Optional[EmbeddingCache]" = None, node_ids=None, rows=None):
         """The frozen, adjacent part (clr_att_gnn.py:107-141): presence masks, ResNet / PointNet /
         RadarNet embeddings of the rows that have the modality, and the sticky ``.eval()`` switch
-        when fewer than two rows have it.
+        when fewer than two rows have it.  ``rows``: the result of ``modality_rows(data)`` if the caller
+        already holds it.
 
         With ``cache`` (inference: every encoder in eval mode) a detection is encoded once per scene instead of
         once per window it appears in -- with the reference's stride-1 windows of ``batch_size_graph`` frames
@@ -271,16 +296,13 @@ class GNN(nn.Module):
         if cache is not None:
             return self._encode_cached(data, cache, node_ids)
         img_feats, lidar_feats, radar_feats = data.img_feats, data.lidar_feats, data.radar_feats
-        pcl_nodes = modality_present(lidar_feats)
-        pr_nodes = modality_present(radar_feats)
+        lidar_nodes, radar_nodes = rows if rows is not None else self.modality_rows(data)
         with torch.no_grad():
             x_img = self.resnet.encode(img_feats).float().contiguous()
-            lidar_nodes = torch.nonzero(pcl_nodes).squeeze(1)
             if lidar_nodes.numel() < 2:
                 self.pointnet.eval()
                 self.fc_lidar_encoder.eval()
             pointnet_out = self.pointnet.forward_feat(lidar_feats[lidar_nodes].view(-1, 3, 128)).float().contiguous()
-            radar_nodes = torch.nonzero(pr_nodes).squeeze(1)
             if radar_nodes.numel() < 2:
                 self.radarnet.eval()
                 self.fc_radar_encoder.eval()
@@ -314,7 +336,9 @@ class GNN(nn.Module):
         return (cache.img[rows].contiguous(), cache.lidar[rows[lidar_nodes]].contiguous(), lidar_nodes.to(torch.int32).contiguous(),
                 cache.radar[rows[radar_nodes]].contiguous(), radar_nodes.to(torch.int32).contiguous())
 
-    def forward(self, data, encoded=None):
+    def forward(self, data, encoded=None, rows=None):
+        """``encoded``: the result of ``encode_modalities(data)`` (precomputed encoder outputs); ``rows``: the result
+        of ``modality_rows(data)``.  Both optional; the reference signature is ``forward(data)``."""
         if not self.use_attention:
             raise NotImplementedError("use_attention=False is a shape error in the reference "
                                       "(clr_att_gnn.py:166-170 vs :82)")
@@ -329,7 +353,7 @@ class GNN(nn.Module):
             raise ValueError("empty graph: the reference's callers skip these (predict.py:179-180)")
         edge_attr = edge_attr.to(torch.float64).contiguous()
         node_timestamps = node_timestamps.to(torch.int64).contiguous()
-        x_img, pointnet_out, lidar_nodes, radarnet_out, radar_nodes = encoded if encoded is not None else self.encode_modalities(data)
+        x_img, pointnet_out, lidar_nodes, radarnet_out, radar_nodes = encoded if encoded is not None else self.encode_modalities(data, rows=rows)
         graph = getattr(data, "_b3d_graph", None)
         if graph is None or graph.N != pose_feats.size(0) or graph.E != edge_index.size(1) \
                 or graph._keep.data_ptr() != edge_index.data_ptr():

@@ -181,5 +181,29 @@ extern "C" int b3d_prof_read(int family, double* total_ms, int* launches) {
   return B3D_OK;
 }
 
-extern "C" int b3d_version(void) { return 100; }   // 0.1.0
+// Cost of one event pair as the family timers see it: the elapsed time between two events recorded back to back
+// with nothing between them, averaged over `reps` pairs on `stream`.  bench.py subtracts it from the per-launch
+// averages (a pair around a 25 us kernel read 2.8 us more than rocprofv3's duration of the same kernel).
+extern "C" int b3d_prof_pair_overhead_us(b3d_stream stream_, int reps, double* out_us) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!out_us || reps < 1 || reps > 4096) return b3d::fail(B3D_ERR_ARG, "b3d_prof_pair_overhead_us: bad argument");
+  std::vector<hipEvent_t> ev(2 * (size_t)reps);
+  for (auto& e : ev) B3D_HIP_CHECK(hipEventCreate(&e));
+  for (int i = 0; i < reps; ++i) {
+    B3D_HIP_CHECK(hipEventRecord(ev[2 * i], stream));
+    B3D_HIP_CHECK(hipEventRecord(ev[2 * i + 1], stream));
+  }
+  B3D_HIP_CHECK(hipEventSynchronize(ev.back()));
+  double tot = 0.0;
+  for (int i = 0; i < reps; ++i) {
+    float ms = 0.f;
+    B3D_HIP_CHECK(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
+    tot += ms;
+  }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  *out_us = 1e3 * tot / reps;
+  return B3D_OK;
+}
+
+extern "C" int b3d_version(void) { return 200; }   // 0.2.0
 extern "C" const char* b3d_last_error(void) { return b3d::last_error_buf(); }

@@ -303,10 +303,10 @@ static int pack_all(const b3d_clr_weights* pw, Ws& w, bool training, hipStream_t
 
 template <class Seq, bool RELU, bool BIAS, class In>
 static int wide(const char* name, const In& in, long rows, float* out, int ostride, int ocol0, const float* mask,
-                const float* wp, hipStream_t stream) {
+                const float* wp, hipStream_t stream, int family = B3D_K_ATT_FWD) {
   WideArgs<In> a;
   a.rows = (int)rows; a.in = in; a.out = out; a.out_stride = ostride; a.out_col0 = ocol0; a.mask = mask; a.wpack = wp;
-  return launch_rows<kNWEdge>(wide_linear_kernel<Seq, RELU, BIAS, In, kNWEdge>, name, a, rows, stream, B3D_K_OTHER, chain_lds<Seq>());
+  return launch_rows<kNWEdge>(wide_linear_kernel<Seq, RELU, BIAS, In, kNWEdge>, name, a, rows, stream, family, chain_lds<Seq>());
 }
 
 // One modality's out_proj(v_proj(x)) on all nodes: x = xsens[:, xc : xc+DD] -> s[:, sc : sc+DD]
@@ -343,6 +343,13 @@ static int affine_bwd(Ws& w, const b3d_graph* g, int m, int N, int xc, int sc, h
 
 using namespace b3d;
 using namespace b3d::clr;
+
+extern "C" uint32_t b3d_features(void) {
+  uint32_t f = 0;
+  const char* e = getenv("B3D_HOIST");
+  if (!e || atoi(e) != 0) f |= B3D_FEATURE_POSE_HOIST;
+  return f;
+}
 
 extern "C" int b3d_modality_mask(const float* feats, int32_t N, int32_t width, uint8_t* has, b3d_stream stream_) {
   B3D_REQUIRE(feats && has && N >= 0 && width > 0, "b3d_modality_mask: bad argument");
@@ -549,11 +556,11 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
   }
 
   // ---- att_edge_encoder backward: d att (summed over the layers) -> d(s[dst] | s[src] | e) ------------
-  B3D_TRY((wide<SeqAT4T, false, false>("att_edge_encoder.8^T", LoadAligned<4>{w.da_acc, nullptr, 64, 0}, E, w.dA[0], 128, 0, w.A[3], w.wp_atT[4], stream)));
-  B3D_TRY((wide<SeqAT3T, false, false>("att_edge_encoder.6^T", LoadAligned<8>{w.dA[0], nullptr, 128, 0}, E, w.dA[1], 256, 0, w.A[2], w.wp_atT[3], stream)));
-  B3D_TRY((wide<SeqAT2T, false, false>("att_edge_encoder.4^T", LoadAligned<16>{w.dA[1], nullptr, 256, 0}, E, w.dA[2], 384, 0, w.A[1], w.wp_atT[2], stream)));
-  B3D_TRY((wide<SeqAT1T, false, false>("att_edge_encoder.2^T", LoadAligned<24>{w.dA[2], nullptr, 384, 0}, E, w.dA[3], 512, 0, w.A[0], w.wp_atT[1], stream)));
-  B3D_TRY((wide<SeqAT0T, false, false>("att_edge_encoder.0^T", LoadAligned<32>{w.dA[3], nullptr, 512, 0}, E, w.dIn, 640, 0, nullptr, w.wp_atT[0], stream)));
+  B3D_TRY((wide<SeqAT4T, false, false>("att_edge_encoder.8^T", LoadAligned<4>{w.da_acc, nullptr, 64, 0}, E, w.dA[0], 128, 0, w.A[3], w.wp_atT[4], stream, B3D_K_ATT_BWD)));
+  B3D_TRY((wide<SeqAT3T, false, false>("att_edge_encoder.6^T", LoadAligned<8>{w.dA[0], nullptr, 128, 0}, E, w.dA[1], 256, 0, w.A[2], w.wp_atT[3], stream, B3D_K_ATT_BWD)));
+  B3D_TRY((wide<SeqAT2T, false, false>("att_edge_encoder.4^T", LoadAligned<16>{w.dA[1], nullptr, 256, 0}, E, w.dA[2], 384, 0, w.A[1], w.wp_atT[2], stream, B3D_K_ATT_BWD)));
+  B3D_TRY((wide<SeqAT1T, false, false>("att_edge_encoder.2^T", LoadAligned<24>{w.dA[2], nullptr, 384, 0}, E, w.dA[3], 512, 0, w.A[0], w.wp_atT[1], stream, B3D_K_ATT_BWD)));
+  B3D_TRY((wide<SeqAT0T, false, false>("att_edge_encoder.0^T", LoadAligned<32>{w.dA[3], nullptr, 512, 0}, E, w.dIn, 640, 0, nullptr, w.wp_atT[0], stream, B3D_K_ATT_BWD)));
 
   // ---- modality attention (per node) backward, then the modality heads -------------------------------
   B3D_TRY(affine_bwd<96>(w, g, 0, N, 0, 192, stream));

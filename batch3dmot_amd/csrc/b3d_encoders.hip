@@ -213,6 +213,7 @@ static int point_feat_launch(const b3d_linear* conv, const float* x, const float
 #define B3D_POINT_LAUNCH(PP, ST)                                                                      \
   do {                                                                                                \
     B3D_TRY(set_lds(point_feat_kernel<PP, ST>, kPointLds));                                           \
+    ProfScope ps(B3D_K_POINT_FEAT, stream);                                                           \
     hipLaunchKernelGGL((point_feat_kernel<PP, ST>), dim3(groups), dim3(512), kPointLds, stream, a);   \
   } while (0)
   if (P == 128 && stats) B3D_POINT_LAUNCH(128, true);

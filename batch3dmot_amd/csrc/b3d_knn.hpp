@@ -363,8 +363,11 @@ inline int knn_gat_block(KnnWs& ws, const float* x, const int64_t* ts, int N, co
     }
     ws.ranked = true;
   }
-  hipLaunchKernelGGL(knn_tile_kernel<D>, dim3((N + kKnnCentres - 1) / kKnnCentres), dim3(kKnnCentres * 64), 0, stream,
-                     x, N, k, ws.order, ws.fbeg, ws.fend, ws.nbr, ws.cnt);
+  {
+    ProfScope ps(B3D_K_KNN, stream);
+    hipLaunchKernelGGL(knn_tile_kernel<D>, dim3((N + kKnnCentres - 1) / kKnnCentres), dim3(kKnnCentres * 64), 0, stream,
+                       x, N, k, ws.order, ws.fbeg, ws.fend, ws.nbr, ws.cnt);
+  }
   B3D_TRY(launch_check("knn_tile_kernel"));
   const float* h = h_pre ? h_pre : ws.h;
   const int hs = h_pre ? h_stride : D;
@@ -376,9 +379,12 @@ inline int knn_gat_block(KnnWs& ws, const float* x, const int64_t* ts, int N, co
     a.in = LoadAligned<D / 16>{x, nullptr, D, 0};
     a.out = StoreAligned<D / 16>{ws.h, nullptr, D, 0};
     a.wpack = ws.wp;
-    B3D_TRY(launch_rows<kNWNode>(chain_fwd_kernel<S, 0u, LoadAligned<D / 16>, StoreAligned<D / 16>, kNWNode>, "gat_linear", a, N, stream, B3D_K_OTHER, chain_lds<S>()));
+    B3D_TRY(launch_rows<kNWNode>(chain_fwd_kernel<S, 0u, LoadAligned<D / 16>, StoreAligned<D / 16>, kNWNode>, "gat_linear", a, N, stream, B3D_K_KNN, chain_lds<S>()));
   }
-  hipLaunchKernelGGL(gat_aggregate_kernel<D>, dim3((N + 3) / 4), dim3(256), 0, stream, h, hs, N, ws.nbr, ws.cnt, gat.att_src, gat.att_dst, gat.bias, ws.y);
+  {
+    ProfScope ps(B3D_K_KNN, stream);
+    hipLaunchKernelGGL(gat_aggregate_kernel<D>, dim3((N + 3) / 4), dim3(256), 0, stream, h, hs, N, ws.nbr, ws.cnt, gat.att_src, gat.att_dst, gat.bias, ws.y);
+  }
   return launch_check("gat_aggregate_kernel");
 }
 

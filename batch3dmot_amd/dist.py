@@ -28,7 +28,10 @@ class FlatGradSync:
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad and id(p) not in skip]
         self.group = group
         self._flat: Optional[torch.Tensor] = None
-        self._avg: Optional[bool] = None
+        # The reduction is chosen ONCE, here: RCCL ("nccl") averages inside the collective; every other backend sums
+        # and the result is scaled.  (A collective that raised may have run on some ranks and not on others, so
+        # nothing is retried with a different op.)
+        self._avg = bool(dist.is_initialized() and dist.get_backend(group) == "nccl")
 
     @property
     def world_size(self) -> int:
@@ -41,14 +44,9 @@ class FlatGradSync:
             return
         if self.flat_opt is not None and (force or not self.flat_opt.fresh):
             g = self.flat_opt.flat_grad
-            if self._avg is None:
-                self._avg = dist.get_backend(self.group) == "nccl"   # RCCL averages inside the collective
             if self._avg:
-                try:
-                    dist.all_reduce(g, op=dist.ReduceOp.AVG, group=self.group)
-                except Exception:                                  # backend without AVG: sum, then scale
-                    self._avg = False
-            if not self._avg:
+                dist.all_reduce(g, op=dist.ReduceOp.AVG, group=self.group)
+            else:
                 dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
                 g.mul_(1.0 / self.world_size)
         live = [p for p in self.params if p.grad is not None]

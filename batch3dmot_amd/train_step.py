@@ -55,11 +55,11 @@ def fused_edge_loss(out: torch.Tensor, data, batch_size: int, loss_kind: str = "
 
 
 def forward_backward(gnn, data, optimizer, batch_size: int = 2, loss_kind: str = "cb", logits: bool = False,
-                     fused_loss: Optional[bool] = None):
+                     fused_loss: Optional[bool] = None, forward_kwargs: Optional[dict] = None):
     """The part of a step in front of the gradient exchange: forward, ``zero_grad``, loss, backward.  Split out so
     that a data-parallel loop can capture it (and ``optimizer.step()``) into hipGraphs and keep only the all-reduce
     eager between the two replays."""
-    out, aux = gnn(data)
+    out, aux = gnn(data, **forward_kwargs) if forward_kwargs else gnn(data)
     if fused_loss is None:
         fused_loss = out.is_cuda
     if hasattr(optimizer, "flat_grad"):
@@ -76,12 +76,12 @@ def forward_backward(gnn, data, optimizer, batch_size: int = 2, loss_kind: str =
 
 
 def train_step(gnn, data, optimizer, batch_size: int = 2, loss_kind: str = "cb", logits: bool = False,
-               grad_sync: Optional[object] = None, fused_loss: Optional[bool] = None):
+               grad_sync: Optional[object] = None, fused_loss: Optional[bool] = None, forward_kwargs: Optional[dict] = None):
     """One optimisation step; ``grad_sync`` (batch3dmot_amd.dist.FlatGradSync) averages gradients over
     the ranks of a data-parallel job between backward and the optimizer step.  ``fused_loss``
     (default: on when the model output lives on the GPU) takes loss and d loss/d out from
     ``b3d_edge_loss`` and seeds ``out.backward`` with it."""
-    loss, out, aux = forward_backward(gnn, data, optimizer, batch_size, loss_kind, logits, fused_loss)
+    loss, out, aux = forward_backward(gnn, data, optimizer, batch_size, loss_kind, logits, fused_loss, forward_kwargs)
     if grad_sync is not None:
         grad_sync.sync()
     optimizer.step()

@@ -5,24 +5,27 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Workload (`configs[1]`): pose_config.yaml poses-only GNN (PoseGNN, depth 6), one step = graph
-structure build + forward + class-balanced BCE loss + backward + gradient all-reduce (N > 1) +
-Adam step on a collated batch of 2 synthetic graphs (1,500 nodes / ~15,000 edges each, T = 5
-frames), i.e. ~3,000 nodes / ~30,000 edges per GPU.  Inputs are resident in HBM before the timed
-region.  Weak scaling: every rank processes its own batches; no data-path collective.
+Workload (default, BASELINE.json `configs[3]`, the configuration the 1/2/4/8-GPU metric is quoted on): the
+camera+LiDAR+radar GNN (clr_att_gnn.py:16-188, depth 6) training step of train.py:124-160 -- modality masks,
+the three frozen encoders in train mode (BatchNorm with batch statistics, clr_att_gnn.py:26-33), graph structure
+build, forward, class-balanced BCE, backward, gradient all-reduce (N > 1), Adam -- on a collated batch of 2 synthetic
+graphs (1,500 nodes / ~15,500 edges each, T = 5 frames): ~3,000 nodes / ~31,000 edges per GPU.  Inputs are resident
+in HBM before the timed region.  Weak scaling: every rank processes its own batches; the only collective is the flat
+all-reduce of the 1,310,193 gradient-carrying parameters (5.24 MB).
 
-Prints ONE JSON line (rank 0).  `roofline` describes the kernel family with the largest summed
-device time, measured with HIP events on the launch stream (b3d_prof_*); `kernels` lists every
-instrumented family; `cpu_baseline` times the CPU oracle (the restated reference path) on the
-host cores, rank 0, N = 1 only.
+    --model pose        `configs[1]`: pose_config.yaml poses-only PoseGNN training step (round-1 headline)
+    --encoders precomputed   the camera+LiDAR+radar step with the encoder outputs given
 
-At N = 1 the timed region replays hipGraph-captured steps (one graph per pool batch, each holding the
-whole step): the device step takes ~1.0 ms while enqueueing it eagerly takes 0.5-0.7 ms of host time --
-1.6 ms on a busy host, which then throttles the GPU.  Event records cannot be captured, so the kernel
-families are timed in an eager pass of the same K steps right after the timed region (`timed_region` in
-the output says which mode ran; `--no-graph` keeps everything eager and inside the timed region).
-At N > 1 the steps are enqueued eagerly (the all-reduce sits inside the step); `--split-graph` replays two graphs
-per step (forward..backward; Adam) around the eager flat all-reduce -- validated at N = 1 only, hence opt-in.
+At N = 1 the default run also reports both of those as `secondary` figures (shorter timed regions).
+
+Prints ONE JSON line (rank 0).  `roofline` describes the kernel family with the largest summed device time, measured
+with HIP events on the launch stream (b3d_prof_*); `cpu_baseline` times the CPU oracle (the restated reference
+path) on the host cores, rank 0, N = 1 only.
+
+Timed region at N = 1: hipGraph replays (one captured step per pool batch; what cannot be captured -- the modality
+masks' row compaction, whose counts are shapes -- runs eagerly in front of each replay and feeds it).  Event records
+cannot be captured, so the kernel families are timed in an eager pass of the same K steps right after the timed
+region.  `--no-graph` and every N > 1 run enqueue eagerly (the all-reduce sits inside the step).
 """
 from __future__ import annotations
 
@@ -40,20 +43,295 @@ if ROOT not in sys.path:
 
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md, v_mfma_f32_16x16x4_f32 (= fp32 vector peak)
 PEAK_HBM_GBS = 8000.0
-
-# MACs per edge / node of one CausalMessagePassing layer (pose_gnn.py:94-120)
-MAC_EDGE = 128 * 96 + 96 * 64 + 64 * 32 + 2 * (128 * 96 + 96 * 64)     # 57,344
-MAC_NODE = 128 * 96 + 96 * 64 + 64 * 48                                  # 21,504
+BOUND = {"mp_edge_fwd": "mfma", "mp_edge_bwd": "mfma", "wgrad_edge": "hbm", "mp_node_fwd": "hbm", "mp_node_bwd": "hbm",
+         "att_fwd": "mfma", "att_bwd": "mfma", "point_feat": "mfma"}
 
 
-def algorithmic_bytes_step(n_nodes: int, n_edges: int) -> float:
-    """compulsory fp32 traffic, fwd = 1,572 E + 9,868 N; fwd+bwd = 3x."""
-    return 3.0 * (1572.0 * n_edges + 9868.0 * n_nodes)
+# ---- work models -------------------------------------------------------------------------------------------------
+class PoseWork:
+    """pose_gnn.py:94-120 widths.  MACs per row of one CausalMessagePassing layer."""
+    name = "pose"
+    MAC_EU, MAC_MSG, MAC_NODE = 128 * 96 + 96 * 64 + 64 * 32, 2 * (128 * 96 + 96 * 64), 128 * 96 + 96 * 64 + 64 * 48
+    # executed: the node columns of the three first layers are evaluated per node (csrc/b3d_hoist.hpp)
+    X_EU, X_MSG = 32 * 96 + 96 * 64 + 64 * 32, 2 * (32 * 96 + 96 * 64)
+    X_NODE_TAB, X_NODE_GP = 48 * 384, 384 * 96
+
+    @staticmethod
+    def step_bytes(n, e):       # SURVEY.md 8d: fwd = 1,572 E + 9,868 N; fwd+bwd = 3x
+        return 3.0 * (1572.0 * e + 9868.0 * n)
+
+    @staticmethod
+    def step_flops(n, e, **_):  # fwd = E * 690,824 + N * 264,144 (2 * MAC); bwd = 2 * fwd
+        return 3.0 * (690824.0 * e + 264144.0 * n)
+
+    @classmethod
+    def families(cls, n, e, depth, **_):
+        alg = {"mp_edge_fwd": 2.0 * (cls.MAC_EU + cls.MAC_MSG) * e, "mp_edge_bwd": 2.0 * (cls.MAC_EU + cls.MAC_MSG) * e,
+               "wgrad_edge": 2.0 * (e * (cls.MAC_EU * depth + cls.MAC_MSG * (depth - 1)) + n * cls.MAC_NODE * (depth - 1)),
+               "mp_node_fwd": 2.0 * cls.MAC_NODE * n, "mp_node_bwd": 2.0 * cls.MAC_NODE * n}
+        exe = {"mp_edge_fwd": 2.0 * (cls.X_EU + cls.X_MSG) * e, "mp_edge_bwd": 2.0 * (cls.X_EU + cls.X_MSG) * e,
+               "wgrad_edge": 2.0 * (e * (cls.X_EU * depth + cls.X_MSG * (depth - 1))
+                                    + n * (cls.MAC_NODE * (depth - 1) + 2 * 96 * 48 * depth + 4 * 96 * 48 * (depth - 1))),
+               "mp_node_fwd": 2.0 * (cls.MAC_NODE + cls.X_NODE_TAB) * n, "mp_node_bwd": 2.0 * (cls.MAC_NODE + cls.X_NODE_GP) * n}
+        byts = {"mp_edge_fwd": e * (8 + 4 * (32 + 32 + 64 + 64 + 352)),      # idx, e in/out, fut, past, saved hidden
+                "mp_edge_bwd": e * (8 + 4 * (32 + 32 + 352 + 192 + 384)),    # de out/in, saved, per-edge node grads, G
+                "wgrad_edge": e * 4 * ((192 + 160 + 64) * depth + (192 + 128 + 192 + 32) * (depth - 1)),
+                "mp_node_fwd": e * 4 * 128 + n * 4 * (128 + 48 + 160),
+                "mp_node_bwd": e * 4 * 192 + n * 4 * (128 + 48 + 48 + 160 + 208)}
+        return alg, exe, byts
 
 
-def algorithmic_flops_step(n_nodes: int, n_edges: int) -> float:
-    """fwd = E * 690,824 + N * 264,144 (2 * MAC); bwd = 2 * fwd."""
-    return 3.0 * (690824.0 * n_edges + 264144.0 * n_nodes)
+class ClrWork:
+    """clr_att_gnn.py:196-222 widths (+ att_edge_encoder :81-91)."""
+    name = "clr"
+    MAC_EU, MAC_MSG = 320 * 256 + 256 * 128 + 128 * 64, 2 * (256 * 192 + 192 * 128)            # 122,880 + 147,456
+    MAC_NODE = 256 * 192 + 192 * 128 + 128 * 96                                                  # 86,016
+    MAC_ATT = 640 * 512 + 512 * 384 + 384 * 256 + 256 * 128 + 128 * 64                           # 663,552
+    # executed once the node columns of a first layer are evaluated per node: edge_update.0 keeps e | att (128
+    # columns), the message stacks keep e' (64), att_edge_encoder.0 keeps e (64)
+    X_EU, X_MSG = 128 * 256 + 256 * 128 + 128 * 64, 2 * (64 * 192 + 192 * 128)
+    X_ATT = 64 * 512 + 512 * 384 + 384 * 256 + 256 * 128 + 128 * 64
+    X_NODE_TAB = 96 * (2 * 256 + 2 * 192)          # per-node table of the next layer's first layers
+    X_NODE_GP = (2 * 256 + 2 * 192) * 96 + 2 * 192 * 96
+    X_ATT_NODE = 2 * 288 * 512                     # per-node parts of att_edge_encoder.0
+    MAC_POINT_L = 128 * (3 * 64 + 64 * 128 + 128 * 1024)      # one PointNet stack (STN or trunk) per LiDAR cloud
+    MAC_POINT_R = 64 * (4 * 64 + 64 * 128 + 128 * 1024)
+
+    @staticmethod
+    def step_bytes(n, e):       # SURVEY.md 8d: fwd ~ 4,900 E + 20,500 N; x3
+        return 3.0 * (4900.0 * e + 20500.0 * n)
+
+    @staticmethod
+    def step_flops(n, e, f_l=0.7, f_r=0.25, **_):   # SURVEY.md 8d (attention hoisted, encoders excluded)
+        return 3.0 * (4581776.0 * e + n * 2.0 * (521616 + 59392 + 73728 * f_l + 81920 * f_r))
+
+    @classmethod
+    def families(cls, n, e, depth, hoist_mp=False, hoist_att=False, nl=0, nr=0, **_):
+        eu, msg = (cls.X_EU, cls.X_MSG) if hoist_mp else (cls.MAC_EU, cls.MAC_MSG)
+        att = cls.X_ATT if hoist_att else cls.MAC_ATT
+        tab = cls.X_NODE_TAB if hoist_mp else 0
+        gp = cls.X_NODE_GP if hoist_mp else 0
+        alg = {"mp_edge_fwd": 2.0 * (cls.MAC_EU + cls.MAC_MSG) * e, "mp_edge_bwd": 2.0 * (cls.MAC_EU + cls.MAC_MSG) * e,
+               "wgrad_edge": 2.0 * (e * (cls.MAC_EU * depth + cls.MAC_MSG * (depth - 1) + cls.MAC_ATT)
+                                    + n * cls.MAC_NODE * (depth - 1)),
+               "mp_node_fwd": 2.0 * cls.MAC_NODE * n, "mp_node_bwd": 2.0 * cls.MAC_NODE * n,
+               "att_fwd": 2.0 * cls.MAC_ATT * e / 5.0, "att_bwd": 2.0 * cls.MAC_ATT * e / 5.0,      # five launches each
+               "point_feat": 2.0 * (2 * cls.MAC_POINT_L * nl + cls.MAC_POINT_R * nr) / 3.0}       # three launches
+        exe = {"mp_edge_fwd": 2.0 * (eu + msg) * e, "mp_edge_bwd": 2.0 * (eu + msg) * e,
+               "wgrad_edge": 2.0 * (e * (eu * depth + msg * (depth - 1) + att) + n * (cls.MAC_NODE + tab) * (depth - 1)
+                                    + (n * cls.X_ATT_NODE if hoist_att else 0)),
+               "mp_node_fwd": 2.0 * (cls.MAC_NODE + tab) * n, "mp_node_bwd": 2.0 * (cls.MAC_NODE + gp) * n,
+               "att_fwd": 2.0 * att * e / 5.0, "att_bwd": 2.0 * att * e / 5.0,
+               "point_feat": alg["point_feat"]}
+        sav = 256 + 128 + 192 + 192
+        byts = {"mp_edge_fwd": e * (8 + 4 * (64 + 64 + 64 + 2 * 128 + sav)),
+                "mp_edge_bwd": e * (8 + 4 * (64 + 64 + 2 * 64 + sav + (256 + 128 + 64 + 192 + 192) + (0 if hoist_mp else 384))),
+                "wgrad_edge": e * 4 * ((256 + 128 + 64 + 256 + 128 + 128) * depth + (2 * 192 + 2 * 128 + 2 * 192 + 64) * (depth - 1)
+                                       + 2 * (512 + 384 + 256 + 128) + 64 + 64),
+                "mp_node_fwd": e * 4 * 256 + n * 4 * (256 + 96 + 320), "mp_node_bwd": e * 4 * 384 + n * 4 * (256 + 96 + 96 + 320 + 416),
+                "att_fwd": e * 4 * (64 + 2 * (512 + 384 + 256 + 128) + 64) / 5.0,
+                "att_bwd": e * 4 * (64 + 3 * (512 + 384 + 256 + 128) + 640) / 5.0,
+                "point_feat": 4.0 * (2 * nl * (3 * 128 + 4 * 1024) + nr * (4 * 64 + 4 * 1024)) / 3.0}
+        return alg, exe, byts
+
+
+# ---- workloads -----------------------------------------------------------------------------------------------------
+class Workload:
+    """One training step over a pool of HBM-resident batches.  `step(i)`: the whole step, eagerly.  `pre(i)` +
+    `captured(i)`: the same step split into the part that cannot be captured into a hipGraph (runs eagerly in front of
+    every replay and feeds it) and the part that can."""
+
+    def __init__(self, kind, dev, rank, world, args, encoders="frozen"):
+        from batch3dmot_amd import encoders as enc_mod, synth
+        from batch3dmot_amd.dist import FlatGradSync
+        from batch3dmot_amd.train_step import make_optimizer
+        self.kind, self.dev, self.encoders = kind, dev, encoders
+        torch.manual_seed(5621)                      # gnn.manual_seed, pose_config.yaml:96
+        if kind == "pose":
+            from batch3dmot_amd.pose_gnn import PoseGNN
+            self.work = PoseWork
+            self.model = PoseGNN().to(dev)
+            self.logits = True
+        else:
+            from batch3dmot_amd.clr_att_gnn import GNN
+            self.work = ClrWork
+            self.model = GNN(enc_mod.ResNetAE(), enc_mod.PointNetClassifier(k=7), enc_mod.RadarNetClassifier(k=7)).to(dev)
+            self.model.mask_stream = torch.cuda.Stream(dev)     # inputs are resident: the masks need not queue behind the previous step
+            self.logits = False
+        self.model.run_dead_knn = not args.no_dead_knn
+        self.model.single_stream = True
+        self.model.train()
+        self.opt = make_optimizer(self.model, capturable=True)   # Adam(lr 1e-4, wd 1e-4, betas .9/.999): train.py:106-109
+        self.sync = FlatGradSync(self.model.parameters(), flat=self.opt if hasattr(self.opt, "flat_grad") else None) if world > 1 else None
+        self.pool_cpu = [synth.make_batch(2, 1500, 15000, first_graph_idx=rank * 1000 + 2 * i, modalities=(kind == "clr"))
+                         for i in range(4)]
+        self.pool = [b.to(dev) for b in self.pool_cpu]
+        self.n_nodes = self.pool[0].pose_feats.size(0)
+        self.edges = [b.edge_index.size(1) for b in self.pool]
+        self.enc = None
+        self.rows_static = None
+        if kind == "clr":
+            rows = [self.model.modality_rows(b) for b in self.pool]
+            self.nl = sum(int(r[0].numel()) for r in rows) / len(rows)
+            self.nr = sum(int(r[1].numel()) for r in rows) / len(rows)
+            if encoders == "precomputed":
+                self.enc = [self.model.encode_modalities(b, rows=r) for b, r in zip(self.pool, rows)]
+            else:
+                self.rows_static = [(r[0].clone(), r[1].clone()) for r in rows]
+
+    def _run(self, i, kwargs):
+        from batch3dmot_amd.train_step import train_step
+        b = self.pool[i % len(self.pool)]
+        if hasattr(b, "_b3d_graph"):
+            del b._b3d_graph                     # the CSR/CSC build is part of every step
+        return train_step(self.model, b, self.opt, batch_size=2, loss_kind="cb", logits=self.logits, grad_sync=self.sync,
+                          forward_kwargs=kwargs)
+
+    def step(self, i):
+        if self.enc is not None:
+            return self._run(i, {"encoded": self.enc[i % len(self.pool)]})
+        return self._run(i, None)
+
+    def pre(self, i):
+        if self.rows_static is None:
+            return
+        k = i % len(self.pool)
+        li, ri = self.model.modality_rows(self.pool[k])           # masks + compaction, every step
+        sl, sr = self.rows_static[k]
+        if li.numel() != sl.numel() or ri.numel() != sr.numel():
+            raise RuntimeError("modality row counts changed under a captured step")
+        sl.copy_(li)                                              # the replay consumes THIS step's rows
+        sr.copy_(ri)
+
+    def captured(self, i):
+        k = i % len(self.pool)
+        if self.enc is not None:
+            return self._run(i, {"encoded": self.enc[k]})
+        if self.rows_static is not None:
+            return self._run(i, {"rows": self.rows_static[k]})
+        return self._run(i, None)
+
+    def describe(self, world):
+        if self.kind == "pose":
+            return ("pose_config.yaml poses-only PoseGNN depth 6, training step (CSR/CSC build + fwd + cb-BCE + bwd + Adam"
+                    + (" + flat RCCL grad all-reduce" if world > 1 else "") + ")")
+        enc = ("frozen ResNetAE / PointNet / RadarNet encoders in train mode inside the step" if self.encoders == "frozen"
+               else "encoder outputs precomputed")
+        return ("camera+LiDAR+radar GNN (clr_att_gnn) depth 6, training step (modality masks + " + enc
+                + " + CSR/CSC build + fwd + cb-BCE + bwd + Adam" + (" + flat RCCL grad all-reduce of 5.24 MB" if world > 1 else "") + ")")
+
+
+def measure(wl: Workload, args, world, dist, steps, warmup, ramp_ms, use_graph):
+    """W instrumented warm-up steps, optional hipGraph capture, untimed clock ramp, K timed steps (barrier +
+    synchronize on both sides), eager instrumented pass.  Returns a dict of raw measurements."""
+    from batch3dmot_amd import _lib
+    dev = wl.dev
+    pool_n = len(wl.pool)
+    fam_names = list(_lib.KERNEL_FAMILIES)
+    # Warm-up doubles as the instrumented pass: every kernel family is timed with HIP event pairs (diagnostic
+    # table) and the family with the largest device time is picked; the TIMED region carries no events.
+    _lib.prof_enable(True)
+    for i in range(warmup):
+        wl.step(i)
+    torch.cuda.synchronize()
+    fam_all = _lib.prof_read() if warmup > 0 else None
+    _lib.prof_enable(False)
+    graphs, graph_note = None, None
+    if use_graph and world == 1:
+        try:
+            graphs = []
+            torch.cuda.synchronize()
+            cap_stream = torch.cuda.Stream()
+            cap_stream.wait_stream(torch.cuda.current_stream())
+            for i in range(pool_n):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=cap_stream, capture_error_mode="thread_local"):
+                    wl.captured(i)
+                graphs.append(g)
+            torch.cuda.current_stream().wait_stream(cap_stream)
+            torch.cuda.synchronize()
+        except Exception as exc:                                   # capture unsupported here: eager timed region
+            graphs = None
+            graph_note = f"hipGraph capture failed ({type(exc).__name__}: {str(exc)[:200]}); eager timed region"
+            torch.cuda.synchronize()
+
+    def timed_step(i):
+        if graphs is not None:
+            wl.pre(i)
+            graphs[i % pool_n].replay()
+        else:
+            wl.step(i)
+
+    # Clock ramp (untimed): a fresh box idles at ~550 MHz; keep the GPU busy until ramp_ms have passed, the same
+    # number of steps on every rank (each holds a collective).
+    ramp_steps = 0
+    if ramp_ms > 0 and world > 1:
+        ramp_steps = max(8, int(ramp_ms / 10.0) // 8 * 8)
+        for i in range(ramp_steps):
+            timed_step(i)
+        torch.cuda.synchronize()
+    elif ramp_ms > 0:
+        t_r = time.perf_counter()
+        while (time.perf_counter() - t_r) * 1e3 < ramp_ms and ramp_steps < 2000:
+            for i in range(4):
+                timed_step(i)
+            torch.cuda.synchronize()
+            ramp_steps += 4
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        timed_step(warmup + i)
+    t_enqueue = time.perf_counter() - t0          # host time to enqueue the K steps (diagnostic)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    # the same K steps again, eagerly, with event pairs: on the dominant family only (undisturbed), then on all
+    dom = None
+    if fam_all:
+        cand = [k for k in fam_names if k in BOUND and fam_all[k][1] > 0]
+        dom = max(cand, key=lambda k: fam_all[k][0]) if cand else None
+    _lib.prof_enable(True, families=[dom] if dom else None)
+    for i in range(steps):
+        wl.step(warmup + i)
+    torch.cuda.synchronize()
+    fam = _lib.prof_read()
+    _lib.prof_enable(False)
+    pair_us = _lib.prof_pair_overhead_us(torch.cuda.current_stream(dev).cuda_stream)
+    my_edges = sum(wl.edges[(warmup + i) % pool_n] for i in range(steps))
+    return {"dt": dt, "edges": my_edges, "t_enqueue": t_enqueue, "fam_all": fam_all, "fam": fam, "dom": dom,
+            "graphs": graphs is not None, "graph_note": graph_note, "ramp_steps": ramp_steps, "pair_us": pair_us}
+
+
+def family_table(famd, steps, alg, exe, byts, pair_us=0.0):
+    out = {}
+    for name, (ms, n) in famd.items():
+        if n == 0 or steps == 0:
+            continue
+        avg_ev = 1e3 * ms / n
+        avg_us = max(avg_ev - pair_us, 1e-3)
+        k = {"launches_per_step": round(n / steps, 2), "avg_us": round(avg_us, 2), "us_per_step": round(avg_us * n / steps, 1)}
+        if name in alg:
+            k["bound"] = BOUND[name]
+            k["executed_tflops"] = round(exe[name] / (avg_us * 1e-6) / 1e12, 2)
+            k["algorithmic_tflops"] = round(alg[name] / (avg_us * 1e-6) / 1e12, 2)
+            k["algorithmic_gbs"] = round(byts[name] / (avg_us * 1e-6) / 1e9, 1)
+        out[name] = k
+    return out
+
+
+def load_traffic(workload_key):
+    """HBM bytes per launch from the rocprofv3 --pmc passes of this command (FETCH_SIZE / WRITE_SIZE in separate
+    passes, read bytes doubled as MI355X_MICROARCH.md prescribes for gfx950), summarised by tools/pmc_summary.py into
+    profiles/traffic_pmc.json, keyed by workload."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic_pmc.json")) as fh:
+            return json.load(fh).get(workload_key)
+    except (OSError, ValueError):
+        return None
 
 
 def main():
@@ -61,28 +339,24 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--model", choices=["clr", "pose"], default="clr")
+    ap.add_argument("--encoders", choices=["frozen", "precomputed"], default="frozen",
+                    help="camera+LiDAR+radar step: frozen encoders in train mode inside the step (default) or their outputs given")
     ap.add_argument("--no-dead-knn", action="store_true",
                     help="skip the k-NN + GAT block whose result the reference discards (secondary figure)")
-    ap.add_argument("--side-stream", action="store_true", help="run the discarded k-NN block on the library's side stream (diagnostic)")
-    ap.add_argument("--no-graph", action="store_true",
-                    help="enqueue every step eagerly (the default for N > 1, see --split-graph); by default at N = 1 the whole training step of "
-                         "each of the 4 pool batches is captured into a hipGraph once and the timed region replays them")
-    ap.add_argument("--split-graph", action="store_true",
-                    help="capture forward..backward and Adam as two graphs with the gradient all-reduce eager between their replays "
-                         "(opt-in for N > 1, where the default is eager: not yet validated on a multi-GPU node; at N = 1 a testing aid)")
+    ap.add_argument("--no-graph", action="store_true", help="enqueue every step eagerly (always the case for N > 1)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary figures of the default N = 1 run")
     ap.add_argument("--ramp-ms", type=float, default=250.0, help="untimed clock ramp in front of the timed region (0 = none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to exercise the N > 1 path on one GPU)")
     ap.add_argument("--all-ranks-on-device-0", action="store_true", help="testing aid for the N > 1 path on a 1-GPU box (with --backend gloo)")
-    ap.add_argument("--cpu-steps", type=int, default=50)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if world == 1 and args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     import torch.distributed as dist
     dev = torch.device("cuda", 0 if args.all_ranks_on_device_0 else local_rank)
     torch.cuda.set_device(dev)
@@ -93,143 +367,11 @@ def main():
         else:
             dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
 
-    from batch3dmot_amd import _lib, synth
-    from batch3dmot_amd.dist import FlatGradSync
-    from batch3dmot_amd.pose_gnn import PoseGNN
-    from batch3dmot_amd.train_step import forward_backward, make_optimizer, train_step
+    from batch3dmot_amd import _lib
+    wl = Workload(args.model, dev, rank, world, args, encoders=args.encoders)
+    m = measure(wl, args, world, dist, args.steps, args.warmup, args.ramp_ms, use_graph=not args.no_graph)
 
-    torch.manual_seed(5621)                      # gnn.manual_seed, pose_config.yaml:96
-    model = PoseGNN().to(dev)
-    model.run_dead_knn = not args.no_dead_knn
-    model.single_stream = not args.side_stream
-    model.train()
-    opt = make_optimizer(model, capturable=True)  # Adam(lr 1e-4, wd 1e-4, betas .9/.999): train.py:106-109 (optim.FlatAdam)
-    sync = FlatGradSync(model.parameters(), flat=opt if hasattr(opt, "flat_grad") else None) if world > 1 else None
-
-    pool_cpu = [synth.make_batch(2, 1500, 15000, first_graph_idx=rank * 1000 + 2 * i) for i in range(4)]
-    pool = [b.to(dev) for b in pool_cpu]
-    n_nodes = pool[0].pose_feats.size(0)
-    edges_per_step = [b.edge_index.size(1) for b in pool]
-
-    def step(i):
-        b = pool[i % len(pool)]
-        if hasattr(b, "_b3d_graph"):
-            del b._b3d_graph                     # the CSR/CSC build is part of every step
-        return train_step(model, b, opt, batch_size=2, loss_kind="cb", logits=True, grad_sync=sync)
-
-    # Warm-up doubles as the instrumented pass: every kernel family is timed with HIP event pairs
-    # (diagnostic `kernels` table) and the family with the largest device time is picked.  Event
-    # pairs around ~35 launches per step cost ~0.25 ms of device time per step, so the TIMED region
-    # keeps events on that one dominant family only (`roofline` is measured live in the timed region).
-    _lib.prof_enable(True)
-    for i in range(args.warmup):
-        step(i)
-    torch.cuda.synchronize()
-    fam_all = _lib.prof_read() if args.warmup > 0 else None
-    measured = [k for k in ("mp_edge_fwd", "mp_edge_bwd", "wgrad_edge", "mp_node_fwd", "mp_node_bwd")]
-    dom = max(measured, key=lambda k: fam_all[k][0]) if fam_all else None
-    # ---- hipGraph capture (N = 1): one graph per pool batch holds the WHOLE step (CSR/CSC build, forward, loss,
-    #      backward, Adam).  The timed region then costs one graph launch of host time per step, so a slow or
-    #      noisy host cannot throttle a ~1.1 ms device step that otherwise needs ~0.6 ms of enqueueing.  Kernel
-    #      families are timed with HIP events in an eager pass of the same K steps right after the timed region
-    #      (event records cannot be captured); eager mode (--no-graph) times them inside the timed region.
-    #      --split-graph: forward..backward and Adam are two graphs, the flat gradient all-reduce between them stays eager.
-    graphs = None
-    graph_note = None
-    opt_graph = None                              # N > 1: graphs[i] = forward..backward of pool batch i, opt_graph = Adam
-    if not args.no_graph and (world == 1 or args.split_graph):
-        _lib.prof_enable(False)
-        try:
-            graphs = []
-            if world > 1:
-                dist.barrier()                    # no collective may be pending while this rank captures
-            torch.cuda.synchronize()
-            cap_stream = torch.cuda.Stream()
-            cap_stream.wait_stream(torch.cuda.current_stream())
-            for i in range(len(pool)):
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=cap_stream, capture_error_mode="thread_local"):
-                    if world == 1 and not args.split_graph:
-                        step(i)
-                    else:
-                        b = pool[i]
-                        if hasattr(b, "_b3d_graph"):
-                            del b._b3d_graph
-                        forward_backward(model, b, opt, batch_size=2, loss_kind="cb", logits=True)
-                graphs.append(g)
-            if world > 1 or args.split_graph:
-                # the flat all-reduce of the gradients stays eager between the two replays of a step: no collective
-                # inside a graph, one graph launch + one RCCL enqueue + one graph launch of host time per step
-                opt_graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(opt_graph, stream=cap_stream, capture_error_mode="thread_local"):
-                    opt.step()
-            torch.cuda.current_stream().wait_stream(cap_stream)
-            torch.cuda.synchronize()
-        except Exception as exc:                                   # capture unsupported here: eager timed region
-            graphs = None
-            opt_graph = None
-            graph_note = f"hipGraph capture failed ({type(exc).__name__}: {exc}); eager timed region"
-            torch.cuda.synchronize()
-        if world > 1:
-            # every rank must run the same mode: a rank that fell back to eager would still match (same kernels,
-            # same collective), but say so in the output
-            ok = torch.tensor([1.0 if graphs is not None else 0.0], device=dev)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if float(ok) == 0.0 and graphs is not None:
-                graph_note = "another rank could not capture; this rank replays graphs"
-
-    def timed_step(i):
-        if graphs is not None:
-            graphs[i % len(pool)].replay()
-            if opt_graph is not None:
-                if sync is not None:
-                    sync.sync(force=True)         # the backward ran inside a graph: Python-side freshness flags did not move
-                opt_graph.replay()
-        else:
-            step(i)
-
-    # Clock ramp (untimed): a fresh box idles at ~550 MHz and the W warm-up steps are ~10 ms of device work; the
-    # first bench run on such a box measured 1.17 ms/step against 0.94 on the runs after it.  Keep the GPU busy
-    # with more untimed steps until 0.25 s have passed, the same on every rank.
-    ramp_steps = 0
-    if args.ramp_ms > 0 and world > 1:
-        # every rank must run the same number of steps (each holds a collective): a fixed count, ~1.2 ms per step
-        ramp_steps = int(args.ramp_ms / 1.2) // 8 * 8
-        for i in range(ramp_steps):
-            timed_step(i)
-        torch.cuda.synchronize()
-    elif args.ramp_ms > 0:
-        t_r = time.perf_counter()
-        while (time.perf_counter() - t_r) * 1e3 < args.ramp_ms and ramp_steps < 2000:
-            for i in range(8):
-                timed_step(i)
-            torch.cuda.synchronize()
-            ramp_steps += 8
-    if graphs is None:
-        _lib.prof_enable(True, families=[dom] if dom else None)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        timed_step(args.warmup + i)
-    t_enqueue = time.perf_counter() - t0          # host time to enqueue the K steps (diagnostic)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if graphs is not None:
-        # the same K steps again, eagerly, with event pairs on the dominant family only
-        _lib.prof_enable(True, families=[dom] if dom else None)
-        for i in range(args.steps):
-            step(args.warmup + i)
-        torch.cuda.synchronize()
-    fam = _lib.prof_read()
-    _lib.prof_enable(False)
-
-    my_edges = sum(edges_per_step[(args.warmup + i) % len(pool)] for i in range(args.steps))
-    tot = torch.tensor([dt, float(my_edges)], dtype=torch.float64, device=dev)
+    tot = torch.tensor([m["dt"], float(m["edges"])], dtype=torch.float64, device=dev)
     if world > 1:
         tmax = tot[:1].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -237,137 +379,148 @@ def main():
         dist.all_reduce(esum, op=dist.ReduceOp.SUM)
         dt, total_edges = float(tmax), float(esum)
     else:
-        total_edges = float(my_edges)
+        dt, total_edges = m["dt"], float(m["edges"])
+
+    secondary = None
+    if world == 1 and rank == 0 and not args.no_secondary and args.model == "clr" and args.encoders == "frozen":
+        secondary = {}
+        for key, kind, enc in (("clr_encoders_precomputed", "clr", "precomputed"), ("pose_gnn", "pose", "frozen")):
+            try:
+                w2 = Workload(kind, dev, rank, world, args, encoders=enc)
+                m2 = measure(w2, args, world, dist, max(10, args.steps // 2), max(3, args.warmup // 2), 60.0, use_graph=not args.no_graph)
+                secondary[key] = {"workload": w2.describe(world), "value": round(m2["edges"] / m2["dt"], 1), "unit": "edges/s",
+                                  "ms_per_step": round(1e3 * m2["dt"] / max(10, args.steps // 2), 4),
+                                  "timed_region": "hipGraph replay" if m2["graphs"] else "eager"}
+                del w2
+            except Exception as exc:                                # a secondary figure must never cost the headline
+                secondary[key] = {"error": f"{type(exc).__name__}: {str(exc)[:200]}"}
+            torch.cuda.empty_cache()
 
     if rank == 0:
-        e_avg = my_edges / args.steps
-        # ---- per-family device time (HIP events on the launch stream, whole timed region) -----
-        depth = model.depth
-        mac_eu = 128 * 96 + 96 * 64 + 64 * 32                  # edge_update stack
-        mac_msg = 2 * (128 * 96 + 96 * 64)                     # create_past_msgs + create_future_msgs
-        # the weight gradient of ALL layers is one launch: edge_update in every layer, the message
-        # and node stacks in layers 0..depth-2 (the last layer's node update feeds nothing)
-        flops = {"mp_edge_fwd": 2.0 * MAC_EDGE * e_avg, "mp_edge_bwd": 2.0 * MAC_EDGE * e_avg,
-                 "wgrad_edge": 2.0 * (e_avg * (mac_eu * depth + mac_msg * (depth - 1)) + n_nodes * MAC_NODE * (depth - 1)),
-                 "mp_node_fwd": 2.0 * MAC_NODE * n_nodes, "mp_node_bwd": 2.0 * MAC_NODE * n_nodes}
-        # FLOPs the kernels actually execute: the three first layers are hoisted (csrc/b3d_hoist.hpp): their
-        # node columns are multiplied per node (N rows) instead of per edge, 29,696 MAC/edge/layer remain
-        mac_eu_x = 32 * 96 + 96 * 64 + 64 * 32
-        mac_msg_x = 2 * (32 * 96 + 96 * 64)
-        mac_node_tab = 48 * 384                                   # per-node table of the next layer
-        mac_node_gp = 384 * 96                                    # per-node (dx | dx0) from the gradient of the table
-        executed = {"mp_edge_fwd": 2.0 * (mac_eu_x + mac_msg_x) * e_avg, "mp_edge_bwd": 2.0 * (mac_eu_x + mac_msg_x) * e_avg,
-                    "wgrad_edge": 2.0 * (e_avg * (mac_eu_x * depth + mac_msg_x * (depth - 1))
-                                         + n_nodes * (MAC_NODE * (depth - 1) + 2 * 96 * 48 * depth + 4 * 96 * 48 * (depth - 1))),
-                    "mp_node_fwd": 2.0 * (MAC_NODE + mac_node_tab) * n_nodes,
-                    "mp_node_bwd": 2.0 * (MAC_NODE + mac_node_gp) * n_nodes}
-        # algorithmic bytes per launch (each logical tensor once, fp32, int32 indices)
-        byts = {"mp_edge_fwd": e_avg * (8 + 4 * (32 + 32 + 64 + 64 + 352)),      # idx, e in/out, fut, past, saved hidden
-                "mp_edge_bwd": e_avg * (8 + 4 * (32 + 32 + 352 + 192 + 384)),    # de out/in, saved, per-edge node grads, G
-                # G (dH1,dH2,de' every layer; dF1,dP1 + gathered dM in the message layers), saved hidden, e / e'
-                "wgrad_edge": e_avg * 4 * ((192 + 160 + 64) * depth + (192 + 128 + 192 + 32) * (depth - 1)),
-                "mp_node_fwd": e_avg * 4 * 128 + n_nodes * 4 * (128 + 48 + 160),
-                "mp_node_bwd": e_avg * 4 * 192 + n_nodes * 4 * (128 + 48 + 48 + 160 + 208)}
-        bound = {"mp_edge_fwd": "mfma", "mp_edge_bwd": "mfma", "wgrad_edge": "hbm", "mp_node_fwd": "hbm", "mp_node_bwd": "hbm"}
-        # HBM bytes per launch measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of
-        # this command (profiles/r01_j_pmc_traffic.txt), FETCH_SIZE doubled as MI355X_MICROARCH.md
-        # prescribes for wide coalesced reads on gfx950.  Valid for the default workload only.
-        traffic_pmc = {"wgrad_edge": 764.0e6, "mp_edge_fwd": 82.7e6, "mp_edge_bwd": 104.9e6, "mp_node_fwd": 29.4e6,
-                       "mp_node_bwd": 57.3e6}
-        def table(famd, steps):
-            out = {}
-            for name, (ms, n) in famd.items():
-                if n == 0 or steps == 0:
-                    continue
-                avg_us = 1e3 * ms / n
-                k = {"launches_per_step": n / steps, "avg_us": round(avg_us, 2), "us_per_step": round(1e3 * ms / steps, 1)}
-                if name in flops:
-                    k["bound"] = bound[name]
-                    k["tflops"] = round(flops[name] / (avg_us * 1e-6) / 1e12, 2)
-                    k["gbs"] = round(byts[name] / (avg_us * 1e-6) / 1e9, 1)
-                out[name] = k
-            return out
-        kernels_warmup = table(fam_all, args.warmup) if fam_all else {}
-        kernels = table(fam, args.steps)             # timed region: the dominant family only (or all if W = 0)
-        if dom is None:
-            dom = max((k for k in kernels if k in flops), key=lambda k: kernels[k]["us_per_step"])
-        default_workload = (depth == 6 and abs(e_avg - 31078) < 200 and not args.no_dead_knn)
-        if bound[dom] == "mfma":
-            achieved, peak, unit = kernels[dom]["tflops"], PEAK_FP32_MFMA_TFLOPS, "TFLOP/s"
+        e_avg = m["edges"] / args.steps
+        depth = wl.model.depth
+        hoist = _lib.features()
+        kw = dict(n=wl.n_nodes, e=e_avg, depth=depth)
+        if args.model == "clr":
+            kw.update(hoist_mp=bool(hoist.get("clr_hoist_mp")), hoist_att=bool(hoist.get("clr_hoist_att")), nl=wl.nl, nr=wl.nr)
+        alg, exe, byts = wl.work.families(**kw)
+        kernels_warmup = family_table(m["fam_all"], args.warmup, alg, exe, byts, m["pair_us"]) if m["fam_all"] else {}
+        kernels = family_table(m["fam"], args.steps, alg, exe, byts, m["pair_us"])
+        dom = m["dom"] or max((k for k in kernels if k in alg), key=lambda k: kernels[k]["us_per_step"])
+        kd = kernels[dom]
+        workload_key = f"{args.model}:{args.encoders if args.model == 'clr' else 'na'}:knn{int(not args.no_dead_knn)}"
+        traffic = load_traffic(workload_key) or {}
+        if BOUND[dom] == "mfma":
+            achieved, peak, unit = kd["executed_tflops"], PEAK_FP32_MFMA_TFLOPS, "TFLOP/s"
         else:
-            achieved, peak, unit = kernels[dom]["gbs"], PEAK_HBM_GBS, "GB/s"
-        roofline = {"kernel": dom, "bound": bound[dom], "achieved": achieved, "peak": peak, "unit": unit,
-                    "frac": round(achieved / peak, 4),
-                    "traffic": round(traffic_pmc[dom]) if default_workload else None,
-                    "avg_launch_us": kernels[dom]["avg_us"],
-                    "algorithmic_flops_per_launch": flops[dom], "algorithmic_bytes_per_launch": byts[dom],
-                    "fp32_tflops": kernels[dom]["tflops"], "fp32_frac": round(kernels[dom]["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4),
-                    "executed_flops_per_launch": executed[dom],
-                    "executed_fp32_tflops": round(executed[dom] / (kernels[dom]["avg_us"] * 1e-6) / 1e12, 2),
-                    "flops_note": "achieved / fp32_tflops count the reference's ALGORITHMIC FLOPs (57,344 MAC per edge and layer); "
-                                  "the kernels execute fewer (executed_*): the node columns of the first layer of every "
-                                  "edge stack are evaluated per node instead of per edge"}
-        if model.run_dead_knn and not model.single_stream and dom in ("mp_edge_fwd", "mp_node_fwd"):
-            roofline["note"] = ("launch durations include CU sharing with the k-NN + GAT block that runs concurrently on "
-                                "the library's side stream; --no-dead-knn measures the kernel undisturbed")
+            achieved, peak, unit = kd["algorithmic_gbs"], PEAK_HBM_GBS, "GB/s"
+        roofline = {"kernel": dom, "bound": BOUND[dom], "achieved": achieved, "peak": peak, "unit": unit,
+                    "frac": round(achieved / peak, 4), "traffic": traffic.get(dom),
+                    "avg_launch_us": kd["avg_us"], "event_pair_overhead_us_subtracted": round(m["pair_us"], 2),
+                    "launches_per_step": kd["launches_per_step"],
+                    "executed_flops_per_launch": exe[dom], "algorithmic_flops_per_launch": alg[dom],
+                    "algorithmic_bytes_per_launch": byts[dom],
+                    "algorithmic_tflops": kd["algorithmic_tflops"],
+                    "algorithmic_frac_of_fp32_peak": round(kd["algorithmic_tflops"] / PEAK_FP32_MFMA_TFLOPS, 4),
+                    "note": "frac = EXECUTED FLOPs of the named kernel / its launch duration / peak for mfma-bound kernels "
+                            "(node columns of a Linear over a concatenation that are evaluated per node are not counted as "
+                            "edge-kernel work); algorithmic_* count the reference's per-edge FLOPs (SURVEY.md 8d) over the same "
+                            "duration.  Durations: HIP event pairs on the launch stream around each launch of this family in "
+                            "an eager pass of the same K steps, minus the measured cost of an empty event pair."}
         ms_step = 1e3 * dt / args.steps
-        step_bytes = algorithmic_bytes_step(n_nodes, e_avg)
-        step_flops = algorithmic_flops_step(n_nodes, e_avg)
+        sf_kw = dict(f_l=wl.nl / wl.n_nodes, f_r=wl.nr / wl.n_nodes) if args.model == "clr" else {}
+        step_bytes = wl.work.step_bytes(wl.n_nodes, e_avg)
+        step_flops = wl.work.step_flops(wl.n_nodes, e_avg, **sf_kw)
         whole = {"algorithmic_bytes_per_step": step_bytes, "hbm_gbs": round(step_bytes / (ms_step * 1e-3) / 1e9, 1),
                  "hbm_frac": round(step_bytes / (ms_step * 1e-3) / 1e9 / PEAK_HBM_GBS, 5),
                  "algorithmic_flops_per_step": step_flops,
                  "fp32_tflops": round(step_flops / (ms_step * 1e-3) / 1e12, 2),
-                 "fp32_frac": round(step_flops / (ms_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
-
+                 "fp32_frac": round(step_flops / (ms_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                 "note": "message-passing path only (SURVEY.md 8d): the frozen encoders' FLOPs are not counted"}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(pool_cpu, args.cpu_steps)
-
+            cpu = cpu_baseline(wl)
         line = {"metric": "edges/sec (fwd+bwd) on nuScenes-shaped detection graphs",
                 "value": round(total_edges / dt, 1), "unit": "edges/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": round(ms_step, 4), "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                "config": {"workload": "pose_config.yaml poses-only PoseGNN depth 6, training step "
-                                       "(CSR/CSC build + fwd + cb-BCE + bwd + Adam"
-                                       + (" + flat RCCL grad all-reduce" if world > 1 else "") + ")",
-                           "graphs_per_gpu": 2, "nodes_per_gpu": n_nodes, "edges_per_gpu": round(e_avg, 1),
-                           "frames": 5, "dead_knn_gat_block_executed": bool(model.run_dead_knn),
+                "config": {"workload": wl.describe(world), "graphs_per_gpu": 2, "nodes_per_gpu": wl.n_nodes,
+                           "edges_per_gpu": round(e_avg, 1), "frames": 5,
+                           "lidar_rows_per_gpu": getattr(wl, "nl", None), "radar_rows_per_gpu": getattr(wl, "nr", None),
+                           "dead_knn_gat_block_executed": bool(wl.model.run_dead_knn),
                            "parallelism": f"graph-batch sharding x{world}"},
-                "roofline": roofline, "whole_step": whole, "kernels_instrumented_warmup": kernels_warmup,
-                "untimed_clock_ramp_steps": ramp_steps, "host_enqueue_ms_per_step": round(1e3 * t_enqueue / args.steps, 4),
-                "timed_region": (("hipGraph replay (one captured training step per pool batch)" if world == 1 else
-                                  "hipGraph replay of forward..backward, eager flat RCCL all-reduce, hipGraph replay of Adam") +
-                                 "; roofline / kernels timed with HIP events in an eager pass of the same K steps right after it")
-                                if graphs is not None
-                                else ("eager" + (f" ({graph_note})" if graph_note else "")), "kernels": kernels, "cpu_baseline": cpu}
+                "roofline": roofline, "cpu_baseline": cpu, "whole_step": whole, "secondary": secondary,
+                "kernels": kernels, "kernels_instrumented_warmup": kernels_warmup,
+                "untimed_clock_ramp_steps": m["ramp_steps"], "host_enqueue_ms_per_step": round(1e3 * m["t_enqueue"] / args.steps, 4),
+                "timed_region": ("hipGraph replay (one captured training step per pool batch"
+                                 + ("; the modality masks + row compaction run eagerly in front of each replay and feed it" if wl.rows_static is not None else "")
+                                 + "); kernel families timed with HIP events in an eager pass of the same K steps right after it")
+                                if m["graphs"] else ("eager" + (f" ({m['graph_note']})" if m["graph_note"] else ""))}
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
 
 
-def cpu_baseline(pool_cpu, steps):
-    """The oracle (oracle/ref_torch.py, pinned against the reference sources) timed on the host:
-    same batches, same step (forward incl. the discarded k-NN + GAT block, loss, backward, Adam)."""
+def host_info():
+    model, cores = "unknown", os.cpu_count() or 1
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for ln in fh:
+                if ln.startswith("model name"):
+                    model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return model, cores
+
+
+def cpu_baseline(wl: Workload):
+    """The oracle (oracle/ref_torch.py, pinned against the reference sources) timed on the host: the same batches, the
+    same step (masks, encoders in train mode, forward incl. the discarded k-NN + GAT block, loss, backward, Adam).
+    Bounded sample: a few steps at the fastest thread count, plus one 1-thread figure on a smaller sample."""
     from oracle import ref_torch                 # checker / baseline only
-    # 16 threads is the fastest setting for this graph size on the GPU box's host (2 x EPYC 9575F,
-    # 256 hardware threads: 1 thr 0.75 s/step, 8 thr 0.26, 16 thr 0.22, 32 thr 0.40, 64 thr 1.1)
-    threads = min(16, os.cpu_count() or 1)
-    torch.set_num_threads(threads)
-    torch.manual_seed(5621)
-    m = ref_torch.PoseGNN(run_dead_knn=True)
-    opt = torch.optim.Adam(m.parameters(), lr=1e-4, weight_decay=1e-4, betas=(0.9, 0.999))
-    for i in range(3):
-        ref_torch.train_step(m, pool_cpu[i % len(pool_cpu)], opt, batch_size=2, loss_kind="cb", logits=True)
-    t0 = time.perf_counter()
-    edges = 0
-    for i in range(steps):
-        b = pool_cpu[i % len(pool_cpu)]
-        ref_torch.train_step(m, b, opt, batch_size=2, loss_kind="cb", logits=True)
-        edges += b.edge_index.size(1)
-    dt = time.perf_counter() - t0
-    return {"value": round(edges / dt, 1), "unit": "edges/s", "cores": threads, "kind": "port",
-            "sample": f"{steps} training steps of the same batches (3 warm-up), torch {torch.__version__} CPU, "
-                      f"{dt:.1f} s"}
+    from batch3dmot_amd import encoders as enc_mod, synth
+    model_name, cores = host_info()
+    threads = min(16, cores)                     # 16 is the fastest setting for this graph size on the GPU box's 2 x EPYC 9575F
+
+    def build():
+        torch.manual_seed(5621)
+        if wl.kind == "pose":
+            mm = ref_torch.PoseGNN(run_dead_knn=True)
+        else:
+            mm = ref_torch.GNN(enc_mod.ResNetAE(), enc_mod.PointNetClassifier(k=7), enc_mod.RadarNetClassifier(k=7),
+                               run_dead_knn=True, loop_masks=False)
+        oo = torch.optim.Adam([p for p in mm.parameters() if p.requires_grad], lr=1e-4, weight_decay=1e-4, betas=(0.9, 0.999))
+        return mm, oo
+
+    def run(nthreads, batches, warm, steps):
+        torch.set_num_threads(nthreads)
+        mm, oo = build()
+        for i in range(warm):
+            ref_torch.train_step(mm, batches[i % len(batches)], oo, batch_size=2, loss_kind="cb", logits=wl.logits)
+        t0 = time.perf_counter()
+        edges = 0
+        for i in range(steps):
+            b = batches[i % len(batches)]
+            ref_torch.train_step(mm, b, oo, batch_size=2, loss_kind="cb", logits=wl.logits)
+            edges += b.edge_index.size(1)
+        return edges / (time.perf_counter() - t0), time.perf_counter() - t0
+
+    if wl.kind == "pose":
+        v, dt = run(threads, wl.pool_cpu, 3, 40)
+        sample = f"40 training steps of the same batches (3 warm-up), {dt:.1f} s"
+        one = [synth.make_batch(2, 1500, 15000, first_graph_idx=0)]
+        v1, dt1 = run(1, one, 1, 8)
+        sample1 = f"8 training steps of one batch (1 warm-up), {dt1:.1f} s"
+    else:
+        v, dt = run(threads, wl.pool_cpu, 1, 3)
+        sample = f"3 training steps of the same batches (1 warm-up), {dt:.1f} s"
+        one = [synth.make_batch(1, 750, 7500, first_graph_idx=0, modalities=True)]
+        v1, dt1 = run(1, one, 0, 1)
+        sample1 = f"1 training step of a 750-node / {one[0].edge_index.size(1)}-edge graph (no warm-up), {dt1:.1f} s"
+    return {"value": round(v, 1), "unit": "edges/s", "cores": threads, "kind": "port", "sample": sample + f", torch {torch.__version__} CPU",
+            "one_thread": {"value": round(v1, 1), "unit": "edges/s", "cores": 1, "sample": sample1},
+            "host_cpu": model_name, "host_logical_cores": cores}
 
 
 if __name__ == "__main__":

@@ -326,13 +326,27 @@ typedef enum b3d_kernel_family {
   B3D_K_WGRAD_EDGE = 4, /* wgrad launch over the edge stacks of one layer        */
   B3D_K_WGRAD_OTHER = 5,
   B3D_K_OTHER = 6,
-  B3D_K_COUNT = 7
+  B3D_K_ATT_FWD = 7,    /* att_edge_encoder (clr_att_gnn.py:161-164), forward                       */
+  B3D_K_ATT_BWD = 8,    /* att_edge_encoder data gradient                                            */
+  B3D_K_KNN = 9,        /* frame-wise k-NN + GAT block whose result the reference discards           */
+  B3D_K_POINT_FEAT = 10,/* point-cloud stacks of the frozen LiDAR / radar encoders                   */
+  B3D_K_COUNT = 11
 } b3d_kernel_family;
 int b3d_prof_enable(int on);
 int b3d_prof_select(uint32_t family_mask);   /* bit f set: family f is timed while enabled (default: all).  Event
                                                pairs cost device time; time one family to measure it undisturbed */
 int b3d_prof_reset(void);
 int b3d_prof_read(int family, double* total_ms /* host */, int* launches /* host */);
+/* Average elapsed time of an EMPTY event pair on `stream` (what a pair adds to the kernel it brackets), in us. */
+int b3d_prof_pair_overhead_us(b3d_stream stream, int reps, double* out_us /* host */);
+
+/* ---- which execution plans this build runs (for callers that account executed FLOPs, e.g. bench.py) ----------
+ * bit 0: PoseGNN first layers evaluated per node (hoisted); bit 1: the same for the camera+LiDAR+radar
+ * message-passing widths; bit 2: att_edge_encoder.0's node columns evaluated per node. */
+#define B3D_FEATURE_POSE_HOIST 1u
+#define B3D_FEATURE_CLR_HOIST_MP 2u
+#define B3D_FEATURE_CLR_HOIST_ATT 4u
+uint32_t b3d_features(void);
 
 #ifdef __cplusplus
 }

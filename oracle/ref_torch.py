@@ -246,7 +246,9 @@ class GNN(nn.Module):
             data.edge_index, data.edge_attr, data.node_timestamps)
         n = pose_feats.size(0)
         pcl_nodes, pr_nodes = self.modality_masks(lidar_feats, radar_feats)
-        edge_attr = self.edge_encoder(edge_attr.float())                 # :123
+        # :123 `edge_attr.float()`; a float64 copy of this module (tests: the accuracy yardstick) keeps the same float32
+        # rounding of the attributes and then computes in its own precision
+        edge_attr = self.edge_encoder(edge_attr.float().to(self.edge_encoder[0].weight.dtype))
         x_img = self.resnet.encode(img_feats)                            # :125
 
         pointnet_out = lidar_feats.new_zeros((n, 256))                   # :127-133
