@@ -281,7 +281,7 @@ def prof_read() -> dict:
 
 
 def prof_pair_overhead_us(stream: int, reps: int = 256) -> float:
-    """Average elapsed time of an empty HIP event pair on ``stream`` (us): what a pair adds to the kernel it brackets."""
+    """Average elapsed time of a HIP event pair around an EMPTY kernel on ``stream`` (us)."""
     out = C.c_double()
     check(load().b3d_prof_pair_overhead_us(stream, reps, C.byref(out)), "b3d_prof_pair_overhead_us")
     return out.value

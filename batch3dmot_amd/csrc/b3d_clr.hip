@@ -4,11 +4,20 @@
 #include "b3d_launch.hpp"
 #include "b3d_knn.hpp"
 #include "b3d_wstream.hpp"
+#include "b3d_wstream2.hpp"
+#include "b3d_hoist.hpp"
 
 namespace b3d {
 namespace clr {
 
 using D = DimsC;
+using DB = DimsCB;                       // hoisted kernels: bf16x3 images for the edge stacks
+using HC = Hoist<DB>;
+// Hoisted first layers (b3d_hoist.hpp) at the camera+LiDAR+radar widths.  B3D_CLR_HOIST=0 selects the unsplit kernels.
+static bool hoist_enabled() {
+  static const bool on = [] { const char* e = getenv("B3D_CLR_HOIST"); return e ? atoi(e) != 0 : true; }();
+  return on;
+}
 constexpr int XS = 288;                                                  // x_sens / s width (96 + 128 + 64)
 using SeqEE = LayerSeq<L<16, 16>, L<16, 32>, L<32, 64>>;                 // 4-16-32-64          :35-41
 using SeqNE = LayerSeq<L<32, 48>, L<48, 96>>;                            // 19-48-96            :43-47
@@ -54,6 +63,10 @@ struct Ws {
   // forward images
   float *wp_ee, *wp_ne, *wp_cls, *wp_fl, *wp_fr, *wp_aff[3], *wp_at[5], *wp_efwd, *wp_nfwd;
   // backward images
+  // hoisted first layers
+  bool hoist;
+  float *wp_proj0, *wp_nfwd_h, *wp_efwd_h, *wp_ebwd_h, *wp_ebwd_nm_h, *wp_gproj, *wp_nbwd_h;
+  float *T, *T0, *dT, *gx;
   float *wp_clsT, *wp_eeT, *wp_neT, *wp_flT, *wp_frT, *wp_affT[3], *wp_atT[5], *wp_ebwd, *wp_ebwd_nm, *wp_nbwd;
   // activations
   float *ea_pad, *ee_a1, *ee_a2, *pose_pad, *ne_a1, *xsens, *fl_a1, *fr_a1, *fr_a2, *aff_v[3], *s;
@@ -102,6 +115,14 @@ static void carve(Ws& w, void* ws, size_t ws_bytes, int N, int E, int nl, int nr
   w.wp_at[4] = c.take<float>(SeqAT4::TOTAL_FLOATS);
   w.wp_efwd = c.take<float>(D::EdgeFwdSeq::TOTAL_FLOATS);
   w.wp_nfwd = c.take<float>(D::NodeFwdSeq::TOTAL_FLOATS);
+  w.hoist = hoist_enabled();
+  if (w.hoist) {
+    w.wp_proj0 = c.take<float>(Proj0Seq2<DB>::TOTAL_FLOATS);
+    w.wp_nfwd_h = c.take<float>(NodeFwdHSeq<DB>::TOTAL_FLOATS);
+    w.wp_efwd_h = c.take<float>(HC::EdgeFwdSeq::TOTAL_FLOATS);
+    w.T = c.take<float>(n_ * HC::TW);
+    w.T0 = c.take<float>(n_ * 2 * DB::MH);
+  }
   w.xsens = c.take<float>(n_ * XS);
   w.s = c.take<float>(n_ * XS);
   w.att = c.take<float>(e_ * 64);
@@ -251,10 +272,10 @@ static int check_weights(const b3d_clr_weights* pw) {
   return B3D_OK;
 }
 
-static int pack_all(const b3d_clr_weights* pw, Ws& w, bool training, hipStream_t stream) {
+static int pack_all(const b3d_clr_weights* pw, Ws& w, bool training, bool knn, hipStream_t stream) {
   LinPtrs L[LIN_COUNT];
   gather_linears(pw, L);
-  PackDesc d[96];
+  PackDesc d[160];
   int n = 0;
   auto F = [&](auto tag, int li, float* base, int lin) {
     using S = decltype(tag);
@@ -279,6 +300,31 @@ static int pack_all(const b3d_clr_weights* pw, Ws& w, bool training, hipStream_t
   for (int i = 0; i < 2; ++i) F(EF{}, 3 + i, w.wp_efwd, FU0 + i);
   for (int i = 0; i < 2; ++i) F(EF{}, 5 + i, w.wp_efwd, PA0 + i);
   for (int i = 0; i < 3; ++i) F(D::NodeFwdSeq{}, i, w.wp_nfwd, CF0 + i);
+  if (w.hoist) {
+    constexpr int DX = DB::DX, DE = DB::DE, EIN = DB::EIN, MIN = DB::MIN, H1 = DB::EH1, MH = DB::MH, KE = HC::KE;
+    const LinPtrs &eu0 = L[EU0], &fu0 = L[FU0], &pa0 = L[PA0];
+    // per-node table T = (eu0[:, x_i] x + b | eu0[:, x_j] x | fu0[:, x] x + b | pa0[:, x] x + b | GATConv.lin x)
+    auto proj = [&](auto tag, int li, float* base) {
+      using S = decltype(tag);
+      d[n++] = pack_slice<S>(li, base, eu0.w, eu0.b, H1, DX, EIN, HC::OA, H1, false);
+      d[n++] = pack_slice<S>(li, base, eu0.w + DX, nullptr, H1, DX, EIN, HC::OB, H1, false);
+      d[n++] = pack_slice<S>(li, base, fu0.w, fu0.b, MH, DX, MIN, HC::OF, MH, false);
+      d[n++] = pack_slice<S>(li, base, pa0.w, pa0.b, MH, DX, MIN, HC::OP, MH, false);
+      d[n++] = pack_slice<S>(li, base, knn ? pw->knn_conv.lin : nullptr, nullptr, DX, DX, DX, HC::OG, DX, false);
+    };
+    d[n++] = pack_slice<Proj0Seq2<DB>>(0, w.wp_proj0, fu0.w + DX + DE, nullptr, MH, DX, MIN, 0, MH, false);    // x0 columns
+    d[n++] = pack_slice<Proj0Seq2<DB>>(0, w.wp_proj0, pa0.w + DX + DE, nullptr, MH, DX, MIN, MH, MH, false);
+    proj(Proj0Seq2<DB>{}, 1, w.wp_proj0);
+    for (int i = 0; i < 3; ++i) F(NodeFwdHSeq<DB>{}, i, w.wp_nfwd_h, CF0 + i);
+    proj(NodeFwdHSeq<DB>{}, 3, w.wp_nfwd_h);
+    using EH = HC::EdgeFwdSeq;
+    d[n++] = pack_slice<EH>(0, w.wp_efwd_h, eu0.w + 2 * DX, nullptr, H1, KE, EIN, 0, H1, false);     // e | att columns of edge_update.0
+    F(EH{}, 1, w.wp_efwd_h, EU1); F(EH{}, 2, w.wp_efwd_h, EU2);
+    d[n++] = pack_slice<EH>(3, w.wp_efwd_h, fu0.w + DX, nullptr, MH, DE, MIN, 0, MH, false);          // e' columns
+    F(EH{}, 4, w.wp_efwd_h, FU1);
+    d[n++] = pack_slice<EH>(5, w.wp_efwd_h, pa0.w + DX, nullptr, MH, DE, MIN, 0, MH, false);
+    F(EH{}, 6, w.wp_efwd_h, PA1);
+  }
   if (training) {
     T(SeqClsT{}, 0, w.wp_clsT, C3); T(SeqClsT{}, 1, w.wp_clsT, C2); T(SeqClsT{}, 2, w.wp_clsT, C1); T(SeqClsT{}, 3, w.wp_clsT, C0);
     T(SeqEET{}, 0, w.wp_eeT, EE2); T(SeqEET{}, 1, w.wp_eeT, EE1);
@@ -298,6 +344,7 @@ static int pack_all(const b3d_clr_weights* pw, Ws& w, bool training, hipStream_t
     using NB = D::NodeBwdSeq;
     T(NB{}, 0, w.wp_nbwd, CF2); T(NB{}, 1, w.wp_nbwd, CF1); T(NB{}, 2, w.wp_nbwd, CF0);
   }
+  if (n > 160) return fail(B3D_ERR_ARG, "pack descriptor table overflow");
   return pack_images(d, n, stream);
 }
 
@@ -392,7 +439,10 @@ extern "C" int b3d_clr_forward(const b3d_clr_weights* pw, const b3d_graph* g, co
   Ws w;
   carve(w, workspace, workspace_bytes, N, E, nl, nr, depth, flags);
   if (!w.ok) return fail(B3D_ERR_WORKSPACE, "b3d_clr_forward: workspace %zu < %zu bytes", workspace_bytes, w.bytes);
-  B3D_TRY(pack_all(pw, w, tr, stream));
+  if (flags & B3D_FLAG_RUN_DEAD_KNN)
+    B3D_REQUIRE(pw->knn_conv.lin && pw->knn_conv.att_src && pw->knn_conv.att_dst && pw->knn_conv.bias,
+                "b3d_clr_forward: knn_conv pointers are required with B3D_FLAG_RUN_DEAD_KNN");
+  B3D_TRY(pack_all(pw, w, tr, (flags & B3D_FLAG_RUN_DEAD_KNN) != 0, stream));
 
   // ---- x_sens = x_img | x_lidar | x_radar; rows without a modality stay zero (:127-141,172) ------
   B3D_HIP_CHECK(hipMemsetAsync(w.xsens, 0, (size_t)N * XS * sizeof(float), stream));
@@ -446,6 +496,11 @@ extern "C" int b3d_clr_forward(const b3d_clr_weights* pw, const b3d_graph* g, co
     a.save_in = w.pose_pad; a.save[0] = w.ne_a1; a.wpack = w.wp_ne;
     B3D_TRY(launch_rows<kNWNode>(chain_fwd_kernel<SeqNE, 0x1u, LoadUnaligned<19>, StoreAligned<6>, kNWNode>, "node_encoder", a, N, stream, B3D_K_OTHER, chain_lds<SeqNE>()));
   }
+  if (w.hoist) {  // x0 terms of the future / past columns (once per forward) + the per-node table of layer 0
+    NodeProj0Args a;
+    a.N = N; a.x0 = w.x[0]; a.T0 = w.T0; a.T = w.T; a.wpack = w.wp_proj0;
+    B3D_TRY(launch_node_split<DB>(node_proj0_split_kernel<DB>, "node_proj0", a, N, stream, B3D_K_OTHER));
+  }
   Side* knn_side = nullptr;
   for (int l = 0; l < depth; ++l) {
     if ((flags & B3D_FLAG_RUN_DEAD_KNN) && (l % 2 == 0)) {
@@ -456,7 +511,29 @@ extern "C" int b3d_clr_forward(const b3d_clr_weights* pw, const b3d_graph* g, co
         B3D_TRY(side_fork(stream, knn_side));              // x[l] is complete on `stream` here
         ks = knn_side->s;
       }
-      B3D_TRY(knn_gat_block<D::DX>(w.knn, w.x[l], in->node_timestamps, N, pw->knn_conv, 20, ks));
+      // on the launch stream the block reads GATConv.lin(x[l]) from the per-node table
+      const bool pre = w.hoist && ks == stream;
+      B3D_TRY(knn_gat_block<D::DX>(w.knn, w.x[l], in->node_timestamps, N, pw->knn_conv, 20, ks, pre ? w.T + HC::OG : nullptr, HC::TW));
+    }
+    NodeFwdArgs na;
+    memset(&na, 0, sizeof(na));
+    na.N = N; na.dst_ptr = g->dst_ptr; na.dst_perm = g->dst_perm; na.src_ptr = g->src_ptr; na.src_perm = g->src_perm;
+    na.past = w.past; na.fut = w.fut; na.M = w.M[l]; na.x_out = w.x[l + 1]; na.sH1 = w.nH1[l]; na.sH2 = w.nH2[l];
+    if (w.hoist) {
+      EdgeFwdHArgs ea;
+      memset(&ea, 0, sizeof(ea));
+      ea.E = E; ea.src = g->src; ea.dst = g->dst; ea.T = w.T; ea.e_in = w.e[l]; ea.a_in = w.att;
+      ea.e_out = w.e[l + 1]; ea.fut = w.fut; ea.past = w.past;
+      ea.sH1 = w.sH1[l]; ea.sH2 = w.sH2[l]; ea.sF1 = w.sF1[l]; ea.sP1 = w.sP1[l]; ea.wpack = w.wp_efwd_h;
+      B3D_TRY(launch_rows<kNWEdge>(mp_edge_fwd_h_kernel<DB, kNWEdge>, "mp_edge_fwd", ea, E, stream, B3D_K_EDGE_FWD, stream_lds_bytes<HC::EdgeFwdSeq>()));
+      if (l + 1 < depth) {                                   // + the per-node table the next layer's edge phase gathers
+        na.wpack = w.wp_nfwd_h; na.T = w.T; na.T0 = w.T0;
+        B3D_TRY((launch_node_split<DB, kNodeWavesWide>(mp_node_fwd_split_h_kernel<DB>, "mp_node_fwd", na, N, stream, B3D_K_NODE_FWD)));
+      } else {
+        na.wpack = w.wp_nfwd;
+        B3D_TRY((launch_node_split<D, kNodeWavesWide>(mp_node_fwd_split_kernel<D, kNodeWavesWide>, "mp_node_fwd", na, N, stream, B3D_K_NODE_FWD)));
+      }
+      continue;
     }
     EdgeFwdArgs ea;
     memset(&ea, 0, sizeof(ea));
@@ -464,10 +541,6 @@ extern "C" int b3d_clr_forward(const b3d_clr_weights* pw, const b3d_graph* g, co
     ea.e_out = w.e[l + 1]; ea.fut = w.fut; ea.past = w.past;
     ea.sH1 = w.sH1[l]; ea.sH2 = w.sH2[l]; ea.sF1 = w.sF1[l]; ea.sP1 = w.sP1[l]; ea.wpack = w.wp_efwd;
     B3D_TRY(launch_rows<kNWEdge>(mp_edge_fwd_kernel<D, kNWEdge>, "mp_edge_fwd", ea, E, stream, B3D_K_EDGE_FWD));
-    NodeFwdArgs na;
-    memset(&na, 0, sizeof(na));
-    na.N = N; na.dst_ptr = g->dst_ptr; na.dst_perm = g->dst_perm; na.src_ptr = g->src_ptr; na.src_perm = g->src_perm;
-    na.past = w.past; na.fut = w.fut; na.M = w.M[l]; na.x_out = w.x[l + 1]; na.sH1 = w.nH1[l]; na.sH2 = w.nH2[l];
     na.wpack = w.wp_nfwd;
     B3D_TRY(launch_node_split<D>(mp_node_fwd_split_kernel<D>, "mp_node_fwd", na, N, stream, B3D_K_NODE_FWD));
   }

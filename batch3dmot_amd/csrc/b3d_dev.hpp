@@ -10,8 +10,7 @@
 //    the next layer, so activations never leave the register file and need no transposition.
 //    "Layout L": lane l = (i = l & 15, q = l >> 4) holds, for feature block b (16 features),
 //    features 16 b + 4 q + {0,1,2,3} of row i as one float4.
-//  * weights are the A operand.  They are pre-packed ("images": row stride K+4 floats, bias in
-//    column K) and streamed global -> LDS in chunks of <= 52 KB through a two-buffer ring,
+//  * weights are the A operand.  They are pre-packed ("images", two formats: see the geometry section) and streamed global -> LDS in chunks of <= 52 KB through a two-buffer ring,
 //    asynchronously with LDS-DMA (global_load_lds_dwordx4) while the previous chunk is being
 //    multiplied; one workgroup barrier per chunk.
 //
@@ -38,36 +37,64 @@ __host__ __device__ constexpr int round_up(int a, int b) { return (a + b - 1) / 
 __host__ __device__ constexpr int pad16(int a) { return round_up(a, 16); }
 
 // ---- packed weight image geometry (shared by host packer and device consumer) ------------
-// image of Linear(K -> N): NP = pad16(N) rows, row stride KP + 4 floats (KP = pad16(K)),
-// columns [0,K) = W[r][c], column KP = bias[r], everything else zero.  The image is cut into
-// row chunks that fit one ring slot; every chunk is padded to a multiple of 1 KB.
-__host__ __device__ constexpr int chunk_rows(int KP, int NP) {
-  int r = (kWBufFloats / (KP + 4)) / 16 * 16;
+// Two image formats, chosen per layer:
+//  * fp32 (KP not a multiple of 32, or opted out): NP = pad16(N) rows, row stride KP + 8 floats, columns [0,K) =
+//    W[r][c], column KP = bias[r], everything else zero.  Consumed by v_mfma_f32_16x16x4_f32 (exact fp32).
+//  * bf16x3 ("BF", KP a multiple of 32): every weight is split EXACTLY into three bf16 pieces (8 + 8 + 8 significand
+//    bits by truncation, w = w0 + w1 + w2); a row is [piece 0: KP/2 dwords][piece 1][piece 2][bias (fp32)][pad],
+//    stride 3 KP / 2 + 8 dwords.  Inside a piece the 32 features of group c sit at dwords 16 c .. 16 c + 15 in the
+//    order in which a wavefront HOLDS the next layer's operand (bf_pos below), so that the fp32 accumulator of one
+//    layer turns into the bf16 B operand of the next without any lane movement.  Consumed by
+//    v_mfma_f32_16x16x32_bf16 as "bf16x6": the activations are split the same way in registers and a product is
+//    formed from the six piece products of weight >= 2^-24 (w0x0, w0x1, w1x0, w0x2, w1x1, w2x0), accumulated in
+//    fp32: fp32-class accuracy (3.5e-7 vs 2.0e-7 of the fmaf chain on two chained layers,
+//    tools/micro/bf16x6_linear.hip) at 16 / 6 of the fp32 MFMA rate (measured 258 vs 134 TFLOP/s fp32-equivalent).
+// Both strides are = 8 mod 16 dwords: conflict-free ds_read_b128 of a 16-row fragment (a stride = 4 mod 16 is 2-way
+// conflicted on gfx950's b128 lane groups).  The image is cut into row chunks that fit one ring slot; every chunk is
+// padded to a multiple of 1 KB.
+#ifndef B3D_BF16X6
+#define B3D_BF16X6 1
+#endif
+__host__ __device__ constexpr bool bf_auto(int KP) { return B3D_BF16X6 != 0 && KP % 32 == 0 && KP <= 256; }
+__host__ __device__ constexpr int row_stride(int KP, bool bf) { return bf ? 3 * KP / 2 + 8 : KP + 8; }
+__host__ __device__ constexpr int bias_col(int KP, bool bf) { return bf ? 3 * KP / 2 : KP; }
+// position (0..31) inside its 32-feature group at which feature f (0..31) of the group is stored / held:
+// lane quarter g = (f & 15) >> 2 holds element j = 4 (f >> 4) + (f & 3) of the bf16 operand fragment
+__host__ __device__ constexpr int bf_pos(int f) { return 8 * ((f & 15) >> 2) + 4 * (f >> 4) + (f & 3); }
+__host__ __device__ constexpr int chunk_rows(int KP, int NP, bool bf) {
+  // whole 16-row blocks; 128-row multiples where they fit, so that a chunk boundary is a multiple of the wave count
+  // for the kernels that deal output blocks round-robin to 4 or 8 wavefronts (b3d_node.hpp)
+  int r = kWBufFloats / row_stride(KP, bf);
+  r = r >= 128 ? r / 128 * 128 : r / 16 * 16;
   return r < NP ? r : NP;
 }
-__host__ __device__ constexpr int n_chunks(int KP, int NP) {
-  return (NP + chunk_rows(KP, NP) - 1) / chunk_rows(KP, NP);
+__host__ __device__ constexpr int n_chunks(int KP, int NP, bool bf) {
+  return (NP + chunk_rows(KP, NP, bf) - 1) / chunk_rows(KP, NP, bf);
 }
-__host__ __device__ constexpr int chunk_nrows(int KP, int NP, int c) {   // rows in chunk c
-  int cr = chunk_rows(KP, NP);
+__host__ __device__ constexpr int chunk_nrows(int KP, int NP, bool bf, int c) {   // rows in chunk c
+  int cr = chunk_rows(KP, NP, bf);
   int left = NP - c * cr;
   return left < cr ? left : cr;
 }
-__host__ __device__ constexpr int chunk_floats(int KP, int rows) {
-  return round_up(rows * (KP + 4), kChunkAlign);
+__host__ __device__ constexpr int chunk_floats(int KP, bool bf, int rows) {
+  return round_up(rows * row_stride(KP, bf), kChunkAlign);
 }
-__host__ __device__ constexpr int image_floats(int KP, int NP) {
+__host__ __device__ constexpr int image_floats(int KP, int NP, bool bf) {
   int tot = 0;
-  for (int c = 0; c < n_chunks(KP, NP); ++c) tot += chunk_floats(KP, chunk_nrows(KP, NP, c));
+  for (int c = 0; c < n_chunks(KP, NP, bf); ++c) tot += chunk_floats(KP, bf, chunk_nrows(KP, NP, bf, c));
   return tot;
 }
 
-// A layer of a kernel's weight sequence: padded input width KP, padded output width NP.
-template <int KP_, int NP_>
+// A layer of a kernel's weight sequence: padded input width KP, padded output width NP, image format
+// (BF_: -1 = by the rule above, 0 = fp32, 1 = bf16x3).
+template <int KP_, int NP_, int BF_ = -1>
 struct L {
   static constexpr int KP = KP_, NP = NP_;
+  static constexpr bool BF = BF_ < 0 ? bf_auto(KP_) : BF_ != 0;
   static_assert(KP_ % 16 == 0 && NP_ % 16 == 0, "pad layer widths to multiples of 16");
+  static_assert(!BF || KP_ % 32 == 0, "the bf16 operand covers 32 features");
 };
+template <int KP_, int NP_> using LF = L<KP_, NP_, 0>;       // fp32 image, exact fmaf chain
 
 // The ordered list of layers a kernel consumes (one weight image each).
 template <class... Ls>
@@ -75,7 +102,8 @@ struct LayerSeq {
   static constexpr int NL = sizeof...(Ls);
   __host__ __device__ static constexpr int kp(int li) { constexpr int a[] = {Ls::KP...}; return a[li]; }
   __host__ __device__ static constexpr int np(int li) { constexpr int a[] = {Ls::NP...}; return a[li]; }
-  __host__ __device__ static constexpr int layer_chunks(int li) { return n_chunks(kp(li), np(li)); }
+  __host__ __device__ static constexpr bool bf(int li) { constexpr bool a[] = {Ls::BF...}; return a[li]; }
+  __host__ __device__ static constexpr int layer_chunks(int li) { return n_chunks(kp(li), np(li), bf(li)); }
   __host__ __device__ static constexpr int first_chunk(int li) {
     int c = 0;
     for (int i = 0; i < li; ++i) c += layer_chunks(i);
@@ -84,7 +112,7 @@ struct LayerSeq {
   static constexpr int NCH = first_chunk(NL);
   __host__ __device__ static constexpr int layer_off(int li) {     // float offset of the image
     int o = 0;
-    for (int i = 0; i < li; ++i) o += image_floats(kp(i), np(i));
+    for (int i = 0; i < li; ++i) o += image_floats(kp(i), np(i), bf(i));
     return o;
   }
   static constexpr int TOTAL_FLOATS = layer_off(NL);
@@ -96,12 +124,12 @@ struct LayerSeq {
   __host__ __device__ static constexpr int chunk_off(int ci) {
     int li = chunk_layer(ci);
     int o = layer_off(li);
-    for (int c = 0; c < ci - first_chunk(li); ++c) o += chunk_floats(kp(li), chunk_nrows(kp(li), np(li), c));
+    for (int c = 0; c < ci - first_chunk(li); ++c) o += chunk_floats(kp(li), bf(li), chunk_nrows(kp(li), np(li), bf(li), c));
     return o;
   }
   __host__ __device__ static constexpr int chunk_size(int ci) {    // floats, padded
     int li = chunk_layer(ci);
-    return chunk_floats(kp(li), chunk_nrows(kp(li), np(li), ci - first_chunk(li)));
+    return chunk_floats(kp(li), bf(li), chunk_nrows(kp(li), np(li), bf(li), ci - first_chunk(li)));
   }
   __host__ __device__ static constexpr int max_chunk() {           // floats of the largest chunk
     int m = 0;
@@ -145,6 +173,9 @@ struct WStreamT {
 #if B3D_USE_LDS_DMA
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float* src = g + off;
+    // opaque per call: hipcc otherwise hoists the per-piece 64-bit source addresses of EVERY chunk of the sequence
+    // out of the tile loop (up to ~150 address pairs) and spills them
+    asm volatile("" : "+v"(src));
     float* dst = lds + to_slot * SLOT;
 #pragma unroll
     for (int i0 = 0; i0 < n4; i0 += NT) {
@@ -261,6 +292,7 @@ struct WStreamG {
     static_assert(G::group_floats(LEAD) <= GSLOT && n4 % 64 == 0, "group larger than a slot");
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float* src = g + off;
+    asm volatile("" : "+v"(src));          // see WStreamT::issue
 #pragma unroll
     for (int i0 = 0; i0 < n4; i0 += NT) {
       const int b = i0 + wave * 64;
@@ -322,18 +354,79 @@ __device__ __forceinline__ v4f relu4(v4f a) {
   return r;
 }
 
+// ---- bf16x6: operand fragments of v_mfma_f32_16x16x32_bf16 --------------------------------------------------
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+struct Bf3 { bf8 p0, p1, p2; };                             // the three pieces of 8 operand elements
+
+// Exact three-way split of two layout-L blocks of one row (features 32 c + 4 q + {0..3} and 32 c + 16 + 4 q + {0..3})
+// into the B-operand fragments of feature group c.  Truncation split: x0 = top 16 bits of x, r = x - x0 (exact, <= 16
+// significant bits), x1 = top 16 bits of r, x2 = r - x1 (exact, <= 8 bits).
+__device__ __forceinline__ Bf3 bf_split(const v4f a, const v4f b) {
+  const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  unsigned h[8], m[8], l[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    h[i] = __float_as_uint(x[i]);
+    const float r1 = x[i] - __uint_as_float(h[i] & 0xffff0000u);
+    m[i] = __float_as_uint(r1);
+    l[i] = __float_as_uint(r1 - __uint_as_float(m[i] & 0xffff0000u));
+  }
+  u4v q0, q1, q2;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {                             // v_perm_b32: the upper halves of two dwords
+    q0[d] = __builtin_amdgcn_perm(h[2 * d + 1], h[2 * d], 0x07060302u);
+    q1[d] = __builtin_amdgcn_perm(m[2 * d + 1], m[2 * d], 0x07060302u);
+    q2[d] = __builtin_amdgcn_perm(l[2 * d + 1], l[2 * d], 0x07060302u);
+  }
+  return Bf3{__builtin_bit_cast(bf8, q0), __builtin_bit_cast(bf8, q1), __builtin_bit_cast(bf8, q2)};
+}
+__device__ __forceinline__ v4f bf_mfma6(const Bf3& w, const Bf3& x, v4f acc) {   // smallest terms first
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.p0, x.p2, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.p1, x.p1, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.p2, x.p0, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.p0, x.p1, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.p1, x.p0, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.p0, x.p0, acc, 0, 0, 0);
+  return acc;
+}
+template <int KP>
+__device__ __forceinline__ Bf3 bf_load(const float* p) {    // p: this lane's 16 bytes of piece 0; pieces are KP/2 dwords apart
+  Bf3 f;
+  f.p0 = __builtin_bit_cast(bf8, *reinterpret_cast<const u4v*>(p));
+  f.p1 = __builtin_bit_cast(bf8, *reinterpret_cast<const u4v*>(p + KP / 2));
+  f.p2 = __builtin_bit_cast(bf8, *reinterpret_cast<const u4v*>(p + KP));
+  return f;
+}
+// The operand a layer consumes: the fp32 blocks themselves (fp32 image) or their bf16 pieces (BF image), made once per
+// layer, in front of its first weight chunk.
+template <int KP, bool BF>
+struct LinIn {
+  const v4f* in;
+  __device__ __forceinline__ void prepare(const v4f* __restrict__ x) { in = x; }
+};
+template <int KP>
+struct LinIn<KP, true> {
+  Bf3 x[KP / 32];
+  __device__ __forceinline__ void prepare(const v4f* __restrict__ in) {
+#pragma unroll
+    for (int c = 0; c < KP / 32; ++c) x[c] = bf_split(in[2 * c], in[2 * c + 1]);
+  }
+};
+
 // act(W . in + b) for layer LI of Seq.  in: KB feature blocks (layout L); every finished output
 // block is handed to emit(mb, value) -- either kept in registers (linear) or streamed to memory
 // (linear_emit, for layers whose input + output do not fit the register file together).
 struct NoHook { __device__ __forceinline__ void operator()() const {} };
 
 template <class Seq, int LI, bool RELU, bool BIAS, int CH, class WS, class Emit, class Hook>
-__device__ __forceinline__ void linear_chunk(WS& ws, bool more, const v4f* __restrict__ in, Emit& emit, Hook& hook,
-                                             const v4f* init = nullptr) {
+__device__ __forceinline__ void linear_chunk(WS& ws, bool more, const v4f* __restrict__ in_blocks, LinIn<Seq::kp(LI), Seq::bf(LI)>& xin,
+                                             Emit& emit, Hook& hook, const v4f* init = nullptr) {
   constexpr int KP = Seq::kp(LI), NP = Seq::np(LI);
+  constexpr bool BF = Seq::bf(LI);
   constexpr int KB = KP / 16, NB = NP / 16;
-  constexpr int STRIDE = KP + 4;
-  constexpr int CR = chunk_rows(KP, NP);
+  constexpr int STRIDE = row_stride(KP, BF);
+  constexpr int CR = chunk_rows(KP, NP, BF);
   constexpr int C0 = Seq::first_chunk(LI);
   constexpr int mb0 = CH * (CR / 16);
   constexpr int mbn = (mb0 + CR / 16 < NB) ? mb0 + CR / 16 : NB;
@@ -341,15 +434,49 @@ __device__ __forceinline__ void linear_chunk(WS& ws, bool more, const v4f* __res
   const int m = lane & 15, q = lane >> 4;
   const float* w = ws.template acquire<Seq, C0 + CH>(more);
   // work that should overlap this layer's MFMAs instead of sitting in front of its barrier (the
-  // acquire above drains vmcnt, stores included): e.g. the previous layer's activation stores
-  if constexpr (CH == 0) hook();
+  // acquire above drains vmcnt, stores included): e.g. the previous layer's activation stores.  The operand is
+  // made AFTER the hook: a hook that stores the input blocks is the last reader of their fp32 form, so those
+  // registers are free as soon as the bf16 pieces exist.
+  if constexpr (CH == 0) { hook(); xin.prepare(in_blocks); }
+  const float* wrow = w + m * STRIDE + 4 * q;                 // A fragment: row m of a block, this lane's 16 bytes
+  const float* wbias = w + 4 * q * STRIDE + bias_col(KP, BF); // bias of output rows 4q..4q+3
+  const v4f zero4 = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (BF) {
+    // One output block at a time (a single accumulation chain of v_mfma_f32_16x16x32_bf16 issues back to back);
+    // the three weight fragments (and the bias) of step t+1 are read from LDS BEFORE the 6 MFMAs of step t.
+    constexpr int KG = KP / 32;
+    auto frag = [&](int mb, int c) { return bf_load<KP>(wrow + (mb - mb0) * 16 * STRIDE + 16 * c); };
+    auto bias = [&](int mb) -> v4f {
+      const float* wb = wbias + (mb - mb0) * 16 * STRIDE;
+      return v4f{wb[0], wb[STRIDE], wb[2 * STRIDE], wb[3 * STRIDE]};
+    };
+    Bf3 cur = frag(mb0, 0);
+    v4f nb = BIAS ? bias(mb0) : zero4;
+#pragma unroll
+    for (int mb = mb0; mb < mbn; ++mb) {
+      v4f acc = nb;
+      if (init) acc += init[mb];
+#pragma unroll
+      for (int c = 0; c < KG; ++c) {
+        Bf3 nxt = cur;
+        if (c + 1 < KG) nxt = frag(mb, c + 1);
+        else if (mb + 1 < mbn) {
+          nxt = frag(mb + 1, 0);
+          if constexpr (BIAS) nb = bias(mb + 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        acc = bf_mfma6(cur, xin.x[c], acc);
+        cur = nxt;
+      }
+      emit(mb, RELU ? relu4(acc) : acc);
+    }
+  } else {
+  const v4f* __restrict__ in = xin.in;
   // Two output blocks at a time (two independent accumulator chains hide the 40-cycle dependent
   // latency of v_mfma_f32_16x16x4_f32 behind its 32-cycle issue interval).  The weight fragments
   // (and the bias) of step t+1 are read from LDS BEFORE the 8 MFMAs of step t are issued, so the
   // LDS latency is always covered by a full step of matrix work.
   constexpr int NPAIR = (mbn - mb0 + 1) / 2;
-  const float* wrow = w + m * STRIDE + 4 * q;                 // A fragment: row m of a block, 4 consecutive k
-  const float* wbias = w + 4 * q * STRIDE + KP;               // bias of output rows 4q..4q+3
   auto frag = [&](int pair, int half, int kb) -> v4f {
     return *reinterpret_cast<const v4f*>(wrow + (pair * 2 + half) * 16 * STRIDE + 16 * kb);
   };
@@ -357,7 +484,6 @@ __device__ __forceinline__ void linear_chunk(WS& ws, bool more, const v4f* __res
     const float* wb = wbias + (pair * 2 + half) * 16 * STRIDE;
     return v4f{wb[0], wb[STRIDE], wb[2 * STRIDE], wb[3 * STRIDE]};
   };
-  const v4f zero4 = {0.f, 0.f, 0.f, 0.f};
   v4f fa0 = frag(0, 0, 0);
   v4f fa1 = (mb0 + 1 < mbn) ? frag(0, 1, 0) : zero4;
   v4f nb0 = BIAS ? bias(0, 0) : zero4;
@@ -396,18 +522,20 @@ __device__ __forceinline__ void linear_chunk(WS& ws, bool more, const v4f* __res
     emit(mb, RELU ? relu4(acc0) : acc0);
     if (two) emit(mb + 1, RELU ? relu4(acc1) : acc1);
   }
+  }
 }
 
 template <class Seq, int LI, bool RELU, bool BIAS, class WS, class Emit, class Hook, int... CH>
 __device__ __forceinline__ void linear_impl(WS& ws, bool more, const v4f* __restrict__ in, Emit& emit, Hook& hook,
                                             std::integer_sequence<int, CH...>, const v4f* init = nullptr) {
-  (linear_chunk<Seq, LI, RELU, BIAS, CH, WS, Emit, Hook>(ws, more, in, emit, hook, init), ...);
+  LinIn<Seq::kp(LI), Seq::bf(LI)> xin;
+  (linear_chunk<Seq, LI, RELU, BIAS, CH, WS, Emit, Hook>(ws, more, in, xin, emit, hook, init), ...);
 }
 
 template <class Seq, int LI, bool RELU, bool BIAS = true, class WS, class Emit, class Hook = NoHook>
 __device__ __forceinline__ void linear_emit(WS& ws, bool more, const v4f* __restrict__ in, Emit emit, Hook hook = Hook{}) {
   linear_impl<Seq, LI, RELU, BIAS, WS, Emit, Hook>(ws, more, in, emit, hook,
-                                                   std::make_integer_sequence<int, n_chunks(Seq::kp(LI), Seq::np(LI))>{});
+                                                   std::make_integer_sequence<int, Seq::layer_chunks(LI)>{});
 }
 
 template <class Seq, int LI, bool RELU, bool BIAS = true, class WS, class Hook = NoHook>
@@ -423,7 +551,7 @@ __device__ __forceinline__ void linear_init(WS& ws, bool more, const v4f* __rest
                                             Hook hook = Hook{}) {
   auto emit = [out](int mb, v4f v) { out[mb] = v; };
   linear_impl<Seq, LI, RELU, BIAS, WS, decltype(emit), Hook>(ws, more, in, emit, hook,
-                                                             std::make_integer_sequence<int, n_chunks(Seq::kp(LI), Seq::np(LI))>{}, init);
+                                                             std::make_integer_sequence<int, Seq::layer_chunks(LI)>{}, init);
 }
 
 // ---- row <-> register helpers (layout L) -----------------------------------------------------

@@ -60,7 +60,7 @@ __device__ __forceinline__ float row_max16(float v) {
 // applies the now-known affine map to the maximum (positive scale) or the minimum (negative scale) -- the [points,
 // 1024] activation is never stored.  Per weight chunk the 8 tile partials meet in a double-buffered LDS area and are
 // combined behind the NEXT chunk's barrier (no extra barrier per chunk).
-constexpr int kStatChunkFeat = 96;                              // features of one weight chunk of the 128 -> 1024 layer
+constexpr int kStatChunkFeat = chunk_rows(128, 1024, PointSeq::bf(2));   // features of one weight chunk of the 128 -> 1024 layer
 template <int P, bool STATS>
 __global__ __launch_bounds__(512, 1) void point_feat_kernel(const PointFeatArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -99,7 +99,6 @@ __global__ __launch_bounds__(512, 1) void point_feat_kernel(const PointFeatArgs 
     if constexpr (STATS) {
       // xpart as [2 parities][4 quantities][8 wavefronts][96 features]
       constexpr int CB = kStatChunkFeat / 16;                  // output blocks per weight chunk
-      static_assert(chunk_rows(128, 1024) == kStatChunkFeat, "chunk geometry of the 128 -> 1024 layer");
       auto fmax_ = [](float x, float y) { return fmaxf(x, y); };
       auto fmin_ = [](float x, float y) { return fminf(x, y); };
       auto fadd_ = [](float x, float y) { return x + y; };

@@ -36,20 +36,20 @@ struct Hoist {
   static constexpr int TW = GW + D::DX;                     // width of the per-node table
   static constexpr int OA = 0, OB = D::EH1, OF = 2 * D::EH1, OP = 2 * D::EH1 + D::MH;
   static constexpr int KE = D::DE + D::DA;                  // per-edge input columns of edge_update.0
-  using ProjSeq = LayerSeq<L<D::DX, TW>>;                   // x[l]  -> T (without the x0 terms)
-  using Proj0Seq = LayerSeq<L<D::DX, 2 * D::MH>>;           // x0    -> x0 terms of the F | P columns
-  using EdgeFwdSeq = LayerSeq<L<KE, D::EH1>, L<D::EH1, D::EH2>, L<D::EH2, D::DE>,     // edge_update (.0: edge columns)
-                              L<D::DE, D::MH>, L<D::MH, D::DM>,                       // create_future_msgs
-                              L<D::DE, D::MH>, L<D::MH, D::DM>>;                      // create_past_msgs
+  using ProjSeq = LayerSeq<typename D::template NL<D::DX, TW>>;                   // x[l]  -> T (without the x0 terms)
+  using Proj0Seq = LayerSeq<typename D::template NL<D::DX, 2 * D::MH>>;           // x0    -> x0 terms of the F | P columns
+  using EdgeFwdSeq = LayerSeq<typename D::template LL<KE, D::EH1>, typename D::template LL<D::EH1, D::EH2>, typename D::template LL<D::EH2, D::DE>,     // edge_update (.0: edge columns)
+                              typename D::template LL<D::DE, D::MH>, typename D::template LL<D::MH, D::DM>,                       // create_future_msgs
+                              typename D::template LL<D::DE, D::MH>, typename D::template LL<D::MH, D::DM>>;                      // create_past_msgs
   // transposed images, data-gradient order; the .0 layers keep their edge columns only
-  using EdgeBwdSeq = LayerSeq<L<D::DM, D::MH>, L<D::MH, D::DE>,                       // past.2^T, past.0[e']^T
-                              L<D::DM, D::MH>, L<D::MH, D::DE>,                       // future.2^T, future.0[e']^T
-                              L<D::DE, D::EH2>, L<D::EH2, D::EH1>, L<D::EH1, KE>>;    // edge_update.4^T/.2^T/.0[e]^T
-  using EdgeBwdSeqNoMsg = LayerSeq<L<D::DE, D::EH2>, L<D::EH2, D::EH1>, L<D::EH1, KE>>;
+  using EdgeBwdSeq = LayerSeq<typename D::template LL<D::DM, D::MH>, typename D::template LL<D::MH, D::DE>,                       // past.2^T, past.0[e']^T
+                              typename D::template LL<D::DM, D::MH>, typename D::template LL<D::MH, D::DE>,                       // future.2^T, future.0[e']^T
+                              typename D::template LL<D::DE, D::EH2>, typename D::template LL<D::EH2, D::EH1>, typename D::template LL<D::EH1, KE>>;    // edge_update.4^T/.2^T/.0[e]^T
+  using EdgeBwdSeqNoMsg = LayerSeq<typename D::template LL<D::DE, D::EH2>, typename D::template LL<D::EH2, D::EH1>, typename D::template LL<D::EH1, KE>>;
   // per-node gradient of (x | x0) from the gradient of T: [W_eu_i^T | W_eu_j^T | W_fu_x^T | W_pa_x^T ; 0 | 0 | W_fu_x0^T | W_pa_x0^T]
   // ... as four accumulating products, one per list (all output blocks of a product sit in one weight chunk,
   // so every owning wavefront works at once): dH1-by-dst and dH1-by-src reach dx only
-  using GradProjSeq = LayerSeq<L<D::EH1, D::DX>, L<D::EH1, D::DX>, L<D::MH, 2 * D::DX>, L<D::MH, 2 * D::DX>>;
+  using GradProjSeq = LayerSeq<typename D::template NL<D::EH1, D::DX>, typename D::template NL<D::EH1, D::DX>, typename D::template NL<D::MH, 2 * D::DX>, typename D::template NL<D::MH, 2 * D::DX>>;
 };
 
 // Storer of the projection chain: the F | P columns receive the layer-invariant x0 terms.
@@ -122,6 +122,9 @@ __global__ __launch_bounds__(NW * 64, 2) void mp_edge_fwd_h_kernel(const EdgeFwd
     add_blocks<H1B>(h1, tb);
     B3D_STAMP(2, 1);
 
+    // wide stacks (camera+LiDAR+radar: 256-wide hidden layer) fetch the past-stack rows two layers later: a layer
+    // there is several microseconds long and the register file is full
+    constexpr bool LATE_PI = D::EH1 > 128;
     v4f h2[H2B], en[EB];
     linear_init<Seq, 0, true, false>(ws, more, ein, h1, h1);
     B3D_STAMP(2, 2);
@@ -135,14 +138,19 @@ __global__ __launch_bounds__(NW * 64, 2) void mp_edge_fwd_h_kernel(const EdgeFwd
     linear<Seq, 2, false>(ws, more, h2, en, [&]() {
       B3D_STAMP(2, 12);
       if (a.sH2) store_row<H2B>(a.sH2, row, D::EH2, 0, valid, h2);
-      load_row_u<MHB>(a.T, s, H::TW, H::OP, pi);
+      if constexpr (!LATE_PI) load_row_u<MHB>(a.T, s, H::TW, H::OP, pi);
       B3D_STAMP(2, 13);
     });
     B3D_STAMP(2, 4);
 
     v4f mo[DMB], mo2[DMB];
     wait_for(fi);
-    linear_init<Seq, 3, true, false>(ws, more, en, fi, fi, [&]() { B3D_STAMP(2, 14); store_row<EB>(a.e_out, row, D::DE, 0, valid, en); B3D_STAMP(2, 15); });
+    linear_init<Seq, 3, true, false>(ws, more, en, fi, fi, [&]() {
+      B3D_STAMP(2, 14);
+      store_row<EB>(a.e_out, row, D::DE, 0, valid, en);
+      if constexpr (LATE_PI) load_row_u<MHB>(a.T, s, H::TW, H::OP, pi);
+      B3D_STAMP(2, 15);
+    });
     B3D_STAMP(2, 5);
     linear<Seq, 4, false>(ws, more, fi, mo, [&]() { B3D_STAMP(2, 16); if (a.sF1) store_row<MHB>(a.sF1, row, D::MH, 0, valid, fi); B3D_STAMP(2, 17); });
     B3D_STAMP(2, 6);
@@ -158,7 +166,8 @@ __global__ __launch_bounds__(NW * 64, 2) void mp_edge_fwd_h_kernel(const EdgeFwd
 
 // Node update + the per-node table of the NEXT layer in one launch (b3d_node.hpp, PROJ stage).
 template <class D>
-using NodeFwdHSeq = LayerSeq<L<D::NIN, D::NH1>, L<D::NH1, D::NH2>, L<D::NH2, D::DX>, L<D::DX, Hoist<D>::TW>>;
+using NodeFwdHSeq = LayerSeq<typename D::template NL<D::NIN, D::NH1>, typename D::template NL<D::NH1, D::NH2>, typename D::template NL<D::NH2, D::DX>,
+                             typename D::template NL<D::DX, Hoist<D>::TW>>;
 
 template <class D>
 __global__ __launch_bounds__(kNodeWavesWide * 64, 1) void mp_node_fwd_split_h_kernel(const NodeFwdArgs a) {
@@ -169,7 +178,7 @@ __global__ __launch_bounds__(kNodeWavesWide * 64, 1) void mp_node_fwd_split_h_ke
 // x0 terms + the table of layer 0 from the node encoder's output, four wavefronts per 16-row tile (the
 // 48 -> 192 and 48 -> 432 products are 468 MFMAs: too long a chain for one wavefront).
 template <class D>
-using Proj0Seq2 = LayerSeq<L<D::DX, 2 * D::MH>, L<D::DX, Hoist<D>::TW>>;
+using Proj0Seq2 = LayerSeq<typename D::template NL<D::DX, 2 * D::MH>, typename D::template NL<D::DX, Hoist<D>::TW>>;
 struct NodeProj0Args {
   int N;
   const float* x0;      // [N, DX]
@@ -454,8 +463,10 @@ __global__ __launch_bounds__(kGradProjWaves * 64, 1) void node_gradproj_kernel(c
 // node_gradproj + the node update's data gradient in ONE launch (layers 0 .. depth-2): the per-node
 // (dx | dx0) never leaves the CU.  8 wavefronts per 16-row tile throughout.
 template <class D>
-using NodeBwdHSeq = LayerSeq<L<D::EH1, D::DX>, L<D::EH1, D::DX>, L<D::MH, 2 * D::DX>, L<D::MH, 2 * D::DX>,   // GradProj
-                             L<D::DX, D::NH2>, L<D::NH2, D::NH1>, L<D::NH1, D::NIN>>;          // combine_future_past^T
+using NodeBwdHSeq = LayerSeq<typename D::template NL<D::EH1, D::DX>, typename D::template NL<D::EH1, D::DX>,
+                             typename D::template NL<D::MH, 2 * D::DX>, typename D::template NL<D::MH, 2 * D::DX>,   // GradProj
+                             typename D::template NL<D::DX, D::NH2>, typename D::template NL<D::NH2, D::NH1>,
+                             typename D::template NL<D::NH1, D::NIN>>;                          // combine_future_past^T
 struct NodeBwdHArgs {
   NodeGradProjArgs gp;  // lists of layer l+1, dT of layer l+1 (gp.gx unused)
   float* dx0_acc;       // [N, DX] running gradient of initial_x

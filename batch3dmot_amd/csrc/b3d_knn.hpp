@@ -38,7 +38,7 @@ inline void knn_carve(KnnWs& k, Carver& c, int N, int D) {
   k.rank = c.take<int>(n); k.order = c.take<int>(n); k.fbeg = c.take<int>(n); k.fend = c.take<int>(n);
   k.nbr = c.take<int>(n * kKnnMaxK); k.cnt = c.take<int>(n); k.rcnt = c.take<int>(3 * n + 64);
   k.h = c.take<float>(n * D); k.y = c.take<float>(n * D);
-  k.wp = c.take<float>(image_floats(D, D));
+  k.wp = c.take<float>(D == 48 ? LayerSeq<L<48, 48>>::TOTAL_FLOATS : LayerSeq<L<96, 96>>::TOTAL_FLOATS);
   k.ranked = false;
   k.packed = false;
 }

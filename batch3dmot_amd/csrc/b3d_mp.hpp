@@ -20,28 +20,34 @@
 
 namespace b3d {
 
-template <int DX_, int DE_, int DA_, int EH1_, int EH2_, int MH_, int DM_, int NH1_, int NH2_>
+// BF_: weight image format of this model's message-passing layers (b3d_dev.hpp: -1 by width, 0 fp32)
+template <int DX_, int DE_, int DA_, int EH1_, int EH2_, int MH_, int DM_, int NH1_, int NH2_, int BF_ = -1>
 struct MPDims {
+  template <int K, int N> using LL = L<K, N, BF_>;
+  // node-sized kernels deal a layer's output blocks to 4-16 wavefronts chunk by chunk: they keep the fp32 format,
+  // whose chunks hold more blocks (and their few thousand rows are latency bound, not MFMA bound)
+  template <int K, int N> using NL = LF<K, N>;
   static constexpr int DX = DX_, DE = DE_, DA = DA_, EH1 = EH1_, EH2 = EH2_, MH = MH_, DM = DM_,
                        NH1 = NH1_, NH2 = NH2_;
   static constexpr int EIN = 2 * DX + DE + DA;   // edge_update input
   static constexpr int MIN = 2 * DX + DE;        // create_*_msgs input
   static constexpr int NIN = 2 * DM;             // combine_future_past input
   // weight consumption order of each kernel (one packed image per entry)
-  using EdgeFwdSeq = LayerSeq<L<EIN, EH1>, L<EH1, EH2>, L<EH2, DE>,      // edge_update.0/.2/.4
-                              L<MIN, MH>, L<MH, DM>,                     // create_future_msgs.0/.2
-                              L<MIN, MH>, L<MH, DM>>;                    // create_past_msgs.0/.2
-  using NodeFwdSeq = LayerSeq<L<NIN, NH1>, L<NH1, NH2>, L<NH2, DX>>;     // combine_future_past
+  using EdgeFwdSeq = LayerSeq<LL<EIN, EH1>, LL<EH1, EH2>, LL<EH2, DE>,      // edge_update.0/.2/.4
+                              LL<MIN, MH>, LL<MH, DM>,                     // create_future_msgs.0/.2
+                              LL<MIN, MH>, LL<MH, DM>>;                    // create_past_msgs.0/.2
+  using NodeFwdSeq = LayerSeq<NL<NIN, NH1>, NL<NH1, NH2>, NL<NH2, DX>>;     // combine_future_past
   // transposed images, data-gradient order
-  using EdgeBwdSeq = LayerSeq<L<DM, MH>, L<MH, MIN>,                     // past.2^T, past.0^T
-                              L<DM, MH>, L<MH, MIN>,                     // future.2^T, future.0^T
-                              L<DE, EH2>, L<EH2, EH1>, L<EH1, EIN>>;     // edge_update.4^T/.2^T/.0^T
-  using EdgeBwdSeqNoMsg = LayerSeq<L<DE, EH2>, L<EH2, EH1>, L<EH1, EIN>>;
-  using NodeBwdSeq = LayerSeq<L<DX, NH2>, L<NH2, NH1>, L<NH1, NIN>>;
+  using EdgeBwdSeq = LayerSeq<LL<DM, MH>, LL<MH, MIN>,                     // past.2^T, past.0^T
+                              LL<DM, MH>, LL<MH, MIN>,                     // future.2^T, future.0^T
+                              LL<DE, EH2>, LL<EH2, EH1>, LL<EH1, EIN>>;     // edge_update.4^T/.2^T/.0^T
+  using EdgeBwdSeqNoMsg = LayerSeq<LL<DE, EH2>, LL<EH2, EH1>, LL<EH1, EIN>>;
+  using NodeBwdSeq = LayerSeq<NL<DX, NH2>, NL<NH2, NH1>, NL<NH1, NIN>>;
 };
 
-using DimsP = MPDims<48, 32, 0, 96, 64, 96, 64, 96, 64>;           // pose_gnn.py:94-120
-using DimsC = MPDims<96, 64, 64, 256, 128, 192, 128, 192, 128>;    // clr_att_gnn.py:196-222
+using DimsP = MPDims<48, 32, 0, 96, 64, 96, 64, 96, 64, 0>;        // fp32 images (exact fmaf chain): its hoisted stacks stay resident in LDS           // pose_gnn.py:94-120
+using DimsC = MPDims<96, 64, 64, 256, 128, 192, 128, 192, 128, 0>;    // clr_att_gnn.py:196-222, unsplit kernels (fp32 images)
+using DimsCB = MPDims<96, 64, 64, 256, 128, 192, 128, 192, 128, -1>;  // the same widths, bf16x3 images: hoisted kernels
 
 struct EdgeFwdArgs {
   int E;

@@ -32,11 +32,13 @@ struct NodeSplit {
 //             LDS writes of every wavefront are visible;
 //   emit(mb, v): called by the wavefront that owns output block mb.
 template <class Seq, int LI, bool RELU, bool BIAS, int NWS, int CH, class WS, class InLoad, class Emit>
-__device__ __forceinline__ void linear_split_chunk(WS& ws, bool more, const v4f* __restrict__ in, InLoad& inload, Emit& emit) {
+__device__ __forceinline__ void linear_split_chunk(WS& ws, bool more, const v4f* __restrict__ in, LinIn<Seq::kp(LI), Seq::bf(LI)>& xin,
+                                                   InLoad& inload, Emit& emit) {
   constexpr int KP = Seq::kp(LI), NP = Seq::np(LI);
+  constexpr bool BF = Seq::bf(LI);
   constexpr int KB = KP / 16, NB = NP / 16;
-  constexpr int STRIDE = KP + 4;
-  constexpr int CR = chunk_rows(KP, NP);
+  constexpr int STRIDE = row_stride(KP, BF);
+  constexpr int CR = chunk_rows(KP, NP, BF);
   constexpr int C0 = Seq::first_chunk(LI);
   constexpr int mb0 = CH * (CR / 16);
   constexpr int mbn = (mb0 + CR / 16 < NB) ? mb0 + CR / 16 : NB;
@@ -44,9 +46,43 @@ __device__ __forceinline__ void linear_split_chunk(WS& ws, bool more, const v4f*
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int m = lane & 15, q = lane >> 4;
   const float* w = ws.template acquire<Seq, C0 + CH>(more);
-  if constexpr (CH == 0) inload();
+  if constexpr (CH == 0) { inload(); xin.prepare(in); }       // the operand (bf16 pieces or the blocks themselves): once per layer
   const int first = mb0 + ((wave - mb0 % NWS) + NWS) % NWS;   // first owned block of the chunk
   const v4f zero4 = {0.f, 0.f, 0.f, 0.f};
+  auto emit_one = [&](int mb, v4f v, int slot) {
+    // emit(mb, v) or emit(mb, v, slot): slot = mb / NWS, the index of the block among those this
+    // wavefront owns -- a compile-time constant after unrolling (for per-wave register arrays)
+    if constexpr (requires { emit(0, zero4, 0); }) {
+      static_assert(mb0 % NWS == 0, "slot numbering needs chunk boundaries on multiples of the wave count");
+      emit(mb, v, slot);
+    } else {
+      emit(mb, v);
+    }
+  };
+  if constexpr (BF) {
+    constexpr int KG = KP / 32;
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) {
+      const int mb = first + NWS * j;
+      if (mb >= mbn) break;                                    // wave-uniform
+      const float* wa = w + ((mb - mb0) * 16 + m) * STRIDE + 4 * q;
+      v4f acc = zero4;
+      if constexpr (BIAS) {
+        const float* ba = w + ((mb - mb0) * 16 + 4 * q) * STRIDE + bias_col(KP, BF);
+        acc = v4f{ba[0], ba[STRIDE], ba[2 * STRIDE], ba[3 * STRIDE]};
+      }
+      Bf3 cur = bf_load<KP>(wa);
+#pragma unroll
+      for (int c = 0; c < KG; ++c) {
+        Bf3 nxt = cur;
+        if (c + 1 < KG) nxt = bf_load<KP>(wa + 16 * (c + 1));
+        __builtin_amdgcn_sched_barrier(0);
+        acc = bf_mfma6(cur, xin.x[c], acc);
+        cur = nxt;
+      }
+      emit_one(mb, RELU ? relu4(acc) : acc, mb0 / NWS + j);
+    }
+  } else {
 #pragma unroll
   for (int j = 0; j < JMAX; j += 2) {
     const int mbA = first + NWS * j, mbB = mbA + NWS;
@@ -74,29 +110,24 @@ __device__ __forceinline__ void linear_split_chunk(WS& ws, bool more, const v4f*
       if (hasB) acc1 = mfma4(fb, in[kb], acc1);
       fa = na; fb = nb;
     }
-    // emit(mb, v) or emit(mb, v, slot): slot = mb / NWS, the index of the block among those this
-    // wavefront owns -- a compile-time constant after unrolling (for per-wave register arrays)
-    if constexpr (requires { emit(0, zero4, 0); }) {
-      static_assert(mb0 % NWS == 0, "slot numbering needs chunk boundaries on multiples of the wave count");
-      emit(mbA, RELU ? relu4(acc0) : acc0, mb0 / NWS + j);
-      if (hasB) emit(mbB, RELU ? relu4(acc1) : acc1, mb0 / NWS + j + 1);
-    } else {
-      emit(mbA, RELU ? relu4(acc0) : acc0);
-      if (hasB) emit(mbB, RELU ? relu4(acc1) : acc1);
-    }
+    emit_one(mbA, RELU ? relu4(acc0) : acc0, mb0 / NWS + j);
+    if (hasB) emit_one(mbB, RELU ? relu4(acc1) : acc1, mb0 / NWS + j + 1);
+  }
   }
 }
 
 template <class Seq, int LI, bool RELU, bool BIAS, int NWS, class WS, class InLoad, class Emit, int... CH>
 __device__ __forceinline__ void linear_split_impl(WS& ws, bool more, const v4f* __restrict__ in, InLoad& inload, Emit& emit,
                                                   std::integer_sequence<int, CH...>) {
-  (linear_split_chunk<Seq, LI, RELU, BIAS, NWS, CH>(ws, more, in, inload, emit), ...);
+  LinIn<Seq::kp(LI), Seq::bf(LI)> xin;
+  if constexpr (!Seq::bf(LI)) xin.prepare(in);
+  (linear_split_chunk<Seq, LI, RELU, BIAS, NWS, CH>(ws, more, in, xin, inload, emit), ...);
 }
 
 template <class Seq, int LI, bool RELU, bool BIAS, int NWS, class WS, class InLoad, class Emit>
 __device__ __forceinline__ void linear_split(WS& ws, bool more, const v4f* __restrict__ in, InLoad inload, Emit emit) {
   linear_split_impl<Seq, LI, RELU, BIAS, NWS>(ws, more, in, inload, emit,
-                                              std::make_integer_sequence<int, n_chunks(Seq::kp(LI), Seq::np(LI))>{});
+                                              std::make_integer_sequence<int, Seq::layer_chunks(LI)>{});
 }
 
 // ------------------------------------------------------------------------------------------

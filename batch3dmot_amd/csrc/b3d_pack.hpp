@@ -1,6 +1,7 @@
 // Weight image packing (see b3d_dev.hpp "packed weight image geometry").
 #pragma once
 #include <hip/hip_runtime.h>
+#include "b3d_dev.hpp"
 
 namespace b3d {
 
@@ -20,6 +21,7 @@ struct PackDesc {
   int col0;          // >= 0 with `partial`: the slice lands at image columns [col0, col0 + K)
   int partial;       // 1: write only the slice's nrows x K cells (w == nullptr: zeros); other cells belong to other
                      //    descriptors of the same image
+  int bf;            // image format of the layer (b3d_dev.hpp): 0 fp32, 1 bf16x3
 };
 
 constexpr int kPackMax = 120;     // 8.5 KB of kernel arguments (the kernarg segment is plain memory on AMD): one launch packs a whole model's images
@@ -42,6 +44,7 @@ inline PackDesc pack_desc(int li, float* base, const float* w, const float* b, i
   d.ld = transposed ? N : K;
   d.row0 = 0; d.nrows = d.NP;
   d.col0 = 0; d.partial = 0;
+  d.bf = Seq::bf(li) ? 1 : 0;
   return d;
 }
 
@@ -70,7 +73,7 @@ inline PackDesc fill_desc(void* dst, int count, bool iota) {
   d.w = nullptr; d.b = nullptr; d.dst = (float*)dst;
   d.N = count; d.K = 0; d.NP = 0; d.KP = 0;
   d.transposed = iota ? 2 : 3;
-  d.ld = 0; d.row0 = 0; d.nrows = 0; d.col0 = 0; d.partial = 0;
+  d.ld = 0; d.row0 = 0; d.nrows = 0; d.col0 = 0; d.partial = 0; d.bf = 0;
   return d;
 }
 

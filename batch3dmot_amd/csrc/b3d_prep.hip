@@ -177,8 +177,59 @@ __global__ void pack_kernel(const PackArgs a) {
       p[id] = (d.transposed == 2) ? id : 0;
     return;
   }
-  const int stride = d.KP + 4;
-  const int cr = chunk_rows(d.KP, d.NP);
+  const bool bf = d.bf != 0;
+  const int stride = row_stride(d.KP, bf);
+  const int cr = chunk_rows(d.KP, d.NP, bf);
+  auto chunk_base = [&](int r, int& rc) -> size_t {          // chunk ch holds image rows [ch*cr, ...), each chunk padded to 1 KB
+    const int ch = r / cr;
+    rc = r - ch * cr;
+    size_t off = 0;
+    for (int i = 0; i < ch; ++i) off += chunk_floats(d.KP, bf, chunk_nrows(d.KP, d.NP, bf, i));
+    return off;
+  };
+  auto value = [&](int rl, int c) -> float {                 // element (rl, c) of the slice, zero outside [N, K]
+    if (rl >= d.N || c >= d.K || !d.w) return 0.f;
+    return d.transposed ? d.w[(size_t)c * d.ld + rl] : d.w[(size_t)rl * d.ld + c];
+  };
+  if (bf) {
+    // bf16x3 image: one thread per PAIR of adjacent columns (they share a dword in each of the three pieces) + one
+    // per bias.  A partial descriptor covers columns [col0, col0 + K): col0 and K even.
+    const int c0 = d.partial ? d.col0 : 0;
+    const int ncol = d.partial ? d.K : d.KP;                 // columns this descriptor writes
+    const int span = ncol / 2 + (d.partial ? 0 : 8);         // + bias and row padding (zeroed)
+    const int total = d.nrows * span;
+    unsigned* dst = reinterpret_cast<unsigned*>(d.dst);
+    for (int id = blockIdx.x * blockDim.x + threadIdx.x; id < total; id += gridDim.x * blockDim.x) {
+      const int rl = id / span, t = id - rl * span;
+      int rc;
+      const size_t base = chunk_base(d.row0 + rl, rc) + (size_t)rc * stride;
+      if (t >= ncol / 2) {                                   // bias (fp32) and padding
+        const int k = t - ncol / 2;
+        float v = 0.f;
+        if (k == 0 && rl < d.N && d.b && !d.transposed) v = d.b[rl];
+        dst[base + 3 * d.KP / 2 + k] = __float_as_uint(v);
+        continue;
+      }
+      const int c = 2 * t;                                   // slice columns c, c + 1 -> image columns c0 + c, c0 + c + 1
+      unsigned pc[3] = {0u, 0u, 0u};
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const float x = value(rl, c + e);
+        const unsigned xb = __float_as_uint(x);
+        const float r1 = x - __uint_as_float(xb & 0xffff0000u);
+        const unsigned mb = __float_as_uint(r1);
+        const float r2 = r1 - __uint_as_float(mb & 0xffff0000u);
+        pc[0] |= (xb >> 16) << (16 * e);
+        pc[1] |= (mb >> 16) << (16 * e);
+        pc[2] |= (__float_as_uint(r2) >> 16) << (16 * e);
+      }
+      const int col = c0 + c;
+      const int pos = 32 * (col / 32) + bf_pos(col % 32);    // even: the pair (pos, pos + 1) is one dword
+#pragma unroll
+      for (int p = 0; p < 3; ++p) dst[base + p * (d.KP / 2) + pos / 2] = pc[p];
+    }
+    return;
+  }
   const int span = d.partial ? d.K : stride;                 // columns this descriptor writes per row
   const int total = d.nrows * span;
   for (int id = blockIdx.x * blockDim.x + threadIdx.x; id < total; id += gridDim.x * blockDim.x) {
@@ -193,11 +244,8 @@ __global__ void pack_kernel(const PackArgs a) {
         v = d.w[(size_t)c * d.ld + rl];
       }
     }
-    // chunked placement: chunk ch holds image rows [ch*cr, ...), each chunk padded to 1 KB
-    const int r = d.row0 + rl;
-    const int ch = r / cr, rc = r - ch * cr;
-    size_t off = 0;
-    for (int i = 0; i < ch; ++i) off += chunk_floats(d.KP, chunk_nrows(d.KP, d.NP, i));
+    int rc;
+    const size_t off = chunk_base(d.row0 + rl, rc);
     d.dst[off + (size_t)rc * stride + d.col0 + c] = v;
   }
 }
@@ -209,7 +257,7 @@ int pack_images(const PackDesc* descs, int n, hipStream_t stream) {
     int maxtot = 0;
     for (int i = 0; i < a.n; ++i) {
       a.d[i] = descs[i0 + i];
-      const int t = (a.d[i].transposed >= 2) ? a.d[i].N : a.d[i].nrows * (a.d[i].partial ? a.d[i].K : a.d[i].KP + 4);
+      const int t = (a.d[i].transposed >= 2) ? a.d[i].N : a.d[i].nrows * (a.d[i].partial ? a.d[i].K : row_stride(a.d[i].KP, a.d[i].bf != 0));
       if (t > maxtot) maxtot = t;
     }
     int gx = (maxtot + 255) / 256;

@@ -43,6 +43,7 @@ if ROOT not in sys.path:
 
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md, v_mfma_f32_16x16x4_f32 (= fp32 vector peak)
 PEAK_HBM_GBS = 8000.0
+EMPTY_KERNEL_US = 1.3             # rocprofv3 duration of b3d_empty_kernel (profiles/r02_*_kernel_stats.csv)
 BOUND = {"mp_edge_fwd": "mfma", "mp_edge_bwd": "mfma", "wgrad_edge": "hbm", "mp_node_fwd": "hbm", "mp_node_bwd": "hbm",
          "att_fwd": "mfma", "att_bwd": "mfma", "point_feat": "mfma"}
 
@@ -221,6 +222,11 @@ class Workload:
                 + " + CSR/CSC build + fwd + cb-BCE + bwd + Adam" + (" + flat RCCL grad all-reduce of 5.24 MB" if world > 1 else "") + ")")
 
 
+def trace(msg):
+    if os.environ.get("B3D_BENCH_TRACE"):
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def measure(wl: Workload, args, world, dist, steps, warmup, ramp_ms, use_graph):
     """W instrumented warm-up steps, optional hipGraph capture, untimed clock ramp, K timed steps (barrier +
     synchronize on both sides), eager instrumented pass.  Returns a dict of raw measurements."""
@@ -230,10 +236,12 @@ def measure(wl: Workload, args, world, dist, steps, warmup, ramp_ms, use_graph):
     fam_names = list(_lib.KERNEL_FAMILIES)
     # Warm-up doubles as the instrumented pass: every kernel family is timed with HIP event pairs (diagnostic
     # table) and the family with the largest device time is picked; the TIMED region carries no events.
+    trace(f"{wl.kind}/{wl.encoders}: warm-up")
     _lib.prof_enable(True)
     for i in range(warmup):
         wl.step(i)
     torch.cuda.synchronize()
+    trace("warm-up done")
     fam_all = _lib.prof_read() if warmup > 0 else None
     _lib.prof_enable(False)
     graphs, graph_note = None, None
@@ -248,6 +256,7 @@ def measure(wl: Workload, args, world, dist, steps, warmup, ramp_ms, use_graph):
                 with torch.cuda.graph(g, stream=cap_stream, capture_error_mode="thread_local"):
                     wl.captured(i)
                 graphs.append(g)
+                trace(f"captured batch {i}")
             torch.cuda.current_stream().wait_stream(cap_stream)
             torch.cuda.synchronize()
         except Exception as exc:                                   # capture unsupported here: eager timed region
@@ -277,6 +286,7 @@ def measure(wl: Workload, args, world, dist, steps, warmup, ramp_ms, use_graph):
                 timed_step(i)
             torch.cuda.synchronize()
             ramp_steps += 4
+    trace(f"ramp done ({ramp_steps} steps)")
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -289,6 +299,7 @@ def measure(wl: Workload, args, world, dist, steps, warmup, ramp_ms, use_graph):
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    trace(f"timed region done: {1e3 * dt / steps:.3f} ms/step")
     # the same K steps again, eagerly, with event pairs: on the dominant family only (undisturbed), then on all
     dom = None
     if fam_all:
@@ -300,7 +311,8 @@ def measure(wl: Workload, args, world, dist, steps, warmup, ramp_ms, use_graph):
     torch.cuda.synchronize()
     fam = _lib.prof_read()
     _lib.prof_enable(False)
-    pair_us = _lib.prof_pair_overhead_us(torch.cuda.current_stream(dev).cuda_stream)
+    # what an event pair adds to the kernel it brackets: a pair around an empty kernel minus that kernel's own duration
+    pair_us = max(_lib.prof_pair_overhead_us(torch.cuda.current_stream(dev).cuda_stream) - EMPTY_KERNEL_US, 0.0)
     my_edges = sum(wl.edges[(warmup + i) % pool_n] for i in range(steps))
     return {"dt": dt, "edges": my_edges, "t_enqueue": t_enqueue, "fam_all": fam_all, "fam": fam, "dom": dom,
             "graphs": graphs is not None, "graph_note": graph_note, "ramp_steps": ramp_steps, "pair_us": pair_us}
@@ -360,6 +372,11 @@ def main():
     import torch.distributed as dist
     dev = torch.device("cuda", 0 if args.all_ranks_on_device_0 else local_rank)
     torch.cuda.set_device(dev)
+    # Nothing of this process runs on the legacy NULL stream: eager work enqueued there between the replays of a
+    # captured step (the modality-row compaction) ended in a GPU memory fault at the next replay on this stack
+    # (tools/debug_clr_capture.py: cases nm_rows_nocopy vs nm_curstream), and a non-blocking stream is what a
+    # training loop with a prefetching loader runs on anyway.
+    torch.cuda.set_stream(torch.cuda.Stream(dev))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":

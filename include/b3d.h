@@ -337,7 +337,7 @@ int b3d_prof_select(uint32_t family_mask);   /* bit f set: family f is timed whi
                                                pairs cost device time; time one family to measure it undisturbed */
 int b3d_prof_reset(void);
 int b3d_prof_read(int family, double* total_ms /* host */, int* launches /* host */);
-/* Average elapsed time of an EMPTY event pair on `stream` (what a pair adds to the kernel it brackets), in us. */
+/* Average elapsed time of an event pair around an EMPTY kernel on `stream`, in us (pair cost = this - that kernel). */
 int b3d_prof_pair_overhead_us(b3d_stream stream, int reps, double* out_us /* host */);
 
 /* ---- which execution plans this build runs (for callers that account executed FLOPs, e.g. bench.py) ----------

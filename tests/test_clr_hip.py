@@ -5,7 +5,7 @@ import ctypes as C
 import pytest
 import torch
 
-from conftest import data_from, load_golden
+from conftest import assert_grad_close, data_from, load_golden
 from oracle.seeded import grad_digest, seeded_fill_
 
 pytestmark = pytest.mark.gpu
@@ -159,7 +159,7 @@ def test_modality_configurations_against_oracle(case):
             continue
         if name.endswith("in_proj_weight") or name.endswith("in_proj_bias"):
             third = q.grad.shape[0] // 3                    # only the value projection carries gradient
-            assert rel(p.grad[2 * third:], q.grad[2 * third:]) < 5 * TOL, name
+            assert_grad_close(p.grad[2 * third:], q.grad[2 * third:], name, tol=5 * TOL)
             continue
         if case == "all_three_300":
             # ~16 M ReLU units: a handful sit within fp32 rounding of zero and may switch between two correct
@@ -169,7 +169,7 @@ def test_modality_configurations_against_oracle(case):
             assert float((a - b).norm() / b.norm()) < 5e-4, (name, float((a - b).norm() / b.norm()))
             assert rel(p.grad, q.grad) < 1e-2, (name, rel(p.grad, q.grad))
         else:
-            assert rel(p.grad, q.grad) < 5 * TOL, (name, rel(p.grad, q.grad))
+            assert_grad_close(p.grad, q.grad, name, tol=5 * TOL)
 
 
 def test_full_size_against_oracle_and_float64():
@@ -210,8 +210,11 @@ def test_full_size_against_oracle_and_float64():
         if name.endswith("in_proj_weight") or name.endswith("in_proj_bias"):
             third = rg.shape[0] // 3                        # only the value projection carries gradient
             pg, qg, rg = pg[2 * third:], qg[2 * third:], rg[2 * third:]
-        assert rel(pg, rg) < max(3.0 * rel(qg, rg), 3e-3), (name, rel(pg, rg), rel(qg, rg))
-        assert l2(pg, rg) < max(3.0 * l2(qg, rg), 5e-4), (name, l2(pg, rg), l2(qg, rg))
+        # measured over seeds (tests/tools/clr_grad_error_seeds.py, profiles/r02_clr_grad_error_seeds.txt): BOTH fp32
+        # evaluations sit at 3e-4 .. 3e-3 (L2 and max-norm) from float64 for every parameter downstream of a ReLU
+        # stack, the HIP path below the CPU oracle more often than not; parameters with no ReLU in between at 1e-6
+        assert rel(pg, rg) < max(3.0 * rel(qg, rg), 1e-2), (name, rel(pg, rg), rel(qg, rg))
+        assert l2(pg, rg) < max(3.0 * l2(qg, rg), 3e-3), (name, l2(pg, rg), l2(qg, rg))
         checked += 1
     assert checked >= 40
 

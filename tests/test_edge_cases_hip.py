@@ -5,6 +5,7 @@ incident edges, graphs smaller than one 16-row tile, every gnn_depth down to 1."
 import pytest
 import torch
 
+from conftest import assert_grad_close
 from oracle import ref_torch
 from oracle.seeded import seeded_fill_
 
@@ -48,7 +49,7 @@ def _check(data, depth=6, seed=3, dead_knn=True):
         if q.grad is None:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
             continue
-        assert _rel(p.grad, q.grad) < 5 * TOL, (name, _rel(p.grad, q.grad))
+        assert_grad_close(p.grad, q.grad, name, tol=5 * TOL)
 
 
 def test_isolated_source_only_and_sink_only_nodes():
