@@ -57,8 +57,16 @@ static const LinDim kDims[LIN_COUNT] = {
 static const int kRowKind[LIN_COUNT] = {0, 0, 0, 1, 1, 0, 0, 0, 0, 2, 2, 3, 3, 3, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0,
                                         0, 0, 0, 0, 0, 0, 0, 1, 1, 1};
 constexpr int kStreamRowsPerTask = 512;       // message-passing stacks (x up to 6 layer variants)
+constexpr int kStreamNodeRowsPerTask = 64;    // hoisted first layers: node columns contract over N rows x depth layers
 constexpr int kStreamRowsPerTaskAtt = 1024;   // att_edge_encoder (one variant)
 
+// column blocks of the hoisted first-layer gradients: (linear, first column, width, rows contracted over edges?)
+enum { VL_EU0XI, VL_EU0XJ, VL_EU0E, VL_FU0X, VL_FU0E, VL_FU0X0, VL_PA0X, VL_PA0E, VL_PA0X0, VL_COUNT };
+struct VlDesc { int lin, col0, width; bool on_edges, bias; };
+static const VlDesc kVl[VL_COUNT] = {
+    {EU0, 0, 96, false, false}, {EU0, 96, 96, false, false}, {EU0, 192, 128, true, true},
+    {FU0, 0, 96, false, false}, {FU0, 96, 64, true, true}, {FU0, 160, 96, false, false},
+    {PA0, 0, 96, false, false}, {PA0, 96, 64, true, true}, {PA0, 160, 96, false, false}};
 struct Ws {
   // forward images
   float *wp_ee, *wp_ne, *wp_cls, *wp_fl, *wp_fr, *wp_aff[3], *wp_at[5], *wp_efwd, *wp_nfwd;
@@ -86,6 +94,7 @@ struct Ws {
   WsJob* ws_table;
   int* ws_task_job;
   LinSlab lin[LIN_COUNT];
+  LinSlab vlin[9];          // hoisted first layers: column blocks of edge_update.0 / create_*_msgs.0 with slabs of their own
   KnnWs knn;
   size_t bytes;
   bool ok;
@@ -152,6 +161,14 @@ static void carve(Ws& w, void* ws, size_t ws_bytes, int N, int E, int nl, int nr
     w.wp_atT[2] = c.take<float>(SeqAT2T::TOTAL_FLOATS);
     w.wp_atT[3] = c.take<float>(SeqAT3T::TOTAL_FLOATS);
     w.wp_atT[4] = c.take<float>(SeqAT4T::TOTAL_FLOATS);
+    if (w.hoist) {
+      w.wp_ebwd_h = c.take<float>(HC::EdgeBwdSeq::TOTAL_FLOATS);
+      w.wp_ebwd_nm_h = c.take<float>(HC::EdgeBwdSeqNoMsg::TOTAL_FLOATS);
+      w.wp_nbwd_h = c.take<float>(NodeBwdHSeq<DB>::TOTAL_FLOATS);
+      w.wp_gproj = c.take<float>(HC::GradProjSeq::TOTAL_FLOATS);
+      w.dT = c.take<float>((size_t)depth * n_ * HC::GW);
+      w.gx = c.take<float>(n_ * 2 * D::DX);
+    }
     w.wp_ebwd = c.take<float>(D::EdgeBwdSeq::TOTAL_FLOATS);
     w.wp_ebwd_nm = c.take<float>(D::EdgeBwdSeqNoMsg::TOTAL_FLOATS);
     w.wp_nbwd = c.take<float>(D::NodeBwdSeq::TOTAL_FLOATS);
@@ -213,6 +230,16 @@ static void carve(Ws& w, void* ws, size_t ws_bytes, int N, int E, int nl, int nr
         ls.nchunks = wg_nchunks(rows, ls.NP, ls.KP, 0);
       }
       ls.slab = c.take<float>(wg_slab_floats(ls.nchunks, ls.NP, ls.KP));
+      ls.used = false;
+    }
+    for (int v = 0; v < VL_COUNT; ++v) {
+      LinSlab& ls = w.vlin[v];
+      ls.N = kDims[kVl[v].lin].N; ls.K = kVl[v].width; ls.NP = pad16(ls.N); ls.KP = pad16(ls.K);
+      const long rows = kVl[v].on_edges ? E : N;
+      const int rpt = kVl[v].on_edges ? kStreamRowsPerTask : kStreamNodeRowsPerTask;
+      ls.nchunks = (int)((rows + rpt - 1) / rpt);
+      if (ls.nchunks < 1) ls.nchunks = 1;
+      ls.slab = w.hoist ? c.take<float>(wg_slab_floats(ls.nchunks, ls.NP, ls.KP)) : nullptr;
       ls.used = false;
     }
   }
@@ -343,6 +370,36 @@ static int pack_all(const b3d_clr_weights* pw, Ws& w, bool training, bool knn, h
     T(EN{}, 0, w.wp_ebwd_nm, EU2); T(EN{}, 1, w.wp_ebwd_nm, EU1); T(EN{}, 2, w.wp_ebwd_nm, EU0);
     using NB = D::NodeBwdSeq;
     T(NB{}, 0, w.wp_nbwd, CF2); T(NB{}, 1, w.wp_nbwd, CF1); T(NB{}, 2, w.wp_nbwd, CF0);
+    if (w.hoist) {
+      constexpr int DX = DB::DX, DE = DB::DE, EIN = DB::EIN, MIN = DB::MIN, H1 = DB::EH1, MH = DB::MH, KE = HC::KE;
+      const LinPtrs &eu0 = L[EU0], &fu0 = L[FU0], &pa0 = L[PA0];
+      // data-gradient images: full transposes, except the .0 layers, which keep their per-edge columns
+      auto TS = [&](auto tag, int li, float* base, const float* wcol, int ld, int rows_in, int cols_out) {
+        using S = decltype(tag);
+        d[n++] = pack_slice<S>(li, base, wcol, nullptr, rows_in, cols_out, ld, 0, S::np(li), true);
+      };
+      using EB2 = HC::EdgeBwdSeq;
+      T(EB2{}, 0, w.wp_ebwd_h, PA1); TS(EB2{}, 1, w.wp_ebwd_h, pa0.w + DX, MIN, DE, MH);
+      T(EB2{}, 2, w.wp_ebwd_h, FU1); TS(EB2{}, 3, w.wp_ebwd_h, fu0.w + DX, MIN, DE, MH);
+      T(EB2{}, 4, w.wp_ebwd_h, EU2); T(EB2{}, 5, w.wp_ebwd_h, EU1); TS(EB2{}, 6, w.wp_ebwd_h, eu0.w + 2 * DX, EIN, KE, H1);
+      using EN2 = HC::EdgeBwdSeqNoMsg;
+      T(EN2{}, 0, w.wp_ebwd_nm_h, EU2); T(EN2{}, 1, w.wp_ebwd_nm_h, EU1); TS(EN2{}, 2, w.wp_ebwd_nm_h, eu0.w + 2 * DX, EIN, KE, H1);
+      // (dx | dx0) = sum over the four lists of (node columns)^T . dT_list: rows 0:DX from the x columns, rows DX:2DX
+      // (future / past only) from the x0 columns
+      using NH = NodeBwdHSeq<DB>;
+      auto gp = [&](auto tag, float* base) {
+        using S = decltype(tag);
+        d[n++] = pack_slice<S>(0, base, eu0.w, nullptr, DX, H1, EIN, 0, DX, true);
+        d[n++] = pack_slice<S>(1, base, eu0.w + DX, nullptr, DX, H1, EIN, 0, DX, true);
+        d[n++] = pack_slice<S>(2, base, fu0.w, nullptr, DX, MH, MIN, 0, DX, true);
+        d[n++] = pack_slice<S>(2, base, fu0.w + DX + DE, nullptr, DX, MH, MIN, DX, DX, true);
+        d[n++] = pack_slice<S>(3, base, pa0.w, nullptr, DX, MH, MIN, 0, DX, true);
+        d[n++] = pack_slice<S>(3, base, pa0.w + DX + DE, nullptr, DX, MH, MIN, DX, DX, true);
+      };
+      gp(NH{}, w.wp_nbwd_h);
+      gp(HC::GradProjSeq{}, w.wp_gproj);
+      T(NH{}, 4, w.wp_nbwd_h, CF2); T(NH{}, 5, w.wp_nbwd_h, CF1); T(NH{}, 6, w.wp_nbwd_h, CF0);
+    }
   }
   if (n > 160) return fail(B3D_ERR_ARG, "pack descriptor table overflow");
   return pack_images(d, n, stream);
@@ -395,6 +452,7 @@ extern "C" uint32_t b3d_features(void) {
   uint32_t f = 0;
   const char* e = getenv("B3D_HOIST");
   if (!e || atoi(e) != 0) f |= B3D_FEATURE_POSE_HOIST;
+  if (b3d::clr::hoist_enabled()) f |= B3D_FEATURE_CLR_HOIST_MP;
   return f;
 }
 
@@ -594,9 +652,39 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
 
   // ---- message-passing layers, last to first (data gradients; G tensors kept per layer) -------------
   bool dx0_first = true, da_first = true;
+  // hoisted first layers: per-node gradient of T from layer `lay`'s first-layer gradients (kept per layer: weight gradient)
+  auto listsum = [&](int lay) -> int {
+    NodeGradProjArgs ga;
+    memset(&ga, 0, sizeof(ga));
+    ga.N = N; ga.dst_ptr = g->dst_ptr; ga.dst_perm = g->dst_perm; ga.src_ptr = g->src_ptr; ga.src_perm = g->src_perm;
+    ga.GdH1 = w.GdH1 + lay * eL1;
+    ga.GdF1 = (lay < depth - 1) ? w.GdF1 + lay * eLm : nullptr;
+    ga.GdP1 = (lay < depth - 1) ? w.GdP1 + lay * eLm : nullptr;
+    ga.dT = w.dT + (size_t)lay * N * HC::GW;
+    const long tasks = (long)((N + 15) / 16) * ListSumGeom<DB>::TASKS;
+    ProfScope ps(B3D_K_NODE_BWD, stream);
+    hipLaunchKernelGGL(node_listsum_kernel<DB>, dim3((unsigned)((tasks + 3) / 4)), dim3(256), 0, stream, ga);
+    return launch_check("node_listsum_kernel");
+  };
   for (int l = depth - 1; l >= 0; --l) {
     const bool msgs = (l < depth - 1);
-    if (msgs) {
+    if (msgs && w.hoist) {
+      B3D_TRY(listsum(l + 1));
+      NodeBwdGArgs nb;
+      memset(&nb, 0, sizeof(nb));
+      nb.N = N; nb.dT = w.dT + (size_t)(l + 1) * N * HC::GW;
+      nb.dx0_acc = w.dx0_acc; nb.dx0_first = dx0_first ? 1 : 0;
+      nb.sH1 = w.nH1[l]; nb.sH2 = w.nH2[l];
+      nb.dM = w.dM + l * nLm; nb.Gdx = w.Gdx + l * nLx; nb.GdH2 = w.GnH2 + l * nL2; nb.GdH1 = w.GnH1 + l * nL1;
+      nb.wpack = w.wp_nbwd_h;
+      B3D_TRY(set_lds(node_bwd_g_kernel<DB, true>, NodeBwdGLds<DB>::BYTES));
+      {
+        ProfScope ps(B3D_K_NODE_BWD, stream);
+        hipLaunchKernelGGL((node_bwd_g_kernel<DB, true>), dim3((N + 15) / 16), dim3(kNodeBwdGWaves * 64), NodeBwdGLds<DB>::BYTES, stream, nb);
+      }
+      B3D_TRY(launch_check("node_bwd_g_kernel"));
+      dx0_first = false;
+    } else if (msgs) {
       NodeBwdArgs nb;
       memset(&nb, 0, sizeof(nb));
       nb.N = N; nb.dst_ptr = g->dst_ptr; nb.dst_perm = g->dst_perm; nb.src_ptr = g->src_ptr; nb.src_perm = g->src_perm;
@@ -606,6 +694,27 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
       nb.wpack = w.wp_nbwd;
       B3D_TRY(launch_node_split<D>(mp_node_bwd_split_kernel<D>, "mp_node_bwd", nb, N, stream, B3D_K_NODE_BWD));
       dx0_first = false;
+    }
+    if (w.hoist) {
+      EdgeBwdHArgs eb;
+      memset(&eb, 0, sizeof(eb));
+      eb.E = E; eb.src = src; eb.dst = dst;
+      eb.dM = msgs ? w.dM + l * nLm : nullptr;
+      eb.de_out = w.de[cur]; eb.de_in = w.de[cur ^ 1];
+      eb.sH1 = w.sH1[l]; eb.sH2 = w.sH2[l]; eb.sF1 = w.sF1[l]; eb.sP1 = w.sP1[l];
+      eb.da_acc = w.da_acc; eb.da_first = da_first ? 1 : 0;
+      eb.GdH1 = w.GdH1 + l * eL1; eb.GdH2 = w.GdH2 + l * eL2; eb.Gde = w.Gde + l * eLe;
+      eb.GdF1 = w.GdF1 + l * eLm; eb.GdP1 = w.GdP1 + l * eLm;
+      if (msgs) {
+        eb.wpack = w.wp_ebwd_h;
+        B3D_TRY(launch_rows<kNWEdge>(mp_edge_bwd_h_kernel<DB, true, kNWEdge>, "mp_edge_bwd", eb, E, stream, B3D_K_EDGE_BWD, stream_lds_bytes<HC::EdgeBwdSeq>()));
+      } else {
+        eb.wpack = w.wp_ebwd_nm_h;
+        B3D_TRY(launch_rows<kNWEdge>(mp_edge_bwd_h_kernel<DB, false, kNWEdge>, "mp_edge_bwd_last", eb, E, stream, B3D_K_OTHER, stream_lds_bytes<HC::EdgeBwdSeqNoMsg>()));
+      }
+      da_first = false;
+      cur ^= 1;
+      continue;
     }
     EdgeBwdArgs eb;
     memset(&eb, 0, sizeof(eb));
@@ -626,6 +735,18 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
     }
     da_first = false;
     cur ^= 1;
+  }
+  if (w.hoist) {   // layer 0's (dx | dx0) for the node encoder
+    B3D_TRY(listsum(0));
+    NodeBwdGArgs nb;
+    memset(&nb, 0, sizeof(nb));
+    nb.N = N; nb.dT = w.dT; nb.gx = w.gx; nb.wpack = w.wp_gproj;
+    B3D_TRY(set_lds(node_bwd_g_kernel<DB, false>, NodeBwdGLds<DB>::BYTES));
+    {
+      ProfScope ps(B3D_K_NODE_BWD, stream);
+      hipLaunchKernelGGL((node_bwd_g_kernel<DB, false>), dim3((N + 15) / 16), dim3(kNodeBwdGWaves * 64), NodeBwdGLds<DB>::BYTES, stream, nb);
+    }
+    B3D_TRY(launch_check("node_bwd_g_kernel"));
   }
 
   // ---- att_edge_encoder backward: d att (summed over the layers) -> d(s[dst] | s[src] | e) ------------
@@ -673,7 +794,17 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
   }
 
   // ---- encoders ----------------------------------------------------------------------------------------
-  {  // node encoder (x = initial_x): running d initial_x + layer-0 scatter transposes
+  if (w.hoist) {  // node encoder (x = initial_x): running d initial_x + layer 0's (dx | dx0)
+    using In = LoadNodeEncGradH<6>;
+    ChainBwdArgs<In, StoreNone> a;
+    memset(&a, 0, sizeof(a));
+    a.rows = N;
+    a.in = In{nullptr, dx0_first ? nullptr : w.dx0_acc, w.gx};
+    a.gtop = w.gn_top; a.act[0] = w.ne_a1; a.gsave[0] = w.gn1; a.wpack = w.wp_neT;
+    B3D_TRY(launch_rows<kNWNode>(chain_bwd_kernel<SeqNET, In, StoreNone, kNWNode>, "node_encoder_bwd", a, N, stream, B3D_K_OTHER, chain_lds<SeqNET>()));
+    WgJob n1 = make_job(w.lin[NE1], N, seg(w.gn_top, nullptr, 96, 0, 96)); add_act(n1, seg(w.ne_a1, nullptr, 48, 0, 48)); smallN.jobs[smallN.njobs++] = n1;
+    WgJob n0 = make_job(w.lin[NE0], N, seg(w.gn1, nullptr, 48, 0, 48)); add_act(n0, seg(w.pose_pad, nullptr, 32, 0, 19)); smallN.jobs[smallN.njobs++] = n0;
+  } else {  // node encoder (x = initial_x): running d initial_x + layer-0 scatter transposes
     using In = LoadNodeEncGrad<6>;
     ChainBwdArgs<In, StoreNone> a;
     memset(&a, 0, sizeof(a));
@@ -709,16 +840,15 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
     const int* iota = w.iota;
     struct Col { const float* p; const int* idx; long vstride; int stride; int col0; int width; };   // activation columns
     // Every (64-row group of G) x (<= 96-column group of an activation segment) pair is one job.
-    auto add_matrix = [&](int lin, long rows, int nvar, int rpt, const float* gp, const int* gidx, long gvs, int gstride, int gcol0,
-                          const Col* cols, int ncols) {
+    auto add_block = [&](LinSlab& ls, long rows, int nvar, int rpt, const float* gp, const int* gidx, long gvs, int gstride, int gcol0,
+                         const Col* cols, int ncols, bool with_bias) {
       if (nvar <= 0) return;
-      LinSlab& ls = w.lin[lin];
       ls.used = true;
       bool first_job_of_group = true;
       for (int g0 = 0; g0 < ls.N; g0 += 64) {
         const int gw = (ls.N - g0 >= 64) ? 64 : ls.N - g0;       // 64, or the 32-row tail of a 96-row matrix
         int wcol = 0;
-        first_job_of_group = true;
+        first_job_of_group = with_bias;
         for (int ci = 0; ci < ncols; ++ci) {
           for (int c0 = 0; c0 < cols[ci].width;) {
             int cw = cols[ci].width - c0;           // column groups of 96 or 64: 128 -> 64+64, 256 -> 96+96+64
@@ -742,7 +872,42 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
         }
       }
     };
+    auto add_matrix = [&](int lin, long rows, int nvar, int rpt, const float* gp, const int* gidx, long gvs, int gstride, int gcol0,
+                          const Col* cols, int ncols) {
+      add_block(w.lin[lin], rows, nvar, rpt, gp, gidx, gvs, gstride, gcol0, cols, ncols, true);
+    };
     const int rp = kStreamRowsPerTask, rpa = kStreamRowsPerTaskAtt;
+    if (w.hoist) {
+      // First layers: per-edge columns contract over edges, node columns over NODES (G = column blocks of dT).
+      const int rn = kStreamNodeRowsPerTask;
+      const long tLs = (long)N * HC::GW;
+      {  // edge_update.0 [256, 320]: x[dst] 0:96 | x[src] 96:192 | e 192:256 | att 256:320
+        Col ce[2] = {{w.e[0], nullptr, (long)eLe, D::DE, 0, 64}, {w.att, nullptr, 0, 64, 0, 64}};
+        add_block(w.vlin[VL_EU0E], E, depth, rp, w.GdH1, nullptr, eL1, D::EH1, 0, ce, 2, true);
+        Col cx[1] = {{w.x[0], nullptr, (long)nLx, D::DX, 0, 96}};
+        add_block(w.vlin[VL_EU0XI], N, depth, rn, w.dT, nullptr, tLs, HC::GW, HC::OA, cx, 1, false);
+        add_block(w.vlin[VL_EU0XJ], N, depth, rn, w.dT, nullptr, tLs, HC::GW, HC::OB, cx, 1, false);
+        Col c1[1] = {{w.sH1[0], nullptr, (long)eL1, D::EH1, 0, 256}};
+        add_matrix(EU1, E, depth, rp, w.GdH2, nullptr, eL2, D::EH2, 0, c1, 1);
+        Col c2[1] = {{w.sH2[0], nullptr, (long)eL2, D::EH2, 0, 128}};
+        add_matrix(EU2, E, depth, rp, w.Gde, nullptr, eLe, D::DE, 0, c2, 1);
+      }
+      {  // message stacks .0 [192, 256] (layers 0 .. depth-2): x[.] 0:96 | e' 96:160 | x0[.] 160:256
+        Col ce[1] = {{w.e[1], nullptr, (long)eLe, D::DE, 0, 64}};
+        Col cx[1] = {{w.x[0], nullptr, (long)nLx, D::DX, 0, 96}};
+        Col c0[1] = {{w.x[0], nullptr, 0, D::DX, 0, 96}};
+        add_block(w.vlin[VL_PA0E], E, depth - 1, rp, w.GdP1, nullptr, eLm, D::MH, 0, ce, 1, true);
+        add_block(w.vlin[VL_PA0X], N, depth - 1, rn, w.dT, nullptr, tLs, HC::GW, HC::OP, cx, 1, false);
+        add_block(w.vlin[VL_PA0X0], N, depth - 1, rn, w.dT, nullptr, tLs, HC::GW, HC::OP, c0, 1, false);
+        add_block(w.vlin[VL_FU0E], E, depth - 1, rp, w.GdF1, nullptr, eLm, D::MH, 0, ce, 1, true);
+        add_block(w.vlin[VL_FU0X], N, depth - 1, rn, w.dT, nullptr, tLs, HC::GW, HC::OF, cx, 1, false);
+        add_block(w.vlin[VL_FU0X0], N, depth - 1, rn, w.dT, nullptr, tLs, HC::GW, HC::OF, c0, 1, false);
+        Col cp1[1] = {{w.sP1[0], nullptr, (long)eLm, D::MH, 0, 192}};
+        add_matrix(PA1, E, depth - 1, rp, w.dM, dst, nLm, D::NIN, 0, cp1, 1);
+        Col cf1[1] = {{w.sF1[0], nullptr, (long)eLm, D::MH, 0, 192}};
+        add_matrix(FU1, E, depth - 1, rp, w.dM, src, nLm, D::NIN, D::DM, cf1, 1);
+      }
+    } else {
     {  // edge_update: x[l][dst] 96 | x[l][src] 96 | e[l] 64 | att 64
       Col c[4] = {{w.x[0], dst, (long)nLx, D::DX, 0, 96}, {w.x[0], src, (long)nLx, D::DX, 0, 96},
                   {w.e[0], nullptr, (long)eLe, D::DE, 0, 64}, {w.att, nullptr, 0, 64, 0, 64}};
@@ -761,6 +926,7 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
       add_matrix(FU0, E, depth - 1, rp, w.GdF1, nullptr, eLm, D::MH, 0, cf, 3);
       Col cf1[1] = {{w.sF1[0], nullptr, (long)eLm, D::MH, 0, 192}};
       add_matrix(FU1, E, depth - 1, rp, w.dM, src, nLm, D::NIN, D::DM, cf1, 1);
+    }
     }
     {  // node update (layers 0 .. depth-2)
       Col c0[1] = {{w.M[0], nullptr, (long)nLm, D::NIN, 0, 256}};
@@ -811,6 +977,20 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
     ra.nentries = 0;
     for (int i = 0; i < LIN_COUNT; ++i) {
       LinSlab& ls = w.lin[i];
+      if (w.hoist && (i == EU0 || i == FU0 || i == PA0)) {
+        bool any = false;
+        for (int v = 0; v < VL_COUNT; ++v) any = any || (kVl[v].lin == i && w.vlin[v].used);
+        if (any) {          // depth == 1: the message stacks receive no gradient (falls through to the zero fill)
+          for (int v = 0; v < VL_COUNT; ++v) {
+            if (kVl[v].lin != i) continue;
+            RedEntry e = red_entry(w.vlin[v], dw[i] ? dw[i] + kVl[v].col0 : nullptr, kVl[v].bias ? db[i] : nullptr);
+            e.ld = ls.K;
+            ra.e[ra.nentries++] = e;
+            if (ra.nentries == kRedMaxEntries) { B3D_TRY(launch_reduce(ra, stream)); ra.nentries = 0; }
+          }
+          continue;
+        }
+      }
       if (!ls.used) {
         if (dw[i]) B3D_HIP_CHECK(hipMemsetAsync(dw[i], 0, (size_t)ls.N * ls.K * sizeof(float), stream));
         if (db[i]) B3D_HIP_CHECK(hipMemsetAsync(db[i], 0, (size_t)ls.N * sizeof(float), stream));

@@ -560,6 +560,141 @@ __global__ __launch_bounds__(kGradProjWaves * 64, 1) void node_bwd_h_kernel(cons
   B3D_STAMP(1, 6);
 }
 
+// ---- the same per-node backward as TWO launches, for stacks whose lists have different widths ------------------
+// (camera+LiDAR+radar: dH1 is 256 wide, dF1 / dP1 192; the fused kernel above would need 216 KB of LDS there)
+//   node_listsum_kernel : dT[n] = ( sum_{dst=n} dH1 | sum_{src=n} dH1 | sum_{dst=n} dF1 | sum_{src=n} dP1 ), one
+//                         wavefront per (16-node tile, list, 64-column group); no LDS, no weights
+//   node_bwd_g_kernel   : (dx | dx0) = GradProj . dT[n]  (+ the node MLP's data gradient), dT rows read back from L2
+template <class D>
+struct ListSumGeom {
+  static constexpr int BPT = 4;                                  // blocks (64 columns) per task
+  static_assert(D::EH1 % 64 == 0 && D::MH % 64 == 0, "list widths in 64-column groups");
+  static constexpr int TA = D::EH1 / 64, TM = D::MH / 64;
+  static constexpr int TASKS = 2 * TA + 2 * TM;                  // per 16-node tile
+};
+template <class D>
+__global__ __launch_bounds__(256) void node_listsum_kernel(const NodeGradProjArgs a) {
+  using G = ListSumGeom<D>;
+  using H = Hoist<D>;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long task = (long)blockIdx.x * 4 + wave;
+  const long tile = task / G::TASKS;
+  int t = (int)(task - tile * G::TASKS);
+  if (tile * 16 >= a.N) return;
+  int list, grp;
+  if (t < G::TA) { list = 0; grp = t; }
+  else if (t < 2 * G::TA) { list = 1; grp = t - G::TA; }
+  else if (t < 2 * G::TA + G::TM) { list = 2; grp = t - 2 * G::TA; }
+  else { list = 3; grp = t - 2 * G::TA - G::TM; }
+  const float* base = (list < 2) ? a.GdH1 : (list == 2 ? a.GdF1 : a.GdP1);
+  const int width = (list < 2) ? D::EH1 : D::MH;
+  const int tcol = (list == 0 ? H::OA : list == 1 ? H::OB : list == 2 ? H::OF : H::OP) + 64 * grp;
+  const long row = tile * 16 + q_row(lane);
+  const bool valid = row < a.N;
+  v4f part[G::BPT];
+#pragma unroll
+  for (int b = 0; b < G::BPT; ++b) part[b] = v4f{0.f, 0.f, 0.f, 0.f};
+  if (valid && base) {
+    const bool by_dst = !(list & 1);
+    const int* ptr = by_dst ? a.dst_ptr : a.src_ptr;
+    segment_sum_deep_q<G::BPT, 6>(base, width, 64 * grp, by_dst ? a.dst_perm : a.src_perm, ptr[row], ptr[row + 1], part, q_piece(lane));
+  }
+  store_row_q<G::BPT>(a.dT, row, H::GW, tcol, valid, part);
+}
+
+struct NodeBwdGArgs {
+  int N;
+  const float* dT;      // [N, GW] of layer l+1 (node_listsum_kernel)
+  float* gx;            // MLP == false: [N, 2 DX] = (dx | dx0 contribution)
+  float* dx0_acc;       // MLP: [N, DX] running gradient of initial_x
+  int dx0_first;
+  const float* sH1;     // MLP: saved activations of layer l's node MLP
+  const float* sH2;
+  float* dM;            // MLP: [N, 2 DM]
+  float* Gdx;           // MLP: [N, DX]  G tensors of layer l's node MLP
+  float* GdH2;
+  float* GdH1;
+  const float* wpack;   // MLP: NodeBwdHSeq images; else Hoist::GradProjSeq images
+};
+template <class D>
+struct NodeBwdGLds {
+  static constexpr int PB = (D::NH1 > 2 * D::DX ? D::NH1 : 2 * D::DX) / 16;
+  static constexpr int BYTES = kLdsBytes + 2 * PB * 64 * 16;
+  static_assert(BYTES <= 160 * 1024, "LDS of one CU");
+};
+constexpr int kNodeBwdGWaves = 16;
+
+template <class D, bool MLP>
+__global__ __launch_bounds__(kNodeBwdGWaves * 64, 1) void node_bwd_g_kernel(const NodeBwdGArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  using H = Hoist<D>;
+  using Seq = typename std::conditional<MLP, NodeBwdHSeq<D>, typename H::GradProjSeq>::type;   // the same four images first
+  constexpr int NWS = kNodeBwdGWaves;
+  constexpr int LA = D::EH1 / 16, LM = D::MH / 16;
+  constexpr int XB = D::DX / 16, GB = 2 * XB, H1B = D::NH1 / 16, H2B = D::NH2 / 16;
+  static_assert(GB <= NWS && H1B <= NWS && H2B <= NWS, "at most one output block per wavefront and layer");
+  constexpr int PB = NodeBwdGLds<D>::PB;
+  WStreamT<NWS * 64> ws;      // one barrier per weight chunk: it is also what publishes the previous layer's LDS activations
+  ws.init(a.wpack, smem);
+  ws.template start<Seq>();
+  v4f* xb0 = reinterpret_cast<v4f*>(smem + 2 * kWBufFloats);
+  v4f* xb1 = xb0 + PB * 64;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 16 + (lane & 15);
+  const bool valid = row < a.N;
+  v4f act2 = {0.f, 0.f, 0.f, 0.f}, act1 = {0.f, 0.f, 0.f, 0.f}, prev0 = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (MLP) {
+    if (wave < H2B) load_row<1>(a.sH2, row, D::NH2, 16 * wave, valid, &act2);
+    if (wave < H1B) load_row<1>(a.sH1, row, D::NH1, 16 * wave, valid, &act1);
+    if (!a.dx0_first && wave >= XB && wave < GB) load_row<1>(a.dx0_acc, row, D::DX, 16 * (wave - XB), valid, &prev0);
+  }
+  // (dx | dx0) = sum over the four lists of (node columns)^T . dT_list; this wavefront owns output block `wave`
+  v4f own = {0.f, 0.f, 0.f, 0.f};
+  v4f dt[LA > LM ? LA : LM];
+  auto acc = [&](int, v4f v) { own += v; };
+  load_row<LA>(a.dT, row, H::GW, H::OA, valid, dt);
+  linear_split<Seq, 0, false, false, NWS>(ws, false, dt, [&]() {}, acc);
+  linear_split<Seq, 1, false, false, NWS>(ws, false, dt, [&]() { load_row<LA>(a.dT, row, H::GW, H::OB, valid, dt); }, acc);
+  linear_split<Seq, 2, false, false, NWS>(ws, false, dt, [&]() { load_row<LM>(a.dT, row, H::GW, H::OF, valid, dt); }, acc);
+  linear_split<Seq, 3, false, false, NWS>(ws, false, dt, [&]() { load_row<LM>(a.dT, row, H::GW, H::OP, valid, dt); }, acc);
+  if constexpr (!MLP) {
+    if (wave < GB) store_row<1>(a.gx, row, 2 * D::DX, 16 * wave, valid, &own);
+    return;
+  } else {
+    if (wave < XB) xb0[wave * 64 + lane] = own;                 // d x': input of the node MLP's data gradient
+    else if (wave < GB) own += prev0;
+    v4f g[XB], d2[H2B], d1[H1B];
+    auto mask = [](v4f v, v4f act) {
+      return v4f{act.x > 0.f ? v.x : 0.f, act.y > 0.f ? v.y : 0.f, act.z > 0.f ? v.z : 0.f, act.w > 0.f ? v.w : 0.f};
+    };
+    linear_split<Seq, 4, false, false, NWS>(
+        ws, false, g,
+        [&]() {
+          if (wave < XB) store_row<1>(a.Gdx, row, D::DX, 16 * wave, valid, &own);            // G of combine_future_past.4
+          else if (wave < GB) store_row<1>(a.dx0_acc, row, D::DX, 16 * (wave - XB), valid, &own);
+#pragma unroll
+          for (int b = 0; b < XB; ++b) g[b] = xb0[b * 64 + lane];
+        },
+        [&](int mb, v4f v) { act2 = mask(v, act2); xb1[mb * 64 + lane] = act2; });          // mb == wave: act2 now holds d H2
+    linear_split<Seq, 5, false, false, NWS>(
+        ws, false, d2,
+        [&]() {
+          if (wave < H2B) store_row<1>(a.GdH2, row, D::NH2, 16 * wave, valid, &act2);
+#pragma unroll
+          for (int b = 0; b < H2B; ++b) d2[b] = xb1[b * 64 + lane];
+        },
+        [&](int mb, v4f v) { act1 = mask(v, act1); xb0[mb * 64 + lane] = act1; });
+    linear_split<Seq, 6, false, false, NWS>(
+        ws, false, d1,
+        [&]() {
+          if (wave < H1B) store_row<1>(a.GdH1, row, D::NH1, 16 * wave, valid, &act1);
+#pragma unroll
+          for (int b = 0; b < H1B; ++b) d1[b] = xb0[b * 64 + lane];
+        },
+        [&](int mb, v4f v) { store_row<1>(a.dM, row, 2 * D::DM, 16 * mb, valid, &v); });
+  }
+}
+
 // Loader of the node-encoder backward: gradient at x_enc = upstream + running d initial_x + layer 0's (dx | dx0).
 template <int XB>
 struct LoadNodeEncGradH {
