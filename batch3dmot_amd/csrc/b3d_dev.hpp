@@ -55,7 +55,7 @@ __host__ __device__ constexpr int pad16(int a) { return round_up(a, 16); }
 #ifndef B3D_BF16X6
 #define B3D_BF16X6 1
 #endif
-__host__ __device__ constexpr bool bf_auto(int KP) { return B3D_BF16X6 != 0 && KP % 32 == 0 && KP <= 256; }
+__host__ __device__ constexpr bool bf_auto(int KP) { return B3D_BF16X6 != 0 && KP % 32 == 0 && KP >= 64 && KP <= 256; }   // narrower layers are not MFMA bound
 __host__ __device__ constexpr int row_stride(int KP, bool bf) { return bf ? 3 * KP / 2 + 8 : KP + 8; }
 __host__ __device__ constexpr int bias_col(int KP, bool bf) { return bf ? 3 * KP / 2 : KP; }
 // position (0..31) inside its 32-feature group at which feature f (0..31) of the group is stored / held:
