@@ -169,3 +169,22 @@ def make_batch(num_graphs: int = 2, nodes_per_graph: int = 1500, edges_per_graph
                          graph_idx=first_graph_idx + i, modalities=modalities)
               for i in range(num_graphs)]
     return collate(graphs)
+
+
+def scene_windows(scene: Data, frames: int, per_frame: int, size: int = 5):
+    """Overlapping windows of `size` frames with stride 1 (predict.py:172): nodes are ordered by frame, a window is
+    a contiguous node range; edges with both ends inside, re-indexed; rel_frame (pose_feats[:, 18]) restarts at 0."""
+    out = []
+    for b in range(frames - size + 1):
+        lo, hi = b * per_frame, (b + size) * per_frame
+        keep = (scene.edge_index[0] >= lo) & (scene.edge_index[1] >= lo) & (scene.edge_index[0] < hi) & (scene.edge_index[1] < hi)
+        pose = scene.pose_feats[lo:hi].clone()
+        pose[:, 18] -= b
+        w = Data(pose_feats=pose, edge_index=(scene.edge_index[:, keep] - lo).contiguous(), edge_attr=scene.edge_attr[keep].clone(),
+                 node_timestamps=scene.node_timestamps[lo:hi].clone())
+        for k in ("img_feats", "lidar_feats", "radar_feats"):
+            if getattr(scene, k, None) is not None:
+                setattr(w, k, getattr(scene, k)[lo:hi].clone())
+        w.global_ids = torch.arange(lo, hi)
+        out.append(w)
+    return out
