@@ -222,6 +222,45 @@ class Workload:
                 + " + CSR/CSC build + fwd + cb-BCE + bwd + Adam" + (" + flat RCCL grad all-reduce of 5.24 MB" if world > 1 else "") + ")")
 
 
+class StubWorkload:
+    """--stub-cpu (testing aid, tests/test_bench_control_flow.py): a tiny torch model on the CPU in place of the HIP
+    workload, so that the N > 1 control flow of this file -- process group, sharded pool, gradient all-reduce inside
+    the step, barrier / ramp / timed loop, MAX / SUM reductions, one JSON line from rank 0 -- runs under gloo without
+    a GPU.  Its numbers mean nothing."""
+    kind, encoders, rows_static, logits = "stub", "na", None, True
+
+    def __init__(self, dev, rank, world):
+        from batch3dmot_amd.dist import FlatGradSync
+        self.dev = dev
+        torch.manual_seed(5621)
+        self.model = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 1))
+        self.model.depth, self.model.run_dead_knn = 1, False
+        self.opt = torch.optim.SGD(self.model.parameters(), lr=1e-3)
+        self.sync = FlatGradSync(self.model.parameters()) if world > 1 else None
+        g = torch.Generator().manual_seed(rank)
+        self.pool = [torch.randn(100 + 10 * i, 8, generator=g) for i in range(4)]
+        self.edges = [b.size(0) for b in self.pool]
+        self.n_nodes = 10
+
+    def step(self, i):
+        b = self.pool[i % len(self.pool)]
+        self.opt.zero_grad()
+        self.model(b).sum().backward()
+        if self.sync is not None:
+            self.sync.sync()
+        self.opt.step()
+
+    pre = captured = step
+
+    def describe(self, world):
+        return "stub (CPU control-flow test)"
+
+
+def dev_sync(dev):
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+
+
 def trace(msg):
     if os.environ.get("B3D_BENCH_TRACE"):
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
@@ -230,9 +269,26 @@ def trace(msg):
 def measure(wl: Workload, args, world, dist, steps, warmup, ramp_ms, use_graph):
     """W instrumented warm-up steps, optional hipGraph capture, untimed clock ramp, K timed steps (barrier +
     synchronize on both sides), eager instrumented pass.  Returns a dict of raw measurements."""
-    from batch3dmot_amd import _lib
     dev = wl.dev
     pool_n = len(wl.pool)
+    stub = wl.kind == "stub"
+    if stub:
+        for i in range(warmup):
+            wl.step(i)
+        ramp_steps = 8 if (ramp_ms > 0 and world > 1) else 0
+        for i in range(ramp_steps):
+            wl.step(i)
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            wl.step(warmup + i)
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        return {"dt": dt, "edges": sum(wl.edges[(warmup + i) % pool_n] for i in range(steps)), "t_enqueue": dt, "fam_all": None,
+                "fam": {}, "dom": None, "graphs": False, "graph_note": "stub", "ramp_steps": ramp_steps, "pair_us": 0.0}
+    from batch3dmot_amd import _lib
     fam_names = list(_lib.KERNEL_FAMILIES)
     # Warm-up doubles as the instrumented pass: every kernel family is timed with HIP event pairs (diagnostic
     # table) and the family with the largest device time is picked; the TIMED region carries no events.
@@ -362,6 +418,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to exercise the N > 1 path on one GPU)")
     ap.add_argument("--all-ranks-on-device-0", action="store_true", help="testing aid for the N > 1 path on a 1-GPU box (with --backend gloo)")
+    ap.add_argument("--stub-cpu", action="store_true", help="testing aid: run this file's control flow with a stub workload on the CPU (gloo)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -370,6 +427,8 @@ def main():
     if world == 1 and args.gpus > 1:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     import torch.distributed as dist
+    if args.stub_cpu:
+        return main_stub(args, rank, world, dist)
     dev = torch.device("cuda", 0 if args.all_ranks_on_device_0 else local_rank)
     torch.cuda.set_device(dev)
     # Nothing of this process runs on the legacy NULL stream: eager work enqueued there between the replays of a
@@ -388,15 +447,7 @@ def main():
     wl = Workload(args.model, dev, rank, world, args, encoders=args.encoders)
     m = measure(wl, args, world, dist, args.steps, args.warmup, args.ramp_ms, use_graph=not args.no_graph)
 
-    tot = torch.tensor([m["dt"], float(m["edges"])], dtype=torch.float64, device=dev)
-    if world > 1:
-        tmax = tot[:1].clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        esum = tot[1:].clone()
-        dist.all_reduce(esum, op=dist.ReduceOp.SUM)
-        dt, total_edges = float(tmax), float(esum)
-    else:
-        dt, total_edges = m["dt"], float(m["edges"])
+    dt, total_edges = reduce_over_ranks(m, dev, world, dist)
 
     secondary = None
     if world == 1 and rank == 0 and not args.no_secondary and args.model == "clr" and args.encoders == "frozen":
@@ -474,6 +525,36 @@ def main():
                                  + "); kernel families timed with HIP events in an eager pass of the same K steps right after it")
                                 if m["graphs"] else ("eager" + (f" ({m['graph_note']})" if m["graph_note"] else ""))}
         print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def reduce_over_ranks(m, dev, world, dist):
+    """(max over ranks of the timed region, sum over ranks of the processed edges)."""
+    if world == 1:
+        return m["dt"], float(m["edges"])
+    tot = torch.tensor([m["dt"], float(m["edges"])], dtype=torch.float64, device=dev)
+    tmax = tot[:1].clone()
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    esum = tot[1:].clone()
+    dist.all_reduce(esum, op=dist.ReduceOp.SUM)
+    return float(tmax), float(esum)
+
+
+def main_stub(args, rank, world, dist):
+    dev = torch.device("cpu")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    wl = StubWorkload(dev, rank, world)
+    m = measure(wl, args, world, dist, args.steps, args.warmup, args.ramp_ms, use_graph=False)
+    dt, total_edges = reduce_over_ranks(m, dev, world, dist)
+    if rank == 0:
+        print(json.dumps({"metric": "edges/sec (fwd+bwd) on nuScenes-shaped detection graphs", "value": round(total_edges / dt, 1),
+                          "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": {"workload": wl.describe(world)},
+                          "edges_summed_over_ranks": total_edges, "untimed_clock_ramp_steps": m["ramp_steps"]}))
     if world > 1:
         dist.destroy_process_group()
 

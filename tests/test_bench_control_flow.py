@@ -1,0 +1,47 @@
+"""bench.py's N > 1 control flow (process group from the torchrun environment, sharded pool, gradient all-reduce inside
+the step, barrier / ramp / timed loop, MAX / SUM reductions over ranks, ONE JSON line from rank 0): on the CPU with a
+stub workload under gloo (world size 2), and -- on the GPU box -- the real camera+LiDAR+radar workload as two ranks
+sharing the one device."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra, nproc=2, timeout=600):
+    port = 29700 + (os.getpid() % 1500)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc)] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout                     # rank 0 only
+    return json.loads(lines[0])
+
+
+def test_two_rank_control_flow_on_cpu():
+    d = _run(["--stub-cpu", "--steps", "5", "--warmup", "2"])
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["scaling"] == "weak"
+    # steps 2..6 of the 4-batch pool (100, 110, 120, 130 rows): both ranks' rows are summed
+    assert d["edges_summed_over_ranks"] == 2 * (120 + 130 + 100 + 110 + 120)
+    assert d["untimed_clock_ramp_steps"] == 8 and d["value"] > 0
+
+
+def test_single_process_stub():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--stub-cpu", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert json.loads(r.stdout.strip().splitlines()[-1])["n_gpus"] == 1
+
+
+@pytest.mark.gpu
+def test_two_ranks_share_the_device_over_gloo():
+    """The real workload, eager steps with the flat all-reduce between backward and Adam, two ranks on device 0."""
+    d = _run(["--backend", "gloo", "--all-ranks-on-device-0", "--steps", "3", "--warmup", "1", "--ramp-ms", "0", "--no-cpu-baseline"],
+             timeout=900)
+    assert d["n_gpus"] == 2 and d["value"] > 0 and "all-reduce" in d["config"]["workload"]
+    assert d["timed_region"].startswith("eager")
