@@ -188,3 +188,35 @@ def scene_windows(scene: Data, frames: int, per_frame: int, size: int = 5):
         w.global_ids = torch.arange(lo, hi)
         out.append(w)
     return out
+
+
+def write_window_files(stem, seed, n_per_frame=12, global_offset=1000):
+    """One synthetic window in the reference's on-disk layout (construct_detection_graphs_parallel.py:623-650), plus one
+    isolated node, which no edge touches.  Returns the number of nodes."""
+    import json
+    from .graph_data import CLASS_DICT
+    INV_CLASS = {v: k for k, v in CLASS_DICT.items()}
+    g = make_graph(5 * n_per_frame, 40 * n_per_frame, graph_idx=seed, modalities=True)
+    n = g.pose_feats.size(0)
+    cls = g.node_classes.long().clone()
+    # append an isolated node: its class never reaches node_classes in the reference's loop
+    pose = torch.cat([g.pose_feats, g.pose_feats[:1]])
+    ts = torch.cat([g.node_timestamps, g.node_timestamps[:1]])
+    torch.save(pose, stem + "_pose_features.pth")
+    torch.save(torch.cat([g.img_feats, g.img_feats[:1]]), stem + "_img_features.pth")
+    torch.save(torch.cat([g.lidar_feats, g.lidar_feats[:1]]), stem + "_lidar_features.pth")
+    torch.save(torch.cat([g.radar_feats, g.radar_feats[:1]]), stem + "_radar_features.pth")
+    torch.save(ts, stem + "_node_timestamps.pth")
+    torch.save(g.edge_attr, stem + "_edge_features.pth")
+    torch.save(g.edge_index.t().contiguous(), stem + "_edges.pth")
+    torch.save(g.y.reshape(1, -1), stem + "_gt.pth")
+    torch.save(torch.arange((n + 1) * 7, dtype=torch.float32).reshape(n + 1, 7), stem + "_node_boxes.pth")
+    gen = torch.Generator().manual_seed(seed)
+    gids = (torch.randperm(5 * (n + 1), generator=gen)[: n + 1] + global_offset).tolist()
+    meta = {}
+    for i in range(n + 1):
+        c = int(cls[i]) if i < n and int(cls[i]) > 0 else 1
+        meta[str(i)] = {"category_name": INV_CLASS[c], "global_node_id": gids[i], "score": 0.5, "token": f"t{i}"}
+    with open(stem + "_node_metadata.json", "w") as fh:
+        json.dump(meta, fh)
+    return n + 1

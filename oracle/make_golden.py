@@ -452,6 +452,81 @@ def golden_scene(ref, path, kind="clr", frames=8, per_frame=8, k=5, graph_idx=40
     print(f"{path}: windows={len(wins)} edges={len(avg_all)} kept={len(kept)}")
 
 
+def golden_loader(path, n_per_frame=3):
+    """the reference's own ``GraphDataset`` class (utils/graph_data.py:22-257), taken from the
+    reference file by ``ast`` and executed with stand-ins for what its module imports but this container lacks
+    (torch_geometric.data.{Dataset, Data}, batch_3dmot.utils.dataset.get_class_config), reads window files written in
+    the reference's on-disk layout; what ``__getitem__`` returns -- training and inference mode -- is the fixture."""
+    import ast
+    import json
+    import tempfile
+    from batch3dmot_amd.graph_data import CLASS_DICT
+    src = open(os.path.join(REF, "batch_3dmot", "utils", "graph_data.py")).read()
+    cls_node = [n for n in ast.parse(src).body if isinstance(n, ast.ClassDef) and n.name == "GraphDataset"][0]
+
+    class _Dataset:                                   # torch_geometric.data.Dataset: constructor arguments are not used
+        def __init__(self, *a, **k):
+            pass
+
+    class _Data:                                      # torch_geometric.data.Data: an attribute bag
+        def __init__(self, **kw):
+            for k, v in kw.items():
+                setattr(self, k, v)
+
+    tg = types.SimpleNamespace(data=types.SimpleNamespace(Dataset=_Dataset, Data=_Data))
+    b3 = types.SimpleNamespace(utils=types.SimpleNamespace(dataset=types.SimpleNamespace(
+        get_class_config=lambda params, class_dict_name: dict(CLASS_DICT))))
+    ns = {"torch": torch, "json": json, "os": os, "torch_geometric": tg, "batch_3dmot": b3, "ParamLib": object}
+    exec(compile(ast.Module([cls_node], []), "graph_data.py", "exec"), ns)
+    RefDataset = ns["GraphDataset"]
+    params = types.SimpleNamespace(main=types.SimpleNamespace(slice_factor=1, class_dict="nuscenes_tracking_eval"),
+                                   gnn=types.SimpleNamespace(batch_size_graph=5))
+    scenes = [{"token": "sceneG", "nbr_samples": 7}]
+    out = {"scenes": scenes, "windows": [], "train": [], "inference": []}
+    with tempfile.TemporaryDirectory() as td:
+        d = td + "/"
+        for b in range(2):
+            stem = d + f"sceneG_len5_{b}"
+            synth.write_window_files(stem, seed=70 + b, n_per_frame=n_per_frame, global_offset=500)
+            files = {sfx: torch.load(stem + sfx) for sfx in ("_pose_features.pth", "_img_features.pth", "_lidar_features.pth",
+                                                               "_radar_features.pth", "_node_timestamps.pth", "_edge_features.pth",
+                                                               "_edges.pth", "_gt.pth", "_node_boxes.pth")}
+            files["_node_metadata.json"] = json.load(open(stem + "_node_metadata.json"))
+            out["windows"].append(files)
+        for inference in (False, True):
+            ds = RefDataset(params, scenes, d, 5, inference)
+            assert len(ds) == 2
+            for idx in range(len(ds)):
+                item = ds[idx]
+                data, meta = (item if inference else (item, None))
+                rec = {k: v for k, v in vars(data).items() if torch.is_tensor(v) or isinstance(v, (int, float))}
+                # tensors handed through unchanged are not stored twice: checked here, named in the fixture
+                passed = {"pose_feats": "_pose_features.pth", "img_feats": "_img_features.pth", "lidar_feats": "_lidar_features.pth",
+                          "radar_feats": "_radar_features.pth", "edge_attr": "_edge_features.pth",
+                          "node_timestamps": "_node_timestamps.pth", "boxes": "_node_boxes.pth"}
+                for k, sfx in passed.items():
+                    if k in rec:
+                        assert torch.equal(rec.pop(k), out["windows"][idx][sfx]), k
+                rec["passed_through"] = {k: v for k, v in passed.items() if inference or k != "boxes"}
+                if inference:
+                    rec["global_node_metadata_str"] = meta
+                out["inference" if inference else "train"].append(rec)
+        # the oracle's loop-for-loop restatement must return the same
+        from batch3dmot_amd.graph_data import REL_FREQ_TRAIN
+        for inference in (False, True):
+            for idx in range(2):
+                got = ref_torch.window_getitem_loop(d + f"sceneG_len5_{idx}", inference, REL_FREQ_TRAIN, CLASS_DICT)
+                got, meta = (got if inference else (got, None))
+                want = out["inference" if inference else "train"][idx]
+                for k, v in got.items():
+                    if torch.is_tensor(v) and k in want:
+                        assert torch.equal(v, want[k]), k
+                if inference:
+                    assert meta == want["global_node_metadata_str"]
+    torch.save(out, path)
+    print(f"{path}: windows=2 nodes={out['windows'][0]['_pose_features.pth'].size(0)} edges={out['windows'][0]['_edges.pth'].size(0)}")
+
+
 def main():
     ref = load_reference()
     gd = os.path.join(ROOT, "tests", "golden")
@@ -464,6 +539,7 @@ def main():
                lidar_frac=0.04, radar_frac=0.04, salt=11)
     golden_train_step(ref, os.path.join(gd, "g3_train_step.pt"))
     golden_predict_post(os.path.join(gd, "g4_predict_post.pt"))
+    golden_loader(os.path.join(gd, "g7_loader.pt"))
     golden_scene(ref, os.path.join(gd, "g6_scene_pose.pt"), kind="pose", graph_idx=400, salt=30)
     golden_scene(ref, os.path.join(gd, "g6_scene_clr.pt"), kind="clr", graph_idx=440, salt=31)
 

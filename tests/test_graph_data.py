@@ -17,31 +17,7 @@ INV_CLASS = {v: k for k, v in CLASS_DICT.items()}
 
 
 def _write_window(stem, seed, n_per_frame=12, global_offset=1000):
-    """One synthetic window in the reference's file layout (plus one isolated node, which no edge touches)."""
-    g = synth.make_graph(5 * n_per_frame, 40 * n_per_frame, graph_idx=seed, modalities=True)
-    n = g.pose_feats.size(0)
-    cls = g.node_classes.long().clone()
-    # append an isolated node: its class never reaches node_classes in the reference's loop
-    pose = torch.cat([g.pose_feats, g.pose_feats[:1]])
-    ts = torch.cat([g.node_timestamps, g.node_timestamps[:1]])
-    torch.save(pose, stem + "_pose_features.pth")
-    torch.save(torch.cat([g.img_feats, g.img_feats[:1]]), stem + "_img_features.pth")
-    torch.save(torch.cat([g.lidar_feats, g.lidar_feats[:1]]), stem + "_lidar_features.pth")
-    torch.save(torch.cat([g.radar_feats, g.radar_feats[:1]]), stem + "_radar_features.pth")
-    torch.save(ts, stem + "_node_timestamps.pth")
-    torch.save(g.edge_attr, stem + "_edge_features.pth")
-    torch.save(g.edge_index.t().contiguous(), stem + "_edges.pth")
-    torch.save(g.y.reshape(1, -1), stem + "_gt.pth")
-    torch.save(torch.arange((n + 1) * 7, dtype=torch.float32).reshape(n + 1, 7), stem + "_node_boxes.pth")
-    gen = torch.Generator().manual_seed(seed)
-    gids = (torch.randperm(5 * (n + 1), generator=gen)[: n + 1] + global_offset).tolist()
-    meta = {}
-    for i in range(n + 1):
-        c = int(cls[i]) if i < n and int(cls[i]) > 0 else 1
-        meta[str(i)] = {"category_name": INV_CLASS[c], "global_node_id": gids[i], "score": 0.5, "token": f"t{i}"}
-    with open(stem + "_node_metadata.json", "w") as fh:
-        json.dump(meta, fh)
-    return n + 1
+    return synth.write_window_files(stem, seed, n_per_frame=n_per_frame, global_offset=global_offset)
 
 
 @pytest.fixture()
@@ -163,3 +139,43 @@ def test_prefetched_batches_stay_intact_under_a_long_running_consumer(window_dir
     for i, (pf, ea, ei) in enumerate(sums):
         w = want[i % 3]
         assert torch.equal(pf.cpu(), w.pose_feats) and torch.equal(ea.cpu(), w.edge_attr) and torch.equal(ei.cpu(), w.edge_index), i
+
+
+def _restore_windows(g, d):
+    """Write the fixture's window files back to disk in the reference's layout."""
+    for b, files in enumerate(g["windows"]):
+        stem = d + f"{g['scenes'][0]['token']}_len5_{b}"
+        for sfx, v in files.items():
+            if sfx.endswith(".json"):
+                with open(stem + sfx, "w") as fh:
+                    json.dump(v, fh)
+            else:
+                torch.save(v, stem + sfx)
+
+
+@pytest.mark.parametrize("inference", [False, True])
+def test_loader_matches_the_reference_class_fixture(tmp_path, inference):
+    """g7: what the REFERENCE's own GraphDataset.__getitem__ returned for these window files (oracle/make_golden.py,
+    golden_loader: the class is taken from utils/graph_data.py by ast and executed).  Both the product loader and the
+    oracle's loop-for-loop restatement must return exactly that."""
+    from conftest import load_golden
+    g = load_golden("g7_loader.pt")
+    d = str(tmp_path) + "/"
+    _restore_windows(g, d)
+    ds = GraphDataset(None, g["scenes"], d, 5, inference)
+    assert len(ds) == len(g["windows"])
+    for idx in range(len(ds)):
+        want = g["inference" if inference else "train"][idx]
+        got = ds[idx]
+        ref = window_getitem_loop(ds.batches[idx], inference, REL_FREQ_TRAIN, CLASS_DICT)
+        if inference:
+            (got, got_meta), (ref, ref_meta) = got, ref
+            assert got_meta == want["global_node_metadata_str"] == ref_meta
+        for k, v in want.items():
+            if torch.is_tensor(v):
+                _same(getattr(got, k), v)
+                _same(ref[k], v)
+            elif k in ("num_nodes", "batch_idx"):
+                assert getattr(got, k) == v
+        for k, sfx in want["passed_through"].items():
+            assert torch.equal(getattr(got, k), g["windows"][idx][sfx]), k
