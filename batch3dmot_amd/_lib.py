@@ -178,6 +178,9 @@ def load() -> C.CDLL:
     lib.b3d_post_greedy.restype = C.c_int
     lib.b3d_post_greedy.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32,
                                     C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.b3d_tracks_from_edges.restype = C.c_int
+    lib.b3d_tracks_from_edges.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32,
+                                          C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
     lib.b3d_prof_enable.argtypes = [C.c_int]
     lib.b3d_prof_select.argtypes = [C.c_uint32]
     lib.b3d_prof_select.restype = C.c_int

@@ -96,3 +96,35 @@ def greedy_edges_hip(pairs: torch.Tensor, scores: torch.Tensor, node_class: torc
         raise ValueError(f"{invalid} entries of pairs / node_class lie outside [0, {n}) / [0, {len(class_names)}) "
                          "(the reference's dictionaries raise a KeyError for them, predict.py:92-117)")
     return {"kept_pairs": kept_pairs[:k], "kept_scores": kept_scores[:k], "pred": pred, "succ": succ}
+
+
+# predict.py:302
+TRACK_JOIN_SCORES = dict(EDGE_SCORE_THRESHOLDS)
+
+
+def create_trajectories(pred_edges, scene_nodes, join_score: Dict[str, float] = TRACK_JOIN_SCORES):
+    """``create_trajectories(pred_edges, scene_nodes)`` of the reference (predict.py:262-375, mode "hier"): the greedy
+    edges ``[((j, i), score), ...]`` of a scene, taken by descending score, grow clusters at their ends and join two
+    clusters tail-to-head where the edge's score exceeds the threshold of the destination's class.  ``scene_nodes``
+    maps node id -> {"category_name": ...}.  Returns the tracks (lists of node ids) in the reference's order.
+
+    The merge is sequential by construction; it runs in the library's host code (``b3d_tracks_from_edges``: linked
+    clusters, O(M log M)) instead of Python lists and dictionaries."""
+    import ctypes as C
+    import numpy as np
+    from . import _lib
+    lib = _lib.load()
+    ids = sorted(scene_nodes.keys())
+    remap = {gid: k for k, gid in enumerate(ids)}
+    names = sorted(join_score.keys())
+    cls = np.asarray([names.index(scene_nodes[g]["category_name"]) for g in ids], dtype=np.int64)
+    thr = np.asarray([join_score[c] for c in names], dtype=np.float64)
+    m = len(pred_edges)
+    pairs = np.asarray([[remap[e[0][0]], remap[e[0][1]]] for e in pred_edges], dtype=np.int64).reshape(m, 2)
+    scores = np.asarray([float(e[1]) for e in pred_edges], dtype=np.float64)
+    nodes = np.empty(max(2 * m, 1), dtype=np.int64)
+    ptr = np.empty(m + 2, dtype=np.int64)
+    nt = C.c_int64()
+    _lib.check(lib.b3d_tracks_from_edges(pairs.ctypes.data, scores.ctypes.data, m, cls.ctypes.data, len(ids), thr.ctypes.data,
+                                         len(names), nodes.ctypes.data, ptr.ctypes.data, C.byref(nt)), "b3d_tracks_from_edges")
+    return [[ids[k] for k in nodes[ptr[t]:ptr[t + 1]]] for t in range(nt.value)]

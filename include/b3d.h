@@ -278,6 +278,18 @@ int b3d_post_greedy(const int64_t* pairs, const float* scores, int64_t M, const 
                     int64_t* kept_pairs,
                     double* kept_scores, int64_t* pred, int64_t* succ, int32_t* counts, b3d_stream stream);
 
+/* ---- hierarchical track clustering of the greedy edges (predict.py:262-375, mode "hier") -- HOST arrays ------------
+ * A sequential greedy merge over at most two edges per detection of a scene (each decision depends on the clusters
+ * the higher-scoring edges formed), so it runs on the host.  pairs [M,2] int64 (source j, destination i), scores [M]
+ * float64 in list order (a repeated pair keeps its first position and takes its last score, as the reference's dict
+ * does); edges are taken by descending score, ties in list order; node_class [N] int64 indexes join_threshold [C]
+ * float64 (the class of the DESTINATION decides whether two clusters join).  Outputs: track_nodes [<= 2 M] int64 =
+ * the tracks' node ids back to back, track_ptr [<= M + 1] int64, *n_tracks; tracks in the reference's order. */
+int b3d_tracks_from_edges(const int64_t* pairs /* host */, const double* scores /* host */, int64_t M,
+                          const int64_t* node_class /* host */, int64_t N, const double* join_threshold /* host */,
+                          int32_t num_classes, int64_t* track_nodes /* host */, int64_t* track_ptr /* host */,
+                          int64_t* n_tracks /* host */);
+
 /* ---- point-cloud feature stacks of the frozen LiDAR / radar encoders, eval mode ------------------------------
  * (models/pointnet.py:9-57 STN3d and :111-165 PointNetfeat, models/radarnet.py:9-37 RadarNetfeat)
  * out[b, :] = max over the P points of  L3(relu(L2(relu(L1(x'[b, :, p])))))  (+ ReLU if relu_last), where L1..L3 are

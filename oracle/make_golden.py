@@ -527,6 +527,56 @@ def golden_loader(path, n_per_frame=3):
     print(f"{path}: windows=2 nodes={out['windows'][0]['_pose_features.pth'].size(0)} edges={out['windows'][0]['_edges.pth'].size(0)}")
 
 
+def golden_tracks(path):
+    """SURVEY.md section 8f #3 (predict.py:246-259, 262-375): the greedy edges of a synthetic scene, built exactly as
+    ``combine_batches_to_scene`` builds them from the greedily filtered node flux, go through the reference's own
+    ``create_trajectories`` (taken from predict.py by ``ast``; its prints are discarded).  Several scenes: sparse,
+    dense (many joins), with exact score ties."""
+    import ast
+    import contextlib
+    import io
+    from collections import defaultdict
+    import numpy as np
+    src = open(os.path.join(REF, "batch_3dmot", "predict.py")).read()
+    ns = {"defaultdict": defaultdict, "np": np}
+    for node in ast.parse(src).body:
+        if isinstance(node, ast.FunctionDef) and node.name in ("greedy_filter_node_flux", "aggregate_node_flux", "create_trajectories"):
+            exec(compile(ast.Module([node], []), "predict.py", "exec"), ns)
+    cls_names = list(synth.CLASSES)
+    thr = {'bicycle': 0.1, 'bus': 0.005, 'car': 0.02, 'motorcycle': 0.03, 'pedestrian': 0.025, 'trailer': 0.04, 'truck': 0.005}
+    cases = []
+    for seed, n_nodes, n_edges, quant in ((1, 60, 150, 0), (2, 200, 900, 0), (3, 120, 500, 32), (4, 40, 30, 0)):
+        g = torch.Generator().manual_seed(500 + seed)
+        frame = torch.sort(torch.randint(0, 8, (n_nodes,), generator=g)).values            # node id ascending with time
+        node_cls = torch.randint(0, 7, (n_nodes,), generator=g)
+        a = torch.randint(0, n_nodes, (n_edges,), generator=g)
+        b = torch.randint(0, n_nodes, (n_edges,), generator=g)
+        ok = frame[a] < frame[b]                                                             # edges go forward in time
+        pairs = torch.unique(torch.stack([a[ok], b[ok]], 1), dim=0)
+        sc = torch.rand(pairs.size(0), generator=g, dtype=torch.float64) * 0.2
+        if quant:
+            sc = torch.round(sc * quant) / quant + 0.001                                     # exact ties
+        scene_nodes = {i: {"category_name": cls_names[int(node_cls[i])], "incoming": dict(), "outgoing": dict()} for i in range(n_nodes)}
+        avg = {(int(p[0]), int(p[1])): float(s) for p, s in zip(pairs, sc) if float(s) > thr[scene_nodes[int(p[0])]["category_name"]]}
+        nodes = ns["aggregate_node_flux"](scene_nodes, avg)
+        for i in nodes:
+            nodes[i]["incoming"], nodes[i]["outgoing"] = ns["greedy_filter_node_flux"](nodes[i])
+        greedy_edges = dict()                                                                # predict.py:246-255
+        for node_idx in nodes:
+            if len(nodes[node_idx]["outgoing"]) > 0:
+                greedy_edges[(node_idx, list(nodes[node_idx]["outgoing"].keys())[0])] = list(nodes[node_idx]["outgoing"].values())[0]
+            if len(nodes[node_idx]["incoming"]) > 0:
+                greedy_edges[(list(nodes[node_idx]["incoming"].keys())[0], node_idx)] = list(nodes[node_idx]["incoming"].values())[0]
+        pred_edges = [(edge, score) for edge, score in greedy_edges.items()]
+        with contextlib.redirect_stdout(io.StringIO()):
+            tracks = ns["create_trajectories"](pred_edges, nodes)
+        cases.append({"node_cls": node_cls, "pred_pairs": torch.tensor([e[0] for e in pred_edges], dtype=torch.long).reshape(-1, 2),
+                      "pred_scores": torch.tensor([e[1] for e in pred_edges], dtype=torch.float64), "tracks": tracks})
+        print(f"  tracks case {seed}: nodes {n_nodes} greedy edges {len(pred_edges)} tracks {len(tracks)} longest {max(map(len, tracks)) if tracks else 0}")
+    torch.save({"class_names": cls_names, "cases": cases}, path)
+    print(path)
+
+
 def main():
     ref = load_reference()
     gd = os.path.join(ROOT, "tests", "golden")
@@ -540,6 +590,7 @@ def main():
     golden_train_step(ref, os.path.join(gd, "g3_train_step.pt"))
     golden_predict_post(os.path.join(gd, "g4_predict_post.pt"))
     golden_loader(os.path.join(gd, "g7_loader.pt"))
+    golden_tracks(os.path.join(gd, "g8_tracks.pt"))
     golden_scene(ref, os.path.join(gd, "g6_scene_pose.pt"), kind="pose", graph_idx=400, salt=30)
     golden_scene(ref, os.path.join(gd, "g6_scene_clr.pt"), kind="clr", graph_idx=440, salt=31)
 
