@@ -125,17 +125,38 @@ def point_feat_train_hip(convs, bns, x: torch.Tensor, trans=None, relu_last: boo
     with torch.no_grad():
         xin = torch.bmm(x.transpose(2, 1), trans).transpose(2, 1) if trans is not None else x
         folded = []
-        h = xin
+        # Batch statistics of the two narrow layers WITHOUT materialising their [B, C, P] pre-activations a second time
+        # or reducing them element by element: the pre-activation of a kernel-1 convolution is affine in its input,
+        # z = W h + b, so over all B * P points   mean(z) = W mean(h) + b,   var(z)_c = W_c Cov(h) W_c^T
+        # with the (small) second-moment matrix of the INPUT: 3x3 / 4x4 for the first layer, 64x64 for the second.
+        # The moments are accumulated by one GEMM and finished in float64.
+        def moments(h2d):                                    # h2d [n_points, C] -> (mean [C], covariance [C, C]) in float64
+            # per-cloud partial sums in fp32 (P terms each), summed over the clouds in float64: a single [C, n] x [n, C]
+            # product would be one tall-skinny GEMM (slow) with a 10^5-term fp32 accumulation (inaccurate)
+            h3 = h2d.view(b, p, h2d.size(1))
+            mu = h3.sum(1).sum(0, dtype=torch.float64) / n
+            second = torch.bmm(h3.transpose(1, 2), h3).sum(0, dtype=torch.float64) / n
+            return mu, second - torch.outer(mu, mu)
+
+        def affine_stats(w2d, bias, mu, cov):                # statistics of z = W h + b over the points
+            wd = w2d.double()
+            mean = wd @ mu + bias.double()
+            var = ((wd @ cov) * wd).sum(1).clamp_min(0.0)
+            return mean.float(), var.float()
+
+        h2d = xin.permute(0, 2, 1).reshape(n, c)
         for li, (cv, bn) in enumerate(zip(convs[:2], bns[:2])):
-            z = F.conv1d(h, cv.weight, cv.bias)
-            var, mean = torch.var_mean(z, dim=(0, 2), unbiased=False)
+            w2d = cv.weight.squeeze(-1)
+            mu, cov = moments(h2d)
+            mean, var = affine_stats(w2d, cv.bias, mu, cov)
             _bn_batch_stats_(bn, mean, var, n)
             scale = bn.weight / torch.sqrt(var + bn.eps)
             shift = bn.bias - mean * scale
-            folded.append(((cv.weight.squeeze(-1) * scale[:, None]).float().contiguous(),
-                           (cv.bias * scale + shift).float().contiguous()))
+            wf = (w2d * scale[:, None]).float().contiguous()
+            bf = (cv.bias * scale + shift).float().contiguous()
+            folded.append((wf, bf))
             if li == 0:                                       # the kernel recomputes the activations itself; only the
-                h = torch.relu(z * scale[None, :, None] + shift[None, :, None])   # next layer's statistics need them here
+                h2d = torch.relu(torch.addmm(bf, h2d, wf.t()))          # next layer's statistics need them here
         folded.append((convs[2].weight.squeeze(-1).float().contiguous(), convs[2].bias.float().contiguous()))
         layers = (_lib.b3d_linear * 3)()
         for i, (w, bias) in enumerate(folded):
