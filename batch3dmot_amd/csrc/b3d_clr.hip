@@ -6,6 +6,7 @@
 #include "b3d_wstream.hpp"
 #include "b3d_wstream2.hpp"
 #include "b3d_hoist.hpp"
+#include "b3d_att.hpp"
 
 namespace b3d {
 namespace clr {
@@ -30,6 +31,11 @@ using SeqAT1 = LayerSeq<L<512, 384>>;
 using SeqAT2 = LayerSeq<L<384, 256>>;
 using SeqAT3 = LayerSeq<L<256, 128>>;
 using SeqAT4 = LayerSeq<L<128, 64>>;
+// att_edge_encoder.0 with its node columns hoisted (b3d_att.hpp)
+using SeqAttU = LayerSeq<LF<96, 1024>, LF<96, 1024>, LF<96, 1024>>;       // U = (W0[:, 0:288] s + b0 | W0[:, 288:576] s), three K-slices
+template <class... Ls> struct Rep16 { using type = LayerSeq<Ls..., Ls..., Ls..., Ls..., Ls..., Ls..., Ls..., Ls..., Ls..., Ls..., Ls..., Ls..., Ls..., Ls..., Ls..., Ls...>; };
+using SeqAttDs = Rep16<LF<64, 288>>::type;                                // d s = W0[:, 0:288]^T dU_i + W0[:, 288:576]^T dU_j, sixteen K-slices
+using SeqAT0eT = LayerSeq<L<512, 64>>;                                    // d e0 = W0[:, 576:640]^T d A0
 // transposed (data gradient)
 using SeqClsT = LayerSeq<L<16, 16>, L<16, 16>, L<16, 32>, L<32, 64>>;
 using SeqEET = LayerSeq<L<64, 32>, L<32, 16>>;
@@ -61,12 +67,13 @@ constexpr int kStreamNodeRowsPerTask = 64;    // hoisted first layers: node colu
 constexpr int kStreamRowsPerTaskAtt = 1024;   // att_edge_encoder (one variant)
 
 // column blocks of the hoisted first-layer gradients: (linear, first column, width, rows contracted over edges?)
-enum { VL_EU0XI, VL_EU0XJ, VL_EU0E, VL_FU0X, VL_FU0E, VL_FU0X0, VL_PA0X, VL_PA0E, VL_PA0X0, VL_COUNT };
+enum { VL_EU0XI, VL_EU0XJ, VL_EU0E, VL_FU0X, VL_FU0E, VL_FU0X0, VL_PA0X, VL_PA0E, VL_PA0X0, VL_AT0I, VL_AT0J, VL_AT0E, VL_COUNT };
 struct VlDesc { int lin, col0, width; bool on_edges, bias; };
 static const VlDesc kVl[VL_COUNT] = {
     {EU0, 0, 96, false, false}, {EU0, 96, 96, false, false}, {EU0, 192, 128, true, true},
     {FU0, 0, 96, false, false}, {FU0, 96, 64, true, true}, {FU0, 160, 96, false, false},
-    {PA0, 0, 96, false, false}, {PA0, 96, 64, true, true}, {PA0, 160, 96, false, false}};
+    {PA0, 0, 96, false, false}, {PA0, 96, 64, true, true}, {PA0, 160, 96, false, false},
+    {AT0, 0, 288, false, false}, {AT0, 288, 288, false, false}, {AT0, 576, 64, true, true}};
 struct Ws {
   // forward images
   float *wp_ee, *wp_ne, *wp_cls, *wp_fl, *wp_fr, *wp_aff[3], *wp_at[5], *wp_efwd, *wp_nfwd;
@@ -75,6 +82,7 @@ struct Ws {
   bool hoist;
   float *wp_proj0, *wp_nfwd_h, *wp_efwd_h, *wp_ebwd_h, *wp_ebwd_nm_h, *wp_gproj, *wp_nbwd_h;
   float *T, *T0, *dT, *gx;
+  float *wp_attU, *wp_att0, *wp_attDs, *wp_at0eT, *U, *dU, *ds, *de0;     // att_edge_encoder.0 hoisted
   float *wp_clsT, *wp_eeT, *wp_neT, *wp_flT, *wp_frT, *wp_affT[3], *wp_atT[5], *wp_ebwd, *wp_ebwd_nm, *wp_nbwd;
   // activations
   float *ea_pad, *ee_a1, *ee_a2, *pose_pad, *ne_a1, *xsens, *fl_a1, *fr_a1, *fr_a2, *aff_v[3], *s;
@@ -94,7 +102,7 @@ struct Ws {
   WsJob* ws_table;
   int* ws_task_job;
   LinSlab lin[LIN_COUNT];
-  LinSlab vlin[9];          // hoisted first layers: column blocks of edge_update.0 / create_*_msgs.0 with slabs of their own
+  LinSlab vlin[VL_COUNT];          // hoisted first layers: column blocks of edge_update.0 / create_*_msgs.0 with slabs of their own
   KnnWs knn;
   size_t bytes;
   bool ok;
@@ -131,6 +139,9 @@ static void carve(Ws& w, void* ws, size_t ws_bytes, int N, int E, int nl, int nr
     w.wp_efwd_h = c.take<float>(HC::EdgeFwdSeq::TOTAL_FLOATS);
     w.T = c.take<float>(n_ * HC::TW);
     w.T0 = c.take<float>(n_ * 2 * DB::MH);
+    w.wp_attU = c.take<float>(SeqAttU::TOTAL_FLOATS);
+    w.wp_att0 = c.take<float>(Att0Seq::TOTAL_FLOATS);
+    w.U = c.take<float>(n_ * 1024);
   }
   w.xsens = c.take<float>(n_ * XS);
   w.s = c.take<float>(n_ * XS);
@@ -166,6 +177,11 @@ static void carve(Ws& w, void* ws, size_t ws_bytes, int N, int E, int nl, int nr
       w.wp_ebwd_nm_h = c.take<float>(HC::EdgeBwdSeqNoMsg::TOTAL_FLOATS);
       w.wp_nbwd_h = c.take<float>(NodeBwdHSeq<DB>::TOTAL_FLOATS);
       w.wp_gproj = c.take<float>(HC::GradProjSeq::TOTAL_FLOATS);
+      w.wp_attDs = c.take<float>(SeqAttDs::TOTAL_FLOATS);
+      w.wp_at0eT = c.take<float>(SeqAT0eT::TOTAL_FLOATS);
+      w.dU = c.take<float>(n_ * 1024);
+      w.ds = c.take<float>(n_ * XS);
+      w.de0 = c.take<float>(e_ * 64);
       w.dT = c.take<float>((size_t)depth * n_ * HC::GW);
       w.gx = c.take<float>(n_ * 2 * D::DX);
     }
@@ -209,7 +225,7 @@ static void carve(Ws& w, void* ws, size_t ws_bytes, int N, int E, int nl, int nr
     w.ge_top = c.take<float>(e_ * 64); w.ge2 = c.take<float>(e_ * 32); w.ge1 = c.take<float>(e_ * 16);
     w.gn_top = c.take<float>(n_ * 96); w.gn1 = c.take<float>(n_ * 48);
     w.dA[0] = c.take<float>(e_ * 128); w.dA[1] = c.take<float>(e_ * 256); w.dA[2] = c.take<float>(e_ * 384); w.dA[3] = c.take<float>(e_ * 512);
-    w.dIn = c.take<float>(e_ * 640);
+    w.dIn = w.hoist ? nullptr : c.take<float>(e_ * 640);
     for (int m = 0; m < 3; ++m) { w.gaff_top[m] = c.take<float>(n_ * affd[m]); w.gaff_v[m] = c.take<float>(n_ * affd[m]); }
     w.dxs = c.take<float>(n_ * XS);
     w.gfl_top = c.take<float>(l_ * 128); w.gfl1 = c.take<float>(l_ * 192);
@@ -236,7 +252,7 @@ static void carve(Ws& w, void* ws, size_t ws_bytes, int N, int E, int nl, int nr
       LinSlab& ls = w.vlin[v];
       ls.N = kDims[kVl[v].lin].N; ls.K = kVl[v].width; ls.NP = pad16(ls.N); ls.KP = pad16(ls.K);
       const long rows = kVl[v].on_edges ? E : N;
-      const int rpt = kVl[v].on_edges ? kStreamRowsPerTask : kStreamNodeRowsPerTask;
+      const int rpt = kVl[v].on_edges ? (kVl[v].lin == AT0 ? kStreamRowsPerTaskAtt : kStreamRowsPerTask) : kStreamNodeRowsPerTask;
       ls.nchunks = (int)((rows + rpt - 1) / rpt);
       if (ls.nchunks < 1) ls.nchunks = 1;
       ls.slab = w.hoist ? c.take<float>(wg_slab_floats(ls.nchunks, ls.NP, ls.KP)) : nullptr;
@@ -302,7 +318,7 @@ static int check_weights(const b3d_clr_weights* pw) {
 static int pack_all(const b3d_clr_weights* pw, Ws& w, bool training, bool knn, hipStream_t stream) {
   LinPtrs L[LIN_COUNT];
   gather_linears(pw, L);
-  PackDesc d[160];
+  PackDesc d[224];
   int n = 0;
   auto F = [&](auto tag, int li, float* base, int lin) {
     using S = decltype(tag);
@@ -351,6 +367,13 @@ static int pack_all(const b3d_clr_weights* pw, Ws& w, bool training, bool knn, h
     F(EH{}, 4, w.wp_efwd_h, FU1);
     d[n++] = pack_slice<EH>(5, w.wp_efwd_h, pa0.w + DX, nullptr, MH, DE, MIN, 0, MH, false);
     F(EH{}, 6, w.wp_efwd_h, PA1);
+    const LinPtrs& a0 = L[AT0];                               // att_edge_encoder.0 [512, 640]
+    for (int k = 0; k < 3; ++k) {
+      d[n++] = pack_slice<SeqAttU>(k, w.wp_attU, a0.w + 96 * k, k == 0 ? a0.b : nullptr, 512, 96, 640, 0, 512, false);
+      d[n++] = pack_slice<SeqAttU>(k, w.wp_attU, a0.w + XS + 96 * k, nullptr, 512, 96, 640, 512, 512, false);
+    }
+    for (int cc = 0; cc < 4; ++cc)
+      d[n++] = pack_slice<Att0Seq>(cc, w.wp_att0, a0.w + (size_t)128 * cc * 640 + 2 * XS, nullptr, 128, 64, 640, 0, 128, false);
   }
   if (training) {
     T(SeqClsT{}, 0, w.wp_clsT, C3); T(SeqClsT{}, 1, w.wp_clsT, C2); T(SeqClsT{}, 2, w.wp_clsT, C1); T(SeqClsT{}, 3, w.wp_clsT, C0);
@@ -399,9 +422,13 @@ static int pack_all(const b3d_clr_weights* pw, Ws& w, bool training, bool knn, h
       gp(NH{}, w.wp_nbwd_h);
       gp(HC::GradProjSeq{}, w.wp_gproj);
       T(NH{}, 4, w.wp_nbwd_h, CF2); T(NH{}, 5, w.wp_nbwd_h, CF1); T(NH{}, 6, w.wp_nbwd_h, CF0);
+      const LinPtrs& a0 = L[AT0];
+      for (int k = 0; k < 16; ++k)                             // slice k: 64 columns of dU_i (k < 8) or dU_j
+        d[n++] = pack_slice<SeqAttDs>(k, w.wp_attDs, a0.w + (size_t)64 * (k & 7) * 640 + (k < 8 ? 0 : XS), nullptr, XS, 64, 640, 0, XS, true);
+      d[n++] = pack_slice<SeqAT0eT>(0, w.wp_at0eT, a0.w + 2 * XS, nullptr, 64, 512, 640, 0, 64, true);
     }
   }
-  if (n > 160) return fail(B3D_ERR_ARG, "pack descriptor table overflow");
+  if (n > 224) return fail(B3D_ERR_ARG, "pack descriptor table overflow");
   return pack_images(d, n, stream);
 }
 
@@ -411,6 +438,17 @@ static int wide(const char* name, const In& in, long rows, float* out, int ostri
   WideArgs<In> a;
   a.rows = (int)rows; a.in = in; a.out = out; a.out_stride = ostride; a.out_col0 = ocol0; a.mask = mask; a.wpack = wp;
   return launch_rows<kNWEdge>(wide_linear_kernel<Seq, RELU, BIAS, In, kNWEdge>, name, a, rows, stream, family, chain_lds<Seq>());
+}
+
+template <class Seq>
+static int node_linear(const char* name, const float* in, int in_stride, int in_col0, float* out, int out_stride, int N,
+                       const float* wp, hipStream_t stream, int family) {
+  NodeLinArgs a;
+  a.N = N; a.in = in; a.in_stride = in_stride; a.in_col0 = in_col0; a.out = out; a.out_stride = out_stride; a.out_col0 = 0; a.wpack = wp;
+  B3D_TRY(set_lds(att_node_linear_kernel<Seq>, kNodeLinLds));
+  ProfScope ps(family, stream);
+  hipLaunchKernelGGL(att_node_linear_kernel<Seq>, dim3((N + 15) / 16), dim3(kNodeLinWaves * 64), kNodeLinLds, stream, a);
+  return launch_check(name);
 }
 
 // One modality's out_proj(v_proj(x)) on all nodes: x = xsens[:, xc : xc+DD] -> s[:, sc : sc+DD]
@@ -427,6 +465,20 @@ static int affine_fwd(Ws& w, int m, int N, int xc, int sc, hipStream_t stream) {
 }
 
 // backward of one modality: G_out = segment sums of d s_i / d s_j columns; d x_m -> dxs[:, xc : xc+DD]
+template <int DD>
+static int affine_bwd_h(Ws& w, int m, int N, int xc, int sc, hipStream_t stream) {      // d s comes per node (att hoisted)
+  using In = LoadAligned<DD / 16>;
+  using Out = StoreAligned<DD / 16>;
+  ChainBwdArgs<In, Out> a;
+  memset(&a, 0, sizeof(a));
+  a.rows = N;
+  a.in = In{w.ds, nullptr, XS, sc};
+  a.out = Out{w.dxs, nullptr, XS, xc};
+  a.gtop = w.gaff_top[m];
+  a.gsave[0] = w.gaff_v[m];
+  a.wpack = w.wp_affT[m];
+  return launch_rows<kNWNode>(chain_bwd_kernel<SeqAffT<DD>, In, Out, kNWNode>, "modality_affine_bwd", a, N, stream, B3D_K_OTHER, chain_lds<SeqAffT<DD>>());
+}
 template <int DD>
 static int affine_bwd(Ws& w, const b3d_graph* g, int m, int N, int xc, int sc, hipStream_t stream) {
   using In = LoadSegSum2<DD / 16>;
@@ -452,7 +504,7 @@ extern "C" uint32_t b3d_features(void) {
   uint32_t f = 0;
   const char* e = getenv("B3D_HOIST");
   if (!e || atoi(e) != 0) f |= B3D_FEATURE_POSE_HOIST;
-  if (b3d::clr::hoist_enabled()) f |= B3D_FEATURE_CLR_HOIST_MP;
+  if (b3d::clr::hoist_enabled()) f |= B3D_FEATURE_CLR_HOIST_MP | B3D_FEATURE_CLR_HOIST_ATT;
   return f;
 }
 
@@ -541,7 +593,14 @@ extern "C" int b3d_clr_forward(const b3d_clr_weights* pw, const b3d_graph* g, co
   {  // att_edge_encoder( s[dst] | s[src] | e ) 640-512-384-256-128-64 (:161-164)
     using In0 = LoadConcat3<18, 18, 4>;
     In0 i0{LoadAligned<18>{w.s, g->dst, XS, 0}, LoadAligned<18>{w.s, g->src, XS, 0}, LoadAligned<4>{w.e[0], nullptr, D::DE, 0}};
-    B3D_TRY((wide<SeqAT0, true, true>("att_edge_encoder.0", i0, E, w.A[0], 512, 0, nullptr, w.wp_at[0], stream)));
+    if (w.hoist) {
+      B3D_TRY(node_linear<SeqAttU>("att_node_linear", w.s, XS, 0, w.U, 1024, N, w.wp_attU, stream, B3D_K_ATT_FWD));
+      Att0FwdArgs fa;
+      fa.E = E; fa.src = g->src; fa.dst = g->dst; fa.U = w.U; fa.e0 = w.e[0]; fa.A0 = w.A[0]; fa.wpack = w.wp_att0;
+      B3D_TRY(launch_rows<kNWEdge>(att0_fwd_kernel<kNWEdge>, "att_edge_encoder.0", fa, E, stream, B3D_K_ATT_FWD, stream_lds_bytes<Att0Seq>()));
+    } else {
+      B3D_TRY((wide<SeqAT0, true, true>("att_edge_encoder.0", i0, E, w.A[0], 512, 0, nullptr, w.wp_at[0], stream)));
+    }
     B3D_TRY((wide<SeqAT1, true, true>("att_edge_encoder.2", LoadAligned<32>{w.A[0], nullptr, 512, 0}, E, w.A[1], 384, 0, nullptr, w.wp_at[1], stream)));
     B3D_TRY((wide<SeqAT2, true, true>("att_edge_encoder.4", LoadAligned<24>{w.A[1], nullptr, 384, 0}, E, w.A[2], 256, 0, nullptr, w.wp_at[2], stream)));
     B3D_TRY((wide<SeqAT3, true, true>("att_edge_encoder.6", LoadAligned<16>{w.A[2], nullptr, 256, 0}, E, w.A[3], 128, 0, nullptr, w.wp_at[3], stream)));
@@ -754,12 +813,30 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
   B3D_TRY((wide<SeqAT3T, false, false>("att_edge_encoder.6^T", LoadAligned<8>{w.dA[0], nullptr, 128, 0}, E, w.dA[1], 256, 0, w.A[2], w.wp_atT[3], stream, B3D_K_ATT_BWD)));
   B3D_TRY((wide<SeqAT2T, false, false>("att_edge_encoder.4^T", LoadAligned<16>{w.dA[1], nullptr, 256, 0}, E, w.dA[2], 384, 0, w.A[1], w.wp_atT[2], stream, B3D_K_ATT_BWD)));
   B3D_TRY((wide<SeqAT1T, false, false>("att_edge_encoder.2^T", LoadAligned<24>{w.dA[2], nullptr, 384, 0}, E, w.dA[3], 512, 0, w.A[0], w.wp_atT[1], stream, B3D_K_ATT_BWD)));
+  if (w.hoist) {
+    // d e0 per edge; d U per node = sums of d A0 over the CSR / CSC lists; d s = W0[:, 0:288]^T dU_i + W0[:, 288:576]^T dU_j
+    B3D_TRY((wide<SeqAT0eT, false, false>("att_edge_encoder.0[e]^T", LoadAligned<32>{w.dA[3], nullptr, 512, 0}, E, w.de0, 64, 0, nullptr, w.wp_at0eT, stream, B3D_K_ATT_BWD)));
+    AttListSumArgs la;
+    la.N = N; la.W = 512; la.dst_ptr = g->dst_ptr; la.dst_perm = g->dst_perm; la.src_ptr = g->src_ptr; la.src_perm = g->src_perm;
+    la.G = w.dA[3]; la.dU = w.dU;
+    {
+      const long tasks = (long)((N + 15) / 16) * 2 * (512 / 64);
+      ProfScope ps(B3D_K_ATT_BWD, stream);
+      hipLaunchKernelGGL(att_listsum_kernel, dim3((unsigned)((tasks + 3) / 4)), dim3(256), 0, stream, la);
+    }
+    B3D_TRY(launch_check("att_listsum_kernel"));
+    B3D_TRY(node_linear<SeqAttDs>("att_node_linear^T", w.dU, 1024, 0, w.ds, XS, N, w.wp_attDs, stream, B3D_K_ATT_BWD));
+    B3D_TRY(affine_bwd_h<96>(w, 0, N, 0, 192, stream));
+    B3D_TRY(affine_bwd_h<128>(w, 1, N, 96, 64, stream));
+    B3D_TRY(affine_bwd_h<64>(w, 2, N, 224, 0, stream));
+  } else {
   B3D_TRY((wide<SeqAT0T, false, false>("att_edge_encoder.0^T", LoadAligned<32>{w.dA[3], nullptr, 512, 0}, E, w.dIn, 640, 0, nullptr, w.wp_atT[0], stream, B3D_K_ATT_BWD)));
 
   // ---- modality attention (per node) backward, then the modality heads -------------------------------
   B3D_TRY(affine_bwd<96>(w, g, 0, N, 0, 192, stream));
   B3D_TRY(affine_bwd<128>(w, g, 1, N, 96, 64, stream));
   B3D_TRY(affine_bwd<64>(w, g, 2, N, 224, 0, stream));
+  }
   {
     const int affd[3] = {96, 128, 64}, xc[3] = {0, 96, 224};
     for (int m = 0; m < 3; ++m) {
@@ -819,7 +896,8 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
     using In = LoadAdd2<4>;
     ChainBwdArgs<In, StoreNone> a;
     memset(&a, 0, sizeof(a));
-    a.rows = E; a.in = In{w.de[cur], D::DE, 0, w.dIn, 640, 576, nullptr};
+    a.rows = E;
+    a.in = w.hoist ? In{w.de[cur], D::DE, 0, w.de0, 64, 0, nullptr} : In{w.de[cur], D::DE, 0, w.dIn, 640, 576, nullptr};
     a.gtop = w.ge_top; a.act[0] = w.ee_a2; a.act[1] = w.ee_a1; a.gsave[0] = w.ge2; a.gsave[1] = w.ge1; a.wpack = w.wp_eeT;
     B3D_TRY(launch_rows<kNWEdge>(chain_bwd_kernel<SeqEET, In, StoreNone, kNWEdge>, "edge_encoder_bwd", a, E, stream, B3D_K_OTHER, chain_lds<SeqEET>()));
     WgJob e2 = make_job(w.lin[EE2], E, seg(w.ge_top, nullptr, 64, 0, 64)); add_act(e2, seg(w.ee_a2, nullptr, 32, 0, 32)); smallE.jobs[smallE.njobs++] = e2;
@@ -937,8 +1015,16 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
       add_matrix(CF2, N, depth - 1, rp, w.Gdx, nullptr, nLx, D::DX, 0, c2, 1);
     }
     {  // att_edge_encoder
+      if (w.hoist) {       // .0: edge columns over edges, node columns over nodes (G = the per-node sums dU_i | dU_j)
+        Col ce[1] = {{w.e[0], nullptr, 0, D::DE, 0, 64}};
+        add_block(w.vlin[VL_AT0E], E, 1, rpa, w.dA[3], nullptr, 0, 512, 0, ce, 1, true);
+        Col cs[1] = {{w.s, nullptr, 0, XS, 0, 288}};
+        add_block(w.vlin[VL_AT0I], N, 1, kStreamNodeRowsPerTask, w.dU, nullptr, 0, 1024, 0, cs, 1, false);
+        add_block(w.vlin[VL_AT0J], N, 1, kStreamNodeRowsPerTask, w.dU, nullptr, 0, 1024, 512, cs, 1, false);
+      } else {
       Col c0[3] = {{w.s, dst, 0, XS, 0, 288}, {w.s, src, 0, XS, 0, 288}, {w.e[0], nullptr, 0, D::DE, 0, 64}};
       add_matrix(AT0, E, 1, rpa, w.dA[3], nullptr, 0, 512, 0, c0, 3);
+      }
       Col c1[1] = {{w.A[0], nullptr, 0, 512, 0, 512}};
       add_matrix(AT1, E, 1, rpa, w.dA[2], nullptr, 0, 384, 0, c1, 1);
       Col c2[1] = {{w.A[1], nullptr, 0, 384, 0, 384}};
@@ -948,7 +1034,12 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
       Col c4[1] = {{w.A[3], nullptr, 0, 128, 0, 128}};
       add_matrix(AT4, E, 1, rpa, w.da_acc, nullptr, 0, 64, 0, c4, 1);
     }
-    wl.launch(w.zrow, B3D_K_WGRAD_EDGE);
+    static const bool ws2 = [] { const char* e = getenv("B3D_WS2"); return e ? atoi(e) != 0 : true; }();   // B3D_WS2=0: register-staged form
+    if (ws2 && w.hoist) {    // every job of the hoisted plan has one un-gathered activation segment: LDS-DMA ring form
+      B3D_REQUIRE(wl.launch2(wstream2_kernel, kWs2LdsBytes, w.zrow, w.iota, B3D_K_WGRAD_EDGE) == 0, "wstream2: LDS attribute");
+    } else {
+      wl.launch(w.zrow, B3D_K_WGRAD_EDGE);
+    }
     B3D_REQUIRE(wl.status == 0, "streaming weight gradient: job table overflow (%d jobs, %d tasks)", wl.njobs, wl.total_tasks);
     B3D_TRY(launch_check("wstream_kernel"));
   }
@@ -977,7 +1068,7 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
     ra.nentries = 0;
     for (int i = 0; i < LIN_COUNT; ++i) {
       LinSlab& ls = w.lin[i];
-      if (w.hoist && (i == EU0 || i == FU0 || i == PA0)) {
+      if (w.hoist && (i == EU0 || i == FU0 || i == PA0 || i == AT0)) {
         bool any = false;
         for (int v = 0; v < VL_COUNT; ++v) any = any || (kVl[v].lin == i && w.vlin[v].used);
         if (any) {          // depth == 1: the message stacks receive no gradient (falls through to the zero fill)
