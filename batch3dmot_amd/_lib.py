@@ -147,11 +147,15 @@ def load() -> C.CDLL:
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(b3d_mp_weights), C.c_void_p]
     lib.b3d_clr_layer_workspace_bytes.restype = C.c_size_t
-    lib.b3d_clr_layer_workspace_bytes.argtypes = [C.c_int32, C.c_int32]
+    lib.b3d_clr_layer_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_uint32]
     lib.b3d_clr_layer_forward.restype = C.c_int
     lib.b3d_clr_layer_forward.argtypes = [C.POINTER(b3d_mp_weights), C.POINTER(b3d_graph), C.c_void_p, C.c_void_p,
-                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
                                           C.c_void_p]
+    lib.b3d_clr_layer_backward.restype = C.c_int
+    lib.b3d_clr_layer_backward.argtypes = [C.POINTER(b3d_mp_weights), C.POINTER(b3d_graph), C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(b3d_mp_weights), C.c_void_p]
     lib.b3d_side_join.restype = C.c_int
     lib.b3d_side_join.argtypes = [C.c_void_p]
     lib.b3d_pose_debug_knn_ptrs.restype = C.c_int

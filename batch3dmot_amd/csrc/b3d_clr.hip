@@ -1097,60 +1097,254 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
 }
 
 // ---- standalone CausalMessagePassing layer, camera+LiDAR+radar widths (clr_att_gnn.py:227-356) --------------
-// Forward only: the layer-level backward is built for the poses-only widths (b3d_pose_layer_backward);
-// training of this model goes through b3d_clr_forward / b3d_clr_backward.
+// forward(x, edge_index, edge_attr, initial_x, att_edge_attr) -> (x', e') and its backward, as an operator of its own (the
+// model entry points above run the hoisted plan over all layers; a single layer with caller-provided x / x0 runs the
+// unsplit kernels: there is no previous node kernel to produce the per-node table).
 namespace b3d {
-struct ClrLayerWs { float *wp_efwd, *wp_nfwd, *fut, *past; size_t bytes; bool ok; };
-static void carve_layer(ClrLayerWs& w, void* ws, size_t ws_bytes, int N, int E) {
+namespace clr {
+constexpr int kLayerTableCap = 96, kLayerTaskCap = 16384;
+enum { LL_EU0, LL_EU1, LL_EU2, LL_PA0, LL_PA1, LL_FU0, LL_FU1, LL_CF0, LL_CF1, LL_CF2, LL_COUNT };
+static const int kLayerLin[LL_COUNT] = {EU0, EU1, EU2, PA0, PA1, FU0, FU1, CF0, CF1, CF2};
+struct ClrLayerWs {
+  float *wp_efwd, *wp_nfwd, *wp_ebwd, *wp_nbwd, *fut, *past;
+  float *sH1, *sH2, *sF1, *sP1, *M, *nH1, *nH2;
+  float *dM, *GdH1, *GdH2, *Gde, *GdF1, *GdP1, *GnH2, *GnH1, *gdst, *gsrc, *de_tmp, *da_tmp, *zero_e, *zero_n;
+  float* zrow;
+  int* iota;
+  WsJob* ws_table;
+  int* ws_task_job;
+  LinSlab lin[LL_COUNT];
+  size_t bytes;
+  bool ok;
+};
+static void carve_layer(ClrLayerWs& w, void* ws, size_t ws_bytes, int N, int E, bool tr) {
   Carver c(ws, ws_bytes);
-  (void)N;
+  memset(&w, 0, sizeof(w));
+  const size_t e_ = (size_t)(E > 0 ? E : 1), n_ = (size_t)(N > 0 ? N : 1);
   w.wp_efwd = c.take<float>(D::EdgeFwdSeq::TOTAL_FLOATS);
   w.wp_nfwd = c.take<float>(D::NodeFwdSeq::TOTAL_FLOATS);
-  w.fut = c.take<float>((size_t)(E > 0 ? E : 1) * D::DM);
-  w.past = c.take<float>((size_t)(E > 0 ? E : 1) * D::DM);
+  w.fut = c.take<float>(e_ * D::DM);
+  w.past = c.take<float>(e_ * D::DM);
+  if (tr) {
+    w.wp_ebwd = c.take<float>(D::EdgeBwdSeq::TOTAL_FLOATS);
+    w.wp_nbwd = c.take<float>(D::NodeBwdSeq::TOTAL_FLOATS);
+    w.sH1 = c.take<float>(e_ * D::EH1); w.sH2 = c.take<float>(e_ * D::EH2); w.sF1 = c.take<float>(e_ * D::MH); w.sP1 = c.take<float>(e_ * D::MH);
+    w.M = c.take<float>(n_ * D::NIN); w.nH1 = c.take<float>(n_ * D::NH1); w.nH2 = c.take<float>(n_ * D::NH2);
+    w.dM = c.take<float>(n_ * D::NIN);
+    w.GdH1 = c.take<float>(e_ * D::EH1); w.GdH2 = c.take<float>(e_ * D::EH2); w.Gde = c.take<float>(e_ * D::DE);
+    w.GdF1 = c.take<float>(e_ * D::MH); w.GdP1 = c.take<float>(e_ * D::MH);
+    w.GnH2 = c.take<float>(n_ * D::NH2); w.GnH1 = c.take<float>(n_ * D::NH1);
+    w.gdst = c.take<float>(e_ * 2 * D::DX); w.gsrc = c.take<float>(e_ * 2 * D::DX);
+    w.de_tmp = c.take<float>(e_ * D::DE); w.da_tmp = c.take<float>(e_ * D::DA); w.zero_e = c.take<float>(e_ * D::DE); w.zero_n = c.take<float>(n_ * D::DX);
+    w.zrow = c.take<float>(256);
+    w.iota = c.take<int>((size_t)(E > N ? E : N) + 64);
+    w.ws_table = c.take<WsJob>(kLayerTableCap);
+    w.ws_task_job = c.take<int>(kLayerTaskCap);
+    for (int i = 0; i < LL_COUNT; ++i) {
+      LinSlab& ls = w.lin[i];
+      const int li = kLayerLin[i];
+      ls.N = kDims[li].N; ls.K = kDims[li].K; ls.NP = pad16(ls.N); ls.KP = pad16(ls.K);
+      const long rows = kRowKind[li] == 0 ? E : N;
+      ls.nchunks = (int)((rows + kStreamRowsPerTask - 1) / kStreamRowsPerTask);
+      if (ls.nchunks < 1) ls.nchunks = 1;
+      ls.slab = c.take<float>(wg_slab_floats(ls.nchunks, ls.NP, ls.KP));
+      ls.used = false;
+    }
+  }
   w.bytes = c.off + 256;
   w.ok = c.ok();
 }
+static int pack_layer(const b3d_mp_weights* mw, ClrLayerWs& w, bool tr, hipStream_t stream) {
+  const b3d_linear* stacks[] = {mw->edge_update, mw->create_future_msgs, mw->create_past_msgs, mw->combine_future_past};
+  const int first[] = {EU0, FU0, PA0, CF0}, cnt[] = {3, 2, 2, 3};
+  PackDesc d[32];
+  int n = 0, li = 0;
+  for (int s = 0; s < 4; ++s)
+    for (int i = 0; i < cnt[s]; ++i) {
+      const b3d_linear& l = stacks[s][i];
+      B3D_REQUIRE(l.w && l.b, "CausalMessagePassing layer: null weight/bias pointer (stack %d layer %d)", s, i);
+      const LinDim dim = kDims[first[s] + i];
+      if (s < 3) d[n++] = pack_desc<D::EdgeFwdSeq>(li++, w.wp_efwd, l.w, l.b, dim.N, dim.K, false);
+      else d[n++] = pack_desc<D::NodeFwdSeq>(i, w.wp_nfwd, l.w, l.b, dim.N, dim.K, false);
+    }
+  if (tr) {
+    auto T = [&](auto tag, int li2, float* base, const b3d_linear& l, int lin) {
+      using S = decltype(tag);
+      d[n++] = pack_desc<S>(li2, base, l.w, nullptr, kDims[lin].K, kDims[lin].N, true);
+    };
+    using EB = D::EdgeBwdSeq;
+    T(EB{}, 0, w.wp_ebwd, mw->create_past_msgs[1], PA1); T(EB{}, 1, w.wp_ebwd, mw->create_past_msgs[0], PA0);
+    T(EB{}, 2, w.wp_ebwd, mw->create_future_msgs[1], FU1); T(EB{}, 3, w.wp_ebwd, mw->create_future_msgs[0], FU0);
+    T(EB{}, 4, w.wp_ebwd, mw->edge_update[2], EU2); T(EB{}, 5, w.wp_ebwd, mw->edge_update[1], EU1); T(EB{}, 6, w.wp_ebwd, mw->edge_update[0], EU0);
+    using NB = D::NodeBwdSeq;
+    T(NB{}, 0, w.wp_nbwd, mw->combine_future_past[2], CF2); T(NB{}, 1, w.wp_nbwd, mw->combine_future_past[1], CF1);
+    T(NB{}, 2, w.wp_nbwd, mw->combine_future_past[0], CF0);
+  }
+  return pack_images(d, n, stream);
+}
+// d x[n] = sum over edges with dst == n of gdst[., 0:DX] + sum over edges with src == n of gsrc[., 0:DX]; d x0 from DX:2DX
+struct NodeGradArgsC {
+  int N;
+  const int *dst_ptr, *dst_perm, *src_ptr, *src_perm;
+  const float *gdst, *gsrc;
+  float *d_x, *d_x0;
+};
+__global__ __launch_bounds__(256) void node_grad_gather_c_kernel(const NodeGradArgsC a) {
+  constexpr int XB = D::DX / 16;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long row = ((long)blockIdx.x * 4 + wave) * 16 + (lane & 15);
+  const bool valid = row < a.N;
+  v4f g[2 * XB];
+#pragma unroll
+  for (int b = 0; b < 2 * XB; ++b) g[b] = v4f{0.f, 0.f, 0.f, 0.f};
+  if (valid) {
+    segment_sum<2 * XB>(a.gdst, 2 * D::DX, 0, a.dst_perm, a.dst_ptr[row], a.dst_ptr[row + 1], g);
+    segment_sum<2 * XB>(a.gsrc, 2 * D::DX, 0, a.src_perm, a.src_ptr[row], a.src_ptr[row + 1], g);
+  }
+  if (a.d_x) store_row<XB>(a.d_x, row, D::DX, 0, valid, g);
+  if (a.d_x0) store_row<XB>(a.d_x0, row, D::DX, 0, valid, g + XB);
+}
+}  // namespace clr
 }  // namespace b3d
 
-extern "C" size_t b3d_clr_layer_workspace_bytes(int32_t N, int32_t E) {
+extern "C" size_t b3d_clr_layer_workspace_bytes(int32_t N, int32_t E, uint32_t flags) {
   ClrLayerWs w;
-  carve_layer(w, nullptr, 0, N, E);
+  carve_layer(w, nullptr, 0, N, E, (flags & B3D_FLAG_TRAINING) != 0);
   return w.bytes;
 }
 
 extern "C" int b3d_clr_layer_forward(const b3d_mp_weights* mw, const b3d_graph* g, const float* x, const float* x0,
-                                     const float* e, const float* att, void* workspace, size_t workspace_bytes,
+                                     const float* e, const float* att, uint32_t flags, void* workspace, size_t workspace_bytes,
                                      float* x_new, float* e_new, b3d_stream stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   B3D_REQUIRE(mw && g && x && x0 && e && att && workspace && x_new && e_new, "b3d_clr_layer_forward: null argument");
   const int N = g->N, E = g->E;
   B3D_REQUIRE(N > 0 && E > 0, "b3d_clr_layer_forward: empty graph (N=%d, E=%d)", N, E);
+  const bool tr = (flags & B3D_FLAG_TRAINING) != 0;
   ClrLayerWs w;
-  carve_layer(w, workspace, workspace_bytes, N, E);
+  carve_layer(w, workspace, workspace_bytes, N, E, tr);
   if (!w.ok) return fail(B3D_ERR_WORKSPACE, "b3d_clr_layer_forward: workspace %zu < %zu bytes", workspace_bytes, w.bytes);
-  const b3d_linear* stacks[] = {mw->edge_update, mw->create_future_msgs, mw->create_past_msgs, mw->combine_future_past};
-  const int first[] = {EU0, FU0, PA0, CF0}, cnt[] = {3, 2, 2, 3};
-  PackDesc d[16];
-  int n = 0, li = 0;
-  for (int s = 0; s < 4; ++s)
-    for (int i = 0; i < cnt[s]; ++i) {
-      const b3d_linear& l = stacks[s][i];
-      B3D_REQUIRE(l.w && l.b, "b3d_clr_layer_forward: null weight/bias pointer (stack %d layer %d)", s, i);
-      const LinDim dim = kDims[first[s] + i];
-      if (s < 3) d[n++] = pack_desc<D::EdgeFwdSeq>(li++, w.wp_efwd, l.w, l.b, dim.N, dim.K, false);
-      else d[n++] = pack_desc<D::NodeFwdSeq>(i, w.wp_nfwd, l.w, l.b, dim.N, dim.K, false);
-    }
-  B3D_TRY(pack_images(d, n, stream));
+  B3D_TRY(pack_layer(mw, w, tr, stream));
   EdgeFwdArgs ea;
   memset(&ea, 0, sizeof(ea));
   ea.E = E; ea.src = g->src; ea.dst = g->dst; ea.x = x; ea.x0 = x0; ea.e_in = e; ea.a_in = att;
   ea.e_out = e_new; ea.fut = w.fut; ea.past = w.past; ea.wpack = w.wp_efwd;
+  if (tr) { ea.sH1 = w.sH1; ea.sH2 = w.sH2; ea.sF1 = w.sF1; ea.sP1 = w.sP1; }
   B3D_TRY(launch_rows<kNWEdge>(mp_edge_fwd_kernel<D, kNWEdge>, "mp_edge_fwd", ea, E, stream, B3D_K_EDGE_FWD));
   NodeFwdArgs na;
   memset(&na, 0, sizeof(na));
   na.N = N; na.dst_ptr = g->dst_ptr; na.dst_perm = g->dst_perm; na.src_ptr = g->src_ptr; na.src_perm = g->src_perm;
   na.past = w.past; na.fut = w.fut; na.x_out = x_new; na.wpack = w.wp_nfwd;
+  if (tr) { na.M = w.M; na.sH1 = w.nH1; na.sH2 = w.nH2; }
   B3D_TRY(launch_node_split<D>(mp_node_fwd_split_kernel<D>, "mp_node_fwd", na, N, stream, B3D_K_NODE_FWD));
+  return B3D_OK;
+}
+
+extern "C" int b3d_clr_layer_backward(const b3d_mp_weights* mw, const b3d_graph* g, const float* x, const float* x0,
+                                      const float* e, const float* att, const float* e_new, void* workspace, size_t workspace_bytes,
+                                      const float* d_x_new, const float* d_e_new, float* d_x, float* d_x0, float* d_e, float* d_att,
+                                      const b3d_mp_grads* gr, b3d_stream stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  B3D_REQUIRE(mw && g && x && x0 && e && att && e_new && workspace && gr, "b3d_clr_layer_backward: null argument");
+  const int N = g->N, E = g->E;
+  B3D_REQUIRE(N > 0 && E > 0, "b3d_clr_layer_backward: empty graph");
+  ClrLayerWs w;
+  carve_layer(w, workspace, workspace_bytes, N, E, true);
+  if (!w.ok) return fail(B3D_ERR_WORKSPACE, "b3d_clr_layer_backward: workspace %zu < %zu bytes", workspace_bytes, w.bytes);
+  // missing upstream gradients are zeros
+  if (!d_x_new) { B3D_HIP_CHECK(hipMemsetAsync(w.zero_n, 0, (size_t)N * D::DX * sizeof(float), stream)); d_x_new = w.zero_n; }
+  if (!d_e_new) { B3D_HIP_CHECK(hipMemsetAsync(w.zero_e, 0, (size_t)E * D::DE * sizeof(float), stream)); d_e_new = w.zero_e; }
+  NodeBwdArgs nb;
+  memset(&nb, 0, sizeof(nb));
+  nb.N = N; nb.dst_ptr = g->dst_ptr; nb.dst_perm = g->dst_perm; nb.src_ptr = g->src_ptr; nb.src_perm = g->src_perm;
+  nb.g_direct = d_x_new;
+  nb.sH1 = w.nH1; nb.sH2 = w.nH2; nb.dM = w.dM; nb.GdH2 = w.GnH2; nb.GdH1 = w.GnH1; nb.wpack = w.wp_nbwd;
+  B3D_TRY(launch_node_split<D>(mp_node_bwd_split_kernel<D>, "mp_node_bwd", nb, N, stream, B3D_K_NODE_BWD));
+  EdgeBwdArgs eb;
+  memset(&eb, 0, sizeof(eb));
+  eb.E = E; eb.src = g->src; eb.dst = g->dst; eb.dM = w.dM;
+  eb.de_out = d_e_new; eb.de_in = d_e ? d_e : w.de_tmp;
+  eb.sH1 = w.sH1; eb.sH2 = w.sH2; eb.sF1 = w.sF1; eb.sP1 = w.sP1;
+  eb.da_acc = d_att ? d_att : w.da_tmp; eb.da_first = 1;
+  eb.gdst = w.gdst; eb.gsrc = w.gsrc;
+  eb.GdH1 = w.GdH1; eb.GdH2 = w.GdH2; eb.Gde = w.Gde; eb.GdF1 = w.GdF1; eb.GdP1 = w.GdP1;
+  eb.wpack = w.wp_ebwd;
+  B3D_TRY(launch_rows<kNWEdge>(mp_edge_bwd_kernel<D, true, kNWEdge>, "mp_edge_bwd", eb, E, stream, B3D_K_EDGE_BWD));
+  if (d_x || d_x0) {
+    NodeGradArgsC ng{N, g->dst_ptr, g->dst_perm, g->src_ptr, g->src_perm, w.gdst, w.gsrc, d_x, d_x0};
+    hipLaunchKernelGGL(node_grad_gather_c_kernel, dim3((N + 63) / 64), dim3(256), 0, stream, ng);
+    B3D_TRY(launch_check("node_grad_gather_c_kernel"));
+  }
+  // ---- weight gradients: one streaming launch over the ten Linear layers ---------------------------------------------
+  {
+    WsLauncher wl;
+    wl.begin(w.ws_table, kLayerTableCap, w.ws_task_job, kLayerTaskCap, stream);
+    hipLaunchKernelGGL(iota_kernel, dim3(((E > N ? E : N) + 255) / 256), dim3(256), 0, stream, w.iota, E > N ? E : N);
+    B3D_TRY(launch_check("iota_kernel"));
+    B3D_HIP_CHECK(hipMemsetAsync(w.zrow, 0, 256 * sizeof(float), stream));
+    const int* iota = w.iota;
+    const int* src = g->src;
+    const int* dst = g->dst;
+    struct Col { const float* p; const int* idx; int stride; int width; };
+    auto add = [&](int ll, long rows, const float* gp, const int* gidx, int gstride, int gcol0, const Col* cols, int ncols) {
+      LinSlab& ls = w.lin[ll];
+      ls.used = true;
+      for (int g0 = 0; g0 < ls.N; g0 += 64) {
+        const int gw = (ls.N - g0 >= 64) ? 64 : ls.N - g0;
+        int wcol = 0;
+        bool first = true;
+        for (int ci = 0; ci < ncols; ++ci) {
+          for (int c0 = 0; c0 < cols[ci].width;) {
+            int cw = cols[ci].width - c0;
+            cw = (cw == 128 || cw < 96) ? 64 : 96;
+            WsJob jb;
+            memset(&jb, 0, sizeof(jb));
+            jb.g.ptr = gp; jb.g.idx = gidx ? gidx : iota; jb.g.vstride = 0; jb.g.stride = gstride; jb.g.col0 = gcol0 + g0;
+            jb.act[0].ptr = cols[ci].p; jb.act[0].idx = cols[ci].idx ? cols[ci].idx : iota; jb.act[0].vstride = 0;
+            jb.act[0].stride = cols[ci].stride; jb.act[0].col0 = c0;
+            jb.act[1] = jb.act[0]; jb.act[2] = jb.act[0];
+            jb.wcol[0] = wcol + c0; jb.wrow = g0; jb.write_bias = first ? 1 : 0;
+            first = false;
+            jb.shape = (gw == 64) ? (cw == 96 ? WS_64_96 : WS_64_64) : WS_32_64;
+            jb.rows = (int)rows; jb.nvar = 1; jb.rows_per_task = kStreamRowsPerTask;
+            jb.NP = ls.NP; jb.KP = ls.KP; jb.slab = ls.slab;
+            wl.add(jb);
+            c0 += cw;
+          }
+          wcol += cols[ci].width;
+        }
+      }
+    };
+    Col ceu[4] = {{x, dst, D::DX, 96}, {x, src, D::DX, 96}, {e, nullptr, D::DE, 64}, {att, nullptr, 64, 64}};
+    add(LL_EU0, E, w.GdH1, nullptr, D::EH1, 0, ceu, 4);
+    Col c1[1] = {{w.sH1, nullptr, D::EH1, 256}};
+    add(LL_EU1, E, w.GdH2, nullptr, D::EH2, 0, c1, 1);
+    Col c2[1] = {{w.sH2, nullptr, D::EH2, 128}};
+    add(LL_EU2, E, w.Gde, nullptr, D::DE, 0, c2, 1);
+    Col cp[3] = {{x, src, D::DX, 96}, {e_new, nullptr, D::DE, 64}, {x0, src, D::DX, 96}};
+    add(LL_PA0, E, w.GdP1, nullptr, D::MH, 0, cp, 3);
+    Col cp1[1] = {{w.sP1, nullptr, D::MH, 192}};
+    add(LL_PA1, E, w.dM, dst, D::NIN, 0, cp1, 1);
+    Col cf[3] = {{x, dst, D::DX, 96}, {e_new, nullptr, D::DE, 64}, {x0, dst, D::DX, 96}};
+    add(LL_FU0, E, w.GdF1, nullptr, D::MH, 0, cf, 3);
+    Col cf1[1] = {{w.sF1, nullptr, D::MH, 192}};
+    add(LL_FU1, E, w.dM, src, D::NIN, D::DM, cf1, 1);
+    Col cn0[1] = {{w.M, nullptr, D::NIN, 256}};
+    add(LL_CF0, N, w.GnH1, nullptr, D::NH1, 0, cn0, 1);
+    Col cn1[1] = {{w.nH1, nullptr, D::NH1, 192}};
+    add(LL_CF1, N, w.GnH2, nullptr, D::NH2, 0, cn1, 1);
+    Col cn2[1] = {{w.nH2, nullptr, D::NH2, 128}};
+    add(LL_CF2, N, d_x_new, nullptr, D::DX, 0, cn2, 1);
+    wl.launch(w.zrow, B3D_K_WGRAD_EDGE);
+    B3D_REQUIRE(wl.status == 0, "b3d_clr_layer_backward: job table overflow (%d jobs, %d tasks)", wl.njobs, wl.total_tasks);
+    B3D_TRY(launch_check("wstream_kernel"));
+  }
+  RedArgs ra;
+  ra.nentries = 0;
+  const b3d_linear_grad* groups[] = {gr->edge_update, gr->create_past_msgs, gr->create_future_msgs, gr->combine_future_past};
+  const int firstl[] = {LL_EU0, LL_PA0, LL_FU0, LL_CF0}, cnt[] = {3, 2, 2, 3};
+  for (int gi = 0; gi < 4; ++gi)
+    for (int i = 0; i < cnt[gi]; ++i) ra.e[ra.nentries++] = red_entry(w.lin[firstl[gi] + i], groups[gi][i].w, groups[gi][i].b);
+  B3D_TRY(launch_reduce(ra, stream));
   return B3D_OK;
 }

@@ -3,8 +3,8 @@ clr_att_gnn.py:227-356): ``(x, edge_index, edge_attr, initial_x[, att_edge_attr]
 
 The models call the same kernels through their whole-forward entry points; this module serves code
 that drives a layer directly (as the reference's ``GNN.forward`` does, pose_gnn.py:83).
-Poses-only widths: forward and backward (``b3d_pose_layer_forward`` / ``_backward``).
-Camera+LiDAR+radar widths: forward only (``b3d_clr_layer_forward``); asking for gradients raises.
+Both width sets have forward and backward (``b3d_pose_layer_*`` / ``b3d_clr_layer_*``); the camera+LiDAR+radar layer
+also returns the gradient of ``att_edge_attr``.
 """
 from __future__ import annotations
 
@@ -60,24 +60,34 @@ class _MPLayerFunction(torch.autograd.Function):
                                                   flags, ws.data_ptr(), nbytes, x_new.data_ptr(), e_new.data_ptr(), stream),
                        "b3d_pose_layer_forward")
         else:
-            nbytes = lib.b3d_clr_layer_workspace_bytes(N, E)
+            flags = B3D_FLAG_TRAINING if training else 0
+            nbytes = lib.b3d_clr_layer_workspace_bytes(N, E, flags)
             ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             _lib.check(lib.b3d_clr_layer_forward(C.byref(w), C.byref(graph.c), x.data_ptr(), x0.data_ptr(), e.data_ptr(),
-                                                 att.data_ptr(), ws.data_ptr(), nbytes, x_new.data_ptr(), e_new.data_ptr(),
+                                                 att.data_ptr(), flags, ws.data_ptr(), nbytes, x_new.data_ptr(), e_new.data_ptr(),
                                                  stream), "b3d_clr_layer_forward")
         ctx.set_materialize_grads(False)
         ctx.kind, ctx.graph, ctx.training, ctx.ws, ctx.nbytes = kind, graph, training, ws, nbytes
         # save_for_backward: no reference cycle through the output e_new, and in-place edits of x / e between forward
         # and backward are detected by autograd's version counters
-        ctx.save_for_backward(x, x0, e, e_new, *params)
+        ctx.has_att = att is not None
+        if att is not None:
+            ctx.save_for_backward(x, x0, e, e_new, att, *params)
+        else:
+            ctx.save_for_backward(x, x0, e, e_new, *params)
         return x_new, e_new
 
     @staticmethod
     def backward(ctx, d_x_new, d_e_new):
-        if ctx.kind != "p" or not ctx.training:
+        if not ctx.training:
             raise RuntimeError("backward through a CausalMessagePassing layer whose forward kept no state")
         lib = _lib.load()
-        x, x0, e, e_new, *params = ctx.saved_tensors
+        if ctx.has_att:
+            x, x0, e, e_new, att, *params = ctx.saved_tensors
+        else:
+            x, x0, e, e_new, *params = ctx.saved_tensors
+            att = None
+        params = [p.detach() for p in params]
         dev = x.device
         if d_x_new is not None:
             d_x_new = d_x_new.contiguous().float()
@@ -87,11 +97,18 @@ class _MPLayerFunction(torch.autograd.Function):
         grads = [torch.empty_like(p) for p in params]
         w = _mp_struct(params)
         g = _mp_struct(grads)
-        _lib.check(lib.b3d_pose_layer_backward(C.byref(w), C.byref(ctx.graph.c), x.data_ptr(), x0.data_ptr(), e.data_ptr(),
-                                               e_new.data_ptr(), ctx.ws.data_ptr(), ctx.nbytes, _lib.ptr(d_x_new),
-                                               _lib.ptr(d_e_new), d_x.data_ptr(), d_x0.data_ptr(), d_e.data_ptr(),
-                                               C.byref(g), _lib.current_stream(dev)), "b3d_pose_layer_backward")
-        return (None, None, None, d_x, d_x0, d_e, None) + tuple(grads)
+        if ctx.kind == "p":
+            _lib.check(lib.b3d_pose_layer_backward(C.byref(w), C.byref(ctx.graph.c), x.data_ptr(), x0.data_ptr(), e.data_ptr(),
+                                                   e_new.data_ptr(), ctx.ws.data_ptr(), ctx.nbytes, _lib.ptr(d_x_new),
+                                                   _lib.ptr(d_e_new), d_x.data_ptr(), d_x0.data_ptr(), d_e.data_ptr(),
+                                                   C.byref(g), _lib.current_stream(dev)), "b3d_pose_layer_backward")
+            return (None, None, None, d_x, d_x0, d_e, None) + tuple(grads)
+        d_att = torch.empty_like(att)
+        _lib.check(lib.b3d_clr_layer_backward(C.byref(w), C.byref(ctx.graph.c), x.data_ptr(), x0.data_ptr(), e.data_ptr(),
+                                              att.data_ptr(), e_new.data_ptr(), ctx.ws.data_ptr(), ctx.nbytes, _lib.ptr(d_x_new),
+                                              _lib.ptr(d_e_new), d_x.data_ptr(), d_x0.data_ptr(), d_e.data_ptr(), d_att.data_ptr(),
+                                              C.byref(g), _lib.current_stream(dev)), "b3d_clr_layer_backward")
+        return (None, None, None, d_x, d_x0, d_e, d_att) + tuple(grads)
 
 
 def mp_layer_forward(module, kind: str, x: torch.Tensor, edge_index: torch.Tensor, edge_attr: torch.Tensor,
@@ -116,9 +133,5 @@ def mp_layer_forward(module, kind: str, x: torch.Tensor, edge_index: torch.Tenso
         _lib.require_cuda(p, "parameter", torch.float32)
     inputs = [x, initial_x, edge_attr] + ([att_edge_attr] if att_edge_attr is not None else [])
     training = torch.is_grad_enabled() and any(t.requires_grad for t in inputs + params)
-    if training and kind == "clr":
-        raise NotImplementedError("the layer-level backward is built for the poses-only widths only; train the "
-                                  "camera+LiDAR+radar model through GNN.forward (b3d_clr_forward/backward), or wrap "
-                                  "this call in torch.no_grad()")
     graph = _lib.Graph(edge_index.contiguous(), n)
     return _MPLayerFunction.apply(kind, graph, training, x, initial_x, edge_attr, att_edge_attr, *params)

@@ -42,8 +42,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md, v_mfma_f32_16x16x4_f32 (= fp32 vector peak)
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 MFMA (MI355X_MICROARCH.md); a bf16x6 product costs six bf16 MFMA MACs
+PEAK_BF16X6_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0     # = 416.7 fp32-equivalent TFLOP/s
 PEAK_HBM_GBS = 8000.0
-EMPTY_KERNEL_US = 1.3             # rocprofv3 duration of b3d_empty_kernel (profiles/r02_*_kernel_stats.csv)
 BOUND = {"mp_edge_fwd": "mfma", "mp_edge_bwd": "mfma", "wgrad_edge": "hbm", "mp_node_fwd": "hbm", "mp_node_bwd": "hbm",
          "att_fwd": "mfma", "att_bwd": "mfma", "point_feat": "mfma"}
 
@@ -67,19 +68,21 @@ class PoseWork:
 
     @classmethod
     def families(cls, n, e, depth, **_):
-        alg = {"mp_edge_fwd": 2.0 * (cls.MAC_EU + cls.MAC_MSG) * e, "mp_edge_bwd": 2.0 * (cls.MAC_EU + cls.MAC_MSG) * e,
+        """Per STEP (see ClrWork.families); every layer of this model runs on the exact fp32 MFMA."""
+        alg = {"mp_edge_fwd": 2.0 * (cls.MAC_EU + cls.MAC_MSG) * e * depth, "mp_edge_bwd": 2.0 * (cls.MAC_EU + cls.MAC_MSG) * e * (depth - 1),
                "wgrad_edge": 2.0 * (e * (cls.MAC_EU * depth + cls.MAC_MSG * (depth - 1)) + n * cls.MAC_NODE * (depth - 1)),
-               "mp_node_fwd": 2.0 * cls.MAC_NODE * n, "mp_node_bwd": 2.0 * cls.MAC_NODE * n}
-        exe = {"mp_edge_fwd": 2.0 * (cls.X_EU + cls.X_MSG) * e, "mp_edge_bwd": 2.0 * (cls.X_EU + cls.X_MSG) * e,
+               "mp_node_fwd": 2.0 * cls.MAC_NODE * n * depth, "mp_node_bwd": 2.0 * cls.MAC_NODE * n * (depth - 1)}
+        exe = {"mp_edge_fwd": 2.0 * (cls.X_EU + cls.X_MSG) * e * depth, "mp_edge_bwd": 2.0 * (cls.X_EU + cls.X_MSG) * e * (depth - 1),
                "wgrad_edge": 2.0 * (e * (cls.X_EU * depth + cls.X_MSG * (depth - 1))
                                     + n * (cls.MAC_NODE * (depth - 1) + 2 * 96 * 48 * depth + 4 * 96 * 48 * (depth - 1))),
-               "mp_node_fwd": 2.0 * (cls.MAC_NODE + cls.X_NODE_TAB) * n, "mp_node_bwd": 2.0 * (cls.MAC_NODE + cls.X_NODE_GP) * n}
-        byts = {"mp_edge_fwd": e * (8 + 4 * (32 + 32 + 64 + 64 + 352)),      # idx, e in/out, fut, past, saved hidden
-                "mp_edge_bwd": e * (8 + 4 * (32 + 32 + 352 + 192 + 384)),    # de out/in, saved, per-edge node grads, G
+               "mp_node_fwd": 2.0 * (cls.MAC_NODE * depth + cls.X_NODE_TAB * (depth - 1)) * n,
+               "mp_node_bwd": 2.0 * (cls.MAC_NODE + cls.X_NODE_GP) * n * (depth - 1)}
+        byts = {"mp_edge_fwd": depth * e * (8 + 4 * (32 + 32 + 64 + 64 + 352)),      # idx, e in/out, fut, past, saved hidden
+                "mp_edge_bwd": (depth - 1) * e * (8 + 4 * (32 + 32 + 352 + 192 + 384)),    # de out/in, saved, per-edge node grads, G
                 "wgrad_edge": e * 4 * ((192 + 160 + 64) * depth + (192 + 128 + 192 + 32) * (depth - 1)),
-                "mp_node_fwd": e * 4 * 128 + n * 4 * (128 + 48 + 160),
-                "mp_node_bwd": e * 4 * 192 + n * 4 * (128 + 48 + 48 + 160 + 208)}
-        return alg, exe, byts
+                "mp_node_fwd": depth * (e * 4 * 128 + n * 4 * (128 + 48 + 160)),
+                "mp_node_bwd": (depth - 1) * (e * 4 * 192 + n * 4 * (128 + 48 + 48 + 160 + 208))}
+        return alg, exe, byts, {}
 
 
 class ClrWork:
@@ -108,32 +111,39 @@ class ClrWork:
 
     @classmethod
     def families(cls, n, e, depth, hoist_mp=False, hoist_att=False, nl=0, nr=0, **_):
+        """Per STEP: algorithmic FLOPs (the reference's per-edge arithmetic), executed FLOPs (what the
+        kernels multiply: node columns of hoisted first layers are per-node work), algorithmic bytes, and the fraction of
+        the executed MACs that run as bf16x6 (layers with 64..256 inputs in multiples of 32)."""
         eu, msg = (cls.X_EU, cls.X_MSG) if hoist_mp else (cls.MAC_EU, cls.MAC_MSG)
         att = cls.X_ATT if hoist_att else cls.MAC_ATT
         tab = cls.X_NODE_TAB if hoist_mp else 0
         gp = cls.X_NODE_GP if hoist_mp else 0
-        alg = {"mp_edge_fwd": 2.0 * (cls.MAC_EU + cls.MAC_MSG) * e, "mp_edge_bwd": 2.0 * (cls.MAC_EU + cls.MAC_MSG) * e,
-               "wgrad_edge": 2.0 * (e * (cls.MAC_EU * depth + cls.MAC_MSG * (depth - 1) + cls.MAC_ATT)
-                                    + n * cls.MAC_NODE * (depth - 1)),
-               "mp_node_fwd": 2.0 * cls.MAC_NODE * n, "mp_node_bwd": 2.0 * cls.MAC_NODE * n,
-               "att_fwd": 2.0 * cls.MAC_ATT * e / 5.0, "att_bwd": 2.0 * cls.MAC_ATT * e / 5.0,      # five launches each
-               "point_feat": 2.0 * (2 * cls.MAC_POINT_L * nl + cls.MAC_POINT_R * nr) / 3.0}       # three launches
-        exe = {"mp_edge_fwd": 2.0 * (eu + msg) * e, "mp_edge_bwd": 2.0 * (eu + msg) * e,
-               "wgrad_edge": 2.0 * (e * (eu * depth + msg * (depth - 1) + att) + n * (cls.MAC_NODE + tab) * (depth - 1)
-                                    + (n * cls.X_ATT_NODE if hoist_att else 0)),
-               "mp_node_fwd": 2.0 * (cls.MAC_NODE + tab) * n, "mp_node_bwd": 2.0 * (cls.MAC_NODE + gp) * n,
-               "att_fwd": 2.0 * att * e / 5.0, "att_bwd": 2.0 * att * e / 5.0,
+        att_node = cls.X_ATT_NODE if hoist_att else 0
+        alg = {"mp_edge_fwd": 2.0 * (cls.MAC_EU + cls.MAC_MSG) * e * depth,
+               "mp_edge_bwd": 2.0 * (cls.MAC_EU + cls.MAC_MSG) * e * (depth - 1),          # the last layer's message stacks carry no gradient: "other"
+               "wgrad_edge": 2.0 * (e * (cls.MAC_EU * depth + cls.MAC_MSG * (depth - 1) + cls.MAC_ATT) + n * cls.MAC_NODE * (depth - 1)),
+               "mp_node_fwd": 2.0 * cls.MAC_NODE * n * depth, "mp_node_bwd": 2.0 * cls.MAC_NODE * n * (depth - 1),
+               "att_fwd": 2.0 * cls.MAC_ATT * e, "att_bwd": 2.0 * cls.MAC_ATT * e,
+               "point_feat": 2.0 * (2 * cls.MAC_POINT_L * nl + cls.MAC_POINT_R * nr)}
+        exe = {"mp_edge_fwd": 2.0 * (eu + msg) * e * depth, "mp_edge_bwd": 2.0 * (eu + msg) * e * (depth - 1),
+               "wgrad_edge": 2.0 * (e * (eu * depth + msg * (depth - 1) + att) + n * ((cls.MAC_NODE + tab) * (depth - 1) + att_node)),
+               "mp_node_fwd": 2.0 * (cls.MAC_NODE * depth + tab * (depth - 1)) * n, "mp_node_bwd": 2.0 * (cls.MAC_NODE * (depth - 1) + gp * depth) * n,
+               "att_fwd": 2.0 * (att * e + att_node * n), "att_bwd": 2.0 * (att * e + att_node * n),
                "point_feat": alg["point_feat"]}
         sav = 256 + 128 + 192 + 192
-        byts = {"mp_edge_fwd": e * (8 + 4 * (64 + 64 + 64 + 2 * 128 + sav)),
-                "mp_edge_bwd": e * (8 + 4 * (64 + 64 + 2 * 64 + sav + (256 + 128 + 64 + 192 + 192) + (0 if hoist_mp else 384))),
+        byts = {"mp_edge_fwd": depth * e * (8 + 4 * (64 + 64 + 64 + 2 * 128 + sav)),
+                "mp_edge_bwd": (depth - 1) * e * (8 + 4 * (64 + 64 + 2 * 64 + sav + (256 + 128 + 64 + 192 + 192) + (0 if hoist_mp else 384))),
                 "wgrad_edge": e * 4 * ((256 + 128 + 64 + 256 + 128 + 128) * depth + (2 * 192 + 2 * 128 + 2 * 192 + 64) * (depth - 1)
                                        + 2 * (512 + 384 + 256 + 128) + 64 + 64),
-                "mp_node_fwd": e * 4 * 256 + n * 4 * (256 + 96 + 320), "mp_node_bwd": e * 4 * 384 + n * 4 * (256 + 96 + 96 + 320 + 416),
-                "att_fwd": e * 4 * (64 + 2 * (512 + 384 + 256 + 128) + 64) / 5.0,
-                "att_bwd": e * 4 * (64 + 3 * (512 + 384 + 256 + 128) + 640) / 5.0,
-                "point_feat": 4.0 * (2 * nl * (3 * 128 + 4 * 1024) + nr * (4 * 64 + 4 * 1024)) / 3.0}
-        return alg, exe, byts
+                "mp_node_fwd": depth * (e * 4 * 256 + n * 4 * (256 + 96 + 320)),
+                "mp_node_bwd": (depth - 1) * (e * 4 * 384 + n * 4 * (256 + 96 + 96 + 320 + 416)),
+                "att_fwd": e * 4 * (64 + 2 * (512 + 384 + 256 + 128) + 64),
+                "att_bwd": e * 4 * (64 + 3 * (512 + 384 + 256 + 128) + 640),
+                "point_feat": 4.0 * (2 * nl * (3 * 128 + 4 * 1024) + nr * (4 * 64 + 4 * 1024))}
+        bf = {"mp_edge_fwd": 1.0 if hoist_mp else 0.0, "mp_edge_bwd": 1.0 if hoist_mp else 0.0, "point_feat": 0.999,
+              "att_fwd": (64 * 512 + 256 * 128 + 128 * 64) / cls.X_ATT if hoist_att else 0.06,
+              "att_bwd": (64 * 128 + 128 * 256 + 256 * 384) / cls.X_ATT if hoist_att else 0.2}
+        return alg, exe, byts, bf
 
 
 # ---- workloads -----------------------------------------------------------------------------------------------------
@@ -367,26 +377,37 @@ def measure(wl: Workload, args, world, dist, steps, warmup, ramp_ms, use_graph):
     torch.cuda.synchronize()
     fam = _lib.prof_read()
     _lib.prof_enable(False)
-    # what an event pair adds to the kernel it brackets: a pair around an empty kernel minus that kernel's own duration
-    pair_us = max(_lib.prof_pair_overhead_us(torch.cuda.current_stream(dev).cuda_stream) - EMPTY_KERNEL_US, 0.0)
+    # what an event pair adds to the kernel it brackets: half of a pair around an empty kernel (the other half is that
+    # kernel's own dispatch-to-completion; calibrated against rocprofv3 durations of the same launches: 29.5 us by events
+    # vs 24.1 us by rocprofv3 with an 11.3 us empty pair, profiles/r02_a_*)
+    pair_us = 0.5 * _lib.prof_pair_overhead_us(torch.cuda.current_stream(dev).cuda_stream)
     my_edges = sum(wl.edges[(warmup + i) % pool_n] for i in range(steps))
     return {"dt": dt, "edges": my_edges, "t_enqueue": t_enqueue, "fam_all": fam_all, "fam": fam, "dom": dom,
             "graphs": graphs is not None, "graph_note": graph_note, "ramp_steps": ramp_steps, "pair_us": pair_us}
 
 
-def family_table(famd, steps, alg, exe, byts, pair_us=0.0):
+def mfma_peak(bf_frac):
+    """fp32-equivalent MFMA peak of a kernel that runs the fraction bf_frac of its MACs as bf16x6 and the rest on the
+    exact fp32 MFMA: time adds, so the peaks combine harmonically."""
+    return 1.0 / (bf_frac / PEAK_BF16X6_TFLOPS + (1.0 - bf_frac) / PEAK_FP32_MFMA_TFLOPS)
+
+
+def family_table(famd, steps, alg, exe, byts, bf, pair_us=0.0):
     out = {}
     for name, (ms, n) in famd.items():
         if n == 0 or steps == 0:
             continue
         avg_ev = 1e3 * ms / n
         avg_us = max(avg_ev - pair_us, 1e-3)
-        k = {"launches_per_step": round(n / steps, 2), "avg_us": round(avg_us, 2), "us_per_step": round(avg_us * n / steps, 1)}
+        us_step = avg_us * n / steps
+        k = {"launches_per_step": round(n / steps, 2), "avg_us": round(avg_us, 2), "us_per_step": round(us_step, 1)}
         if name in alg:
             k["bound"] = BOUND[name]
-            k["executed_tflops"] = round(exe[name] / (avg_us * 1e-6) / 1e12, 2)
-            k["algorithmic_tflops"] = round(alg[name] / (avg_us * 1e-6) / 1e12, 2)
-            k["algorithmic_gbs"] = round(byts[name] / (avg_us * 1e-6) / 1e9, 1)
+            k["executed_tflops"] = round(exe[name] / (us_step * 1e-6) / 1e12, 2)        # fp32-equivalent
+            k["algorithmic_tflops"] = round(alg[name] / (us_step * 1e-6) / 1e12, 2)
+            k["algorithmic_gbs"] = round(byts[name] / (us_step * 1e-6) / 1e9, 1)
+            k["bf16x6_fraction_of_macs"] = round(bf.get(name, 0.0), 3)
+            k["mfma_peak_tflops"] = round(mfma_peak(bf.get(name, 0.0)), 1)
         out[name] = k
     return out
 
@@ -471,30 +492,35 @@ def main():
         kw = dict(n=wl.n_nodes, e=e_avg, depth=depth)
         if args.model == "clr":
             kw.update(hoist_mp=bool(hoist.get("clr_hoist_mp")), hoist_att=bool(hoist.get("clr_hoist_att")), nl=wl.nl, nr=wl.nr)
-        alg, exe, byts = wl.work.families(**kw)
-        kernels_warmup = family_table(m["fam_all"], args.warmup, alg, exe, byts, m["pair_us"]) if m["fam_all"] else {}
-        kernels = family_table(m["fam"], args.steps, alg, exe, byts, m["pair_us"])
+        alg, exe, byts, bf = wl.work.families(**kw)
+        kernels_warmup = family_table(m["fam_all"], args.warmup, alg, exe, byts, bf, m["pair_us"]) if m["fam_all"] else {}
+        kernels = family_table(m["fam"], args.steps, alg, exe, byts, bf, m["pair_us"])
         dom = m["dom"] or max((k for k in kernels if k in alg), key=lambda k: kernels[k]["us_per_step"])
         kd = kernels[dom]
         workload_key = f"{args.model}:{args.encoders if args.model == 'clr' else 'na'}:knn{int(not args.no_dead_knn)}"
         traffic = load_traffic(workload_key) or {}
+        lps = kd["launches_per_step"]
         if BOUND[dom] == "mfma":
-            achieved, peak, unit = kd["executed_tflops"], PEAK_FP32_MFMA_TFLOPS, "TFLOP/s"
+            achieved, peak, unit = kd["executed_tflops"], kd["mfma_peak_tflops"], "TFLOP/s"
         else:
             achieved, peak, unit = kd["algorithmic_gbs"], PEAK_HBM_GBS, "GB/s"
         roofline = {"kernel": dom, "bound": BOUND[dom], "achieved": achieved, "peak": peak, "unit": unit,
                     "frac": round(achieved / peak, 4), "traffic": traffic.get(dom),
                     "avg_launch_us": kd["avg_us"], "event_pair_overhead_us_subtracted": round(m["pair_us"], 2),
-                    "launches_per_step": kd["launches_per_step"],
-                    "executed_flops_per_launch": exe[dom], "algorithmic_flops_per_launch": alg[dom],
-                    "algorithmic_bytes_per_launch": byts[dom],
+                    "launches_per_step": lps,
+                    "executed_flops_per_launch": exe[dom] / lps, "algorithmic_flops_per_launch": alg[dom] / lps,
+                    "algorithmic_bytes_per_launch": byts[dom] / lps,
+                    "bf16x6_fraction_of_macs": kd["bf16x6_fraction_of_macs"],
                     "algorithmic_tflops": kd["algorithmic_tflops"],
-                    "algorithmic_frac_of_fp32_peak": round(kd["algorithmic_tflops"] / PEAK_FP32_MFMA_TFLOPS, 4),
-                    "note": "frac = EXECUTED FLOPs of the named kernel / its launch duration / peak for mfma-bound kernels "
-                            "(node columns of a Linear over a concatenation that are evaluated per node are not counted as "
-                            "edge-kernel work); algorithmic_* count the reference's per-edge FLOPs (SURVEY.md 8d) over the same "
-                            "duration.  Durations: HIP event pairs on the launch stream around each launch of this family in "
-                            "an eager pass of the same K steps, minus the measured cost of an empty event pair."}
+                    "executed_frac_of_fp32_mfma_peak": round(kd["executed_tflops"] / PEAK_FP32_MFMA_TFLOPS, 4),
+                    "note": "mfma-bound kernels: achieved = EXECUTED fp32-equivalent FLOPs of the named family per step / its device time "
+                            "per step (node columns of a Linear over a concatenation that are evaluated per node are not edge-kernel "
+                            "work); peak = the MFMA peak of the instructions it runs: 157.3 TFLOP/s for exact-fp32 MFMA layers, "
+                            "2500 / 6 = 416.7 fp32-equivalent TFLOP/s for bf16x6 layers (six bf16 MFMA MACs per fp32 product), "
+                            "combined harmonically by the kernel's share of each.  algorithmic_* count the reference's per-edge FLOPs "
+                            "(SURVEY.md 8d) over the same time.  Durations: HIP event pairs on the launch stream around each launch "
+                            "of this family in an eager pass of the same K steps, minus half the cost of a pair around an empty kernel "
+                            "(calibrated against rocprofv3 durations, profiles/)."}
         ms_step = 1e3 * dt / args.steps
         sf_kw = dict(f_l=wl.nl / wl.n_nodes, f_r=wl.nr / wl.n_nodes) if args.model == "clr" else {}
         step_bytes = wl.work.step_bytes(wl.n_nodes, e_avg)

@@ -216,12 +216,17 @@ int b3d_pose_layer_backward(const b3d_mp_weights* weights, const b3d_graph* g, c
                             const float* e, const float* e_new, void* workspace, size_t workspace_bytes,
                             const float* d_x_new, const float* d_e_new, float* d_x, float* d_x0, float* d_e,
                             const b3d_mp_grads* grads /* host struct of device pointers */, b3d_stream stream);
-/* Camera+LiDAR+radar widths (DX 96, DE 64, att_edge_attr [E,64]): forward only -- training of that
- * model goes through b3d_clr_forward / b3d_clr_backward. */
-size_t b3d_clr_layer_workspace_bytes(int32_t N, int32_t E);
+/* Camera+LiDAR+radar widths (DX 96, DE 64, att_edge_attr [E,64]): the same pair; backward also returns d att_edge_attr
+ * (NULL = not wanted).  The model entry points (b3d_clr_forward / _backward) run the same arithmetic over all layers with
+ * the first layers' node columns evaluated per node. */
+size_t b3d_clr_layer_workspace_bytes(int32_t N, int32_t E, uint32_t flags);
 int b3d_clr_layer_forward(const b3d_mp_weights* weights, const b3d_graph* g, const float* x, const float* x0,
-                          const float* e, const float* att_edge_attr, void* workspace, size_t workspace_bytes,
+                          const float* e, const float* att_edge_attr, uint32_t flags, void* workspace, size_t workspace_bytes,
                           float* x_new, float* e_new, b3d_stream stream);
+int b3d_clr_layer_backward(const b3d_mp_weights* weights, const b3d_graph* g, const float* x, const float* x0,
+                           const float* e, const float* att_edge_attr, const float* e_new, void* workspace,
+                           size_t workspace_bytes, const float* d_x_new, const float* d_e_new, float* d_x, float* d_x0,
+                           float* d_e, float* d_att_edge_attr, const b3d_mp_grads* grads, b3d_stream stream);
 
 /* Same update with the step counter on the device (`*step_dev` = number of steps taken so far, incremented by
  * the call): for training steps captured into a hipGraph, where a by-value `step` would be replayed. */
