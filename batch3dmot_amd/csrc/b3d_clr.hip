@@ -109,7 +109,9 @@ struct Ws {
 };
 constexpr int kTableCap = 320, kTaskCap = 32768;
 
-static bool is_streamed(int lin) { return lin >= AT0; }
+constexpr int kStreamRowsPerTaskFc = 128;     // modality heads: a few thousand rows
+static bool is_fc(int lin) { return lin >= FL0 && lin <= FR2; }
+static bool is_streamed(int lin, bool hoist) { return lin >= AT0 || (hoist && is_fc(lin)); }   // fc heads: streamed with the hoisted plan
 
 static void carve(Ws& w, void* ws, size_t ws_bytes, int N, int E, int nl, int nr, int depth, uint32_t flags) {
   Carver c(ws, ws_bytes);
@@ -238,8 +240,8 @@ static void carve(Ws& w, void* ws, size_t ws_bytes, int N, int E, int nl, int nr
       LinSlab& ls = w.lin[i];
       ls.N = kDims[i].N; ls.K = kDims[i].K; ls.NP = pad16(ls.N); ls.KP = pad16(ls.K);
       const long rows = kRowKind[i] == 0 ? E : kRowKind[i] == 1 ? N : kRowKind[i] == 2 ? nl : nr;
-      if (is_streamed(i)) {
-        const int rpt = (i <= AT4) ? kStreamRowsPerTaskAtt : kStreamRowsPerTask;
+      if (is_streamed(i, w.hoist)) {
+        const int rpt = is_fc(i) ? kStreamRowsPerTaskFc : (i <= AT4) ? kStreamRowsPerTaskAtt : kStreamRowsPerTask;
         ls.nchunks = (int)((rows + rpt - 1) / rpt);
         if (ls.nchunks < 1) ls.nchunks = 1;
       } else {
@@ -855,8 +857,10 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
     a.rows = nl; a.in = In{w.dxs, XS, 96, d_x_sens, XS, 96, in->lidar_nodes};
     a.gtop = w.gfl_top; a.act[0] = w.fl_a1; a.gsave[0] = w.gfl1; a.wpack = w.wp_flT;
     B3D_TRY(launch_rows<kNWNode>(chain_bwd_kernel<SeqFLT, In, StoreNone, kNWNode>, "fc_lidar_encoder_bwd", a, nl, stream, B3D_K_OTHER, chain_lds<SeqFLT>()));
+    if (!w.hoist) {
     WgJob j1 = make_job(w.lin[FL1], nl, seg(w.gfl_top, nullptr, 128, 0, 128)); add_act(j1, seg(w.fl_a1, nullptr, 192, 0, 192)); fc.jobs[fc.njobs++] = j1;
     WgJob j0 = make_job(w.lin[FL0], nl, seg(w.gfl1, nullptr, 192, 0, 192)); add_act(j0, seg(in->pointnet_out, nullptr, 256, 0, 256)); fc.jobs[fc.njobs++] = j0;
+    }
   }
   if (nr > 0) {  // fc_radar_encoder
     using In = LoadAdd2<4>;
@@ -865,9 +869,11 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
     a.rows = nr; a.in = In{w.dxs, XS, 224, d_x_sens, XS, 224, in->radar_nodes};
     a.gtop = w.gfr_top; a.act[0] = w.fr_a2; a.act[1] = w.fr_a1; a.gsave[0] = w.gfr2; a.gsave[1] = w.gfr1; a.wpack = w.wp_frT;
     B3D_TRY(launch_rows<kNWNode>(chain_bwd_kernel<SeqFRT, In, StoreNone, kNWNode>, "fc_radar_encoder_bwd", a, nr, stream, B3D_K_OTHER, chain_lds<SeqFRT>()));
+    if (!w.hoist) {
     WgJob j2 = make_job(w.lin[FR2], nr, seg(w.gfr_top, nullptr, 64, 0, 64)); add_act(j2, seg(w.fr_a2, nullptr, 128, 0, 128)); fc.jobs[fc.njobs++] = j2;
     WgJob j1 = make_job(w.lin[FR1], nr, seg(w.gfr2, nullptr, 128, 0, 128)); add_act(j1, seg(w.fr_a1, nullptr, 192, 0, 192)); fc.jobs[fc.njobs++] = j1;
     WgJob j0 = make_job(w.lin[FR0], nr, seg(w.gfr1, nullptr, 192, 0, 192)); add_act(j0, seg(in->radarnet_out, nullptr, 256, 0, 256)); fc.jobs[fc.njobs++] = j0;
+    }
   }
 
   // ---- encoders ----------------------------------------------------------------------------------------
@@ -1005,6 +1011,23 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
       Col cf1[1] = {{w.sF1[0], nullptr, (long)eLm, D::MH, 0, 192}};
       add_matrix(FU1, E, depth - 1, rp, w.dM, src, nLm, D::NIN, D::DM, cf1, 1);
     }
+    }
+    if (w.hoist) {  // modality heads on the rows that carry the modality (the LDS-staged kernel spilled ~3,000 VGPRs at these widths)
+      const int rf = kStreamRowsPerTaskFc;
+      if (nl > 0) {
+        Col a1[1] = {{w.fl_a1, nullptr, 0, 192, 0, 192}};
+        add_matrix(FL1, nl, 1, rf, w.gfl_top, nullptr, 0, 128, 0, a1, 1);
+        Col a0[1] = {{in->pointnet_out, nullptr, 0, 256, 0, 256}};
+        add_matrix(FL0, nl, 1, rf, w.gfl1, nullptr, 0, 192, 0, a0, 1);
+      }
+      if (nr > 0) {
+        Col a2[1] = {{w.fr_a2, nullptr, 0, 128, 0, 128}};
+        add_matrix(FR2, nr, 1, rf, w.gfr_top, nullptr, 0, 64, 0, a2, 1);
+        Col a1[1] = {{w.fr_a1, nullptr, 0, 192, 0, 192}};
+        add_matrix(FR1, nr, 1, rf, w.gfr2, nullptr, 0, 128, 0, a1, 1);
+        Col a0[1] = {{in->radarnet_out, nullptr, 0, 256, 0, 256}};
+        add_matrix(FR0, nr, 1, rf, w.gfr1, nullptr, 0, 192, 0, a0, 1);
+      }
     }
     {  // node update (layers 0 .. depth-2)
       Col c0[1] = {{w.M[0], nullptr, (long)nLm, D::NIN, 0, 256}};
