@@ -177,6 +177,16 @@ def load() -> C.CDLL:
     lib.b3d_point_feat.restype = C.c_int
     lib.b3d_point_feat.argtypes = [C.POINTER(b3d_linear), C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                    C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    lib.b3d_bn_fold_moments.restype = C.c_int
+    lib.b3d_bn_fold_moments.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int64, C.c_void_p, C.c_void_p,
+                                        C.c_void_p]
+    lib.b3d_bn_minmax_workspace_bytes.restype = C.c_size_t
+    lib.b3d_bn_minmax_workspace_bytes.argtypes = [C.c_int32]
+    lib.b3d_bn_minmax_apply.restype = C.c_int
+    lib.b3d_bn_minmax_apply.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int32, C.c_void_p,
+                                        C.c_size_t, C.c_void_p, C.c_void_p]
     lib.b3d_post_workspace_bytes.restype = C.c_size_t
     lib.b3d_post_workspace_bytes.argtypes = [C.c_int64, C.c_int64]
     lib.b3d_post_greedy.restype = C.c_int

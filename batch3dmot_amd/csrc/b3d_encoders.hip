@@ -4,12 +4,19 @@
 // with kernel 1 is a Linear applied to every point; in eval mode BatchNorm is an affine map and is folded into the
 // Linear by the caller.  35.7 MMAC per LiDAR detection (both stacks) -- 96 % of forward_feat.
 //
-// One workgroup of 8 wavefronts takes 128 points (one LiDAR cloud, two radar clouds): each wavefront carries a
-// 16-point tile through the three layers in registers (b3d_dev.hpp), the 128 -> 1024 layer streams its weights in
-// 11 chunks and never materialises the [points, 1024] activation: every finished 16x16 output block is reduced to
-// its per-feature maximum over the 16 points with four DPP row rotations, the 8 tile maxima meet in LDS once per
-// cloud.  Optionally the input is multiplied by a per-cloud 3x3 matrix (PointNet's input transform, the `bmm` of
-// pointnet.py:137) while it is loaded.  ReLU after the last layer commutes with the maximum and is applied once.
+// One workgroup of 8 wavefronts takes 256 points (two LiDAR clouds, four radar clouds): each wavefront carries TWO
+// 16-point tiles through the three layers in registers, so that every weight fragment read from LDS feeds two tiles
+// (the 16-row form reads 512 B of weights per MFMA -- half of the LDS array's rate at full MFMA rate -- and meets a
+// workgroup barrier every 96 MFMAs).  The 128 -> 1024 layer streams its weights in 16 chunks and never materialises
+// the [points, 1024] activation.  It is evaluated with the operands SWAPPED (points x features instead of features x
+// points: same registers, the other MFMA argument), which leaves the 4 accumulator values of a lane on 4 POINTS of
+// one feature: the per-feature maximum / minimum / sum / sum of squares over a wavefront's 32 points is 7 in-lane
+// operations per quantity and two v_permlane{32,16}_swap steps that each finish two quantities at once, instead of
+// sixteen 4-step DPP rotations per output block.  The epilogue of block k is issued behind the first MFMAs of block
+// k + 1.  The clouds that do not fill a last round of 256-point groups go through the same code one tile per
+// wavefront (128-point groups), so that the tail is spread over all CUs.  Optionally the input is multiplied by a
+// per-cloud 3x3 matrix (PointNet's input transform, the `bmm` of pointnet.py:137) while it is loaded.  ReLU after the
+// last layer commutes with the maximum and is applied once.
 #include "b3d_common.hpp"
 #include "b3d_dev.hpp"
 #include "b3d_pack.hpp"
@@ -31,134 +38,269 @@ struct PointFeatArgs {
   float* out_sum;
   float* out_sq;
   const float* wpack;   // PointSeq images
+  int n_wide, n_narrow; // groups of 8 x 2 tiles, then groups of 8 x 1 tiles
 };
 
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+// v_max_f32 / v_add_f32 on raw registers (fmaxf on a bit-cast value makes hipcc canonicalise both inputs first)
+__device__ __forceinline__ float vmax_raw(float x, float y) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+  return r;
 }
-template <class Op>
-__device__ __forceinline__ float row_reduce16(float v, Op op) {
-  v = op(v, dpp_f<0x128>(v));
-  v = op(v, dpp_f<0x124>(v));
-  v = op(v, dpp_f<0x122>(v));
-  v = op(v, dpp_f<0x121>(v));
-  return v;
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
+// lanes 0..31 hold quantity A of (feature = lane & 15, point quarter = lane >> 4), lanes 32..63 ... : given A and B per
+// lane, returns op over the four lane quarters of A in lanes 0..31 and of B in lanes 32..63
+template <bool MAX>
+__device__ __forceinline__ float quarter_reduce2(float a, float b) {
+  const u2v r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  const float x = __uint_as_float(r.x), y = __uint_as_float(r.y);
+  const float e = MAX ? vmax_raw(x, y) : x + y;             // lanes 0..31: A of quarters {0,2} / {1,3}; 32..63: B
+  const u2v s = __builtin_amdgcn_permlane16_swap(__float_as_uint(e), __float_as_uint(e), false, false);
+  const float u = __uint_as_float(s.x), v = __uint_as_float(s.y);
+  return MAX ? vmax_raw(u, v) : u + v;
 }
-// maximum over the 16 lanes of a DPP row (= the 16 points of a tile that share feature piece q); every lane gets it
-__device__ __forceinline__ float row_max16(float v) {
-  v = fmaxf(v, dpp_f<0x128>(v));      // row_ror:8
-  v = fmaxf(v, dpp_f<0x124>(v));      // row_ror:4
-  v = fmaxf(v, dpp_f<0x122>(v));      // row_ror:2
-  v = fmaxf(v, dpp_f<0x121>(v));      // row_ror:1
-  return v;
+__device__ __forceinline__ v4f bf_mfma6_pts(const Bf3& x, const Bf3& w, v4f acc) {   // rows = points, columns = features
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x.p2, w.p0, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x.p1, w.p1, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x.p0, w.p2, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x.p1, w.p0, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x.p0, w.p1, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x.p0, w.p0, acc, 0, 0, 0);
+  return acc;
 }
 
 // STATS (train mode: the last BatchNorm uses the statistics of THIS batch, so it cannot be folded before its input
 // exists): the last layer is evaluated raw (conv bias only) and every cloud's per-feature maximum, minimum, sum and
 // sum of squares over its points are written; the caller derives mean / variance per feature from the sums and
 // applies the now-known affine map to the maximum (positive scale) or the minimum (negative scale) -- the [points,
-// 1024] activation is never stored.  Per weight chunk the 8 tile partials meet in a double-buffered LDS area and are
-// combined behind the NEXT chunk's barrier (no extra barrier per chunk).
+// 1024] activation is never stored.  Per weight chunk the wavefronts' partials meet in a double-buffered LDS area and
+// are combined behind the NEXT chunk's barrier (no extra barrier per chunk).
 constexpr int kStatChunkFeat = chunk_rows(128, 1024, PointSeq::bf(2));   // features of one weight chunk of the 128 -> 1024 layer
+static_assert(PointSeq::layer_chunks(0) == 1 && PointSeq::layer_chunks(1) == 1 && !PointSeq::bf(0) && PointSeq::bf(1) && PointSeq::bf(2),
+              "point_pass is written for a one-chunk fp32 first layer and bf16x3 images after it");
+
+// One group of 8 * 16 * T points: T tiles per wavefront.
+template <int P, int T, bool STATS>
+struct PointPass {
+  static constexpr int WPC = P / (16 * T);                   // wavefronts per cloud
+  static constexpr int CPW = 8 / WPC;                        // clouds per group
+  static_assert(P % (16 * T) == 0 && WPC >= 1 && 8 % WPC == 0, "a wavefront's tiles lie in one cloud");
+  static constexpr int CB = kStatChunkFeat / 16;             // output blocks per weight chunk
+  static constexpr int S3 = row_stride(128, true);
+  static constexpr int NCH3 = PointSeq::layer_chunks(2);
+  static constexpr int F = kStatChunkFeat;
+
+  // STATS: the wavefronts' partials of `chunk` -> global (all 512 threads)
+  static __device__ __forceinline__ void combine(const PointFeatArgs& a, const float* xpart, int cloud0, int chunk) {
+    const float* buf = xpart + (chunk & 1) * 4 * 8 * F;
+    const int nfeat = min(F, kPointFeat - chunk * F);
+    for (int f = threadIdx.x; f < CPW * nfeat; f += 512) {
+      const int cl = f / nfeat, feat = f - cl * nfeat;
+      const float* src = buf + (cl * WPC) * F + feat;
+      float vmax = src[0], vmin = src[8 * F], vsum = src[16 * F], vsq = src[24 * F];
+#pragma unroll
+      for (int t = 1; t < WPC; ++t) {
+        vmax = fmaxf(vmax, src[t * F]);
+        vmin = fminf(vmin, src[(8 + t) * F]);
+        vsum += src[(16 + t) * F];
+        vsq += src[(24 + t) * F];
+      }
+      const int c = cloud0 + cl;
+      if (c < a.B) {
+        const long o = (long)c * kPointFeat + chunk * F + feat;
+        a.out[o] = vmax; a.out_min[o] = vmin; a.out_sum[o] = vsum; a.out_sq[o] = vsq;
+      }
+    }
+  }
+
+  template <int CH>
+  static __device__ __forceinline__ void chunk3(WStreamT<512>& ws, bool more, const PointFeatArgs& a, float* xpart, int cloud0,
+                                                const Bf3 (&x3)[T][4]) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int m = lane & 15, q = lane >> 4;
+    const float* w = ws.template acquire<PointSeq, 2 + CH>(more);
+    if constexpr (STATS && CH > 0) combine(a, xpart, cloud0, CH - 1);   // behind this chunk's barrier: every partial is there
+    constexpr int nb = (kPointFeat - CH * F < F ? kPointFeat - CH * F : F) / 16;
+    const float* wrow = w + m * S3 + 4 * q;
+    const float* wbias = w + m * S3 + bias_col(128, true);   // bias of feature m of a block
+    // where this lane's finished values go: lanes 0..31 hold maximum | sum, lanes 32..63 minimum (negated) | sum of squares
+    float* mm;
+    float* ss = nullptr;
+    if constexpr (STATS) {
+      mm = xpart + (CH & 1) * 4 * 8 * F + (lane >> 5) * 8 * F + wave * F + m;
+      ss = mm + 16 * F;
+    } else {
+      mm = xpart + wave * kPointFeat + CH * F + m;
+    }
+    const unsigned flip = (STATS && lane >= 32) ? 0x80000000u : 0u;
+    auto epilogue = [&](int lb, const v4f (&acc)[T]) {
+      float mx = acc[0].x;
+      mx = fmaxf(mx, acc[0].y); mx = fmaxf(mx, acc[0].z); mx = fmaxf(mx, acc[0].w);
+#pragma unroll
+      for (int t = 1; t < T; ++t) { mx = fmaxf(mx, acc[t].x); mx = fmaxf(mx, acc[t].y); mx = fmaxf(mx, acc[t].z); mx = fmaxf(mx, acc[t].w); }
+      if constexpr (STATS) {
+        float mn = acc[0].x, sm = acc[0].x, sq = acc[0].x * acc[0].x;
+        mn = fminf(mn, acc[0].y); mn = fminf(mn, acc[0].z); mn = fminf(mn, acc[0].w);
+        sm += acc[0].y; sm += acc[0].z; sm += acc[0].w;
+        sq = fmaf(acc[0].y, acc[0].y, sq); sq = fmaf(acc[0].z, acc[0].z, sq); sq = fmaf(acc[0].w, acc[0].w, sq);
+#pragma unroll
+        for (int t = 1; t < T; ++t) {
+          mn = fminf(mn, acc[t].x); mn = fminf(mn, acc[t].y); mn = fminf(mn, acc[t].z); mn = fminf(mn, acc[t].w);
+          sm += acc[t].x; sm += acc[t].y; sm += acc[t].z; sm += acc[t].w;
+          sq = fmaf(acc[t].x, acc[t].x, sq); sq = fmaf(acc[t].y, acc[t].y, sq); sq = fmaf(acc[t].z, acc[t].z, sq); sq = fmaf(acc[t].w, acc[t].w, sq);
+        }
+        const float r = quarter_reduce2<true>(mx, -mn);
+        mm[lb * 16] = __uint_as_float(__float_as_uint(r) ^ flip);
+        ss[lb * 16] = quarter_reduce2<false>(sm, sq);
+      } else {
+        mm[lb * 16] = quarter_reduce2<true>(mx, mx);
+      }
+    };
+    Bf3 cur = bf_load<128>(wrow);
+    float nbias = wbias[0];
+    v4f prev[T];
+#pragma unroll
+    for (int lb = 0; lb < nb; ++lb) {
+      v4f acc[T];
+#pragma unroll
+      for (int t = 0; t < T; ++t) acc[t] = v4f{nbias, nbias, nbias, nbias};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        Bf3 nxt = cur;
+        if (c + 1 < 4) nxt = bf_load<128>(wrow + lb * 16 * S3 + 16 * (c + 1));
+        else if (lb + 1 < nb) { nxt = bf_load<128>(wrow + (lb + 1) * 16 * S3); nbias = wbias[(lb + 1) * 16 * S3]; }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc[t] = bf_mfma6_pts(x3[t][c], cur, acc[t]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c == 0 && lb > 0) epilogue(lb - 1, prev);        // the previous block's reductions run under these MFMAs
+        cur = nxt;
+      }
+#pragma unroll
+      for (int t = 0; t < T; ++t) prev[t] = acc[t];
+    }
+    epilogue(nb - 1, prev);
+  }
+
+  template <int... CH>
+  static __device__ __forceinline__ void layer3(WStreamT<512>& ws, bool more, const PointFeatArgs& a, float* xpart, int cloud0,
+                                                const Bf3 (&x3)[T][4], std::integer_sequence<int, CH...>) {
+    (chunk3<CH>(ws, more, a, xpart, cloud0, x3), ...);
+  }
+
+  static __device__ __forceinline__ void run(WStreamT<512>& ws, bool more, const PointFeatArgs& a, float* xpart, int cloud0) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int m = lane & 15, q = lane >> 4;
+    const int cloud = cloud0 + wave / WPC;
+    const int cc = cloud < a.B ? cloud : a.B - 1;            // idle wavefronts of the last group recompute a valid cloud
+    v4f in[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      in[t] = v4f{0.f, 0.f, 0.f, 0.f};
+      if (q == 0) {                                          // features 0..3 of the 16-wide padded input block
+        const int p = ((wave % WPC) * T + t) * 16 + m;
+        const float* xp = a.x + ((long)cc * a.C) * P + p;
+        float f[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < a.C && c < 4; ++c) f[c] = xp[(long)c * P];
+        if (a.trans) {                                       // x' = x^T . T  (row vector times the cloud's 3x3)
+          const float* tr = a.trans + (long)cc * 9;
+          const float x0 = f[0], x1 = f[1], x2 = f[2];
+          f[0] = x0 * tr[0] + x1 * tr[3] + x2 * tr[6];
+          f[1] = x0 * tr[1] + x1 * tr[4] + x2 * tr[7];
+          f[2] = x0 * tr[2] + x1 * tr[5] + x2 * tr[8];
+        }
+        in[t] = v4f{f[0], f[1], f[2], f[3]};
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t) wait_for(in[t]);
+    // C -> 64, exact fp32 MFMA
+    v4f h1[T][4];
+    {
+      constexpr int S = row_stride(16, false);
+      const float* w = ws.template acquire<PointSeq, 0>(more);
+      const float* wrow = w + m * S + 4 * q;
+      const float* wb = w + 4 * q * S + bias_col(16, false);
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) {
+        const v4f frag = *reinterpret_cast<const v4f*>(wrow + mb * 16 * S);
+        const float* b = wb + mb * 16 * S;
+        const v4f bias = v4f{b[0], b[S], b[2 * S], b[3 * S]};
+#pragma unroll
+        for (int t = 0; t < T; ++t) h1[t][mb] = relu4(mfma4(frag, in[t], bias));
+      }
+    }
+    // 64 -> 128
+    Bf3 x3[T][4];
+    {
+      constexpr int S = row_stride(64, true);
+      Bf3 x2[T][2];
+      const float* w = ws.template acquire<PointSeq, 1>(more);
+#pragma unroll
+      for (int t = 0; t < T; ++t) { x2[t][0] = bf_split(h1[t][0], h1[t][1]); x2[t][1] = bf_split(h1[t][2], h1[t][3]); }
+      const float* wrow = w + m * S + 4 * q;
+      const float* wb = w + 4 * q * S + bias_col(64, true);
+      auto bias = [&](int mb) { const float* b = wb + mb * 16 * S; return v4f{b[0], b[S], b[2 * S], b[3 * S]}; };
+      Bf3 cur = bf_load<64>(wrow);
+      v4f nbias = bias(0);
+      v4f h2[T][2];                                          // two blocks at a time -> one operand group of the next layer
+#pragma unroll
+      for (int mb = 0; mb < 8; ++mb) {
+        v4f acc[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc[t] = nbias;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          Bf3 nxt = cur;
+          if (c == 0) nxt = bf_load<64>(wrow + mb * 16 * S + 16);
+          else if (mb + 1 < 8) { nxt = bf_load<64>(wrow + (mb + 1) * 16 * S); nbias = bias(mb + 1); }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int t = 0; t < T; ++t) acc[t] = bf_mfma6(cur, x2[t][c], acc[t]);
+          cur = nxt;
+        }
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          h2[t][mb & 1] = relu4(acc[t]);
+          if (mb & 1) x3[t][mb >> 1] = bf_split(h2[t][0], h2[t][1]);
+        }
+      }
+    }
+    layer3(ws, more, a, xpart, cloud0, x3, std::make_integer_sequence<int, NCH3>{});
+    __syncthreads();
+    if constexpr (STATS) {
+      combine(a, xpart, cloud0, NCH3 - 1);
+    } else {
+      for (int f = threadIdx.x; f < CPW * kPointFeat; f += 512) {
+        const int cl = f / kPointFeat, feat = f % kPointFeat;
+        const float* src = xpart + (cl * WPC) * kPointFeat + feat;
+        float v = src[0];
+#pragma unroll
+        for (int t = 1; t < WPC; ++t) v = fmaxf(v, src[t * kPointFeat]);
+        if (a.relu_last) v = fmaxf(v, 0.f);
+        const int c = cloud0 + cl;
+        if (c < a.B) a.out[(long)c * kPointFeat + feat] = v;
+      }
+    }
+    // the next group's first write to xpart sits behind three more weight-chunk barriers: no barrier needed here
+  }
+};
+
+// items 0 .. n_wide-1: groups of two tiles per wavefront; then n_narrow groups of one tile per wavefront
 template <int P, bool STATS>
 __global__ __launch_bounds__(512, 1) void point_feat_kernel(const PointFeatArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int TPC = P / 16, CPW = 8 / TPC;                   // tiles per cloud, clouds per workgroup
-  static_assert(P % 16 == 0 && 8 % TPC == 0, "a cloud is a whole number of tiles, a workgroup a whole number of clouds");
+  using Wide = PointPass<P, 2, STATS>;
+  using Narrow = PointPass<P, 1, STATS>;
   WStreamT<512> ws;
   ws.init(a.wpack, smem);
   ws.template start<PointSeq>();
-  float* xpart = smem + 2 * kWBufFloats;                       // [8 wavefronts][1024]
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int m = lane & 15, q = lane >> 4;
-  const int ngroups = (a.B + CPW - 1) / CPW;
-  for (int g = blockIdx.x; g < ngroups; g += gridDim.x) {
-    const bool more = g + (int)gridDim.x < ngroups;
-    const int cloud = g * CPW + wave / TPC;
-    const int cc = cloud < a.B ? cloud : a.B - 1;              // idle wavefronts of the last group recompute a valid cloud
-    const int p = (wave % TPC) * 16 + m;
-    v4f in[1] = {v4f{0.f, 0.f, 0.f, 0.f}};
-    if (q == 0) {                                              // features 0..3 of the 16-wide padded input block
-      const float* xp = a.x + ((long)cc * a.C) * P + p;
-      float f[4] = {0.f, 0.f, 0.f, 0.f};
-      for (int c = 0; c < a.C && c < 4; ++c) f[c] = xp[(long)c * P];
-      if (a.trans) {                                           // x' = x^T . T  (row vector times the cloud's 3x3)
-        const float* t = a.trans + (long)cc * 9;
-        const float x0 = f[0], x1 = f[1], x2 = f[2];
-        f[0] = x0 * t[0] + x1 * t[3] + x2 * t[6];
-        f[1] = x0 * t[1] + x1 * t[4] + x2 * t[7];
-        f[2] = x0 * t[2] + x1 * t[5] + x2 * t[8];
-      }
-      in[0] = v4f{f[0], f[1], f[2], f[3]};
-    }
-    wait_for(in[0]);
-    v4f h1[4], h2[8];
-    linear<PointSeq, 0, true>(ws, more, in, h1);
-    linear<PointSeq, 1, true>(ws, more, h1, h2);
-    if constexpr (STATS) {
-      // xpart as [2 parities][4 quantities][8 wavefronts][96 features]
-      constexpr int CB = kStatChunkFeat / 16;                  // output blocks per weight chunk
-      auto fmax_ = [](float x, float y) { return fmaxf(x, y); };
-      auto fmin_ = [](float x, float y) { return fminf(x, y); };
-      auto fadd_ = [](float x, float y) { return x + y; };
-      auto combine = [&](int chunk) {                          // all wavefronts: tile partials of `chunk` -> global
-        const float* buf = xpart + (chunk & 1) * 4 * 8 * kStatChunkFeat;
-        const int nfeat = min(kStatChunkFeat, kPointFeat - chunk * kStatChunkFeat);
-        for (int f = threadIdx.x; f < CPW * nfeat; f += 512) {
-          const int cl = f / nfeat, feat = f - cl * nfeat;
-          const float* src = buf + (cl * TPC) * kStatChunkFeat + feat;
-          float vmax = src[0], vmin = src[8 * kStatChunkFeat], vsum = src[16 * kStatChunkFeat], vsq = src[24 * kStatChunkFeat];
-#pragma unroll
-          for (int t = 1; t < TPC; ++t) {
-            vmax = fmaxf(vmax, src[t * kStatChunkFeat]);
-            vmin = fminf(vmin, src[(8 + t) * kStatChunkFeat]);
-            vsum += src[(16 + t) * kStatChunkFeat];
-            vsq += src[(24 + t) * kStatChunkFeat];
-          }
-          const int c = g * CPW + cl;
-          if (c < a.B) {
-            const long o = (long)c * kPointFeat + chunk * kStatChunkFeat + feat;
-            a.out[o] = vmax; a.out_min[o] = vmin; a.out_sum[o] = vsum; a.out_sq[o] = vsq;
-          }
-        }
-      };
-      linear_emit<PointSeq, 2, false>(ws, more, h2, [&](int mb, v4f v) {
-        const int chunk = mb / CB, lb = mb - chunk * CB;
-        if (lb == 0 && chunk > 0) combine(chunk - 1);          // behind this chunk's barrier: every tile partial is there
-        float* buf = xpart + (chunk & 1) * 4 * 8 * kStatChunkFeat + wave * kStatChunkFeat + lb * 16 + 4 * q;
-        v4f t;
-        t.x = row_reduce16(v.x, fmax_); t.y = row_reduce16(v.y, fmax_); t.z = row_reduce16(v.z, fmax_); t.w = row_reduce16(v.w, fmax_);
-        if (m == 0) *reinterpret_cast<v4f*>(buf) = t;
-        t.x = row_reduce16(v.x, fmin_); t.y = row_reduce16(v.y, fmin_); t.z = row_reduce16(v.z, fmin_); t.w = row_reduce16(v.w, fmin_);
-        if (m == 0) *reinterpret_cast<v4f*>(buf + 8 * kStatChunkFeat) = t;
-        t.x = row_reduce16(v.x, fadd_); t.y = row_reduce16(v.y, fadd_); t.z = row_reduce16(v.z, fadd_); t.w = row_reduce16(v.w, fadd_);
-        if (m == 0) *reinterpret_cast<v4f*>(buf + 16 * kStatChunkFeat) = t;
-        t.x = row_reduce16(v.x * v.x, fadd_); t.y = row_reduce16(v.y * v.y, fadd_); t.z = row_reduce16(v.z * v.z, fadd_);
-        t.w = row_reduce16(v.w * v.w, fadd_);
-        if (m == 0) *reinterpret_cast<v4f*>(buf + 24 * kStatChunkFeat) = t;
-      });
-      __syncthreads();
-      combine((kPointFeat + kStatChunkFeat - 1) / kStatChunkFeat - 1);
-      continue;                                                // next group: its first xpart write is 3 barriers away
-    }
-    float* mine = xpart + wave * kPointFeat;
-    linear_emit<PointSeq, 2, false>(ws, more, h2, [&](int mb, v4f v) {
-      v.x = row_max16(v.x); v.y = row_max16(v.y); v.z = row_max16(v.z); v.w = row_max16(v.w);
-      if (m == 0) *reinterpret_cast<v4f*>(mine + mb * 16 + 4 * q) = v;
-    });
-    __syncthreads();
-    for (int f = threadIdx.x; f < CPW * kPointFeat; f += 512) {
-      const int cl = f / kPointFeat, feat = f % kPointFeat;
-      const float* src = xpart + (cl * TPC) * kPointFeat + feat;
-      float v = src[0];
-#pragma unroll
-      for (int t = 1; t < TPC; ++t) v = fmaxf(v, src[t * kPointFeat]);
-      if (a.relu_last) v = fmaxf(v, 0.f);
-      const int c = g * CPW + cl;
-      if (c < a.B) a.out[(long)c * kPointFeat + feat] = v;
-    }
-    // the next group's first write to xpart sits behind two more weight-chunk barriers: no barrier needed here
+  float* xpart = smem + 2 * kWBufFloats;
+  const int items = a.n_wide + a.n_narrow;
+  for (int it = blockIdx.x; it < items; it += gridDim.x) {
+    const bool more = it + (int)gridDim.x < items;
+    if (it < a.n_wide) Wide::run(ws, more, a, xpart, it * Wide::CPW);
+    else Narrow::run(ws, more, a, xpart, a.n_wide * Wide::CPW + (it - a.n_wide) * Narrow::CPW);
   }
 }
 
@@ -206,9 +348,24 @@ static int point_feat_launch(const b3d_linear* conv, const float* x, const float
   a.x = x; a.trans = trans; a.B = B; a.C = C; a.relu_last = relu_last; a.out = out; a.wpack = wp;
   a.out_min = out_min; a.out_sum = out_sum; a.out_sq = out_sq;
   const bool stats = out_min != nullptr;
-  const int cpw = P == 128 ? 1 : 2;
-  int groups = (B + cpw - 1) / cpw;
-  if (groups > 1024) groups = 1024;                            // persistent: <= 4 groups per CU in flight order
+  // 256-point groups; when the last round of them over the CUs would be less than half full, its clouds go as 128-point
+  // groups instead (twice as many workgroups share the tail)
+  const int cpw_wide = 256 / P, cpw_narrow = 128 / P;
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    return n;
+  }();
+  int n_wide = (B + cpw_wide - 1) / cpw_wide, n_narrow = 0;
+  const int tail = n_wide % cus;
+  if (tail > 0 && 2 * tail < cus) {
+    n_wide -= tail;
+    n_narrow = (B - n_wide * cpw_wide + cpw_narrow - 1) / cpw_narrow;
+  }
+  a.n_wide = n_wide; a.n_narrow = n_narrow;
+  int groups = n_wide + n_narrow;
+  if (groups > 4 * cus) groups = 4 * cus;                      // persistent beyond that: <= 4 workgroups per CU in dispatch order
 #define B3D_POINT_LAUNCH(PP, ST)                                                                      \
   do {                                                                                                \
     B3D_TRY(set_lds(point_feat_kernel<PP, ST>, kPointLds));                                           \
@@ -221,4 +378,159 @@ static int point_feat_launch(const b3d_linear* conv, const float* x, const float
   else B3D_POINT_LAUNCH(64, false);
 #undef B3D_POINT_LAUNCH
   return launch_check("point_feat_kernel");
+}
+
+
+// ---- train-mode BatchNorm bookkeeping of the point stacks, fused (the PyTorch form is ~25 tiny launches per layer) --------
+namespace b3d {
+namespace {
+
+// running statistics as nn.BatchNorm1d updates them in a train-mode forward (unbiased variance, momentum or the
+// cumulative average when momentum < 0, num_batches_tracked)
+__device__ __forceinline__ void bn_track(float* running_mean, float* running_var, int o, double mean, double var_biased,
+                                         long long count, float momentum, long long nbt_after) {
+  if (!running_mean) return;
+  const double mom = momentum >= 0.f ? (double)momentum : 1.0 / (double)nbt_after;
+  const double unbiased = var_biased * ((double)count / (double)(count > 1 ? count - 1 : 1));
+  running_mean[o] = (float)((1.0 - mom) * (double)running_mean[o] + mom * (double)(float)mean);
+  running_var[o] = (float)((1.0 - mom) * (double)running_var[o] + mom * (double)(float)unbiased);
+}
+
+__global__ void bn_tick_kernel(long long* nbt) { *nbt += 1; }
+
+// z = W h + b over all points: mean(z) = W mu + b, var(z)_o = W_o Cov W_o^T with Cov = second - mu mu^T (float64); then the
+// BatchNorm of THIS batch folded into the layer: wf = W * scale, bf = b * scale + shift.
+struct BnFoldArgs {
+  const double* mu;       // [C]
+  const double* second;   // [C, C] = E[h h^T]
+  int C, O;
+  const float *W, *b, *gamma, *beta;
+  float *running_mean, *running_var;
+  long long* nbt;
+  float momentum, eps;
+  long long count;
+  float *wf, *bf;
+};
+__global__ __launch_bounds__(256) void bn_fold_moments_kernel(const BnFoldArgs a) {
+  // one wavefront per output channel, 4 per workgroup; lane i holds row i of Cov . w
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int o = blockIdx.x * 4 + wave;
+  if (o >= a.O) return;
+  const float* w = a.W + (size_t)o * a.C;
+  double mean_part = 0.0, var_part = 0.0;
+  if (lane < a.C) {
+    const double mi = a.mu[lane], wi = (double)w[lane];
+    double t = 0.0;
+    for (int j = 0; j < a.C; ++j) t += (a.second[lane * a.C + j] - mi * a.mu[j]) * (double)w[j];
+    mean_part = wi * mi;
+    var_part = wi * t;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    mean_part += __shfl_xor(mean_part, off);
+    var_part += __shfl_xor(var_part, off);
+  }
+  const double mean = mean_part + (double)a.b[o];
+  const double var = var_part < 0.0 ? 0.0 : var_part;
+  const float meanf = (float)mean, varf = (float)var;
+  const float scale = a.gamma[o] / sqrtf(varf + a.eps);
+  const float shift = a.beta[o] - meanf * scale;
+  if (lane < a.C) a.wf[(size_t)o * a.C + lane] = w[lane] * scale;
+  if (lane == 0) {
+    a.bf[o] = a.b[o] * scale + shift;
+    bn_track(a.running_mean, a.running_var, o, mean, var, a.count, a.momentum, a.nbt ? *a.nbt + 1 : 1);
+  }
+}
+
+// last layer: per-cloud max / min / sum / sum of squares of the raw conv output -> batch statistics -> y = BN(max or min)
+struct BnMinMaxArgs {
+  const float *vmax, *vmin, *vsum, *vsq;   // [B, F]
+  int B, F, relu;
+  long long count;
+  const float *gamma, *beta;
+  float *running_mean, *running_var;
+  long long* nbt;
+  float momentum, eps;
+  double* part;                            // [chunks][2][F]
+  int chunks;
+  float* y;                                // [B, F]
+};
+__global__ __launch_bounds__(256) void bn_minmax_partial_kernel(const BnMinMaxArgs a) {
+  const int f = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+  if (f >= a.F) return;
+  const int per = (a.B + a.chunks - 1) / a.chunks;
+  const int b0 = c * per, b1 = min(a.B, b0 + per);
+  double s = 0.0, q = 0.0;
+  for (int b = b0; b < b1; ++b) { s += (double)a.vsum[(size_t)b * a.F + f]; q += (double)a.vsq[(size_t)b * a.F + f]; }
+  a.part[((size_t)c * 2 + 0) * a.F + f] = s;
+  a.part[((size_t)c * 2 + 1) * a.F + f] = q;
+}
+__global__ __launch_bounds__(256) void bn_minmax_apply_kernel(const BnMinMaxArgs a) {
+  const int f = blockIdx.x * 256 + threadIdx.x;
+  if (f >= a.F) return;
+  double s = 0.0, q = 0.0;
+  for (int c = 0; c < a.chunks; ++c) { s += a.part[((size_t)c * 2 + 0) * a.F + f]; q += a.part[((size_t)c * 2 + 1) * a.F + f]; }
+  const double mean = s / (double)a.count;
+  double var = q / (double)a.count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const double scale = (double)a.gamma[f] / sqrt(var + (double)a.eps);
+  const double shift = (double)a.beta[f] - mean * scale;
+  if (blockIdx.y == 0) {
+    const long long nbt_after = a.nbt ? *a.nbt + 1 : 1;
+    bn_track(a.running_mean, a.running_var, f, (double)(float)mean, (double)(float)var, a.count, a.momentum, nbt_after);
+  }
+  const int per = (a.B + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * per, b1 = min(a.B, b0 + per);
+  for (int b = b0; b < b1; ++b) {
+    const size_t o = (size_t)b * a.F + f;
+    const double ext = scale > 0.0 ? (double)a.vmax[o] : (double)a.vmin[o];
+    float v = (float)(ext * scale + shift);
+    if (a.relu) v = fmaxf(v, 0.f);
+    a.y[o] = v;
+  }
+}
+
+}  // namespace
+}  // namespace b3d
+
+extern "C" int b3d_bn_fold_moments(const double* mu, const double* second, int32_t C, const float* W, const float* b, int32_t O,
+                                   const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                   int64_t* num_batches_tracked, float momentum, float eps, int64_t count, float* wf, float* bf,
+                                   b3d_stream stream_) {
+  B3D_REQUIRE(mu && second && W && b && gamma && beta && wf && bf, "b3d_bn_fold_moments: null argument");
+  B3D_REQUIRE(C >= 1 && C <= 64 && O >= 1 && count >= 1, "b3d_bn_fold_moments: C %d (<= 64), O %d", (int)C, (int)O);
+  B3D_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "b3d_bn_fold_moments: running statistics come as a pair");
+  BnFoldArgs a{mu, second, C, O, W, b, gamma, beta, running_mean, running_var, (long long*)num_batches_tracked, momentum, eps,
+               (long long)count, wf, bf};
+  hipLaunchKernelGGL(bn_fold_moments_kernel, dim3((unsigned)((O + 3) / 4)), dim3(256), 0, (hipStream_t)stream_, a);
+  B3D_TRY(launch_check("bn_fold_moments_kernel"));
+  if (num_batches_tracked) {
+    hipLaunchKernelGGL(bn_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream_, (long long*)num_batches_tracked);
+    B3D_TRY(launch_check("bn_tick_kernel"));
+  }
+  return B3D_OK;
+}
+
+extern "C" size_t b3d_bn_minmax_workspace_bytes(int32_t F) { return (size_t)32 * 2 * (size_t)F * sizeof(double) + 256; }
+
+extern "C" int b3d_bn_minmax_apply(const float* vmax, const float* vmin, const float* vsum, const float* vsq, int32_t B, int32_t F,
+                                   int64_t count, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                   int64_t* num_batches_tracked, float momentum, float eps, int32_t relu, void* workspace,
+                                   size_t workspace_bytes, float* y, b3d_stream stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  B3D_REQUIRE(vmax && vmin && vsum && vsq && gamma && beta && workspace && y, "b3d_bn_minmax_apply: null argument");
+  B3D_REQUIRE(B >= 1 && F >= 1 && count >= 1, "b3d_bn_minmax_apply: B %d, F %d", (int)B, (int)F);
+  if (workspace_bytes < b3d_bn_minmax_workspace_bytes(F)) return fail(B3D_ERR_WORKSPACE, "b3d_bn_minmax_apply: workspace too small");
+  BnMinMaxArgs a{vmax, vmin, vsum, vsq, B, F, relu, (long long)count, gamma, beta, running_mean, running_var,
+                 (long long*)num_batches_tracked, momentum, eps, (double*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255), 32, y};
+  const unsigned fb = (unsigned)((F + 255) / 256);
+  hipLaunchKernelGGL(bn_minmax_partial_kernel, dim3(fb, 32), dim3(256), 0, stream, a);
+  B3D_TRY(launch_check("bn_minmax_partial_kernel"));
+  hipLaunchKernelGGL(bn_minmax_apply_kernel, dim3(fb, 32), dim3(256), 0, stream, a);
+  B3D_TRY(launch_check("bn_minmax_apply_kernel"));
+  if (num_batches_tracked) {
+    hipLaunchKernelGGL(bn_tick_kernel, dim3(1), dim3(1), 0, stream, (long long*)num_batches_tracked);
+    B3D_TRY(launch_check("bn_tick_kernel"));
+  }
+  return B3D_OK;
 }

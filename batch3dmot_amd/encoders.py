@@ -96,18 +96,6 @@ def point_feat_hip(convs, bns, x: torch.Tensor, trans=None, relu_last: bool = Fa
     return out
 
 
-def _bn_batch_stats_(bn: nn.BatchNorm1d, mean: torch.Tensor, var_biased: torch.Tensor, count: int):
-    """What a train-mode BatchNorm forward does besides normalising: the running-statistics update
-    (torch.nn.modules.batchnorm: unbiased variance, momentum, num_batches_tracked)."""
-    if not bn.track_running_stats or bn.running_mean is None:
-        return
-    bn.num_batches_tracked += 1
-    mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
-    unbiased = var_biased * (count / max(count - 1, 1))
-    bn.running_mean.mul_(1.0 - mom).add_(mean.to(bn.running_mean.dtype), alpha=mom)
-    bn.running_var.mul_(1.0 - mom).add_(unbiased.to(bn.running_var.dtype), alpha=mom)
-
-
 def point_feat_train_hip(convs, bns, x: torch.Tensor, trans=None, relu_last: bool = False) -> torch.Tensor:
     """Train-mode (batch-statistics BatchNorm) form of ``point_feat_hip``.  The first two layers are narrow: their
     pre-activations and statistics come from PyTorch ops (0.1 % / 6 % of the stack's arithmetic); the 128 -> 1024
@@ -130,30 +118,39 @@ def point_feat_train_hip(convs, bns, x: torch.Tensor, trans=None, relu_last: boo
         # z = W h + b, so over all B * P points   mean(z) = W mean(h) + b,   var(z)_c = W_c Cov(h) W_c^T
         # with the (small) second-moment matrix of the INPUT: 3x3 / 4x4 for the first layer, 64x64 for the second.
         # The moments are accumulated by one GEMM and finished in float64.
-        def moments(h2d):                                    # h2d [n_points, C] -> (mean [C], covariance [C, C]) in float64
+        def moments(h2d):                                    # h2d [n_points, C] -> (mean [C], E[h h^T] [C, C]) in float64
             # per-cloud partial sums in fp32 (P terms each), summed over the clouds in float64: a single [C, n] x [n, C]
             # product would be one tall-skinny GEMM (slow) with a 10^5-term fp32 accumulation (inaccurate)
             h3 = h2d.view(b, p, h2d.size(1))
             mu = h3.sum(1).sum(0, dtype=torch.float64) / n
             second = torch.bmm(h3.transpose(1, 2), h3).sum(0, dtype=torch.float64) / n
-            return mu, second - torch.outer(mu, mu)
+            return mu.contiguous(), second.contiguous()
 
-        def affine_stats(w2d, bias, mu, cov):                # statistics of z = W h + b over the points
-            wd = w2d.double()
-            mean = wd @ mu + bias.double()
-            var = ((wd @ cov) * wd).sum(1).clamp_min(0.0)
-            return mean.float(), var.float()
+        def tracked(bn):                                      # (running_mean, running_var, num_batches_tracked, momentum)
+            if not bn.track_running_stats or bn.running_mean is None:
+                return None, None, None, 0.0
+            for t_ in (bn.running_mean, bn.running_var):
+                _lib.require_cuda(t_, "BatchNorm running statistic", torch.float32)
+            _lib.require_cuda(bn.num_batches_tracked, "num_batches_tracked", torch.int64)
+            return (bn.running_mean.data_ptr(), bn.running_var.data_ptr(), bn.num_batches_tracked.data_ptr(),
+                    float(bn.momentum) if bn.momentum is not None else -1.0)
 
+        stream = _lib.current_stream(x.device)
         h2d = xin.permute(0, 2, 1).reshape(n, c)
+        keep = []
         for li, (cv, bn) in enumerate(zip(convs[:2], bns[:2])):
-            w2d = cv.weight.squeeze(-1)
-            mu, cov = moments(h2d)
-            mean, var = affine_stats(w2d, cv.bias, mu, cov)
-            _bn_batch_stats_(bn, mean, var, n)
-            scale = bn.weight / torch.sqrt(var + bn.eps)
-            shift = bn.bias - mean * scale
-            wf = (w2d * scale[:, None]).float().contiguous()
-            bf = (cv.bias * scale + shift).float().contiguous()
+            w2d = cv.weight.squeeze(-1).float().contiguous()
+            bias, gamma, beta = cv.bias.float().contiguous(), bn.weight.float().contiguous(), bn.bias.float().contiguous()
+            mu, second = moments(h2d)
+            o = w2d.size(0)
+            wf = torch.empty_like(w2d)
+            bf = torch.empty(o, dtype=torch.float32, device=x.device)
+            rm, rv, nbt, mom = tracked(bn)
+            # mean / variance of the pre-activation, the running-statistics update and the fold: one launch
+            _lib.check(lib.b3d_bn_fold_moments(mu.data_ptr(), second.data_ptr(), w2d.size(1), w2d.data_ptr(), bias.data_ptr(), o,
+                                               gamma.data_ptr(), beta.data_ptr(), rm, rv, nbt, mom, float(bn.eps), n,
+                                               wf.data_ptr(), bf.data_ptr(), stream), "b3d_bn_fold_moments")
+            keep.append((w2d, bias, gamma, beta, mu, second))
             folded.append((wf, bf))
             if li == 0:                                       # the kernel recomputes the activations itself; only the
                 h2d = torch.relu(torch.addmm(bf, h2d, wf.t()))          # next layer's statistics need them here
@@ -167,16 +164,18 @@ def point_feat_train_hip(convs, bns, x: torch.Tensor, trans=None, relu_last: boo
         t = trans.float().contiguous() if trans is not None else None
         _lib.check(lib.b3d_point_feat_stats(layers, x.data_ptr(), t.data_ptr() if t is not None else None, b, c, p,
                                             ws.data_ptr(), nbytes, outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(),
-                                            outs[3].data_ptr(), _lib.current_stream(x.device)), "b3d_point_feat_stats")
+                                            outs[3].data_ptr(), stream), "b3d_point_feat_stats")
+        # batch statistics of the last layer, its running statistics and y = BN(max | min) (+ ReLU): two launches
         bn3 = bns[2]
-        mean = outs[2].double().sum(0) / n
-        var = (outs[3].double().sum(0) / n - mean * mean).clamp_min(0.0)
-        _bn_batch_stats_(bn3, mean.float(), var.float(), n)
-        scale = bn3.weight.double() / torch.sqrt(var + bn3.eps)
-        shift = bn3.bias.double() - mean * scale
-        ext = torch.where(scale[None, :] > 0, outs[0].double(), outs[1].double())
-        y = (ext * scale[None, :] + shift[None, :]).float()
-        return torch.relu(y) if relu_last else y
+        gamma, beta = bn3.weight.float().contiguous(), bn3.bias.float().contiguous()
+        rm, rv, nbt, mom = tracked(bn3)
+        y = torch.empty(b, 1024, dtype=torch.float32, device=x.device)
+        nb2 = lib.b3d_bn_minmax_workspace_bytes(1024)
+        ws2 = torch.empty(nb2, dtype=torch.uint8, device=x.device)
+        _lib.check(lib.b3d_bn_minmax_apply(outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), outs[3].data_ptr(), b, 1024, n,
+                                           gamma.data_ptr(), beta.data_ptr(), rm, rv, nbt, mom, float(bn3.eps), int(relu_last),
+                                           ws2.data_ptr(), nb2, y.data_ptr(), stream), "b3d_bn_minmax_apply")
+        return y
 
 
 def _use_hip(module: nn.Module, x: torch.Tensor) -> bool:

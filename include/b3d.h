@@ -312,6 +312,25 @@ int b3d_point_feat_stats(const b3d_linear* conv, const float* x, const float* tr
 int b3d_point_feat(const b3d_linear* conv, const float* x, const float* trans, int32_t B, int32_t C, int32_t P,
                    int32_t relu_last, void* workspace, size_t workspace_bytes, float* out, b3d_stream stream);
 
+/* Train-mode BatchNorm bookkeeping of the point stacks in one or two launches each (the PyTorch form is ~25 tiny launches per
+ * layer).  b3d_bn_fold_moments: the pre-activation of a kernel-1 convolution is affine in its input, z = W h + b, so over all
+ * `count` points mean(z) = W mu + b and var(z)_o = W_o (second - mu mu^T) W_o^T with the input's mean `mu` [C] and second
+ * moments `second` [C,C] (float64, C <= 64); the batch's BatchNorm is folded into the layer (wf [O,C] = W * scale, bf [O] =
+ * b * scale + shift) and the running statistics / num_batches_tracked are updated as nn.BatchNorm1d does (momentum < 0: the
+ * cumulative average of momentum=None; NULL running statistics: not tracked).
+ * b3d_bn_minmax_apply: from the per-cloud max / min / sum / sum of squares [B,F] that b3d_point_feat_stats returns, the batch
+ * statistics over `count` points, the running-statistics update, and y [B,F] = BN(max) where the scale is positive, BN(min)
+ * where it is negative (+ ReLU). */
+int b3d_bn_fold_moments(const double* mu, const double* second, int32_t C, const float* W, const float* b, int32_t O,
+                        const float* gamma, const float* beta, float* running_mean, float* running_var,
+                        int64_t* num_batches_tracked, float momentum, float eps, int64_t count, float* wf, float* bf,
+                        b3d_stream stream);
+size_t b3d_bn_minmax_workspace_bytes(int32_t F);
+int b3d_bn_minmax_apply(const float* vmax, const float* vmin, const float* vsum, const float* vsq, int32_t B, int32_t F,
+                        int64_t count, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                        int64_t* num_batches_tracked, float momentum, float eps, int32_t relu, void* workspace,
+                        size_t workspace_bytes, float* y, b3d_stream stream);
+
 /* ---- average precision of the edge scores (train.py:18,143-150,188-196) -----------------------------------
  * torchmetrics.functional average_precision(out, gt, pos_label=1) of the whole batch (ap[0]) and of the edges of
  * every class c in 1..num_classes (ap[c], the reference's out[edge_classes == c]); count[s] = edges in the set
