@@ -177,6 +177,11 @@ def load() -> C.CDLL:
     lib.b3d_point_feat.restype = C.c_int
     lib.b3d_point_feat.argtypes = [C.POINTER(b3d_linear), C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                    C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    lib.b3d_point_moments_workspace_bytes.restype = C.c_size_t
+    lib.b3d_point_moments_workspace_bytes.argtypes = []
+    lib.b3d_point_moments.restype = C.c_int
+    lib.b3d_point_moments.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t,
+                                      C.c_void_p, C.c_void_p, C.c_void_p]
     lib.b3d_bn_fold_moments.restype = C.c_int
     lib.b3d_bn_fold_moments.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int64, C.c_void_p, C.c_void_p,

@@ -381,6 +381,176 @@ static int point_feat_launch(const b3d_linear* conv, const float* x, const float
 }
 
 
+// ---- first and second moments of a point stack's first two layer inputs (train-mode BatchNorm statistics) -----------------
+// The pre-activation of a kernel-1 convolution is affine in its input, so its batch mean / variance follow from the
+// input's mean and second-moment matrix over all B * P points (b3d_bn_fold_moments).  For the first layer the input is
+// the (transformed) point itself, K = C <= 4: plain VALU sums.  For the second layer it is h1 = relu(W1' x + b1') [64]:
+// h1 is recomputed per 16-point tile with one fp32 MFMA per 16 features in the points x features orientation, which
+// leaves a lane's 4 accumulator values on 4 points of one feature -- exactly the operand layout of h1^T h1 (both MFMA
+// arguments, k = points), so the 64 x 64 matrix accumulates in 64 registers per wavefront with no data movement.
+namespace b3d {
+namespace {
+
+constexpr int kMomGrid = 256, kMomK = 64, kMomRow = kMomK * kMomK + kMomK;
+
+struct MomArgs {
+  const float* x;       // [B, C, P]
+  const float* trans;   // [B, 3, 3] or nullptr
+  int B, C;
+  const float* w1;      // folded first layer [64, C], [64]; nullptr: moments of the input
+  const float* b1;
+  float* part;          // [kMomGrid][kMomRow] (h1) or [kMomGrid][20] (input: 16 products, 4 sums)
+};
+
+__device__ __forceinline__ void load_point(const MomArgs& a, int P, int cloud, int p, float (&f)[4]) {
+  const float* xp = a.x + ((long)cloud * a.C) * P + p;
+  f[0] = f[1] = f[2] = f[3] = 0.f;
+  for (int c = 0; c < a.C && c < 4; ++c) f[c] = xp[(long)c * P];
+  if (a.trans) {
+    const float* tr = a.trans + (long)cloud * 9;
+    const float x0 = f[0], x1 = f[1], x2 = f[2];
+    f[0] = x0 * tr[0] + x1 * tr[3] + x2 * tr[6];
+    f[1] = x0 * tr[1] + x1 * tr[4] + x2 * tr[7];
+    f[2] = x0 * tr[2] + x1 * tr[5] + x2 * tr[8];
+  }
+}
+
+__global__ __launch_bounds__(256) void point_moments_in_kernel(const MomArgs a, int P) {
+  __shared__ float red[4][20];
+  float acc[20];
+#pragma unroll
+  for (int i = 0; i < 20; ++i) acc[i] = 0.f;
+  const long n = (long)a.B * P;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    float f[4];
+    load_point(a, P, (int)(i / P), (int)(i % P), f);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[4 * r + c] = fmaf(f[r], f[c], acc[4 * r + c]);
+      acc[16 + r] += f[r];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 20; ++i) {
+    float v = acc[i];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][i] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 20) a.part[blockIdx.x * 20 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+template <int P>
+__global__ __launch_bounds__(256) void point_moments_h1_kernel(const MomArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];      // [4 wavefronts][kMomRow]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n = lane & 15, q = lane >> 4;
+  float wv[4], bv[4];
+#pragma unroll
+  for (int bi = 0; bi < 4; ++bi) {                            // B operand of the first layer: W1'[16 bi + n][q]
+    wv[bi] = q < a.C ? a.w1[(16 * bi + n) * a.C + q] : 0.f;
+    bv[bi] = a.b1[16 * bi + n];
+  }
+  v4f sec[4][4];
+  float sm[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sec[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
+  constexpr int TPC = P / 16;
+  const long tiles = (long)a.B * TPC;
+  for (long tile = (long)blockIdx.x * 4 + wave; tile < tiles; tile += (long)gridDim.x * 4) {
+    float f[4];
+    load_point(a, P, (int)(tile / TPC), (int)(tile % TPC) * 16 + n, f);
+    const float xa = q == 0 ? f[0] : q == 1 ? f[1] : q == 2 ? f[2] : f[3];     // A operand: x[point n][channel q]
+    v4f h[4];
+#pragma unroll
+    for (int bi = 0; bi < 4; ++bi) {
+      h[bi] = relu4(__builtin_amdgcn_mfma_f32_16x16x4f32(xa, wv[bi], v4f{bv[bi], bv[bi], bv[bi], bv[bi]}, 0, 0, 0));
+      sm[bi] += (h[bi].x + h[bi].y) + (h[bi].z + h[bi].w);
+    }
+#pragma unroll
+    for (int bi = 0; bi < 4; ++bi)
+#pragma unroll
+      for (int bj = 0; bj < 4; ++bj) sec[bi][bj] = mfma4(h[bi], h[bj], sec[bi][bj]);
+  }
+  float* mine = smem + wave * kMomRow;
+#pragma unroll
+  for (int bi = 0; bi < 4; ++bi) {
+#pragma unroll
+    for (int bj = 0; bj < 4; ++bj) {                          // element [16 bi + 4 q + j][16 bj + n]
+      float* d = mine + (16 * bi + 4 * q) * kMomK + 16 * bj + n;
+      d[0] = sec[bi][bj].x; d[kMomK] = sec[bi][bj].y; d[2 * kMomK] = sec[bi][bj].z; d[3 * kMomK] = sec[bi][bj].w;
+    }
+    float v = sm[bi];
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    if (q == 0) mine[kMomK * kMomK + 16 * bi + n] = v;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < kMomRow; i += 256)
+    a.part[(long)blockIdx.x * kMomRow + i] = (smem[i] + smem[kMomRow + i]) + (smem[2 * kMomRow + i] + smem[3 * kMomRow + i]);
+}
+
+// partials -> mu [K], second [K, K] = sums / count in float64 (row: KP*KP products then KP sums)
+__global__ __launch_bounds__(256) void point_moments_finish_kernel(const float* part, int rows, int KP, int K, long long count,
+                                                                   double* mu, double* second) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int row_len = KP * KP + KP;
+  if (i >= row_len) return;
+  double s = 0.0;
+  for (int r = 0; r < rows; ++r) s += (double)part[(long)r * row_len + i];
+  s /= (double)count;
+  if (i < KP * KP) {
+    const int rr = i / KP, cc = i % KP;
+    if (rr < K && cc < K) second[rr * K + cc] = s;
+  } else if (i - KP * KP < K) {
+    mu[i - KP * KP] = s;
+  }
+}
+
+}  // namespace
+}  // namespace b3d
+
+extern "C" size_t b3d_point_moments_workspace_bytes(void) { return (size_t)kMomGrid * kMomRow * sizeof(float) + 256; }
+
+extern "C" int b3d_point_moments(const b3d_linear* fold1, const float* x, const float* trans, int32_t B, int32_t C, int32_t P,
+                                 void* workspace, size_t workspace_bytes, double* mu, double* second, b3d_stream stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  B3D_REQUIRE(x && workspace && mu && second, "b3d_point_moments: null argument");
+  B3D_REQUIRE(B >= 1 && C >= 1 && C <= 4 && (P == 64 || P == 128), "b3d_point_moments: B %d, C %d, P %d (C <= 4, P 64 or 128)", B, C, P);
+  B3D_REQUIRE(!trans || C == 3, "b3d_point_moments: the input transform is 3x3");
+  B3D_REQUIRE(!fold1 || (fold1->w && fold1->b), "b3d_point_moments: null layer");
+  if (workspace_bytes < b3d_point_moments_workspace_bytes()) return fail(B3D_ERR_WORKSPACE, "b3d_point_moments: workspace too small");
+  MomArgs a;
+  a.x = x; a.trans = trans; a.B = B; a.C = C;
+  a.w1 = fold1 ? (const float*)fold1->w : nullptr;
+  a.b1 = fold1 ? (const float*)fold1->b : nullptr;
+  a.part = (float*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  const long long count = (long long)B * P;
+  if (!fold1) {
+    hipLaunchKernelGGL(point_moments_in_kernel, dim3(kMomGrid), dim3(256), 0, stream, a, (int)P);
+    B3D_TRY(launch_check("point_moments_in_kernel"));
+    hipLaunchKernelGGL(point_moments_finish_kernel, dim3(1), dim3(256), 0, stream, a.part, kMomGrid, 4, (int)C, count, mu, second);
+  } else {
+    constexpr int lds = 4 * kMomRow * (int)sizeof(float);
+    if (P == 128) {
+      B3D_TRY(set_lds(point_moments_h1_kernel<128>, lds));
+      hipLaunchKernelGGL(point_moments_h1_kernel<128>, dim3(kMomGrid), dim3(256), lds, stream, a);
+    } else {
+      B3D_TRY(set_lds(point_moments_h1_kernel<64>, lds));
+      hipLaunchKernelGGL(point_moments_h1_kernel<64>, dim3(kMomGrid), dim3(256), lds, stream, a);
+    }
+    B3D_TRY(launch_check("point_moments_h1_kernel"));
+    hipLaunchKernelGGL(point_moments_finish_kernel, dim3((kMomRow + 255) / 256), dim3(256), 0, stream, a.part, kMomGrid, kMomK, kMomK,
+                       count, mu, second);
+  }
+  return launch_check("point_moments_finish_kernel");
+}
+
+
 // ---- train-mode BatchNorm bookkeeping of the point stacks, fused (the PyTorch form is ~25 tiny launches per layer) --------
 namespace b3d {
 namespace {

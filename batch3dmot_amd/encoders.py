@@ -97,9 +97,9 @@ def point_feat_hip(convs, bns, x: torch.Tensor, trans=None, relu_last: bool = Fa
 
 
 def point_feat_train_hip(convs, bns, x: torch.Tensor, trans=None, relu_last: bool = False) -> torch.Tensor:
-    """Train-mode (batch-statistics BatchNorm) form of ``point_feat_hip``.  The first two layers are narrow: their
-    pre-activations and statistics come from PyTorch ops (0.1 % / 6 % of the stack's arithmetic); the 128 -> 1024
-    layer -- 94 % -- runs in ``b3d_point_feat_stats``, which never stores its [points, 1024] output: per cloud it
+    """Train-mode (batch-statistics BatchNorm) form of ``point_feat_hip``, all HIP.  The batch statistics of the two
+    narrow layers follow from the moments of their inputs (``b3d_point_moments`` + ``b3d_bn_fold_moments``); the
+    128 -> 1024 layer runs in ``b3d_point_feat_stats``, which never stores its [points, 1024] output: per cloud it
     returns max / min / sum / sum of squares per feature, enough for the batch statistics and for
     max_p BN(z) = scale * (max_p z if scale > 0 else min_p z) + shift.  Running statistics are updated as
     ``nn.BatchNorm1d`` would."""
@@ -111,21 +111,11 @@ def point_feat_train_hip(convs, bns, x: torch.Tensor, trans=None, relu_last: boo
     b, c, p = x.shape
     n = b * p
     with torch.no_grad():
-        xin = torch.bmm(x.transpose(2, 1), trans).transpose(2, 1) if trans is not None else x
         folded = []
-        # Batch statistics of the two narrow layers WITHOUT materialising their [B, C, P] pre-activations a second time
-        # or reducing them element by element: the pre-activation of a kernel-1 convolution is affine in its input,
-        # z = W h + b, so over all B * P points   mean(z) = W mean(h) + b,   var(z)_c = W_c Cov(h) W_c^T
-        # with the (small) second-moment matrix of the INPUT: 3x3 / 4x4 for the first layer, 64x64 for the second.
-        # The moments are accumulated by one GEMM and finished in float64.
-        def moments(h2d):                                    # h2d [n_points, C] -> (mean [C], E[h h^T] [C, C]) in float64
-            # per-cloud partial sums in fp32 (P terms each), summed over the clouds in float64: a single [C, n] x [n, C]
-            # product would be one tall-skinny GEMM (slow) with a 10^5-term fp32 accumulation (inaccurate)
-            h3 = h2d.view(b, p, h2d.size(1))
-            mu = h3.sum(1).sum(0, dtype=torch.float64) / n
-            second = torch.bmm(h3.transpose(1, 2), h3).sum(0, dtype=torch.float64) / n
-            return mu.contiguous(), second.contiguous()
-
+        # Batch statistics of the two narrow layers WITHOUT materialising their [B, C, P] pre-activations: the
+        # pre-activation of a kernel-1 convolution is affine in its input, z = W h + b, so over all B * P points
+        # mean(z) = W mean(h) + b,   var(z)_c = W_c Cov(h) W_c^T   with the (small) second-moment matrix of the INPUT:
+        # 3x3 / 4x4 for the first layer, 64x64 for the second (b3d_point_moments, accumulated on the matrix cores).
         def tracked(bn):                                      # (running_mean, running_var, num_batches_tracked, momentum)
             if not bn.track_running_stats or bn.running_mean is None:
                 return None, None, None, 0.0
@@ -136,24 +126,34 @@ def point_feat_train_hip(convs, bns, x: torch.Tensor, trans=None, relu_last: boo
                     float(bn.momentum) if bn.momentum is not None else -1.0)
 
         stream = _lib.current_stream(x.device)
-        h2d = xin.permute(0, 2, 1).reshape(n, c)
+        t = trans.float().contiguous() if trans is not None else None
+        tp = t.data_ptr() if t is not None else None
+        nbm = lib.b3d_point_moments_workspace_bytes()
+        wsm = torch.empty(nbm, dtype=torch.uint8, device=x.device)
         keep = []
+        prev = None
         for li, (cv, bn) in enumerate(zip(convs[:2], bns[:2])):
             w2d = cv.weight.squeeze(-1).float().contiguous()
             bias, gamma, beta = cv.bias.float().contiguous(), bn.weight.float().contiguous(), bn.bias.float().contiguous()
-            mu, second = moments(h2d)
-            o = w2d.size(0)
+            o, k = w2d.shape
+            mu = torch.empty(k, dtype=torch.float64, device=x.device)
+            second = torch.empty(k, k, dtype=torch.float64, device=x.device)
+            fold1 = None
+            if prev is not None:
+                fold1 = _lib.b3d_linear()
+                fold1.w, fold1.b = prev[0].data_ptr(), prev[1].data_ptr()
+            _lib.check(lib.b3d_point_moments(C.byref(fold1) if fold1 is not None else None, x.data_ptr(), tp, b, c, p,
+                                             wsm.data_ptr(), nbm, mu.data_ptr(), second.data_ptr(), stream), "b3d_point_moments")
             wf = torch.empty_like(w2d)
             bf = torch.empty(o, dtype=torch.float32, device=x.device)
             rm, rv, nbt, mom = tracked(bn)
             # mean / variance of the pre-activation, the running-statistics update and the fold: one launch
-            _lib.check(lib.b3d_bn_fold_moments(mu.data_ptr(), second.data_ptr(), w2d.size(1), w2d.data_ptr(), bias.data_ptr(), o,
+            _lib.check(lib.b3d_bn_fold_moments(mu.data_ptr(), second.data_ptr(), k, w2d.data_ptr(), bias.data_ptr(), o,
                                                gamma.data_ptr(), beta.data_ptr(), rm, rv, nbt, mom, float(bn.eps), n,
                                                wf.data_ptr(), bf.data_ptr(), stream), "b3d_bn_fold_moments")
             keep.append((w2d, bias, gamma, beta, mu, second))
-            folded.append((wf, bf))
-            if li == 0:                                       # the kernel recomputes the activations itself; only the
-                h2d = torch.relu(torch.addmm(bf, h2d, wf.t()))          # next layer's statistics need them here
+            prev = (wf, bf)
+            folded.append(prev)
         folded.append((convs[2].weight.squeeze(-1).float().contiguous(), convs[2].bias.float().contiguous()))
         layers = (_lib.b3d_linear * 3)()
         for i, (w, bias) in enumerate(folded):
@@ -161,8 +161,7 @@ def point_feat_train_hip(convs, bns, x: torch.Tensor, trans=None, relu_last: boo
         outs = torch.empty(4, b, 1024, dtype=torch.float32, device=x.device)
         nbytes = lib.b3d_point_feat_workspace_bytes()
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-        t = trans.float().contiguous() if trans is not None else None
-        _lib.check(lib.b3d_point_feat_stats(layers, x.data_ptr(), t.data_ptr() if t is not None else None, b, c, p,
+        _lib.check(lib.b3d_point_feat_stats(layers, x.data_ptr(), tp, b, c, p,
                                             ws.data_ptr(), nbytes, outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(),
                                             outs[3].data_ptr(), stream), "b3d_point_feat_stats")
         # batch statistics of the last layer, its running statistics and y = BN(max | min) (+ ReLU): two launches

@@ -312,6 +312,13 @@ int b3d_point_feat_stats(const b3d_linear* conv, const float* x, const float* tr
 int b3d_point_feat(const b3d_linear* conv, const float* x, const float* trans, int32_t B, int32_t C, int32_t P,
                    int32_t relu_last, void* workspace, size_t workspace_bytes, float* out, b3d_stream stream);
 
+/* Mean mu [K] and second moments second [K,K] = E[h h^T] (float64) over all B * P points of the input of a point stack's
+ * first layer (fold1 == NULL: h = the point, transformed by `trans` if given, K = C) or of its second layer (fold1 = the first
+ * layer with ITS BatchNorm folded in, [64,C] / [64]: h = relu(fold1(point)), K = 64). */
+size_t b3d_point_moments_workspace_bytes(void);
+int b3d_point_moments(const b3d_linear* fold1, const float* x, const float* trans, int32_t B, int32_t C, int32_t P,
+                      void* workspace, size_t workspace_bytes, double* mu, double* second, b3d_stream stream);
+
 /* Train-mode BatchNorm bookkeeping of the point stacks in one or two launches each (the PyTorch form is ~25 tiny launches per
  * layer).  b3d_bn_fold_moments: the pre-activation of a kernel-1 convolution is affine in its input, z = W h + b, so over all
  * `count` points mean(z) = W mu + b and var(z)_o = W_o (second - mu mu^T) W_o^T with the input's mean `mu` [C] and second
