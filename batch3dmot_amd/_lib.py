@@ -36,6 +36,11 @@ class b3d_gat(C.Structure):
     _fields_ = [("lin", C.c_void_p), ("att_src", C.c_void_p), ("att_dst", C.c_void_p), ("bias", C.c_void_p)]
 
 
+class b3d_batchnorm(C.Structure):
+    _fields_ = [("gamma", C.c_void_p), ("beta", C.c_void_p), ("running_mean", C.c_void_p), ("running_var", C.c_void_p),
+                ("num_batches_tracked", C.c_void_p), ("momentum", C.c_float), ("eps", C.c_float)]
+
+
 class b3d_mp_weights(C.Structure):
     _fields_ = [("edge_update", b3d_linear * 3), ("create_past_msgs", b3d_linear * 2),
                 ("create_future_msgs", b3d_linear * 2), ("combine_future_past", b3d_linear * 3)]
@@ -177,6 +182,11 @@ def load() -> C.CDLL:
     lib.b3d_point_feat.restype = C.c_int
     lib.b3d_point_feat.argtypes = [C.POINTER(b3d_linear), C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                    C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    lib.b3d_resnet_encode_workspace_bytes.restype = C.c_size_t
+    lib.b3d_resnet_encode_workspace_bytes.argtypes = [C.c_int32]
+    lib.b3d_resnet_encode.restype = C.c_int
+    lib.b3d_resnet_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p,
+                                      C.c_void_p]
     lib.b3d_point_moments_workspace_bytes.restype = C.c_size_t
     lib.b3d_point_moments_workspace_bytes.argtypes = []
     lib.b3d_point_moments.restype = C.c_int

@@ -1,0 +1,526 @@
+// ResNetAE.encode -- the frozen camera encoder of the camera+LiDAR+radar model (reference
+// models/resnet_ae.py: conv(3,12,4,2,1) -> ResidualBlock(12,24,k4,s2) -> ResidualBlock(24,48,k3,s1) ->
+// ResidualBlock(48,96,k3,s2) on [N,3,32,32] crops -> [N,96]), train-mode BatchNorm included.
+//
+// The whole encoder is 1.5 MMAC per crop (9 GFLOP per 3,000 crops) on activations of at most 12 KB per crop: what it
+// costs through the library path is launches -- ten convolutions, nine batch-statistics BatchNorms (one workgroup per
+// CHANNEL there: 12-96 workgroups on a 256-CU part), ReLUs and residual adds, ~60 launches, 0.9 ms.  Here: six phase
+// kernels.  A phase boundary sits where train-mode BatchNorm needs the statistics of the WHOLE batch before its output
+// can be formed; inside a phase everything stays in LDS.  Every phase
+//   * stages its input crops into zero-bordered LDS tiles, applying the producer's BatchNorm (scale / shift formed from
+//     the batch sums the previous phase accumulated, or from the running statistics in eval mode), the residual add and
+//     the ReLU on the way -- BatchNorm / ReLU / add never run as kernels of their own;
+//   * evaluates its convolutions as direct convolutions on the vector ALUs: lanes <-> (crop, output pixel), a
+//     wavefront <-> a group of output channels, so that the weights are wave-uniform and arrive through the scalar
+//     cache (s_load, v_fmac with an SGPR operand); one LDS read of an input value feeds all channels of the group;
+//   * writes the RAW convolution outputs and accumulates their per-channel sum and sum of squares (wavefront reduction
+//     -> LDS -> one float64 atomic per channel and workgroup).
+// Phases (crops per workgroup): P0 conv + block1.conv1 + block1.downsample (2), P1 block1.conv2 (4), P2 block2.conv1 +
+// downsample (4), P3 block2.conv2 (4), P4 block3.conv1 + downsample (16), P5 block3.conv2 (64), then the output
+// kernel (BatchNorm + add + ReLU of the last block) and the running-statistics update of all nine BatchNorms.
+#include "b3d_common.hpp"
+#include "b3d_launch.hpp"
+
+namespace b3d {
+namespace {
+
+constexpr int kConvs = 10, kBns = 9;
+// convolution order: 0 conv, 1 b1.conv1, 2 b1.conv2, 3 b1.down, 4 b2.conv1, 5 b2.conv2, 6 b2.down, 7 b3.conv1, 8 b3.conv2, 9 b3.down
+// BatchNorm order:   0 b1.bn1, 1 b1.bn2, 2 b1.down, 3 b2.bn1, 4 b2.bn2, 5 b2.down, 6 b3.bn1, 7 b3.bn2, 8 b3.down
+constexpr int kCin[kConvs] = {3, 12, 24, 12, 24, 48, 24, 48, 96, 48};
+constexpr int kCout[kConvs] = {12, 24, 24, 24, 48, 48, 48, 96, 96, 96};
+constexpr int kKer[kConvs] = {4, 4, 4, 5, 3, 3, 1, 3, 3, 3};
+constexpr int kBnC[kBns] = {24, 24, 24, 48, 48, 48, 96, 96, 96};
+constexpr int kBnPix[kBns] = {64, 16, 16, 16, 16, 16, 4, 1, 1};        // output pixels per crop behind each BatchNorm
+__host__ __device__ constexpr int conv_floats(int i) { return kCin[i] * kKer[i] * kKer[i] * kCout[i]; }
+__host__ __device__ constexpr int conv_off(int i) { int o = 0; for (int k = 0; k < i; ++k) o += conv_floats(k); return o; }
+constexpr int kWeightFloats = conv_off(kConvs);
+__host__ __device__ constexpr int bn_off(int i) { int o = 0; for (int k = 0; k < i; ++k) o += kBnC[k]; return o; }
+constexpr int kBnChannels = bn_off(kBns);                              // 504
+
+struct BnDev {
+  const float *gamma, *beta;
+  float *running_mean, *running_var;
+  long long* nbt;
+  float momentum, eps;
+};
+struct ResArgs {
+  int N, train;
+  const float* x;          // [N, 3, 32, 32]
+  const float* w;          // packed weights: conv i at conv_off(i), [ci][ky][kx][co]
+  const float* bias[kConvs];
+  BnDev bn[kBns];
+  double* sums;            // [kBnChannels][2]
+  float *z1, *zd1, *z2, *z3, *zd2, *z4, *z5, *zd3, *z6;
+  float* out;              // [N, 96]
+};
+
+// ---- weight transposition [co][ci][ky][kx] -> [ci][ky][kx][co] ------------------------------------------------------------
+struct PackW { const float* src[kConvs]; float* dst; };
+__global__ __launch_bounds__(256) void resnet_pack_kernel(const PackW p) {
+  const int i = blockIdx.y;
+  const int n = conv_floats(i), co_n = kCout[i], inner = kCin[i] * kKer[i] * kKer[i];
+  for (int t = blockIdx.x * 256 + threadIdx.x; t < n; t += gridDim.x * 256) {
+    const int co = t % co_n, k = t / co_n;
+    p.dst[conv_off(i) + t] = p.src[i][(long)co * inner + k];
+  }
+}
+
+// ---- per-channel affine of a BatchNorm: batch statistics (train) or running statistics (eval) -----------------------------
+__device__ __forceinline__ void bn_affine(const ResArgs& a, int b, int c, float& scale, float& shift) {
+  const BnDev& bn = a.bn[b];
+  float mean, var;
+  if (a.train) {
+    const double cnt = (double)a.N * kBnPix[b];
+    const double m = a.sums[2 * (bn_off(b) + c)] / cnt;
+    double v = a.sums[2 * (bn_off(b) + c) + 1] / cnt - m * m;
+    if (v < 0.0) v = 0.0;
+    mean = (float)m; var = (float)v;
+  } else {
+    mean = bn.running_mean[c]; var = bn.running_var[c];
+  }
+  scale = bn.gamma[c] / sqrtf(var + bn.eps);
+  shift = bn.beta[c] - mean * scale;
+}
+// aff[0..C) = scale, aff[C..2C) = shift
+__device__ __forceinline__ void bn_affine_to_lds(const ResArgs& a, int b, float* aff) {
+  const int C = kBnC[b];
+  for (int c = threadIdx.x; c < C; c += blockDim.x) bn_affine(a, b, c, aff[c], aff[C + c]);
+}
+
+// ---- wavefront sums of a channel's outputs -> LDS accumulators ------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row_sum16(float v) {
+  v += dpp_mov<0x128>(v);      // row_ror:8
+  v += dpp_mov<0x124>(v);
+  v += dpp_mov<0x122>(v);
+  v += dpp_mov<0x121>(v);
+  return v;
+}
+typedef unsigned u2r __attribute__((ext_vector_type(2)));
+// stat[2 c] += sum over the wavefront of v, stat[2 c + 1] += sum of v^2 (v already 0 on lanes that do not count)
+__device__ __forceinline__ void stat_add(float* stat, int c, float v) {
+  const float s = row_sum16(v), q = row_sum16(v * v);
+  const u2r r = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(q), false, false);
+  const float e = __uint_as_float(r.x) + __uint_as_float(r.y);       // lanes 0..31: s of rows {0,2} / {1,3}; 32..63: q
+  const u2r t = __builtin_amdgcn_permlane16_swap(__float_as_uint(e), __float_as_uint(e), false, false);
+  const float f = __uint_as_float(t.x) + __uint_as_float(t.y);
+  const int lane = threadIdx.x & 63;
+  if ((lane & 31) == 0) atomicAdd(&stat[2 * c + (lane >> 5)], f);
+}
+__device__ __forceinline__ void stat_flush(const ResArgs& a, int b, const float* stat) {
+  for (int i = threadIdx.x; i < 2 * kBnC[b]; i += blockDim.x) atomicAdd(&a.sums[2 * bn_off(b) + i], (double)stat[i]);
+}
+
+// ---- direct convolution on the lanes ----------------------------------------------------------------------------------------
+// in: this lane's first input element (LDS tile of its crop, channel 0, top-left tap); HP x WP: the padded tile.
+// w: the wave-uniform weights [CIN][K][K][COUT] already offset to the first channel of the group.
+// The weights are read through the CONSTANT address space: with a wave-uniform address that selects scalar loads (s_load_dwordxN
+// into SGPRs, which the FMAs take as an operand); as plain global loads every lane fetched the same 16 bytes into VGPRs and the
+// loop was bound by the vector-memory return path.  (The packed weights are written by an earlier kernel of the stream.)
+typedef const __attribute__((address_space(4))) float* cfloat_p;
+template <int CIN, int HP, int WP, int K, int CG, int COUT>
+__device__ __forceinline__ void conv_acc(const float* __restrict__ in, const float* __restrict__ w_, float (&acc)[CG]) {
+  cfloat_p w = (cfloat_p)w_;
+#pragma unroll 1
+  for (int ci = 0; ci < CIN; ++ci) {
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky) {
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx) {
+        const float v = in[(ci * HP + ky) * WP + kx];
+        cfloat_p wk = w + ((ci * K + ky) * K + kx) * COUT;
+#pragma unroll
+        for (int j = 0; j < CG; ++j) acc[j] = fmaf(wk[j], v, acc[j]);
+      }
+    }
+  }
+}
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// Occupancy is what these kernels live on: the weights of a tap arrive by scalar loads whose latency (L2 -- 20-330 KB of
+// weights do not stay in the 16 KB scalar cache) nothing inside a wavefront hides, so a CU needs many wavefronts.  The
+// first version gave every wavefront 4 crops and ALL output channels (110 KB of LDS tiles per workgroup, one wavefront
+// per SIMD): 0.92 ms for the six phases, as slow as the library path.  Now a workgroup stages FEW crops and its
+// wavefronts split the output channels, 12-20 wavefronts per CU.
+
+// ---- P0: conv -> block1.conv1 (+ statistics) and block1.downsample (+ statistics): 2 crops, 8 wavefronts -------------------
+constexpr int kP0Crops = 2;
+constexpr int kP0X = 3 * 34 * 34, kP0A = 12 * 18 * 18;
+constexpr int kP0Lds = (kP0Crops * (kP0X + kP0A) + 2 * 24 * 2) * 4;
+__global__ __launch_bounds__(512) void resnet_p0_kernel(const ResArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* xin = smem;                               // [2][3][34][34]
+  float* a0 = xin + kP0Crops * kP0X;               // [2][12][18][18]
+  float* st1 = a0 + kP0Crops * kP0A;               // [24][2] block1.bn1
+  float* std_ = st1 + 48;                          // [24][2] block1.downsample
+  for (int i = threadIdx.x; i < kP0Crops * (kP0X + kP0A) + 96; i += 512) smem[i] = 0.f;
+  const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const float* w0 = a.w + conv_off(0);
+  const float* w1 = a.w + conv_off(1);
+  const float* w3 = a.w + conv_off(3);
+  const int groups = (a.N + kP0Crops - 1) / kP0Crops;
+  for (int g = blockIdx.x; g < groups; g += gridDim.x) {
+    const int img0 = g * kP0Crops;
+    __syncthreads();                               // the previous pass is done with the tiles (and the zero fill is visible)
+    for (int i = threadIdx.x; i < kP0Crops * 3 * 1024; i += 512) {
+      const int im = i / 3072, r = i - im * 3072, c = r >> 10, y = (r >> 5) & 31, xx = r & 31;
+      const float v = img0 + im < a.N ? a.x[(long)(img0 + im) * 3072 + r] : 0.f;
+      xin[im * kP0X + (c * 34 + y + 1) * 34 + xx + 1] = v;
+    }
+    __syncthreads();
+    {                                              // conv: 3 -> 12, k4 s2 p1, 32 -> 16; wavefront <-> (crop, 4 output rows)
+      const int im = wave >> 2, oy = 4 * (wave & 3) + (lane >> 4), ox = lane & 15;
+      float acc[12];
+#pragma unroll
+      for (int j = 0; j < 12; ++j) acc[j] = a.bias[0][j];
+      conv_acc<3, 34, 34, 4, 12, 12>(xin + im * kP0X + (oy * 2) * 34 + ox * 2, w0, acc);
+#pragma unroll
+      for (int j = 0; j < 12; ++j) a0[im * kP0A + (j * 18 + oy + 1) * 18 + ox + 1] = acc[j];
+    }
+    __syncthreads();
+    {                                              // block1.conv1: 12 -> 24, k4 s2 p1, 16 -> 8; wavefront <-> (crop, 6 channels), lane <-> pixel
+      const int im = wave >> 2, c0 = 6 * (wave & 3), oy = lane >> 3, ox = lane & 7;
+      const bool valid = img0 + im < a.N;
+      float acc[6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) acc[j] = a.bias[1][c0 + j];
+      conv_acc<12, 18, 18, 4, 6, 24>(a0 + im * kP0A + (oy * 2) * 18 + ox * 2, w1 + c0, acc);
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        if (valid) a.z1[((long)(img0 + im) * 24 + c0 + j) * 64 + lane] = acc[j];
+        if (a.train) stat_add(st1, c0 + j, valid ? acc[j] : 0.f);
+      }
+    }
+    {                                              // block1.downsample: 12 -> 24, k5 s3 p0, 16 -> 4; lane <-> (crop, pixel), wavefront <-> 3 channels
+      const int im = (lane >> 4) & 1, px = lane & 15, oy = px >> 2, ox = px & 3;
+      const bool valid = lane < 32 && img0 + im < a.N;
+      const int c0 = wave * 3;
+      float acc[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[j] = a.bias[3][c0 + j];
+      conv_acc<12, 18, 18, 5, 3, 24>(a0 + im * kP0A + (oy * 3 + 1) * 18 + ox * 3 + 1, w3 + c0, acc);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        if (valid) a.zd1[((long)(img0 + im) * 24 + c0 + j) * 16 + px] = acc[j];
+        if (a.train) stat_add(std_, c0 + j, valid ? acc[j] : 0.f);
+      }
+    }
+  }
+  if (a.train) {
+    __syncthreads();
+    stat_flush(a, 0, st1);
+    stat_flush(a, 2, std_);
+  }
+}
+
+// ---- middle phases: stage relu(bn(zA) [+ bn(zB)]) into [CROPS][CIN][HP][HP] tiles, then 1-2 convolutions ------------------
+// HP: HIN + 2 for a full zero border, HIN + 1 when no tap reaches past the bottom / right edge.
+template <int CROPS, int CIN, int HIN, int HP, int NT>
+__device__ __forceinline__ void stage_tiles(const ResArgs& a, int img0, const float* zA, const float* affA, const float* zB,
+                                            const float* affB, float* tiles) {
+  constexpr int PIX = HIN * HIN;
+  for (int i = threadIdx.x; i < CROPS * CIN * PIX; i += NT) {
+    const int im = i / (CIN * PIX), r = i - im * (CIN * PIX), c = r / PIX, p = r - c * PIX;
+    float v = 0.f;
+    if (img0 + im < a.N) {
+      const long o = (long)(img0 + im) * (CIN * PIX) + r;
+      v = fmaf(zA[o], affA[c], affA[CIN + c]);
+      if (zB) v += fmaf(zB[o], affB[c], affB[CIN + c]);
+      v = fmaxf(v, 0.f);
+    }
+    tiles[(im * CIN + c) * HP * HP + (p / HIN + 1) * HP + (p % HIN) + 1] = v;
+  }
+}
+
+// One convolution of a middle phase: lanes <-> (crop, output pixel), this wavefront computes channels c0 .. c0 + CG - 1.
+// HO: output height = width; S: stride; OFF: 0 for a padded convolution (pad 1), 1 for an unpadded one (the window starts at
+// the tile's interior); LPC: lanes per crop (>= HO * HO; the others idle); CROPS: crops of the tile.
+template <int CIN, int HP, int K, int S, int OFF, int HO, int COUT, int CG, int LPC, int CROPS>
+__device__ __forceinline__ void conv_phase(const ResArgs& a, int img0, const float* tiles, const float* w, const float* bias, float* z,
+                                           float* stat, int c0) {
+  constexpr int PIX = HO * HO;
+  const int lane = threadIdx.x & 63;
+  const int im = lane / LPC, px = lane % LPC;
+  const bool active = px < PIX && im < CROPS;
+  const int oy = active ? px / HO : 0, ox = active ? px % HO : 0;
+  const bool valid = active && img0 + im < a.N;
+  const float* in = tiles + (active ? im : 0) * CIN * HP * HP + (oy * S + OFF) * HP + ox * S + OFF;
+  float acc[CG];
+#pragma unroll
+  for (int j = 0; j < CG; ++j) acc[j] = bias[c0 + j];
+  conv_acc<CIN, HP, HP, K, CG, COUT>(in, w + c0, acc);
+#pragma unroll
+  for (int j = 0; j < CG; ++j) {
+    if (valid) z[((long)(img0 + im) * COUT + c0 + j) * PIX + px] = acc[j];
+    if (a.train) stat_add(stat, c0 + j, valid ? acc[j] : 0.f);
+  }
+}
+
+// P1: block1.conv2 24 -> 24, k4 s2 p1, 8 -> 4.  4 crops, 4 wavefronts x 6 channels.
+constexpr int kP1Crops = 4;
+constexpr int kP1Lds = (kP1Crops * 24 * 10 * 10 + 48 + 48) * 4;
+__global__ __launch_bounds__(256) void resnet_p1_kernel(const ResArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* tiles = smem;
+  float* aff = tiles + kP1Crops * 24 * 100;
+  float* stat = aff + 48;
+  for (int i = threadIdx.x; i < kP1Crops * 24 * 100 + 96; i += 256) smem[i] = 0.f;
+  __syncthreads();
+  bn_affine_to_lds(a, 0, aff);
+  const int wave = uniform(threadIdx.x >> 6);
+  const int groups = (a.N + kP1Crops - 1) / kP1Crops;
+  for (int g = blockIdx.x; g < groups; g += gridDim.x) {
+    const int img0 = g * kP1Crops;
+    __syncthreads();
+    stage_tiles<kP1Crops, 24, 8, 10, 256>(a, img0, a.z1, aff, nullptr, nullptr, tiles);
+    __syncthreads();
+    conv_phase<24, 10, 4, 2, 0, 4, 24, 6, 16, kP1Crops>(a, img0, tiles, a.w + conv_off(2), a.bias[2], a.z2, stat, 6 * wave);
+  }
+  if (a.train) { __syncthreads(); stat_flush(a, 1, stat); }
+}
+
+// P2: y1 = relu(bn2(z2) + bn_d(zd1)); block2.conv1 24 -> 48 k3 s1 p1 and block2.downsample 24 -> 48 k1, 4 -> 4.
+// 4 crops, 4 wavefronts x 12 channels.
+constexpr int kP2Crops = 4;
+constexpr int kP2Lds = (kP2Crops * 24 * 36 + 48 + 48 + 96 + 96) * 4;
+__global__ __launch_bounds__(256) void resnet_p2_kernel(const ResArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* tiles = smem;
+  float* affA = tiles + kP2Crops * 24 * 36;
+  float* affB = affA + 48;
+  float* stat1 = affB + 48;
+  float* statd = stat1 + 96;
+  for (int i = threadIdx.x; i < kP2Crops * 24 * 36 + 96 + 192; i += 256) smem[i] = 0.f;
+  __syncthreads();
+  bn_affine_to_lds(a, 1, affA);
+  bn_affine_to_lds(a, 2, affB);
+  const int wave = uniform(threadIdx.x >> 6);
+  const int groups = (a.N + kP2Crops - 1) / kP2Crops;
+  for (int g = blockIdx.x; g < groups; g += gridDim.x) {
+    const int img0 = g * kP2Crops;
+    __syncthreads();
+    stage_tiles<kP2Crops, 24, 4, 6, 256>(a, img0, a.z2, affA, a.zd1, affB, tiles);
+    __syncthreads();
+    conv_phase<24, 6, 3, 1, 0, 4, 48, 12, 16, kP2Crops>(a, img0, tiles, a.w + conv_off(4), a.bias[4], a.z3, stat1, 12 * wave);
+    conv_phase<24, 6, 1, 1, 1, 4, 48, 12, 16, kP2Crops>(a, img0, tiles, a.w + conv_off(6), a.bias[6], a.zd2, statd, 12 * wave);
+  }
+  if (a.train) { __syncthreads(); stat_flush(a, 3, stat1); stat_flush(a, 5, statd); }
+}
+
+// P3: block2.conv2 48 -> 48 k3 s1 p1 on relu(bn1(z3)).  4 crops, 4 wavefronts x 12 channels.
+constexpr int kP3Crops = 4;
+constexpr int kP3Lds = (kP3Crops * 48 * 36 + 96 + 96) * 4;
+__global__ __launch_bounds__(256) void resnet_p3_kernel(const ResArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* tiles = smem;
+  float* aff = tiles + kP3Crops * 48 * 36;
+  float* stat = aff + 96;
+  for (int i = threadIdx.x; i < kP3Crops * 48 * 36 + 192; i += 256) smem[i] = 0.f;
+  __syncthreads();
+  bn_affine_to_lds(a, 3, aff);
+  const int wave = uniform(threadIdx.x >> 6);
+  const int groups = (a.N + kP3Crops - 1) / kP3Crops;
+  for (int g = blockIdx.x; g < groups; g += gridDim.x) {
+    const int img0 = g * kP3Crops;
+    __syncthreads();
+    stage_tiles<kP3Crops, 48, 4, 6, 256>(a, img0, a.z3, aff, nullptr, nullptr, tiles);
+    __syncthreads();
+    conv_phase<48, 6, 3, 1, 0, 4, 48, 12, 16, kP3Crops>(a, img0, tiles, a.w + conv_off(5), a.bias[5], a.z4, stat, 12 * wave);
+  }
+  if (a.train) { __syncthreads(); stat_flush(a, 4, stat); }
+}
+
+// P4: y2 = relu(bn2(z4) + bn_d(zd2)); block3.conv1 48 -> 96 k3 s2 p1 (4 -> 2) and block3.downsample 48 -> 96 k3 s2 p0 (4 -> 1).
+// 16 crops in 5x5 tiles (no tap reaches the bottom / right border), lane <-> (crop, pixel of the 2x2 output), 8 wavefronts
+// x 12 channels.
+constexpr int kP4Crops = 16;
+constexpr int kP4Lds = (kP4Crops * 48 * 25 + 96 + 96 + 192 + 192) * 4;
+__global__ __launch_bounds__(512) void resnet_p4_kernel(const ResArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* tiles = smem;
+  float* affA = tiles + kP4Crops * 48 * 25;
+  float* affB = affA + 96;
+  float* stat1 = affB + 96;
+  float* statd = stat1 + 192;
+  for (int i = threadIdx.x; i < kP4Crops * 48 * 25 + 192 + 384; i += 512) smem[i] = 0.f;
+  __syncthreads();
+  bn_affine_to_lds(a, 4, affA);
+  bn_affine_to_lds(a, 5, affB);
+  const int wave = uniform(threadIdx.x >> 6);
+  const int groups = (a.N + kP4Crops - 1) / kP4Crops;
+  for (int g = blockIdx.x; g < groups; g += gridDim.x) {
+    const int img0 = g * kP4Crops;
+    __syncthreads();
+    stage_tiles<kP4Crops, 48, 4, 5, 512>(a, img0, a.z4, affA, a.zd2, affB, tiles);
+    __syncthreads();
+    conv_phase<48, 5, 3, 2, 0, 2, 96, 12, 4, kP4Crops>(a, img0, tiles, a.w + conv_off(7), a.bias[7], a.z5, stat1, 12 * wave);
+    conv_phase<48, 5, 3, 2, 1, 1, 96, 12, 4, kP4Crops>(a, img0, tiles, a.w + conv_off(9), a.bias[9], a.zd3, statd, 12 * wave);
+  }
+  if (a.train) { __syncthreads(); stat_flush(a, 6, stat1); stat_flush(a, 8, statd); }
+}
+
+// P5: block3.conv2 96 -> 96 k3 s2 p1 on relu(bn1(z5)), 2 -> 1: only the taps (1..2, 1..2) meet the 2x2 input, a 384-wide
+// matrix-vector product per crop.  64 crops (lane <-> crop, rows of 385 floats: conflict-free), 16 wavefronts x 6 channels.
+constexpr int kP5Crops = 64, kP5Row = 385, kP5Threads = 1024;
+constexpr int kP5Lds = (kP5Crops * kP5Row + 192 + 192) * 4;
+__global__ __launch_bounds__(kP5Threads) void resnet_p5_kernel(const ResArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* rows = smem;
+  float* aff = rows + kP5Crops * kP5Row;
+  float* stat = aff + 192;
+  for (int i = threadIdx.x; i < 192; i += kP5Threads) stat[i] = 0.f;
+  bn_affine_to_lds(a, 6, aff);
+  const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const float* w = a.w + conv_off(8);
+  const int groups = (a.N + kP5Crops - 1) / kP5Crops;
+  for (int g = blockIdx.x; g < groups; g += gridDim.x) {
+    const int img0 = g * kP5Crops;
+    __syncthreads();
+    for (int i = threadIdx.x; i < kP5Crops * 384; i += kP5Threads) {
+      const int im = i / 384, r = i - im * 384;
+      float v = 0.f;
+      if (img0 + im < a.N) v = fmaxf(fmaf(a.z5[(long)(img0 + im) * 384 + r], aff[r >> 2], aff[96 + (r >> 2)]), 0.f);
+      rows[im * kP5Row + r] = v;
+    }
+    __syncthreads();
+    const bool valid = img0 + lane < a.N;
+    const float* in = rows + lane * kP5Row;
+    const int c0 = wave * 6;
+    float acc[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) acc[j] = a.bias[8][c0 + j];
+#pragma unroll 1
+    for (int ci = 0; ci < 96; ++ci) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const float v = in[ci * 4 + p];
+        cfloat_p wk = (cfloat_p)w + ((ci * 3 + 1 + (p >> 1)) * 3 + 1 + (p & 1)) * 96 + c0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) acc[j] = fmaf(wk[j], v, acc[j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      if (valid) a.z6[(long)(img0 + lane) * 96 + c0 + j] = acc[j];
+      if (a.train) stat_add(stat, c0 + j, valid ? acc[j] : 0.f);
+    }
+  }
+  if (a.train) { __syncthreads(); stat_flush(a, 7, stat); }
+}
+
+// out = relu(bn2(z6) + bn_d(zd3)); in train mode block 0.. also update the running statistics of all nine BatchNorms
+__global__ __launch_bounds__(256) void resnet_out_kernel(const ResArgs a) {
+  const long n = (long)a.N * 96;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % 96);
+    float s1, t1, s2, t2;
+    bn_affine(a, 7, c, s1, t1);
+    bn_affine(a, 8, c, s2, t2);
+    a.out[i] = fmaxf(fmaf(a.z6[i], s1, t1) + fmaf(a.zd3[i], s2, t2), 0.f);
+  }
+}
+__global__ __launch_bounds__(128) void resnet_track_kernel(const ResArgs a) {
+  const int b = blockIdx.x, c = threadIdx.x;
+  const BnDev& bn = a.bn[b];
+  if (!bn.running_mean) return;
+  const long long nbt_after = bn.nbt ? *bn.nbt + 1 : 1;
+  if (c < kBnC[b]) {
+    const double cnt = (double)a.N * kBnPix[b];
+    const double m = a.sums[2 * (bn_off(b) + c)] / cnt;
+    double v = a.sums[2 * (bn_off(b) + c) + 1] / cnt - m * m;
+    if (v < 0.0) v = 0.0;
+    const double mom = bn.momentum >= 0.f ? (double)bn.momentum : 1.0 / (double)nbt_after;
+    const double unbiased = (double)(float)v * (cnt / (cnt > 1.0 ? cnt - 1.0 : 1.0));
+    bn.running_mean[c] = (float)((1.0 - mom) * (double)bn.running_mean[c] + mom * (double)(float)m);
+    bn.running_var[c] = (float)((1.0 - mom) * (double)bn.running_var[c] + mom * (double)(float)unbiased);
+  }
+  __syncthreads();
+  if (c == 0 && bn.nbt) *bn.nbt = nbt_after;
+}
+
+constexpr size_t kActFloatsPerCrop = 24 * 64 + 24 * 16 + 24 * 16 + 48 * 16 + 48 * 16 + 48 * 16 + 96 * 4 + 96 + 96;
+
+}  // namespace
+}  // namespace b3d
+
+using namespace b3d;
+
+extern "C" size_t b3d_resnet_encode_workspace_bytes(int32_t N) {
+  if (N < 0) N = 0;
+  return 256 + (size_t)kWeightFloats * 4 + 256 + (size_t)kBnChannels * 2 * 8 + 256 + (size_t)N * kActFloatsPerCrop * 4 + 64;
+}
+
+extern "C" int b3d_resnet_encode(const b3d_linear* conv, const b3d_batchnorm* bn, const float* x, int32_t N, int32_t train,
+                                 void* workspace, size_t workspace_bytes, float* out, b3d_stream stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  B3D_REQUIRE(conv && bn && workspace && (N == 0 || (x && out)), "b3d_resnet_encode: null argument");
+  B3D_REQUIRE(N >= 0, "b3d_resnet_encode: N %d", (int)N);
+  for (int i = 0; i < kConvs; ++i) B3D_REQUIRE(conv[i].w && conv[i].b, "b3d_resnet_encode: null convolution %d", i);
+  for (int i = 0; i < kBns; ++i) {
+    B3D_REQUIRE(bn[i].gamma && bn[i].beta, "b3d_resnet_encode: null BatchNorm %d", i);
+    B3D_REQUIRE((bn[i].running_mean == nullptr) == (bn[i].running_var == nullptr), "b3d_resnet_encode: running statistics come as a pair");
+    B3D_REQUIRE(train || bn[i].running_mean, "b3d_resnet_encode: eval mode needs the running statistics of BatchNorm %d", i);
+  }
+  B3D_REQUIRE(!train || N != 1, "b3d_resnet_encode: batch statistics need more than one value per channel");
+  if (workspace_bytes < b3d_resnet_encode_workspace_bytes(N)) return fail(B3D_ERR_WORKSPACE, "b3d_resnet_encode: workspace too small");
+  if (N == 0) return B3D_OK;
+  auto align = [](uintptr_t p) { return (p + 255) & ~(uintptr_t)255; };
+  uintptr_t p = align((uintptr_t)workspace);
+  float* wp = (float*)p; p = align(p + (size_t)kWeightFloats * 4);
+  double* sums = (double*)p; p = align(p + (size_t)kBnChannels * 16);
+  float* act = (float*)p;
+  ResArgs a;
+  a.N = N; a.train = train ? 1 : 0; a.x = x; a.w = wp; a.sums = sums; a.out = out;
+  for (int i = 0; i < kConvs; ++i) a.bias[i] = (const float*)conv[i].b;
+  for (int i = 0; i < kBns; ++i) {
+    a.bn[i].gamma = bn[i].gamma; a.bn[i].beta = bn[i].beta;
+    a.bn[i].running_mean = bn[i].running_mean; a.bn[i].running_var = bn[i].running_var;
+    a.bn[i].nbt = (long long*)bn[i].num_batches_tracked; a.bn[i].momentum = bn[i].momentum; a.bn[i].eps = bn[i].eps;
+  }
+  const size_t n = (size_t)N;
+  a.z1 = act; act += n * 24 * 64;
+  a.zd1 = act; act += n * 24 * 16;
+  a.z2 = act; act += n * 24 * 16;
+  a.z3 = act; act += n * 48 * 16;
+  a.zd2 = act; act += n * 48 * 16;
+  a.z4 = act; act += n * 48 * 16;
+  a.z5 = act; act += n * 96 * 4;
+  a.zd3 = act; act += n * 96;
+  a.z6 = act;
+  PackW pw;
+  for (int i = 0; i < kConvs; ++i) pw.src[i] = (const float*)conv[i].w;
+  pw.dst = wp;
+  hipLaunchKernelGGL(resnet_pack_kernel, dim3(16, kConvs), dim3(256), 0, stream, pw);
+  B3D_TRY(launch_check("resnet_pack_kernel"));
+  if (train) B3D_HIP_CHECK(hipMemsetAsync(sums, 0, (size_t)kBnChannels * 16, stream));
+  auto grid = [&](int crops) { const int g = (N + crops - 1) / crops; return dim3((unsigned)(g < 2048 ? g : 2048)); };
+  B3D_TRY(set_lds(resnet_p0_kernel, kP0Lds));
+  hipLaunchKernelGGL(resnet_p0_kernel, grid(kP0Crops), dim3(512), kP0Lds, stream, a);
+  B3D_TRY(launch_check("resnet_p0_kernel"));
+  B3D_TRY(set_lds(resnet_p1_kernel, kP1Lds));
+  hipLaunchKernelGGL(resnet_p1_kernel, grid(kP1Crops), dim3(256), kP1Lds, stream, a);
+  B3D_TRY(launch_check("resnet_p1_kernel"));
+  B3D_TRY(set_lds(resnet_p2_kernel, kP2Lds));
+  hipLaunchKernelGGL(resnet_p2_kernel, grid(kP2Crops), dim3(256), kP2Lds, stream, a);
+  B3D_TRY(launch_check("resnet_p2_kernel"));
+  B3D_TRY(set_lds(resnet_p3_kernel, kP3Lds));
+  hipLaunchKernelGGL(resnet_p3_kernel, grid(kP3Crops), dim3(256), kP3Lds, stream, a);
+  B3D_TRY(launch_check("resnet_p3_kernel"));
+  B3D_TRY(set_lds(resnet_p4_kernel, kP4Lds));
+  hipLaunchKernelGGL(resnet_p4_kernel, grid(kP4Crops), dim3(512), kP4Lds, stream, a);
+  B3D_TRY(launch_check("resnet_p4_kernel"));
+  B3D_TRY(set_lds(resnet_p5_kernel, kP5Lds));
+  hipLaunchKernelGGL(resnet_p5_kernel, grid(kP5Crops), dim3(kP5Threads), kP5Lds, stream, a);
+  B3D_TRY(launch_check("resnet_p5_kernel"));
+  hipLaunchKernelGGL(resnet_out_kernel, dim3((unsigned)((n * 96 + 255) / 256 < 1024 ? (n * 96 + 255) / 256 : 1024)), dim3(256), 0, stream, a);
+  B3D_TRY(launch_check("resnet_out_kernel"));
+  if (train) {
+    hipLaunchKernelGGL(resnet_track_kernel, dim3(kBns), dim3(128), 0, stream, a);
+    B3D_TRY(launch_check("resnet_track_kernel"));
+  }
+  return B3D_OK;
+}

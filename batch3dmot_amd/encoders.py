@@ -187,6 +187,67 @@ def _use_hip_train(module: nn.Module, x: torch.Tensor) -> bool:
             and not any(p.requires_grad for p in module.parameters()) and not x.requires_grad)
 
 
+def _no_autograd(module: nn.Module, x: torch.Tensor) -> bool:
+    return not torch.is_grad_enabled() or not (x.requires_grad or any(p.requires_grad for p in module.parameters()))
+
+
+def _use_hip_resnet_train(module: nn.Module, x: torch.Tensor) -> bool:
+    return (x.is_cuda and module.training and getattr(module, "use_hip", True) and x.size(0) > 1
+            and not any(p.requires_grad for p in module.parameters()) and not x.requires_grad)
+
+
+def resnet_encode_hip(m: "ResNetAE", x: torch.Tensor) -> torch.Tensor:
+    """``ResNetAE.encode`` in six HIP phase kernels (``b3d_resnet_encode``): direct convolutions with the producer's
+    BatchNorm / residual add / ReLU applied while the next phase stages its input; in train mode the batch statistics
+    are accumulated by the producing phase and the running statistics updated as ``nn.BatchNorm2d`` does.  No autograd
+    (the GNN holds the encoder frozen, clr_att_gnn.py:26-33)."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    x = x.float().contiguous()
+    _lib.require_cuda(x, "image crops", torch.float32)
+    if x.dim() != 4 or tuple(x.shape[1:]) != (3, 32, 32):
+        raise ValueError(f"resnet_encode_hip: crops are [N, 3, 32, 32], got {tuple(x.shape)}")
+    blocks = (m.res_block1, m.res_block2, m.res_block3)
+    for blk in blocks:
+        if not (isinstance(blk.downsample, nn.Sequential) and len(blk.downsample) == 2):
+            raise ValueError("resnet_encode_hip: every block of ResNetAE has a conv + BatchNorm downsample branch")
+    convs = [m.conv] + [c for blk in blocks for c in (blk.conv1, blk.conv2, blk.downsample[0])]
+    bns = [b for blk in blocks for b in (blk.bn1, blk.bn2, blk.downsample[1])]
+    train = bool(m.training)
+    n = x.size(0)
+    keep = []
+
+    def f32(t_):
+        t_ = t_.detach().float().contiguous()
+        _lib.require_cuda(t_, "ResNetAE parameter", torch.float32)
+        keep.append(t_)
+        return t_.data_ptr()
+
+    cl = (_lib.b3d_linear * 10)()
+    for i, cv in enumerate(convs):
+        cl[i].w, cl[i].b = f32(cv.weight), f32(cv.bias)
+    bl = (_lib.b3d_batchnorm * 9)()
+    for i, bn in enumerate(bns):
+        bl[i].gamma, bl[i].beta = f32(bn.weight), f32(bn.bias)
+        tracked = bn.track_running_stats and bn.running_mean is not None
+        if tracked:
+            _lib.require_cuda(bn.running_mean, "BatchNorm running statistic", torch.float32)
+            _lib.require_cuda(bn.running_var, "BatchNorm running statistic", torch.float32)
+            bl[i].running_mean, bl[i].running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+            bl[i].num_batches_tracked = bn.num_batches_tracked.data_ptr() if train else None
+        elif not train:
+            raise ValueError("resnet_encode_hip: eval mode needs running statistics")
+        bl[i].momentum = float(bn.momentum) if bn.momentum is not None else -1.0
+        bl[i].eps = float(bn.eps)
+    out = torch.empty(n, 96, dtype=torch.float32, device=x.device)
+    nbytes = lib.b3d_resnet_encode_workspace_bytes(n)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    _lib.check(lib.b3d_resnet_encode(cl, bl, x.data_ptr(), n, int(train), ws.data_ptr(), nbytes, out.data_ptr(),
+                                     _lib.current_stream(x.device)), "b3d_resnet_encode")
+    return out
+
+
 def reference_order_(module: nn.Module) -> nn.Module:
     """Make every sub-module evaluate operation for operation as the reference does (no HIP kernels, no BatchNorm
     folding): what the CPU oracle runs on."""
@@ -241,6 +302,8 @@ class ResNetAE(nn.Module):
             nn.ConvTranspose2d(12, 3, 4, stride=2, padding=1), nn.Sigmoid())
 
     def encode(self, x):
+        if (_use_hip(self, x) and _no_autograd(self, x)) or _use_hip_resnet_train(self, x):
+            return resnet_encode_hip(self, x)
         out = self.res_block3(self.res_block2(self.res_block1(self.conv(x))))
         return out.view(out.size(0), -1)
 

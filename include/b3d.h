@@ -312,6 +312,23 @@ int b3d_point_feat_stats(const b3d_linear* conv, const float* x, const float* tr
 int b3d_point_feat(const b3d_linear* conv, const float* x, const float* trans, int32_t B, int32_t C, int32_t P,
                    int32_t relu_last, void* workspace, size_t workspace_bytes, float* out, b3d_stream stream);
 
+/* ResNetAE.encode (reference models/resnet_ae.py: conv(3,12,4,2,1), ResidualBlock(12,24,k4,s2), ResidualBlock(24,48,k3,s1),
+ * ResidualBlock(48,96,k3,s2)) on x [N,3,32,32] -> out [N,96], BatchNorm in train mode (`train` != 0: batch statistics, running
+ * statistics and num_batches_tracked updated as nn.BatchNorm2d does) or eval mode (running statistics).
+ * conv[10]: conv, block1.{conv1,conv2,downsample.0}, block2.{...}, block3.{...}, weights [out,in,k,k];
+ * bn[9]: block1.{bn1,bn2,downsample.1}, block2.{...}, block3.{...}.  momentum < 0: cumulative average (momentum=None). */
+typedef struct b3d_batchnorm {
+  const float* gamma;
+  const float* beta;
+  float* running_mean;             /* NULL (with running_var): statistics not tracked; train mode only */
+  float* running_var;
+  int64_t* num_batches_tracked;    /* may be NULL */
+  float momentum, eps;
+} b3d_batchnorm;
+size_t b3d_resnet_encode_workspace_bytes(int32_t N);
+int b3d_resnet_encode(const b3d_linear* conv, const b3d_batchnorm* bn, const float* x, int32_t N, int32_t train,
+                      void* workspace, size_t workspace_bytes, float* out, b3d_stream stream);
+
 /* Mean mu [K] and second moments second [K,K] = E[h h^T] (float64) over all B * P points of the input of a point stack's
  * first layer (fold1 == NULL: h = the point, transformed by `trans` if given, K = C) or of its second layer (fold1 = the first
  * layer with ITS BatchNorm folded in, [64,C] / [64]: h = relu(fold1(point)), K = 64). */

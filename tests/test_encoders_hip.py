@@ -151,3 +151,65 @@ def test_train_mode_with_frozen_parameters_uses_batch_statistics(kind, b):
             assert rel(b1, b2) < TOL, n1
         else:
             assert torch.equal(b1, b2), n1                  # num_batches_tracked
+
+
+@pytest.mark.parametrize("n", [1500, 37, 5])
+def test_resnet_encode_train_mode_matches_the_pytorch_modules(n):
+    """``ResNetAE.encode`` as the GNN runs it during training (frozen, train mode: batch-statistics BatchNorm, running
+    statistics updated): the six HIP phase kernels against the PyTorch modules (MIOpen convolutions + BatchNorm)."""
+    import copy
+    from batch3dmot_amd import encoders
+    dev = torch.device("cuda:0")
+    m = encoders.ResNetAE()
+    seeded_fill_(m, 21)
+    _randomise_bn(m, 22)
+    with torch.no_grad():                                   # negative scales too
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.weight.mul_(torch.where(torch.arange(mod.num_features) % 4 == 0, -1.0, 1.0))
+    for p in m.parameters():
+        p.requires_grad = False
+    m = m.to(dev).train()
+    ref = copy.deepcopy(m)
+    for mod in ref.modules():
+        mod.use_hip = False
+    g = torch.Generator().manual_seed(5)
+    for step in range(2):                                   # two steps: the running statistics compound
+        x = torch.rand(n, 3, 32, 32, generator=g).to(dev)
+        with torch.no_grad():
+            got, want = m.encode(x), ref.encode(x)
+        assert got.shape == (n, 96)
+        # n = 5: the last BatchNorms see 5 values per channel, their normalised output amplifies rounding differences
+        assert rel(got, want) < (2e-5 if n > 5 else 1e-3), (step, rel(got, want))
+    for (k, a), (_, b) in zip(m.state_dict().items(), ref.state_dict().items()):
+        if "running" in k:
+            assert rel(a, b) < 1e-5, k
+        elif "num_batches_tracked" in k:
+            assert int(a) == int(b), k
+    # block 1/2/3 BatchNorms were exercised, the unused top-level `bn` was not
+    assert int(m.res_block3.bn2.num_batches_tracked) == 2 and int(m.bn.num_batches_tracked) == 0
+
+
+def test_resnet_encode_eval_mode_and_argument_checks():
+    import copy
+    from batch3dmot_amd import encoders, _lib
+    dev = torch.device("cuda:0")
+    m = encoders.ResNetAE()
+    seeded_fill_(m, 23)
+    _randomise_bn(m, 24)
+    m = m.to(dev).eval()
+    ref = encoders.reference_order_(copy.deepcopy(m))
+    for n in (1, 65, 1000):
+        x = torch.rand(n, 3, 32, 32, device=dev)
+        with torch.no_grad():
+            got, want = m.encode(x), ref.encode(x)
+        assert rel(got, want) < 1e-5
+    before = copy.deepcopy(m.state_dict())
+    with torch.no_grad():
+        m.encode(torch.rand(4, 3, 32, 32, device=dev))
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, before[k]), k                 # eval mode leaves the statistics alone
+    with pytest.raises(ValueError):
+        encoders.resnet_encode_hip(m, torch.rand(4, 3, 16, 16, device=dev))
+    lib = _lib.load()
+    assert lib.b3d_resnet_encode(None, None, None, 4, 0, None, 0, None, None) != 0
