@@ -10,6 +10,21 @@
 
 namespace b3d {
 namespace clr {
+// several small buffers zeroed by one launch (one memset node each costs ~4 us of a captured step)
+constexpr int kZeroMax = 24;
+struct ZeroArgs { float* p[kZeroMax]; int n[kZeroMax]; int count; };
+__global__ __launch_bounds__(256) void zero_many_kernel(const ZeroArgs a) {
+  const int k = blockIdx.y;
+  if (k >= a.count) return;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < a.n[k]; i += gridDim.x * 256) a.p[k][i] = 0.f;
+}
+inline void zero_add(ZeroArgs& z, float* p, size_t n) { if (p && n && z.count < kZeroMax) { z.p[z.count] = p; z.n[z.count] = (int)n; ++z.count; } }
+inline int zero_launch(ZeroArgs& z, hipStream_t stream) {
+  if (z.count == 0) return B3D_OK;
+  hipLaunchKernelGGL(zero_many_kernel, dim3(16, z.count), dim3(256), 0, stream, z);
+  z.count = 0;
+  return launch_check("zero_many_kernel");
+}
 
 using D = DimsC;
 using DB = DimsCB;                       // hoisted kernels: bf16x3 images for the edge stacks
@@ -1078,15 +1093,18 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
     put(CF0, gr->mp.combine_future_past, 3);
     const b3d_mha_grad* mg[3] = {&gr->c2c_att, &gr->l2l_att, &gr->r2r_att};
     const int dd[3] = {96, 128, 64};
+    ZeroArgs zz;
+    zz.count = 0;
     for (int m = 0; m < 3; ++m) {
       // q / k thirds of in_proj receive no gradient (softmax over one key is constant)
-      if (mg[m]->in_proj_weight) B3D_HIP_CHECK(hipMemsetAsync(mg[m]->in_proj_weight, 0, (size_t)3 * dd[m] * dd[m] * sizeof(float), stream));
-      if (mg[m]->in_proj_bias) B3D_HIP_CHECK(hipMemsetAsync(mg[m]->in_proj_bias, 0, (size_t)3 * dd[m] * sizeof(float), stream));
+      zero_add(zz, mg[m]->in_proj_weight, (size_t)3 * dd[m] * dd[m]);
+      zero_add(zz, mg[m]->in_proj_bias, (size_t)3 * dd[m]);
       dw[AVC + 2 * m] = mg[m]->in_proj_weight ? mg[m]->in_proj_weight + (size_t)2 * dd[m] * dd[m] : nullptr;
       db[AVC + 2 * m] = mg[m]->in_proj_bias ? mg[m]->in_proj_bias + 2 * dd[m] : nullptr;
       dw[AOC + 2 * m] = mg[m]->out_proj_weight;
       db[AOC + 2 * m] = mg[m]->out_proj_bias;
     }
+    B3D_TRY(zero_launch(zz, stream));            // in front of every reduction: they write the v third of in_proj
     RedArgs ra;
     ra.nentries = 0;
     for (int i = 0; i < LIN_COUNT; ++i) {
@@ -1106,13 +1124,15 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
         }
       }
       if (!ls.used) {
-        if (dw[i]) B3D_HIP_CHECK(hipMemsetAsync(dw[i], 0, (size_t)ls.N * ls.K * sizeof(float), stream));
-        if (db[i]) B3D_HIP_CHECK(hipMemsetAsync(db[i], 0, (size_t)ls.N * sizeof(float), stream));
+        if (zz.count + 2 > kZeroMax) B3D_TRY(zero_launch(zz, stream));
+        zero_add(zz, dw[i], (size_t)ls.N * ls.K);
+        zero_add(zz, db[i], (size_t)ls.N);
         continue;
       }
       ra.e[ra.nentries++] = red_entry(ls, dw[i], db[i]);
       if (ra.nentries == kRedMaxEntries) { B3D_TRY(launch_reduce(ra, stream)); ra.nentries = 0; }
     }
+    B3D_TRY(zero_launch(zz, stream));            // gradients of layers that took no part (disjoint from the reductions)
     B3D_TRY(launch_reduce(ra, stream));
   }
   B3D_TRY(b3d_side_join(stream_));

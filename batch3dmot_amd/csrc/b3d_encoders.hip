@@ -494,14 +494,21 @@ __global__ __launch_bounds__(256) void point_moments_h1_kernel(const MomArgs a) 
     a.part[(long)blockIdx.x * kMomRow + i] = (smem[i] + smem[kMomRow + i]) + (smem[2 * kMomRow + i] + smem[3 * kMomRow + i]);
 }
 
-// partials -> mu [K], second [K, K] = sums / count in float64 (row: KP*KP products then KP sums)
-__global__ __launch_bounds__(256) void point_moments_finish_kernel(const float* part, int rows, int KP, int K, long long count,
-                                                                   double* mu, double* second) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+// partials -> mu [K], second [K, K] = sums / count in float64 (row: KP*KP products then KP sums).  A workgroup owns 16
+// columns; 64 threads per column split the rows (a thread per column walking all 256 rows was 52 us of load latency).
+__global__ __launch_bounds__(1024) void point_moments_finish_kernel(const float* part, int rows, int KP, int K, long long count,
+                                                                    double* mu, double* second) {
+  __shared__ double red[64][17];
+  const int col = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + col;
   const int row_len = KP * KP + KP;
-  if (i >= row_len) return;
   double s = 0.0;
-  for (int r = 0; r < rows; ++r) s += (double)part[(long)r * row_len + i];
+  if (i < row_len)
+    for (int r = rl; r < rows; r += 64) s += (double)part[(long)r * row_len + i];
+  red[rl][col] = s;
+  __syncthreads();
+  if (rl != 0 || i >= row_len) return;
+  for (int r = 1; r < 64; ++r) s += red[r][col];
   s /= (double)count;
   if (i < KP * KP) {
     const int rr = i / KP, cc = i % KP;
@@ -533,7 +540,7 @@ extern "C" int b3d_point_moments(const b3d_linear* fold1, const float* x, const 
   if (!fold1) {
     hipLaunchKernelGGL(point_moments_in_kernel, dim3(kMomGrid), dim3(256), 0, stream, a, (int)P);
     B3D_TRY(launch_check("point_moments_in_kernel"));
-    hipLaunchKernelGGL(point_moments_finish_kernel, dim3(1), dim3(256), 0, stream, a.part, kMomGrid, 4, (int)C, count, mu, second);
+    hipLaunchKernelGGL(point_moments_finish_kernel, dim3(2), dim3(1024), 0, stream, a.part, kMomGrid, 4, (int)C, count, mu, second);
   } else {
     constexpr int lds = 4 * kMomRow * (int)sizeof(float);
     if (P == 128) {
@@ -544,7 +551,7 @@ extern "C" int b3d_point_moments(const b3d_linear* fold1, const float* x, const 
       hipLaunchKernelGGL(point_moments_h1_kernel<64>, dim3(kMomGrid), dim3(256), lds, stream, a);
     }
     B3D_TRY(launch_check("point_moments_h1_kernel"));
-    hipLaunchKernelGGL(point_moments_finish_kernel, dim3((kMomRow + 255) / 256), dim3(256), 0, stream, a.part, kMomGrid, kMomK, kMomK,
+    hipLaunchKernelGGL(point_moments_finish_kernel, dim3((kMomRow + 15) / 16), dim3(1024), 0, stream, a.part, kMomGrid, kMomK, kMomK,
                        count, mu, second);
   }
   return launch_check("point_moments_finish_kernel");
@@ -608,7 +615,10 @@ __global__ __launch_bounds__(256) void bn_fold_moments_kernel(const BnFoldArgs a
   if (lane < a.C) a.wf[(size_t)o * a.C + lane] = w[lane] * scale;
   if (lane == 0) {
     a.bf[o] = a.b[o] * scale + shift;
-    bn_track(a.running_mean, a.running_var, o, mean, var, a.count, a.momentum, a.nbt ? *a.nbt + 1 : 1);
+    bn_track(a.running_mean, a.running_var, o, mean, var, a.count, a.momentum, (a.nbt && a.momentum < 0.f) ? *a.nbt + 1 : 1);
+    // with a fixed momentum nobody reads the counter: it is advanced here; the cumulative average reads it in every
+    // workgroup, there the host launches bn_tick_kernel behind this kernel
+    if (o == 0 && a.nbt && a.momentum >= 0.f) *a.nbt += 1;
   }
 }
 
@@ -646,8 +656,9 @@ __global__ __launch_bounds__(256) void bn_minmax_apply_kernel(const BnMinMaxArgs
   const double scale = (double)a.gamma[f] / sqrt(var + (double)a.eps);
   const double shift = (double)a.beta[f] - mean * scale;
   if (blockIdx.y == 0) {
-    const long long nbt_after = a.nbt ? *a.nbt + 1 : 1;
+    const long long nbt_after = (a.nbt && a.momentum < 0.f) ? *a.nbt + 1 : 1;
     bn_track(a.running_mean, a.running_var, f, (double)(float)mean, (double)(float)var, a.count, a.momentum, nbt_after);
+    if (f == 0 && a.nbt && a.momentum >= 0.f) *a.nbt += 1;       // fixed momentum: nobody reads the counter (see bn_fold_moments_kernel)
   }
   const int per = (a.B + gridDim.y - 1) / gridDim.y;
   const int b0 = blockIdx.y * per, b1 = min(a.B, b0 + per);
@@ -674,7 +685,7 @@ extern "C" int b3d_bn_fold_moments(const double* mu, const double* second, int32
                (long long)count, wf, bf};
   hipLaunchKernelGGL(bn_fold_moments_kernel, dim3((unsigned)((O + 3) / 4)), dim3(256), 0, (hipStream_t)stream_, a);
   B3D_TRY(launch_check("bn_fold_moments_kernel"));
-  if (num_batches_tracked) {
+  if (num_batches_tracked && momentum < 0.f) {
     hipLaunchKernelGGL(bn_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream_, (long long*)num_batches_tracked);
     B3D_TRY(launch_check("bn_tick_kernel"));
   }
@@ -698,7 +709,7 @@ extern "C" int b3d_bn_minmax_apply(const float* vmax, const float* vmin, const f
   B3D_TRY(launch_check("bn_minmax_partial_kernel"));
   hipLaunchKernelGGL(bn_minmax_apply_kernel, dim3(fb, 32), dim3(256), 0, stream, a);
   B3D_TRY(launch_check("bn_minmax_apply_kernel"));
-  if (num_batches_tracked) {
+  if (num_batches_tracked && momentum < 0.f) {
     hipLaunchKernelGGL(bn_tick_kernel, dim3(1), dim3(1), 0, stream, (long long*)num_batches_tracked);
     B3D_TRY(launch_check("bn_tick_kernel"));
   }
