@@ -5,6 +5,7 @@
 #include "b3d_knn.hpp"
 #include "b3d_wstream.hpp"
 #include "b3d_wstream2.hpp"
+#include "b3d_wgemm.hpp"
 #include "b3d_hoist.hpp"
 #include "b3d_att.hpp"
 
@@ -931,18 +932,102 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
 
   // ---- streamed weight gradients: message-passing stacks (all layers) + att_edge_encoder -------------
   {
-    WsLauncher wl;
-    wl.begin(w.ws_table, kTableCap, w.ws_task_job, kTaskCap, stream);
+    // Hoisted plan: the cooperative bf16x6 kernel (b3d_wgemm.hpp) takes every block it has a shape for; the per-wavefront
+    // streaming kernel keeps the rest (and everything when B3D_WGEMM=0).  Both share the device tables, split in halves.
+    static const bool wgemm_on = [] { const char* e = getenv("B3D_WGEMM"); return e ? atoi(e) != 0 : true; }();
+    const bool coop = wgemm_on && w.hoist;
+    WsLauncher wl, wlc;
+    wl.begin(w.ws_table, kTableCap / 2, w.ws_task_job, kTaskCap / 2, stream);
+    wlc.begin(w.ws_table + kTableCap / 2, kTableCap / 2, w.ws_task_job + kTaskCap / 2, kTaskCap / 2, stream);
     hipLaunchKernelGGL(iota_kernel, dim3(((E > N ? E : N) + 255) / 256), dim3(256), 0, stream, w.iota, E > N ? E : N);
     B3D_TRY(launch_check("iota_kernel"));
     B3D_HIP_CHECK(hipMemsetAsync(w.zrow, 0, 256 * sizeof(float), stream));
     const int* iota = w.iota;
     struct Col { const float* p; const int* idx; long vstride; int stride; int col0; int width; };   // activation columns
     // Every (64-row group of G) x (<= 96-column group of an activation segment) pair is one job.
+    // Cooperative decomposition: column groups of <= 256 per activation segment, row groups chosen per column group
+    // from the compiled shapes; false (nothing added) if some pair has none.
+    auto col_groups = [](int width, int* out) -> int {
+      switch (width) {
+        case 512: out[0] = 256; out[1] = 256; return 2;
+        case 384: out[0] = 256; out[1] = 128; return 2;
+        case 288: out[0] = 192; out[1] = 96; return 2;
+        case 256: case 192: case 128: case 96: case 64: out[0] = width; return 1;
+        default: return 0;
+      }
+    };
+    auto row_groups = [](int n, int kg, int* out) -> int {
+      int k = 0;
+      if (kg <= 96) {
+        while (n >= 256) { out[k++] = 256; n -= 256; }
+        while (n >= 192) { out[k++] = 192; n -= 192; }
+        if (n == 128 && kg == 96) { out[k++] = 128; n = 0; }
+      } else if (kg == 128) {
+        if (n % 192 == 0) while (n > 0) { out[k++] = 192; n -= 192; }
+        while (n >= 128) { out[k++] = 128; n -= 128; }
+        if (n == 96 || n == 64) { out[k++] = n; n = 0; }
+      } else {
+        while (n >= 128) { out[k++] = 128; n -= 128; }
+      }
+      return n == 0 ? k : -1;
+    };
+    auto add_block_coop = [&](LinSlab& ls, long rows, int nvar, int rpt, const float* gp, const int* gidx, long gvs, int gstride,
+                              int gcol0, const Col* cols, int ncols, bool with_bias) -> bool {
+      WsJob jobs[48];
+      int nj = 0;
+      int wcol = 0;
+      for (int ci = 0; ci < ncols; ++ci) {
+        if (cols[ci].idx) return false;                      // gathered activations: streaming kernel
+        if ((uintptr_t)cols[ci].p % 16 != 0 || cols[ci].stride % 4 != 0 || cols[ci].col0 % 4 != 0 || cols[ci].vstride % 4 != 0) return false;
+        int cg[4];
+        int ncg = col_groups(cols[ci].width, cg);
+        if (ncg == 0) return false;
+        int c0 = 0;
+        for (int k = 0; k < ncg; ++k) {
+          int kgs[4] = {cg[k], 0, 0, 0}, nk = 1;
+          int rg[8];
+          int nr = row_groups(ls.N, cg[k], rg);
+          if (nr < 0 && cg[k] > 128) {                       // 192 x 256 and the like: narrower column groups
+            nk = 0;
+            for (int left = cg[k]; left > 0;) { const int t = left >= 128 ? 128 : left; kgs[nk++] = t; left -= t; }
+          }
+          for (int kk = 0; kk < nk; ++kk) {
+            nr = row_groups(ls.N, kgs[kk], rg);
+            if (nr < 0) return false;
+            int g0 = 0;
+            for (int r = 0; r < nr; ++r) {
+              const int shape = wgm_shape(rg[r], kgs[kk]);
+              if (shape < 0 || nj == 48) return false;
+              WsJob jb;
+              memset(&jb, 0, sizeof(jb));
+              jb.g.ptr = gp; jb.g.idx = gidx ? gidx : iota; jb.g.vstride = gvs; jb.g.stride = gstride; jb.g.col0 = gcol0 + g0;
+              jb.act[0].ptr = cols[ci].p; jb.act[0].idx = iota; jb.act[0].vstride = cols[ci].vstride;
+              jb.act[0].stride = cols[ci].stride; jb.act[0].col0 = cols[ci].col0 + c0;
+              jb.act[1] = jb.act[0]; jb.act[2] = jb.act[0];
+              jb.wcol[0] = wcol + c0; jb.wrow = g0;
+              jb.write_bias = (with_bias && ci == 0 && c0 == 0) ? 1 : 0;     // the first column group of every row group
+              jb.shape = shape;
+              jb.rows = (int)rows; jb.nvar = nvar; jb.rows_per_task = rpt;
+              jb.NP = ls.NP; jb.KP = ls.KP; jb.slab = ls.slab;
+              if (gidx && shape != WGM_128_192) return false;             // the only compiled gathered shape
+              jobs[nj++] = jb;
+              g0 += rg[r];
+            }
+            c0 += kgs[kk];
+          }
+        }
+        wcol += cols[ci].width;
+      }
+      for (int j = 0; j < nj; ++j) wlc.add(jobs[j]);
+      return true;
+    };
     auto add_block = [&](LinSlab& ls, long rows, int nvar, int rpt, const float* gp, const int* gidx, long gvs, int gstride, int gcol0,
                          const Col* cols, int ncols, bool with_bias) {
       if (nvar <= 0) return;
       ls.used = true;
+      if (coop && ((uintptr_t)gp % 16 == 0) && gstride % 4 == 0 && gcol0 % 4 == 0 &&
+          add_block_coop(ls, rows, nvar, rpt, gp, gidx, gvs, gstride, gcol0, cols, ncols, with_bias))
+        return;
       bool first_job_of_group = true;
       for (int g0 = 0; g0 < ls.N; g0 += 64) {
         const int gw = (ls.N - g0 >= 64) ? 64 : ls.N - g0;       // 64, or the 32-row tail of a 96-row matrix
@@ -982,7 +1067,22 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
       const long tLs = (long)N * HC::GW;
       {  // edge_update.0 [256, 320]: x[dst] 0:96 | x[src] 96:192 | e 192:256 | att 256:320
         Col ce[2] = {{w.e[0], nullptr, (long)eLe, D::DE, 0, 64}, {w.att, nullptr, 0, 64, 0, 64}};
+        if (coop) {        // one job over both sources: GdH1 (256 wide, the bulk of the bytes) is read once
+          LinSlab& ls = w.vlin[VL_EU0E];
+          ls.used = true;
+          WsJob jb;
+          memset(&jb, 0, sizeof(jb));
+          jb.g.ptr = w.GdH1; jb.g.idx = iota; jb.g.vstride = eL1; jb.g.stride = D::EH1; jb.g.col0 = 0;
+          for (int k = 0; k < 2; ++k) {
+            jb.act[k].ptr = ce[k].p; jb.act[k].idx = iota; jb.act[k].vstride = ce[k].vstride; jb.act[k].stride = ce[k].stride; jb.act[k].col0 = 0;
+          }
+          jb.act[2] = jb.act[0];
+          jb.wcol[0] = 0; jb.wcol[1] = 64; jb.wrow = 0; jb.write_bias = 1; jb.shape = WGM_256_128;
+          jb.rows = E; jb.nvar = depth; jb.rows_per_task = rp; jb.NP = ls.NP; jb.KP = ls.KP; jb.slab = ls.slab;
+          wlc.add(jb);
+        } else {
         add_block(w.vlin[VL_EU0E], E, depth, rp, w.GdH1, nullptr, eL1, D::EH1, 0, ce, 2, true);
+        }
         Col cx[1] = {{w.x[0], nullptr, (long)nLx, D::DX, 0, 96}};
         add_block(w.vlin[VL_EU0XI], N, depth, rn, w.dT, nullptr, tLs, HC::GW, HC::OA, cx, 1, false);
         add_block(w.vlin[VL_EU0XJ], N, depth, rn, w.dT, nullptr, tLs, HC::GW, HC::OB, cx, 1, false);
@@ -1080,6 +1180,15 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
     }
     B3D_REQUIRE(wl.status == 0, "streaming weight gradient: job table overflow (%d jobs, %d tasks)", wl.njobs, wl.total_tasks);
     B3D_TRY(launch_check("wstream_kernel"));
+    wlc.flush();
+    B3D_REQUIRE(wlc.status == 0, "cooperative weight gradient: job table overflow (%d jobs, %d tasks)", wlc.njobs, wlc.total_tasks);
+    if (wlc.total_tasks > 0) {
+      B3D_TRY(set_lds(wgemm_kernel, kWgmLdsBytes));
+      ProfScope ps(B3D_K_WGRAD_EDGE, stream);
+      hipLaunchKernelGGL(wgemm_kernel, dim3((unsigned)(wlc.total_tasks < 2048 ? wlc.total_tasks : 2048)), dim3(kWgmThreads), kWgmLdsBytes,
+                         stream, (const WsJob*)wlc.table, (const int*)wlc.task_job, wlc.total_tasks, w.iota);
+      B3D_TRY(launch_check("wgemm_kernel"));
+    }
   }
 
   // ---- slabs -> parameter gradients -----------------------------------------------------------------------

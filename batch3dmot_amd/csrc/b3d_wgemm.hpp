@@ -1,0 +1,301 @@
+// Cooperative weight gradient (same jobs, tasks and slabs as b3d_wstream.hpp; the hoisted plan's launch).
+//
+//   dW[n][k] = sum over layer variants v, rows r of  G_v[r][n] * Act_v[r][k]        db[n] = sum G_v[r][n]
+//
+// wstream gives every WAVEFRONT a 64 x 96 block of dW and lets it stream its own rows: a 384 x 512 matrix becomes 36
+// jobs that read G six times and Act six times (measured: 4.7 GB of HBM traffic per backward pass for 1.7 GB of
+// operands, 5.3 TB/s -- the launch sits on the HBM roofline of its OWN re-reads), on exact-fp32 MFMA.  Here a WORKGROUP
+// of 8 wavefronts owns up to 128 x 256 (256 x 96, 192 x 128 ...) of dW: per step it stages 32 rows of G and Act ONCE
+// -- split on the way into three bf16 pieces each (x = x0 + x1 + x2 exactly, b3d_dev.hpp) -- as row-major [32][W] bf16
+// images in LDS, and every wavefront reads the operands of its 2-24 output blocks from there.  The contraction index
+// of v_mfma_f32_16x16x32_bf16 is the ROW of those images, i.e. the operands are needed column-major:
+// ds_read_b64_tr_b16 delivers exactly that (per 16 lanes a 4 rows x 16 columns block, transposed), so nothing is
+// transposed in registers or at staging time.  Lane group g takes rows {4g..4g+3} and {16+4g..16+4g+3} as its eight
+// k-slots -- any assignment works as long as both operands use the same one -- which with a row pitch = 8 (mod 64)
+// dwords makes both transposed reads of a 32-lane half conflict-free.  Six piece products per block (bf16x6) in fp32
+// accumulators; two LDS buffers, one barrier per 32-row step; the global loads run one or two steps ahead of the MFMAs.
+// A job may take its activation columns from two sources (edge_update.0: e | att), so that G is read once for both.
+#pragma once
+#include "b3d_wstream.hpp"
+
+namespace b3d {
+
+constexpr int kWgmThreads = 512, kWgmRows = 32, kWgmMaxW = 384;
+__host__ __device__ constexpr int wgm_pitch(int W) { return ((W / 2 - 8 + 63) / 64) * 64 + 8; }     // dwords, >= W / 2, = 8 mod 64
+constexpr int kWgmLdsBytes = 2 * 3 * kWgmRows * wgm_pitch(kWgmMaxW) * 4;
+
+typedef short wgm_s4 __attribute__((ext_vector_type(4)));
+typedef short wgm_s8 __attribute__((ext_vector_type(8)));
+
+// shapes: (wave grid WR x WC) x (blocks per wavefront MBW x NBW): G width NG = 16 WR MBW, activation width KG = 16 WC NBW
+enum {
+  WGM_128_256 = 0, WGM_128_192, WGM_128_128, WGM_64_128, WGM_256_64, WGM_256_96, WGM_192_64, WGM_192_96, WGM_96_128,
+  WGM_192_128, WGM_128_96, WGM_256_128, WGM_SHAPES
+};
+inline int wgm_shape(int ng, int kg) {
+  static const int t[WGM_SHAPES][2] = {{128, 256}, {128, 192}, {128, 128}, {64, 128}, {256, 64}, {256, 96}, {192, 64}, {192, 96},
+                                       {96, 128}, {192, 128}, {128, 96}, {256, 128}};
+  for (int i = 0; i < WGM_SHAPES; ++i)
+    if (t[i][0] == ng && t[i][1] == kg) return i;
+  return -1;
+}
+
+__device__ __forceinline__ void wgm_split4(const v4f x, unsigned (&p0)[2], unsigned (&p1)[2], unsigned (&p2)[2]) {
+  const float f[4] = {x.x, x.y, x.z, x.w};
+  unsigned h[4], m[4], l[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    h[i] = __float_as_uint(f[i]);
+    const float r1 = f[i] - __uint_as_float(h[i] & 0xffff0000u);
+    m[i] = __float_as_uint(r1);
+    l[i] = __float_as_uint(r1 - __uint_as_float(m[i] & 0xffff0000u));
+  }
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    p0[d] = __builtin_amdgcn_perm(h[2 * d + 1], h[2 * d], 0x07060302u);
+    p1[d] = __builtin_amdgcn_perm(m[2 * d + 1], m[2 * d], 0x07060302u);
+    p2[d] = __builtin_amdgcn_perm(l[2 * d + 1], l[2 * d], 0x07060302u);
+  }
+}
+
+// operand fragment: rows {4g+q} and {16+4g+q} of 16 columns starting at dword column `cd` of one piece image
+__device__ __forceinline__ bf8 wgm_frag(const float* img, int lane_off /* (4g+q) * pitch + 2p, dwords */, int pitch, int cd) {
+  auto* p0 = (__attribute__((address_space(3))) wgm_s4*)(img + lane_off + cd);
+  auto* p1 = (__attribute__((address_space(3))) wgm_s4*)(img + lane_off + 16 * pitch + cd);
+  const wgm_s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(p0);
+  const wgm_s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(p1);
+  const wgm_s8 v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  return __builtin_bit_cast(bf8, v);
+}
+
+// not inlined: one register allocation per shape (inlined into the dispatch switch the kernel spilled 164 VGPRs)
+template <int WR, int WC, int MBW, int NBW, bool GATHER>
+__device__ __attribute__((noinline)) void wgm_task(const WsJob& job, int chunk, float* lds) {
+  constexpr int NG = 16 * WR * MBW, KG = 16 * WC * NBW, W = NG + KG, PITCH = wgm_pitch(W);
+  constexpr int PIECE = kWgmRows * PITCH, BUF = 3 * PIECE;
+  constexpr int G4 = NG / 4, A4 = KG / 4;
+  static_assert(WR * WC == 8 && W <= kWgmMaxW && 2 * BUF * 4 <= kWgmLdsBytes, "shape does not fit the workgroup / LDS");
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wr = wave / WC, wc = wave % WC;
+  const int r0 = chunk * job.rows_per_task;
+  int r1 = r0 + job.rows_per_task;
+  if (r1 > job.rows) r1 = job.rows;
+  const int nrows = r1 > r0 ? r1 - r0 : 0;
+  const int nsteps = (nrows + kWgmRows - 1) / kWgmRows;
+  const int total = nsteps * job.nvar;
+  const int gstride = job.g.stride;
+  const long gvs = job.g.vstride;
+  const int* gidx = job.g.idx + r0;
+  const int split4 = job.wcol[1] > 0 ? job.wcol[1] / 4 : A4;          // float4 columns served by act[0]; the rest by act[1]
+
+  // Staging: thread tid owns float4 column tid % G4 of the gradient rows tid / G4 + RG i (i = 0 .. GL-1; threads past
+  // RG * G4 idle), likewise for the activation rows: one source pointer and one LDS offset per thread, every slot a
+  // compile-time multiple of the row stride away.
+  constexpr int RG = kWgmThreads / G4, RA = kWgmThreads / A4;
+  constexpr int GLs = (kWgmRows + RG - 1) / RG, ALs = (kWgmRows + RA - 1) / RA;
+  const int grow0 = tid / G4, gc4 = tid % G4, arow0 = tid / A4, ac4 = tid % A4;
+  const bool gthread = grow0 < RG, athread = arow0 < RA;
+  const bool second = ac4 >= split4;
+  const WsSeg& asg = second ? job.act[1] : job.act[0];
+  const int astride = asg.stride;
+  const long avs = asg.vstride;
+  const float* abase = asg.ptr + asg.col0 + (long)(r0 + arow0) * astride + 4 * (second ? ac4 - split4 : ac4);
+  const float* gbase = job.g.ptr + job.g.col0 + 4 * gc4 + (GATHER ? 0L : (long)(r0 + grow0) * gstride);
+  const int gdst0 = grow0 * PITCH + 2 * gc4, adst0 = arow0 * PITCH + NG / 2 + 2 * ac4;
+  v4f gx[(MBW * NBW <= 9) ? 2 : 1][GLs], ax[(MBW * NBW <= 9) ? 2 : 1][ALs];
+  v4f bs = {0.f, 0.f, 0.f, 0.f};
+  int gi[GLs];
+#pragma unroll
+  for (int i = 0; i < GLs; ++i) gi[i] = 0;
+  const v4f zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  auto load_idx = [&](int t) {                               // gather indices of step t (GATHER only)
+    if constexpr (GATHER) {
+      const int s = (t < total ? t : 0) % nsteps;
+#pragma unroll
+      for (int i = 0; i < GLs; ++i) {
+        const int row = kWgmRows * s + grow0 + RG * i;
+        gi[i] = (t < total && gthread && grow0 + RG * i < kWgmRows && row < nrows) ? gidx[row] : 0;
+      }
+    }
+  };
+  auto load_rows = [&](int t, v4f (&gq)[GLs], v4f (&aq)[ALs]) {    // rows of step t -> registers
+    const bool live = t < total;
+    const int tt = live ? t : 0;
+    const int v = tt / nsteps, s = tt - v * nsteps;
+    const float* gv = gbase + v * gvs + (GATHER ? 0L : (long)(kWgmRows * s) * gstride);
+    const float* av = abase + v * avs + (long)(kWgmRows * s) * astride;
+    const int left = nrows - kWgmRows * s;                   // rows of this step that exist
+#pragma unroll
+    for (int i = 0; i < GLs; ++i) {
+      const int row = grow0 + RG * i;
+      const bool ok = live && gthread && row < kWgmRows && row < left;
+      const float* ptr = GATHER ? gv + (long)gi[i] * gstride : gv + (long)(RG * i) * gstride;
+      gq[i] = ok ? *reinterpret_cast<const v4f*>(ptr) : zero4;
+    }
+#pragma unroll
+    for (int i = 0; i < ALs; ++i) {
+      const int row = arow0 + RA * i;
+      const bool ok = live && athread && row < kWgmRows && row < left;
+      aq[i] = ok ? *reinterpret_cast<const v4f*>(av + (long)(RA * i) * astride) : zero4;
+    }
+  };
+  auto put = [&](float* buf, int off, const v4f x) {
+    unsigned p0[2], p1[2], p2[2];
+    wgm_split4(x, p0, p1, p2);
+    unsigned* d = reinterpret_cast<unsigned*>(buf) + off;
+    *reinterpret_cast<uint2*>(d) = uint2{p0[0], p0[1]};
+    *reinterpret_cast<uint2*>(d + PIECE) = uint2{p1[0], p1[1]};
+    *reinterpret_cast<uint2*>(d + 2 * PIECE) = uint2{p2[0], p2[1]};
+  };
+  auto stage = [&](float* buf, const v4f (&gq)[GLs], const v4f (&aq)[ALs]) {    // registers -> three bf16 piece images
+#pragma unroll
+    for (int i = 0; i < GLs; ++i) {
+      if (gthread && grow0 + RG * i < kWgmRows) {
+        put(buf, gdst0 + RG * i * PITCH, gq[i]);
+        bs += gq[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < ALs; ++i)
+      if (athread && arow0 + RA * i < kWgmRows) put(buf, adst0 + RA * i * PITCH, aq[i]);
+  };
+
+  v4f acc[MBW][NBW];
+#pragma unroll
+  for (int a = 0; a < MBW; ++a)
+#pragma unroll
+    for (int b = 0; b < NBW; ++b) acc[a][b] = zero4;
+
+  const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+  const int lane_off = (4 * g + q) * PITCH + 2 * p;
+  auto compute = [&](const float* cur) {
+    Bf3 af[MBW];
+#pragma unroll
+    for (int a = 0; a < MBW; ++a) {
+      const int cd = 8 * (wr * MBW + a);
+      af[a].p0 = wgm_frag(cur, lane_off, PITCH, cd);
+      af[a].p1 = wgm_frag(cur + PIECE, lane_off, PITCH, cd);
+      af[a].p2 = wgm_frag(cur + 2 * PIECE, lane_off, PITCH, cd);
+    }
+#pragma unroll
+    for (int b = 0; b < NBW; ++b) {
+      const int cd = NG / 2 + 8 * (wc * NBW + b);
+      Bf3 bfr;
+      bfr.p0 = wgm_frag(cur, lane_off, PITCH, cd);
+      bfr.p1 = wgm_frag(cur + PIECE, lane_off, PITCH, cd);
+      bfr.p2 = wgm_frag(cur + 2 * PIECE, lane_off, PITCH, cd);
+#pragma unroll
+      for (int a = 0; a < MBW; ++a) acc[a][b] = bf_mfma6(af[a], bfr, acc[a][b]);
+    }
+  };
+  // Prefetch depth: rows are fetched TWO steps ahead where the registers allow it (a step of a small shape is far
+  // shorter than an HBM round trip); the shapes with 12+ accumulator blocks per wavefront keep one step in flight
+  // -- their MFMA phase (>= 1 us) covers most of the latency and a second register set made them spill.
+  constexpr bool DEEP = MBW * NBW <= 9;
+  __syncthreads();                                           // the previous task of this workgroup is done with the LDS
+  if constexpr (DEEP) {
+    // at the top of iteration t, LDS buffer t & 1 holds step t, register set (t + 1) & 1 step t + 1
+    load_idx(0);
+    load_rows(0, gx[0], ax[0]);
+    load_idx(1);
+    load_rows(1, gx[1], ax[1]);
+    load_idx(2);
+    stage(lds, gx[0], ax[0]);
+    __syncthreads();
+    for (int t = 0; t < total; t += 2) {
+      load_rows(t + 2, gx[0], ax[0]);
+      load_idx(t + 3);
+      compute(lds);
+      stage(lds + BUF, gx[1], ax[1]);                        // step t + 1 (zeros past the end)
+      __syncthreads();
+      if (t + 1 >= total) break;
+      load_rows(t + 3, gx[1], ax[1]);
+      load_idx(t + 4);
+      compute(lds + BUF);
+      stage(lds, gx[0], ax[0]);                              // step t + 2
+      __syncthreads();
+    }
+  } else {
+    load_idx(0);
+    load_rows(0, gx[0], ax[0]);
+    load_idx(1);
+    stage(lds, gx[0], ax[0]);
+    __syncthreads();
+    for (int t = 0; t < total; ++t) {
+      load_rows(t + 1, gx[0], ax[0]);                        // in flight during this step's MFMAs
+      load_idx(t + 2);
+      compute(lds + (t & 1) * BUF);
+      stage(lds + ((t + 1) & 1) * BUF, gx[0], ax[0]);
+      __syncthreads();
+    }
+  }
+
+  // ---- partial -> slab (row-major [NP][KP], then bias) ---------------------------------------
+  float* slab = job.slab + (size_t)chunk * ((size_t)job.NP * job.KP + job.NP);
+  const int n = lane & 15, qq = lane >> 4;
+#pragma unroll
+  for (int a = 0; a < MBW; ++a) {
+#pragma unroll
+    for (int b = 0; b < NBW; ++b) {
+      const float* vv = reinterpret_cast<const float*>(&acc[a][b]);
+      const int colf = job.wcol[0] + 16 * (wc * NBW + b) + n;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int rowf = job.wrow + 16 * (wr * MBW + a) + 4 * qq + j;
+        slab[(size_t)rowf * job.KP + colf] = vv[j];
+      }
+    }
+  }
+  if (job.write_bias) {
+    float* colsum = lds;                                     // every wavefront is past its last LDS read (barrier above)
+    for (int i = tid; i < NG; i += kWgmThreads) colsum[i] = 0.f;
+    __syncthreads();
+    if (gthread) {
+      atomicAdd(&colsum[4 * gc4 + 0], bs.x);
+      atomicAdd(&colsum[4 * gc4 + 1], bs.y);
+      atomicAdd(&colsum[4 * gc4 + 2], bs.z);
+      atomicAdd(&colsum[4 * gc4 + 3], bs.w);
+    }
+    __syncthreads();
+    for (int i = tid; i < NG; i += kWgmThreads) slab[(size_t)job.NP * job.KP + job.wrow + i] = colsum[i];
+  }
+}
+
+static __global__ __launch_bounds__(kWgmThreads, 1) void wgemm_kernel(const WsJob* __restrict__ table, const int* __restrict__ task_job,
+                                                                      int total_tasks, const int* __restrict__ iota) {
+  extern __shared__ __attribute__((aligned(16))) float wgm_lds[];
+  __shared__ WsJob sj;
+  for (int task = blockIdx.x; task < total_tasks; task += gridDim.x) {
+    __syncthreads();
+    {
+      const int* srcw = reinterpret_cast<const int*>(&table[task_job[task]]);
+      int* dstw = reinterpret_cast<int*>(&sj);
+      for (int i = threadIdx.x; i < (int)(sizeof(WsJob) / 4); i += kWgmThreads) dstw[i] = srcw[i];
+    }
+    __syncthreads();
+    const WsJob& job = sj;
+    const int chunk = task - job.task_begin;
+    const bool gather = job.g.idx != iota;
+    switch (job.shape) {
+      case WGM_128_256: wgm_task<2, 4, 4, 4, false>(job, chunk, wgm_lds); break;
+      case WGM_128_192:
+        if (gather) wgm_task<2, 4, 4, 3, true>(job, chunk, wgm_lds);
+        else wgm_task<2, 4, 4, 3, false>(job, chunk, wgm_lds);
+        break;
+      case WGM_128_128: wgm_task<2, 4, 4, 2, false>(job, chunk, wgm_lds); break;
+      case WGM_64_128: wgm_task<2, 4, 2, 2, false>(job, chunk, wgm_lds); break;
+      case WGM_256_64: wgm_task<8, 1, 2, 4, false>(job, chunk, wgm_lds); break;
+      case WGM_256_96: wgm_task<8, 1, 2, 6, false>(job, chunk, wgm_lds); break;
+      case WGM_192_64: wgm_task<4, 2, 3, 2, false>(job, chunk, wgm_lds); break;
+      case WGM_192_96: wgm_task<4, 2, 3, 3, false>(job, chunk, wgm_lds); break;
+      case WGM_96_128: wgm_task<2, 4, 3, 2, false>(job, chunk, wgm_lds); break;
+      case WGM_192_128: wgm_task<2, 4, 6, 2, false>(job, chunk, wgm_lds); break;
+      case WGM_128_96: wgm_task<4, 2, 2, 3, false>(job, chunk, wgm_lds); break;
+      case WGM_256_128: wgm_task<8, 1, 2, 8, false>(job, chunk, wgm_lds); break;
+      default: break;
+    }
+  }
+}
+
+}  // namespace b3d
