@@ -141,74 +141,138 @@ __device__ __forceinline__ void conv_acc(const float* __restrict__ in, const flo
 }
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-// Occupancy is what these kernels live on: the weights of a tap arrive by scalar loads whose latency (L2 -- 20-330 KB of
-// weights do not stay in the 16 KB scalar cache) nothing inside a wavefront hides, so a CU needs many wavefronts.  The
-// first version gave every wavefront 4 crops and ALL output channels (110 KB of LDS tiles per workgroup, one wavefront
-// per SIMD): 0.92 ms for the six phases, as slow as the library path.  Now a workgroup stages FEW crops and its
-// wavefronts split the output channels, 12-20 wavefronts per CU.
+// What these kernels live on is the LENGTH OF THE CHAIN of scalar-load round trips in a wavefront: the weights of a tap
+// arrive by s_load (L2: 20-330 KB of weights do not stay in the 16 KB scalar cache), ~100 SGPRs hold at most one input
+// channel's taps for 12 output channels, so every input channel costs 2-3 dependent round trips of ~0.4 us that nothing
+// inside the wavefront hides -- and more wavefronts per CU only run more such chains side by side.  First version
+// (every wavefront 4 crops x ALL output channels, 110 KB of tiles, one wavefront per SIMD): 0.92 ms; output channels
+// split over the wavefronts of a workgroup: 0.45 ms, each phase still lasting (input channels x 3) round trips.  Now
+// the INPUT channels are split as well: 16 wavefronts per workgroup = (output-channel groups) x (input-channel
+// slices), the partial sums of the slices meet in LDS (plain stores into per-slice buffers, summed in a fixed order,
+// so the result does not depend on timing) and a short second pass adds the bias, writes the raw output and
+// accumulates the BatchNorm statistics.
 
-// ---- P0: conv -> block1.conv1 (+ statistics) and block1.downsample (+ statistics): 2 crops, 8 wavefronts -------------------
+// partial convolution of input channels [ci0, ci0 + NCI) -- see conv_acc
+template <int NCI, int HP, int WP, int K, int CG, int COUT>
+__device__ __forceinline__ void conv_acc_slice(const float* __restrict__ in, const float* __restrict__ w_, int ci0, float (&acc)[CG]) {
+  cfloat_p w = (cfloat_p)w_ + (long)ci0 * K * K * COUT;
+  in += ci0 * HP * WP;
+#pragma unroll 1
+  for (int ci = 0; ci < NCI; ++ci) {
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky) {
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx) {
+        const float v = in[(ci * HP + ky) * WP + kx];
+        cfloat_p wk = w + ((ci * K + ky) * K + kx) * COUT;
+#pragma unroll
+        for (int j = 0; j < CG; ++j) acc[j] = fmaf(wk[j], v, acc[j]);
+      }
+    }
+  }
+}
+
+// One convolution, first pass: lanes <-> (crop, output pixel); this wavefront takes output channels CG cg .. and input
+// channels (CIN / KS) ks ..; partial sums -> part[ks][crop][channel][pixel].
+// HO: output height = width; S: stride; OFF: 0 for a padded convolution (pad 1), 1 for an unpadded one (the window starts at
+// the tile's interior); LPC: lanes per crop (>= HO * HO; the others idle); CROPS: crops of the tile.
+template <int CIN, int HP, int K, int S, int OFF, int HO, int COUT, int CG, int LPC, int CROPS, int KS>
+__device__ __forceinline__ void conv_part(const float* tiles, const float* w, float* part, int cg, int ks) {
+  constexpr int PIX = HO * HO, NCI = CIN / KS;
+  static_assert(CIN % KS == 0 && COUT % CG == 0, "slices divide the channels");
+  const int lane = threadIdx.x & 63;
+  const int im = lane / LPC, px = lane % LPC;
+  const bool active = px < PIX && im < CROPS;
+  const int oy = active ? px / HO : 0, ox = active ? px % HO : 0;
+  const float* in = tiles + (active ? im : 0) * CIN * HP * HP + (oy * S + OFF) * HP + ox * S + OFF;
+  const int c0 = uniform(cg * CG);
+  float acc[CG];
+#pragma unroll
+  for (int j = 0; j < CG; ++j) acc[j] = 0.f;
+  conv_acc_slice<NCI, HP, HP, K, CG, COUT>(in, w + c0, uniform(ks * NCI), acc);
+  if (active) {
+    float* o = part + ((ks * CROPS + im) * COUT + c0) * PIX + px;
+#pragma unroll
+    for (int j = 0; j < CG; ++j) o[j * PIX] = acc[j];
+  }
+}
+// second pass (behind a barrier): channel c by wavefront c % nwaves; bias, raw output, statistics
+template <int HO, int COUT, int LPC, int CROPS, int KS>
+__device__ __forceinline__ void conv_finish(const ResArgs& a, int img0, const float* part, const float* bias, float* z, float* stat,
+                                            int wave, int nwaves) {
+  constexpr int PIX = HO * HO;
+  const int lane = threadIdx.x & 63;
+  const int im = lane / LPC, px = lane % LPC;
+  const bool active = px < PIX && im < CROPS;
+  const bool valid = active && img0 + im < a.N;
+  for (int c = wave; c < COUT; c += nwaves) {
+    float v = 0.f;
+    if (active) {
+      v = bias[c];
+#pragma unroll
+      for (int k = 0; k < KS; ++k) v += part[((k * CROPS + im) * COUT + c) * PIX + px];
+    }
+    if (valid) z[((long)(img0 + im) * COUT + c) * PIX + px] = v;
+    if (a.train) stat_add(stat, c, valid ? v : 0.f);
+  }
+}
+
+constexpr int kResThreads = 1024, kResWaves = 16;
+
+// ---- P0: conv -> block1.conv1 (+ statistics) and block1.downsample (+ statistics): 2 crops, 16 wavefronts ------------------
 constexpr int kP0Crops = 2;
 constexpr int kP0X = 3 * 34 * 34, kP0A = 12 * 18 * 18;
+constexpr int kP0Part = 2 * kP0Crops * 24 * 64;                       // block1.conv1: 2 input-channel slices
+static_assert(kP0Part <= kP0Crops * kP0X, "the partial sums reuse the input tiles (dead once conv has run)");
 constexpr int kP0Lds = (kP0Crops * (kP0X + kP0A) + 2 * 24 * 2) * 4;
-__global__ __launch_bounds__(512) void resnet_p0_kernel(const ResArgs a) {
+__global__ __launch_bounds__(kResThreads) void resnet_p0_kernel(const ResArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* xin = smem;                               // [2][3][34][34]
   float* a0 = xin + kP0Crops * kP0X;               // [2][12][18][18]
+  float* part = xin;                               // partial sums of the slices: over the input tiles, dead by then
   float* st1 = a0 + kP0Crops * kP0A;               // [24][2] block1.bn1
   float* std_ = st1 + 48;                          // [24][2] block1.downsample
-  for (int i = threadIdx.x; i < kP0Crops * (kP0X + kP0A) + 96; i += 512) smem[i] = 0.f;
+  for (int i = threadIdx.x; i < kP0Crops * (kP0X + kP0A); i += kResThreads) smem[i] = 0.f;
+  for (int i = threadIdx.x; i < 96; i += kResThreads) st1[i] = 0.f;
   const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const float* w0 = a.w + conv_off(0);
-  const float* w1 = a.w + conv_off(1);
-  const float* w3 = a.w + conv_off(3);
   const int groups = (a.N + kP0Crops - 1) / kP0Crops;
   for (int g = blockIdx.x; g < groups; g += gridDim.x) {
     const int img0 = g * kP0Crops;
     __syncthreads();                               // the previous pass is done with the tiles (and the zero fill is visible)
-    for (int i = threadIdx.x; i < kP0Crops * 3 * 1024; i += 512) {
+    if (g != (int)blockIdx.x) {                    // the partial sums of the previous pass lie over the zero borders
+      for (int i = threadIdx.x; i < kP0Crops * kP0X; i += kResThreads) xin[i] = 0.f;
+      __syncthreads();
+    }
+    for (int i = threadIdx.x; i < kP0Crops * 3 * 1024; i += kResThreads) {
       const int im = i / 3072, r = i - im * 3072, c = r >> 10, y = (r >> 5) & 31, xx = r & 31;
       const float v = img0 + im < a.N ? a.x[(long)(img0 + im) * 3072 + r] : 0.f;
       xin[im * kP0X + (c * 34 + y + 1) * 34 + xx + 1] = v;
     }
     __syncthreads();
-    {                                              // conv: 3 -> 12, k4 s2 p1, 32 -> 16; wavefront <-> (crop, 4 output rows)
-      const int im = wave >> 2, oy = 4 * (wave & 3) + (lane >> 4), ox = lane & 15;
-      float acc[12];
-#pragma unroll
-      for (int j = 0; j < 12; ++j) acc[j] = a.bias[0][j];
-      conv_acc<3, 34, 34, 4, 12, 12>(xin + im * kP0X + (oy * 2) * 34 + ox * 2, w0, acc);
-#pragma unroll
-      for (int j = 0; j < 12; ++j) a0[im * kP0A + (j * 18 + oy + 1) * 18 + ox + 1] = acc[j];
-    }
-    __syncthreads();
-    {                                              // block1.conv1: 12 -> 24, k4 s2 p1, 16 -> 8; wavefront <-> (crop, 6 channels), lane <-> pixel
-      const int im = wave >> 2, c0 = 6 * (wave & 3), oy = lane >> 3, ox = lane & 7;
-      const bool valid = img0 + im < a.N;
+    {                                              // conv: 3 -> 12, k4 s2 p1, 32 -> 16; wavefront <-> (crop, 4 output rows, 6 channels)
+      const int im = wave >> 3, oy = 4 * ((wave >> 1) & 3) + (lane >> 4), ox = lane & 15, c0 = uniform(6 * (wave & 1));
       float acc[6];
 #pragma unroll
-      for (int j = 0; j < 6; ++j) acc[j] = a.bias[1][c0 + j];
-      conv_acc<12, 18, 18, 4, 6, 24>(a0 + im * kP0A + (oy * 2) * 18 + ox * 2, w1 + c0, acc);
+      for (int j = 0; j < 6; ++j) acc[j] = a.bias[0][c0 + j];
+      conv_acc<3, 34, 34, 4, 6, 12>(xin + im * kP0X + (oy * 2) * 34 + ox * 2, w0 + c0, acc);
 #pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        if (valid) a.z1[((long)(img0 + im) * 24 + c0 + j) * 64 + lane] = acc[j];
-        if (a.train) stat_add(st1, c0 + j, valid ? acc[j] : 0.f);
-      }
+      for (int j = 0; j < 6; ++j) a0[im * kP0A + ((c0 + j) * 18 + oy + 1) * 18 + ox + 1] = acc[j];
     }
-    {                                              // block1.downsample: 12 -> 24, k5 s3 p0, 16 -> 4; lane <-> (crop, pixel), wavefront <-> 3 channels
-      const int im = (lane >> 4) & 1, px = lane & 15, oy = px >> 2, ox = px & 3;
-      const bool valid = lane < 32 && img0 + im < a.N;
-      const int c0 = wave * 3;
-      float acc[3];
-#pragma unroll
-      for (int j = 0; j < 3; ++j) acc[j] = a.bias[3][c0 + j];
-      conv_acc<12, 18, 18, 5, 3, 24>(a0 + im * kP0A + (oy * 3 + 1) * 18 + ox * 3 + 1, w3 + c0, acc);
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        if (valid) a.zd1[((long)(img0 + im) * 24 + c0 + j) * 16 + px] = acc[j];
-        if (a.train) stat_add(std_, c0 + j, valid ? acc[j] : 0.f);
-      }
+    __syncthreads();
+    // block1.conv1: 12 -> 24, k4 s2 p1, 16 -> 8: lanes <-> the 64 pixels of ONE crop, wavefront <-> (crop, 6 channels, 6 input channels)
+    {
+      const int im = wave >> 3, cg = (wave >> 1) & 3, ks = wave & 1;
+      conv_part<12, 18, 4, 2, 0, 8, 24, 6, 64, 1, 2>(a0 + im * kP0A, a.w + conv_off(1), part + im * (2 * 24 * 64), cg, ks);
     }
+    __syncthreads();
+    for (int im = 0; im < kP0Crops; ++im)
+      conv_finish<8, 24, 64, 1, 2>(a, img0 + im, part + im * (2 * 24 * 64), a.bias[1], a.z1, st1, wave, kResWaves);
+    __syncthreads();
+    // block1.downsample: 12 -> 24, k5 s3 p0, 16 -> 4: lanes <-> (crop, pixel) (32 of 64), wavefront <-> (3 channels, 6 input channels)
+    conv_part<12, 18, 5, 3, 1, 4, 24, 3, 16, kP0Crops, 2>(a0, a.w + conv_off(3), part, wave >> 1, wave & 1);
+    __syncthreads();
+    conv_finish<4, 24, 16, kP0Crops, 2>(a, img0, part, a.bias[3], a.zd1, std_, wave, kResWaves);
   }
   if (a.train) {
     __syncthreads();
@@ -236,39 +300,18 @@ __device__ __forceinline__ void stage_tiles(const ResArgs& a, int img0, const fl
   }
 }
 
-// One convolution of a middle phase: lanes <-> (crop, output pixel), this wavefront computes channels c0 .. c0 + CG - 1.
-// HO: output height = width; S: stride; OFF: 0 for a padded convolution (pad 1), 1 for an unpadded one (the window starts at
-// the tile's interior); LPC: lanes per crop (>= HO * HO; the others idle); CROPS: crops of the tile.
-template <int CIN, int HP, int K, int S, int OFF, int HO, int COUT, int CG, int LPC, int CROPS>
-__device__ __forceinline__ void conv_phase(const ResArgs& a, int img0, const float* tiles, const float* w, const float* bias, float* z,
-                                           float* stat, int c0) {
-  constexpr int PIX = HO * HO;
-  const int lane = threadIdx.x & 63;
-  const int im = lane / LPC, px = lane % LPC;
-  const bool active = px < PIX && im < CROPS;
-  const int oy = active ? px / HO : 0, ox = active ? px % HO : 0;
-  const bool valid = active && img0 + im < a.N;
-  const float* in = tiles + (active ? im : 0) * CIN * HP * HP + (oy * S + OFF) * HP + ox * S + OFF;
-  float acc[CG];
-#pragma unroll
-  for (int j = 0; j < CG; ++j) acc[j] = bias[c0 + j];
-  conv_acc<CIN, HP, HP, K, CG, COUT>(in, w + c0, acc);
-#pragma unroll
-  for (int j = 0; j < CG; ++j) {
-    if (valid) z[((long)(img0 + im) * COUT + c0 + j) * PIX + px] = acc[j];
-    if (a.train) stat_add(stat, c0 + j, valid ? acc[j] : 0.f);
-  }
-}
-
-// P1: block1.conv2 24 -> 24, k4 s2 p1, 8 -> 4.  4 crops, 4 wavefronts x 6 channels.
+// P1: block1.conv2 24 -> 24, k4 s2 p1, 8 -> 4.  4 crops; 4 groups of 6 channels x 4 slices of 6 input channels.
 constexpr int kP1Crops = 4;
-constexpr int kP1Lds = (kP1Crops * 24 * 10 * 10 + 48 + 48) * 4;
-__global__ __launch_bounds__(256) void resnet_p1_kernel(const ResArgs a) {
+constexpr int kP1Tiles = kP1Crops * 24 * 100, kP1Part = 4 * kP1Crops * 24 * 16;
+constexpr int kP1Lds = (kP1Tiles + kP1Part + 48 + 48) * 4;
+__global__ __launch_bounds__(kResThreads) void resnet_p1_kernel(const ResArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* tiles = smem;
-  float* aff = tiles + kP1Crops * 24 * 100;
+  float* part = tiles + kP1Tiles;
+  float* aff = part + kP1Part;
   float* stat = aff + 48;
-  for (int i = threadIdx.x; i < kP1Crops * 24 * 100 + 96; i += 256) smem[i] = 0.f;
+  for (int i = threadIdx.x; i < kP1Tiles; i += kResThreads) tiles[i] = 0.f;
+  for (int i = threadIdx.x; i < 48; i += kResThreads) stat[i] = 0.f;
   __syncthreads();
   bn_affine_to_lds(a, 0, aff);
   const int wave = uniform(threadIdx.x >> 6);
@@ -276,25 +319,30 @@ __global__ __launch_bounds__(256) void resnet_p1_kernel(const ResArgs a) {
   for (int g = blockIdx.x; g < groups; g += gridDim.x) {
     const int img0 = g * kP1Crops;
     __syncthreads();
-    stage_tiles<kP1Crops, 24, 8, 10, 256>(a, img0, a.z1, aff, nullptr, nullptr, tiles);
+    stage_tiles<kP1Crops, 24, 8, 10, kResThreads>(a, img0, a.z1, aff, nullptr, nullptr, tiles);
     __syncthreads();
-    conv_phase<24, 10, 4, 2, 0, 4, 24, 6, 16, kP1Crops>(a, img0, tiles, a.w + conv_off(2), a.bias[2], a.z2, stat, 6 * wave);
+    conv_part<24, 10, 4, 2, 0, 4, 24, 6, 16, kP1Crops, 4>(tiles, a.w + conv_off(2), part, wave & 3, wave >> 2);
+    __syncthreads();
+    conv_finish<4, 24, 16, kP1Crops, 4>(a, img0, part, a.bias[2], a.z2, stat, wave, kResWaves);
   }
   if (a.train) { __syncthreads(); stat_flush(a, 1, stat); }
 }
 
 // P2: y1 = relu(bn2(z2) + bn_d(zd1)); block2.conv1 24 -> 48 k3 s1 p1 and block2.downsample 24 -> 48 k1, 4 -> 4.
-// 4 crops, 4 wavefronts x 12 channels.
+// 4 crops; 4 groups of 12 channels x 4 slices of 6 input channels (both convolutions).
 constexpr int kP2Crops = 4;
-constexpr int kP2Lds = (kP2Crops * 24 * 36 + 48 + 48 + 96 + 96) * 4;
-__global__ __launch_bounds__(256) void resnet_p2_kernel(const ResArgs a) {
+constexpr int kP2Tiles = kP2Crops * 24 * 36, kP2Part = 4 * kP2Crops * 48 * 16;
+constexpr int kP2Lds = (kP2Tiles + kP2Part + 48 + 48 + 96 + 96) * 4;
+__global__ __launch_bounds__(kResThreads) void resnet_p2_kernel(const ResArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* tiles = smem;
-  float* affA = tiles + kP2Crops * 24 * 36;
+  float* part = tiles + kP2Tiles;
+  float* affA = part + kP2Part;
   float* affB = affA + 48;
   float* stat1 = affB + 48;
   float* statd = stat1 + 96;
-  for (int i = threadIdx.x; i < kP2Crops * 24 * 36 + 96 + 192; i += 256) smem[i] = 0.f;
+  for (int i = threadIdx.x; i < kP2Tiles; i += kResThreads) tiles[i] = 0.f;
+  for (int i = threadIdx.x; i < 192; i += kResThreads) stat1[i] = 0.f;
   __syncthreads();
   bn_affine_to_lds(a, 1, affA);
   bn_affine_to_lds(a, 2, affB);
@@ -303,23 +351,31 @@ __global__ __launch_bounds__(256) void resnet_p2_kernel(const ResArgs a) {
   for (int g = blockIdx.x; g < groups; g += gridDim.x) {
     const int img0 = g * kP2Crops;
     __syncthreads();
-    stage_tiles<kP2Crops, 24, 4, 6, 256>(a, img0, a.z2, affA, a.zd1, affB, tiles);
+    stage_tiles<kP2Crops, 24, 4, 6, kResThreads>(a, img0, a.z2, affA, a.zd1, affB, tiles);
     __syncthreads();
-    conv_phase<24, 6, 3, 1, 0, 4, 48, 12, 16, kP2Crops>(a, img0, tiles, a.w + conv_off(4), a.bias[4], a.z3, stat1, 12 * wave);
-    conv_phase<24, 6, 1, 1, 1, 4, 48, 12, 16, kP2Crops>(a, img0, tiles, a.w + conv_off(6), a.bias[6], a.zd2, statd, 12 * wave);
+    conv_part<24, 6, 3, 1, 0, 4, 48, 12, 16, kP2Crops, 4>(tiles, a.w + conv_off(4), part, wave & 3, wave >> 2);
+    __syncthreads();
+    conv_finish<4, 48, 16, kP2Crops, 4>(a, img0, part, a.bias[4], a.z3, stat1, wave, kResWaves);
+    __syncthreads();
+    conv_part<24, 6, 1, 1, 1, 4, 48, 12, 16, kP2Crops, 4>(tiles, a.w + conv_off(6), part, wave & 3, wave >> 2);
+    __syncthreads();
+    conv_finish<4, 48, 16, kP2Crops, 4>(a, img0, part, a.bias[6], a.zd2, statd, wave, kResWaves);
   }
   if (a.train) { __syncthreads(); stat_flush(a, 3, stat1); stat_flush(a, 5, statd); }
 }
 
-// P3: block2.conv2 48 -> 48 k3 s1 p1 on relu(bn1(z3)).  4 crops, 4 wavefronts x 12 channels.
+// P3: block2.conv2 48 -> 48 k3 s1 p1 on relu(bn1(z3)).  4 crops; 4 groups of 12 channels x 4 slices of 12 input channels.
 constexpr int kP3Crops = 4;
-constexpr int kP3Lds = (kP3Crops * 48 * 36 + 96 + 96) * 4;
-__global__ __launch_bounds__(256) void resnet_p3_kernel(const ResArgs a) {
+constexpr int kP3Tiles = kP3Crops * 48 * 36, kP3Part = 4 * kP3Crops * 48 * 16;
+constexpr int kP3Lds = (kP3Tiles + kP3Part + 96 + 96) * 4;
+__global__ __launch_bounds__(kResThreads) void resnet_p3_kernel(const ResArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* tiles = smem;
-  float* aff = tiles + kP3Crops * 48 * 36;
+  float* part = tiles + kP3Tiles;
+  float* aff = part + kP3Part;
   float* stat = aff + 96;
-  for (int i = threadIdx.x; i < kP3Crops * 48 * 36 + 192; i += 256) smem[i] = 0.f;
+  for (int i = threadIdx.x; i < kP3Tiles; i += kResThreads) tiles[i] = 0.f;
+  for (int i = threadIdx.x; i < 96; i += kResThreads) stat[i] = 0.f;
   __syncthreads();
   bn_affine_to_lds(a, 3, aff);
   const int wave = uniform(threadIdx.x >> 6);
@@ -327,26 +383,31 @@ __global__ __launch_bounds__(256) void resnet_p3_kernel(const ResArgs a) {
   for (int g = blockIdx.x; g < groups; g += gridDim.x) {
     const int img0 = g * kP3Crops;
     __syncthreads();
-    stage_tiles<kP3Crops, 48, 4, 6, 256>(a, img0, a.z3, aff, nullptr, nullptr, tiles);
+    stage_tiles<kP3Crops, 48, 4, 6, kResThreads>(a, img0, a.z3, aff, nullptr, nullptr, tiles);
     __syncthreads();
-    conv_phase<48, 6, 3, 1, 0, 4, 48, 12, 16, kP3Crops>(a, img0, tiles, a.w + conv_off(5), a.bias[5], a.z4, stat, 12 * wave);
+    conv_part<48, 6, 3, 1, 0, 4, 48, 12, 16, kP3Crops, 4>(tiles, a.w + conv_off(5), part, wave & 3, wave >> 2);
+    __syncthreads();
+    conv_finish<4, 48, 16, kP3Crops, 4>(a, img0, part, a.bias[5], a.z4, stat, wave, kResWaves);
   }
   if (a.train) { __syncthreads(); stat_flush(a, 4, stat); }
 }
 
 // P4: y2 = relu(bn2(z4) + bn_d(zd2)); block3.conv1 48 -> 96 k3 s2 p1 (4 -> 2) and block3.downsample 48 -> 96 k3 s2 p0 (4 -> 1).
-// 16 crops in 5x5 tiles (no tap reaches the bottom / right border), lane <-> (crop, pixel of the 2x2 output), 8 wavefronts
-// x 12 channels.
+// 16 crops in 5x5 tiles (no tap reaches the bottom / right border), lane <-> (crop, pixel of the 2x2 output); 8 groups of
+// 12 channels x 2 slices of 24 input channels.
 constexpr int kP4Crops = 16;
-constexpr int kP4Lds = (kP4Crops * 48 * 25 + 96 + 96 + 192 + 192) * 4;
-__global__ __launch_bounds__(512) void resnet_p4_kernel(const ResArgs a) {
+constexpr int kP4Tiles = kP4Crops * 48 * 25, kP4Part = 2 * kP4Crops * 96 * 4;
+constexpr int kP4Lds = (kP4Tiles + kP4Part + 96 + 96 + 192 + 192) * 4;
+__global__ __launch_bounds__(kResThreads) void resnet_p4_kernel(const ResArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* tiles = smem;
-  float* affA = tiles + kP4Crops * 48 * 25;
+  float* part = tiles + kP4Tiles;
+  float* affA = part + kP4Part;
   float* affB = affA + 96;
   float* stat1 = affB + 96;
   float* statd = stat1 + 192;
-  for (int i = threadIdx.x; i < kP4Crops * 48 * 25 + 192 + 384; i += 512) smem[i] = 0.f;
+  for (int i = threadIdx.x; i < kP4Tiles; i += kResThreads) tiles[i] = 0.f;
+  for (int i = threadIdx.x; i < 384; i += kResThreads) stat1[i] = 0.f;
   __syncthreads();
   bn_affine_to_lds(a, 4, affA);
   bn_affine_to_lds(a, 5, affB);
@@ -355,27 +416,35 @@ __global__ __launch_bounds__(512) void resnet_p4_kernel(const ResArgs a) {
   for (int g = blockIdx.x; g < groups; g += gridDim.x) {
     const int img0 = g * kP4Crops;
     __syncthreads();
-    stage_tiles<kP4Crops, 48, 4, 5, 512>(a, img0, a.z4, affA, a.zd2, affB, tiles);
+    stage_tiles<kP4Crops, 48, 4, 5, kResThreads>(a, img0, a.z4, affA, a.zd2, affB, tiles);
     __syncthreads();
-    conv_phase<48, 5, 3, 2, 0, 2, 96, 12, 4, kP4Crops>(a, img0, tiles, a.w + conv_off(7), a.bias[7], a.z5, stat1, 12 * wave);
-    conv_phase<48, 5, 3, 2, 1, 1, 96, 12, 4, kP4Crops>(a, img0, tiles, a.w + conv_off(9), a.bias[9], a.zd3, statd, 12 * wave);
+    conv_part<48, 5, 3, 2, 0, 2, 96, 12, 4, kP4Crops, 2>(tiles, a.w + conv_off(7), part, wave & 7, wave >> 3);
+    __syncthreads();
+    conv_finish<2, 96, 4, kP4Crops, 2>(a, img0, part, a.bias[7], a.z5, stat1, wave, kResWaves);
+    __syncthreads();
+    conv_part<48, 5, 3, 2, 1, 1, 96, 12, 4, kP4Crops, 2>(tiles, a.w + conv_off(9), part, wave & 7, wave >> 3);
+    __syncthreads();
+    conv_finish<1, 96, 4, kP4Crops, 2>(a, img0, part, a.bias[9], a.zd3, statd, wave, kResWaves);
   }
   if (a.train) { __syncthreads(); stat_flush(a, 6, stat1); stat_flush(a, 8, statd); }
 }
 
 // P5: block3.conv2 96 -> 96 k3 s2 p1 on relu(bn1(z5)), 2 -> 1: only the taps (1..2, 1..2) meet the 2x2 input, a 384-wide
-// matrix-vector product per crop.  64 crops (lane <-> crop, rows of 385 floats: conflict-free), 16 wavefronts x 6 channels.
-constexpr int kP5Crops = 64, kP5Row = 385, kP5Threads = 1024;
-constexpr int kP5Lds = (kP5Crops * kP5Row + 192 + 192) * 4;
+// matrix-vector product per crop.  64 crops (lane <-> crop, rows of 385 floats: conflict-free); 8 groups of 12 channels x
+// 2 slices of 48 input channels.
+constexpr int kP5Crops = 64, kP5Row = 385, kP5Threads = kResThreads;
+constexpr int kP5PartRow = 97;                                        // odd: lane <-> crop rows on distinct banks
+constexpr int kP5Part = 2 * kP5Crops * kP5PartRow;
+constexpr int kP5Lds = (kP5Crops * kP5Row + kP5Part + 192 + 192) * 4;
 __global__ __launch_bounds__(kP5Threads) void resnet_p5_kernel(const ResArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* rows = smem;
-  float* aff = rows + kP5Crops * kP5Row;
+  float* part = rows + kP5Crops * kP5Row;
+  float* aff = part + kP5Part;
   float* stat = aff + 192;
   for (int i = threadIdx.x; i < 192; i += kP5Threads) stat[i] = 0.f;
   bn_affine_to_lds(a, 6, aff);
   const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const float* w = a.w + conv_off(8);
   const int groups = (a.N + kP5Crops - 1) / kP5Crops;
   for (int g = blockIdx.x; g < groups; g += gridDim.x) {
     const int img0 = g * kP5Crops;
@@ -387,26 +456,32 @@ __global__ __launch_bounds__(kP5Threads) void resnet_p5_kernel(const ResArgs a) 
       rows[im * kP5Row + r] = v;
     }
     __syncthreads();
-    const bool valid = img0 + lane < a.N;
-    const float* in = rows + lane * kP5Row;
-    const int c0 = wave * 6;
-    float acc[6];
+    {
+      const int c0 = uniform(12 * (wave & 7)), ks = wave >> 3, ci0 = uniform(48 * ks);
+      const float* in = rows + lane * kP5Row + ci0 * 4;
+      cfloat_p w = (cfloat_p)(a.w + conv_off(8)) + (long)ci0 * 9 * 96;
+      float acc[12];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) acc[j] = a.bias[8][c0 + j];
+      for (int j = 0; j < 12; ++j) acc[j] = 0.f;
 #pragma unroll 1
-    for (int ci = 0; ci < 96; ++ci) {
+      for (int ci = 0; ci < 48; ++ci) {
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        const float v = in[ci * 4 + p];
-        cfloat_p wk = (cfloat_p)w + ((ci * 3 + 1 + (p >> 1)) * 3 + 1 + (p & 1)) * 96 + c0;
+        for (int p = 0; p < 4; ++p) {
+          const float v = in[ci * 4 + p];
+          cfloat_p wk = w + ((ci * 3 + 1 + (p >> 1)) * 3 + 1 + (p & 1)) * 96 + c0;
 #pragma unroll
-        for (int j = 0; j < 6; ++j) acc[j] = fmaf(wk[j], v, acc[j]);
+          for (int j = 0; j < 12; ++j) acc[j] = fmaf(wk[j], v, acc[j]);
+        }
       }
-    }
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      if (valid) a.z6[(long)(img0 + lane) * 96 + c0 + j] = acc[j];
-      if (a.train) stat_add(stat, c0 + j, valid ? acc[j] : 0.f);
+      for (int j = 0; j < 12; ++j) part[(ks * kP5Crops + lane) * kP5PartRow + c0 + j] = acc[j];
+    }
+    __syncthreads();
+    const bool valid = img0 + lane < a.N;
+    for (int c = wave; c < 96; c += kResWaves) {
+      const float v = a.bias[8][c] + part[lane * kP5PartRow + c] + part[(kP5Crops + lane) * kP5PartRow + c];
+      if (valid) a.z6[(long)(img0 + lane) * 96 + c] = v;
+      if (a.train) stat_add(stat, c, valid ? v : 0.f);
     }
   }
   if (a.train) { __syncthreads(); stat_flush(a, 7, stat); }
@@ -497,24 +572,25 @@ extern "C" int b3d_resnet_encode(const b3d_linear* conv, const b3d_batchnorm* bn
   hipLaunchKernelGGL(resnet_pack_kernel, dim3(16, kConvs), dim3(256), 0, stream, pw);
   B3D_TRY(launch_check("resnet_pack_kernel"));
   if (train) B3D_HIP_CHECK(hipMemsetAsync(sums, 0, (size_t)kBnChannels * 16, stream));
-  auto grid = [&](int crops) { const int g = (N + crops - 1) / crops; return dim3((unsigned)(g < 2048 ? g : 2048)); };
+  // persistent workgroups (as many as are resident at once): the tile zero fill and the BatchNorm affine are per workgroup
+  auto grid = [&](int crops, int resident = 512) { const int g = (N + crops - 1) / crops; return dim3((unsigned)(g < resident ? g : resident)); };
   B3D_TRY(set_lds(resnet_p0_kernel, kP0Lds));
-  hipLaunchKernelGGL(resnet_p0_kernel, grid(kP0Crops), dim3(512), kP0Lds, stream, a);
+  hipLaunchKernelGGL(resnet_p0_kernel, grid(kP0Crops), dim3(kResThreads), kP0Lds, stream, a);
   B3D_TRY(launch_check("resnet_p0_kernel"));
   B3D_TRY(set_lds(resnet_p1_kernel, kP1Lds));
-  hipLaunchKernelGGL(resnet_p1_kernel, grid(kP1Crops), dim3(256), kP1Lds, stream, a);
+  hipLaunchKernelGGL(resnet_p1_kernel, grid(kP1Crops), dim3(kResThreads), kP1Lds, stream, a);
   B3D_TRY(launch_check("resnet_p1_kernel"));
   B3D_TRY(set_lds(resnet_p2_kernel, kP2Lds));
-  hipLaunchKernelGGL(resnet_p2_kernel, grid(kP2Crops), dim3(256), kP2Lds, stream, a);
+  hipLaunchKernelGGL(resnet_p2_kernel, grid(kP2Crops), dim3(kResThreads), kP2Lds, stream, a);
   B3D_TRY(launch_check("resnet_p2_kernel"));
   B3D_TRY(set_lds(resnet_p3_kernel, kP3Lds));
-  hipLaunchKernelGGL(resnet_p3_kernel, grid(kP3Crops), dim3(256), kP3Lds, stream, a);
+  hipLaunchKernelGGL(resnet_p3_kernel, grid(kP3Crops), dim3(kResThreads), kP3Lds, stream, a);
   B3D_TRY(launch_check("resnet_p3_kernel"));
   B3D_TRY(set_lds(resnet_p4_kernel, kP4Lds));
-  hipLaunchKernelGGL(resnet_p4_kernel, grid(kP4Crops), dim3(512), kP4Lds, stream, a);
+  hipLaunchKernelGGL(resnet_p4_kernel, grid(kP4Crops, 256), dim3(kResThreads), kP4Lds, stream, a);
   B3D_TRY(launch_check("resnet_p4_kernel"));
   B3D_TRY(set_lds(resnet_p5_kernel, kP5Lds));
-  hipLaunchKernelGGL(resnet_p5_kernel, grid(kP5Crops), dim3(kP5Threads), kP5Lds, stream, a);
+  hipLaunchKernelGGL(resnet_p5_kernel, grid(kP5Crops, 256), dim3(kP5Threads), kP5Lds, stream, a);
   B3D_TRY(launch_check("resnet_p5_kernel"));
   hipLaunchKernelGGL(resnet_out_kernel, dim3((unsigned)((n * 96 + 255) / 256 < 1024 ? (n * 96 + 255) / 256 : 1024)), dim3(256), 0, stream, a);
   B3D_TRY(launch_check("resnet_out_kernel"));
