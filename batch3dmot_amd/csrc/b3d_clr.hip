@@ -1500,3 +1500,9 @@ extern "C" int b3d_clr_layer_backward(const b3d_mp_weights* mw, const b3d_graph*
   B3D_TRY(launch_reduce(ra, stream));
   return B3D_OK;
 }
+
+#ifdef B3D_EXP_STAMPS
+extern "C" int b3d_debug_stamps_clr(long long* host_dst) {
+  return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(b3d::g_stamps), sizeof(long long) * 4 * 512 * 32) == hipSuccess ? 0 : 1;
+}
+#endif

@@ -143,7 +143,7 @@ struct LayerSeq {
 
 // ---- experiment support: per-workgroup phase time stamps (off unless built with -DB3D_EXP_STAMPS) ----
 #ifdef B3D_EXP_STAMPS
-extern __device__ long long g_stamps[4][512 * 32];
+static __device__ long long g_stamps[4][512 * 32];     // one copy per translation unit (no relocatable device code)
 #define B3D_STAMP(k, i) do { if (threadIdx.x == 0 && blockIdx.x < 512) b3d::g_stamps[k][blockIdx.x * 32 + (i)] = wall_clock64(); } while (0)
 #else
 #define B3D_STAMP(k, i) do {} while (0)

@@ -530,7 +530,6 @@ extern "C" int b3d_pose_debug_layer_ptrs(void* workspace, size_t workspace_bytes
 }
 
 #ifdef B3D_EXP_STAMPS
-namespace b3d { __device__ long long g_stamps[4][512 * 32]; }
 extern "C" int b3d_debug_stamps(long long* host_dst) {
   return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(b3d::g_stamps), sizeof(long long) * 4 * 512 * 32) == hipSuccess ? 0 : 1;
 }
