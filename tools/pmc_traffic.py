@@ -9,7 +9,7 @@ import collections, csv, glob, json, os, sys
 
 FAMILY = [("mp_edge_fwd", "mp_edge_fwd"), ("mp_edge_bwd", "mp_edge_bwd"), ("mp_node_fwd", "mp_node_fwd"),
           ("node_bwd", "mp_node_bwd"), ("node_listsum", "mp_node_bwd"), ("node_gradproj", "mp_node_bwd"),
-          ("wstream", "wgrad_edge"), ("wgrad_kernel", "wgrad_other"), ("point_feat", "point_feat"), ("knn_", "knn_gat"),
+          ("wstream", "wgrad_edge"), ("wgemm", "wgrad_edge"), ("wgrad_kernel", "wgrad_other"), ("point_feat", "point_feat"), ("knn_", "knn_gat"),
           ("gat_", "knn_gat")]
 
 
