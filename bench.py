@@ -22,10 +22,12 @@ Prints ONE JSON line (rank 0).  `roofline` describes the kernel family with the 
 with HIP events on the launch stream (b3d_prof_*); `cpu_baseline` times the CPU oracle (the restated reference
 path) on the host cores, rank 0, N = 1 only.
 
-Timed region at N = 1: hipGraph replays (one captured step per pool batch; what cannot be captured -- the modality
-masks' row compaction, whose counts are shapes -- runs eagerly in front of each replay and feeds it).  Event records
-cannot be captured, so the kernel families are timed in an eager pass of the same K steps right after the timed
-region.  `--no-graph` and every N > 1 run enqueue eagerly (the all-reduce sits inside the step).
+Timed region: hipGraph replays (one captured step per pool batch; what cannot be captured -- the modality masks' row
+compaction, whose counts are shapes -- runs eagerly in front of each replay and feeds it).  At N > 1 a step is two
+replays around the eager gradient all-reduce: graph A = forward + backward (writes the flat gradient buffer), the flat
+all-reduce, graph B = the optimizer step (host enqueue of the eager step, ~10 ms, would otherwise bound the N > 1
+figure, not the GPU).  Event records cannot be captured, so the kernel families are timed in an eager pass of the same
+K steps right after the timed region.  `--no-graph` enqueues every step eagerly.
 """
 from __future__ import annotations
 
@@ -199,6 +201,26 @@ class Workload:
         return train_step(self.model, b, self.opt, batch_size=2, loss_kind="cb", logits=self.logits, grad_sync=self.sync,
                           forward_kwargs=kwargs)
 
+    def _run_fb(self, i, kwargs):
+        from batch3dmot_amd.train_step import forward_backward
+        b = self.pool[i % len(self.pool)]
+        if hasattr(b, "_b3d_graph"):
+            del b._b3d_graph
+        return forward_backward(self.model, b, self.opt, batch_size=2, loss_kind="cb", logits=self.logits, forward_kwargs=kwargs)
+
+    def captured_fb(self, i):
+        """The part of `captured` in front of the gradient exchange (N > 1: graph A; the all-reduce runs eagerly between
+        it and the optimizer graph)."""
+        k = i % len(self.pool)
+        if self.enc is not None:
+            return self._run_fb(i, {"encoded": self.enc[k]})
+        if self.rows_static is not None:
+            return self._run_fb(i, {"rows": self.rows_static[k]})
+        return self._run_fb(i, None)
+
+    def opt_step(self):
+        self.opt.step()
+
     def step(self, i):
         if self.enc is not None:
             return self._run(i, {"encoded": self.enc[i % len(self.pool)]})
@@ -311,8 +333,9 @@ def measure(wl: Workload, args, world, dist, steps, warmup, ramp_ms, use_graph):
     trace("warm-up done")
     fam_all = _lib.prof_read() if warmup > 0 else None
     _lib.prof_enable(False)
-    graphs, graph_note = None, None
-    if use_graph and world == 1:
+    graphs, graph_note, opt_graph = None, None, None
+    split = world > 1                      # N > 1: graph A (forward + backward) | eager all-reduce | graph B (optimizer)
+    if use_graph:
         try:
             graphs = []
             torch.cuda.synchronize()
@@ -321,20 +344,37 @@ def measure(wl: Workload, args, world, dist, steps, warmup, ramp_ms, use_graph):
             for i in range(pool_n):
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, stream=cap_stream, capture_error_mode="thread_local"):
-                    wl.captured(i)
+                    if split:
+                        wl.captured_fb(i)
+                    else:
+                        wl.captured(i)
                 graphs.append(g)
                 trace(f"captured batch {i}")
+            if split:
+                opt_graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(opt_graph, stream=cap_stream, capture_error_mode="thread_local"):
+                    wl.opt_step()
+                trace("captured the optimizer step")
             torch.cuda.current_stream().wait_stream(cap_stream)
             torch.cuda.synchronize()
         except Exception as exc:                                   # capture unsupported here: eager timed region
-            graphs = None
+            graphs, opt_graph = None, None
             graph_note = f"hipGraph capture failed ({type(exc).__name__}: {str(exc)[:200]}); eager timed region"
             torch.cuda.synchronize()
+        if world > 1:                                              # every rank takes the same path (each step holds a collective)
+            ok = torch.tensor([1.0 if graphs is not None else 0.0], device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if float(ok.item()) == 0.0 and graphs is not None:
+                graphs, opt_graph = None, None
+                graph_note = "hipGraph capture failed on another rank; eager timed region"
 
     def timed_step(i):
         if graphs is not None:
             wl.pre(i)
             graphs[i % pool_n].replay()
+            if split:
+                wl.sync.sync(force=True)                           # the flat gradient buffer was written by the replay
+                opt_graph.replay()
         else:
             wl.step(i)
 
@@ -434,7 +474,7 @@ def main():
                     help="camera+LiDAR+radar step: frozen encoders in train mode inside the step (default) or their outputs given")
     ap.add_argument("--no-dead-knn", action="store_true",
                     help="skip the k-NN + GAT block whose result the reference discards (secondary figure)")
-    ap.add_argument("--no-graph", action="store_true", help="enqueue every step eagerly (always the case for N > 1)")
+    ap.add_argument("--no-graph", action="store_true", help="enqueue every step eagerly")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary figures of the default N = 1 run")
     ap.add_argument("--ramp-ms", type=float, default=250.0, help="untimed clock ramp in front of the timed region (0 = none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -548,6 +588,7 @@ def main():
                 "kernels": kernels, "kernels_instrumented_warmup": kernels_warmup,
                 "untimed_clock_ramp_steps": m["ramp_steps"], "host_enqueue_ms_per_step": round(1e3 * m["t_enqueue"] / args.steps, 4),
                 "timed_region": ("hipGraph replay (one captured training step per pool batch"
+                                 + (": forward + backward graph, eager flat all-reduce, optimizer graph" if world > 1 else "")
                                  + ("; the modality masks + row compaction run eagerly in front of each replay and feed it" if wl.rows_static is not None else "")
                                  + "); kernel families timed with HIP events in an eager pass of the same K steps right after it")
                                 if m["graphs"] else ("eager" + (f" ({m['graph_note']})" if m["graph_note"] else ""))}

@@ -40,8 +40,13 @@ def test_single_process_stub():
 
 @pytest.mark.gpu
 def test_two_ranks_share_the_device_over_gloo():
-    """The real workload, eager steps with the flat all-reduce between backward and Adam, two ranks on device 0."""
-    d = _run(["--backend", "gloo", "--all-ranks-on-device-0", "--steps", "3", "--warmup", "1", "--ramp-ms", "0", "--no-cpu-baseline"],
+    """The real workload with the flat all-reduce between backward and Adam, two ranks on device 0: eager steps, and the
+    N > 1 timed region proper (forward + backward graph | eager all-reduce | optimizer graph)."""
+    d = _run(["--backend", "gloo", "--all-ranks-on-device-0", "--steps", "3", "--warmup", "1", "--ramp-ms", "0", "--no-cpu-baseline", "--no-graph"],
              timeout=900)
     assert d["n_gpus"] == 2 and d["value"] > 0 and "all-reduce" in d["config"]["workload"]
     assert d["timed_region"].startswith("eager")
+    g = _run(["--backend", "gloo", "--all-ranks-on-device-0", "--steps", "4", "--warmup", "1", "--ramp-ms", "0", "--no-cpu-baseline"],
+             timeout=900)
+    assert g["n_gpus"] == 2 and g["value"] > 0
+    assert g["timed_region"].startswith("hipGraph replay") and "all-reduce" in g["timed_region"], g["timed_region"]
