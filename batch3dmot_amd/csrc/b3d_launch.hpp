@@ -100,14 +100,14 @@ inline int launch_wgrad(WgArgs& a, hipStream_t stream, int family = B3D_K_WGRAD_
 }
 
 inline int launch_reduce(RedArgs& a, hipStream_t stream) {
-  int total = 0;
+  int total = 0;                                 // in quads of elements
   for (int i = 0; i < a.nentries; ++i) {
     a.e[i].begin = total;
-    total += a.e[i].N * a.e[i].K + a.e[i].N;
+    total += (a.e[i].N * a.e[i].K + a.e[i].N + 3) / 4;
   }
   a.total = total;
   if (total == 0) return B3D_OK;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + kRedElems - 1) / kRedElems), dim3(kRedElems * kRedParts), 0, stream, a);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + kRedQuads - 1) / kRedQuads), dim3(kRedQuads * kRedParts), 0, stream, a);
   return launch_check("wgrad_reduce_kernel");
 }
 
