@@ -1,5 +1,5 @@
 // ResNetAE.encode -- the frozen camera encoder of the camera+LiDAR+radar model (reference
-// models/resnet_ae.py: conv(3,12,4,2,1) -> ResidualBlock(12,24,k4,s2) -> ResidualBlock(24,48,k3,s1) ->
+// batch_3dmot/models/resnet_fully_conv.py:42-82,84-161: conv(3,12,4,2,1) -> ResidualBlock(12,24,k4,s2) -> ResidualBlock(24,48,k3,s1) ->
 // ResidualBlock(48,96,k3,s2) on [N,3,32,32] crops -> [N,96]), train-mode BatchNorm included.
 //
 // The whole encoder is 1.5 MMAC per crop (9 GFLOP per 3,000 crops) on activations of at most 12 KB per crop: what it

@@ -312,7 +312,7 @@ int b3d_point_feat_stats(const b3d_linear* conv, const float* x, const float* tr
 int b3d_point_feat(const b3d_linear* conv, const float* x, const float* trans, int32_t B, int32_t C, int32_t P,
                    int32_t relu_last, void* workspace, size_t workspace_bytes, float* out, b3d_stream stream);
 
-/* ResNetAE.encode (reference models/resnet_ae.py: conv(3,12,4,2,1), ResidualBlock(12,24,k4,s2), ResidualBlock(24,48,k3,s1),
+/* ResNetAE.encode (reference batch_3dmot/models/resnet_fully_conv.py:42-82 ResidualBlock, :84-161 ResNetAE.encode: conv(3,12,4,2,1), ResidualBlock(12,24,k4,s2), ResidualBlock(24,48,k3,s1),
  * ResidualBlock(48,96,k3,s2)) on x [N,3,32,32] -> out [N,96], BatchNorm in train mode (`train` != 0: batch statistics, running
  * statistics and num_batches_tracked updated as nn.BatchNorm2d does) or eval mode (running statistics).
  * conv[10]: conv, block1.{conv1,conv2,downsample.0}, block2.{...}, block3.{...}, weights [out,in,k,k];
