@@ -6,6 +6,8 @@
 #include "b3d_wstream.hpp"
 #include "b3d_wstream2.hpp"
 #include "b3d_wgemm.hpp"
+#include <algorithm>
+#include <vector>
 #include "b3d_hoist.hpp"
 #include "b3d_att.hpp"
 
@@ -937,6 +939,8 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
     static const bool wgemm_on = [] { const char* e = getenv("B3D_WGEMM"); return e ? atoi(e) != 0 : true; }();
     const bool coop = wgemm_on && w.hoist;
     WsLauncher wl, wlc;
+    std::vector<WsJob> coop_jobs;                // added to wlc longest task first (below)
+    coop_jobs.reserve(128);
     wl.begin(w.ws_table, kTableCap / 2, w.ws_task_job, kTaskCap / 2, stream);
     wlc.begin(w.ws_table + kTableCap / 2, kTableCap / 2, w.ws_task_job + kTaskCap / 2, kTaskCap / 2, stream);
     hipLaunchKernelGGL(iota_kernel, dim3(((E > N ? E : N) + 255) / 256), dim3(256), 0, stream, w.iota, E > N ? E : N);
@@ -1018,7 +1022,7 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
         }
         wcol += cols[ci].width;
       }
-      for (int j = 0; j < nj; ++j) wlc.add(jobs[j]);
+      for (int j = 0; j < nj; ++j) coop_jobs.push_back(jobs[j]);
       return true;
     };
     auto add_block = [&](LinSlab& ls, long rows, int nvar, int rpt, const float* gp, const int* gidx, long gvs, int gstride, int gcol0,
@@ -1079,7 +1083,7 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
           jb.act[2] = jb.act[0];
           jb.wcol[0] = 0; jb.wcol[1] = 64; jb.wrow = 0; jb.write_bias = 1; jb.shape = WGM_256_128;
           jb.rows = E; jb.nvar = depth; jb.rows_per_task = rp; jb.NP = ls.NP; jb.KP = ls.KP; jb.slab = ls.slab;
-          wlc.add(jb);
+          coop_jobs.push_back(jb);
         } else {
         add_block(w.vlin[VL_EU0E], E, depth, rp, w.GdH1, nullptr, eL1, D::EH1, 0, ce, 2, true);
         }
@@ -1180,6 +1184,18 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
     }
     B3D_REQUIRE(wl.status == 0, "streaming weight gradient: job table overflow (%d jobs, %d tasks)", wl.njobs, wl.total_tasks);
     B3D_TRY(launch_check("wstream_kernel"));
+    {
+      // One workgroup per task, dispatched in task order as CUs free up: longest tasks first, or the 60 us tasks of
+      // att_edge_encoder (last in plan order) start when the rest of the chip has run dry.  Cost of a task ~ its 32-row
+      // steps times the bytes of a step.
+      auto cost = [](const WsJob& j) {
+        static const int w[WGM_SHAPES] = {384, 320, 256, 192, 320, 352, 256, 288, 224, 320, 224, 384};
+        const long rows = j.rows < j.rows_per_task ? j.rows : j.rows_per_task;
+        return ((rows + kWgmRows - 1) / kWgmRows) * (long)j.nvar * w[j.shape];
+      };
+      std::stable_sort(coop_jobs.begin(), coop_jobs.end(), [&](const WsJob& a, const WsJob& b) { return cost(a) > cost(b); });
+      for (const WsJob& j : coop_jobs) wlc.add(j);
+    }
     wlc.flush();
     B3D_REQUIRE(wlc.status == 0, "cooperative weight gradient: job table overflow (%d jobs, %d tasks)", wlc.njobs, wlc.total_tasks);
     if (wlc.total_tasks > 0) {
