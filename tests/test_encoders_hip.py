@@ -213,3 +213,64 @@ def test_resnet_encode_eval_mode_and_argument_checks():
         encoders.resnet_encode_hip(m, torch.rand(4, 3, 16, 16, device=dev))
     lib = _lib.load()
     assert lib.b3d_resnet_encode(None, None, None, 4, 0, None, 0, None, None) != 0
+
+
+@pytest.mark.parametrize("c,p,b,with_trans", [(3, 128, 257, True), (3, 128, 5, False), (4, 64, 130, False)])
+def test_point_moments_and_bn_fold_match_float64(c, p, b, with_trans):
+    """``b3d_point_moments`` (mean / second moments of a point stack's layer inputs, the 64 x 64 case accumulated by
+    fp32 MFMA) and ``b3d_bn_fold_moments`` (batch statistics of the affine pre-activation from those moments, the
+    running-statistics update and the fold) against the same quantities formed in float64 by PyTorch."""
+    import ctypes as C
+    from batch3dmot_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(31)
+    x = (torch.randn(b, c, p, generator=g) * 2.0 + 0.5).to(dev)
+    trans = (torch.eye(3).repeat(b, 1, 1) + 0.1 * torch.randn(b, 3, 3, generator=g)).to(dev) if with_trans else None
+    w1 = (torch.randn(64, c, generator=g) * 0.5).to(dev)
+    b1 = (torch.randn(64, generator=g) * 0.1).to(dev)
+    xin = torch.bmm(x.transpose(2, 1), trans).transpose(2, 1) if with_trans else x
+    pts = xin.permute(0, 2, 1).reshape(-1, c).double()                     # [n, c]
+    n = pts.size(0)
+    nbytes = lib.b3d_point_moments_workspace_bytes()
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    stream = _lib.current_stream(dev)
+    tp = trans.contiguous().data_ptr() if with_trans else None
+
+    def moments(fold):
+        k = 64 if fold is not None else c
+        mu = torch.empty(k, dtype=torch.float64, device=dev)
+        sec = torch.empty(k, k, dtype=torch.float64, device=dev)
+        _lib.check(lib.b3d_point_moments(C.byref(fold) if fold is not None else None, x.data_ptr(), tp, b, c, p, ws.data_ptr(), nbytes,
+                                         mu.data_ptr(), sec.data_ptr(), stream), "b3d_point_moments")
+        return mu, sec
+
+    mu, sec = moments(None)
+    assert rel(mu, pts.mean(0)) < 1e-6 and rel(sec, pts.t() @ pts / n) < 1e-6
+    fold = _lib.b3d_linear()
+    fold.w, fold.b = w1.data_ptr(), b1.data_ptr()
+    mu2, sec2 = moments(fold)
+    h1 = torch.relu(pts @ w1.double().t() + b1.double())
+    assert rel(mu2, h1.mean(0)) < 2e-6 and rel(sec2, h1.t() @ h1 / n) < 2e-6
+    # fold: a 64 -> 128 layer behind h1, BatchNorm with negative scales and tracked statistics
+    w2 = (torch.randn(128, 64, generator=g) * 0.2).to(dev)
+    b2 = (torch.randn(128, generator=g) * 0.1).to(dev)
+    bn = torch.nn.BatchNorm1d(128).to(dev)
+    with torch.no_grad():
+        bn.weight.copy_(torch.randn(128, generator=g))
+        bn.bias.copy_(torch.randn(128, generator=g))
+    ref = torch.nn.BatchNorm1d(128).to(dev).double()
+    ref.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in bn.state_dict().items()})
+    z = h1 @ w2.double().t() + b2.double()
+    ref.train()
+    want = ref(z)                                                            # normalised pre-activation, float64
+    wf = torch.empty_like(w2)
+    bf = torch.empty_like(b2)
+    _lib.check(lib.b3d_bn_fold_moments(mu2.data_ptr(), sec2.data_ptr(), 64, w2.data_ptr(), b2.data_ptr(), 128, bn.weight.data_ptr(),
+                                       bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+                                       bn.num_batches_tracked.data_ptr(), 0.1, float(bn.eps), n, wf.data_ptr(), bf.data_ptr(), stream),
+               "b3d_bn_fold_moments")
+    got = h1 @ wf.double().t() + bf.double()
+    assert rel(got, want) < 2e-5
+    assert rel(bn.running_mean.double(), ref.running_mean) < 1e-5 and rel(bn.running_var.double(), ref.running_var) < 1e-5
+    assert int(bn.num_batches_tracked) == 1
