@@ -45,15 +45,15 @@ using SeqFL = LayerSeq<L<256, 192>, L<192, 128>>;                        // 256-
 using SeqFR = LayerSeq<L<256, 192>, L<192, 128>, L<128, 64>>;            // 256-192-128-64      :66-72
 template <int DD> using SeqAff = LayerSeq<L<DD, DD>, L<DD, DD>>;         // out_proj(v_proj(x)) :77-79,148-155
 using SeqAT0 = LayerSeq<L<640, 512>>;                                    // att_edge_encoder    :81-91
-using SeqAT1 = LayerSeq<L<512, 384>>;
-using SeqAT2 = LayerSeq<L<384, 256>>;
+using SeqAT1 = LayerSeq<L<512, 384, 1>>;     // 384 / 512 inputs: bf16x6 too (one wide layer per kernel: the operand pieces fit)
+using SeqAT2 = LayerSeq<L<384, 256, 1>>;
 using SeqAT3 = LayerSeq<L<256, 128>>;
 using SeqAT4 = LayerSeq<L<128, 64>>;
 // att_edge_encoder.0 with its node columns hoisted (b3d_att.hpp)
 using SeqAttU = LayerSeq<LF<96, 1024>, LF<96, 1024>, LF<96, 1024>>;       // U = (W0[:, 0:288] s + b0 | W0[:, 288:576] s), three K-slices
 template <class... Ls> struct Rep16 { using type = LayerSeq<Ls..., Ls..., Ls..., Ls..., Ls..., Ls..., Ls..., Ls..., Ls..., Ls..., Ls..., Ls..., Ls..., Ls..., Ls..., Ls...>; };
 using SeqAttDs = Rep16<LF<64, 288>>::type;                                // d s = W0[:, 0:288]^T dU_i + W0[:, 288:576]^T dU_j, sixteen K-slices
-using SeqAT0eT = LayerSeq<L<512, 64>>;                                    // d e0 = W0[:, 576:640]^T d A0
+using SeqAT0eT = LayerSeq<L<512, 64, 1>>;                                    // d e0 = W0[:, 576:640]^T d A0
 // transposed (data gradient)
 using SeqClsT = LayerSeq<L<16, 16>, L<16, 16>, L<16, 32>, L<32, 64>>;
 using SeqEET = LayerSeq<L<64, 32>, L<32, 16>>;
@@ -64,7 +64,7 @@ template <int DD> using SeqAffT = LayerSeq<L<DD, DD>, L<DD, DD>>;
 using SeqAT4T = LayerSeq<L<64, 128>>;
 using SeqAT3T = LayerSeq<L<128, 256>>;
 using SeqAT2T = LayerSeq<L<256, 384>>;
-using SeqAT1T = LayerSeq<L<384, 512>>;
+using SeqAT1T = LayerSeq<L<384, 512, 1>>;
 using SeqAT0T = LayerSeq<L<512, 640>>;
 
 enum { EE0, EE1, EE2, NE0, NE1, C0, C1, C2, C3, FL0, FL1, FR0, FR1, FR2,

@@ -144,8 +144,10 @@ class ClrWork:
                 "point_feat": 4.0 * (2 * nl * (3 * 128 + 4 * 1024) + nr * (4 * 64 + 4 * 1024))}
         bf = {"mp_edge_fwd": 1.0 if hoist_mp else 0.0, "mp_edge_bwd": 1.0 if hoist_mp else 0.0, "point_feat": 0.999,
               "wgrad_edge": 1.0 if hoist_mp else 0.0,       # the cooperative kernel of the hoisted plan (csrc/b3d_wgemm.hpp)
-              "att_fwd": (64 * 512 + 256 * 128 + 128 * 64) / cls.X_ATT if hoist_att else 0.06,
-              "att_bwd": (64 * 128 + 128 * 256 + 256 * 384) / cls.X_ATT if hoist_att else 0.2}
+              # every per-edge layer of att_edge_encoder runs as bf16x6 (384 / 512-input layers included); the per-node
+              # parts of its first layer (att_node_linear) are exact-fp32 MFMA
+              "att_fwd": cls.X_ATT * e / (cls.X_ATT * e + att_node * n) if hoist_att else 0.06,
+              "att_bwd": cls.X_ATT * e / (cls.X_ATT * e + att_node * n) if hoist_att else 0.2}
         return alg, exe, byts, bf
 
 
