@@ -302,8 +302,9 @@ class ResNetAE(nn.Module):
             nn.ConvTranspose2d(12, 3, 4, stride=2, padding=1), nn.Sigmoid())
 
     def encode(self, x):
-        if (_use_hip(self, x) and _no_autograd(self, x)) or _use_hip_resnet_train(self, x):
-            return resnet_encode_hip(self, x)
+        if x.dim() == 4 and tuple(x.shape[1:]) == (3, 32, 32) and x.size(0) > 0 and (
+                (_use_hip(self, x) and _no_autograd(self, x)) or _use_hip_resnet_train(self, x)):
+            return resnet_encode_hip(self, x)          # the crop size the GNN feeds (other sizes: the PyTorch modules below)
         out = self.res_block3(self.res_block2(self.res_block1(self.conv(x))))
         return out.view(out.size(0), -1)
 
