@@ -941,8 +941,10 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
     WsLauncher wl, wlc;
     std::vector<WsJob> coop_jobs;                // added to wlc longest task first (below)
     coop_jobs.reserve(128);
-    wl.begin(w.ws_table, kTableCap / 2, w.ws_task_job, kTaskCap / 2, stream);
-    wlc.begin(w.ws_table + kTableCap / 2, kTableCap / 2, w.ws_task_job + kTaskCap / 2, kTaskCap / 2, stream);
+    // the per-wavefront decomposition alone needs > 160 jobs: it gets the whole table when the cooperative kernel is off
+    const int jobs_c = coop ? kTableCap / 2 : 0, tasks_c = coop ? kTaskCap / 2 : 0;
+    wl.begin(w.ws_table, kTableCap - jobs_c, w.ws_task_job, kTaskCap - tasks_c, stream);
+    wlc.begin(w.ws_table + (kTableCap - jobs_c), jobs_c, w.ws_task_job + (kTaskCap - tasks_c), tasks_c, stream);
     hipLaunchKernelGGL(iota_kernel, dim3(((E > N ? E : N) + 255) / 256), dim3(256), 0, stream, w.iota, E > N ? E : N);
     B3D_TRY(launch_check("iota_kernel"));
     B3D_HIP_CHECK(hipMemsetAsync(w.zrow, 0, 256 * sizeof(float), stream));
