@@ -24,6 +24,12 @@ constexpr int kWgmThreads = 512, kWgmRows = 32, kWgmMaxW = 384;
 __host__ __device__ constexpr int wgm_pitch(int W) { return ((W / 2 - 8 + 63) / 64) * 64 + 8; }     // dwords, >= W / 2, = 8 mod 64
 constexpr int kWgmLdsBytes = 2 * 3 * kWgmRows * wgm_pitch(kWgmMaxW) * 4;
 
+// LDS pointers stay in the LDS address space end to end: through a generic float* (a noinline function's argument) every one
+// of the 48 transposed reads of a step paid an address-space cast with its null check (cmp + cndmask + 64-bit add).
+typedef __attribute__((address_space(3))) float lds_float;
+// ... and the operand rows are read as GLOBAL loads: the job's pointers come out of a struct, i.e. generic, and generic
+// loads are flat_load (they also tick the LDS counter and check the LDS aperture)
+typedef const __attribute__((address_space(1))) v4f* gbl_v4f_p;
 typedef short wgm_s4 __attribute__((ext_vector_type(4)));
 typedef short wgm_s8 __attribute__((ext_vector_type(8)));
 
@@ -59,7 +65,7 @@ __device__ __forceinline__ void wgm_split4(const v4f x, unsigned (&p0)[2], unsig
 }
 
 // operand fragment: rows {4g+q} and {16+4g+q} of 16 columns starting at dword column `cd` of one piece image
-__device__ __forceinline__ bf8 wgm_frag(const float* img, int lane_off /* (4g+q) * pitch + 2p, dwords */, int pitch, int cd) {
+__device__ __forceinline__ bf8 wgm_frag(const lds_float* img, int lane_off /* (4g+q) * pitch + 2p, dwords */, int pitch, int cd) {
   auto* p0 = (__attribute__((address_space(3))) wgm_s4*)(img + lane_off + cd);
   auto* p1 = (__attribute__((address_space(3))) wgm_s4*)(img + lane_off + 16 * pitch + cd);
   const wgm_s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(p0);
@@ -70,7 +76,7 @@ __device__ __forceinline__ bf8 wgm_frag(const float* img, int lane_off /* (4g+q)
 
 // not inlined: one register allocation per shape (inlined into the dispatch switch the kernel spilled 164 VGPRs)
 template <int WR, int WC, int MBW, int NBW, bool GATHER>
-__device__ __attribute__((noinline)) void wgm_task(const WsJob& job, int chunk, float* lds) {
+__device__ __attribute__((noinline)) void wgm_task(const WsJob& job, int chunk, lds_float* lds) {
   constexpr int NG = 16 * WR * MBW, KG = 16 * WC * NBW, W = NG + KG, PITCH = wgm_pitch(W);
   constexpr int PIECE = kWgmRows * PITCH, BUF = 3 * PIECE;
   constexpr int G4 = NG / 4, A4 = KG / 4;
@@ -131,24 +137,26 @@ __device__ __attribute__((noinline)) void wgm_task(const WsJob& job, int chunk, 
       const int row = grow0 + RG * i;
       const bool ok = live && gthread && row < kWgmRows && row < left;
       const float* ptr = GATHER ? gv + (long)gi[i] * gstride : gv + (long)(RG * i) * gstride;
-      gq[i] = ok ? *reinterpret_cast<const v4f*>(ptr) : zero4;
+      gq[i] = ok ? *(gbl_v4f_p)ptr : zero4;
     }
 #pragma unroll
     for (int i = 0; i < ALs; ++i) {
       const int row = arow0 + RA * i;
       const bool ok = live && athread && row < kWgmRows && row < left;
-      aq[i] = ok ? *reinterpret_cast<const v4f*>(av + (long)(RA * i) * astride) : zero4;
+      aq[i] = ok ? *(gbl_v4f_p)(av + (long)(RA * i) * astride) : zero4;
     }
   };
-  auto put = [&](float* buf, int off, const v4f x) {
+  auto put = [&](lds_float* buf, int off, const v4f x) {
     unsigned p0[2], p1[2], p2[2];
     wgm_split4(x, p0, p1, p2);
-    unsigned* d = reinterpret_cast<unsigned*>(buf) + off;
-    *reinterpret_cast<uint2*>(d) = uint2{p0[0], p0[1]};
-    *reinterpret_cast<uint2*>(d + PIECE) = uint2{p1[0], p1[1]};
-    *reinterpret_cast<uint2*>(d + 2 * PIECE) = uint2{p2[0], p2[1]};
+    typedef unsigned wgm_u2 __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(3))) wgm_u2 lds_u2;
+    lds_float* d = buf + off;
+    *(lds_u2*)d = wgm_u2{p0[0], p0[1]};
+    *(lds_u2*)(d + PIECE) = wgm_u2{p1[0], p1[1]};
+    *(lds_u2*)(d + 2 * PIECE) = wgm_u2{p2[0], p2[1]};
   };
-  auto stage = [&](float* buf, const v4f (&gq)[GLs], const v4f (&aq)[ALs]) {    // registers -> three bf16 piece images
+  auto stage = [&](lds_float* buf, const v4f (&gq)[GLs], const v4f (&aq)[ALs]) {    // registers -> three bf16 piece images
 #pragma unroll
     for (int i = 0; i < GLs; ++i) {
       if (gthread && grow0 + RG * i < kWgmRows) {
@@ -169,7 +177,7 @@ __device__ __attribute__((noinline)) void wgm_task(const WsJob& job, int chunk, 
 
   const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
   const int lane_off = (4 * g + q) * PITCH + 2 * p;
-  auto compute = [&](const float* cur) {
+  auto compute = [&](const lds_float* cur) {
     Bf3 af[MBW];
 #pragma unroll
     for (int a = 0; a < MBW; ++a) {
@@ -248,14 +256,14 @@ __device__ __attribute__((noinline)) void wgm_task(const WsJob& job, int chunk, 
     }
   }
   if (job.write_bias) {
-    float* colsum = lds;                                     // every wavefront is past its last LDS read (barrier above)
+    lds_float* colsum = lds;                                 // every wavefront is past its last LDS read (barrier above)
     for (int i = tid; i < NG; i += kWgmThreads) colsum[i] = 0.f;
     __syncthreads();
     if (gthread) {
-      atomicAdd(&colsum[4 * gc4 + 0], bs.x);
-      atomicAdd(&colsum[4 * gc4 + 1], bs.y);
-      atomicAdd(&colsum[4 * gc4 + 2], bs.z);
-      atomicAdd(&colsum[4 * gc4 + 3], bs.w);
+      atomicAdd((float*)&colsum[4 * gc4 + 0], bs.x);
+      atomicAdd((float*)&colsum[4 * gc4 + 1], bs.y);
+      atomicAdd((float*)&colsum[4 * gc4 + 2], bs.z);
+      atomicAdd((float*)&colsum[4 * gc4 + 3], bs.w);
     }
     __syncthreads();
     for (int i = tid; i < NG; i += kWgmThreads) slab[(size_t)job.NP * job.KP + job.wrow + i] = colsum[i];
@@ -278,21 +286,21 @@ static __global__ __launch_bounds__(kWgmThreads, 1) void wgemm_kernel(const WsJo
     const int chunk = task - job.task_begin;
     const bool gather = job.g.idx != iota;
     switch (job.shape) {
-      case WGM_128_256: wgm_task<2, 4, 4, 4, false>(job, chunk, wgm_lds); break;
+      case WGM_128_256: wgm_task<2, 4, 4, 4, false>(job, chunk, (lds_float*)wgm_lds); break;
       case WGM_128_192:
-        if (gather) wgm_task<2, 4, 4, 3, true>(job, chunk, wgm_lds);
-        else wgm_task<2, 4, 4, 3, false>(job, chunk, wgm_lds);
+        if (gather) wgm_task<2, 4, 4, 3, true>(job, chunk, (lds_float*)wgm_lds);
+        else wgm_task<2, 4, 4, 3, false>(job, chunk, (lds_float*)wgm_lds);
         break;
-      case WGM_128_128: wgm_task<2, 4, 4, 2, false>(job, chunk, wgm_lds); break;
-      case WGM_64_128: wgm_task<2, 4, 2, 2, false>(job, chunk, wgm_lds); break;
-      case WGM_256_64: wgm_task<8, 1, 2, 4, false>(job, chunk, wgm_lds); break;
-      case WGM_256_96: wgm_task<8, 1, 2, 6, false>(job, chunk, wgm_lds); break;
-      case WGM_192_64: wgm_task<4, 2, 3, 2, false>(job, chunk, wgm_lds); break;
-      case WGM_192_96: wgm_task<4, 2, 3, 3, false>(job, chunk, wgm_lds); break;
-      case WGM_96_128: wgm_task<2, 4, 3, 2, false>(job, chunk, wgm_lds); break;
-      case WGM_192_128: wgm_task<2, 4, 6, 2, false>(job, chunk, wgm_lds); break;
-      case WGM_128_96: wgm_task<4, 2, 2, 3, false>(job, chunk, wgm_lds); break;
-      case WGM_256_128: wgm_task<8, 1, 2, 8, false>(job, chunk, wgm_lds); break;
+      case WGM_128_128: wgm_task<2, 4, 4, 2, false>(job, chunk, (lds_float*)wgm_lds); break;
+      case WGM_64_128: wgm_task<2, 4, 2, 2, false>(job, chunk, (lds_float*)wgm_lds); break;
+      case WGM_256_64: wgm_task<8, 1, 2, 4, false>(job, chunk, (lds_float*)wgm_lds); break;
+      case WGM_256_96: wgm_task<8, 1, 2, 6, false>(job, chunk, (lds_float*)wgm_lds); break;
+      case WGM_192_64: wgm_task<4, 2, 3, 2, false>(job, chunk, (lds_float*)wgm_lds); break;
+      case WGM_192_96: wgm_task<4, 2, 3, 3, false>(job, chunk, (lds_float*)wgm_lds); break;
+      case WGM_96_128: wgm_task<2, 4, 3, 2, false>(job, chunk, (lds_float*)wgm_lds); break;
+      case WGM_192_128: wgm_task<2, 4, 6, 2, false>(job, chunk, (lds_float*)wgm_lds); break;
+      case WGM_128_96: wgm_task<4, 2, 2, 3, false>(job, chunk, (lds_float*)wgm_lds); break;
+      case WGM_256_128: wgm_task<8, 1, 2, 8, false>(job, chunk, (lds_float*)wgm_lds); break;
       default: break;
     }
   }
