@@ -12,7 +12,8 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libb3d_hip.so")
+# B3D_LIB=name selects an experiment build (make VARIANT=name: libb3d_hip_name.so); profiling / A-B tools only
+LIB_PATH = os.path.join(_HERE, "libb3d_hip_%s.so" % os.environ["B3D_LIB"] if os.environ.get("B3D_LIB") else "libb3d_hip.so")
 
 B3D_FLAG_TRAINING = 1
 B3D_FLAG_RUN_DEAD_KNN = 2

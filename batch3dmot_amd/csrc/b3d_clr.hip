@@ -789,7 +789,7 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
         B3D_TRY(launch_rows<kNWEdge>(mp_edge_bwd_h_kernel<DB, true, kNWEdge>, "mp_edge_bwd", eb, E, stream, B3D_K_EDGE_BWD, stream_lds_bytes<HC::EdgeBwdSeq>()));
       } else {
         eb.wpack = w.wp_ebwd_nm_h;
-        B3D_TRY(launch_rows<kNWEdge>(mp_edge_bwd_h_kernel<DB, false, kNWEdge>, "mp_edge_bwd_last", eb, E, stream, B3D_K_OTHER, stream_lds_bytes<HC::EdgeBwdSeqNoMsg>()));
+        B3D_TRY(launch_rows<kNWEdge>(mp_edge_bwd_h_kernel<DB, false, kNWEdge>, "mp_edge_bwd_last", eb, E, stream, B3D_K_EDGE_BWD, stream_lds_bytes<HC::EdgeBwdSeqNoMsg>()));
       }
       da_first = false;
       cur ^= 1;
@@ -810,7 +810,7 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
       B3D_TRY(launch_rows<kNWEdge>(mp_edge_bwd_kernel<D, true, kNWEdge>, "mp_edge_bwd", eb, E, stream, B3D_K_EDGE_BWD));
     } else {
       eb.wpack = w.wp_ebwd_nm;
-      B3D_TRY(launch_rows<kNWEdge>(mp_edge_bwd_kernel<D, false, kNWEdge>, "mp_edge_bwd_last", eb, E, stream, B3D_K_OTHER));
+      B3D_TRY(launch_rows<kNWEdge>(mp_edge_bwd_kernel<D, false, kNWEdge>, "mp_edge_bwd_last", eb, E, stream, B3D_K_EDGE_BWD));
     }
     da_first = false;
     cur ^= 1;

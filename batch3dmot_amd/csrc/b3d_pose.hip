@@ -752,7 +752,7 @@ extern "C" int b3d_pose_backward(const b3d_pose_weights* pw, const b3d_graph* g,
         B3D_TRY(launch_rows<kNWEdgeH>(mp_edge_bwd_h_kernel<D, true, kNWEdgeH>, "mp_edge_bwd", eb, E, stream, B3D_K_EDGE_BWD, stream_lds_bytes<HP::EdgeBwdSeq>()));
       } else {
         eb.wpack = w.wp_ebwd_nm_h;
-        B3D_TRY(launch_rows<kNWEdgeH>(mp_edge_bwd_h_kernel<D, false, kNWEdgeH>, "mp_edge_bwd_last", eb, E, stream, B3D_K_OTHER, stream_lds_bytes<HP::EdgeBwdSeqNoMsg>()));
+        B3D_TRY(launch_rows<kNWEdgeH>(mp_edge_bwd_h_kernel<D, false, kNWEdgeH>, "mp_edge_bwd_last", eb, E, stream, B3D_K_EDGE_BWD, stream_lds_bytes<HP::EdgeBwdSeqNoMsg>()));
       }
     } else {
     EdgeBwdArgs eb;
@@ -770,7 +770,7 @@ extern "C" int b3d_pose_backward(const b3d_pose_weights* pw, const b3d_graph* g,
       B3D_TRY(launch_rows<kNWEdge>(mp_edge_bwd_kernel<D, true, kNWEdge>, "mp_edge_bwd", eb, E, stream, B3D_K_EDGE_BWD));
     } else {
       eb.wpack = w.wp_ebwd_nm;
-      B3D_TRY(launch_rows<kNWEdge>(mp_edge_bwd_kernel<D, false, kNWEdge>, "mp_edge_bwd_last", eb, E, stream, B3D_K_OTHER));
+      B3D_TRY(launch_rows<kNWEdge>(mp_edge_bwd_kernel<D, false, kNWEdge>, "mp_edge_bwd_last", eb, E, stream, B3D_K_EDGE_BWD));
     }
     }
     cur ^= 1;

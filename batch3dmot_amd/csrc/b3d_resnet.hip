@@ -14,7 +14,8 @@
 //     wavefront <-> a group of output channels, so that the weights are wave-uniform and arrive through the scalar
 //     cache (s_load, v_fmac with an SGPR operand); one LDS read of an input value feeds all channels of the group;
 //   * writes the RAW convolution outputs and accumulates their per-channel sum and sum of squares (wavefront reduction
-//     -> LDS -> one float64 atomic per channel and workgroup).
+//     -> LDS -> a per-workgroup row of partial sums -> added in block order by the last workgroup to arrive: bitwise
+//     reproducible).
 // Phases (crops per workgroup): P0 conv + block1.conv1 + block1.downsample (2), P1 block1.conv2 (4), P2 block2.conv1 +
 // downsample (4), P3 block2.conv2 (4), P4 block3.conv1 + downsample (16), P5 block3.conv2 (64), then the output
 // kernel (BatchNorm + add + ReLU of the last block) and the running-statistics update of all nine BatchNorms.
@@ -37,6 +38,8 @@ __host__ __device__ constexpr int conv_off(int i) { int o = 0; for (int k = 0; k
 constexpr int kWeightFloats = conv_off(kConvs);
 __host__ __device__ constexpr int bn_off(int i) { int o = 0; for (int k = 0; k < i; ++k) o += kBnC[k]; return o; }
 constexpr int kBnChannels = bn_off(kBns);                              // 504
+constexpr int kResThreads = 1024, kResWaves = 16;                      // every phase kernel
+constexpr int kResMaxGrid = 512;                                       // persistent workgroups of a phase, at most
 
 struct BnDev {
   const float *gamma, *beta;
@@ -50,7 +53,9 @@ struct ResArgs {
   const float* w;          // packed weights: conv i at conv_off(i), [ci][ky][kx][co]
   const float* bias[kConvs];
   BnDev bn[kBns];
-  double* sums;            // [kBnChannels][2]
+  double* sums;            // [kBnChannels][2]  batch sums, written by the LAST workgroup of the producing phase
+  float* part;             // [kResMaxGrid][2 kBnChannels]  per-workgroup partial sums (train mode)
+  unsigned* tickets;       // [kBns] arrival counters of the workgroups of a phase (zeroed per call)
   float *z1, *zd1, *z2, *z3, *zd2, *z4, *z5, *zd3, *z6;
   float* out;              // [N, 96]
 };
@@ -111,8 +116,62 @@ __device__ __forceinline__ void stat_add(float* stat, int c, float v) {
   const int lane = threadIdx.x & 63;
   if ((lane & 31) == 0) atomicAdd(&stat[2 * c + (lane >> 5)], f);
 }
-__device__ __forceinline__ void stat_flush(const ResArgs& a, int b, const float* stat) {
-  for (int i = threadIdx.x; i < 2 * kBnC[b]; i += blockDim.x) atomicAdd(&a.sums[2 * bn_off(b) + i], (double)stat[i]);
+// Batch sums in a FIXED order (the result must not depend on which workgroup arrives first: no float or double atomics
+// across workgroups).  Every workgroup parks its partial sums in its own row of `part`; the workgroup whose ticket is the
+// last one adds the rows in block order (float64) into `sums`, which the NEXT launch reads.  Hand-off as
+// MI355X_MICROARCH.md prescribes: stores drained by every storing wavefront, workgroup barrier, one lane's agent-scope
+// release in front of the ticket; on the last workgroup one agent-scope acquire in front of the barrier that precedes the reads.
+typedef float v4s __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void stat_flush(const ResArgs& a, int b, const float* stat, double* scratch) {
+  __shared__ int s_last;
+  const int n2 = 2 * kBnC[b], off = 2 * bn_off(b);
+  for (int i = threadIdx.x; i < n2; i += blockDim.x) a.part[(size_t)blockIdx.x * (2 * kBnChannels) + off + i] = stat[i];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned t = __hip_atomic_fetch_add(&a.tickets[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = (t == gridDim.x - 1) ? 1 : 0;
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    s_last = last;
+  }
+  __syncthreads();
+  if (s_last) {
+    // rows added in block order, the blocks cut into contiguous slices that the threads share out (the partition depends
+    // on the launch geometry only): a thread adds four neighbouring columns of its slice (16-byte loads, eight rows in
+    // flight), float64; then the slices are added in order.  `scratch`: 32 KB of this workgroup's LDS that is dead by now.
+    double* s_slice = scratch;
+    const int n4 = n2 / 4;
+    const int nsl = (int)blockDim.x / n4;                    // 21 .. 85 slices
+    const int per = ((int)gridDim.x + nsl - 1) / nsl;
+    const int sl = (int)threadIdx.x / n4, q = (int)threadIdx.x - sl * n4;
+    if (sl < nsl) {
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      const int b0 = sl * per, b1 = min(b0 + per, (int)gridDim.x);
+      const float* base = a.part + off + 4 * q;
+      for (int blk = b0; blk < b1; blk += 8) {
+        v4s v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          v[u] = (blk + u < b1) ? *reinterpret_cast<const v4s*>(base + (size_t)(blk + u) * (2 * kBnChannels)) : v4s{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { s0 += (double)v[u].x; s1 += (double)v[u].y; s2 += (double)v[u].z; s3 += (double)v[u].w; }
+      }
+      double* d = s_slice + (size_t)sl * n2 + 4 * q;
+      d[0] = s0; d[1] = s1; d[2] = s2; d[3] = s3;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < n2) {
+      double sum = 0.0;
+      for (int k = 0; k < nsl; ++k) sum += s_slice[k * n2 + threadIdx.x];
+      a.sums[off + threadIdx.x] = sum;
+    }
+  }
+  __syncthreads();                                  // s_last is reused by a second flush of the same kernel
 }
 
 // ---- direct convolution on the lanes ----------------------------------------------------------------------------------------
@@ -217,7 +276,6 @@ __device__ __forceinline__ void conv_finish(const ResArgs& a, int img0, const fl
   }
 }
 
-constexpr int kResThreads = 1024, kResWaves = 16;
 
 // ---- P0: conv -> block1.conv1 (+ statistics) and block1.downsample (+ statistics): 2 crops, 16 wavefronts ------------------
 constexpr int kP0Crops = 2;
@@ -276,8 +334,8 @@ __global__ __launch_bounds__(kResThreads) void resnet_p0_kernel(const ResArgs a)
   }
   if (a.train) {
     __syncthreads();
-    stat_flush(a, 0, st1);
-    stat_flush(a, 2, std_);
+    stat_flush(a, 0, st1, reinterpret_cast<double*>(smem));
+    stat_flush(a, 2, std_, reinterpret_cast<double*>(smem));
   }
 }
 
@@ -325,7 +383,7 @@ __global__ __launch_bounds__(kResThreads) void resnet_p1_kernel(const ResArgs a)
     __syncthreads();
     conv_finish<4, 24, 16, kP1Crops, 4>(a, img0, part, a.bias[2], a.z2, stat, wave, kResWaves);
   }
-  if (a.train) { __syncthreads(); stat_flush(a, 1, stat); }
+  if (a.train) { __syncthreads(); stat_flush(a, 1, stat, reinterpret_cast<double*>(smem)); }
 }
 
 // P2: y1 = relu(bn2(z2) + bn_d(zd1)); block2.conv1 24 -> 48 k3 s1 p1 and block2.downsample 24 -> 48 k1, 4 -> 4.
@@ -361,7 +419,7 @@ __global__ __launch_bounds__(kResThreads) void resnet_p2_kernel(const ResArgs a)
     __syncthreads();
     conv_finish<4, 48, 16, kP2Crops, 4>(a, img0, part, a.bias[6], a.zd2, statd, wave, kResWaves);
   }
-  if (a.train) { __syncthreads(); stat_flush(a, 3, stat1); stat_flush(a, 5, statd); }
+  if (a.train) { __syncthreads(); stat_flush(a, 3, stat1, reinterpret_cast<double*>(smem)); stat_flush(a, 5, statd, reinterpret_cast<double*>(smem)); }
 }
 
 // P3: block2.conv2 48 -> 48 k3 s1 p1 on relu(bn1(z3)).  4 crops; 4 groups of 12 channels x 4 slices of 12 input channels.
@@ -389,7 +447,7 @@ __global__ __launch_bounds__(kResThreads) void resnet_p3_kernel(const ResArgs a)
     __syncthreads();
     conv_finish<4, 48, 16, kP3Crops, 4>(a, img0, part, a.bias[5], a.z4, stat, wave, kResWaves);
   }
-  if (a.train) { __syncthreads(); stat_flush(a, 4, stat); }
+  if (a.train) { __syncthreads(); stat_flush(a, 4, stat, reinterpret_cast<double*>(smem)); }
 }
 
 // P4: y2 = relu(bn2(z4) + bn_d(zd2)); block3.conv1 48 -> 96 k3 s2 p1 (4 -> 2) and block3.downsample 48 -> 96 k3 s2 p0 (4 -> 1).
@@ -426,7 +484,7 @@ __global__ __launch_bounds__(kResThreads) void resnet_p4_kernel(const ResArgs a)
     __syncthreads();
     conv_finish<1, 96, 4, kP4Crops, 2>(a, img0, part, a.bias[9], a.zd3, statd, wave, kResWaves);
   }
-  if (a.train) { __syncthreads(); stat_flush(a, 6, stat1); stat_flush(a, 8, statd); }
+  if (a.train) { __syncthreads(); stat_flush(a, 6, stat1, reinterpret_cast<double*>(smem)); stat_flush(a, 8, statd, reinterpret_cast<double*>(smem)); }
 }
 
 // P5: block3.conv2 96 -> 96 k3 s2 p1 on relu(bn1(z5)), 2 -> 1: only the taps (1..2, 1..2) meet the 2x2 input, a 384-wide
@@ -484,7 +542,7 @@ __global__ __launch_bounds__(kP5Threads) void resnet_p5_kernel(const ResArgs a) 
       if (a.train) stat_add(stat, c, valid ? v : 0.f);
     }
   }
-  if (a.train) { __syncthreads(); stat_flush(a, 7, stat); }
+  if (a.train) { __syncthreads(); stat_flush(a, 7, stat, reinterpret_cast<double*>(smem)); }
 }
 
 // out = relu(bn2(z6) + bn_d(zd3)); in train mode block 0.. also update the running statistics of all nine BatchNorms
@@ -526,7 +584,8 @@ using namespace b3d;
 
 extern "C" size_t b3d_resnet_encode_workspace_bytes(int32_t N) {
   if (N < 0) N = 0;
-  return 256 + (size_t)kWeightFloats * 4 + 256 + (size_t)kBnChannels * 2 * 8 + 256 + (size_t)N * kActFloatsPerCrop * 4 + 64;
+  return 256 + (size_t)kWeightFloats * 4 + 256 + (size_t)kBnChannels * 2 * 8 + 64 + 256 + (size_t)kResMaxGrid * 2 * kBnChannels * 4 + 256
+         + (size_t)N * kActFloatsPerCrop * 4 + 64;
 }
 
 extern "C" int b3d_resnet_encode(const b3d_linear* conv, const b3d_batchnorm* bn, const float* x, int32_t N, int32_t train,
@@ -546,10 +605,11 @@ extern "C" int b3d_resnet_encode(const b3d_linear* conv, const b3d_batchnorm* bn
   auto align = [](uintptr_t p) { return (p + 255) & ~(uintptr_t)255; };
   uintptr_t p = align((uintptr_t)workspace);
   float* wp = (float*)p; p = align(p + (size_t)kWeightFloats * 4);
-  double* sums = (double*)p; p = align(p + (size_t)kBnChannels * 16);
+  double* sums = (double*)p; p = align(p + (size_t)kBnChannels * 16 + 64);      // + the arrival counters behind the sums
+  float* part = (float*)p; p = align(p + (size_t)kResMaxGrid * 2 * kBnChannels * 4);
   float* act = (float*)p;
   ResArgs a;
-  a.N = N; a.train = train ? 1 : 0; a.x = x; a.w = wp; a.sums = sums; a.out = out;
+  a.N = N; a.train = train ? 1 : 0; a.x = x; a.w = wp; a.sums = sums; a.part = part; a.tickets = (unsigned*)(sums + 2 * kBnChannels); a.out = out;
   for (int i = 0; i < kConvs; ++i) a.bias[i] = (const float*)conv[i].b;
   for (int i = 0; i < kBns; ++i) {
     a.bn[i].gamma = bn[i].gamma; a.bn[i].beta = bn[i].beta;
@@ -571,9 +631,9 @@ extern "C" int b3d_resnet_encode(const b3d_linear* conv, const b3d_batchnorm* bn
   pw.dst = wp;
   hipLaunchKernelGGL(resnet_pack_kernel, dim3(16, kConvs), dim3(256), 0, stream, pw);
   B3D_TRY(launch_check("resnet_pack_kernel"));
-  if (train) B3D_HIP_CHECK(hipMemsetAsync(sums, 0, (size_t)kBnChannels * 16, stream));
+  if (train) B3D_HIP_CHECK(hipMemsetAsync(sums, 0, (size_t)kBnChannels * 16 + 64, stream));
   // persistent workgroups (as many as are resident at once): the tile zero fill and the BatchNorm affine are per workgroup
-  auto grid = [&](int crops, int resident = 512) { const int g = (N + crops - 1) / crops; return dim3((unsigned)(g < resident ? g : resident)); };
+  auto grid = [&](int crops, int resident = kResMaxGrid) { const int g = (N + crops - 1) / crops; return dim3((unsigned)(g < resident ? g : resident)); };
   B3D_TRY(set_lds(resnet_p0_kernel, kP0Lds));
   hipLaunchKernelGGL(resnet_p0_kernel, grid(kP0Crops), dim3(kResThreads), kP0Lds, stream, a);
   B3D_TRY(launch_check("resnet_p0_kernel"));

@@ -256,17 +256,21 @@ __device__ __attribute__((noinline)) void wgm_task(const WsJob& job, int chunk, 
     }
   }
   if (job.write_bias) {
-    lds_float* colsum = lds;                                 // every wavefront is past its last LDS read (barrier above)
-    for (int i = tid; i < NG; i += kWgmThreads) colsum[i] = 0.f;
-    __syncthreads();
+    // column sums of G in a FIXED order (no float atomics: the result must not depend on which wavefront arrives first):
+    // thread (grow0, gc4) parks its partial float4 at [grow0][gc4]; thread i then adds the RG partials of column i in
+    // row order.  Every wavefront is past its last LDS read (barrier above).
+    lds_float* colsum = lds;
     if (gthread) {
-      atomicAdd((float*)&colsum[4 * gc4 + 0], bs.x);
-      atomicAdd((float*)&colsum[4 * gc4 + 1], bs.y);
-      atomicAdd((float*)&colsum[4 * gc4 + 2], bs.z);
-      atomicAdd((float*)&colsum[4 * gc4 + 3], bs.w);
+      lds_float* d = colsum + (grow0 * G4 + gc4) * 4;
+      d[0] = bs.x; d[1] = bs.y; d[2] = bs.z; d[3] = bs.w;
     }
     __syncthreads();
-    for (int i = tid; i < NG; i += kWgmThreads) slab[(size_t)job.NP * job.KP + job.wrow + i] = colsum[i];
+    for (int i = tid; i < NG; i += kWgmThreads) {
+      float s = 0.f;
+#pragma unroll
+      for (int r = 0; r < RG; ++r) s += colsum[r * NG + i];
+      slab[(size_t)job.NP * job.KP + job.wrow + i] = s;
+    }
   }
 }
 

@@ -15,6 +15,11 @@ all-reduce of the 1,310,193 gradient-carrying parameters (5.24 MB).
 
     --model pose        `configs[1]`: pose_config.yaml poses-only PoseGNN training step (round-1 headline)
     --encoders precomputed   the camera+LiDAR+radar step with the encoder outputs given
+    --modalities cl     `configs[2]`: radar rows all zero ("camera+LiDAR")
+    --scaling strong    SURVEY.md 8d(4): the global batch is fixed at 16 graphs, every rank steps 16 / N of them
+    --mode infer        `configs[4]`: forward only under no_grad, 64 windows of 2,000 nodes / ~20,000 edges in flight
+                        per GPU (predict.py:172-196; replicas only, no collective) + the stand-alone k-NN + GAT block
+                        at n_t = 400, D = 96, k = 20
 
 At N = 1 the default run also reports both of those as `secondary` figures (shorter timed regions).
 
@@ -49,6 +54,10 @@ PEAK_BF16X6_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0     # = 416.7 fp32-equivalent T
 PEAK_HBM_GBS = 8000.0
 BOUND = {"mp_edge_fwd": "mfma", "mp_edge_bwd": "mfma", "wgrad_edge": "hbm", "mp_node_fwd": "hbm", "mp_node_bwd": "hbm",
          "att_fwd": "mfma", "att_bwd": "mfma", "point_feat": "mfma"}
+# the kernel families of the message-passing path itself; `roofline` names the one with the most device
+# time.  The encoder family (8f #1, next to the path) is reported as a labelled secondary (`roofline_encoders`).
+PATH_FAMILIES = ("mp_edge_fwd", "mp_edge_bwd", "wgrad_edge", "mp_node_fwd", "mp_node_bwd", "att_fwd", "att_bwd")
+DTYPE = "f32 (bf16x6 split products, fp32 accumulate)"     # what the wide layers compute in: b3d_dev.hpp
 
 
 # ---- work models -------------------------------------------------------------------------------------------------
@@ -71,16 +80,18 @@ class PoseWork:
     @classmethod
     def families(cls, n, e, depth, **_):
         """Per STEP (see ClrWork.families); every layer of this model runs on the exact fp32 MFMA."""
-        alg = {"mp_edge_fwd": 2.0 * (cls.MAC_EU + cls.MAC_MSG) * e * depth, "mp_edge_bwd": 2.0 * (cls.MAC_EU + cls.MAC_MSG) * e * (depth - 1),
+        # mp_edge_bwd: depth launches -- the last layer's message stacks carry no gradient (edge_update only there)
+        alg = {"mp_edge_fwd": 2.0 * (cls.MAC_EU + cls.MAC_MSG) * e * depth, "mp_edge_bwd": 2.0 * (cls.MAC_EU * depth + cls.MAC_MSG * (depth - 1)) * e,
                "wgrad_edge": 2.0 * (e * (cls.MAC_EU * depth + cls.MAC_MSG * (depth - 1)) + n * cls.MAC_NODE * (depth - 1)),
                "mp_node_fwd": 2.0 * cls.MAC_NODE * n * depth, "mp_node_bwd": 2.0 * cls.MAC_NODE * n * (depth - 1)}
-        exe = {"mp_edge_fwd": 2.0 * (cls.X_EU + cls.X_MSG) * e * depth, "mp_edge_bwd": 2.0 * (cls.X_EU + cls.X_MSG) * e * (depth - 1),
+        exe = {"mp_edge_fwd": 2.0 * (cls.X_EU + cls.X_MSG) * e * depth, "mp_edge_bwd": 2.0 * (cls.X_EU * depth + cls.X_MSG * (depth - 1)) * e,
                "wgrad_edge": 2.0 * (e * (cls.X_EU * depth + cls.X_MSG * (depth - 1))
                                     + n * (cls.MAC_NODE * (depth - 1) + 2 * 96 * 48 * depth + 4 * 96 * 48 * (depth - 1))),
                "mp_node_fwd": 2.0 * (cls.MAC_NODE * depth + cls.X_NODE_TAB * (depth - 1)) * n,
                "mp_node_bwd": 2.0 * (cls.MAC_NODE + cls.X_NODE_GP) * n * (depth - 1)}
         byts = {"mp_edge_fwd": depth * e * (8 + 4 * (32 + 32 + 64 + 64 + 352)),      # idx, e in/out, fut, past, saved hidden
-                "mp_edge_bwd": (depth - 1) * e * (8 + 4 * (32 + 32 + 352 + 192 + 384)),    # de out/in, saved, per-edge node grads, G
+                "mp_edge_bwd": (depth - 1) * e * (8 + 4 * (32 + 32 + 352 + 192 + 384))    # de out/in, saved, per-edge node grads, G
+                               + e * (8 + 4 * (32 + 32 + 160 + 192)),                      # last layer: edge_update only
                 "wgrad_edge": e * 4 * ((192 + 160 + 64) * depth + (192 + 128 + 192 + 32) * (depth - 1)),
                 "mp_node_fwd": depth * (e * 4 * 128 + n * 4 * (128 + 48 + 160)),
                 "mp_node_bwd": (depth - 1) * (e * 4 * 192 + n * 4 * (128 + 48 + 48 + 160 + 208))}
@@ -122,19 +133,20 @@ class ClrWork:
         gp = cls.X_NODE_GP if hoist_mp else 0
         att_node = cls.X_ATT_NODE if hoist_att else 0
         alg = {"mp_edge_fwd": 2.0 * (cls.MAC_EU + cls.MAC_MSG) * e * depth,
-               "mp_edge_bwd": 2.0 * (cls.MAC_EU + cls.MAC_MSG) * e * (depth - 1),          # the last layer's message stacks carry no gradient: "other"
+               "mp_edge_bwd": 2.0 * (cls.MAC_EU * depth + cls.MAC_MSG * (depth - 1)) * e,  # depth launches: the last layer's message stacks carry no gradient
                "wgrad_edge": 2.0 * (e * (cls.MAC_EU * depth + cls.MAC_MSG * (depth - 1) + cls.MAC_ATT) + n * cls.MAC_NODE * (depth - 1)),
                "mp_node_fwd": 2.0 * cls.MAC_NODE * n * depth, "mp_node_bwd": 2.0 * cls.MAC_NODE * n * (depth - 1),
                "att_fwd": 2.0 * cls.MAC_ATT * e, "att_bwd": 2.0 * cls.MAC_ATT * e,
                "point_feat": 2.0 * (2 * cls.MAC_POINT_L * nl + cls.MAC_POINT_R * nr)}
-        exe = {"mp_edge_fwd": 2.0 * (eu + msg) * e * depth, "mp_edge_bwd": 2.0 * (eu + msg) * e * (depth - 1),
+        exe = {"mp_edge_fwd": 2.0 * (eu + msg) * e * depth, "mp_edge_bwd": 2.0 * (eu * depth + msg * (depth - 1)) * e,
                "wgrad_edge": 2.0 * (e * (eu * depth + msg * (depth - 1) + att) + n * ((cls.MAC_NODE + tab) * (depth - 1) + att_node)),
                "mp_node_fwd": 2.0 * (cls.MAC_NODE * depth + tab * (depth - 1)) * n, "mp_node_bwd": 2.0 * (cls.MAC_NODE * (depth - 1) + gp * depth) * n,
                "att_fwd": 2.0 * (att * e + att_node * n), "att_bwd": 2.0 * (att * e + att_node * n),
                "point_feat": alg["point_feat"]}
         sav = 256 + 128 + 192 + 192
         byts = {"mp_edge_fwd": depth * e * (8 + 4 * (64 + 64 + 64 + 2 * 128 + sav)),
-                "mp_edge_bwd": (depth - 1) * e * (8 + 4 * (64 + 64 + 2 * 64 + sav + (256 + 128 + 64 + 192 + 192) + (0 if hoist_mp else 384))),
+                "mp_edge_bwd": (depth - 1) * e * (8 + 4 * (64 + 64 + 2 * 64 + sav + (256 + 128 + 64 + 192 + 192) + (0 if hoist_mp else 384)))
+                               + e * (8 + 4 * (64 + 64 + 2 * 64 + (256 + 128) + (256 + 128 + 64))),
                 "wgrad_edge": e * 4 * ((256 + 128 + 64 + 256 + 128 + 128) * depth + (2 * 192 + 2 * 128 + 2 * 192 + 64) * (depth - 1)
                                        + 2 * (512 + 384 + 256 + 128) + 64 + 64),
                 "mp_node_fwd": depth * (e * 4 * 256 + n * 4 * (256 + 96 + 320)),
@@ -157,11 +169,13 @@ class Workload:
     `captured(i)`: the same step split into the part that cannot be captured into a hipGraph (runs eagerly in front of
     every replay and feeds it) and the part that can."""
 
-    def __init__(self, kind, dev, rank, world, args, encoders="frozen"):
+    def __init__(self, kind, dev, rank, world, args, encoders="frozen", graphs=2, modalities="clr"):
         from batch3dmot_amd import encoders as enc_mod, synth
         from batch3dmot_amd.dist import FlatGradSync
         from batch3dmot_amd.train_step import make_optimizer
         self.kind, self.dev, self.encoders = kind, dev, encoders
+        self.graphs, self.modalities = graphs, modalities       # graphs per step and GPU (train.py:86-90: batch_size 2)
+        self.cap_ret = {}                                        # pool batch -> (loss, out, aux) tensors of its captured step
         torch.manual_seed(5621)                      # gnn.manual_seed, pose_config.yaml:96
         if kind == "pose":
             from batch3dmot_amd.pose_gnn import PoseGNN
@@ -179,8 +193,11 @@ class Workload:
         self.model.train()
         self.opt = make_optimizer(self.model, capturable=True)   # Adam(lr 1e-4, wd 1e-4, betas .9/.999): train.py:106-109
         self.sync = FlatGradSync(self.model.parameters(), flat=self.opt if hasattr(self.opt, "flat_grad") else None) if world > 1 else None
-        self.pool_cpu = [synth.make_batch(2, 1500, 15000, first_graph_idx=rank * 1000 + 2 * i, modalities=(kind == "clr"))
+        self.pool_cpu = [synth.make_batch(graphs, 1500, 15000, first_graph_idx=rank * 1000 + graphs * i, modalities=(kind == "clr"))
                          for i in range(4)]
+        if kind == "clr" and modalities == "cl":                 # BASELINE.json configs[2]: no radar return anywhere
+            for b in self.pool_cpu:
+                b.radar_feats = torch.zeros_like(b.radar_feats)
         self.pool = [b.to(dev) for b in self.pool_cpu]
         self.n_nodes = self.pool[0].pose_feats.size(0)
         self.edges = [b.edge_index.size(1) for b in self.pool]
@@ -200,7 +217,7 @@ class Workload:
         b = self.pool[i % len(self.pool)]
         if hasattr(b, "_b3d_graph"):
             del b._b3d_graph                     # the CSR/CSC build is part of every step
-        return train_step(self.model, b, self.opt, batch_size=2, loss_kind="cb", logits=self.logits, grad_sync=self.sync,
+        return train_step(self.model, b, self.opt, batch_size=self.graphs, loss_kind="cb", logits=self.logits, grad_sync=self.sync,
                           forward_kwargs=kwargs)
 
     def _run_fb(self, i, kwargs):
@@ -208,17 +225,20 @@ class Workload:
         b = self.pool[i % len(self.pool)]
         if hasattr(b, "_b3d_graph"):
             del b._b3d_graph
-        return forward_backward(self.model, b, self.opt, batch_size=2, loss_kind="cb", logits=self.logits, forward_kwargs=kwargs)
+        return forward_backward(self.model, b, self.opt, batch_size=self.graphs, loss_kind="cb", logits=self.logits, forward_kwargs=kwargs)
 
     def captured_fb(self, i):
         """The part of `captured` in front of the gradient exchange (N > 1: graph A; the all-reduce runs eagerly between
         it and the optimizer graph)."""
         k = i % len(self.pool)
         if self.enc is not None:
-            return self._run_fb(i, {"encoded": self.enc[k]})
-        if self.rows_static is not None:
-            return self._run_fb(i, {"rows": self.rows_static[k]})
-        return self._run_fb(i, None)
+            ret = self._run_fb(i, {"encoded": self.enc[k]})
+        elif self.rows_static is not None:
+            ret = self._run_fb(i, {"rows": self.rows_static[k]})
+        else:
+            ret = self._run_fb(i, None)
+        self.cap_ret[k] = ret
+        return ret
 
     def opt_step(self):
         self.opt.step()
@@ -242,10 +262,13 @@ class Workload:
     def captured(self, i):
         k = i % len(self.pool)
         if self.enc is not None:
-            return self._run(i, {"encoded": self.enc[k]})
-        if self.rows_static is not None:
-            return self._run(i, {"rows": self.rows_static[k]})
-        return self._run(i, None)
+            ret = self._run(i, {"encoded": self.enc[k]})
+        elif self.rows_static is not None:
+            ret = self._run(i, {"rows": self.rows_static[k]})
+        else:
+            ret = self._run(i, None)
+        self.cap_ret[k] = ret              # static tensors of the graph: they hold the last replay's loss / scores
+        return ret
 
     def describe(self, world):
         if self.kind == "pose":
@@ -253,7 +276,8 @@ class Workload:
                     + (" + flat RCCL grad all-reduce" if world > 1 else "") + ")")
         enc = ("frozen ResNetAE / PointNet / RadarNet encoders in train mode inside the step" if self.encoders == "frozen"
                else "encoder outputs precomputed")
-        return ("camera+LiDAR+radar GNN (clr_att_gnn) depth 6, training step (modality masks + " + enc
+        name = "camera+LiDAR+radar" if self.modalities == "clr" else "camera+LiDAR (radar rows all zero)"
+        return (name + " GNN (clr_att_gnn) depth 6, training step (modality masks + " + enc
                 + " + CSR/CSC build + fwd + cb-BCE + bwd + Adam" + (" + flat RCCL grad all-reduce of 5.24 MB" if world > 1 else "") + ")")
 
 
@@ -301,6 +325,99 @@ def trace(msg):
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
+def capture(wl, split):
+    """One hipGraph per pool batch, captured on a side stream as `torch.cuda.graph` wants it.  split (N > 1): graph A =
+    forward + backward per batch, plus one graph B = the optimizer step.  Returns (graphs, opt_graph); raises if the
+    stack cannot capture."""
+    graphs, opt_graph = [], None
+    torch.cuda.synchronize()
+    cap_stream = torch.cuda.Stream()
+    cap_stream.wait_stream(torch.cuda.current_stream())
+    for i in range(len(wl.pool)):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=cap_stream, capture_error_mode="thread_local"):
+            if split:
+                wl.captured_fb(i)
+            else:
+                wl.captured(i)
+        graphs.append(g)
+        trace(f"captured batch {i}")
+    if split:
+        opt_graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(opt_graph, stream=cap_stream, capture_error_mode="thread_local"):
+            wl.opt_step()
+        trace("captured the optimizer step")
+    torch.cuda.current_stream().wait_stream(cap_stream)
+    torch.cuda.synchronize()
+    return graphs, opt_graph
+
+
+def run_step(wl, graphs, opt_graph, split, i):
+    """Step i of the timed region: the eager part in front of the replay (`pre`), the replay(s), and at N > 1 the eager
+    flat all-reduce between them; or the eager step when nothing was captured."""
+    if graphs is not None:
+        wl.pre(i)
+        graphs[i % len(wl.pool)].replay()
+        if split:
+            wl.sync.sync(force=True)                           # the flat gradient buffer was written by the replay
+            opt_graph.replay()
+    else:
+        wl.step(i)
+
+
+def snapshot(wl):
+    """Everything a step changes: parameters and buffers (BatchNorm running statistics, counters), Adam state, the
+    device RNG state (Dropout of the frozen encoders' heads)."""
+    o = wl.opt
+    sd = {k: v.detach().clone() for k, v in wl.model.state_dict().items()}
+    st = {"exp_avg": o.exp_avg.clone(), "exp_avg_sq": o.exp_avg_sq.clone(),
+          "step_dev": o.step_dev.clone() if getattr(o, "step_dev", None) is not None else None,
+          "step_count": o.step_count, "fresh": o.fresh}
+    return sd, st, torch.cuda.get_rng_state(wl.dev)
+
+
+def restore(wl, snap):
+    sd, st, rng = snap
+    o = wl.opt
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        for k, v in wl.model.state_dict().items():
+            v.copy_(sd[k])
+        o.exp_avg.copy_(st["exp_avg"])
+        o.exp_avg_sq.copy_(st["exp_avg_sq"])
+        if st["step_dev"] is not None:
+            o.step_dev.copy_(st["step_dev"])
+    o.step_count, o.fresh = st["step_count"], st["fresh"]
+    torch.cuda.set_rng_state(rng, wl.dev)
+    torch.cuda.synchronize()
+
+
+def state_digest(wl):
+    """Flat copies of what `snapshot` covers, for bitwise comparisons (tests/test_timed_config.py)."""
+    sd = wl.model.state_dict()
+    return {**{"model." + k: v.detach().clone() for k, v in sd.items()},
+            "adam.exp_avg": wl.opt.exp_avg.clone(), "adam.exp_avg_sq": wl.opt.exp_avg_sq.clone(),
+            **({"adam.step": wl.opt.step_dev.clone()} if getattr(wl.opt, "step_dev", None) is not None else {})}
+
+
+def loss_check(wl, graphs, i):
+    """What the timed region computes, checked against the eager step: from the same state, replay step i (with its eager
+    prologue) and read the loss out of the graph's static tensor; restore; run the eager step on the same batch.  The two
+    losses must agree (they are the same kernels on the same inputs: bitwise on this stack).  State is left as after the
+    eager step."""
+    k = i % len(wl.pool)
+    snap = snapshot(wl)
+    wl.pre(i)
+    graphs[k].replay()
+    torch.cuda.synchronize()
+    loss_replay = float(wl.cap_ret[k][0])
+    restore(wl, snap)
+    loss_eager = float(wl.step(i)[0])
+    torch.cuda.synchronize()
+    return {"batch": k, "replayed_loss": loss_replay, "eager_loss": loss_eager, "equal": loss_replay == loss_eager,
+            "abs_diff": abs(loss_replay - loss_eager)}
+
+
 def measure(wl: Workload, args, world, dist, steps, warmup, ramp_ms, use_graph):
     """W instrumented warm-up steps, optional hipGraph capture, untimed clock ramp, K timed steps (barrier +
     synchronize on both sides), eager instrumented pass.  Returns a dict of raw measurements."""
@@ -322,11 +439,12 @@ def measure(wl: Workload, args, world, dist, steps, warmup, ramp_ms, use_graph):
             dist.barrier()
         dt = time.perf_counter() - t0
         return {"dt": dt, "edges": sum(wl.edges[(warmup + i) % pool_n] for i in range(steps)), "t_enqueue": dt, "fam_all": None,
-                "fam": {}, "dom": None, "graphs": False, "graph_note": "stub", "ramp_steps": ramp_steps, "pair_us": 0.0}
+                "fam": {}, "dom": None, "graphs": False, "graph_note": "stub", "ramp_steps": ramp_steps, "pair_us": 0.0,
+                "step_ms": None, "loss_check": None}
     from batch3dmot_amd import _lib
     fam_names = list(_lib.KERNEL_FAMILIES)
     # Warm-up doubles as the instrumented pass: every kernel family is timed with HIP event pairs (diagnostic
-    # table) and the family with the largest device time is picked; the TIMED region carries no events.
+    # table) and the family with the largest device time is picked; the TIMED region carries no event pairs.
     trace(f"{wl.kind}/{wl.encoders}: warm-up")
     _lib.prof_enable(True)
     for i in range(warmup):
@@ -339,26 +457,7 @@ def measure(wl: Workload, args, world, dist, steps, warmup, ramp_ms, use_graph):
     split = world > 1                      # N > 1: graph A (forward + backward) | eager all-reduce | graph B (optimizer)
     if use_graph:
         try:
-            graphs = []
-            torch.cuda.synchronize()
-            cap_stream = torch.cuda.Stream()
-            cap_stream.wait_stream(torch.cuda.current_stream())
-            for i in range(pool_n):
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=cap_stream, capture_error_mode="thread_local"):
-                    if split:
-                        wl.captured_fb(i)
-                    else:
-                        wl.captured(i)
-                graphs.append(g)
-                trace(f"captured batch {i}")
-            if split:
-                opt_graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(opt_graph, stream=cap_stream, capture_error_mode="thread_local"):
-                    wl.opt_step()
-                trace("captured the optimizer step")
-            torch.cuda.current_stream().wait_stream(cap_stream)
-            torch.cuda.synchronize()
+            graphs, opt_graph = capture(wl, split)
         except Exception as exc:                                   # capture unsupported here: eager timed region
             graphs, opt_graph = None, None
             graph_note = f"hipGraph capture failed ({type(exc).__name__}: {str(exc)[:200]}); eager timed region"
@@ -371,14 +470,7 @@ def measure(wl: Workload, args, world, dist, steps, warmup, ramp_ms, use_graph):
                 graph_note = "hipGraph capture failed on another rank; eager timed region"
 
     def timed_step(i):
-        if graphs is not None:
-            wl.pre(i)
-            graphs[i % pool_n].replay()
-            if split:
-                wl.sync.sync(force=True)                           # the flat gradient buffer was written by the replay
-                opt_graph.replay()
-        else:
-            wl.step(i)
+        run_step(wl, graphs, opt_graph, split, i)
 
     # Clock ramp (untimed): a fresh box idles at ~550 MHz; keep the GPU busy until ramp_ms have passed, the same
     # number of steps on every rank (each holds a collective).
@@ -396,37 +488,57 @@ def measure(wl: Workload, args, world, dist, steps, warmup, ramp_ms, use_graph):
             torch.cuda.synchronize()
             ramp_steps += 4
     trace(f"ramp done ({ramp_steps} steps)")
+    # one event per step boundary (K + 1 records on the launch stream, no synchronisation): per-step durations for the
+    # median beside the contract's mean
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(steps):
         timed_step(warmup + i)
+        marks[i + 1].record()
     t_enqueue = time.perf_counter() - t0          # host time to enqueue the K steps (diagnostic)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
     trace(f"timed region done: {1e3 * dt / steps:.3f} ms/step")
-    # the same K steps again, eagerly, with event pairs: on the dominant family only (undisturbed), then on all
+    # the replayed step against the eager step, from the same state (N = 1: at N > 1 a step holds a collective)
+    lc = None
+    if graphs is not None and not split:
+        try:
+            lc = loss_check(wl, graphs, warmup + steps)
+        except Exception as exc:
+            lc = {"error": f"{type(exc).__name__}: {str(exc)[:200]}"}
+    # the same K steps again, eagerly, with event pairs: on the dominant path family only (undisturbed), then on all
     dom = None
     if fam_all:
-        cand = [k for k in fam_names if k in BOUND and fam_all[k][1] > 0]
+        cand = [k for k in fam_names if k in PATH_FAMILIES and fam_all[k][1] > 0]
         dom = max(cand, key=lambda k: fam_all[k][0]) if cand else None
-    _lib.prof_enable(True, families=[dom] if dom else None)
-    for i in range(steps):
-        wl.step(warmup + i)
-    torch.cuda.synchronize()
-    fam = _lib.prof_read()
-    _lib.prof_enable(False)
+    fam = {}
+    for sel in ([dom] if dom else [None]) + (["point_feat"] if fam_all and fam_all.get("point_feat", (0, 0))[1] > 0 else []):
+        _lib.prof_enable(True, families=[sel] if sel else None)
+        for i in range(steps):
+            wl.step(warmup + i)
+        torch.cuda.synchronize()
+        got = _lib.prof_read()
+        _lib.prof_enable(False)
+        if sel is None:
+            fam = got
+        else:
+            fam[sel] = got[sel]
     # what an event pair adds to the kernel it brackets: half of a pair around an empty kernel (the other half is that
     # kernel's own dispatch-to-completion; calibrated against rocprofv3 durations of the same launches: 29.5 us by events
     # vs 24.1 us by rocprofv3 with an 11.3 us empty pair, profiles/r02_a_*)
     pair_us = 0.5 * _lib.prof_pair_overhead_us(torch.cuda.current_stream(dev).cuda_stream)
     my_edges = sum(wl.edges[(warmup + i) % pool_n] for i in range(steps))
     return {"dt": dt, "edges": my_edges, "t_enqueue": t_enqueue, "fam_all": fam_all, "fam": fam, "dom": dom,
-            "graphs": graphs is not None, "graph_note": graph_note, "ramp_steps": ramp_steps, "pair_us": pair_us}
+            "graphs": graphs is not None, "graph_note": graph_note, "ramp_steps": ramp_steps, "pair_us": pair_us,
+            "step_ms": step_ms, "loss_check": lc}
 
 
 def mfma_peak(bf_frac):
@@ -455,15 +567,60 @@ def family_table(famd, steps, alg, exe, byts, bf, pair_us=0.0):
     return out
 
 
+def lib_sha16():
+    import hashlib
+    from batch3dmot_amd import _lib
+    try:
+        with open(_lib.LIB_PATH, "rb") as fh:
+            return hashlib.sha256(fh.read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
 def load_traffic(workload_key):
     """HBM bytes per launch from the rocprofv3 --pmc passes of this command (FETCH_SIZE / WRITE_SIZE in separate
-    passes, read bytes doubled as MI355X_MICROARCH.md prescribes for gfx950), summarised by tools/pmc_summary.py into
-    profiles/traffic_pmc.json, keyed by workload."""
+    passes, read bytes doubled as MI355X_MICROARCH.md prescribes for gfx950), summarised by tools/pmc_traffic.py into
+    profiles/traffic_pmc.json, keyed by workload.  Counters cannot be collected from inside this process: the figure
+    comes from the builder's last PMC session, and `_source` says which library build and day that was."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic_pmc.json")) as fh:
-            return json.load(fh).get(workload_key)
+            d = json.load(fh)
+        return d.get(workload_key), d.get("_source")
     except (OSError, ValueError):
-        return None
+        return None, None
+
+
+def roofline_of(dom, kd, alg, exe, byts, pair_us, traffic, traffic_src):
+    lps = kd["launches_per_step"]
+    if BOUND[dom] == "mfma":
+        achieved, peak, unit = kd["executed_tflops"], kd["mfma_peak_tflops"], "TFLOP/s"
+    else:
+        achieved, peak, unit = kd["algorithmic_gbs"], PEAK_HBM_GBS, "GB/s"
+    src = None
+    if traffic_src:
+        src = dict(traffic_src)
+        src["matches_this_library"] = (traffic_src.get("lib_sha16") == lib_sha16())
+    return {"kernel": dom, "bound": BOUND[dom], "achieved": achieved, "peak": peak, "unit": unit,
+            "frac": round(achieved / peak, 4), "traffic": (traffic or {}).get(dom), "traffic_source": src,
+            "avg_launch_us": kd["avg_us"], "event_pair_overhead_us_subtracted": round(pair_us, 2),
+            "launches_per_step": lps,
+            "executed_flops_per_launch": exe[dom] / lps, "algorithmic_flops_per_launch": alg[dom] / lps,
+            "algorithmic_bytes_per_launch": byts[dom] / lps,
+            "bf16x6_fraction_of_macs": kd["bf16x6_fraction_of_macs"],
+            "algorithmic_tflops": kd["algorithmic_tflops"],
+            "executed_frac_of_fp32_mfma_peak": round(kd["executed_tflops"] / PEAK_FP32_MFMA_TFLOPS, 4)}
+
+
+ROOFLINE_NOTE = ("roofline.kernel = the SURVEY.md 8a kernel family (message passing, attention encoder, their weight gradient) "
+                 "with the most device time per step; the frozen encoders' point stacks (8f #1, next to the path) are "
+                 "`roofline_encoders`.  mfma-bound kernels: achieved = EXECUTED fp32-equivalent FLOPs of the family per step / its "
+                 "device time per step (node columns of a Linear over a concatenation that are evaluated per node are not "
+                 "edge-kernel work); peak = the MFMA peak of the instructions it runs: 157.3 TFLOP/s for exact-fp32 MFMA layers, "
+                 "2500 / 6 = 416.7 fp32-equivalent TFLOP/s for bf16x6 layers (six bf16 MFMA MACs per fp32 product), combined "
+                 "harmonically by the kernel's share of each.  algorithmic_* count the reference's per-edge FLOPs (SURVEY.md 8d) "
+                 "over the same time.  Durations: HIP event pairs on the launch stream around each launch of the family in an "
+                 "eager pass of the same K steps, minus half the cost of a pair around an empty kernel (calibrated against "
+                 "rocprofv3 durations, profiles/).  traffic: HBM bytes per launch from rocprofv3 PMC passes (see traffic_source).")
 
 
 def main():
@@ -471,9 +628,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--mode", choices=["train", "infer"], default="train",
+                    help="train: the training step (default).  infer: BASELINE.json configs[4], forward only")
     ap.add_argument("--model", choices=["clr", "pose"], default="clr")
     ap.add_argument("--encoders", choices=["frozen", "precomputed"], default="frozen",
                     help="camera+LiDAR+radar step: frozen encoders in train mode inside the step (default) or their outputs given")
+    ap.add_argument("--modalities", choices=["clr", "cl"], default="clr", help="cl: radar rows all zero (camera+LiDAR, configs[2])")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: 2 graphs per GPU and step.  strong: global batch of 16 graphs, 16 / N per GPU (SURVEY.md 8d(4))")
     ap.add_argument("--no-dead-knn", action="store_true",
                     help="skip the k-NN + GAT block whose result the reference discards (secondary figure)")
     ap.add_argument("--no-graph", action="store_true", help="enqueue every step eagerly")
@@ -506,23 +668,35 @@ def main():
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
+    if args.mode == "infer":
+        return main_infer(args, dev, rank, world, dist)
 
     from batch3dmot_amd import _lib
-    wl = Workload(args.model, dev, rank, world, args, encoders=args.encoders)
+    graphs_per_gpu = 2
+    if args.scaling == "strong":
+        if 16 % world:
+            raise SystemExit("--scaling strong: the global batch of 16 graphs must divide over the ranks")
+        graphs_per_gpu = 16 // world
+    wl = Workload(args.model, dev, rank, world, args, encoders=args.encoders, graphs=graphs_per_gpu, modalities=args.modalities)
     m = measure(wl, args, world, dist, args.steps, args.warmup, args.ramp_ms, use_graph=not args.no_graph)
 
     dt, total_edges = reduce_over_ranks(m, dev, world, dist)
 
     secondary = None
-    if world == 1 and rank == 0 and not args.no_secondary and args.model == "clr" and args.encoders == "frozen":
+    if (world == 1 and rank == 0 and not args.no_secondary and args.model == "clr" and args.encoders == "frozen"
+            and args.modalities == "clr" and args.scaling == "weak"):
         secondary = {}
-        for key, kind, enc in (("clr_encoders_precomputed", "clr", "precomputed"), ("pose_gnn", "pose", "frozen")):
+        for key, kind, enc, mod in (("clr_encoders_precomputed", "clr", "precomputed", "clr"), ("camera_lidar", "clr", "frozen", "cl"),
+                                    ("camera_lidar_encoders_precomputed", "clr", "precomputed", "cl"), ("pose_gnn", "pose", "frozen", "clr")):
             try:
-                w2 = Workload(kind, dev, rank, world, args, encoders=enc)
-                m2 = measure(w2, args, world, dist, max(10, args.steps // 2), max(3, args.warmup // 2), 60.0, use_graph=not args.no_graph)
+                w2 = Workload(kind, dev, rank, world, args, encoders=enc, modalities=mod)
+                k2 = max(10, args.steps // 2)
+                m2 = measure(w2, args, world, dist, k2, max(3, args.warmup // 2), 60.0, use_graph=not args.no_graph)
                 secondary[key] = {"workload": w2.describe(world), "value": round(m2["edges"] / m2["dt"], 1), "unit": "edges/s",
-                                  "ms_per_step": round(1e3 * m2["dt"] / max(10, args.steps // 2), 4),
-                                  "timed_region": "hipGraph replay" if m2["graphs"] else "eager"}
+                                  "ms_per_step": round(1e3 * m2["dt"] / k2, 4),
+                                  "ms_per_step_median": round(m2["step_ms"][len(m2["step_ms"]) // 2], 4),
+                                  "timed_region": "hipGraph replay" if m2["graphs"] else "eager",
+                                  "replay_vs_eager_loss": m2["loss_check"]}
                 del w2
             except Exception as exc:                                # a secondary figure must never cost the headline
                 secondary[key] = {"error": f"{type(exc).__name__}: {str(exc)[:200]}"}
@@ -538,32 +712,15 @@ def main():
         alg, exe, byts, bf = wl.work.families(**kw)
         kernels_warmup = family_table(m["fam_all"], args.warmup, alg, exe, byts, bf, m["pair_us"]) if m["fam_all"] else {}
         kernels = family_table(m["fam"], args.steps, alg, exe, byts, bf, m["pair_us"])
-        dom = m["dom"] or max((k for k in kernels if k in alg), key=lambda k: kernels[k]["us_per_step"])
-        kd = kernels[dom]
+        dom = m["dom"] or max((k for k in kernels if k in PATH_FAMILIES), key=lambda k: kernels[k]["us_per_step"])
         workload_key = f"{args.model}:{args.encoders if args.model == 'clr' else 'na'}:knn{int(not args.no_dead_knn)}"
-        traffic = load_traffic(workload_key) or {}
-        lps = kd["launches_per_step"]
-        if BOUND[dom] == "mfma":
-            achieved, peak, unit = kd["executed_tflops"], kd["mfma_peak_tflops"], "TFLOP/s"
-        else:
-            achieved, peak, unit = kd["algorithmic_gbs"], PEAK_HBM_GBS, "GB/s"
-        roofline = {"kernel": dom, "bound": BOUND[dom], "achieved": achieved, "peak": peak, "unit": unit,
-                    "frac": round(achieved / peak, 4), "traffic": traffic.get(dom),
-                    "avg_launch_us": kd["avg_us"], "event_pair_overhead_us_subtracted": round(m["pair_us"], 2),
-                    "launches_per_step": lps,
-                    "executed_flops_per_launch": exe[dom] / lps, "algorithmic_flops_per_launch": alg[dom] / lps,
-                    "algorithmic_bytes_per_launch": byts[dom] / lps,
-                    "bf16x6_fraction_of_macs": kd["bf16x6_fraction_of_macs"],
-                    "algorithmic_tflops": kd["algorithmic_tflops"],
-                    "executed_frac_of_fp32_mfma_peak": round(kd["executed_tflops"] / PEAK_FP32_MFMA_TFLOPS, 4),
-                    "note": "mfma-bound kernels: achieved = EXECUTED fp32-equivalent FLOPs of the named family per step / its device time "
-                            "per step (node columns of a Linear over a concatenation that are evaluated per node are not edge-kernel "
-                            "work); peak = the MFMA peak of the instructions it runs: 157.3 TFLOP/s for exact-fp32 MFMA layers, "
-                            "2500 / 6 = 416.7 fp32-equivalent TFLOP/s for bf16x6 layers (six bf16 MFMA MACs per fp32 product), "
-                            "combined harmonically by the kernel's share of each.  algorithmic_* count the reference's per-edge FLOPs "
-                            "(SURVEY.md 8d) over the same time.  Durations: HIP event pairs on the launch stream around each launch "
-                            "of this family in an eager pass of the same K steps, minus half the cost of a pair around an empty kernel "
-                            "(calibrated against rocprofv3 durations, profiles/)."}
+        traffic, traffic_src = load_traffic(workload_key)
+        roofline = roofline_of(dom, kernels[dom], alg, exe, byts, m["pair_us"], traffic, traffic_src)
+        roofline["note"] = ROOFLINE_NOTE
+        roofline_enc = None
+        if "point_feat" in kernels and "point_feat" in alg:
+            roofline_enc = roofline_of("point_feat", kernels["point_feat"], alg, exe, byts, m["pair_us"], traffic, traffic_src)
+            roofline_enc["note"] = "frozen encoders' point stacks (SURVEY.md 8f #1): next to the path, not the path"
         ms_step = 1e3 * dt / args.steps
         sf_kw = dict(f_l=wl.nl / wl.n_nodes, f_r=wl.nr / wl.n_nodes) if args.model == "clr" else {}
         step_bytes = wl.work.step_bytes(wl.n_nodes, e_avg)
@@ -580,14 +737,18 @@ def main():
         line = {"metric": "edges/sec (fwd+bwd) on nuScenes-shaped detection graphs",
                 "value": round(total_edges / dt, 1), "unit": "edges/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": round(ms_step, 4), "higher_is_better": True,
-                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                "config": {"workload": wl.describe(world), "graphs_per_gpu": 2, "nodes_per_gpu": wl.n_nodes,
+                "scaling": args.scaling, "vs_baseline": None, "dtype": DTYPE if args.model == "clr" else "f32", "data": "synthetic",
+                "config": {"workload": wl.describe(world), "graphs_per_gpu": graphs_per_gpu, "nodes_per_gpu": wl.n_nodes,
                            "edges_per_gpu": round(e_avg, 1), "frames": 5,
                            "lidar_rows_per_gpu": getattr(wl, "nl", None), "radar_rows_per_gpu": getattr(wl, "nr", None),
                            "dead_knn_gat_block_executed": bool(wl.model.run_dead_knn),
                            "parallelism": f"graph-batch sharding x{world}"},
-                "roofline": roofline, "cpu_baseline": cpu, "whole_step": whole, "secondary": secondary,
+                "roofline": roofline, "roofline_encoders": roofline_enc, "cpu_baseline": cpu, "whole_step": whole,
+                "replay_vs_eager_loss": m["loss_check"],
+                "ms_per_step_median": round(m["step_ms"][len(m["step_ms"]) // 2], 4) if m["step_ms"] else None,
+                "secondary": secondary,
                 "kernels": kernels, "kernels_instrumented_warmup": kernels_warmup,
+                "library_sha16": lib_sha16(),
                 "untimed_clock_ramp_steps": m["ramp_steps"], "host_enqueue_ms_per_step": round(1e3 * m["t_enqueue"] / args.steps, 4),
                 "timed_region": ("hipGraph replay (one captured training step per pool batch"
                                  + (": forward + backward graph, eager flat all-reduce, optimizer graph" if world > 1 else "")
@@ -595,6 +756,110 @@ def main():
                                  + "); kernel families timed with HIP events in an eager pass of the same K steps right after it")
                                 if m["graphs"] else ("eager" + (f" ({m['graph_note']})" if m["graph_note"] else ""))}
         print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def main_infer(args, dev, rank, world, dist):
+    """BASELINE.json configs[4] (predict.py:172-196): forward only under no_grad, eval-mode encoders inside, windows of
+    2,000 detections / ~20,000 edges; a step = 64 windows enqueued back to back on the launch stream (no host
+    synchronisation inside: the modality row counts of the pool windows are read once, in front of the timed region).
+    Replicas only: no collective; at N > 1 every rank runs its own windows and the edges are summed."""
+    from batch3dmot_amd import _lib, encoders as enc_mod, synth
+    from batch3dmot_amd.clr_att_gnn import GNN
+    from batch3dmot_amd.pose_gnn import GATConvParams, PoseGNN
+    torch.manual_seed(5621)
+    windows = 64
+    clr = args.model == "clr"
+    if clr:
+        model = GNN(enc_mod.ResNetAE(), enc_mod.PointNetClassifier(k=7), enc_mod.RadarNetClassifier(k=7)).to(dev).eval()
+    else:
+        model = PoseGNN().to(dev).eval()
+    model.run_dead_knn = not args.no_dead_knn
+    pool = [synth.make_graph(2000, 20000, graph_idx=rank * 1000 + 300 + i, modalities=clr).to(dev) for i in range(8)]
+    rows = [model.modality_rows(b) for b in pool] if clr else None
+    edges = [b.edge_index.size(1) for b in pool]
+
+    def window(k):
+        b = pool[k]
+        if hasattr(b, "_b3d_graph"):
+            del b._b3d_graph                     # the CSR/CSC build is part of every window
+        return model(b, rows=rows[k]) if clr else model(b)
+
+    with torch.no_grad():
+        for k in range(len(pool)):
+            window(k)
+        torch.cuda.synchronize()
+        # one hipGraph per pool window (eager enqueue of ~150 launches costs as much host time as the window takes on
+        # the GPU); the outputs are the graphs' static tensors, as a serving loop would read them
+        graphs, keep, note = None, [], None
+        if not args.no_graph:
+            try:
+                graphs = []
+                cap_stream = torch.cuda.Stream()
+                cap_stream.wait_stream(torch.cuda.current_stream())
+                for k in range(len(pool)):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=cap_stream, capture_error_mode="thread_local"):
+                        keep.append(window(k))
+                    graphs.append(g)
+                torch.cuda.current_stream().wait_stream(cap_stream)
+                torch.cuda.synchronize()
+            except Exception as exc:
+                graphs, note = None, f"hipGraph capture failed ({type(exc).__name__}: {str(exc)[:160]})"
+                torch.cuda.synchronize()
+
+        def step(i):
+            for w in range(windows):
+                k = (i * windows + w) % len(pool)
+                if graphs is not None:
+                    graphs[k].replay()
+                else:
+                    window(k)
+
+        for i in range(max(1, args.warmup // 4)):
+            step(i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i)
+        t_enq = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        my_edges = float(sum(edges[(i * windows + w) % len(pool)] for i in range(args.steps) for w in range(windows)))
+        # the k-NN + GAT block alone at n_t = 400, D = 96, k = 20 (5 frames of 400 detections)
+        x = torch.randn(2000, 96, device=dev)
+        ts = torch.arange(5, device=dev).repeat_interleave(400)
+        conv = GATConvParams(96).to(dev)
+        for _ in range(5):
+            _lib.knn_gat(x, ts, conv, k=20)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(50):
+            _lib.knn_gat(x, ts, conv, k=20)
+        torch.cuda.synchronize()
+        knn_ms = 1e3 * (time.perf_counter() - t1) / 50
+    dtm, tot = reduce_over_ranks({"dt": dt, "edges": my_edges}, dev, world, dist)
+    if rank == 0:
+        name = "camera+LiDAR+radar GNN (clr_att_gnn), eval-mode encoders inside" if clr else "poses-only PoseGNN"
+        print(json.dumps({
+            "metric": "edges/sec (forward only) on nuScenes-shaped detection graphs", "value": round(tot / dtm, 1), "unit": "edges/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dtm / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE if clr else "f32", "data": "synthetic",
+            "config": {"workload": f"large-batch inference (predict.py:172-196): {name}, depth 6, forward under no_grad, "
+                                   f"{windows} windows of 2,000 nodes / ~20,000 edges in flight per GPU and step, CSR/CSC build per window",
+                       "windows_per_step": windows, "nodes_per_window": 2000, "edges_per_window": round(sum(edges) / len(edges), 1),
+                       "dead_knn_gat_block_executed": bool(model.run_dead_knn), "parallelism": f"replicas x{world} (no collective)"},
+            "ms_per_window": round(1e3 * dtm / args.steps / windows, 4),
+            "host_enqueue_ms_per_window": round(1e3 * t_enq / args.steps / windows, 4),
+            "knn_gat_block_nt400_d96_k20_ms": round(knn_ms, 4), "library_sha16": lib_sha16(),
+            "timed_region": "hipGraph replay (one captured forward per pool window)" if graphs is not None else "eager" + (f" ({note})" if note else "")}))
     if world > 1:
         dist.destroy_process_group()
 
@@ -662,30 +927,36 @@ def cpu_baseline(wl: Workload):
         return mm, oo
 
     def run(nthreads, batches, warm, steps):
+        """(edges/s from the MEDIAN step time, seconds spent)"""
         torch.set_num_threads(nthreads)
         mm, oo = build()
+        t_all = time.perf_counter()
         for i in range(warm):
-            ref_torch.train_step(mm, batches[i % len(batches)], oo, batch_size=2, loss_kind="cb", logits=wl.logits)
-        t0 = time.perf_counter()
-        edges = 0
+            ref_torch.train_step(mm, batches[i % len(batches)], oo, batch_size=wl.graphs, loss_kind="cb", logits=wl.logits)
+        per_edge = []
         for i in range(steps):
-            b = batches[i % len(batches)]
-            ref_torch.train_step(mm, b, oo, batch_size=2, loss_kind="cb", logits=wl.logits)
-            edges += b.edge_index.size(1)
-        return edges / (time.perf_counter() - t0), time.perf_counter() - t0
+            b = batches[(warm + i) % len(batches)]
+            t0 = time.perf_counter()
+            ref_torch.train_step(mm, b, oo, batch_size=wl.graphs, loss_kind="cb", logits=wl.logits)
+            per_edge.append((time.perf_counter() - t0) / b.edge_index.size(1))
+        per_edge.sort()
+        return 1.0 / per_edge[len(per_edge) // 2], time.perf_counter() - t_all
 
+    # SURVEY.md 8d protocol, bounded to ~1 minute of CPU work: >= 2 warm-up steps, median of >= 10 (40 for the small model)
     if wl.kind == "pose":
-        v, dt = run(threads, wl.pool_cpu, 3, 40)
-        sample = f"40 training steps of the same batches (3 warm-up), {dt:.1f} s"
+        v, dt = run(threads, wl.pool_cpu, 5, 40)
+        sample = f"median of 40 training steps of the same batches (5 warm-up), {dt:.1f} s"
         one = [synth.make_batch(2, 1500, 15000, first_graph_idx=0)]
-        v1, dt1 = run(1, one, 1, 8)
-        sample1 = f"8 training steps of one batch (1 warm-up), {dt1:.1f} s"
+        v1, dt1 = run(1, one, 2, 10)
+        sample1 = f"median of 10 training steps of one batch (2 warm-up), {dt1:.1f} s"
     else:
-        v, dt = run(threads, wl.pool_cpu, 1, 3)
-        sample = f"3 training steps of the same batches (1 warm-up), {dt:.1f} s"
+        v, dt = run(threads, wl.pool_cpu, 2, 10)
+        sample = f"median of 10 training steps of the same batches (2 warm-up), {dt:.1f} s"
         one = [synth.make_batch(1, 750, 7500, first_graph_idx=0, modalities=True)]
-        v1, dt1 = run(1, one, 0, 1)
-        sample1 = f"1 training step of a 750-node / {one[0].edge_index.size(1)}-edge graph (no warm-up), {dt1:.1f} s"
+        if wl.modalities == "cl":
+            one[0].radar_feats = torch.zeros_like(one[0].radar_feats)
+        v1, dt1 = run(1, one, 2, 10)
+        sample1 = f"median of 10 training steps of a 750-node / {one[0].edge_index.size(1)}-edge graph (2 warm-up), {dt1:.1f} s"
     return {"value": round(v, 1), "unit": "edges/s", "cores": threads, "kind": "port", "sample": sample + f", torch {torch.__version__} CPU",
             "one_thread": {"value": round(v1, 1), "unit": "edges/s", "cores": 1, "sample": sample1},
             "host_cpu": model_name, "host_logical_cores": cores}

@@ -308,6 +308,54 @@ def golden_train_step(ref, path, num_nodes=60, k=6, graph_idx=300, salt=20):
     print(f"{path}: loss={loss.item():.6f}")
 
 
+def golden_train_mode_step(ref, path, num_nodes=60, k=6, graph_idx=900, lidar_frac=0.7, radar_frac=0.25, salt=40):
+    """The training step as train.py runs it: the model in .train() -- clr_att_gnn.py:26-33 freezes the encoders'
+    PARAMETERS but leaves them in train mode, so their BatchNorms use batch statistics and update their running
+    statistics (pointnet.py:188-192, radarnet.py:60-64, resnet_fully_conv.py:42-82), and fewer than two rows of a
+    modality flip that encoder to eval for good (clr_att_gnn.py:128-130,136-138).  Dropout (pointnet.py:190,
+    radarnet.py:62) is neutralised (p = 0): its mask is torch's Philox stream, not part of the contract."""
+    graphs = [synth.make_graph(num_nodes, None, k=k, graph_idx=graph_idx + i, modalities=True,
+                               lidar_frac=lidar_frac, radar_frac=radar_frac) for i in range(2)]
+    data = collate(graphs)
+
+    def run(model):
+        model.train()
+        model.pointnet.dropout.p = 0.0
+        model.radarnet.dropout.p = 0.0
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-4, betas=(0.9, 0.999))
+        gt = data.y.float()
+        out, x_sens = model.forward(data)
+        out = out.squeeze(1)
+        loss = torch.nn.BCELoss(weight=data.edge_weights)(out, gt) / 2   # params.gnn.batch_size = 2
+        opt.zero_grad()
+        loss.backward()
+        grads = {n: (p.grad.clone() if p.grad is not None else None)
+                 for n, p in model.named_parameters() if p.requires_grad}
+        opt.step()
+        after = {n: p.detach().clone() for n, p in model.named_parameters() if p.requires_grad}
+        stats = {n: b.detach().clone() for n, b in model.named_buffers()
+                 if n.endswith("running_mean") or n.endswith("running_var") or n.endswith("num_batches_tracked")}
+        modes = {"pointnet": model.pointnet.training, "radarnet": model.radarnet.training, "resnet": model.resnet.training,
+                 "fc_lidar_encoder": model.fc_lidar_encoder.training, "fc_radar_encoder": model.fc_radar_encoder.training}
+        return out.detach(), x_sens.detach(), loss.detach(), grads, after, stats, modes
+
+    model = _build_clr(ref, salt)
+    out, x_sens, loss, grads, after, stats, modes = run(model)
+    o2, x2, loss2, g2, a2, s2, m2 = run(_build_clr_oracle(salt))
+    assert modes == m2, (modes, m2)
+    _check_oracle(os.path.basename(path), {"out": out, "x_sens": x_sens, "loss": loss, **{f"g.{n}": g for n, g in grads.items()},
+                                           **{f"a.{n}": g for n, g in after.items()},
+                                           **{f"s.{n}": v.double() for n, v in stats.items()}},
+                  {"out": o2, "x_sens": x2, "loss": loss2, **{f"g.{n}": g for n, g in g2.items()},
+                   **{f"a.{n}": g for n, g in a2.items()}, **{f"s.{n}": v.double() for n, v in s2.items()}}, tol=1e-5)
+    n = data.pose_feats.size(0)
+    torch.save({"data": _data_dict(data), "salt": salt, "out": out, "x_sens": x_sens, "loss": loss,
+                "grad_digest": grad_digest(grads), "after_digest": grad_digest(after), "running_stats": stats, "modes": modes,
+                "lidar_rows": int((data.lidar_feats.reshape(n, -1).sum(1) != 0).sum()),
+                "radar_rows": int((data.radar_feats.reshape(n, -1).sum(1) != 0).sum())}, path)
+    print(f"{path}: loss={loss.item():.6f} modes={modes}")
+
+
 def golden_predict_post(path):
     """H2 (predict.py:92-124, 221-259): window-mean edge scores, per-class thresholds, greedy
     flux.  ``greedy_filter_node_flux`` / ``aggregate_node_flux`` are taken from the reference file
@@ -578,21 +626,30 @@ def golden_tracks(path):
 
 
 def main():
+    """python oracle/make_golden.py [name-prefix ...]: all fixtures, or those whose file name starts with a prefix."""
     ref = load_reference()
     gd = os.path.join(ROOT, "tests", "golden")
     os.makedirs(gd, exist_ok=True)
-    golden_pose(ref, os.path.join(gd, "g1_pose.pt"))
-    golden_pose(ref, os.path.join(gd, "g1b_pose_batch2.pt"), num_nodes=60, k=5, graph_idx=110, batch=2, salt=1)
-    golden_pose(ref, os.path.join(gd, "g5_pose_tiny.pt"), num_nodes=25, k=3, graph_idx=120, salt=2)
-    golden_clr(ref, os.path.join(gd, "g2_clr.pt"))
-    golden_clr(ref, os.path.join(gd, "g2b_clr_one_lidar.pt"), num_nodes=30, k=4, graph_idx=219,
-               lidar_frac=0.04, radar_frac=0.04, salt=11)
-    golden_train_step(ref, os.path.join(gd, "g3_train_step.pt"))
-    golden_predict_post(os.path.join(gd, "g4_predict_post.pt"))
-    golden_loader(os.path.join(gd, "g7_loader.pt"))
-    golden_tracks(os.path.join(gd, "g8_tracks.pt"))
-    golden_scene(ref, os.path.join(gd, "g6_scene_pose.pt"), kind="pose", graph_idx=400, salt=30)
-    golden_scene(ref, os.path.join(gd, "g6_scene_clr.pt"), kind="clr", graph_idx=440, salt=31)
+    only = sys.argv[1:]
+    jobs = [
+        ("g1_pose.pt", lambda p: golden_pose(ref, p)),
+        ("g1b_pose_batch2.pt", lambda p: golden_pose(ref, p, num_nodes=60, k=5, graph_idx=110, batch=2, salt=1)),
+        ("g5_pose_tiny.pt", lambda p: golden_pose(ref, p, num_nodes=25, k=3, graph_idx=120, salt=2)),
+        ("g2_clr.pt", lambda p: golden_clr(ref, p)),
+        ("g2b_clr_one_lidar.pt", lambda p: golden_clr(ref, p, num_nodes=30, k=4, graph_idx=219, lidar_frac=0.04, radar_frac=0.04, salt=11)),
+        ("g3_train_step.pt", lambda p: golden_train_step(ref, p)),
+        ("g9_train_mode_step.pt", lambda p: golden_train_mode_step(ref, p)),
+        ("g9b_train_mode_one_radar_row.pt", lambda p: golden_train_mode_step(ref, p, num_nodes=40, k=5, graph_idx=920, lidar_frac=0.6,
+                                                                              radar_frac=0.013, salt=41)),
+        ("g4_predict_post.pt", lambda p: golden_predict_post(p)),
+        ("g7_loader.pt", lambda p: golden_loader(p)),
+        ("g8_tracks.pt", lambda p: golden_tracks(p)),
+        ("g6_scene_pose.pt", lambda p: golden_scene(ref, p, kind="pose", graph_idx=400, salt=30)),
+        ("g6_scene_clr.pt", lambda p: golden_scene(ref, p, kind="clr", graph_idx=440, salt=31)),
+    ]
+    for name, fn in jobs:
+        if not only or any(name.startswith(o) for o in only):
+            fn(os.path.join(gd, name))
 
 
 if __name__ == "__main__":

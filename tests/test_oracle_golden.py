@@ -108,6 +108,30 @@ def test_train_step_oracle_matches_reference():
     _digest_close(grad_digest(after), g["after_digest"], rtol=1e-6)
 
 
+@pytest.mark.parametrize("name", ["g9_train_mode_step.pt", "g9b_train_mode_one_radar_row.pt"])
+def test_train_mode_step_oracle_matches_reference(name):
+    """The step as train.py runs it -- model in .train(): batch-statistics BatchNorm in the frozen encoders, running
+    statistics updated, the < 2 rows switch to eval (g9b) -- from the reference itself, Dropout neutralised."""
+    g = load_golden(name)
+    data = data_from(g["data"])
+    m = _clr(g["salt"])
+    m.train()
+    m.pointnet.dropout.p = 0.0
+    m.radarnet.dropout.p = 0.0
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4, weight_decay=1e-4, betas=(0.9, 0.999))
+    loss, out, x_sens = ref_torch.train_step(m, data, opt, batch_size=2, loss_kind="cb")
+    torch.testing.assert_close(out, g["out"], rtol=0, atol=2e-6)
+    torch.testing.assert_close(x_sens, g["x_sens"], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(loss, g["loss"], rtol=1e-5, atol=0)
+    assert {"pointnet": m.pointnet.training, "radarnet": m.radarnet.training, "resnet": m.resnet.training,
+            "fc_lidar_encoder": m.fc_lidar_encoder.training, "fc_radar_encoder": m.fc_radar_encoder.training} == g["modes"]
+    bufs = dict(m.named_buffers())
+    for n, v in g["running_stats"].items():
+        torch.testing.assert_close(bufs[n].double(), v.double(), rtol=1e-5, atol=1e-6)
+    after = {n: p.detach() for n, p in m.named_parameters() if p.requires_grad}
+    _digest_close(grad_digest(after), g["after_digest"], rtol=1e-6)
+
+
 def test_predict_post_oracle_matches_reference():
     g = load_golden("g4_predict_post.pt")
     pairs, present, scores = g["pairs"], g["present"], g["scores"]

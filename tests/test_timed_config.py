@@ -1,0 +1,197 @@
+"""GPU: the configuration bench.py TIMES, checked as a whole.
+
+* the hipGraph-captured camera+LiDAR+radar training step -- train-mode frozen encoders, ``mask_stream``, ``pre()`` +
+  ``rows_static`` feeding the replay, a non-null launch stream: bench.Workload / bench.capture / bench.run_step themselves --
+  replayed over the 4-batch pool must leave bitwise the same parameters, BatchNorm statistics and Adam state as the same
+  number of eager steps from the same state;
+* the train-mode training step (encoders in train mode: batch-statistics BatchNorm, running-statistics updates; Dropout
+  neutralised on both sides) against the CPU oracle's ``train_step`` at 300 nodes and at the benchmark size.
+"""
+import argparse
+
+import pytest
+import torch
+
+from oracle.seeded import grad_digest, seeded_fill_
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def _bench_workload(kind, encoders="frozen"):
+    import bench
+    dev = torch.device("cuda:0")
+    torch.cuda.set_stream(torch.cuda.Stream(dev))            # bench.main(): nothing runs on the legacy NULL stream
+    args = argparse.Namespace(no_dead_knn=False)
+    return bench, bench.Workload(kind, dev, 0, 1, args, encoders=encoders)
+
+
+@pytest.mark.parametrize("kind,encoders", [("clr", "frozen"), ("clr", "precomputed"), ("pose", "frozen")])
+def test_captured_replay_equals_eager_bitwise(kind, encoders):
+    bench, wl = _bench_workload(kind, encoders)
+    K = 4
+    for i in range(2):                                        # warm-up, as bench.measure does before it captures
+        wl.step(i)
+    torch.cuda.synchronize()
+    graphs, opt_graph = bench.capture(wl, split=False)
+    start = bench.snapshot(wl)
+    for i in range(K):                                        # the timed region's step, verbatim
+        bench.run_step(wl, graphs, opt_graph, False, 2 + i)
+    torch.cuda.synchronize()
+    replayed = bench.state_digest(wl)
+    losses_replayed = [float(wl.cap_ret[(2 + i) % len(wl.pool)][0]) for i in range(K)]   # each pool batch once: its last replay
+    bench.restore(wl, start)
+    losses_eager = []
+    for i in range(K):
+        losses_eager.append(float(wl.step(2 + i)[0]))
+    torch.cuda.synchronize()
+    eager = bench.state_digest(wl)
+    assert losses_replayed == losses_eager
+    assert replayed.keys() == eager.keys()
+    changed = 0
+    for k in eager:
+        assert torch.equal(replayed[k], eager[k]), k
+        changed += int(not torch.equal(eager[k], start[0][k[6:]])) if k.startswith("model.") else 0
+    assert changed >= 30                                      # the steps did train (weights, running statistics, counters)
+    # and twice the same eager steps from the same state: run-to-run reproducibility of the whole step
+    bench.restore(wl, start)
+    for i in range(K):
+        wl.step(2 + i)
+    torch.cuda.synchronize()
+    again = bench.state_digest(wl)
+    for k in eager:
+        assert torch.equal(again[k], eager[k]), k
+
+
+def test_bench_loss_check_field():
+    bench, wl = _bench_workload("clr")
+    for i in range(2):
+        wl.step(i)
+    torch.cuda.synchronize()
+    graphs, _ = bench.capture(wl, split=False)
+    lc = bench.loss_check(wl, graphs, 5)
+    assert lc["equal"] and lc["replayed_loss"] > 0, lc
+
+
+def _train_pair(salt, dev):
+    """Oracle and HIP model with the same weights, both in TRAIN mode (clr_att_gnn.py:26-33 freezes the encoders'
+    parameters but leaves them in train mode: batch-statistics BatchNorm, running-statistics updates); Dropout
+    (pointnet.py:190, radarnet.py:62) neutralised on both sides, its mask is not part of the contract."""
+    from batch3dmot_amd import encoders
+    from batch3dmot_amd.clr_att_gnn import GNN
+    from oracle import ref_torch
+    ora = ref_torch.GNN(encoders.ResNetAE(), encoders.PointNetClassifier(k=7), encoders.RadarNetClassifier(k=7),
+                        run_dead_knn=False, loop_masks=False)
+    seeded_fill_(ora, salt)
+    m = GNN(encoders.ResNetAE(), encoders.PointNetClassifier(k=7), encoders.RadarNetClassifier(k=7))
+    m.load_state_dict(ora.state_dict())
+    m = m.to(dev)
+    for mod in (ora, m):
+        mod.train()
+        mod.pointnet.dropout.p = 0.0
+        mod.radarnet.dropout.p = 0.0
+    return ora, m
+
+
+@pytest.mark.parametrize("size", ["n300", "bench_size"])
+def test_train_mode_step_matches_oracle(size):
+    from batch3dmot_amd import synth
+    from batch3dmot_amd.train_step import make_optimizer, train_step
+    from oracle import ref_torch
+    dev = torch.device("cuda:0")
+    if size == "n300":
+        data = synth.make_graph(300, None, k=6, graph_idx=733, modalities=True)
+        bs = 1
+    else:
+        data = synth.make_batch(2, 1500, 15000, first_graph_idx=52, modalities=True)
+        bs = 2
+    ora, m = _train_pair(31, dev)
+    o_opt = torch.optim.Adam([p for p in ora.parameters() if p.requires_grad], lr=1e-4, weight_decay=1e-4, betas=(0.9, 0.999))
+    r_loss, r_out, r_sens = ref_torch.train_step(ora, data, o_opt, batch_size=bs, loss_kind="cb", logits=False)
+    opt = make_optimizer(m)
+    loss, out, x_sens = train_step(m, data.to(dev), opt, batch_size=bs, loss_kind="cb", logits=False)
+    torch.cuda.synchronize()
+    assert m.pointnet.training and m.radarnet.training and m.resnet.training        # no sticky eval switch here
+    assert abs(float(loss) - float(r_loss)) <= 1e-5 * abs(float(r_loss)), (float(loss), float(r_loss))
+    assert rel(out.reshape(-1), r_out.reshape(-1)) < TOL
+    assert rel(x_sens, r_sens) < TOL
+    # running statistics of every BatchNorm of the three encoders (the train-mode side effect)
+    ob = dict(ora.named_buffers())
+    n_stats = 0
+    for name, buf in m.named_buffers():
+        if name.endswith("running_mean") or name.endswith("running_var"):
+            if not any(name.startswith(p) for p in ("resnet.bn.", "resnet.fc_", "pointnet.fc3", "radarnet.fc3")):
+                assert rel(buf, ob[name]) < 1e-5, (name, rel(buf, ob[name]))
+                n_stats += 1
+        elif name.endswith("num_batches_tracked"):
+            assert int(buf) == int(ob[name]), name
+    assert n_stats >= 40
+    # weights after the Adam step
+    have = grad_digest({n: p.detach() for n, p in m.named_parameters() if p.requires_grad})
+    want = grad_digest({n: p.detach() for n, p in ora.named_parameters() if p.requires_grad})
+    for n, w in want.items():
+        assert abs(have[n]["norm"] - w["norm"]) <= 2e-6 * max(w["norm"], 1e-6), n
+        torch.testing.assert_close(have[n]["head"], w["head"], rtol=1e-5, atol=2e-7)
+
+
+def test_sticky_eval_switch_inside_a_training_step():
+    """clr_att_gnn.py:128-130,136-138: fewer than two rows of a modality switch that encoder (and its head) to eval for
+    good; the step still trains everything else."""
+    from batch3dmot_amd import synth
+    from batch3dmot_amd.train_step import make_optimizer, train_step
+    from oracle import ref_torch
+    dev = torch.device("cuda:0")
+    data = synth.make_graph(120, None, k=6, graph_idx=741, modalities=True)
+    data.radar_feats[1:] = 0.0                                 # one radar row at most
+    data.radar_feats[0, 0, 0] = 1.0
+    ora, m = _train_pair(37, dev)
+    o_opt = torch.optim.Adam([p for p in ora.parameters() if p.requires_grad], lr=1e-4, weight_decay=1e-4, betas=(0.9, 0.999))
+    r_loss, r_out, _ = ref_torch.train_step(ora, data, o_opt, batch_size=1, loss_kind="cb", logits=False)
+    opt = make_optimizer(m)
+    loss, out, _ = train_step(m, data.to(dev), opt, batch_size=1, loss_kind="cb", logits=False)
+    assert not m.radarnet.training and not m.fc_radar_encoder.training and m.pointnet.training
+    assert not ora.radarnet.training
+    assert abs(float(loss) - float(r_loss)) <= 1e-5 * abs(float(r_loss))
+    assert rel(out.reshape(-1), r_out.reshape(-1)) < TOL
+
+
+@pytest.mark.parametrize("name", ["g9_train_mode_step.pt", "g9b_train_mode_one_radar_row.pt"])
+def test_train_mode_step_matches_reference_golden(name):
+    """The same step against the REFERENCE's own train-mode run (oracle/make_golden.py:golden_train_mode_step executes
+    clr_att_gnn.py / pointnet.py / radarnet.py / resnet_fully_conv.py in .train(), Dropout p = 0): scores, loss, x_sens,
+    the encoders' BatchNorm running statistics, which sub-modules ended in eval mode (g9b: one radar row), and every
+    trainable weight after Adam."""
+    from conftest import data_from, load_golden
+    from batch3dmot_amd import encoders
+    from batch3dmot_amd.clr_att_gnn import GNN
+    from batch3dmot_amd.train_step import make_optimizer, train_step
+    dev = torch.device("cuda:0")
+    g = load_golden(name)
+    data = data_from(g["data"]).to(dev)
+    m = GNN(encoders.ResNetAE(), encoders.PointNetClassifier(k=7), encoders.RadarNetClassifier(k=7))
+    seeded_fill_(m, g["salt"])
+    m = m.to(dev).train()
+    m.pointnet.dropout.p = 0.0
+    m.radarnet.dropout.p = 0.0
+    opt = make_optimizer(m)
+    loss, out, x_sens = train_step(m, data, opt, batch_size=2, loss_kind="cb", logits=False)
+    torch.cuda.synchronize()
+    assert rel(out.reshape(-1), g["out"].reshape(-1)) < TOL and rel(x_sens, g["x_sens"]) < TOL
+    assert abs(float(loss) - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
+    assert {"pointnet": m.pointnet.training, "radarnet": m.radarnet.training, "resnet": m.resnet.training,
+            "fc_lidar_encoder": m.fc_lidar_encoder.training, "fc_radar_encoder": m.fc_radar_encoder.training} == g["modes"]
+    bufs = dict(m.named_buffers())
+    for n, v in g["running_stats"].items():
+        if n.endswith("num_batches_tracked"):
+            assert int(bufs[n]) == int(v), n
+        else:
+            assert rel(bufs[n], v) < 1e-5, (n, rel(bufs[n], v))
+    have = grad_digest({n: p.detach() for n, p in m.named_parameters() if p.requires_grad})
+    for n, w in g["after_digest"].items():
+        assert abs(have[n]["norm"] - w["norm"]) <= 2e-6 * max(w["norm"], 1e-6), n
+        torch.testing.assert_close(have[n]["head"], w["head"], rtol=1e-5, atol=2e-7)

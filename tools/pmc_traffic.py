@@ -57,6 +57,14 @@ def main():
     if os.path.exists(out):
         data = json.load(open(out))
     data[key] = res
+    # which library build and day the counters belong to (bench.py prints it beside roofline.traffic)
+    import datetime, hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        sha = hashlib.sha256(open(os.path.join(root, "batch3dmot_amd", "libb3d_hip.so"), "rb").read()).hexdigest()[:16]
+    except OSError:
+        sha = None
+    data["_source"] = {"lib_sha16": sha, "date": datetime.date.today().isoformat(), "tool": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes"}
     json.dump(data, open(out, "w"), indent=1, sort_keys=True)
     text = "\n".join(lines[:60])
     if table:
