@@ -1,14 +1,13 @@
 // Stand-alone harness for the camera+LiDAR+radar EDGE stack (hoisted form, forward), the kernel shape under development:
-//   8 wavefronts per workgroup (two per SIMD, 256 registers each), each owning ONE 16-row tile, 128 edges per workgroup.
-//   Every Linear is Y^T[out][row] = W[out][in] . X^T[in][row] on v_mfma_f32_16x16x32_bf16 ("bf16x6": exact three-way bf16
-//   split of both operands, six piece products, fp32 accumulation).  Two wavefronts per SIMD are what keeps the matrix pipe
-//   busy (tools/micro/mfma_rate.hip: 13.8 cycles per MFMA and SIMD against 24.7 for a single wavefront with two row tiles, and
-//   a single wavefront on the 32x32x16 form is no better: edge_stack32.hip, 85 us).  The 16x16 accumulator of a layer (lane = row,
-//   4 registers = features 4 q + {0..3} of a 16-feature block, q = lane >> 4) is the B operand of the next layer without lane
-//   movement; the weight images are stored FRAGMENT BY FRAGMENT in exactly that k order (1 KB = one ds_read_b128 of a
-//   wavefront = one LDS-DMA piece: no strides, no bank conflicts).
+//   4 wavefronts per workgroup (one per SIMD, up to 512 registers), each owning ONE 32-row tile (32 edges), 128 edges per
+//   workgroup.  Every Linear is Y^T[out][row] = W[out][in] . X^T[in][row] on v_mfma_f32_32x32x16_bf16 ("bf16x6": exact
+//   three-way bf16 split of both operands, six piece products, fp32 accumulation): ONE wavefront per SIMD issues the
+//   32-cycle instruction back to back (tools/micro/mfma_rate.hip: the 16-cycle 16x16x32 form needs two wavefronts per SIMD:
+//   24.7 vs 13.8 cycles per MFMA and SIMD with the LDS fragment reads in the loop).  The 32x32 accumulator of a layer
+//   (lane = row, 16 registers = features (i & 3) + 8 (i >> 2) + 4 (lane >> 5)) is the B operand of the next layer without
+//   lane movement; the weight images are stored fragment by fragment in exactly that k order.
 //   Weights stream global -> LDS through a ring of 24 KB slots by LDS-DMA issued from inline asm (invisible to hipcc's
-//   s_waitcnt bookkeeping) with counted vmcnt waits; one s_barrier per 8 steps (48 MFMAs per wavefront).
+//   s_waitcnt bookkeeping) with counted vmcnt waits; one s_barrier per 8 k-steps (48 MFMAs per wavefront).
 // Checks the result against a float64 CPU evaluation and times the launch.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++20 edge_stack.hip -o edge_stack && ./edge_stack
 #include <hip/hip_runtime.h>
@@ -20,9 +19,6 @@
 #include <utility>
 #include <vector>
 
-#ifndef PRIO_MODE
-#define PRIO_MODE 0
-#endif
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -34,26 +30,14 @@ constexpr int DE = 64, DA = 64, EH1 = 256, EH2 = 128, MH = 192, DM = 128;
 constexpr int TW = 992, OA = 0, OB = 256, OF = 512, OP = 704;
 
 // ---- weight stream geometry ---------------------------------------------------------------------------------------------
-// A layer with K inputs and N outputs is (N / 32) x (K / 32) steps; a step is TWO 16 x 32 blocks of W (output blocks 2 p and
-// 2 p + 1 against the same 32 inputs: two independent accumulator chains per wavefront -- with a single chain the dependent
-// MFMAs of a wavefront issue ~42 cycles apart and two wavefronts per SIMD reach 21.4 cycles per MFMA instead of 13.8,
-// tools/micro/mfma_rate.hip), each as three 1 KB fragments (bf16 pieces 0, 1, 2): lane l = (m = l & 15, q = l >> 4) holds the 8
-// bf16 W[16 ob + m][32 c + 16 (j >> 2) + 4 q + (j & 3)], j = 0..7.  Steps are stored in execution order (for p: for c); a chunk is
-// kChunkSteps consecutive steps.
-#ifndef WAVES
-#define WAVES 8
-#endif
-#ifndef CSTEPS
-#define CSTEPS 4
-#endif
-#ifndef SLOTS
-#define SLOTS (WAVES == 8 ? 6 : 3)
-#endif
-constexpr int kWaves = WAVES, kChunkSteps = CSTEPS, kStepBytes = 6144, kChunkBytes = kChunkSteps * kStepBytes, kSlots = SLOTS;
-constexpr int kPiecesPerWave = kChunkBytes / 1024 / kWaves;          // 3 (8 wavefronts) or 6 (4 wavefronts, two workgroups per CU)
+// A layer with K inputs and N outputs is (N / 32) x (K / 16) steps; a step is the three 1 KB fragments (bf16 pieces 0, 1, 2) of
+// one 32 x 16 block of W: lane l = (r = l & 31, h = l >> 5) holds the 8 bf16 W[32 ob + r][32 ib + 16 s + 8 (j >> 2) + 4 h + (j & 3)],
+// j = 0..7, for k-step ks = 2 ib + s.  Steps are stored in execution order; a chunk is kChunkSteps consecutive steps.
+constexpr int kWaves = 4, kChunkSteps = 8, kStepBytes = 3072, kChunkBytes = kChunkSteps * kStepBytes, kSlots = 6;
+constexpr int kPiecesPerWave = kChunkBytes / 1024 / kWaves;          // 6
 template <int K_, int N_>
 struct LY {
-  static constexpr int K = K_, N = N_, KS = K / 32, OB = N / 32, STEPS = KS * OB;
+  static constexpr int K = K_, N = N_, KS = K / 16, OB = N / 32, STEPS = KS * OB;
   static_assert(K % 32 == 0 && N % 32 == 0 && STEPS % kChunkSteps == 0, "layer geometry");
 };
 template <class... Ls>
@@ -72,7 +56,7 @@ struct SeqT {
 };
 using FwdSeq = SeqT<LY<128, 256>, LY<256, 128>, LY<128, 64>, LY<64, 192>, LY<192, 128>, LY<64, 192>, LY<192, 128>>;
 static_assert(FwdSeq::NCH % kSlots == 0, "the slot of a chunk must not depend on the tile");
-static_assert(FwdSeq::BIAS_BYTES == 8192, "bias DMA below moves 8 KB");
+static_assert(FwdSeq::BIAS_BYTES == 8192, "bias DMA below moves two pieces per wavefront");
 constexpr int kLdsBytes = kSlots * kChunkBytes + FwdSeq::BIAS_BYTES;
 
 // ---- bf16x6 ---------------------------------------------------------------------------------------------------------------
@@ -96,53 +80,54 @@ __device__ __forceinline__ Bf3 bf_split(const v4f a, const v4f b) {
   }
   return Bf3{__builtin_bit_cast(bf8, q0), __builtin_bit_cast(bf8, q1), __builtin_bit_cast(bf8, q2)};
 }
-// A 16-feature block of one row IS the accumulator: element e = feature 4 q + e (q = lane >> 4).
-typedef v4f Blk;
-__device__ __forceinline__ Blk relu4(const Blk a) { return Blk{fmaxf(a.x, 0.f), fmaxf(a.y, 0.f), fmaxf(a.z, 0.f), fmaxf(a.w, 0.f)}; }
+// A 32-feature block of one row IS the accumulator vector: element 4 g + e = feature 8 g + 4 h + e (g = 0..3, e = 0..3).
+typedef v16f Blk;
+typedef float v8f __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ Blk blk_from(const v4f a, const v4f b, const v4f c, const v4f d) {
+  const v8f lo = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+  const v8f hi = __builtin_shufflevector(c, d, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+}
+template <int G>
+__device__ __forceinline__ v4f blk_part(const Blk b) { return __builtin_shufflevector(b, b, 4 * G, 4 * G + 1, 4 * G + 2, 4 * G + 3); }
+__device__ __forceinline__ Blk relu16(const Blk a) {
+  const Blk z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  return __builtin_elementwise_max(a, z);
+}
 
 // ---- LDS-DMA ring -----------------------------------------------------------------------------------------------------------
-// One asm statement per chunk and wavefront: 3 pieces of 1 KB (64 lanes x 16 B), contiguous in global memory and in LDS.  The
+// One asm statement per chunk and wavefront: 6 pieces of 1 KB (64 lanes x 16 B), contiguous in global memory and in LDS.  The
 // instruction offset advances the global AND the LDS address (tools/micro/dma_probe.hip).  M0 carries the LDS byte address;
 // it is compiler-reserved, so it is saved and restored inside the statement.
-__device__ __forceinline__ void dma3(const void* gsrc, unsigned lds_dst, unsigned voff) {
+__device__ __forceinline__ void dma6(const void* gsrc, unsigned lds_dst, unsigned voff) {
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-               "global_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\tglobal_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+               "global_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+               "global_load_lds_dwordx4 %1, %2 offset:2048\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072\n\t"
+               "s_add_u32 m0, m0, 0x1000\n\tv_add_u32 %1, 0x1000, %1\n\t"
+               "global_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
                "s_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(voff), "s"(gsrc), "s"(lds_dst) : "memory");
+               : "=&s"(keep), "+v"(voff) : "s"(gsrc), "s"(lds_dst) : "memory");
 }
 __device__ __forceinline__ void dma2(const void* gsrc, unsigned lds_dst, unsigned voff) {
   unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(voff), "s"(gsrc), "s"(lds_dst) : "memory");
-}
-__device__ __forceinline__ void dma1(const void* gsrc, unsigned lds_dst, unsigned voff) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+               "global_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+               "s_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(voff), "s"(gsrc), "s"(lds_dst) : "memory");
 }
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// HK::before(c): ordinary vector-memory instructions (stores / loads that hipcc issues) in front of step 0 of chunk c, i.e.
-// between chunk_start<c - 1> and chunk_start<c>.  They are YOUNGER than the DMA pieces issued at chunk_start<c - 1>: a wait that
-// does not count them drains every DMA in flight and every store.  The counts must not exceed what is really issued (an
-// over-count would let the wait return early): rows past the end are stored too (into the buffers' padding), so every store
-// is unconditional.
-//
-//
-// RENDEZVOUS.  One s_barrier in front of step 0 of every chunk C, with the meaning "every wavefront's pieces of chunk C + 1 have
-// landed (each waited for its own with a counted vmcnt in front of the barrier) and every wavefront is done with chunk C - 1":
-// chunk C + 1 is known to be complete a whole chunk before it is needed, so the fragments of its first step are fetched
-// during the last step of chunk C like any others -- no LDS latency is exposed behind the barrier -- and the slot of chunk
-// C - 1 is refilled with chunk C + 5, one piece in front of each of the steps 0, 1, 2 (the three LDS-DMA issues of a wavefront
-// are then spread over the chunk instead of standing between the barrier and its first MFMA).
+// HK::before(ci): ordinary vector-memory instructions (stores / loads that hipcc issues) between acquire<ci - 1> and
+// acquire<ci>.  They are YOUNGER than the DMA pieces issued at acquire<ci - 1>: a wait that does not count them drains every DMA
+// in flight and every store.  The counts must not exceed what is really issued (an over-count would let the wait return
+// early): rows past the end are stored too (into the buffers' padding), so every store is unconditional.
 template <class S, class HK>
 struct Ring {
   const char* g;        // images: weights, then the biases
   unsigned lds0;        // byte address of the ring in the LDS address space
   int wave, lane;
-  long long* sstamps;
   __device__ __forceinline__ void init(const void* gw, const void* lds) {
     g = (const char*)gw;
     lds0 = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)lds;
@@ -150,67 +135,41 @@ struct Ring {
     lane = threadIdx.x & 63;
   }
   __device__ __forceinline__ unsigned bias_lds() const { return lds0 + kSlots * kChunkBytes; }
-  // the pieces [J0, J1) of this wavefront's share of chunk CI
-  template <int CI, int J0, int J1>
-  __device__ __forceinline__ void issue_pieces() {
+  template <int CI>
+  __device__ __forceinline__ void issue() {
 #ifdef NO_DMA
     return;          // timing experiment: no weight stream (results are garbage)
 #endif
     constexpr int SLOT = CI % kSlots;
-    if constexpr (J1 > J0) {
-      const unsigned woff = (unsigned)wave * (kPiecesPerWave * 1024) + J0 * 1024;
-      if constexpr (J1 - J0 == 1) dma1(g + (size_t)CI * kChunkBytes, lds0 + SLOT * kChunkBytes + woff, woff + lane * 16);
-      else if constexpr (J1 - J0 == 2) dma2(g + (size_t)CI * kChunkBytes, lds0 + SLOT * kChunkBytes + woff, woff + lane * 16);
-      else { issue_pieces<CI, J0, J0 + 2>(); issue_pieces<CI, J0 + 2, J1>(); }
-    }
+    const unsigned woff = (unsigned)wave * (kPiecesPerWave * 1024);
+    dma6(g + (size_t)CI * kChunkBytes, lds0 + SLOT * kChunkBytes + woff, woff + lane * 16);
   }
+  // pieces of this wavefront that may still be in flight when chunk CI is needed: those of the chunks issued after it
   template <int CI>
-  __device__ __forceinline__ void issue() { issue_pieces<CI, 0, kPiecesPerWave>(); }
-  // pieces of this wavefront younger than its pieces of chunk C + 1 when rendezvous<C> waits: chunks C + 2 .. C + 4 (chunk C + 4 was
-  // issued during chunk C - 1), and the ordinary loads / stores in front of the chunks C - 2 .. C
-  template <int C>
   static constexpr int pending(bool more) {
     int p = 0;
-    for (int c = C + 2; c <= C + kSlots - 2; ++c)
+    for (int c = CI + 1; c < CI + kSlots - 1; ++c)
       if (c < S::NCH || more) p += kPiecesPerWave;
-    for (int c = C - (kSlots - 4 > 0 ? kSlots - 4 : 0); c <= C; ++c)
-      if (c >= 0) p += HK::before(c);                     // (first tile: nothing before chunk 0; later tiles: under-counted, safe)
+    for (int j = 0; j < kSlots - 1; ++j)
+      if (CI - j >= 0) p += HK::before(CI - j);          // (first tile: nothing before chunk 0; later tiles: under-counted, safe)
     return p < 63 ? p : 63;
   }
-  // Stream start (once per kernel): chunks 0..4 in flight, chunks 0 and 1 complete for everybody.
   __device__ __forceinline__ void start() {
-    if constexpr (kWaves == 8) {
-      const unsigned woff = (unsigned)wave * 1024;
-      dma1(g + S::WEIGHT_BYTES, bias_lds() + woff, woff + lane * 16);          // biases: 8 KB, older than every chunk
-    } else {
-      const unsigned woff = (unsigned)wave * 2048;
-      dma2(g + S::WEIGHT_BYTES, bias_lds() + woff, woff + lane * 16);
-    }
-    issue_first(std::make_integer_sequence<int, kSlots - 1>{});
-    wait_vm<(kSlots - 3) * kPiecesPerWave>();        // mine of chunks 0 and 1 (and of the biases) have landed
-    __builtin_amdgcn_s_barrier();
+    const unsigned woff = (unsigned)wave * 2048;
+    dma2(g + S::WEIGHT_BYTES, bias_lds() + woff, woff + lane * 16);          // biases: 8 KB, older than every chunk
+    issue<0>(); issue<1>(); issue<2>(); issue<3>(); issue<4>();
   }
-  template <int... CI>
-  __device__ __forceinline__ void issue_first(std::integer_sequence<int, CI...>) { (issue<CI>(), ...); }
-  template <int C>
-  __device__ __forceinline__ unsigned slot_addr() const { return lds0 + (C % kSlots) * kChunkBytes; }
-  template <int C>
-  __device__ __forceinline__ void rendezvous(bool more) {
-    if constexpr (C == 0) { if (!more_tiles_started) { more_tiles_started = true; return; } }   // Ring::start covered the first one
-    constexpr int P1 = pending<C>(true), P0 = pending<C>(false);
-    if constexpr (P1 == P0) wait_vm<P1>();
-    else { if (more) wait_vm<P1>(); else wait_vm<P0>(); }
-#ifndef NO_BARRIER
+  // chunk CI has landed for every wavefront, the slot of chunk CI - 1 is free: refill it with chunk CI + kSlots - 1
+  template <int CI>
+  __device__ __forceinline__ unsigned acquire(bool more) {
+    constexpr int PM = pending<CI>(true), PN = pending<CI>(false);
+    if constexpr (PM == PN) wait_vm<PM>();
+    else { if (more) wait_vm<PM>(); else wait_vm<PN>(); }
     __builtin_amdgcn_s_barrier();
-#endif
-  }
-  bool more_tiles_started = false;
-  // in front of step J of chunk C: this step's share of the pieces of chunk C + kSlots - 1
-  template <int C, int J>
-  __device__ __forceinline__ void refill(bool more) {
-    constexpr int NXT = C + kSlots - 1, J0 = J * kPiecesPerWave / kChunkSteps, J1 = (J + 1) * kPiecesPerWave / kChunkSteps;
-    if constexpr (NXT < S::NCH) issue_pieces<NXT, J0, J1>();
-    else if (more) issue_pieces<NXT - S::NCH, J0, J1>();
+    constexpr int NXT = CI + kSlots - 1;
+    if constexpr (NXT < S::NCH) issue<NXT>();
+    else if (more) issue<NXT - S::NCH>();
+    return lds0 + (CI % kSlots) * kChunkBytes;
   }
 };
 
@@ -223,113 +182,112 @@ __device__ __forceinline__ Bf3 frag_load(unsigned addr) {          // addr: this
   f.p2 = __builtin_bit_cast(bf8, *(lds_u4v_p)(size_t)(addr + 2048));
   return f;
 }
-__device__ __forceinline__ v4f mfma6(const Bf3& w, const Bf3& x, v4f acc) {   // smallest terms first
-  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.p0, x.p2, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.p1, x.p1, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.p2, x.p0, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.p0, x.p1, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.p1, x.p0, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.p0, x.p0, acc, 0, 0, 0);
+__device__ __forceinline__ v16f mfma6(const Bf3& w, const Bf3& x, v16f acc) {   // smallest terms first
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.p0, x.p2, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.p1, x.p1, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.p2, x.p0, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.p0, x.p1, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.p1, x.p0, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.p0, x.p0, acc, 0, 0, 0);
   return acc;
 }
 
 // State of a layer's step loop (everything else is compile-time).
 struct StepState {
   unsigned base;     // LDS address of the current chunk
-  Bf3 cur0, cur1;    // fragments of the current step (output blocks 2 p, 2 p + 1)
-  v4f acc0, acc1;
+  Bf3 cur;           // fragments of the current step
+  v16f acc;
 };
-__device__ __forceinline__ void frag_load2(unsigned addr, Bf3& f0, Bf3& f1) { f0 = frag_load(addr); f1 = frag_load(addr + 3072); }
-// two independent chains, interleaved
-__device__ __forceinline__ void mfma12(const Bf3& w0, const Bf3& w1, const Bf3& x, v4f& a0, v4f& a1) {
-  a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0.p0, x.p2, a0, 0, 0, 0);
-  a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1.p0, x.p2, a1, 0, 0, 0);
-  a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0.p1, x.p1, a0, 0, 0, 0);
-  a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1.p1, x.p1, a1, 0, 0, 0);
-  a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0.p2, x.p0, a0, 0, 0, 0);
-  a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1.p2, x.p0, a1, 0, 0, 0);
-  a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0.p0, x.p1, a0, 0, 0, 0);
-  a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1.p0, x.p1, a1, 0, 0, 0);
-  a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0.p1, x.p0, a0, 0, 0, 0);
-  a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1.p1, x.p0, a1, 0, 0, 0);
-  a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0.p0, x.p0, a0, 0, 0, 0);
-  a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1.p0, x.p0, a1, 0, 0, 0);
-}
 
 // One step of layer LI: k-step ks of output block ob.  io[ob] holds the initial value (INIT) on entry of the block and the
 // activation on exit.
 template <class S, int LI, int ST, bool RELU, bool BIAS, bool INIT, class RingT>
-__device__ __forceinline__ void step(RingT& ring, bool more, StepState& st, const Bf3 (&x)[S::k(LI) / 32], Blk (&io)[S::n(LI) / 16]) {
-  constexpr int KS = S::k(LI) / 32, NST = S::steps(LI);
+__device__ __forceinline__ void step(RingT& ring, bool more, StepState& st, const Bf3 (&x)[S::k(LI) / 16], Blk (&io)[S::n(LI) / 32]) {
+  constexpr int KS = S::k(LI) / 16, NST = S::steps(LI);
   constexpr int ob = ST / KS, ks = ST % KS;
   constexpr int GST = S::first_step(LI) + ST;                    // step of the tile
   constexpr int IN_CHUNK = GST % kChunkSteps;
-  constexpr int CJ = GST / kChunkSteps;
-#ifdef STEP_STAMPS
-  if (blockIdx.x == 7 && ring.lane == 0 && (ring.wave & 1) == 0) ring.sstamps[(ring.wave >> 1) * 512 + 2 * GST] = clock64();
-#endif
   if constexpr (IN_CHUNK == 0) {
-    ring.template rendezvous<CJ>(more);
-    st.base = ring.template slot_addr<CJ>();       // (its first fragments were fetched during the previous step)
+    st.base = ring.template acquire<GST / kChunkSteps>(more);
+    st.cur = frag_load(st.base + ring.lane * 16);
   }
-  ring.template refill<CJ, IN_CHUNK>(more);
   if constexpr (ks == 0) {
-    v4f a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+    v16f a = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if constexpr (BIAS) {
-      const unsigned ba = ring.bias_lds() + (S::bias_off(LI) + 32 * ob + 4 * (ring.lane >> 4)) * 4;
-      a0 = *(lds_v4f_p)(size_t)ba;
-      a1 = *(lds_v4f_p)(size_t)(ba + 64);
+      const unsigned ba = ring.bias_lds() + (S::bias_off(LI) + 32 * ob + 4 * (ring.lane >> 5)) * 4;
+      a = blk_from(*(lds_v4f_p)(size_t)(ba), *(lds_v4f_p)(size_t)(ba + 32), *(lds_v4f_p)(size_t)(ba + 64), *(lds_v4f_p)(size_t)(ba + 96));
     }
-    if constexpr (INIT) { a0 += io[2 * ob]; a1 += io[2 * ob + 1]; }
-    st.acc0 = a0; st.acc1 = a1;
+    if constexpr (INIT) a += io[ob];
+    st.acc = a;
   }
-  // the LDS reads of the NEXT step are issued in front of this step's twelve MFMAs (hipcc otherwise sinks them next to their use)
-  Bf3 n0 = st.cur0, n1 = st.cur1;
-  if constexpr (IN_CHUNK + 1 < kChunkSteps) frag_load2(st.base + (IN_CHUNK + 1) * kStepBytes + ring.lane * 16, n0, n1);
-  else if constexpr (CJ + 1 < S::NCH) frag_load2(ring.template slot_addr<CJ + 1>() + ring.lane * 16, n0, n1);
-  else { if (more) frag_load2(ring.template slot_addr<0>() + ring.lane * 16, n0, n1); }
+  // The three LDS reads of the NEXT step go one each into the first three MFMA gaps of this step: issued between MFMAs a
+  // read costs a few cycles of the gap; issued as a group in front of them the matrix pipe drains meanwhile
+  // (tools/micro/mfma_rate.hip: 39 vs 47 cycles per MFMA for one wavefront per SIMD).
   __builtin_amdgcn_sched_barrier(0);
-#ifdef STEP_STAMPS
-  if (blockIdx.x == 7 && ring.lane == 0 && (ring.wave & 1) == 0) ring.sstamps[(ring.wave >> 1) * 512 + 2 * GST + 1] = clock64();
-#endif
-  mfma12(st.cur0, st.cur1, x[ks], st.acc0, st.acc1);
+  Bf3 nxt = st.cur;
+  constexpr bool PREFETCH = IN_CHUNK + 1 < kChunkSteps && ST + 1 < NST;
+  if constexpr (PREFETCH) nxt = frag_load(st.base + (IN_CHUNK + 1) * kStepBytes + ring.lane * 16);
+  st.acc = mfma6(st.cur, x[ks], st.acc);
+  if constexpr (PREFETCH) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+  }
   __builtin_amdgcn_sched_barrier(0);
-  st.cur0 = n0; st.cur1 = n1;
-  if constexpr (ks == KS - 1) { io[2 * ob] = RELU ? relu4(st.acc0) : st.acc0; io[2 * ob + 1] = RELU ? relu4(st.acc1) : st.acc1; }
+  st.cur = nxt;
+  if constexpr (ks == KS - 1) io[ob] = RELU ? relu16(st.acc) : st.acc;
 }
 template <class S, int LI, bool RELU, bool BIAS, bool INIT, class RingT, int... ST>
-__device__ __forceinline__ void layer_impl(RingT& ring, bool more, const Bf3 (&x)[S::k(LI) / 32], Blk (&io)[S::n(LI) / 16],
-                                           StepState& st, std::integer_sequence<int, ST...>) {
+__device__ __forceinline__ void layer_impl(RingT& ring, bool more, const Bf3 (&x)[S::k(LI) / 16], Blk (&io)[S::n(LI) / 32],
+                                           std::integer_sequence<int, ST...>) {
+  StepState st;
   (step<S, LI, ST, RELU, BIAS, INIT>(ring, more, st, x, io), ...);
 }
 template <class S, int LI, bool RELU, bool BIAS, bool INIT, class RingT>
-__device__ __forceinline__ void layer(RingT& ring, bool more, StepState& st, const Bf3 (&x)[S::k(LI) / 32], Blk (&io)[S::n(LI) / 16]) {
-  layer_impl<S, LI, RELU, BIAS, INIT>(ring, more, x, io, st, std::make_integer_sequence<int, S::steps(LI)>{});
+__device__ __forceinline__ void layer(RingT& ring, bool more, const Bf3 (&x)[S::k(LI) / 16], Blk (&io)[S::n(LI) / 32]) {
+  layer_impl<S, LI, RELU, BIAS, INIT>(ring, more, x, io, std::make_integer_sequence<int, S::steps(LI)>{});
 }
 
 template <int NB>
-__device__ __forceinline__ void split_blocks(const Blk (&a)[NB], Bf3 (&x)[NB / 2]) {
+__device__ __forceinline__ void split_blocks(const Blk (&a)[NB], Bf3 (&x)[2 * NB]) {
 #pragma unroll
-  for (int c = 0; c < NB / 2; ++c) x[c] = bf_split(a[2 * c], a[2 * c + 1]);
+  for (int b = 0; b < NB; ++b) {
+    x[2 * b] = bf_split(blk_part<0>(a[b]), blk_part<1>(a[b]));
+    x[2 * b + 1] = bf_split(blk_part<2>(a[b]), blk_part<3>(a[b]));
+  }
 }
 // Row tables are addressed as (uniform base pointer) + (32-bit byte offset): one VGPR per row and table, and hipcc selects
 // the saddr form of global_load / global_store (no 64-bit address arithmetic, no address pairs to keep alive).
 template <int NB>
 __device__ __forceinline__ void load_row(const float* __restrict__ base, unsigned row, int stride, int col0, Blk (&dst)[NB]) {
-  const unsigned q = (threadIdx.x & 63) >> 4;
-  const unsigned off = (row * (unsigned)stride + (unsigned)col0 + 4u * q) * 4u;
+  const unsigned h = (threadIdx.x & 63) >> 5;
+  const unsigned off = (row * (unsigned)stride + (unsigned)col0 + 4u * h) * 4u;
 #pragma unroll
-  for (int b = 0; b < NB; ++b) dst[b] = *reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(base) + off + 64u * b);
+  for (int b = 0; b < NB; ++b) {
+    const char* p = reinterpret_cast<const char*>(base) + off + 128u * b;
+    dst[b] = blk_from(*reinterpret_cast<const v4f*>(p), *reinterpret_cast<const v4f*>(p + 32), *reinterpret_cast<const v4f*>(p + 64),
+                      *reinterpret_cast<const v4f*>(p + 96));
+  }
 }
 template <int NB>
 __device__ __forceinline__ void store_row(float* __restrict__ base, unsigned row, int stride, const Blk (&src)[NB]) {
 #ifdef NO_STORE
   return;            // timing experiment
 #endif
-  const unsigned q = (threadIdx.x & 63) >> 4;
-  const unsigned off = (row * (unsigned)stride + 4u * q) * 4u;
+  const unsigned h = (threadIdx.x & 63) >> 5;
+  const unsigned off = (row * (unsigned)stride + 4u * h) * 4u;
 #pragma unroll
-  for (int b = 0; b < NB; ++b) *reinterpret_cast<v4f*>(reinterpret_cast<char*>(base) + off + 64u * b) = src[b];
+  for (int b = 0; b < NB; ++b) {
+    char* p = reinterpret_cast<char*>(base) + off + 128u * b;
+    *reinterpret_cast<v4f*>(p) = blk_part<0>(src[b]);
+    *reinterpret_cast<v4f*>(p + 32) = blk_part<1>(src[b]);
+    *reinterpret_cast<v4f*>(p + 64) = blk_part<2>(src[b]);
+    *reinterpret_cast<v4f*>(p + 96) = blk_part<3>(src[b]);
+  }
 }
 
 #ifdef STAMPS
@@ -349,104 +307,97 @@ struct Args {
 struct FwdHooks {     // stores + loads in front of the first chunk of layers 1 .. 6 (edge_fwd_kernel below)
   __host__ __device__ static constexpr int before(int ci) {
     using S = FwdSeq;
-    return ci == S::first_chunk(1) ? 16 + 12 : ci == S::first_chunk(2) ? 8 + 12 : ci == S::first_chunk(3) ? 4 : ci == S::first_chunk(4) ? 12
-         : ci == S::first_chunk(5) ? 8 : ci == S::first_chunk(6) ? 12 : 0;
+    return ci == S::first_chunk(1) ? 32 + 24 : ci == S::first_chunk(2) ? 16 + 24 : ci == S::first_chunk(3) ? 8 : ci == S::first_chunk(4) ? 24
+         : ci == S::first_chunk(5) ? 16 : ci == S::first_chunk(6) ? 24 : 0;
   }
 };
-__global__ __launch_bounds__(kWaves * 64, 2) void edge_fwd_kernel(const Args a) {
-  constexpr int kTileRows = kWaves * 16;
+__global__ __launch_bounds__(kWaves * 64, 1) void edge_fwd_kernel(const Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using S = FwdSeq;
   STAMP(0);
   Ring<S, FwdHooks> ring;
   ring.init(a.wpack, smem);
-  ring.sstamps = a.stamps + 4096 * 8;
   ring.start();
   const int lane = threadIdx.x & 63;
-  const int ntiles = (a.E + kTileRows - 1) / kTileRows;
-  StepState st;
-  st.base = ring.template slot_addr<0>();
-  frag_load2(st.base + ring.lane * 16, st.cur0, st.cur1);       // chunk 0 is complete (Ring::start)
+  const int ntiles = (a.E + 127) / 128;
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const bool more = tile + (int)gridDim.x < ntiles;
-    const unsigned row = (unsigned)tile * (unsigned)kTileRows + ring.wave * 16 + (lane & 15);
+    const unsigned row = (unsigned)tile * 128u + ring.wave * 32 + (lane & 31);
     const unsigned rc = row < (unsigned)a.E ? row : (unsigned)a.E - 1u;         // rows past the end compute on the last edge
     const unsigned s = (unsigned)a.src[rc], d = (unsigned)a.dst[rc];
-    Blk ein[8];
+    Blk ein[4];
     {
-      Blk e0[4], a0[4];
-      load_row<4>(a.e_in, rc, DE, 0, e0);
-      load_row<4>(a.a_in, rc, DA, 0, a0);
-#pragma unroll
-      for (int b = 0; b < 4; ++b) { ein[b] = e0[b]; ein[4 + b] = a0[b]; }
+      Blk e0[2], a0[2];
+      load_row<2>(a.e_in, rc, DE, 0, e0);
+      load_row<2>(a.a_in, rc, DA, 0, a0);
+      ein[0] = e0[0]; ein[1] = e0[1]; ein[2] = a0[0]; ein[3] = a0[1];
     }
-    Blk h1[16];
+    Blk h1[8];
     {
-      Blk tb[16];
-      load_row<16>(a.T, d, TW, OA, h1);
-      load_row<16>(a.T, s, TW, OB, tb);
+      Blk tb[8];
+      load_row<8>(a.T, d, TW, OA, h1);
+      load_row<8>(a.T, s, TW, OB, tb);
 #pragma unroll
-      for (int b = 0; b < 16; ++b) h1[b] += tb[b];
+      for (int b = 0; b < 8; ++b) h1[b] += tb[b];
     }
     // ---- edge_update ----
     {
-      Bf3 x0[4];
-      split_blocks<8>(ein, x0);
+      Bf3 x0[8];
+      split_blocks<4>(ein, x0);
       STAMP(1);
-      layer<S, 0, true, false, true>(ring, more, st, x0, h1);
+      layer<S, 0, true, false, true>(ring, more, x0, h1);
     }
     STAMP(2);
-    store_row<16>(a.sH1, row, EH1, h1);
-    Blk fi[12];
-    load_row<12>(a.T, d, TW, OF, fi);
-    Blk h2[8];
+    store_row<8>(a.sH1, row, EH1, h1);
+    Blk fi[6];
+    load_row<6>(a.T, d, TW, OF, fi);
+    Blk h2[4];
     {
-      Bf3 x1[8];
-      split_blocks<16>(h1, x1);
-      layer<S, 1, true, true, false>(ring, more, st, x1, h2);
+      Bf3 x1[16];
+      split_blocks<8>(h1, x1);
+      layer<S, 1, true, true, false>(ring, more, x1, h2);
     }
     STAMP(3);
-    store_row<8>(a.sH2, row, EH2, h2);
-    Blk pi[12];
-    load_row<12>(a.T, s, TW, OP, pi);
-    Blk en[4];
+    store_row<4>(a.sH2, row, EH2, h2);
+    Blk pi[6];
+    load_row<6>(a.T, s, TW, OP, pi);
+    Blk en[2];
     {
-      Bf3 x2[4];
-      split_blocks<8>(h2, x2);
-      layer<S, 2, false, true, false>(ring, more, st, x2, en);
+      Bf3 x2[8];
+      split_blocks<4>(h2, x2);
+      layer<S, 2, false, true, false>(ring, more, x2, en);
     }
     STAMP(4);
-    store_row<4>(a.e_out, row, DE, en);
-    Bf3 xe[2];
-    split_blocks<4>(en, xe);
+    store_row<2>(a.e_out, row, DE, en);
+    Bf3 xe[4];
+    split_blocks<2>(en, xe);
     // ---- create_future_msgs ----
-    layer<S, 3, true, false, true>(ring, more, st, xe, fi);
+    layer<S, 3, true, false, true>(ring, more, xe, fi);
     STAMP(5);
-    store_row<12>(a.sF1, row, MH, fi);
+    store_row<6>(a.sF1, row, MH, fi);
     {
-      Blk mo[8];
-      Bf3 x4[6];
-      split_blocks<12>(fi, x4);
-      layer<S, 4, false, true, false>(ring, more, st, x4, mo);
+      Blk mo[4];
+      Bf3 x4[12];
+      split_blocks<6>(fi, x4);
+      layer<S, 4, false, true, false>(ring, more, x4, mo);
       STAMP(6);
-      store_row<8>(a.fut, row, DM, mo);
+      store_row<4>(a.fut, row, DM, mo);
     }
     // ---- create_past_msgs ----
-    layer<S, 5, true, false, true>(ring, more, st, xe, pi);
+    layer<S, 5, true, false, true>(ring, more, xe, pi);
     STAMP(7);
-    store_row<12>(a.sP1, row, MH, pi);
+    store_row<6>(a.sP1, row, MH, pi);
     {
-      Blk mo[8];
-      Bf3 x6[6];
-      split_blocks<12>(pi, x6);
-      layer<S, 6, false, true, false>(ring, more, st, x6, mo);
+      Blk mo[4];
+      Bf3 x6[12];
+      split_blocks<6>(pi, x6);
+      layer<S, 6, false, true, false>(ring, more, x6, mo);
       STAMP(8);
-      store_row<8>(a.past, row, DM, mo);
+      store_row<4>(a.past, row, DM, mo);
       STAMP(9);
     }
   }
 }
-
 
 // ---- host ---------------------------------------------------------------------------------------------------------------
 struct HostLayer { int K, N; std::vector<float> w, b; bool has_bias; };
@@ -461,24 +412,23 @@ static void split3(float x, unsigned short (&p)[3]) {
   unsigned lb; memcpy(&lb, &r2, 4);
   p[0] = (unsigned short)(xb >> 16); p[1] = (unsigned short)(mb >> 16); p[2] = (unsigned short)(lb >> 16);
 }
-// steps of a layer in execution order: for p (pair of 16-row output blocks): for c: block 2 p pieces 0, 1, 2, block 2 p + 1 pieces 0, 1, 2
+// steps of a layer in execution order: for ob: for ks: pieces 0, 1, 2, each 64 lanes x 8 bf16
 static void pack_layer(unsigned short* img, const HostLayer& L) {
-  const int KS = L.K / 32, PN = L.N / 32;
-  for (int pr = 0; pr < PN; ++pr)
-    for (int c = 0; c < KS; ++c)
-      for (int half = 0; half < 2; ++half) {
-        const int ob = 2 * pr + half;
-        unsigned short* stp = img + ((size_t)(pr * KS + c) * kStepBytes + (size_t)half * 3072) / 2;
-        for (int lane = 0; lane < 64; ++lane) {
-          const int m = lane & 15, q = lane >> 4;
-          for (int j = 0; j < 8; ++j) {
-            const int col = 32 * c + 16 * (j >> 2) + 4 * q + (j & 3);
-            unsigned short p[3];
-            split3(L.w[(size_t)(16 * ob + m) * L.K + col], p);
-            for (int pc = 0; pc < 3; ++pc) stp[(size_t)pc * 512 + lane * 8 + j] = p[pc];
-          }
+  const int KS = L.K / 16, OBN = L.N / 32;
+  for (int ob = 0; ob < OBN; ++ob)
+    for (int ks = 0; ks < KS; ++ks) {
+      unsigned short* stp = img + ((size_t)(ob * KS + ks) * kStepBytes) / 2;
+      const int ib = ks / 2, s = ks % 2;
+      for (int lane = 0; lane < 64; ++lane) {
+        const int r = lane & 31, h = lane >> 5;
+        for (int j = 0; j < 8; ++j) {
+          const int col = 32 * ib + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3);
+          unsigned short p[3];
+          split3(L.w[(size_t)(32 * ob + r) * L.K + col], p);
+          for (int pc = 0; pc < 3; ++pc) stp[(size_t)pc * 512 + lane * 8 + j] = p[pc];
         }
       }
+    }
 }
 
 int main(int argc, char** argv) {
@@ -521,10 +471,9 @@ int main(int argc, char** argv) {
   a.sF1 = (float*)dev(nullptr, EP * MH * 4); a.sP1 = (float*)dev(nullptr, EP * MH * 4);
   a.wpack = dev(img.data(), img.size() * 2);
   a.stamps = (long long*)dev(nullptr, (size_t)4096 * 16 * 8);
-  CHECK(hipMemset(a.stamps, 0, (size_t)4096 * 16 * 8));
   const int lds = kLdsBytes;
   CHECK(hipFuncSetAttribute((const void*)edge_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  const int ntiles = (E + kWaves * 16 - 1) / (kWaves * 16);
+  const int ntiles = (E + 127) / 128;
   const int grid = ntiles;
   hipLaunchKernelGGL(edge_fwd_kernel, dim3(grid), dim3(kWaves * 64), lds, 0, a);
   CHECK(hipDeviceSynchronize());
@@ -589,22 +538,6 @@ int main(int argc, char** argv) {
   const double us = 1e3 * ms / reps;
   const double flops = 2.0 * 147456.0 * E;
   printf("E = %d, %d workgroups: %.2f us per launch, %.1f TFLOP/s fp32-equivalent (%.3f of 416.7)\n", E, grid, us, flops / us * 1e-6, flops / us * 1e-6 / 416.7);
-#ifdef STEP_STAMPS
-  {
-    std::vector<long long> ws(1024);
-    CHECK(hipMemcpy(ws.data(), a.stamps + 4096 * 8, ws.size() * 8, hipMemcpyDeviceToHost));
-    printf("workgroup 7, wavefronts 0 and 4: per step: cycles from the step's start to its first MFMA | to the next step's start\n");
-    for (int w = 0; w < 2; ++w) {
-      printf(" wavefront %d (t0 %lld)\n", 4 * w, ws[w * 512] - ws[0]);
-      for (int stp = 0; stp + 1 < FwdSeq::NSTEPS; ++stp) {
-        if (stp % 4 == 0) printf("  chunk %2d:", stp / 4);
-        printf("  %5lld|%5lld", ws[w * 512 + 2 * stp + 1] - ws[w * 512 + 2 * stp], ws[w * 512 + 2 * stp + 2] - ws[w * 512 + 2 * stp]);
-        if (stp % 4 == 3) printf("\n");
-      }
-      printf("\n");
-    }
-  }
-#endif
 #ifdef STAMPS
   {
     std::vector<long long> st((size_t)grid * 16);
