@@ -10,6 +10,7 @@
 #include <vector>
 #include "b3d_hoist.hpp"
 #include "b3d_att.hpp"
+#include "b3d_edge2.hpp"
 
 namespace b3d {
 namespace clr {
@@ -37,6 +38,14 @@ static bool hoist_enabled() {
   static const bool on = [] { const char* e = getenv("B3D_CLR_HOIST"); return e ? atoi(e) != 0 : true; }();
   return on;
 }
+// Fragment-streamed edge kernels (b3d_edge2.hpp, round 3).  B3D_EDGE2=0 selects round 2's kernels (A/B aid).
+static bool edge2_enabled() {
+  static const bool on = [] { const char* e = getenv("B3D_EDGE2"); return e ? atoi(e) != 0 : true; }();
+  return on && hoist_enabled();
+}
+using ES = es::EdgeSeqs<DB>;
+// rows of every per-edge workspace buffer: the fragment-streamed kernels store whole 64-row tiles
+static size_t edge_rows(int E) { return ((size_t)(E > 0 ? E : 1) + 63) / 64 * 64; }
 constexpr int XS = 288;                                                  // x_sens / s width (96 + 128 + 64)
 using SeqEE = LayerSeq<L<16, 16>, L<16, 32>, L<32, 64>>;                 // 4-16-32-64          :35-41
 using SeqNE = LayerSeq<L<32, 48>, L<48, 96>>;                            // 19-48-96            :43-47
@@ -99,6 +108,8 @@ struct Ws {
   // hoisted first layers
   bool hoist;
   float *wp_proj0, *wp_nfwd_h, *wp_efwd_h, *wp_ebwd_h, *wp_ebwd_nm_h, *wp_gproj, *wp_nbwd_h;
+  float *wp_efwd2, *wp_ebwd2, *wp_ebwd_nm2;       // fragment-stream images (b3d_estream.hpp)
+  bool edge2;
   float *T, *T0, *dT, *gx;
   float *wp_attU, *wp_att0, *wp_attDs, *wp_at0eT, *U, *dU, *ds, *de0;     // att_edge_encoder.0 hoisted
   float *wp_clsT, *wp_eeT, *wp_neT, *wp_flT, *wp_frT, *wp_affT[3], *wp_atT[5], *wp_ebwd, *wp_ebwd_nm, *wp_nbwd;
@@ -134,7 +145,7 @@ static bool is_streamed(int lin, bool hoist) { return lin >= AT0 || (hoist && is
 static void carve(Ws& w, void* ws, size_t ws_bytes, int N, int E, int nl, int nr, int depth, uint32_t flags) {
   Carver c(ws, ws_bytes);
   const bool tr = flags & B3D_FLAG_TRAINING;
-  const size_t e_ = (size_t)(E > 0 ? E : 1), n_ = (size_t)(N > 0 ? N : 1);
+  const size_t e_ = edge_rows(E), n_ = (size_t)(N > 0 ? N : 1);
   const size_t l_ = (size_t)(nl > 0 ? nl : 1), r_ = (size_t)(nr > 0 ? nr : 1);
   memset(&w, 0, sizeof(w));
   w.wp_ee = c.take<float>(SeqEE::TOTAL_FLOATS);
@@ -153,10 +164,12 @@ static void carve(Ws& w, void* ws, size_t ws_bytes, int N, int E, int nl, int nr
   w.wp_efwd = c.take<float>(D::EdgeFwdSeq::TOTAL_FLOATS);
   w.wp_nfwd = c.take<float>(D::NodeFwdSeq::TOTAL_FLOATS);
   w.hoist = hoist_enabled();
+  w.edge2 = edge2_enabled();
   if (w.hoist) {
     w.wp_proj0 = c.take<float>(Proj0Seq2<DB>::TOTAL_FLOATS);
     w.wp_nfwd_h = c.take<float>(NodeFwdHSeq<DB>::TOTAL_FLOATS);
     w.wp_efwd_h = c.take<float>(HC::EdgeFwdSeq::TOTAL_FLOATS);
+    w.wp_efwd2 = c.take<float>(ES::Fwd::TOTAL_FLOATS);
     w.T = c.take<float>(n_ * HC::TW);
     w.T0 = c.take<float>(n_ * 2 * DB::MH);
     w.wp_attU = c.take<float>(SeqAttU::TOTAL_FLOATS);
@@ -195,6 +208,8 @@ static void carve(Ws& w, void* ws, size_t ws_bytes, int N, int E, int nl, int nr
     if (w.hoist) {
       w.wp_ebwd_h = c.take<float>(HC::EdgeBwdSeq::TOTAL_FLOATS);
       w.wp_ebwd_nm_h = c.take<float>(HC::EdgeBwdSeqNoMsg::TOTAL_FLOATS);
+      w.wp_ebwd2 = c.take<float>(ES::Bwd::TOTAL_FLOATS);
+      w.wp_ebwd_nm2 = c.take<float>(ES::BwdNoMsg::TOTAL_FLOATS);
       w.wp_nbwd_h = c.take<float>(NodeBwdHSeq<DB>::TOTAL_FLOATS);
       w.wp_gproj = c.take<float>(HC::GradProjSeq::TOTAL_FLOATS);
       w.wp_attDs = c.take<float>(SeqAttDs::TOTAL_FLOATS);
@@ -449,7 +464,37 @@ static int pack_all(const b3d_clr_weights* pw, Ws& w, bool training, bool knn, h
     }
   }
   if (n > 224) return fail(B3D_ERR_ARG, "pack descriptor table overflow");
-  return pack_images(d, n, stream);
+  B3D_TRY(pack_images(d, n, stream));
+  if (w.edge2) {
+    constexpr int DX = DB::DX, EIN = DB::EIN, MIN = DB::MIN;
+    const LinPtrs &eu0 = L[EU0], &fu0 = L[FU0], &pa0 = L[PA0];
+    FragDesc f[kFragMax];
+    int m = 0;
+    using FS = ES::Fwd;
+    f[m++] = frag_desc<FS>(0, w.wp_efwd2, eu0.w + 2 * DX, nullptr, EIN, false);        // e | att columns (bias: in the table T)
+    f[m++] = frag_desc<FS>(1, w.wp_efwd2, L[EU1].w, L[EU1].b, kDims[EU1].K, false);
+    f[m++] = frag_desc<FS>(2, w.wp_efwd2, L[EU2].w, L[EU2].b, kDims[EU2].K, false);
+    f[m++] = frag_desc<FS>(3, w.wp_efwd2, fu0.w + DX, nullptr, MIN, false);             // e' columns
+    f[m++] = frag_desc<FS>(4, w.wp_efwd2, L[FU1].w, L[FU1].b, kDims[FU1].K, false);
+    f[m++] = frag_desc<FS>(5, w.wp_efwd2, pa0.w + DX, nullptr, MIN, false);
+    f[m++] = frag_desc<FS>(6, w.wp_efwd2, L[PA1].w, L[PA1].b, kDims[PA1].K, false);
+    if (training) {
+      using BS = ES::Bwd;
+      f[m++] = frag_desc<BS>(0, w.wp_ebwd2, L[PA1].w, nullptr, kDims[PA1].K, true);
+      f[m++] = frag_desc<BS>(1, w.wp_ebwd2, pa0.w + DX, nullptr, MIN, true);
+      f[m++] = frag_desc<BS>(2, w.wp_ebwd2, L[FU1].w, nullptr, kDims[FU1].K, true);
+      f[m++] = frag_desc<BS>(3, w.wp_ebwd2, fu0.w + DX, nullptr, MIN, true);
+      f[m++] = frag_desc<BS>(4, w.wp_ebwd2, L[EU2].w, nullptr, kDims[EU2].K, true);
+      f[m++] = frag_desc<BS>(5, w.wp_ebwd2, L[EU1].w, nullptr, kDims[EU1].K, true);
+      f[m++] = frag_desc<BS>(6, w.wp_ebwd2, eu0.w + 2 * DX, nullptr, EIN, true);
+      using NS = ES::BwdNoMsg;
+      f[m++] = frag_desc<NS>(0, w.wp_ebwd_nm2, L[EU2].w, nullptr, kDims[EU2].K, true);
+      f[m++] = frag_desc<NS>(1, w.wp_ebwd_nm2, L[EU1].w, nullptr, kDims[EU1].K, true);
+      f[m++] = frag_desc<NS>(2, w.wp_ebwd_nm2, eu0.w + 2 * DX, nullptr, EIN, true);
+    }
+    B3D_TRY(pack_frags(f, m, stream));
+  }
+  return B3D_OK;
 }
 
 template <class Seq, bool RELU, bool BIAS, class In>
@@ -662,6 +707,11 @@ extern "C" int b3d_clr_forward(const b3d_clr_weights* pw, const b3d_graph* g, co
       ea.E = E; ea.src = g->src; ea.dst = g->dst; ea.T = w.T; ea.e_in = w.e[l]; ea.a_in = w.att;
       ea.e_out = w.e[l + 1]; ea.fut = w.fut; ea.past = w.past;
       ea.sH1 = w.sH1[l]; ea.sH2 = w.sH2[l]; ea.sF1 = w.sF1[l]; ea.sP1 = w.sP1[l]; ea.wpack = w.wp_efwd_h;
+      if (w.edge2) {
+        ea.wpack = w.wp_efwd2;
+        if (tr) B3D_TRY(launch_rows<es::kWaves>(es::edge_fwd_kernel<DB, true>, "edge_fwd", ea, E, stream, B3D_K_EDGE_FWD, ES::Fwd::LDS_BYTES));
+        else B3D_TRY(launch_rows<es::kWaves>(es::edge_fwd_kernel<DB, false>, "edge_fwd", ea, E, stream, B3D_K_EDGE_FWD, ES::Fwd::LDS_BYTES));
+      } else
       B3D_TRY(launch_rows<kNWEdge>(mp_edge_fwd_h_kernel<DB, kNWEdge>, "mp_edge_fwd", ea, E, stream, B3D_K_EDGE_FWD, stream_lds_bytes<HC::EdgeFwdSeq>()));
       if (l + 1 < depth) {                                   // + the per-node table the next layer's edge phase gathers
         na.wpack = w.wp_nfwd_h; na.T = w.T; na.T0 = w.T0;
@@ -707,7 +757,8 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
   if (!w.ok) return fail(B3D_ERR_WORKSPACE, "b3d_clr_backward: workspace %zu < %zu bytes", workspace_bytes, w.bytes);
   const int* src = g->src;
   const int* dst = g->dst;
-  const size_t eL1 = (size_t)E * D::EH1, eL2 = (size_t)E * D::EH2, eLe = (size_t)E * D::DE, eLm = (size_t)E * D::MH;
+  const size_t EP = edge_rows(E);           // per-edge buffers are padded to whole 64-row tiles (carve)
+  const size_t eL1 = EP * D::EH1, eL2 = EP * D::EH2, eLe = EP * D::DE, eLm = EP * D::MH;
   const size_t nLm = (size_t)N * D::NIN, nLx = (size_t)N * D::DX, nL1 = (size_t)N * D::NH1, nL2 = (size_t)N * D::NH2;
   WgArgs smallE, smallN, fc;       // LDS-staged weight gradients of the narrow / unaligned layers
   smallE.njobs = smallN.njobs = fc.njobs = 0;
@@ -784,7 +835,13 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
       eb.da_acc = w.da_acc; eb.da_first = da_first ? 1 : 0;
       eb.GdH1 = w.GdH1 + l * eL1; eb.GdH2 = w.GdH2 + l * eL2; eb.Gde = w.Gde + l * eLe;
       eb.GdF1 = w.GdF1 + l * eLm; eb.GdP1 = w.GdP1 + l * eLm;
-      if (msgs) {
+      if (w.edge2 && msgs) {
+        eb.wpack = w.wp_ebwd2;
+        B3D_TRY(launch_rows<es::kWaves>(es::edge_bwd_kernel<DB, true>, "edge_bwd", eb, E, stream, B3D_K_EDGE_BWD, ES::Bwd::LDS_BYTES));
+      } else if (w.edge2) {
+        eb.wpack = w.wp_ebwd_nm2;
+        B3D_TRY(launch_rows<es::kWaves>(es::edge_bwd_kernel<DB, false>, "edge_bwd_last", eb, E, stream, B3D_K_EDGE_BWD, ES::BwdNoMsg::LDS_BYTES));
+      } else if (msgs) {
         eb.wpack = w.wp_ebwd_h;
         B3D_TRY(launch_rows<kNWEdge>(mp_edge_bwd_h_kernel<DB, true, kNWEdge>, "mp_edge_bwd", eb, E, stream, B3D_K_EDGE_BWD, stream_lds_bytes<HC::EdgeBwdSeq>()));
       } else {

@@ -1,0 +1,255 @@
+// Edge phase of a CausalMessagePassing layer at the camera+LiDAR+radar widths, hoisted form (b3d_hoist.hpp), on the
+// fragment stream of b3d_estream.hpp: forward (clr_att_gnn.py:302-334 without the node columns of the three first layers,
+// which arrive as gathered rows of the per-node table T) and its data gradient.  Same arguments, same results (up to fp32
+// summation order inside a Linear: 32-wide k groups instead of whole rows) as mp_edge_fwd_h_kernel / mp_edge_bwd_h_kernel,
+// which remain the kernels of the poses-only model (its weights are resident in LDS).
+//
+// Every per-edge buffer these kernels touch must hold round_up(E, 64) rows: rows past the end are computed on the last
+// edge and STORED (into the padding), so that the number of vector-memory instructions between two rendezvous is a
+// compile-time constant (b3d_estream.hpp, Ring).
+#pragma once
+#include "b3d_estream.hpp"
+#include "b3d_hoist.hpp"
+
+namespace b3d {
+namespace es {
+
+template <class D>
+struct EdgeSeqs {
+  using H = Hoist<D>;
+  static constexpr int KE = H::KE;
+  using Fwd = Seq<LY<KE, D::EH1>, LY<D::EH1, D::EH2>, LY<D::EH2, D::DE>,        // edge_update (.0: e | att columns)
+                  LY<D::DE, D::MH>, LY<D::MH, D::DM>,                             // create_future_msgs (.0: e' columns)
+                  LY<D::DE, D::MH>, LY<D::MH, D::DM>>;                            // create_past_msgs
+  // transposed, data-gradient order
+  using Bwd = Seq<LY<D::DM, D::MH>, LY<D::MH, D::DE>,                            // past.2^T, past.0[e']^T
+                  LY<D::DM, D::MH>, LY<D::MH, D::DE>,                            // future.2^T, future.0[e']^T
+                  LY<D::DE, D::EH2>, LY<D::EH2, D::EH1>, LY<D::EH1, KE>>;        // edge_update.4^T / .2^T / .0[e | att]^T
+  using BwdNoMsg = Seq<LY<D::DE, D::EH2>, LY<D::EH2, D::EH1>, LY<D::EH1, KE>>;
+};
+
+// ---- forward -----------------------------------------------------------------------------------------------------------------
+// loads / stores in front of the first chunk of layers 1 .. 6, per wavefront (16 rows: one 16-byte access per 16-feature block)
+template <class D, bool TRAIN>
+struct FwdHooks {
+  using S = typename EdgeSeqs<D>::Fwd;
+  __host__ __device__ static constexpr int before(int ci) {
+    constexpr int H1B = D::EH1 / 16, H2B = D::EH2 / 16, EB = D::DE / 16, MHB = D::MH / 16, DMB = D::DM / 16, SV = TRAIN ? 1 : 0;
+    return ci == S::first_chunk(1) ? SV * H1B + MHB          // sH1 store, T[dst] future rows
+         : ci == S::first_chunk(2) ? SV * H2B + MHB          // sH2 store, T[src] past rows
+         : ci == S::first_chunk(3) ? EB                      // e' store
+         : ci == S::first_chunk(4) ? SV * MHB                // sF1 store
+         : ci == S::first_chunk(5) ? DMB                     // fut store
+         : ci == S::first_chunk(6) ? SV * MHB : 0;           // sP1 store
+  }
+};
+
+template <class D, bool TRAIN>
+__global__ __launch_bounds__(kWaves * 64, 2) void edge_fwd_kernel(const EdgeFwdHArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char es_smem[];
+  using H = Hoist<D>;
+  using S = typename EdgeSeqs<D>::Fwd;
+  static_assert(D::DA > 0, "camera+LiDAR+radar widths (e | att columns)");
+  constexpr int EB = D::DE / 16, AB = D::DA / 16, H1B = D::EH1 / 16, H2B = D::EH2 / 16, MHB = D::MH / 16, DMB = D::DM / 16;
+  Ring<S, FwdHooks<D, TRAIN>> ring;
+  ring.init(a.wpack, es_smem);
+  ring.start();
+  const int lane = threadIdx.x & 63;
+  const int ntiles = (a.E + kTileRows - 1) / kTileRows;
+  StepState st;
+  st.base = ring.template slot_addr<0>();
+  frag_load2(st.base + lane * 16, st.cur0, st.cur1);       // chunk 0 is complete (Ring::start)
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const bool more = tile + (int)gridDim.x < ntiles;
+    const unsigned row = (unsigned)tile * (unsigned)kTileRows + ring.wave * 16 + (lane & 15);
+    const unsigned rc = row < (unsigned)a.E ? row : (unsigned)a.E - 1u;         // rows past the end compute on the last edge
+    const unsigned s = (unsigned)a.src[rc], d = (unsigned)a.dst[rc];
+    v4f ein[EB + AB];
+    {
+      v4f e0[EB], a0[AB];
+      load_row<EB>(a.e_in, rc, D::DE, 0, e0);
+      load_row<AB>(a.a_in, rc, D::DA, 0, a0);
+#pragma unroll
+      for (int b = 0; b < EB; ++b) ein[b] = e0[b];
+#pragma unroll
+      for (int b = 0; b < AB; ++b) ein[EB + b] = a0[b];
+    }
+    v4f h1[H1B];
+    {
+      v4f tb[H1B];
+      load_row<H1B>(a.T, d, H::TW, H::OA, h1);
+      load_row<H1B>(a.T, s, H::TW, H::OB, tb);
+#pragma unroll
+      for (int b = 0; b < H1B; ++b) h1[b] += tb[b];
+    }
+    // ---- edge_update ----
+    {
+      Bf3 x0[(EB + AB) / 2];
+      split_blocks<EB + AB>(ein, x0);
+      layer<S, 0, true, false, true>(ring, more, st, x0, h1);
+    }
+    if constexpr (TRAIN) store_row<H1B>(a.sH1, row, D::EH1, h1);
+    v4f fi[MHB];
+    load_row<MHB>(a.T, d, H::TW, H::OF, fi);
+    v4f h2[H2B];
+    {
+      Bf3 x1[H1B / 2];
+      split_blocks<H1B>(h1, x1);
+      layer<S, 1, true, true, false>(ring, more, st, x1, h2);
+    }
+    if constexpr (TRAIN) store_row<H2B>(a.sH2, row, D::EH2, h2);
+    v4f pi[MHB];
+    load_row<MHB>(a.T, s, H::TW, H::OP, pi);
+    v4f en[EB];
+    {
+      Bf3 x2[H2B / 2];
+      split_blocks<H2B>(h2, x2);
+      layer<S, 2, false, true, false>(ring, more, st, x2, en);
+    }
+    store_row<EB>(a.e_out, row, D::DE, en);
+    Bf3 xe[EB / 2];
+    split_blocks<EB>(en, xe);
+    // ---- create_future_msgs ----
+    layer<S, 3, true, false, true>(ring, more, st, xe, fi);
+    if constexpr (TRAIN) store_row<MHB>(a.sF1, row, D::MH, fi);
+    {
+      v4f mo[DMB];
+      Bf3 x4[MHB / 2];
+      split_blocks<MHB>(fi, x4);
+      layer<S, 4, false, true, false>(ring, more, st, x4, mo);
+      store_row<DMB>(a.fut, row, D::DM, mo);
+    }
+    // ---- create_past_msgs ----
+    layer<S, 5, true, false, true>(ring, more, st, xe, pi);
+    if constexpr (TRAIN) store_row<MHB>(a.sP1, row, D::MH, pi);
+    {
+      v4f mo[DMB];
+      Bf3 x6[MHB / 2];
+      split_blocks<MHB>(pi, x6);
+      layer<S, 6, false, true, false>(ring, more, st, x6, mo);
+      store_row<DMB>(a.past, row, D::DM, mo);
+    }
+  }
+}
+
+// ---- backward ----------------------------------------------------------------------------------------------------------------
+template <class D, bool MSGS>
+struct BwdHooks {
+  using S = typename std::conditional<MSGS, typename EdgeSeqs<D>::Bwd, typename EdgeSeqs<D>::BwdNoMsg>::type;
+  __host__ __device__ static constexpr int before(int ci) {
+    constexpr int H1B = D::EH1 / 16, H2B = D::EH2 / 16, EB = D::DE / 16, AB = D::DA / 16, MHB = D::MH / 16;
+    if (MSGS)
+      return ci == S::first_chunk(1) ? MHB + MHB               // GdP1 store, sF1 load
+           : ci == S::first_chunk(3) ? MHB + H2B               // GdF1 store, sH2 load
+           : ci == S::first_chunk(4) ? EB + H1B                // Gde store, sH1 load
+           : ci == S::first_chunk(5) ? H2B                     // GdH2 store
+           : ci == S::first_chunk(6) ? H1B + AB : 0;           // GdH1 store, running d att load
+    return ci == S::first_chunk(1) ? H2B : ci == S::first_chunk(2) ? H1B + AB : 0;
+  }
+};
+
+// Data gradient of the edge phase without the node columns of the three first layers (those are contracted per node from
+// the segment sums of GdH1 / GdF1 / GdP1: node_listsum_kernel + node_bwd_g_kernel).
+template <class D, bool MSGS>
+__global__ __launch_bounds__(kWaves * 64, 2) void edge_bwd_kernel(const EdgeBwdHArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char es_smem[];
+  using S = typename BwdHooks<D, MSGS>::S;
+  static_assert(D::DA > 0, "camera+LiDAR+radar widths (e | att columns)");
+  constexpr int L0 = MSGS ? 4 : 0;
+  constexpr int EB = D::DE / 16, AB = D::DA / 16, H1B = D::EH1 / 16, H2B = D::EH2 / 16, MHB = D::MH / 16, DMB = D::DM / 16;
+  Ring<S, BwdHooks<D, MSGS>> ring;
+  ring.init(a.wpack, es_smem);
+  ring.start();
+  const int lane = threadIdx.x & 63;
+  const int ntiles = (a.E + kTileRows - 1) / kTileRows;
+  StepState st;
+  st.base = ring.template slot_addr<0>();
+  frag_load2(st.base + lane * 16, st.cur0, st.cur1);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const bool more = tile + (int)gridDim.x < ntiles;
+    const unsigned row = (unsigned)tile * (unsigned)kTileRows + ring.wave * 16 + (lane & 15);
+    const unsigned rc = row < (unsigned)a.E ? row : (unsigned)a.E - 1u;
+    v4f de[EB];
+    load_row<EB>(a.de_out, rc, D::DE, 0, de);
+    v4f act2[H2B], act1[H1B];
+    if constexpr (MSGS) {
+      const unsigned s = (unsigned)a.src[rc], d = (unsigned)a.dst[rc];
+      v4f dmp[DMB], dmf[DMB], actp[MHB], actf[MHB];
+      load_row<DMB>(a.dM, d, 2 * D::DM, 0, dmp);             // past messages were summed at dst
+      load_row<DMB>(a.dM, s, 2 * D::DM, D::DM, dmf);         // future messages were summed at src
+      load_row<MHB>(a.sP1, rc, D::MH, 0, actp);
+      v4f dh[MHB], dee[EB];
+      {
+        Bf3 x0[DMB / 2];
+        split_blocks<DMB>(dmp, x0);
+        layer<S, 0, false, false, false>(ring, more, st, x0, dh);
+      }
+      relu_bwd_blocks<MHB>(dh, actp);
+      store_row<MHB>(a.GdP1, row, D::MH, dh);
+      load_row<MHB>(a.sF1, rc, D::MH, 0, actf);
+      {
+        Bf3 x1[MHB / 2];
+        split_blocks<MHB>(dh, x1);
+        layer<S, 1, false, false, false>(ring, more, st, x1, dee);
+      }
+#pragma unroll
+      for (int b = 0; b < EB; ++b) de[b] += dee[b];
+      {
+        Bf3 x2[DMB / 2];
+        split_blocks<DMB>(dmf, x2);
+        layer<S, 2, false, false, false>(ring, more, st, x2, dh);
+      }
+      relu_bwd_blocks<MHB>(dh, actf);
+      store_row<MHB>(a.GdF1, row, D::MH, dh);
+      load_row<H2B>(a.sH2, rc, D::EH2, 0, act2);
+      {
+        Bf3 x3[MHB / 2];
+        split_blocks<MHB>(dh, x3);
+        layer<S, 3, false, false, false>(ring, more, st, x3, dee);
+      }
+#pragma unroll
+      for (int b = 0; b < EB; ++b) de[b] += dee[b];
+      store_row<EB>(a.Gde, row, D::DE, de);
+      load_row<H1B>(a.sH1, rc, D::EH1, 0, act1);
+    } else {
+      load_row<H2B>(a.sH2, rc, D::EH2, 0, act2);
+      load_row<H1B>(a.sH1, rc, D::EH1, 0, act1);
+      store_row<EB>(a.Gde, row, D::DE, de);
+    }
+    v4f d2[H2B], d1[H1B], dein[EB + AB];
+    {
+      Bf3 x4[EB / 2];
+      split_blocks<EB>(de, x4);
+      layer<S, L0 + 0, false, false, false>(ring, more, st, x4, d2);
+    }
+    relu_bwd_blocks<H2B>(d2, act2);
+    store_row<H2B>(a.GdH2, row, D::EH2, d2);
+    {
+      Bf3 x5[H2B / 2];
+      split_blocks<H2B>(d2, x5);
+      layer<S, L0 + 1, false, false, false>(ring, more, st, x5, d1);
+    }
+    relu_bwd_blocks<H1B>(d1, act1);
+    store_row<H1B>(a.GdH1, row, D::EH1, d1);
+    v4f prev[AB];
+    load_row<AB>(a.da_acc, rc, D::DA, 0, prev);
+    {
+      Bf3 x6[H1B / 2];
+      split_blocks<H1B>(d1, x6);
+      layer<S, L0 + 2, false, false, false>(ring, more, st, x6, dein);
+    }
+    {
+      v4f o[EB];
+#pragma unroll
+      for (int b = 0; b < EB; ++b) o[b] = dein[b];
+      store_row<EB>(a.de_in, row, D::DE, o);
+      v4f da[AB];
+#pragma unroll
+      for (int b = 0; b < AB; ++b) da[b] = a.da_first ? dein[EB + b] : dein[EB + b] + prev[b];   // (always loaded: a fixed number of loads)
+      store_row<AB>(a.da_acc, row, D::DA, da);
+    }
+  }
+}
+
+}  // namespace es
+}  // namespace b3d

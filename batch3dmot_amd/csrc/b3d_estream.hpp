@@ -1,0 +1,269 @@
+// Fragment-streamed MLP stacks on 16-row wave tiles (round 3): the edge kernels of the camera+LiDAR+radar model.
+//
+// What round 2's kernels (b3d_dev.hpp: 8 wavefronts per workgroup, weight rows in a two-slot LDS ring filled by the
+// LDS-DMA BUILTIN) lost their time on -- measured on MI355X with tools/micro/edge_stack*.hip, mfma_rate.hip, dma_probe.hip:
+//   * hipcc waits vmcnt(0) for every ordinary load (and every scratch reload) while an LDS-DMA it knows about is in
+//     flight: the spilled activations of a 256-register kernel were reloaded block by block behind a drain of the whole
+//     next weight group.  Here the DMA is issued from inline asm (hipcc does not see it) and waited for with COUNTED
+//     vmcnt immediates: the count of younger DMA pieces plus the loads / stores the kernel itself issued since (a static
+//     table per kernel); rows past the end are computed and stored too (buffers are padded), so those counts are exact.
+//   * one accumulator chain per wavefront: dependent v_mfma_f32_16x16x32_bf16 issue ~42 cycles apart, two wavefronts per
+//     SIMD then reach 21 cycles per MFMA; with two chains (two 16-row output blocks against the same inputs) 13.8.
+//   * a workgroup barrier per weight chunk between wavefronts that SHARE a SIMD: whichever the arbiter prefers (the
+//     older one) finishes its chunk first and the other completes alone at a single wavefront's rate (2,300 - 2,500
+//     cycles per chunk against 1,540 free-running; staggering, per-chunk flag words and priorities did not recover it).
+//     Here a workgroup is 4 wavefronts, ONE PER SIMD, and TWO workgroups share a CU (80 KB of LDS each): the wavefronts
+//     that meet at a barrier do not compete for a matrix pipe, the two that share one belong to different workgroups
+//     and drift freely.  The price is that every CU stages the weights twice (L2 -> LDS, 2 x 0.87 MB per 128 edges).
+//   * 64-bit row addresses (pairs of VGPRs per table, kept alive across the kernel): rows are addressed as uniform
+//     base + 32-bit byte offset (global_load / store saddr form).
+//   * row-major weight images with padded strides: the image is a sequence of 1 KB FRAGMENTS in execution order, each
+//     exactly what one ds_read_b128 of a wavefront (= one LDS-DMA piece) moves: no strides, no bank conflicts.
+// What bounds the kernels now: a 16-row tile needs one 1 KB LDS fragment per two MFMAs (bf16x6: three weight pieces per
+// six products), which holds two wavefronts per SIMD at ~19 cycles per MFMA (tools/micro/mfma_rate.hip: 21.4 for this
+// read rate); 32-row tiles would halve it but 31 k edges are only 121 rows per CU.
+#pragma once
+#include <utility>
+#include "b3d_dev.hpp"
+
+namespace b3d {
+namespace es {
+
+constexpr int kWaves = 4, kTileRows = kWaves * 16;          // 64 rows per workgroup, two workgroups per CU
+constexpr int kChunkSteps = 4, kStepBytes = 6144, kChunkBytes = kChunkSteps * kStepBytes, kSlots = 3;
+constexpr int kPiecesPerWave = kChunkBytes / 1024 / kWaves;  // 6
+
+// ---- weight stream geometry (host packer: b3d_prep.hip pack_frag_kernel) -------------------------------------------------
+// A layer with K inputs and N outputs is (N / 32) x (K / 32) steps; a step is TWO 16 x 32 blocks of W (output blocks 2 p and
+// 2 p + 1 against the same 32 inputs), each as three 1 KB fragments (bf16 pieces 0, 1, 2 of the exact split w = w0 + w1 + w2):
+// lane l = (m = l & 15, q = l >> 4) holds the 8 bf16 W[16 ob + m][32 c + 16 (j >> 2) + 4 q + (j & 3)], j = 0..7 -- the k order in
+// which a wavefront holds the previous layer's accumulator (b3d_dev.hpp bf_pos).  Steps are stored in execution order
+// (for p: for c); a chunk is kChunkSteps consecutive steps of the kernel's whole sequence.  The biases of all layers follow
+// the steps as fp32 (zeros for layers without one), padded to 4 KB.
+template <int K_, int N_>
+struct LY {
+  static constexpr int K = K_, N = N_, KS = K / 32, OB = N / 32, STEPS = KS * OB;
+  static_assert(K % 32 == 0 && N % 32 == 0, "layer widths in multiples of 32");
+};
+template <class... Ls>
+struct Seq {
+  static constexpr int NL = sizeof...(Ls);
+  __host__ __device__ static constexpr int k(int li) { constexpr int a[] = {Ls::K...}; return a[li]; }
+  __host__ __device__ static constexpr int n(int li) { constexpr int a[] = {Ls::N...}; return a[li]; }
+  __host__ __device__ static constexpr int steps(int li) { constexpr int a[] = {Ls::STEPS...}; return a[li]; }
+  __host__ __device__ static constexpr int first_step(int li) { int c = 0; for (int i = 0; i < li; ++i) c += steps(i); return c; }
+  __host__ __device__ static constexpr int bias_off(int li) { int c = 0; for (int i = 0; i < li; ++i) c += n(i); return c; }   // floats
+  static constexpr int NSTEPS = first_step(NL), NCH = NSTEPS / kChunkSteps, NBIAS = bias_off(NL);
+  static_assert(NSTEPS % kChunkSteps == 0 && NCH % kSlots == 0, "whole chunks; the slot of a chunk must not depend on the tile");
+  // chunk that holds the first step of layer li (hook tables)
+  __host__ __device__ static constexpr int first_chunk(int li) { return first_step(li) / kChunkSteps; }
+  static constexpr int WEIGHT_BYTES = NSTEPS * kStepBytes;
+  static constexpr int BIAS_BYTES = (NBIAS * 4 + 4095) / 4096 * 4096;
+  static constexpr int TOTAL_BYTES = WEIGHT_BYTES + BIAS_BYTES;
+  static constexpr int TOTAL_FLOATS = TOTAL_BYTES / 4;
+  static constexpr int LDS_BYTES = kSlots * kChunkBytes + BIAS_BYTES;
+  static_assert(BIAS_BYTES == 4096 || BIAS_BYTES == 8192, "bias DMA: one or two pieces per wavefront");
+  static_assert(LDS_BYTES <= 80 * 1024, "two workgroups per CU");
+};
+
+// ---- LDS-DMA from inline asm ---------------------------------------------------------------------------------------------
+// N pieces of 1 KB (64 lanes x 16 B), contiguous in global memory and in LDS.  The instruction offset advances the global AND
+// the LDS address (tools/micro/dma_probe.hip).  M0 carries the LDS byte address; it is compiler-reserved, so it is saved and
+// restored inside the statement (cdna_hip_programming.md 5.7).
+__device__ __forceinline__ void dma1(const void* gsrc, unsigned lds_dst, unsigned voff) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void dma2(const void* gsrc, unsigned lds_dst, unsigned voff) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// ---- the ring --------------------------------------------------------------------------------------------------------------
+// RENDEZVOUS.  One s_barrier in front of step 0 of every chunk C, with the meaning "every wavefront's pieces of chunk C + 1 have
+// landed (each waited for its own with a counted vmcnt in front of the barrier) and every wavefront is done with chunk C - 1":
+// chunk C + 1 is known to be complete a whole chunk before it is needed, so the fragments of its first step are fetched
+// during the last step of chunk C like any others -- no LDS latency is exposed behind the barrier -- and the slot of chunk
+// C - 1 is refilled with chunk C + 2, a share of the pieces in front of every step of chunk C.
+//
+// HK::before(c): ordinary vector-memory instructions (stores / loads that hipcc issues) in front of step 0 of chunk c, i.e.
+// between rendezvous<c - 1> and rendezvous<c>.  They are YOUNGER than the DMA pieces of chunk c + 1 (issued during chunk c - 1):
+// a wait that does not count them drains every store (measured: microseconds per layer boundary).  The counts must not
+// exceed what is really issued -- an over-count would let the wait return before the pieces have landed.
+template <class S, class HK>
+struct Ring {
+  const char* g;        // images: steps, then the biases
+  unsigned lds0;        // byte address of the ring in the LDS address space
+  int wave, lane;
+  bool first;           // rendezvous<0> of the first tile is Ring::start's barrier
+  __device__ __forceinline__ void init(const void* gw, const void* lds) {
+    g = (const char*)gw;
+    lds0 = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)lds;
+    wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    lane = threadIdx.x & 63;
+    first = true;
+  }
+  __device__ __forceinline__ unsigned bias_lds() const { return lds0 + kSlots * kChunkBytes; }
+  // the pieces [J0, J1) of this wavefront's share of chunk CI
+  template <int CI, int J0, int J1>
+  __device__ __forceinline__ void issue_pieces() {
+    constexpr int SLOT = CI % kSlots;
+    if constexpr (J1 > J0) {
+      const unsigned woff = (unsigned)wave * (kPiecesPerWave * 1024) + J0 * 1024;
+      if constexpr (J1 - J0 == 1) dma1(g + (size_t)CI * kChunkBytes, lds0 + SLOT * kChunkBytes + woff, woff + lane * 16);
+      else if constexpr (J1 - J0 == 2) dma2(g + (size_t)CI * kChunkBytes, lds0 + SLOT * kChunkBytes + woff, woff + lane * 16);
+      else { issue_pieces<CI, J0, J0 + 2>(); issue_pieces<CI, J0 + 2, J1>(); }
+    }
+  }
+  // Pieces of this wavefront younger than its pieces of chunk C + 1 when rendezvous<C> waits: none (chunk C + 2 is issued behind the
+  // barrier) -- only the ordinary loads / stores in front of chunk C.
+  template <int C>
+  static constexpr int pending() { const int p = HK::before(C); return p < 63 ? p : 63; }
+  // Stream start (once per kernel): the biases and chunks 0, 1 in flight, then complete for everybody.
+  __device__ __forceinline__ void start() {
+    if constexpr (S::BIAS_BYTES == 8192) {
+      const unsigned woff = (unsigned)wave * 2048;
+      dma2(g + S::WEIGHT_BYTES, bias_lds() + woff, woff + lane * 16);
+    } else {
+      const unsigned woff = (unsigned)wave * 1024;
+      dma1(g + S::WEIGHT_BYTES, bias_lds() + woff, woff + lane * 16);
+    }
+    issue_pieces<0, 0, kPiecesPerWave>();
+    issue_pieces<1, 0, kPiecesPerWave>();
+    wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+  }
+  template <int C>
+  __device__ __forceinline__ unsigned slot_addr() const { return lds0 + (C % kSlots) * kChunkBytes; }
+  template <int C>
+  __device__ __forceinline__ void rendezvous() {
+    if constexpr (C == 0) { if (first) { first = false; return; } }
+    wait_vm<pending<C>()>();
+    __builtin_amdgcn_s_barrier();
+  }
+  // in front of step J of chunk C: this step's share of the pieces of chunk C + 2
+  template <int C, int J>
+  __device__ __forceinline__ void refill(bool more) {
+    constexpr int NXT = C + kSlots - 1, J0 = J * kPiecesPerWave / kChunkSteps, J1 = (J + 1) * kPiecesPerWave / kChunkSteps;
+    if constexpr (NXT < S::NCH) issue_pieces<NXT, J0, J1>();
+    else if (more) issue_pieces<NXT - S::NCH, J0, J1>();
+  }
+};
+
+// ---- steps ---------------------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) const u4v* lds_u4v_p;
+typedef __attribute__((address_space(3))) const v4f* lds_v4f_p;
+__device__ __forceinline__ Bf3 frag_load(unsigned addr) {          // addr: this lane's 16 bytes of piece 0 of a 16 x 32 block
+  Bf3 f;
+  f.p0 = __builtin_bit_cast(bf8, *(lds_u4v_p)(size_t)addr);
+  f.p1 = __builtin_bit_cast(bf8, *(lds_u4v_p)(size_t)(addr + 1024));
+  f.p2 = __builtin_bit_cast(bf8, *(lds_u4v_p)(size_t)(addr + 2048));
+  return f;
+}
+__device__ __forceinline__ void frag_load2(unsigned addr, Bf3& f0, Bf3& f1) { f0 = frag_load(addr); f1 = frag_load(addr + 3072); }
+// two independent chains, interleaved; smallest terms first (as bf_mfma6)
+__device__ __forceinline__ void mfma12(const Bf3& w0, const Bf3& w1, const Bf3& x, v4f& a0, v4f& a1) {
+  a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0.p0, x.p2, a0, 0, 0, 0);
+  a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1.p0, x.p2, a1, 0, 0, 0);
+  a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0.p1, x.p1, a0, 0, 0, 0);
+  a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1.p1, x.p1, a1, 0, 0, 0);
+  a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0.p2, x.p0, a0, 0, 0, 0);
+  a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1.p2, x.p0, a1, 0, 0, 0);
+  a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0.p0, x.p1, a0, 0, 0, 0);
+  a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1.p0, x.p1, a1, 0, 0, 0);
+  a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0.p1, x.p0, a0, 0, 0, 0);
+  a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1.p1, x.p0, a1, 0, 0, 0);
+  a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0.p0, x.p0, a0, 0, 0, 0);
+  a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1.p0, x.p0, a1, 0, 0, 0);
+}
+
+// State of the step loop, carried across layers (everything else is compile-time).
+struct StepState {
+  unsigned base;     // LDS address of the current chunk
+  Bf3 cur0, cur1;    // fragments of the current step (output blocks 2 p, 2 p + 1)
+  v4f acc0, acc1;
+};
+
+// One step of layer LI: 32 inputs (group ks) against the output blocks 2 ob, 2 ob + 1.  io[b] holds the initial value (INIT) on
+// entry of a block and the activation on exit.
+template <class S, int LI, int ST, bool RELU, bool BIAS, bool INIT, class RingT>
+__device__ __forceinline__ void step(RingT& ring, bool more, StepState& st, const Bf3 (&x)[S::k(LI) / 32], v4f (&io)[S::n(LI) / 16]) {
+  constexpr int KS = S::k(LI) / 32;
+  constexpr int ob = ST / KS, ks = ST % KS;
+  constexpr int GST = S::first_step(LI) + ST;                    // step of the tile
+  constexpr int IN_CHUNK = GST % kChunkSteps, CJ = GST / kChunkSteps;
+  if constexpr (IN_CHUNK == 0) {
+    ring.template rendezvous<CJ>();
+    st.base = ring.template slot_addr<CJ>();       // (its first fragments were fetched during the previous step)
+  }
+  ring.template refill<CJ, IN_CHUNK>(more);
+  if constexpr (ks == 0) {
+    v4f a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (BIAS) {
+      const unsigned ba = ring.bias_lds() + (S::bias_off(LI) + 32 * ob + 4 * (ring.lane >> 4)) * 4;
+      a0 = *(lds_v4f_p)(size_t)ba;
+      a1 = *(lds_v4f_p)(size_t)(ba + 64);
+    }
+    if constexpr (INIT) { a0 += io[2 * ob]; a1 += io[2 * ob + 1]; }
+    st.acc0 = a0; st.acc1 = a1;
+  }
+  // the LDS reads of the NEXT step are issued in front of this step's twelve MFMAs (hipcc otherwise sinks them next to their use)
+  Bf3 n0 = st.cur0, n1 = st.cur1;
+  if constexpr (IN_CHUNK + 1 < kChunkSteps) frag_load2(st.base + (IN_CHUNK + 1) * kStepBytes + ring.lane * 16, n0, n1);
+  else if constexpr (CJ + 1 < S::NCH) frag_load2(ring.template slot_addr<CJ + 1>() + ring.lane * 16, n0, n1);
+  else { if (more) frag_load2(ring.template slot_addr<0>() + ring.lane * 16, n0, n1); }
+  __builtin_amdgcn_sched_barrier(0);
+  mfma12(st.cur0, st.cur1, x[ks], st.acc0, st.acc1);
+  __builtin_amdgcn_sched_barrier(0);
+  st.cur0 = n0; st.cur1 = n1;
+  if constexpr (ks == KS - 1) { io[2 * ob] = RELU ? relu4(st.acc0) : st.acc0; io[2 * ob + 1] = RELU ? relu4(st.acc1) : st.acc1; }
+}
+template <class S, int LI, bool RELU, bool BIAS, bool INIT, class RingT, int... ST>
+__device__ __forceinline__ void layer_impl(RingT& ring, bool more, const Bf3 (&x)[S::k(LI) / 32], v4f (&io)[S::n(LI) / 16],
+                                           StepState& st, std::integer_sequence<int, ST...>) {
+  (step<S, LI, ST, RELU, BIAS, INIT>(ring, more, st, x, io), ...);
+}
+// io = act(W . x (+ b) (+ io))
+template <class S, int LI, bool RELU, bool BIAS, bool INIT, class RingT>
+__device__ __forceinline__ void layer(RingT& ring, bool more, StepState& st, const Bf3 (&x)[S::k(LI) / 32], v4f (&io)[S::n(LI) / 16]) {
+  layer_impl<S, LI, RELU, BIAS, INIT>(ring, more, x, io, st, std::make_integer_sequence<int, S::steps(LI)>{});
+}
+
+template <int NB>
+__device__ __forceinline__ void split_blocks(const v4f (&a)[NB], Bf3 (&x)[NB / 2]) {
+#pragma unroll
+  for (int c = 0; c < NB / 2; ++c) x[c] = bf_split(a[2 * c], a[2 * c + 1]);
+}
+// Row tables are addressed as (uniform base pointer) + (32-bit byte offset): one VGPR per row and table, and hipcc selects
+// the saddr form of global_load / global_store (no 64-bit address arithmetic, no address pairs to keep alive).  Unconditional.
+template <int NB>
+__device__ __forceinline__ void load_row(const float* __restrict__ base, unsigned row, int stride, int col0, v4f (&dst)[NB]) {
+  const unsigned q = (threadIdx.x & 63) >> 4;
+  const unsigned off = (row * (unsigned)stride + (unsigned)col0 + 4u * q) * 4u;
+#pragma unroll
+  for (int b = 0; b < NB; ++b) dst[b] = *reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(base) + off + 64u * b);
+}
+template <int NB>
+__device__ __forceinline__ void store_row(float* __restrict__ base, unsigned row, int stride, const v4f (&src)[NB]) {
+  const unsigned q = (threadIdx.x & 63) >> 4;
+  const unsigned off = (row * (unsigned)stride + 4u * q) * 4u;
+#pragma unroll
+  for (int b = 0; b < NB; ++b) *reinterpret_cast<v4f*>(reinterpret_cast<char*>(base) + off + 64u * b) = src[b];
+}
+template <int NB>
+__device__ __forceinline__ void relu_bwd_blocks(v4f (&g)[NB], const v4f (&act)[NB]) {
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    g[b].x = act[b].x > 0.f ? g[b].x : 0.f;
+    g[b].y = act[b].y > 0.f ? g[b].y : 0.f;
+    g[b].z = act[b].z > 0.f ? g[b].z : 0.f;
+    g[b].w = act[b].w > 0.f ? g[b].w : 0.f;
+  }
+}
+
+}  // namespace es
+}  // namespace b3d

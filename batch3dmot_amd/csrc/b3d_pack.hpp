@@ -68,6 +68,27 @@ inline PackDesc pack_block(int li, float* base, const float* w, int N, int K, in
   return d;
 }
 
+// Fragment-stream images (b3d_estream.hpp): one descriptor per layer of a sequence.
+struct FragDesc {
+  const float* w;      // element (n, k) of the layer = w[n * ld + k] (transposed: w[k * ld + n])
+  const float* b;      // bias [N] or nullptr
+  void* steps;         // first step of the layer inside the image
+  float* bias;         // the layer's slot in the image's bias table (always written: zeros without a bias)
+  int N, K, ld, transposed;
+};
+constexpr int kFragMax = 24;
+struct FragArgs { int n; FragDesc d[kFragMax]; };
+int pack_frags(const FragDesc* descs, int n, hipStream_t stream);
+template <class S>
+inline FragDesc frag_desc(int li, float* image, const float* w, const float* b, int ld, bool transposed) {
+  FragDesc d;
+  d.w = w; d.b = b;
+  d.steps = reinterpret_cast<char*>(image) + (size_t)S::first_step(li) * 6144;
+  d.bias = reinterpret_cast<float*>(reinterpret_cast<char*>(image) + S::WEIGHT_BYTES) + S::bias_off(li);
+  d.N = S::n(li); d.K = S::k(li); d.ld = ld; d.transposed = transposed ? 1 : 0;
+  return d;
+}
+
 inline PackDesc fill_desc(void* dst, int count, bool iota) {
   PackDesc d;
   d.w = nullptr; d.b = nullptr; d.dst = (float*)dst;

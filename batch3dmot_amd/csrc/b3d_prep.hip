@@ -250,6 +250,52 @@ __global__ void pack_kernel(const PackArgs a) {
   }
 }
 
+// Fragment-stream image of one layer (b3d_estream.hpp): steps in execution order (for p: for c), a step = the output blocks
+// 2 p and 2 p + 1 against the inputs [32 c, 32 c + 32), each block three 1 KB fragments (bf16 pieces 0, 1, 2), a fragment = 64
+// lanes x 8 bf16: lane (m = l & 15, q = l >> 4), element j <-> W[16 ob + m][32 c + 16 (j >> 2) + 4 q + (j & 3)].
+// One thread per pair of adjacent elements (one dword in each of the three pieces).
+__global__ __launch_bounds__(256) void pack_frag_kernel(const FragArgs a) {
+  const FragDesc& d = a.d[blockIdx.y];
+  const int KS = d.K / 32;
+  const int total = d.N * d.K / 2;
+  unsigned* dst = reinterpret_cast<unsigned*>(d.steps);
+  for (int t = blockIdx.x * 256 + threadIdx.x; t < total; t += gridDim.x * 256) {
+    const int step = t >> 9, r = t & 511;
+    const int half = r >> 8, lane = (r & 255) >> 2, jp = r & 3;
+    const int p = step / KS, c = step - p * KS;
+    const int row = 32 * p + 16 * half + (lane & 15);
+    unsigned pc[3] = {0u, 0u, 0u};
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int j = 2 * jp + e;
+      const int col = 32 * c + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3);
+      const float x = d.transposed ? d.w[(size_t)col * d.ld + row] : d.w[(size_t)row * d.ld + col];
+      const unsigned xb = __float_as_uint(x);
+      const float r1 = x - __uint_as_float(xb & 0xffff0000u);
+      const unsigned mb = __float_as_uint(r1);
+      const float r2 = r1 - __uint_as_float(mb & 0xffff0000u);
+      pc[0] |= (xb >> 16) << (16 * e);
+      pc[1] |= (mb >> 16) << (16 * e);
+      pc[2] |= (__float_as_uint(r2) >> 16) << (16 * e);
+    }
+    const size_t o = (size_t)step * 1536 + half * 768 + lane * 4 + jp;     // dwords
+#pragma unroll
+    for (int q = 0; q < 3; ++q) dst[o + q * 256] = pc[q];
+  }
+  if (blockIdx.x == 0)
+    for (int n = threadIdx.x; n < d.N; n += 256) d.bias[n] = d.b ? d.b[n] : 0.f;
+}
+
+int pack_frags(const FragDesc* descs, int n, hipStream_t stream) {
+  if (n > kFragMax) return fail(B3D_ERR_ARG, "fragment pack table overflow");
+  if (n == 0) return B3D_OK;
+  FragArgs a;
+  a.n = n;
+  for (int i = 0; i < n; ++i) a.d[i] = descs[i];
+  hipLaunchKernelGGL(pack_frag_kernel, dim3(32, n), dim3(256), 0, stream, a);
+  return launch_check("pack_frag_kernel");
+}
+
 int pack_images(const PackDesc* descs, int n, hipStream_t stream) {
   for (int i0 = 0; i0 < n; i0 += kPackMax) {
     PackArgs a;

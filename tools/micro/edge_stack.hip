@@ -208,7 +208,11 @@ struct Ring {
   // in front of step J of chunk C: this step's share of the pieces of chunk C + kSlots - 1
   template <int C, int J>
   __device__ __forceinline__ void refill(bool more) {
-    constexpr int NXT = C + kSlots - 1, J0 = J * kPiecesPerWave / kChunkSteps, J1 = (J + 1) * kPiecesPerWave / kChunkSteps;
+#ifndef ISSUE_STEPS
+#define ISSUE_STEPS kChunkSteps
+#endif
+    constexpr int IS = ISSUE_STEPS;      // the pieces go in front of the first IS steps of the chunk
+    constexpr int NXT = C + kSlots - 1, J0 = J < IS ? J * kPiecesPerWave / IS : kPiecesPerWave, J1 = J < IS ? (J + 1) * kPiecesPerWave / IS : kPiecesPerWave;
     if constexpr (NXT < S::NCH) issue_pieces<NXT, J0, J1>();
     else if (more) issue_pieces<NXT - S::NCH, J0, J1>();
   }
