@@ -139,7 +139,7 @@ struct BwdHooks {
   __host__ __device__ static constexpr int before(int ci) {
     constexpr int H1B = D::EH1 / 16, H2B = D::EH2 / 16, EB = D::DE / 16, AB = D::DA / 16, MHB = D::MH / 16;
     if (MSGS)
-      return ci == S::first_chunk(1) ? MHB + MHB               // GdP1 store, sF1 load
+      return ci == S::first_chunk(1) ? MHB + MHB + D::DM / 16  // GdP1 store, sF1 load, dM[src] load
            : ci == S::first_chunk(3) ? MHB + H2B               // GdF1 store, sH2 load
            : ci == S::first_chunk(4) ? EB + H1B                // Gde store, sH1 load
            : ci == S::first_chunk(5) ? H2B                     // GdH2 store
@@ -176,7 +176,6 @@ __global__ __launch_bounds__(kWaves * 64, 2) void edge_bwd_kernel(const EdgeBwdH
       const unsigned s = (unsigned)a.src[rc], d = (unsigned)a.dst[rc];
       v4f dmp[DMB], dmf[DMB], actp[MHB], actf[MHB];
       load_row<DMB>(a.dM, d, 2 * D::DM, 0, dmp);             // past messages were summed at dst
-      load_row<DMB>(a.dM, s, 2 * D::DM, D::DM, dmf);         // future messages were summed at src
       load_row<MHB>(a.sP1, rc, D::MH, 0, actp);
       v4f dh[MHB], dee[EB];
       {
@@ -187,6 +186,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void edge_bwd_kernel(const EdgeBwdH
       relu_bwd_blocks<MHB>(dh, actp);
       store_row<MHB>(a.GdP1, row, D::MH, dh);
       load_row<MHB>(a.sF1, rc, D::MH, 0, actf);
+      load_row<DMB>(a.dM, s, 2 * D::DM, D::DM, dmf);         // future messages were summed at src (needed a layer from here)
       {
         Bf3 x1[MHB / 2];
         split_blocks<MHB>(dh, x1);

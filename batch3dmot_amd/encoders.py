@@ -177,6 +177,99 @@ def point_feat_train_hip(convs, bns, x: torch.Tensor, trans=None, relu_last: boo
         return y
 
 
+class _FcWorkspace:
+    """Per-module scratch of the fc-head chain: the arrival counter in front of it must be zero on entry and every launch
+    leaves it zero, so it is zero-filled once, when the buffer is (re)allocated."""
+
+    def __init__(self):
+        self.buf = None
+
+    def get(self, nbytes, device):
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
+            self.buf = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+        return self.buf
+
+
+def _bn_struct(bn: nn.BatchNorm1d, train: bool, keep: list):
+    from . import _lib
+    s = _lib.b3d_batchnorm()
+    g, b = bn.weight.detach().float().contiguous(), bn.bias.detach().float().contiguous()
+    keep += [g, b]
+    s.gamma, s.beta = g.data_ptr(), b.data_ptr()
+    tracked = bn.track_running_stats and bn.running_mean is not None
+    if tracked:
+        _lib.require_cuda(bn.running_mean, "BatchNorm running statistic", torch.float32)
+        _lib.require_cuda(bn.running_var, "BatchNorm running statistic", torch.float32)
+        s.running_mean, s.running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+        s.num_batches_tracked = bn.num_batches_tracked.data_ptr() if train else None
+    elif not train:
+        raise ValueError("fc head: eval mode needs running statistics")
+    s.momentum = float(bn.momentum) if bn.momentum is not None else -1.0
+    s.eps = float(bn.eps)
+    return s
+
+
+def fc_head_hip(owner: nn.Module, x: torch.Tensor, stages, final_relu: bool = True):
+    """A chain of Linear (+ BatchNorm1d + ReLU) stages on [B, K] rows, one HIP launch per Linear (``b3d_fc_bn_forward``):
+    every launch applies the PREVIOUS stage's BatchNorm + ReLU while it reads its input, multiplies an optional Dropout
+    mask into its output and accumulates the batch statistics its own BatchNorm needs -- BatchNorm / ReLU / Dropout
+    never run as kernels of their own.  ``stages``: list of ``(fc, bn or None, dropout or None, add or None)``; a stage without ``bn``
+    must be the last one.  Train mode (``bn.training``): batch statistics, running statistics updated as torch does; the
+    Dropout mask is drawn by ONE torch call on a tensor of ones (the Philox stream stays torch's).  No autograd (frozen)."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    x = x.detach().float().contiguous()
+    _lib.require_cuda(x, "fc head input", torch.float32)
+    b = x.size(0)
+    dev = x.device
+    stream = _lib.current_stream(dev)
+    ws_owner = owner.__dict__.setdefault("_b3d_fc_ws", _FcWorkspace())
+    nmax = max(fc.out_features for fc, _, _, _ in stages)
+    nbytes = lib.b3d_fc_bn_workspace_bytes(b, nmax)
+    ws = ws_owner.get(nbytes, dev)
+    keep = []
+    in_scale = in_shift = None
+    cur = x
+    with torch.no_grad():
+        for i, (fc, bn, dropout, add) in enumerate(stages):
+            w = fc.weight.detach().float().contiguous()
+            bias = fc.bias.detach().float().contiguous() if fc.bias is not None else None
+            n, k = w.shape
+            if cur.size(1) != k:
+                raise ValueError(f"fc head: stage {i} expects {k} inputs, got {cur.size(1)}")
+            train = bool(bn.training) if bn is not None else False
+            mask = None
+            if dropout is not None and dropout.training and dropout.p > 0:
+                mask = F.dropout(torch.ones(b, n, dtype=torch.float32, device=dev), dropout.p, True)
+            y = torch.empty(b, n, dtype=torch.float32, device=dev)
+            sc = torch.empty(n, dtype=torch.float32, device=dev) if bn is not None else None
+            sh = torch.empty(n, dtype=torch.float32, device=dev) if bn is not None else None
+            bs = _bn_struct(bn, train, keep) if bn is not None else None
+            addv = add.detach().float().contiguous() if add is not None else None
+            _lib.check(lib.b3d_fc_bn_forward(cur.data_ptr(), b, k, w.data_ptr(), _lib.ptr(bias), n, _lib.ptr(in_scale), _lib.ptr(in_shift),
+                                             _lib.ptr(mask), _lib.ptr(addv), C.byref(bs) if bs is not None else None, int(train),
+                                             y.data_ptr(), _lib.ptr(sc), _lib.ptr(sh), ws.data_ptr(), ws.numel(), stream),
+                       "b3d_fc_bn_forward")
+            keep += [w, bias, mask, addv, cur, in_scale, in_shift]
+            cur, in_scale, in_shift = y, sc, sh
+        if in_scale is not None:                     # the last stage had a BatchNorm: materialise relu(bn(y))
+            if not final_relu:
+                raise ValueError("fc head: a trailing BatchNorm without ReLU is not a shape of these encoders")
+            out = torch.empty_like(cur)
+            _lib.check(lib.b3d_affine_relu(cur.data_ptr(), in_scale.data_ptr(), in_shift.data_ptr(), b, cur.size(1), out.data_ptr(), stream),
+                       "b3d_affine_relu")
+            cur = out
+    return cur
+
+
+def _use_hip_fc(module: nn.Module, x: torch.Tensor, bns) -> bool:
+    """HIP fc-head chain: GPU rows, no autograd (frozen or no_grad), and -- in train mode -- more than one row."""
+    if not (x.is_cuda and getattr(module, "use_hip", True) and x.size(0) > 0 and _no_autograd(module, x)):
+        return False
+    return not any(bn.training for bn in bns) or x.size(0) > 1
+
+
 def _use_hip(module: nn.Module, x: torch.Tensor) -> bool:
     return x.is_cuda and not module.training and getattr(module, "use_hip", True)
 
@@ -328,6 +421,10 @@ class _STN3d(nn.Module):
             x = F.relu(self.bn2(self.conv2(x)))
             x = F.relu(self.bn3(self.conv3(x)))
             x = torch.max(x, 2, keepdim=True)[0].view(-1, 1024)
+        if _use_hip_fc(self, x, (self.bn4, self.bn5)):
+            iden = torch.eye(3, dtype=torch.float32, device=x.device).view(9)
+            x = fc_head_hip(self, x, [(self.fc1, self.bn4, None, None), (self.fc2, self.bn5, None, None), (self.fc3, None, None, iden)])
+            return x.view(-1, 3, 3)
         x = F.relu(_fc_bn(self.fc1, self.bn4, x))
         x = F.relu(_fc_bn(self.fc2, self.bn5, x))
         x = self.fc3(x)
@@ -367,6 +464,8 @@ class PointNetClassifier(nn.Module):
 
     def forward_feat(self, x):
         x = self.feat(x)
+        if _use_hip_fc(self, x, (self.bn1, self.bn2)):
+            return fc_head_hip(self, x, [(self.fc1, self.bn1, None, None), (self.fc2, self.bn2, self.dropout, None)])
         x = F.relu(_fc_bn(self.fc1, self.bn1, x))
         if not _fold_on(self.bn2):
             return F.relu(self.bn2(self.dropout(self.fc2(x))))
@@ -400,6 +499,8 @@ class RadarNetClassifier(nn.Module):
 
     def forward_feat(self, x):
         x = self.feat(x)
+        if _use_hip_fc(self, x, (self.bn1, self.bn2)):
+            return fc_head_hip(self, x, [(self.fc1, self.bn1, None, None), (self.fc2, self.bn2, self.dropout, None)])
         x = F.relu(_fc_bn(self.fc1, self.bn1, x))
         if not _fold_on(self.bn2):
             return F.relu(self.bn2(self.dropout(self.fc2(x))))

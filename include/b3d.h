@@ -329,6 +329,25 @@ size_t b3d_resnet_encode_workspace_bytes(int32_t N);
 int b3d_resnet_encode(const b3d_linear* conv, const b3d_batchnorm* bn, const float* x, int32_t N, int32_t train,
                       void* workspace, size_t workspace_bytes, float* out, b3d_stream stream);
 
+/* Fully connected heads of the frozen point encoders (reference batch_3dmot/models/pointnet.py:46-48 STN3d fc1-bn4-relu, fc2-bn5-relu,
+ * fc3 + identity; pointnet.py:188-192 and radarnet.py:60-64 forward_feat: fc1-bn1-relu, fc2-dropout-bn2-relu), one launch per Linear:
+ *     y [B,N] = mask * ( relu(x * in_scale + in_shift) . w^T + bias ) + add
+ * x [B,K] (K a multiple of 4), w [N,K] row-major; in_scale / in_shift [K] (both or neither: the PRODUCER's BatchNorm affine, applied
+ * with its ReLU while x is read), mask [B,N] (Dropout: 0 or 1 / (1 - p), drawn by the caller so that the random stream stays the
+ * caller's), add [N] (STN3d's flattened identity); each may be NULL.  With `bn` the launch also produces THIS layer's BatchNorm
+ * affine out_scale / out_shift [N]: from the batch statistics of y in train mode (`train` != 0, B > 1; running statistics and
+ * num_batches_tracked updated as nn.BatchNorm1d does; summed in a fixed order, bitwise reproducible), from the running statistics
+ * in eval mode.  The first 256 bytes of the (256-byte aligned) workspace are an arrival counter that must be ZERO on entry; the
+ * launch leaves it zero (b3d_fc_ticket_init zeroes it for a fresh workspace).  b3d_affine_relu: out = relu(y * scale + shift),
+ * the last activation of a chain.  Exact fp32 (v_mfma_f32_16x16x4_f32). */
+size_t b3d_fc_bn_workspace_bytes(int32_t B, int32_t N);
+int b3d_fc_ticket_init(void* workspace, size_t workspace_bytes, b3d_stream stream);
+int b3d_fc_bn_forward(const float* x, int32_t B, int32_t K, const float* w, const float* bias, int32_t N,
+                      const float* in_scale, const float* in_shift, const float* mask, const float* add,
+                      const b3d_batchnorm* bn, int32_t train, float* y, float* out_scale, float* out_shift,
+                      void* workspace, size_t workspace_bytes, b3d_stream stream);
+int b3d_affine_relu(const float* y, const float* scale, const float* shift, int32_t B, int32_t N, float* out, b3d_stream stream);
+
 /* Mean mu [K] and second moments second [K,K] = E[h h^T] (float64) over all B * P points of the input of a point stack's
  * first layer (fold1 == NULL: h = the point, transformed by `trans` if given, K = C) or of its second layer (fold1 = the first
  * layer with ITS BatchNorm folded in, [64,C] / [64]: h = relu(fold1(point)), K = 64). */
