@@ -185,6 +185,8 @@ def load() -> C.CDLL:
                                    C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     lib.b3d_resnet_encode_workspace_bytes.restype = C.c_size_t
     lib.b3d_resnet_encode_workspace_bytes.argtypes = [C.c_int32]
+    lib.b3d_modality_rows.restype = C.c_int
+    lib.b3d_modality_rows.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.b3d_fc_bn_workspace_bytes.restype = C.c_size_t
     lib.b3d_fc_bn_workspace_bytes.argtypes = [C.c_int32, C.c_int32]
     lib.b3d_fc_bn_forward.restype = C.c_int

@@ -53,6 +53,21 @@ def modality_present(feats: torch.Tensor) -> torch.Tensor:
     return has.bool()
 
 
+def modality_row_ids(feats: torch.Tensor) -> torch.Tensor:
+    """``torch.nonzero(modality_present(feats)).squeeze(1)`` (int64, ascending) from two HIP launches (``b3d_modality_rows``:
+    the presence mask, then a one-workgroup ballot / scan compaction).  The count is a shape: one read-back, on the
+    current stream."""
+    n = feats.size(0)
+    f = feats.reshape(n, -1).contiguous()
+    _lib.require_cuda(f, "modality features", torch.float32)
+    has = torch.empty(max(n, 1), dtype=torch.uint8, device=f.device)
+    rows = torch.empty(max(n, 1), dtype=torch.int64, device=f.device)
+    count = torch.empty(1, dtype=torch.int32, device=f.device)
+    _lib.check(_lib.load().b3d_modality_rows(f.data_ptr(), n, f.size(1), has.data_ptr(), rows.data_ptr(), count.data_ptr(),
+                                             _lib.current_stream(f.device)), "b3d_modality_rows")
+    return rows[: int(count.item())]
+
+
 def _param_list(m: "GNN") -> List[torch.Tensor]:
     out: List[torch.Tensor] = []
     for seq in (m.edge_encoder, m.node_encoder, m.edge_classifier, m.fc_lidar_encoder, m.fc_radar_encoder):
@@ -267,17 +282,20 @@ class GNN(nn.Module):
 
         With ``self.mask_stream`` set (a ``torch.cuda.Stream``) the masks run there and only that stream is
         waited for, so the caller's stream keeps its queue -- the host can enqueue step k+1 while step k runs.
-        The caller then guarantees that ``lidar_feats`` / ``radar_feats`` are complete when this is called (resident
-        inputs, or a loader that has already made the caller's stream wait for its copy)."""
+        A batch from ``graph_data``'s prefetching loader carries the event of its H2D copy (``_b3d_ready_event``) and the
+        side stream waits for it; for any other producer the caller guarantees that ``lidar_feats`` / ``radar_feats`` are
+        complete when this is called (resident inputs)."""
         lidar_feats, radar_feats = data.lidar_feats, data.radar_feats
         ms = self.mask_stream
         if ms is None or torch.cuda.is_current_stream_capturing():
-            return (torch.nonzero(modality_present(lidar_feats)).squeeze(1),
-                    torch.nonzero(modality_present(radar_feats)).squeeze(1))
+            return modality_row_ids(lidar_feats), modality_row_ids(radar_feats)
         cur = torch.cuda.current_stream(lidar_feats.device)
+        ev = getattr(data, "_b3d_ready_event", None)      # set by graph_data's prefetching loader: the H2D copy of this batch
+        if ev is not None:
+            ms.wait_event(ev)
         with torch.cuda.stream(ms):
-            li = torch.nonzero(modality_present(lidar_feats)).squeeze(1)      # nonzero() waits for `ms` only
-            ri = torch.nonzero(modality_present(radar_feats)).squeeze(1)
+            li = modality_row_ids(lidar_feats)      # the count read-back waits for `ms` only
+            ri = modality_row_ids(radar_feats)
         cur.wait_stream(ms)
         li.record_stream(cur)
         ri.record_stream(cur)

@@ -326,6 +326,33 @@ __global__ __launch_bounds__(256) void modality_mask_kernel(const float* __restr
   if (lane == 0) has[row] = (s != 0.f) ? 1 : 0;
 }
 
+// Ascending ids of the rows with has[n] != 0 (torch.nonzero of clr_att_gnn.py:107-121's masks) and their count: ONE workgroup, a
+// ballot per wavefront and an LDS scan over the wavefronts per 1,024 rows (N is a few thousand: rocPRIM's partition + reduce +
+// lookback launches cost 75 us per modality in front of every step).
+__global__ __launch_bounds__(1024) void compact_rows_kernel(const uint8_t* __restrict__ has, int N, long long* __restrict__ rows,
+                                                            int* __restrict__ count) {
+  __shared__ int wsum[16];
+  __shared__ int base_s;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if (tid == 0) base_s = 0;
+  __syncthreads();
+  for (int n0 = 0; n0 < N; n0 += 1024) {
+    const int n = n0 + tid;
+    const bool f = n < N && has[n] != 0;
+    const unsigned long long b = __ballot(f);
+    const int below = __popcll(b & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[wave] = __popcll(b);
+    __syncthreads();
+    int off = base_s;
+    for (int w = 0; w < wave; ++w) off += wsum[w];
+    if (f) rows[off + below] = n;
+    __syncthreads();
+    if (tid == 0) { int t = 0; for (int w = 0; w < 16; ++w) t += wsum[w]; base_s += t; }
+    __syncthreads();
+  }
+  if (tid == 0) *count = base_s;
+}
+
 struct LinPtrs { const float* w; const float* b; };
 static void gather_linears(const b3d_clr_weights* pw, LinPtrs* L) {
   auto put = [&](int first, const b3d_linear* a, int n) { for (int i = 0; i < n; ++i) L[first + i] = LinPtrs{a[i].w, a[i].b}; };
@@ -578,6 +605,18 @@ extern "C" int b3d_modality_mask(const float* feats, int32_t N, int32_t width, u
   if (N == 0) return B3D_OK;
   hipLaunchKernelGGL(modality_mask_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream_, feats, N, width, has);
   return launch_check("modality_mask_kernel");
+}
+
+extern "C" int b3d_modality_rows(const float* feats, int32_t N, int32_t width, uint8_t* has, int64_t* rows, int32_t* count,
+                                 b3d_stream stream_) {
+  B3D_REQUIRE(feats && has && rows && count && N >= 0 && width > 0, "b3d_modality_rows: bad argument");
+  hipStream_t stream = (hipStream_t)stream_;
+  if (N > 0) {
+    hipLaunchKernelGGL(modality_mask_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, feats, N, width, has);
+    B3D_TRY(launch_check("modality_mask_kernel"));
+  }
+  hipLaunchKernelGGL(compact_rows_kernel, dim3(1), dim3(1024), 0, stream, has, N, (long long*)rows, count);
+  return launch_check("compact_rows_kernel");
 }
 
 extern "C" size_t b3d_clr_workspace_bytes(int32_t N, int32_t E, int32_t n_lidar, int32_t n_radar, int32_t depth, uint32_t flags) {

@@ -190,6 +190,7 @@ def iterate_batches(dataset, batch_size: int, shuffle: bool = False, generator: 
             if ev is not None:
                 cur = torch.cuda.current_stream(dev)
                 cur.wait_event(ev)
+                batch._b3d_ready_event = ev      # a side stream that reads the batch (GNN.mask_stream) waits for the copy too
                 # The batch was allocated on the copy stream: without this the caching allocator would hand its blocks
                 # back to the copy stream the moment the consumer drops the batch, and the worker's next H2D copy could
                 # overwrite them while kernels of the consumer's (asynchronously enqueued) step are still reading.

@@ -200,6 +200,10 @@ int b3d_clr_backward(const b3d_clr_weights* w, const b3d_graph* g, const b3d_clr
                      const b3d_clr_grads* grads, b3d_stream stream);
 /* Modality presence (clr_att_gnn.py:107-121): has[n] = (sum of row n) != 0, rows of `width` floats. */
 int b3d_modality_mask(const float* feats, int32_t N, int32_t width, uint8_t* has /* [N] */, b3d_stream stream);
+/* The same masks as ascending row ids (torch.nonzero(mask).squeeze(1), clr_att_gnn.py:131,139): has [N] (scratch, also returned),
+ * rows [N] int64 (the first *count entries are valid), count [1] int32 -- two launches, no library scan. */
+int b3d_modality_rows(const float* feats, int32_t N, int32_t width, uint8_t* has, int64_t* rows, int32_t* count,
+                      b3d_stream stream);
 
 /* ---- one CausalMessagePassing layer as a standalone operator ------------------------------------------
  * Replaces `CausalMessagePassing.forward(x, edge_index, edge_attr, initial_x[, att_edge_attr])`
