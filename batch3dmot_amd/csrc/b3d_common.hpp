@@ -10,6 +10,10 @@
 
 namespace b3d {
 
+// ReLU as torch computes it: NaN stays NaN.  v_max_f32 returns the OTHER operand for a quiet NaN, so fmaxf(NaN, 0) = 0
+// would turn a diverged activation back into a finite one; one compare + one select per element instead.
+__device__ __forceinline__ float relu1(float x) { return x < 0.f ? 0.f : x; }
+
 // thread-local error string returned by b3d_last_error(); the only mutable global state.
 char* last_error_buf();
 int fail(int code, const char* fmt, ...);

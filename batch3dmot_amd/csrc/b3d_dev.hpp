@@ -350,7 +350,7 @@ __device__ __forceinline__ v4f mfma4(const v4f a, const v4f b, v4f c) {
 
 __device__ __forceinline__ v4f relu4(v4f a) {
   v4f r;
-  r.x = fmaxf(a.x, 0.f); r.y = fmaxf(a.y, 0.f); r.z = fmaxf(a.z, 0.f); r.w = fmaxf(a.w, 0.f);
+  r.x = relu1(a.x); r.y = relu1(a.y); r.z = relu1(a.z); r.w = relu1(a.w);
   return r;
 }
 

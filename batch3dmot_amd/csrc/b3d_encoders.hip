@@ -277,7 +277,7 @@ struct PointPass {
         float v = src[0];
 #pragma unroll
         for (int t = 1; t < WPC; ++t) v = fmaxf(v, src[t * kPointFeat]);
-        if (a.relu_last) v = fmaxf(v, 0.f);
+        if (a.relu_last) v = relu1(v);
         const int c = cloud0 + cl;
         if (c < a.B) a.out[(long)c * kPointFeat + feat] = v;
       }
@@ -666,7 +666,7 @@ __global__ __launch_bounds__(256) void bn_minmax_apply_kernel(const BnMinMaxArgs
     const size_t o = (size_t)b * a.F + f;
     const double ext = scale > 0.0 ? (double)a.vmax[o] : (double)a.vmin[o];
     float v = (float)(ext * scale + shift);
-    if (a.relu) v = fmaxf(v, 0.f);
+    if (a.relu) v = relu1(v);
     a.y[o] = v;
   }
 }

@@ -98,8 +98,8 @@ __global__ __launch_bounds__(kFcThreads) void fc_kernel(const FcArgs a) {
       typedef float v2f __attribute__((ext_vector_type(2)));
       v4f v = axs[h];
       if constexpr (AFFINE) {
-        v.x = fmaxf(fmaf(v.x, scs.x, shs.x), 0.f); v.y = fmaxf(fmaf(v.y, scs.y, shs.y), 0.f);
-        v.z = fmaxf(fmaf(v.z, scs.z, shs.z), 0.f); v.w = fmaxf(fmaf(v.w, scs.w, shs.w), 0.f);
+        v.x = relu1(fmaf(v.x, scs.x, shs.x)); v.y = relu1(fmaf(v.y, scs.y, shs.y));
+        v.z = relu1(fmaf(v.z, scs.z, shs.z)); v.w = relu1(fmaf(v.w, scs.w, shs.w));
       }
       const bool oa = okA[h] && kok, ob = okB[h] && kok;
       const v4f u = bxs[h];
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void affine_relu_kernel(const float* __restric
                                                           const float* __restrict__ shift, long total, int N, float* __restrict__ out) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int n = (int)(i % N);
-    out[i] = fmaxf(fmaf(y[i], scale[n], shift[n]), 0.f);
+    out[i] = relu1(fmaf(y[i], scale[n], shift[n]));
   }
 }
 

@@ -352,7 +352,7 @@ __device__ __forceinline__ void stage_tiles(const ResArgs& a, int img0, const fl
       const long o = (long)(img0 + im) * (CIN * PIX) + r;
       v = fmaf(zA[o], affA[c], affA[CIN + c]);
       if (zB) v += fmaf(zB[o], affB[c], affB[CIN + c]);
-      v = fmaxf(v, 0.f);
+      v = relu1(v);
     }
     tiles[(im * CIN + c) * HP * HP + (p / HIN + 1) * HP + (p % HIN) + 1] = v;
   }
@@ -510,7 +510,7 @@ __global__ __launch_bounds__(kP5Threads) void resnet_p5_kernel(const ResArgs a) 
     for (int i = threadIdx.x; i < kP5Crops * 384; i += kP5Threads) {
       const int im = i / 384, r = i - im * 384;
       float v = 0.f;
-      if (img0 + im < a.N) v = fmaxf(fmaf(a.z5[(long)(img0 + im) * 384 + r], aff[r >> 2], aff[96 + (r >> 2)]), 0.f);
+      if (img0 + im < a.N) v = relu1(fmaf(a.z5[(long)(img0 + im) * 384 + r], aff[r >> 2], aff[96 + (r >> 2)]));
       rows[im * kP5Row + r] = v;
     }
     __syncthreads();
@@ -553,7 +553,7 @@ __global__ __launch_bounds__(256) void resnet_out_kernel(const ResArgs a) {
     float s1, t1, s2, t2;
     bn_affine(a, 7, c, s1, t1);
     bn_affine(a, 8, c, s2, t2);
-    a.out[i] = fmaxf(fmaf(a.z6[i], s1, t1) + fmaf(a.zd3[i], s2, t2), 0.f);
+    a.out[i] = relu1(fmaf(a.z6[i], s1, t1) + fmaf(a.zd3[i], s2, t2));
   }
 }
 __global__ __launch_bounds__(128) void resnet_track_kernel(const ResArgs a) {

@@ -269,7 +269,7 @@ def golden_clr(ref, path, num_nodes=60, k=6, graph_idx=200, lidar_frac=0.7, rada
     torch.save({"data": _data_dict(data), "salt": salt,
                 "state_keys": {k_: tuple(v.shape) for k_, v in model.state_dict().items()},
                 "encoder_out": _encoder_outputs(model, data), "out": out, "x_sens": x_sens,
-                "layers": layers, "loss": loss, "grad_digest": grad_digest(grads)}, path)
+                "layers": layers, "loss": loss, "grad_digest": grad_digest(grads), "grads": grads}, path)
     print(f"{path}: N={data.pose_feats.size(0)} E={data.edge_index.size(1)} "
           f"lidar rows={int(_encoder_outputs(model, data)['has_lidar'].sum())} "
           f"out range=[{out.min():.4f},{out.max():.4f}] |e5|max={layers[-1][1].abs().max():.3f}")
@@ -303,7 +303,7 @@ def golden_train_step(ref, path, num_nodes=60, k=6, graph_idx=300, salt=20):
                   {"out": o2, "loss": loss2, **{f"g.{n}": g for n, g in g2.items()},
                    **{f"a.{n}": g for n, g in a2.items()}}, tol=1e-5)
     torch.save({"data": _data_dict(data), "salt": salt, "encoder_out": _encoder_outputs(model, data),
-                "out": out, "loss": loss, "grad_digest": grad_digest(grads),
+                "out": out, "loss": loss, "grad_digest": grad_digest(grads), "grads": grads,
                 "after_digest": grad_digest(after)}, path)
     print(f"{path}: loss={loss.item():.6f}")
 

@@ -7,7 +7,7 @@ reads are tallied at half their bytes): bytes = 2 * 1024 * FETCH_SIZE + 1024 * W
 Merges {WORKLOAD_KEY: {family: bytes per launch}} into out.json (default profiles/traffic_pmc.json, read by bench.py)."""
 import collections, csv, glob, json, os, sys
 
-FAMILY = [("mp_edge_fwd", "mp_edge_fwd"), ("mp_edge_bwd", "mp_edge_bwd"), ("mp_node_fwd", "mp_node_fwd"),
+FAMILY = [("mp_edge_fwd", "mp_edge_fwd"), ("mp_edge_bwd", "mp_edge_bwd"), ("edge_fwd_kernel", "mp_edge_fwd"), ("edge_bwd_kernel", "mp_edge_bwd"), ("mp_node_fwd", "mp_node_fwd"),
           ("node_bwd", "mp_node_bwd"), ("node_listsum", "mp_node_bwd"), ("node_gradproj", "mp_node_bwd"),
           ("wstream", "wgrad_edge"), ("wgemm", "wgrad_edge"), ("wgrad_kernel", "wgrad_other"), ("point_feat", "point_feat"), ("knn_", "knn_gat"),
           ("gat_", "knn_gat")]
