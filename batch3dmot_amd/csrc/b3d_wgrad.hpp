@@ -292,9 +292,12 @@ struct RedArgs {
 
 // A workgroup reduces kRedQuads consecutive QUADS of output elements (an entry's elements are numbered [0, N K + N)
 // and padded to a multiple of 4; entry.begin counts quads); kRedParts threads share one quad: each sums every
-// kRedParts-th slab with 16-byte loads where the quad is four consecutive columns of one weight row (K % 4 == 0 and an
-// aligned slab: every layer of both models), 8 loads in flight per thread, 1 KB runs per wavefront -- 64-element runs
-// of 4-byte loads ran this at 0.7 TB/s.  The partials meet in LDS and are added in a fixed order.  Bitwise reproducible.
+// kRedParts-th slab, 8 slabs in flight per thread.  Where the quad is four consecutive floats of the slab -- four columns
+// of one weight row (K % 4 == 0) or four bias entries, 16-byte aligned: every layer of both models -- one 16-byte load
+// per slab, 1 KB runs per wavefront (64-element runs of 4-byte loads ran this at 0.7 TB/s); otherwise four 4-byte loads
+// per slab, still 8 slabs in flight (a plain scalar loop here -- it held the BIAS quads in round 2 -- walks the slabs one
+// load latency at a time: 450 slabs / 8 threads x 4 elements x ~0.4 us was the whole 80 us of the PoseGNN launch).  The
+// partials meet in LDS and are added in a fixed order.  Bitwise reproducible.
 constexpr int kRedQuads = 64, kRedParts = 8;
 static __global__ __launch_bounds__(kRedQuads * kRedParts) void wgrad_reduce_kernel(const RedArgs a) {
   __shared__ v4f part[kRedParts][kRedQuads];
@@ -308,13 +311,18 @@ static __global__ __launch_bounds__(kRedQuads * kRedParts) void wgrad_reduce_ker
   const int l0 = live ? 4 * (id - e.begin) : 0;  // first element of the quad, in [0, N*K + N)
   const size_t cs = (size_t)e.NP * e.KP + e.NP;
   const int nk = e.N * e.K, tot = nk + e.N;
-  // fast path: four consecutive columns of one weight row, 16-byte aligned in every slab and in the output
-  const bool vec = live && e.dw && (e.K & 3) == 0 && (e.KP & 3) == 0 && (cs & 3) == 0 && l0 + 3 < nk && (e.ld & 3) == 0 &&
-                   (((uintptr_t)e.slab | (uintptr_t)e.dw) & 15) == 0;
+  const bool in_w = l0 + 3 < nk, in_b = l0 >= nk && l0 + 3 < tot;
+  // slab offset of element l of this entry, -1: nothing to sum (past the end, or no output requested)
+  auto off_of = [&](int l) -> long {
+    if (l >= tot) return -1;
+    if (l < nk) { const int n = l / e.K, k = l - n * e.K; return e.dw ? (long)n * e.KP + k : -1; }
+    return e.db ? (long)e.NP * e.KP + (l - nk) : -1;
+  };
+  const bool aligned = (e.KP & 3) == 0 && (cs & 3) == 0 && ((uintptr_t)e.slab & 15) == 0;
+  const bool vec = live && aligned && ((in_w && e.dw && (e.K & 3) == 0) || (in_b && e.db && (nk & 3) == 0));
   v4f s = {0.f, 0.f, 0.f, 0.f};
   if (vec) {
-    const int n = l0 / e.K, k = l0 - n * e.K;
-    const float* src = e.slab + (size_t)n * e.KP + k;
+    const float* src = e.slab + off_of(l0);
     int c = sub;
     for (; c + 7 * kRedParts < e.nchunks; c += 8 * kRedParts) {
       v4f t[8];
@@ -325,18 +333,25 @@ static __global__ __launch_bounds__(kRedQuads * kRedParts) void wgrad_reduce_ker
     }
     for (; c < e.nchunks; c += kRedParts) s += *reinterpret_cast<const v4f*>(src + (size_t)c * cs);
   } else if (live) {
-    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    long off[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int l = l0 + r;
-      if (l >= tot) continue;
-      size_t off;
-      bool has;
-      if (l < nk) { const int n = l / e.K, k = l - n * e.K; off = (size_t)n * e.KP + k; has = e.dw != nullptr; }
-      else { off = (size_t)e.NP * e.KP + (l - nk); has = e.db != nullptr; }
-      if (!has) continue;
-      for (int c = sub; c < e.nchunks; c += kRedParts) v[r] += e.slab[(size_t)c * cs + off];
+    for (int r = 0; r < 4; ++r) off[r] = off_of(l0 + r);
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    int c = sub;
+    for (; c + 7 * kRedParts < e.nchunks; c += 8 * kRedParts) {
+      float t[8][4];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[u][r] = off[r] >= 0 ? e.slab[(size_t)(c + u * kRedParts) * cs + off[r]] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += t[u][r];
     }
+    for (; c < e.nchunks; c += kRedParts)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] += off[r] >= 0 ? e.slab[(size_t)c * cs + off[r]] : 0.f;
     s = v4f{v[0], v[1], v[2], v[3]};
   }
   part[sub][el] = s;
@@ -345,7 +360,7 @@ static __global__ __launch_bounds__(kRedQuads * kRedParts) void wgrad_reduce_ker
     v4f t = part[0][el];
 #pragma unroll
     for (int p = 1; p < kRedParts; ++p) t += part[p][el];
-    if (vec) {
+    if (vec && in_w && (e.ld & 3) == 0 && ((uintptr_t)e.dw & 15) == 0) {
       const int n = l0 / e.K, k = l0 - n * e.K;
       *reinterpret_cast<v4f*>(e.dw + (size_t)n * e.ld + k) = t;
     } else {
