@@ -63,15 +63,6 @@ struct LoadScalar {                  // [rows, 1] -> feature 0
   }
 };
 
-template <int NB0, int NB1, int NB2>
-struct LoadConcat3 {                 // three aligned segments side by side
-  static constexpr int NB = NB0 + NB1 + NB2;
-  LoadAligned<NB0> a; LoadAligned<NB1> b; LoadAligned<NB2> c;
-  __device__ __forceinline__ void operator()(long row, bool valid, v4f* dst) const {
-    a(row, valid, dst); b(row, valid, dst + NB0); c(row, valid, dst + NB0 + NB1);
-  }
-};
-
 // Gradient arriving at the node encoder output (x = initial_x = x_enc):
 //   upstream d x_enc + running d initial_x + the layer-0 edge backward's per-edge rows
 //   (d x | d x0 at dst, d x | d x0 at src) summed over the node's CSR / CSC lists.
@@ -114,23 +105,6 @@ struct LoadAdd2 {
       v4f t[NB];
       load_row<NB>(p1, r, stride1, col1, valid, t);
       add_blocks<NB>(dst, t);
-    }
-  }
-};
-
-// node gradient = per-edge rows summed over the node's CSR list (columns col_dst) plus over its CSC
-// list (columns col_src) -- the transpose of gathering node rows at both ends of every edge
-template <int NB_>
-struct LoadSegSum2 {
-  static constexpr int NB = NB_;
-  const float* base; int stride; int col_dst; int col_src;
-  const int* dst_ptr; const int* dst_perm; const int* src_ptr; const int* src_perm;
-  __device__ __forceinline__ void operator()(long row, bool valid, v4f* dst) const {
-#pragma unroll
-    for (int b = 0; b < NB; ++b) dst[b] = v4f{0.f, 0.f, 0.f, 0.f};
-    if (valid) {
-      segment_sum<NB>(base, stride, col_dst, dst_perm, dst_ptr[row], dst_ptr[row + 1], dst);
-      segment_sum<NB>(base, stride, col_src, src_perm, src_ptr[row], src_ptr[row + 1], dst);
     }
   }
 };

@@ -33,16 +33,10 @@ inline int zero_launch(ZeroArgs& z, hipStream_t stream) {
 using D = DimsC;
 using DB = DimsCB;                       // hoisted kernels: bf16x3 images for the edge stacks
 using HC = Hoist<DB>;
-// Hoisted first layers (b3d_hoist.hpp) at the camera+LiDAR+radar widths.  B3D_CLR_HOIST=0 selects the unsplit kernels.
-static bool hoist_enabled() {
-  static const bool on = [] { const char* e = getenv("B3D_CLR_HOIST"); return e ? atoi(e) != 0 : true; }();
-  return on;
-}
-// Fragment-streamed edge kernels (b3d_edge2.hpp, round 3).  B3D_EDGE2=0 selects round 2's kernels (A/B aid).
-static bool edge2_enabled() {
-  static const bool on = [] { const char* e = getenv("B3D_EDGE2"); return e ? atoi(e) != 0 : true; }();
-  return on && hoist_enabled();
-}
+// The model runs ONE plan: first layers hoisted to per-node tables (b3d_hoist.hpp, b3d_att.hpp), edge stacks on the
+// fragment-streamed kernels (b3d_edge2.hpp), weight gradients on the cooperative kernel (b3d_wgemm.hpp) with the
+// per-wavefront LDS-DMA kernel (b3d_wstream2.hpp) for the shapes it has no tile for.  The unsplit kernels of b3d_mp.hpp
+// serve the single-layer operator at the end of this file.
 using ES = es::EdgeSeqs<DB>;
 // rows of every per-edge workspace buffer: the fragment-streamed kernels store whole 64-row tiles
 static size_t edge_rows(int E) { return ((size_t)(E > 0 ? E : 1) + 63) / 64 * 64; }
@@ -53,7 +47,7 @@ using SeqCls = LayerSeq<L<64, 32>, L<32, 16>, L<16, 16>, L<16, 16>>;     // 64-3
 using SeqFL = LayerSeq<L<256, 192>, L<192, 128>>;                        // 256-192-128         :60-64
 using SeqFR = LayerSeq<L<256, 192>, L<192, 128>, L<128, 64>>;            // 256-192-128-64      :66-72
 template <int DD> using SeqAff = LayerSeq<L<DD, DD>, L<DD, DD>>;         // out_proj(v_proj(x)) :77-79,148-155
-using SeqAT0 = LayerSeq<L<640, 512>>;                                    // att_edge_encoder    :81-91
+// att_edge_encoder :81-91 (640-512-384-256-128-64); .0 runs hoisted (b3d_att.hpp)
 using SeqAT1 = LayerSeq<L<512, 384, 1>>;     // 384 / 512 inputs: bf16x6 too (one wide layer per kernel: the operand pieces fit)
 using SeqAT2 = LayerSeq<L<384, 256, 1>>;
 using SeqAT3 = LayerSeq<L<256, 128>>;
@@ -74,7 +68,6 @@ using SeqAT4T = LayerSeq<L<64, 128>>;
 using SeqAT3T = LayerSeq<L<128, 256>>;
 using SeqAT2T = LayerSeq<L<256, 384>>;
 using SeqAT1T = LayerSeq<L<384, 512, 1>>;
-using SeqAT0T = LayerSeq<L<512, 640>>;
 
 enum { EE0, EE1, EE2, NE0, NE1, C0, C1, C2, C3, FL0, FL1, FR0, FR1, FR2,
        AVC, AOC, AVL, AOL, AVR, AOR, AT0, AT1, AT2, AT3, AT4,
@@ -90,7 +83,12 @@ static const LinDim kDims[LIN_COUNT] = {
 static const int kRowKind[LIN_COUNT] = {0, 0, 0, 1, 1, 0, 0, 0, 0, 2, 2, 3, 3, 3, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0,
                                         0, 0, 0, 0, 0, 0, 0, 1, 1, 1};
 constexpr int kStreamRowsPerTask = 512;       // message-passing stacks (x up to 6 layer variants)
-constexpr int kStreamNodeRowsPerTask = 64;    // hoisted first layers: node columns contract over N rows x depth layers
+#ifndef B3D_RN
+#define B3D_RN 128
+#define B3D_RNA 512
+#endif
+constexpr int kStreamNodeRowsPerTask = B3D_RN;   // hoisted first layers: node columns contract over N rows x depth layers
+constexpr int kStreamNodeRowsPerTaskAtt = B3D_RNA;  // att_edge_encoder.0's node columns: one variant, a [512, 288] partial per task
 constexpr int kStreamRowsPerTaskAtt = 1024;   // att_edge_encoder (one variant)
 
 // column blocks of the hoisted first-layer gradients: (linear, first column, width, rows contracted over edges?)
@@ -103,16 +101,14 @@ static const VlDesc kVl[VL_COUNT] = {
     {AT0, 0, 288, false, false}, {AT0, 288, 288, false, false}, {AT0, 576, 64, true, true}};
 struct Ws {
   // forward images
-  float *wp_ee, *wp_ne, *wp_cls, *wp_fl, *wp_fr, *wp_aff[3], *wp_at[5], *wp_efwd, *wp_nfwd;
+  float *wp_ee, *wp_ne, *wp_cls, *wp_fl, *wp_fr, *wp_aff[3], *wp_at[5], *wp_nfwd;
   // backward images
   // hoisted first layers
-  bool hoist;
-  float *wp_proj0, *wp_nfwd_h, *wp_efwd_h, *wp_ebwd_h, *wp_ebwd_nm_h, *wp_gproj, *wp_nbwd_h;
+  float *wp_proj0, *wp_nfwd_h, *wp_gproj, *wp_nbwd_h;
   float *wp_efwd2, *wp_ebwd2, *wp_ebwd_nm2;       // fragment-stream images (b3d_estream.hpp)
-  bool edge2;
   float *T, *T0, *dT, *gx;
   float *wp_attU, *wp_att0, *wp_attDs, *wp_at0eT, *U, *dU, *ds, *de0;     // att_edge_encoder.0 hoisted
-  float *wp_clsT, *wp_eeT, *wp_neT, *wp_flT, *wp_frT, *wp_affT[3], *wp_atT[5], *wp_ebwd, *wp_ebwd_nm, *wp_nbwd;
+  float *wp_clsT, *wp_eeT, *wp_neT, *wp_flT, *wp_frT, *wp_affT[3], *wp_atT[5], *wp_nbwd;
   // activations
   float *ea_pad, *ee_a1, *ee_a2, *pose_pad, *ne_a1, *xsens, *fl_a1, *fr_a1, *fr_a2, *aff_v[3], *s;
   float *A[4], *att;                 // att_edge_encoder hidden [E,512/384/256/128], output [E,64]
@@ -123,7 +119,7 @@ struct Ws {
   float *de[2], *da_acc, *gdst, *gsrc, *dx0_acc;
   float *dM, *GdH1, *GdH2, *Gde, *GdF1, *GdP1, *Gdx, *GnH2, *GnH1;     // per layer, uniform stride
   float *gc_top, *gc3, *gc2, *gc1, *ge_top, *ge2, *ge1, *gn_top, *gn1;
-  float *dA[4], *dIn;                // att backward: [E,128/256/384/512], [E,640]
+  float *dA[4];                      // att backward: [E,128/256/384/512]
   float *gaff_top[3], *gaff_v[3], *dxs;   // affine backward; dxs [N,288] gradient of x_sens columns
   float *gfl_top, *gfl1, *gfr_top, *gfr2, *gfr1;
   float* zrow;
@@ -140,7 +136,7 @@ constexpr int kTableCap = 320, kTaskCap = 32768;
 
 constexpr int kStreamRowsPerTaskFc = 128;     // modality heads: a few thousand rows
 static bool is_fc(int lin) { return lin >= FL0 && lin <= FR2; }
-static bool is_streamed(int lin, bool hoist) { return lin >= AT0 || (hoist && is_fc(lin)); }   // fc heads: streamed with the hoisted plan
+static bool is_streamed(int lin) { return lin >= AT0 || is_fc(lin); }   // att_edge_encoder, message passing, fc heads
 
 static void carve(Ws& w, void* ws, size_t ws_bytes, int N, int E, int nl, int nr, int depth, uint32_t flags) {
   Carver c(ws, ws_bytes);
@@ -156,26 +152,19 @@ static void carve(Ws& w, void* ws, size_t ws_bytes, int N, int E, int nl, int nr
   w.wp_aff[0] = c.take<float>(SeqAff<96>::TOTAL_FLOATS);
   w.wp_aff[1] = c.take<float>(SeqAff<128>::TOTAL_FLOATS);
   w.wp_aff[2] = c.take<float>(SeqAff<64>::TOTAL_FLOATS);
-  w.wp_at[0] = c.take<float>(SeqAT0::TOTAL_FLOATS);
   w.wp_at[1] = c.take<float>(SeqAT1::TOTAL_FLOATS);
   w.wp_at[2] = c.take<float>(SeqAT2::TOTAL_FLOATS);
   w.wp_at[3] = c.take<float>(SeqAT3::TOTAL_FLOATS);
   w.wp_at[4] = c.take<float>(SeqAT4::TOTAL_FLOATS);
-  w.wp_efwd = c.take<float>(D::EdgeFwdSeq::TOTAL_FLOATS);
   w.wp_nfwd = c.take<float>(D::NodeFwdSeq::TOTAL_FLOATS);
-  w.hoist = hoist_enabled();
-  w.edge2 = edge2_enabled();
-  if (w.hoist) {
-    w.wp_proj0 = c.take<float>(Proj0Seq2<DB>::TOTAL_FLOATS);
-    w.wp_nfwd_h = c.take<float>(NodeFwdHSeq<DB>::TOTAL_FLOATS);
-    w.wp_efwd_h = c.take<float>(HC::EdgeFwdSeq::TOTAL_FLOATS);
-    w.wp_efwd2 = c.take<float>(ES::Fwd::TOTAL_FLOATS);
-    w.T = c.take<float>(n_ * HC::TW);
-    w.T0 = c.take<float>(n_ * 2 * DB::MH);
-    w.wp_attU = c.take<float>(SeqAttU::TOTAL_FLOATS);
-    w.wp_att0 = c.take<float>(Att0Seq::TOTAL_FLOATS);
-    w.U = c.take<float>(n_ * 1024);
-  }
+  w.wp_proj0 = c.take<float>(Proj0Seq2<DB>::TOTAL_FLOATS);
+  w.wp_nfwd_h = c.take<float>(NodeFwdHSeq<DB>::TOTAL_FLOATS);
+  w.wp_efwd2 = c.take<float>(ES::Fwd::TOTAL_FLOATS);
+  w.T = c.take<float>(n_ * HC::TW);
+  w.T0 = c.take<float>(n_ * 2 * DB::MH);
+  w.wp_attU = c.take<float>(SeqAttU::TOTAL_FLOATS);
+  w.wp_att0 = c.take<float>(Att0Seq::TOTAL_FLOATS);
+  w.U = c.take<float>(n_ * 1024);
   w.xsens = c.take<float>(n_ * XS);
   w.s = c.take<float>(n_ * XS);
   w.att = c.take<float>(e_ * 64);
@@ -200,28 +189,21 @@ static void carve(Ws& w, void* ws, size_t ws_bytes, int N, int E, int nl, int nr
     w.wp_affT[0] = c.take<float>(SeqAffT<96>::TOTAL_FLOATS);
     w.wp_affT[1] = c.take<float>(SeqAffT<128>::TOTAL_FLOATS);
     w.wp_affT[2] = c.take<float>(SeqAffT<64>::TOTAL_FLOATS);
-    w.wp_atT[0] = c.take<float>(SeqAT0T::TOTAL_FLOATS);
     w.wp_atT[1] = c.take<float>(SeqAT1T::TOTAL_FLOATS);
     w.wp_atT[2] = c.take<float>(SeqAT2T::TOTAL_FLOATS);
     w.wp_atT[3] = c.take<float>(SeqAT3T::TOTAL_FLOATS);
     w.wp_atT[4] = c.take<float>(SeqAT4T::TOTAL_FLOATS);
-    if (w.hoist) {
-      w.wp_ebwd_h = c.take<float>(HC::EdgeBwdSeq::TOTAL_FLOATS);
-      w.wp_ebwd_nm_h = c.take<float>(HC::EdgeBwdSeqNoMsg::TOTAL_FLOATS);
-      w.wp_ebwd2 = c.take<float>(ES::Bwd::TOTAL_FLOATS);
-      w.wp_ebwd_nm2 = c.take<float>(ES::BwdNoMsg::TOTAL_FLOATS);
-      w.wp_nbwd_h = c.take<float>(NodeBwdHSeq<DB>::TOTAL_FLOATS);
-      w.wp_gproj = c.take<float>(HC::GradProjSeq::TOTAL_FLOATS);
-      w.wp_attDs = c.take<float>(SeqAttDs::TOTAL_FLOATS);
-      w.wp_at0eT = c.take<float>(SeqAT0eT::TOTAL_FLOATS);
-      w.dU = c.take<float>(n_ * 1024);
-      w.ds = c.take<float>(n_ * XS);
-      w.de0 = c.take<float>(e_ * 64);
-      w.dT = c.take<float>((size_t)depth * n_ * HC::GW);
-      w.gx = c.take<float>(n_ * 2 * D::DX);
-    }
-    w.wp_ebwd = c.take<float>(D::EdgeBwdSeq::TOTAL_FLOATS);
-    w.wp_ebwd_nm = c.take<float>(D::EdgeBwdSeqNoMsg::TOTAL_FLOATS);
+    w.wp_ebwd2 = c.take<float>(ES::Bwd::TOTAL_FLOATS);
+    w.wp_ebwd_nm2 = c.take<float>(ES::BwdNoMsg::TOTAL_FLOATS);
+    w.wp_nbwd_h = c.take<float>(NodeBwdHSeq<DB>::TOTAL_FLOATS);
+    w.wp_gproj = c.take<float>(HC::GradProjSeq::TOTAL_FLOATS);
+    w.wp_attDs = c.take<float>(SeqAttDs::TOTAL_FLOATS);
+    w.wp_at0eT = c.take<float>(SeqAT0eT::TOTAL_FLOATS);
+    w.dU = c.take<float>(n_ * 1024);
+    w.ds = c.take<float>(n_ * XS);
+    w.de0 = c.take<float>(e_ * 64);
+    w.dT = c.take<float>((size_t)depth * n_ * HC::GW);
+    w.gx = c.take<float>(n_ * 2 * D::DX);
     w.wp_nbwd = c.take<float>(D::NodeBwdSeq::TOTAL_FLOATS);
     w.ea_pad = c.take<float>(e_ * 16); w.ee_a1 = c.take<float>(e_ * 16); w.ee_a2 = c.take<float>(e_ * 32);
     w.pose_pad = c.take<float>(n_ * 32); w.ne_a1 = c.take<float>(n_ * 48);
@@ -260,7 +242,6 @@ static void carve(Ws& w, void* ws, size_t ws_bytes, int N, int E, int nl, int nr
     w.ge_top = c.take<float>(e_ * 64); w.ge2 = c.take<float>(e_ * 32); w.ge1 = c.take<float>(e_ * 16);
     w.gn_top = c.take<float>(n_ * 96); w.gn1 = c.take<float>(n_ * 48);
     w.dA[0] = c.take<float>(e_ * 128); w.dA[1] = c.take<float>(e_ * 256); w.dA[2] = c.take<float>(e_ * 384); w.dA[3] = c.take<float>(e_ * 512);
-    w.dIn = w.hoist ? nullptr : c.take<float>(e_ * 640);
     for (int m = 0; m < 3; ++m) { w.gaff_top[m] = c.take<float>(n_ * affd[m]); w.gaff_v[m] = c.take<float>(n_ * affd[m]); }
     w.dxs = c.take<float>(n_ * XS);
     w.gfl_top = c.take<float>(l_ * 128); w.gfl1 = c.take<float>(l_ * 192);
@@ -273,7 +254,7 @@ static void carve(Ws& w, void* ws, size_t ws_bytes, int N, int E, int nl, int nr
       LinSlab& ls = w.lin[i];
       ls.N = kDims[i].N; ls.K = kDims[i].K; ls.NP = pad16(ls.N); ls.KP = pad16(ls.K);
       const long rows = kRowKind[i] == 0 ? E : kRowKind[i] == 1 ? N : kRowKind[i] == 2 ? nl : nr;
-      if (is_streamed(i, w.hoist)) {
+      if (is_streamed(i)) {
         const int rpt = is_fc(i) ? kStreamRowsPerTaskFc : (i <= AT4) ? kStreamRowsPerTaskAtt : kStreamRowsPerTask;
         ls.nchunks = (int)((rows + rpt - 1) / rpt);
         if (ls.nchunks < 1) ls.nchunks = 1;
@@ -287,10 +268,11 @@ static void carve(Ws& w, void* ws, size_t ws_bytes, int N, int E, int nl, int nr
       LinSlab& ls = w.vlin[v];
       ls.N = kDims[kVl[v].lin].N; ls.K = kVl[v].width; ls.NP = pad16(ls.N); ls.KP = pad16(ls.K);
       const long rows = kVl[v].on_edges ? E : N;
-      const int rpt = kVl[v].on_edges ? (kVl[v].lin == AT0 ? kStreamRowsPerTaskAtt : kStreamRowsPerTask) : kStreamNodeRowsPerTask;
+      const int rpt = kVl[v].on_edges ? (kVl[v].lin == AT0 ? kStreamRowsPerTaskAtt : kStreamRowsPerTask)
+                                      : (kVl[v].lin == AT0 ? kStreamNodeRowsPerTaskAtt : kStreamNodeRowsPerTask);
       ls.nchunks = (int)((rows + rpt - 1) / rpt);
       if (ls.nchunks < 1) ls.nchunks = 1;
-      ls.slab = w.hoist ? c.take<float>(wg_slab_floats(ls.nchunks, ls.NP, ls.KP)) : nullptr;
+      ls.slab = c.take<float>(wg_slab_floats(ls.nchunks, ls.NP, ls.KP));
       ls.used = false;
     }
   }
@@ -398,45 +380,32 @@ static int pack_all(const b3d_clr_weights* pw, Ws& w, bool training, bool knn, h
   F(SeqAff<96>{}, 0, w.wp_aff[0], AVC); F(SeqAff<96>{}, 1, w.wp_aff[0], AOC);
   F(SeqAff<128>{}, 0, w.wp_aff[1], AVL); F(SeqAff<128>{}, 1, w.wp_aff[1], AOL);
   F(SeqAff<64>{}, 0, w.wp_aff[2], AVR); F(SeqAff<64>{}, 1, w.wp_aff[2], AOR);
-  F(SeqAT0{}, 0, w.wp_at[0], AT0); F(SeqAT1{}, 0, w.wp_at[1], AT1); F(SeqAT2{}, 0, w.wp_at[2], AT2);
+  F(SeqAT1{}, 0, w.wp_at[1], AT1); F(SeqAT2{}, 0, w.wp_at[2], AT2);
   F(SeqAT3{}, 0, w.wp_at[3], AT3); F(SeqAT4{}, 0, w.wp_at[4], AT4);
-  using EF = D::EdgeFwdSeq;
-  for (int i = 0; i < 3; ++i) F(EF{}, i, w.wp_efwd, EU0 + i);
-  for (int i = 0; i < 2; ++i) F(EF{}, 3 + i, w.wp_efwd, FU0 + i);
-  for (int i = 0; i < 2; ++i) F(EF{}, 5 + i, w.wp_efwd, PA0 + i);
   for (int i = 0; i < 3; ++i) F(D::NodeFwdSeq{}, i, w.wp_nfwd, CF0 + i);
-  if (w.hoist) {
-    constexpr int DX = DB::DX, DE = DB::DE, EIN = DB::EIN, MIN = DB::MIN, H1 = DB::EH1, MH = DB::MH, KE = HC::KE;
-    const LinPtrs &eu0 = L[EU0], &fu0 = L[FU0], &pa0 = L[PA0];
-    // per-node table T = (eu0[:, x_i] x + b | eu0[:, x_j] x | fu0[:, x] x + b | pa0[:, x] x + b | GATConv.lin x)
-    auto proj = [&](auto tag, int li, float* base) {
-      using S = decltype(tag);
-      d[n++] = pack_slice<S>(li, base, eu0.w, eu0.b, H1, DX, EIN, HC::OA, H1, false);
-      d[n++] = pack_slice<S>(li, base, eu0.w + DX, nullptr, H1, DX, EIN, HC::OB, H1, false);
-      d[n++] = pack_slice<S>(li, base, fu0.w, fu0.b, MH, DX, MIN, HC::OF, MH, false);
-      d[n++] = pack_slice<S>(li, base, pa0.w, pa0.b, MH, DX, MIN, HC::OP, MH, false);
-      d[n++] = pack_slice<S>(li, base, knn ? pw->knn_conv.lin : nullptr, nullptr, DX, DX, DX, HC::OG, DX, false);
-    };
-    d[n++] = pack_slice<Proj0Seq2<DB>>(0, w.wp_proj0, fu0.w + DX + DE, nullptr, MH, DX, MIN, 0, MH, false);    // x0 columns
-    d[n++] = pack_slice<Proj0Seq2<DB>>(0, w.wp_proj0, pa0.w + DX + DE, nullptr, MH, DX, MIN, MH, MH, false);
-    proj(Proj0Seq2<DB>{}, 1, w.wp_proj0);
-    for (int i = 0; i < 3; ++i) F(NodeFwdHSeq<DB>{}, i, w.wp_nfwd_h, CF0 + i);
-    proj(NodeFwdHSeq<DB>{}, 3, w.wp_nfwd_h);
-    using EH = HC::EdgeFwdSeq;
-    d[n++] = pack_slice<EH>(0, w.wp_efwd_h, eu0.w + 2 * DX, nullptr, H1, KE, EIN, 0, H1, false);     // e | att columns of edge_update.0
-    F(EH{}, 1, w.wp_efwd_h, EU1); F(EH{}, 2, w.wp_efwd_h, EU2);
-    d[n++] = pack_slice<EH>(3, w.wp_efwd_h, fu0.w + DX, nullptr, MH, DE, MIN, 0, MH, false);          // e' columns
-    F(EH{}, 4, w.wp_efwd_h, FU1);
-    d[n++] = pack_slice<EH>(5, w.wp_efwd_h, pa0.w + DX, nullptr, MH, DE, MIN, 0, MH, false);
-    F(EH{}, 6, w.wp_efwd_h, PA1);
-    const LinPtrs& a0 = L[AT0];                               // att_edge_encoder.0 [512, 640]
-    for (int k = 0; k < 3; ++k) {
-      d[n++] = pack_slice<SeqAttU>(k, w.wp_attU, a0.w + 96 * k, k == 0 ? a0.b : nullptr, 512, 96, 640, 0, 512, false);
-      d[n++] = pack_slice<SeqAttU>(k, w.wp_attU, a0.w + XS + 96 * k, nullptr, 512, 96, 640, 512, 512, false);
-    }
-    for (int cc = 0; cc < 4; ++cc)
-      d[n++] = pack_slice<Att0Seq>(cc, w.wp_att0, a0.w + (size_t)128 * cc * 640 + 2 * XS, nullptr, 128, 64, 640, 0, 128, false);
+  constexpr int DX = DB::DX, DE = DB::DE, EIN = DB::EIN, MIN = DB::MIN, H1 = DB::EH1, MH = DB::MH;
+  const LinPtrs &eu0 = L[EU0], &fu0 = L[FU0], &pa0 = L[PA0];
+  // per-node table T = (eu0[:, x_i] x + b | eu0[:, x_j] x | fu0[:, x] x + b | pa0[:, x] x + b | GATConv.lin x)
+  auto proj = [&](auto tag, int li, float* base) {
+    using S = decltype(tag);
+    d[n++] = pack_slice<S>(li, base, eu0.w, eu0.b, H1, DX, EIN, HC::OA, H1, false);
+    d[n++] = pack_slice<S>(li, base, eu0.w + DX, nullptr, H1, DX, EIN, HC::OB, H1, false);
+    d[n++] = pack_slice<S>(li, base, fu0.w, fu0.b, MH, DX, MIN, HC::OF, MH, false);
+    d[n++] = pack_slice<S>(li, base, pa0.w, pa0.b, MH, DX, MIN, HC::OP, MH, false);
+    d[n++] = pack_slice<S>(li, base, knn ? pw->knn_conv.lin : nullptr, nullptr, DX, DX, DX, HC::OG, DX, false);
+  };
+  d[n++] = pack_slice<Proj0Seq2<DB>>(0, w.wp_proj0, fu0.w + DX + DE, nullptr, MH, DX, MIN, 0, MH, false);    // x0 columns
+  d[n++] = pack_slice<Proj0Seq2<DB>>(0, w.wp_proj0, pa0.w + DX + DE, nullptr, MH, DX, MIN, MH, MH, false);
+  proj(Proj0Seq2<DB>{}, 1, w.wp_proj0);
+  for (int i = 0; i < 3; ++i) F(NodeFwdHSeq<DB>{}, i, w.wp_nfwd_h, CF0 + i);
+  proj(NodeFwdHSeq<DB>{}, 3, w.wp_nfwd_h);
+  const LinPtrs& a0 = L[AT0];                               // att_edge_encoder.0 [512, 640]
+  for (int k = 0; k < 3; ++k) {
+    d[n++] = pack_slice<SeqAttU>(k, w.wp_attU, a0.w + 96 * k, k == 0 ? a0.b : nullptr, 512, 96, 640, 0, 512, false);
+    d[n++] = pack_slice<SeqAttU>(k, w.wp_attU, a0.w + XS + 96 * k, nullptr, 512, 96, 640, 512, 512, false);
   }
+  for (int cc = 0; cc < 4; ++cc)
+    d[n++] = pack_slice<Att0Seq>(cc, w.wp_att0, a0.w + (size_t)128 * cc * 640 + 2 * XS, nullptr, 128, 64, 640, 0, 128, false);
   if (training) {
     T(SeqClsT{}, 0, w.wp_clsT, C3); T(SeqClsT{}, 1, w.wp_clsT, C2); T(SeqClsT{}, 2, w.wp_clsT, C1); T(SeqClsT{}, 3, w.wp_clsT, C0);
     T(SeqEET{}, 0, w.wp_eeT, EE2); T(SeqEET{}, 1, w.wp_eeT, EE1);
@@ -446,81 +415,56 @@ static int pack_all(const b3d_clr_weights* pw, Ws& w, bool training, bool knn, h
     T(SeqAffT<96>{}, 0, w.wp_affT[0], AOC); T(SeqAffT<96>{}, 1, w.wp_affT[0], AVC);
     T(SeqAffT<128>{}, 0, w.wp_affT[1], AOL); T(SeqAffT<128>{}, 1, w.wp_affT[1], AVL);
     T(SeqAffT<64>{}, 0, w.wp_affT[2], AOR); T(SeqAffT<64>{}, 1, w.wp_affT[2], AVR);
-    T(SeqAT0T{}, 0, w.wp_atT[0], AT0); T(SeqAT1T{}, 0, w.wp_atT[1], AT1); T(SeqAT2T{}, 0, w.wp_atT[2], AT2);
+    T(SeqAT1T{}, 0, w.wp_atT[1], AT1); T(SeqAT2T{}, 0, w.wp_atT[2], AT2);
     T(SeqAT3T{}, 0, w.wp_atT[3], AT3); T(SeqAT4T{}, 0, w.wp_atT[4], AT4);
-    using EB = D::EdgeBwdSeq;
-    T(EB{}, 0, w.wp_ebwd, PA1); T(EB{}, 1, w.wp_ebwd, PA0); T(EB{}, 2, w.wp_ebwd, FU1); T(EB{}, 3, w.wp_ebwd, FU0);
-    T(EB{}, 4, w.wp_ebwd, EU2); T(EB{}, 5, w.wp_ebwd, EU1); T(EB{}, 6, w.wp_ebwd, EU0);
-    using EN = D::EdgeBwdSeqNoMsg;
-    T(EN{}, 0, w.wp_ebwd_nm, EU2); T(EN{}, 1, w.wp_ebwd_nm, EU1); T(EN{}, 2, w.wp_ebwd_nm, EU0);
     using NB = D::NodeBwdSeq;
     T(NB{}, 0, w.wp_nbwd, CF2); T(NB{}, 1, w.wp_nbwd, CF1); T(NB{}, 2, w.wp_nbwd, CF0);
-    if (w.hoist) {
-      constexpr int DX = DB::DX, DE = DB::DE, EIN = DB::EIN, MIN = DB::MIN, H1 = DB::EH1, MH = DB::MH, KE = HC::KE;
-      const LinPtrs &eu0 = L[EU0], &fu0 = L[FU0], &pa0 = L[PA0];
-      // data-gradient images: full transposes, except the .0 layers, which keep their per-edge columns
-      auto TS = [&](auto tag, int li, float* base, const float* wcol, int ld, int rows_in, int cols_out) {
-        using S = decltype(tag);
-        d[n++] = pack_slice<S>(li, base, wcol, nullptr, rows_in, cols_out, ld, 0, S::np(li), true);
-      };
-      using EB2 = HC::EdgeBwdSeq;
-      T(EB2{}, 0, w.wp_ebwd_h, PA1); TS(EB2{}, 1, w.wp_ebwd_h, pa0.w + DX, MIN, DE, MH);
-      T(EB2{}, 2, w.wp_ebwd_h, FU1); TS(EB2{}, 3, w.wp_ebwd_h, fu0.w + DX, MIN, DE, MH);
-      T(EB2{}, 4, w.wp_ebwd_h, EU2); T(EB2{}, 5, w.wp_ebwd_h, EU1); TS(EB2{}, 6, w.wp_ebwd_h, eu0.w + 2 * DX, EIN, KE, H1);
-      using EN2 = HC::EdgeBwdSeqNoMsg;
-      T(EN2{}, 0, w.wp_ebwd_nm_h, EU2); T(EN2{}, 1, w.wp_ebwd_nm_h, EU1); TS(EN2{}, 2, w.wp_ebwd_nm_h, eu0.w + 2 * DX, EIN, KE, H1);
-      // (dx | dx0) = sum over the four lists of (node columns)^T . dT_list: rows 0:DX from the x columns, rows DX:2DX
-      // (future / past only) from the x0 columns
-      using NH = NodeBwdHSeq<DB>;
-      auto gp = [&](auto tag, float* base) {
-        using S = decltype(tag);
-        d[n++] = pack_slice<S>(0, base, eu0.w, nullptr, DX, H1, EIN, 0, DX, true);
-        d[n++] = pack_slice<S>(1, base, eu0.w + DX, nullptr, DX, H1, EIN, 0, DX, true);
-        d[n++] = pack_slice<S>(2, base, fu0.w, nullptr, DX, MH, MIN, 0, DX, true);
-        d[n++] = pack_slice<S>(2, base, fu0.w + DX + DE, nullptr, DX, MH, MIN, DX, DX, true);
-        d[n++] = pack_slice<S>(3, base, pa0.w, nullptr, DX, MH, MIN, 0, DX, true);
-        d[n++] = pack_slice<S>(3, base, pa0.w + DX + DE, nullptr, DX, MH, MIN, DX, DX, true);
-      };
-      gp(NH{}, w.wp_nbwd_h);
-      gp(HC::GradProjSeq{}, w.wp_gproj);
-      T(NH{}, 4, w.wp_nbwd_h, CF2); T(NH{}, 5, w.wp_nbwd_h, CF1); T(NH{}, 6, w.wp_nbwd_h, CF0);
-      const LinPtrs& a0 = L[AT0];
-      for (int k = 0; k < 16; ++k)                             // slice k: 64 columns of dU_i (k < 8) or dU_j
-        d[n++] = pack_slice<SeqAttDs>(k, w.wp_attDs, a0.w + (size_t)64 * (k & 7) * 640 + (k < 8 ? 0 : XS), nullptr, XS, 64, 640, 0, XS, true);
-      d[n++] = pack_slice<SeqAT0eT>(0, w.wp_at0eT, a0.w + 2 * XS, nullptr, 64, 512, 640, 0, 64, true);
-    }
+    // (dx | dx0) = sum over the four lists of (node columns)^T . dT_list: rows 0:DX from the x columns, rows DX:2DX
+    // (future / past only) from the x0 columns
+    using NH = NodeBwdHSeq<DB>;
+    auto gp = [&](auto tag, float* base) {
+      using S = decltype(tag);
+      d[n++] = pack_slice<S>(0, base, eu0.w, nullptr, DX, H1, EIN, 0, DX, true);
+      d[n++] = pack_slice<S>(1, base, eu0.w + DX, nullptr, DX, H1, EIN, 0, DX, true);
+      d[n++] = pack_slice<S>(2, base, fu0.w, nullptr, DX, MH, MIN, 0, DX, true);
+      d[n++] = pack_slice<S>(2, base, fu0.w + DX + DE, nullptr, DX, MH, MIN, DX, DX, true);
+      d[n++] = pack_slice<S>(3, base, pa0.w, nullptr, DX, MH, MIN, 0, DX, true);
+      d[n++] = pack_slice<S>(3, base, pa0.w + DX + DE, nullptr, DX, MH, MIN, DX, DX, true);
+    };
+    gp(NH{}, w.wp_nbwd_h);
+    gp(HC::GradProjSeq{}, w.wp_gproj);
+    T(NH{}, 4, w.wp_nbwd_h, CF2); T(NH{}, 5, w.wp_nbwd_h, CF1); T(NH{}, 6, w.wp_nbwd_h, CF0);
+    for (int k = 0; k < 16; ++k)                             // slice k: 64 columns of dU_i (k < 8) or dU_j
+      d[n++] = pack_slice<SeqAttDs>(k, w.wp_attDs, a0.w + (size_t)64 * (k & 7) * 640 + (k < 8 ? 0 : XS), nullptr, XS, 64, 640, 0, XS, true);
+    d[n++] = pack_slice<SeqAT0eT>(0, w.wp_at0eT, a0.w + 2 * XS, nullptr, 64, 512, 640, 0, 64, true);
   }
   if (n > 224) return fail(B3D_ERR_ARG, "pack descriptor table overflow");
   B3D_TRY(pack_images(d, n, stream));
-  if (w.edge2) {
-    constexpr int DX = DB::DX, EIN = DB::EIN, MIN = DB::MIN;
-    const LinPtrs &eu0 = L[EU0], &fu0 = L[FU0], &pa0 = L[PA0];
-    FragDesc f[kFragMax];
-    int m = 0;
-    using FS = ES::Fwd;
-    f[m++] = frag_desc<FS>(0, w.wp_efwd2, eu0.w + 2 * DX, nullptr, EIN, false);        // e | att columns (bias: in the table T)
-    f[m++] = frag_desc<FS>(1, w.wp_efwd2, L[EU1].w, L[EU1].b, kDims[EU1].K, false);
-    f[m++] = frag_desc<FS>(2, w.wp_efwd2, L[EU2].w, L[EU2].b, kDims[EU2].K, false);
-    f[m++] = frag_desc<FS>(3, w.wp_efwd2, fu0.w + DX, nullptr, MIN, false);             // e' columns
-    f[m++] = frag_desc<FS>(4, w.wp_efwd2, L[FU1].w, L[FU1].b, kDims[FU1].K, false);
-    f[m++] = frag_desc<FS>(5, w.wp_efwd2, pa0.w + DX, nullptr, MIN, false);
-    f[m++] = frag_desc<FS>(6, w.wp_efwd2, L[PA1].w, L[PA1].b, kDims[PA1].K, false);
-    if (training) {
-      using BS = ES::Bwd;
-      f[m++] = frag_desc<BS>(0, w.wp_ebwd2, L[PA1].w, nullptr, kDims[PA1].K, true);
-      f[m++] = frag_desc<BS>(1, w.wp_ebwd2, pa0.w + DX, nullptr, MIN, true);
-      f[m++] = frag_desc<BS>(2, w.wp_ebwd2, L[FU1].w, nullptr, kDims[FU1].K, true);
-      f[m++] = frag_desc<BS>(3, w.wp_ebwd2, fu0.w + DX, nullptr, MIN, true);
-      f[m++] = frag_desc<BS>(4, w.wp_ebwd2, L[EU2].w, nullptr, kDims[EU2].K, true);
-      f[m++] = frag_desc<BS>(5, w.wp_ebwd2, L[EU1].w, nullptr, kDims[EU1].K, true);
-      f[m++] = frag_desc<BS>(6, w.wp_ebwd2, eu0.w + 2 * DX, nullptr, EIN, true);
-      using NS = ES::BwdNoMsg;
-      f[m++] = frag_desc<NS>(0, w.wp_ebwd_nm2, L[EU2].w, nullptr, kDims[EU2].K, true);
-      f[m++] = frag_desc<NS>(1, w.wp_ebwd_nm2, L[EU1].w, nullptr, kDims[EU1].K, true);
-      f[m++] = frag_desc<NS>(2, w.wp_ebwd_nm2, eu0.w + 2 * DX, nullptr, EIN, true);
-    }
-    B3D_TRY(pack_frags(f, m, stream));
+  FragDesc f[kFragMax];
+  int m = 0;
+  using FS = ES::Fwd;
+  f[m++] = frag_desc<FS>(0, w.wp_efwd2, eu0.w + 2 * DX, nullptr, EIN, false);        // e | att columns (bias: in the table T)
+  f[m++] = frag_desc<FS>(1, w.wp_efwd2, L[EU1].w, L[EU1].b, kDims[EU1].K, false);
+  f[m++] = frag_desc<FS>(2, w.wp_efwd2, L[EU2].w, L[EU2].b, kDims[EU2].K, false);
+  f[m++] = frag_desc<FS>(3, w.wp_efwd2, fu0.w + DX, nullptr, MIN, false);             // e' columns
+  f[m++] = frag_desc<FS>(4, w.wp_efwd2, L[FU1].w, L[FU1].b, kDims[FU1].K, false);
+  f[m++] = frag_desc<FS>(5, w.wp_efwd2, pa0.w + DX, nullptr, MIN, false);
+  f[m++] = frag_desc<FS>(6, w.wp_efwd2, L[PA1].w, L[PA1].b, kDims[PA1].K, false);
+  if (training) {
+    using BS = ES::Bwd;
+    f[m++] = frag_desc<BS>(0, w.wp_ebwd2, L[PA1].w, nullptr, kDims[PA1].K, true);
+    f[m++] = frag_desc<BS>(1, w.wp_ebwd2, pa0.w + DX, nullptr, MIN, true);
+    f[m++] = frag_desc<BS>(2, w.wp_ebwd2, L[FU1].w, nullptr, kDims[FU1].K, true);
+    f[m++] = frag_desc<BS>(3, w.wp_ebwd2, fu0.w + DX, nullptr, MIN, true);
+    f[m++] = frag_desc<BS>(4, w.wp_ebwd2, L[EU2].w, nullptr, kDims[EU2].K, true);
+    f[m++] = frag_desc<BS>(5, w.wp_ebwd2, L[EU1].w, nullptr, kDims[EU1].K, true);
+    f[m++] = frag_desc<BS>(6, w.wp_ebwd2, eu0.w + 2 * DX, nullptr, EIN, true);
+    using NS = ES::BwdNoMsg;
+    f[m++] = frag_desc<NS>(0, w.wp_ebwd_nm2, L[EU2].w, nullptr, kDims[EU2].K, true);
+    f[m++] = frag_desc<NS>(1, w.wp_ebwd_nm2, L[EU1].w, nullptr, kDims[EU1].K, true);
+    f[m++] = frag_desc<NS>(2, w.wp_ebwd_nm2, eu0.w + 2 * DX, nullptr, EIN, true);
   }
+  B3D_TRY(pack_frags(f, m, stream));
   return B3D_OK;
 }
 
@@ -556,9 +500,9 @@ static int affine_fwd(Ws& w, int m, int N, int xc, int sc, hipStream_t stream) {
   return launch_rows<kNWNode>(chain_fwd_kernel<SeqAff<DD>, 0u, In, Out, kNWNode>, "modality_affine", a, N, stream, B3D_K_OTHER, chain_lds<SeqAff<DD>>());
 }
 
-// backward of one modality: G_out = segment sums of d s_i / d s_j columns; d x_m -> dxs[:, xc : xc+DD]
+// backward of one modality: d s[:, sc : sc+DD] -> d x_m = dxs[:, xc : xc+DD]
 template <int DD>
-static int affine_bwd_h(Ws& w, int m, int N, int xc, int sc, hipStream_t stream) {      // d s comes per node (att hoisted)
+static int affine_bwd(Ws& w, int m, int N, int xc, int sc, hipStream_t stream) {      // d s arrives per node (att_edge_encoder.0 is hoisted)
   using In = LoadAligned<DD / 16>;
   using Out = StoreAligned<DD / 16>;
   ChainBwdArgs<In, Out> a;
@@ -571,21 +515,6 @@ static int affine_bwd_h(Ws& w, int m, int N, int xc, int sc, hipStream_t stream)
   a.wpack = w.wp_affT[m];
   return launch_rows<kNWNode>(chain_bwd_kernel<SeqAffT<DD>, In, Out, kNWNode>, "modality_affine_bwd", a, N, stream, B3D_K_OTHER, chain_lds<SeqAffT<DD>>());
 }
-template <int DD>
-static int affine_bwd(Ws& w, const b3d_graph* g, int m, int N, int xc, int sc, hipStream_t stream) {
-  using In = LoadSegSum2<DD / 16>;
-  using Out = StoreAligned<DD / 16>;
-  ChainBwdArgs<In, Out> a;
-  memset(&a, 0, sizeof(a));
-  a.rows = N;
-  a.in = In{w.dIn, 640, sc, XS + sc, g->dst_ptr, g->dst_perm, g->src_ptr, g->src_perm};
-  a.out = Out{w.dxs, nullptr, XS, xc};
-  a.gtop = w.gaff_top[m];
-  a.gsave[0] = w.gaff_v[m];
-  a.wpack = w.wp_affT[m];
-  return launch_rows<kNWNode>(chain_bwd_kernel<SeqAffT<DD>, In, Out, kNWNode>, "modality_affine_bwd", a, N, stream, B3D_K_OTHER, chain_lds<SeqAffT<DD>>());
-}
-
 }  // namespace clr
 }  // namespace b3d
 
@@ -593,11 +522,7 @@ using namespace b3d;
 using namespace b3d::clr;
 
 extern "C" uint32_t b3d_features(void) {
-  uint32_t f = 0;
-  const char* e = getenv("B3D_HOIST");
-  if (!e || atoi(e) != 0) f |= B3D_FEATURE_POSE_HOIST;
-  if (b3d::clr::hoist_enabled()) f |= B3D_FEATURE_CLR_HOIST_MP | B3D_FEATURE_CLR_HOIST_ATT;
-  return f;
+  return B3D_FEATURE_POSE_HOIST | B3D_FEATURE_CLR_HOIST_MP | B3D_FEATURE_CLR_HOIST_ATT;
 }
 
 extern "C" int b3d_modality_mask(const float* feats, int32_t N, int32_t width, uint8_t* has, b3d_stream stream_) {
@@ -695,16 +620,10 @@ extern "C" int b3d_clr_forward(const b3d_clr_weights* pw, const b3d_graph* g, co
     B3D_TRY(launch_rows<kNWEdge>(chain_fwd_kernel<SeqEE, 0x3u, LoadEdgeAttrF64, StoreAligned<4>, kNWEdge>, "edge_encoder", a, E, stream, B3D_K_OTHER, chain_lds<SeqEE>()));
   }
   {  // att_edge_encoder( s[dst] | s[src] | e ) 640-512-384-256-128-64 (:161-164)
-    using In0 = LoadConcat3<18, 18, 4>;
-    In0 i0{LoadAligned<18>{w.s, g->dst, XS, 0}, LoadAligned<18>{w.s, g->src, XS, 0}, LoadAligned<4>{w.e[0], nullptr, D::DE, 0}};
-    if (w.hoist) {
-      B3D_TRY(node_linear<SeqAttU>("att_node_linear", w.s, XS, 0, w.U, 1024, N, w.wp_attU, stream, B3D_K_ATT_FWD));
-      Att0FwdArgs fa;
-      fa.E = E; fa.src = g->src; fa.dst = g->dst; fa.U = w.U; fa.e0 = w.e[0]; fa.A0 = w.A[0]; fa.wpack = w.wp_att0;
-      B3D_TRY(launch_rows<kNWEdge>(att0_fwd_kernel<kNWEdge>, "att_edge_encoder.0", fa, E, stream, B3D_K_ATT_FWD, stream_lds_bytes<Att0Seq>()));
-    } else {
-      B3D_TRY((wide<SeqAT0, true, true>("att_edge_encoder.0", i0, E, w.A[0], 512, 0, nullptr, w.wp_at[0], stream)));
-    }
+    B3D_TRY(node_linear<SeqAttU>("att_node_linear", w.s, XS, 0, w.U, 1024, N, w.wp_attU, stream, B3D_K_ATT_FWD));
+    Att0FwdArgs fa;
+    fa.E = E; fa.src = g->src; fa.dst = g->dst; fa.U = w.U; fa.e0 = w.e[0]; fa.A0 = w.A[0]; fa.wpack = w.wp_att0;
+    B3D_TRY(launch_rows<kNWEdge>(att0_fwd_kernel<kNWEdge>, "att_edge_encoder.0", fa, E, stream, B3D_K_ATT_FWD, stream_lds_bytes<Att0Seq>()));
     B3D_TRY((wide<SeqAT1, true, true>("att_edge_encoder.2", LoadAligned<32>{w.A[0], nullptr, 512, 0}, E, w.A[1], 384, 0, nullptr, w.wp_at[1], stream)));
     B3D_TRY((wide<SeqAT2, true, true>("att_edge_encoder.4", LoadAligned<24>{w.A[1], nullptr, 384, 0}, E, w.A[2], 256, 0, nullptr, w.wp_at[2], stream)));
     B3D_TRY((wide<SeqAT3, true, true>("att_edge_encoder.6", LoadAligned<16>{w.A[2], nullptr, 256, 0}, E, w.A[3], 128, 0, nullptr, w.wp_at[3], stream)));
@@ -717,11 +636,10 @@ extern "C" int b3d_clr_forward(const b3d_clr_weights* pw, const b3d_graph* g, co
     a.save_in = w.pose_pad; a.save[0] = w.ne_a1; a.wpack = w.wp_ne;
     B3D_TRY(launch_rows<kNWNode>(chain_fwd_kernel<SeqNE, 0x1u, LoadUnaligned<19>, StoreAligned<6>, kNWNode>, "node_encoder", a, N, stream, B3D_K_OTHER, chain_lds<SeqNE>()));
   }
-  if (w.hoist) {  // x0 terms of the future / past columns (once per forward) + the per-node table of layer 0
-    NodeProj0Args a;
-    a.N = N; a.x0 = w.x[0]; a.T0 = w.T0; a.T = w.T; a.wpack = w.wp_proj0;
-    B3D_TRY(launch_node_split<DB>(node_proj0_split_kernel<DB>, "node_proj0", a, N, stream, B3D_K_OTHER));
-  }
+  // x0 terms of the future / past columns (once per forward) + the per-node table of layer 0
+  NodeProj0Args a;
+  a.N = N; a.x0 = w.x[0]; a.T0 = w.T0; a.T = w.T; a.wpack = w.wp_proj0;
+  B3D_TRY(launch_node_split<DB>(node_proj0_split_kernel<DB>, "node_proj0", a, N, stream, B3D_K_OTHER));
   Side* knn_side = nullptr;
   for (int l = 0; l < depth; ++l) {
     if ((flags & B3D_FLAG_RUN_DEAD_KNN) && (l % 2 == 0)) {
@@ -733,42 +651,27 @@ extern "C" int b3d_clr_forward(const b3d_clr_weights* pw, const b3d_graph* g, co
         ks = knn_side->s;
       }
       // on the launch stream the block reads GATConv.lin(x[l]) from the per-node table
-      const bool pre = w.hoist && ks == stream;
+      const bool pre = ks == stream;
       B3D_TRY(knn_gat_block<D::DX>(w.knn, w.x[l], in->node_timestamps, N, pw->knn_conv, 20, ks, pre ? w.T + HC::OG : nullptr, HC::TW));
     }
     NodeFwdArgs na;
     memset(&na, 0, sizeof(na));
     na.N = N; na.dst_ptr = g->dst_ptr; na.dst_perm = g->dst_perm; na.src_ptr = g->src_ptr; na.src_perm = g->src_perm;
     na.past = w.past; na.fut = w.fut; na.M = w.M[l]; na.x_out = w.x[l + 1]; na.sH1 = w.nH1[l]; na.sH2 = w.nH2[l];
-    if (w.hoist) {
-      EdgeFwdHArgs ea;
-      memset(&ea, 0, sizeof(ea));
-      ea.E = E; ea.src = g->src; ea.dst = g->dst; ea.T = w.T; ea.e_in = w.e[l]; ea.a_in = w.att;
-      ea.e_out = w.e[l + 1]; ea.fut = w.fut; ea.past = w.past;
-      ea.sH1 = w.sH1[l]; ea.sH2 = w.sH2[l]; ea.sF1 = w.sF1[l]; ea.sP1 = w.sP1[l]; ea.wpack = w.wp_efwd_h;
-      if (w.edge2) {
-        ea.wpack = w.wp_efwd2;
-        if (tr) B3D_TRY(launch_rows<es::kWaves>(es::edge_fwd_kernel<DB, true>, "edge_fwd", ea, E, stream, B3D_K_EDGE_FWD, ES::Fwd::LDS_BYTES));
-        else B3D_TRY(launch_rows<es::kWaves>(es::edge_fwd_kernel<DB, false>, "edge_fwd", ea, E, stream, B3D_K_EDGE_FWD, ES::Fwd::LDS_BYTES));
-      } else
-      B3D_TRY(launch_rows<kNWEdge>(mp_edge_fwd_h_kernel<DB, kNWEdge>, "mp_edge_fwd", ea, E, stream, B3D_K_EDGE_FWD, stream_lds_bytes<HC::EdgeFwdSeq>()));
-      if (l + 1 < depth) {                                   // + the per-node table the next layer's edge phase gathers
-        na.wpack = w.wp_nfwd_h; na.T = w.T; na.T0 = w.T0;
-        B3D_TRY((launch_node_split<DB, kNodeWavesWide>(mp_node_fwd_split_h_kernel<DB>, "mp_node_fwd", na, N, stream, B3D_K_NODE_FWD)));
-      } else {
-        na.wpack = w.wp_nfwd;
-        B3D_TRY((launch_node_split<D, kNodeWavesWide>(mp_node_fwd_split_kernel<D, kNodeWavesWide>, "mp_node_fwd", na, N, stream, B3D_K_NODE_FWD)));
-      }
-      continue;
-    }
-    EdgeFwdArgs ea;
+    EdgeFwdHArgs ea;
     memset(&ea, 0, sizeof(ea));
-    ea.E = E; ea.src = g->src; ea.dst = g->dst; ea.x = w.x[l]; ea.x0 = w.x[0]; ea.e_in = w.e[l]; ea.a_in = w.att;
+    ea.E = E; ea.src = g->src; ea.dst = g->dst; ea.T = w.T; ea.e_in = w.e[l]; ea.a_in = w.att;
     ea.e_out = w.e[l + 1]; ea.fut = w.fut; ea.past = w.past;
-    ea.sH1 = w.sH1[l]; ea.sH2 = w.sH2[l]; ea.sF1 = w.sF1[l]; ea.sP1 = w.sP1[l]; ea.wpack = w.wp_efwd;
-    B3D_TRY(launch_rows<kNWEdge>(mp_edge_fwd_kernel<D, kNWEdge>, "mp_edge_fwd", ea, E, stream, B3D_K_EDGE_FWD));
-    na.wpack = w.wp_nfwd;
-    B3D_TRY(launch_node_split<D>(mp_node_fwd_split_kernel<D>, "mp_node_fwd", na, N, stream, B3D_K_NODE_FWD));
+    ea.sH1 = w.sH1[l]; ea.sH2 = w.sH2[l]; ea.sF1 = w.sF1[l]; ea.sP1 = w.sP1[l]; ea.wpack = w.wp_efwd2;
+    if (tr) B3D_TRY(launch_rows<es::kWaves>(es::edge_fwd_kernel<DB, true>, "edge_fwd", ea, E, stream, B3D_K_EDGE_FWD, ES::Fwd::LDS_BYTES));
+    else B3D_TRY(launch_rows<es::kWaves>(es::edge_fwd_kernel<DB, false>, "edge_fwd", ea, E, stream, B3D_K_EDGE_FWD, ES::Fwd::LDS_BYTES));
+    if (l + 1 < depth) {                                   // + the per-node table the next layer's edge phase gathers
+      na.wpack = w.wp_nfwd_h; na.T = w.T; na.T0 = w.T0;
+      B3D_TRY((launch_node_split<DB, kNodeWavesWide>(mp_node_fwd_split_h_kernel<DB>, "mp_node_fwd", na, N, stream, B3D_K_NODE_FWD)));
+    } else {
+      na.wpack = w.wp_nfwd;
+      B3D_TRY((launch_node_split<D, kNodeWavesWide>(mp_node_fwd_split_kernel<D, kNodeWavesWide>, "mp_node_fwd", na, N, stream, B3D_K_NODE_FWD)));
+    }
   }
   {  // edge classifier 64-32-16-8-1 + Sigmoid (:49-58,188)
     ChainFwdArgs<LoadAligned<4>, StoreScalar> a;
@@ -799,8 +702,8 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
   const size_t EP = edge_rows(E);           // per-edge buffers are padded to whole 64-row tiles (carve)
   const size_t eL1 = EP * D::EH1, eL2 = EP * D::EH2, eLe = EP * D::DE, eLm = EP * D::MH;
   const size_t nLm = (size_t)N * D::NIN, nLx = (size_t)N * D::DX, nL1 = (size_t)N * D::NH1, nL2 = (size_t)N * D::NH2;
-  WgArgs smallE, smallN, fc;       // LDS-staged weight gradients of the narrow / unaligned layers
-  smallE.njobs = smallN.njobs = fc.njobs = 0;
+  WgArgs smallE, smallN;           // LDS-staged weight gradients of the narrow / unaligned layers
+  smallE.njobs = smallN.njobs = 0;
 
   // ---- classifier (with the sigmoid derivative) -> d e[depth] --------------------------------------
   int cur = 0;
@@ -837,7 +740,7 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
   };
   for (int l = depth - 1; l >= 0; --l) {
     const bool msgs = (l < depth - 1);
-    if (msgs && w.hoist) {
+    if (msgs) {
       B3D_TRY(listsum(l + 1));
       NodeBwdGArgs nb;
       memset(&nb, 0, sizeof(nb));
@@ -853,106 +756,58 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
       }
       B3D_TRY(launch_check("node_bwd_g_kernel"));
       dx0_first = false;
-    } else if (msgs) {
-      NodeBwdArgs nb;
-      memset(&nb, 0, sizeof(nb));
-      nb.N = N; nb.dst_ptr = g->dst_ptr; nb.dst_perm = g->dst_perm; nb.src_ptr = g->src_ptr; nb.src_perm = g->src_perm;
-      nb.gdst = w.gdst; nb.gsrc = w.gsrc; nb.dx0_acc = w.dx0_acc; nb.dx0_first = dx0_first ? 1 : 0;
-      nb.sH1 = w.nH1[l]; nb.sH2 = w.nH2[l];
-      nb.dM = w.dM + l * nLm; nb.Gdx = w.Gdx + l * nLx; nb.GdH2 = w.GnH2 + l * nL2; nb.GdH1 = w.GnH1 + l * nL1;
-      nb.wpack = w.wp_nbwd;
-      B3D_TRY(launch_node_split<D>(mp_node_bwd_split_kernel<D>, "mp_node_bwd", nb, N, stream, B3D_K_NODE_BWD));
-      dx0_first = false;
     }
-    if (w.hoist) {
-      EdgeBwdHArgs eb;
-      memset(&eb, 0, sizeof(eb));
-      eb.E = E; eb.src = src; eb.dst = dst;
-      eb.dM = msgs ? w.dM + l * nLm : nullptr;
-      eb.de_out = w.de[cur]; eb.de_in = w.de[cur ^ 1];
-      eb.sH1 = w.sH1[l]; eb.sH2 = w.sH2[l]; eb.sF1 = w.sF1[l]; eb.sP1 = w.sP1[l];
-      eb.da_acc = w.da_acc; eb.da_first = da_first ? 1 : 0;
-      eb.GdH1 = w.GdH1 + l * eL1; eb.GdH2 = w.GdH2 + l * eL2; eb.Gde = w.Gde + l * eLe;
-      eb.GdF1 = w.GdF1 + l * eLm; eb.GdP1 = w.GdP1 + l * eLm;
-      if (w.edge2 && msgs) {
-        eb.wpack = w.wp_ebwd2;
-        B3D_TRY(launch_rows<es::kWaves>(es::edge_bwd_kernel<DB, true>, "edge_bwd", eb, E, stream, B3D_K_EDGE_BWD, ES::Bwd::LDS_BYTES));
-      } else if (w.edge2) {
-        eb.wpack = w.wp_ebwd_nm2;
-        B3D_TRY(launch_rows<es::kWaves>(es::edge_bwd_kernel<DB, false>, "edge_bwd_last", eb, E, stream, B3D_K_EDGE_BWD, ES::BwdNoMsg::LDS_BYTES));
-      } else if (msgs) {
-        eb.wpack = w.wp_ebwd_h;
-        B3D_TRY(launch_rows<kNWEdge>(mp_edge_bwd_h_kernel<DB, true, kNWEdge>, "mp_edge_bwd", eb, E, stream, B3D_K_EDGE_BWD, stream_lds_bytes<HC::EdgeBwdSeq>()));
-      } else {
-        eb.wpack = w.wp_ebwd_nm_h;
-        B3D_TRY(launch_rows<kNWEdge>(mp_edge_bwd_h_kernel<DB, false, kNWEdge>, "mp_edge_bwd_last", eb, E, stream, B3D_K_EDGE_BWD, stream_lds_bytes<HC::EdgeBwdSeqNoMsg>()));
-      }
-      da_first = false;
-      cur ^= 1;
-      continue;
-    }
-    EdgeBwdArgs eb;
+    EdgeBwdHArgs eb;
     memset(&eb, 0, sizeof(eb));
     eb.E = E; eb.src = src; eb.dst = dst;
     eb.dM = msgs ? w.dM + l * nLm : nullptr;
     eb.de_out = w.de[cur]; eb.de_in = w.de[cur ^ 1];
     eb.sH1 = w.sH1[l]; eb.sH2 = w.sH2[l]; eb.sF1 = w.sF1[l]; eb.sP1 = w.sP1[l];
     eb.da_acc = w.da_acc; eb.da_first = da_first ? 1 : 0;
-    eb.gdst = w.gdst; eb.gsrc = w.gsrc;
     eb.GdH1 = w.GdH1 + l * eL1; eb.GdH2 = w.GdH2 + l * eL2; eb.Gde = w.Gde + l * eLe;
     eb.GdF1 = w.GdF1 + l * eLm; eb.GdP1 = w.GdP1 + l * eLm;
     if (msgs) {
-      eb.wpack = w.wp_ebwd;
-      B3D_TRY(launch_rows<kNWEdge>(mp_edge_bwd_kernel<D, true, kNWEdge>, "mp_edge_bwd", eb, E, stream, B3D_K_EDGE_BWD));
-    } else {
-      eb.wpack = w.wp_ebwd_nm;
-      B3D_TRY(launch_rows<kNWEdge>(mp_edge_bwd_kernel<D, false, kNWEdge>, "mp_edge_bwd_last", eb, E, stream, B3D_K_EDGE_BWD));
+      eb.wpack = w.wp_ebwd2;
+      B3D_TRY(launch_rows<es::kWaves>(es::edge_bwd_kernel<DB, true>, "edge_bwd", eb, E, stream, B3D_K_EDGE_BWD, ES::Bwd::LDS_BYTES));
+    } else {                                                 // last layer: its node output is not used (only e feeds the classifier)
+      eb.wpack = w.wp_ebwd_nm2;
+      B3D_TRY(launch_rows<es::kWaves>(es::edge_bwd_kernel<DB, false>, "edge_bwd_last", eb, E, stream, B3D_K_EDGE_BWD, ES::BwdNoMsg::LDS_BYTES));
     }
     da_first = false;
     cur ^= 1;
   }
-  if (w.hoist) {   // layer 0's (dx | dx0) for the node encoder
-    B3D_TRY(listsum(0));
-    NodeBwdGArgs nb;
-    memset(&nb, 0, sizeof(nb));
-    nb.N = N; nb.dT = w.dT; nb.gx = w.gx; nb.wpack = w.wp_gproj;
-    B3D_TRY(set_lds(node_bwd_g_kernel<DB, false>, NodeBwdGLds<DB>::BYTES));
-    {
-      ProfScope ps(B3D_K_NODE_BWD, stream);
-      hipLaunchKernelGGL((node_bwd_g_kernel<DB, false>), dim3((N + 15) / 16), dim3(kNodeBwdGWaves * 64), NodeBwdGLds<DB>::BYTES, stream, nb);
-    }
-    B3D_TRY(launch_check("node_bwd_g_kernel"));
+  // layer 0's (dx | dx0) for the node encoder
+  B3D_TRY(listsum(0));
+  NodeBwdGArgs nb;
+  memset(&nb, 0, sizeof(nb));
+  nb.N = N; nb.dT = w.dT; nb.gx = w.gx; nb.wpack = w.wp_gproj;
+  B3D_TRY(set_lds(node_bwd_g_kernel<DB, false>, NodeBwdGLds<DB>::BYTES));
+  {
+    ProfScope ps(B3D_K_NODE_BWD, stream);
+    hipLaunchKernelGGL((node_bwd_g_kernel<DB, false>), dim3((N + 15) / 16), dim3(kNodeBwdGWaves * 64), NodeBwdGLds<DB>::BYTES, stream, nb);
   }
+  B3D_TRY(launch_check("node_bwd_g_kernel"));
 
   // ---- att_edge_encoder backward: d att (summed over the layers) -> d(s[dst] | s[src] | e) ------------
   B3D_TRY((wide<SeqAT4T, false, false>("att_edge_encoder.8^T", LoadAligned<4>{w.da_acc, nullptr, 64, 0}, E, w.dA[0], 128, 0, w.A[3], w.wp_atT[4], stream, B3D_K_ATT_BWD)));
   B3D_TRY((wide<SeqAT3T, false, false>("att_edge_encoder.6^T", LoadAligned<8>{w.dA[0], nullptr, 128, 0}, E, w.dA[1], 256, 0, w.A[2], w.wp_atT[3], stream, B3D_K_ATT_BWD)));
   B3D_TRY((wide<SeqAT2T, false, false>("att_edge_encoder.4^T", LoadAligned<16>{w.dA[1], nullptr, 256, 0}, E, w.dA[2], 384, 0, w.A[1], w.wp_atT[2], stream, B3D_K_ATT_BWD)));
   B3D_TRY((wide<SeqAT1T, false, false>("att_edge_encoder.2^T", LoadAligned<24>{w.dA[2], nullptr, 384, 0}, E, w.dA[3], 512, 0, w.A[0], w.wp_atT[1], stream, B3D_K_ATT_BWD)));
-  if (w.hoist) {
-    // d e0 per edge; d U per node = sums of d A0 over the CSR / CSC lists; d s = W0[:, 0:288]^T dU_i + W0[:, 288:576]^T dU_j
-    B3D_TRY((wide<SeqAT0eT, false, false>("att_edge_encoder.0[e]^T", LoadAligned<32>{w.dA[3], nullptr, 512, 0}, E, w.de0, 64, 0, nullptr, w.wp_at0eT, stream, B3D_K_ATT_BWD)));
-    AttListSumArgs la;
-    la.N = N; la.W = 512; la.dst_ptr = g->dst_ptr; la.dst_perm = g->dst_perm; la.src_ptr = g->src_ptr; la.src_perm = g->src_perm;
-    la.G = w.dA[3]; la.dU = w.dU;
-    {
-      const long tasks = (long)((N + 15) / 16) * 2 * (512 / 64);
-      ProfScope ps(B3D_K_ATT_BWD, stream);
-      hipLaunchKernelGGL(att_listsum_kernel, dim3((unsigned)((tasks + 3) / 4)), dim3(256), 0, stream, la);
-    }
-    B3D_TRY(launch_check("att_listsum_kernel"));
-    B3D_TRY(node_linear<SeqAttDs>("att_node_linear^T", w.dU, 1024, 0, w.ds, XS, N, w.wp_attDs, stream, B3D_K_ATT_BWD));
-    B3D_TRY(affine_bwd_h<96>(w, 0, N, 0, 192, stream));
-    B3D_TRY(affine_bwd_h<128>(w, 1, N, 96, 64, stream));
-    B3D_TRY(affine_bwd_h<64>(w, 2, N, 224, 0, stream));
-  } else {
-  B3D_TRY((wide<SeqAT0T, false, false>("att_edge_encoder.0^T", LoadAligned<32>{w.dA[3], nullptr, 512, 0}, E, w.dIn, 640, 0, nullptr, w.wp_atT[0], stream, B3D_K_ATT_BWD)));
-
-  // ---- modality attention (per node) backward, then the modality heads -------------------------------
-  B3D_TRY(affine_bwd<96>(w, g, 0, N, 0, 192, stream));
-  B3D_TRY(affine_bwd<128>(w, g, 1, N, 96, 64, stream));
-  B3D_TRY(affine_bwd<64>(w, g, 2, N, 224, 0, stream));
+  // d e0 per edge; d U per node = sums of d A0 over the CSR / CSC lists; d s = W0[:, 0:288]^T dU_i + W0[:, 288:576]^T dU_j
+  B3D_TRY((wide<SeqAT0eT, false, false>("att_edge_encoder.0[e]^T", LoadAligned<32>{w.dA[3], nullptr, 512, 0}, E, w.de0, 64, 0, nullptr, w.wp_at0eT, stream, B3D_K_ATT_BWD)));
+  AttListSumArgs la;
+  la.N = N; la.W = 512; la.dst_ptr = g->dst_ptr; la.dst_perm = g->dst_perm; la.src_ptr = g->src_ptr; la.src_perm = g->src_perm;
+  la.G = w.dA[3]; la.dU = w.dU;
+  {
+    const long tasks = (long)((N + 15) / 16) * 2 * (512 / 64);
+    ProfScope ps(B3D_K_ATT_BWD, stream);
+    hipLaunchKernelGGL(att_listsum_kernel, dim3((unsigned)((tasks + 3) / 4)), dim3(256), 0, stream, la);
   }
+  B3D_TRY(launch_check("att_listsum_kernel"));
+  B3D_TRY(node_linear<SeqAttDs>("att_node_linear^T", w.dU, 1024, 0, w.ds, XS, N, w.wp_attDs, stream, B3D_K_ATT_BWD));
+  B3D_TRY(affine_bwd<96>(w, 0, N, 0, 192, stream));
+  B3D_TRY(affine_bwd<128>(w, 1, N, 96, 64, stream));
+  B3D_TRY(affine_bwd<64>(w, 2, N, 224, 0, stream));
   {
     const int affd[3] = {96, 128, 64}, xc[3] = {0, 96, 224};
     for (int m = 0; m < 3; ++m) {
@@ -971,10 +826,7 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
     a.rows = nl; a.in = In{w.dxs, XS, 96, d_x_sens, XS, 96, in->lidar_nodes};
     a.gtop = w.gfl_top; a.act[0] = w.fl_a1; a.gsave[0] = w.gfl1; a.wpack = w.wp_flT;
     B3D_TRY(launch_rows<kNWNode>(chain_bwd_kernel<SeqFLT, In, StoreNone, kNWNode>, "fc_lidar_encoder_bwd", a, nl, stream, B3D_K_OTHER, chain_lds<SeqFLT>()));
-    if (!w.hoist) {
-    WgJob j1 = make_job(w.lin[FL1], nl, seg(w.gfl_top, nullptr, 128, 0, 128)); add_act(j1, seg(w.fl_a1, nullptr, 192, 0, 192)); fc.jobs[fc.njobs++] = j1;
-    WgJob j0 = make_job(w.lin[FL0], nl, seg(w.gfl1, nullptr, 192, 0, 192)); add_act(j0, seg(in->pointnet_out, nullptr, 256, 0, 256)); fc.jobs[fc.njobs++] = j0;
-    }
+
   }
   if (nr > 0) {  // fc_radar_encoder
     using In = LoadAdd2<4>;
@@ -983,41 +835,26 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
     a.rows = nr; a.in = In{w.dxs, XS, 224, d_x_sens, XS, 224, in->radar_nodes};
     a.gtop = w.gfr_top; a.act[0] = w.fr_a2; a.act[1] = w.fr_a1; a.gsave[0] = w.gfr2; a.gsave[1] = w.gfr1; a.wpack = w.wp_frT;
     B3D_TRY(launch_rows<kNWNode>(chain_bwd_kernel<SeqFRT, In, StoreNone, kNWNode>, "fc_radar_encoder_bwd", a, nr, stream, B3D_K_OTHER, chain_lds<SeqFRT>()));
-    if (!w.hoist) {
-    WgJob j2 = make_job(w.lin[FR2], nr, seg(w.gfr_top, nullptr, 64, 0, 64)); add_act(j2, seg(w.fr_a2, nullptr, 128, 0, 128)); fc.jobs[fc.njobs++] = j2;
-    WgJob j1 = make_job(w.lin[FR1], nr, seg(w.gfr2, nullptr, 128, 0, 128)); add_act(j1, seg(w.fr_a1, nullptr, 192, 0, 192)); fc.jobs[fc.njobs++] = j1;
-    WgJob j0 = make_job(w.lin[FR0], nr, seg(w.gfr1, nullptr, 192, 0, 192)); add_act(j0, seg(in->radarnet_out, nullptr, 256, 0, 256)); fc.jobs[fc.njobs++] = j0;
-    }
+
   }
 
   // ---- encoders ----------------------------------------------------------------------------------------
-  if (w.hoist) {  // node encoder (x = initial_x): running d initial_x + layer 0's (dx | dx0)
-    using In = LoadNodeEncGradH<6>;
-    ChainBwdArgs<In, StoreNone> a;
-    memset(&a, 0, sizeof(a));
-    a.rows = N;
-    a.in = In{nullptr, dx0_first ? nullptr : w.dx0_acc, w.gx};
-    a.gtop = w.gn_top; a.act[0] = w.ne_a1; a.gsave[0] = w.gn1; a.wpack = w.wp_neT;
-    B3D_TRY(launch_rows<kNWNode>(chain_bwd_kernel<SeqNET, In, StoreNone, kNWNode>, "node_encoder_bwd", a, N, stream, B3D_K_OTHER, chain_lds<SeqNET>()));
-    WgJob n1 = make_job(w.lin[NE1], N, seg(w.gn_top, nullptr, 96, 0, 96)); add_act(n1, seg(w.ne_a1, nullptr, 48, 0, 48)); smallN.jobs[smallN.njobs++] = n1;
-    WgJob n0 = make_job(w.lin[NE0], N, seg(w.gn1, nullptr, 48, 0, 48)); add_act(n0, seg(w.pose_pad, nullptr, 32, 0, 19)); smallN.jobs[smallN.njobs++] = n0;
-  } else {  // node encoder (x = initial_x): running d initial_x + layer-0 scatter transposes
-    using In = LoadNodeEncGrad<6>;
-    ChainBwdArgs<In, StoreNone> a;
-    memset(&a, 0, sizeof(a));
-    a.rows = N;
-    a.in = In{nullptr, dx0_first ? nullptr : w.dx0_acc, w.gdst, w.gsrc, g->dst_ptr, g->dst_perm, g->src_ptr, g->src_perm};
-    a.gtop = w.gn_top; a.act[0] = w.ne_a1; a.gsave[0] = w.gn1; a.wpack = w.wp_neT;
-    B3D_TRY(launch_rows<kNWNode>(chain_bwd_kernel<SeqNET, In, StoreNone, kNWNode>, "node_encoder_bwd", a, N, stream, B3D_K_OTHER, chain_lds<SeqNET>()));
-    WgJob n1 = make_job(w.lin[NE1], N, seg(w.gn_top, nullptr, 96, 0, 96)); add_act(n1, seg(w.ne_a1, nullptr, 48, 0, 48)); smallN.jobs[smallN.njobs++] = n1;
-    WgJob n0 = make_job(w.lin[NE0], N, seg(w.gn1, nullptr, 48, 0, 48)); add_act(n0, seg(w.pose_pad, nullptr, 32, 0, 19)); smallN.jobs[smallN.njobs++] = n0;
-  }
+  // node encoder (x = initial_x): running d initial_x + layer 0's (dx | dx0)
+  using In = LoadNodeEncGradH<6>;
+  ChainBwdArgs<In, StoreNone> a;
+  memset(&a, 0, sizeof(a));
+  a.rows = N;
+  a.in = In{nullptr, dx0_first ? nullptr : w.dx0_acc, w.gx};
+  a.gtop = w.gn_top; a.act[0] = w.ne_a1; a.gsave[0] = w.gn1; a.wpack = w.wp_neT;
+  B3D_TRY(launch_rows<kNWNode>(chain_bwd_kernel<SeqNET, In, StoreNone, kNWNode>, "node_encoder_bwd", a, N, stream, B3D_K_OTHER, chain_lds<SeqNET>()));
+  WgJob n1 = make_job(w.lin[NE1], N, seg(w.gn_top, nullptr, 96, 0, 96)); add_act(n1, seg(w.ne_a1, nullptr, 48, 0, 48)); smallN.jobs[smallN.njobs++] = n1;
+  WgJob n0 = make_job(w.lin[NE0], N, seg(w.gn1, nullptr, 48, 0, 48)); add_act(n0, seg(w.pose_pad, nullptr, 32, 0, 19)); smallN.jobs[smallN.njobs++] = n0;
   {  // edge encoder: e[0] feeds layer 0 AND att_edge_encoder (columns 576:640 of its input)
     using In = LoadAdd2<4>;
     ChainBwdArgs<In, StoreNone> a;
     memset(&a, 0, sizeof(a));
     a.rows = E;
-    a.in = w.hoist ? In{w.de[cur], D::DE, 0, w.de0, 64, 0, nullptr} : In{w.de[cur], D::DE, 0, w.dIn, 640, 576, nullptr};
+    a.in = In{w.de[cur], D::DE, 0, w.de0, 64, 0, nullptr};
     a.gtop = w.ge_top; a.act[0] = w.ee_a2; a.act[1] = w.ee_a1; a.gsave[0] = w.ge2; a.gsave[1] = w.ge1; a.wpack = w.wp_eeT;
     B3D_TRY(launch_rows<kNWEdge>(chain_bwd_kernel<SeqEET, In, StoreNone, kNWEdge>, "edge_encoder_bwd", a, E, stream, B3D_K_OTHER, chain_lds<SeqEET>()));
     WgJob e2 = make_job(w.lin[EE2], E, seg(w.ge_top, nullptr, 64, 0, 64)); add_act(e2, seg(w.ee_a2, nullptr, 32, 0, 32)); smallE.jobs[smallE.njobs++] = e2;
@@ -1026,19 +863,15 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
   }
   B3D_TRY((launch_wgrad<8, 1>(smallE, stream, B3D_K_WGRAD_OTHER)));
   B3D_TRY((launch_wgrad<8, 1>(smallN, stream, B3D_K_WGRAD_OTHER)));
-  B3D_TRY((launch_wgrad<8, 2>(fc, stream, B3D_K_WGRAD_OTHER)));
 
   // ---- streamed weight gradients: message-passing stacks (all layers) + att_edge_encoder -------------
   {
-    // Hoisted plan: the cooperative bf16x6 kernel (b3d_wgemm.hpp) takes every block it has a shape for; the per-wavefront
-    // streaming kernel keeps the rest (and everything when B3D_WGEMM=0).  Both share the device tables, split in halves.
-    static const bool wgemm_on = [] { const char* e = getenv("B3D_WGEMM"); return e ? atoi(e) != 0 : true; }();
-    const bool coop = wgemm_on && w.hoist;
+    // The cooperative bf16x6 kernel (b3d_wgemm.hpp) takes every block it has a shape for; the per-wavefront streaming kernel
+    // (b3d_wstream2.hpp) keeps the rest.  Both share the device tables, split in halves.
     WsLauncher wl, wlc;
     std::vector<WsJob> coop_jobs;                // added to wlc longest task first (below)
     coop_jobs.reserve(128);
-    // the per-wavefront decomposition alone needs > 160 jobs: it gets the whole table when the cooperative kernel is off
-    const int jobs_c = coop ? kTableCap / 2 : 0, tasks_c = coop ? kTaskCap / 2 : 0;
+    const int jobs_c = kTableCap / 2, tasks_c = kTaskCap / 2;
     wl.begin(w.ws_table, kTableCap - jobs_c, w.ws_task_job, kTaskCap - tasks_c, stream);
     wlc.begin(w.ws_table + (kTableCap - jobs_c), jobs_c, w.ws_task_job + (kTaskCap - tasks_c), tasks_c, stream);
     hipLaunchKernelGGL(iota_kernel, dim3(((E > N ? E : N) + 255) / 256), dim3(256), 0, stream, w.iota, E > N ? E : N);
@@ -1127,7 +960,7 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
                          const Col* cols, int ncols, bool with_bias) {
       if (nvar <= 0) return;
       ls.used = true;
-      if (coop && ((uintptr_t)gp % 16 == 0) && gstride % 4 == 0 && gcol0 % 4 == 0 &&
+      if (((uintptr_t)gp % 16 == 0) && gstride % 4 == 0 && gcol0 % 4 == 0 &&
           add_block_coop(ls, rows, nvar, rpt, gp, gidx, gvs, gstride, gcol0, cols, ncols, with_bias))
         return;
       bool first_job_of_group = true;
@@ -1163,88 +996,62 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
       add_block(w.lin[lin], rows, nvar, rpt, gp, gidx, gvs, gstride, gcol0, cols, ncols, true);
     };
     const int rp = kStreamRowsPerTask, rpa = kStreamRowsPerTaskAtt;
-    if (w.hoist) {
-      // First layers: per-edge columns contract over edges, node columns over NODES (G = column blocks of dT).
-      const int rn = kStreamNodeRowsPerTask;
-      const long tLs = (long)N * HC::GW;
-      {  // edge_update.0 [256, 320]: x[dst] 0:96 | x[src] 96:192 | e 192:256 | att 256:320
-        Col ce[2] = {{w.e[0], nullptr, (long)eLe, D::DE, 0, 64}, {w.att, nullptr, 0, 64, 0, 64}};
-        if (coop) {        // one job over both sources: GdH1 (256 wide, the bulk of the bytes) is read once
-          LinSlab& ls = w.vlin[VL_EU0E];
-          ls.used = true;
-          WsJob jb;
-          memset(&jb, 0, sizeof(jb));
-          jb.g.ptr = w.GdH1; jb.g.idx = iota; jb.g.vstride = eL1; jb.g.stride = D::EH1; jb.g.col0 = 0;
-          for (int k = 0; k < 2; ++k) {
-            jb.act[k].ptr = ce[k].p; jb.act[k].idx = iota; jb.act[k].vstride = ce[k].vstride; jb.act[k].stride = ce[k].stride; jb.act[k].col0 = 0;
-          }
-          jb.act[2] = jb.act[0];
-          jb.wcol[0] = 0; jb.wcol[1] = 64; jb.wrow = 0; jb.write_bias = 1; jb.shape = WGM_256_128;
-          jb.rows = E; jb.nvar = depth; jb.rows_per_task = rp; jb.NP = ls.NP; jb.KP = ls.KP; jb.slab = ls.slab;
-          coop_jobs.push_back(jb);
-        } else {
-        add_block(w.vlin[VL_EU0E], E, depth, rp, w.GdH1, nullptr, eL1, D::EH1, 0, ce, 2, true);
-        }
-        Col cx[1] = {{w.x[0], nullptr, (long)nLx, D::DX, 0, 96}};
-        add_block(w.vlin[VL_EU0XI], N, depth, rn, w.dT, nullptr, tLs, HC::GW, HC::OA, cx, 1, false);
-        add_block(w.vlin[VL_EU0XJ], N, depth, rn, w.dT, nullptr, tLs, HC::GW, HC::OB, cx, 1, false);
-        Col c1[1] = {{w.sH1[0], nullptr, (long)eL1, D::EH1, 0, 256}};
-        add_matrix(EU1, E, depth, rp, w.GdH2, nullptr, eL2, D::EH2, 0, c1, 1);
-        Col c2[1] = {{w.sH2[0], nullptr, (long)eL2, D::EH2, 0, 128}};
-        add_matrix(EU2, E, depth, rp, w.Gde, nullptr, eLe, D::DE, 0, c2, 1);
+    // First layers: per-edge columns contract over edges, node columns over NODES (G = column blocks of dT).
+    const int rn = kStreamNodeRowsPerTask;
+    const long tLs = (long)N * HC::GW;
+    {  // edge_update.0 [256, 320]: x[dst] 0:96 | x[src] 96:192 | e 192:256 | att 256:320
+      Col ce[2] = {{w.e[0], nullptr, (long)eLe, D::DE, 0, 64}, {w.att, nullptr, 0, 64, 0, 64}};
+      // one job over both sources: GdH1 (256 wide, the bulk of the bytes) is read once
+      LinSlab& ls = w.vlin[VL_EU0E];
+      ls.used = true;
+      WsJob jb;
+      memset(&jb, 0, sizeof(jb));
+      jb.g.ptr = w.GdH1; jb.g.idx = iota; jb.g.vstride = eL1; jb.g.stride = D::EH1; jb.g.col0 = 0;
+      for (int k = 0; k < 2; ++k) {
+        jb.act[k].ptr = ce[k].p; jb.act[k].idx = iota; jb.act[k].vstride = ce[k].vstride; jb.act[k].stride = ce[k].stride; jb.act[k].col0 = 0;
       }
-      {  // message stacks .0 [192, 256] (layers 0 .. depth-2): x[.] 0:96 | e' 96:160 | x0[.] 160:256
-        Col ce[1] = {{w.e[1], nullptr, (long)eLe, D::DE, 0, 64}};
-        Col cx[1] = {{w.x[0], nullptr, (long)nLx, D::DX, 0, 96}};
-        Col c0[1] = {{w.x[0], nullptr, 0, D::DX, 0, 96}};
-        add_block(w.vlin[VL_PA0E], E, depth - 1, rp, w.GdP1, nullptr, eLm, D::MH, 0, ce, 1, true);
-        add_block(w.vlin[VL_PA0X], N, depth - 1, rn, w.dT, nullptr, tLs, HC::GW, HC::OP, cx, 1, false);
-        add_block(w.vlin[VL_PA0X0], N, depth - 1, rn, w.dT, nullptr, tLs, HC::GW, HC::OP, c0, 1, false);
-        add_block(w.vlin[VL_FU0E], E, depth - 1, rp, w.GdF1, nullptr, eLm, D::MH, 0, ce, 1, true);
-        add_block(w.vlin[VL_FU0X], N, depth - 1, rn, w.dT, nullptr, tLs, HC::GW, HC::OF, cx, 1, false);
-        add_block(w.vlin[VL_FU0X0], N, depth - 1, rn, w.dT, nullptr, tLs, HC::GW, HC::OF, c0, 1, false);
-        Col cp1[1] = {{w.sP1[0], nullptr, (long)eLm, D::MH, 0, 192}};
-        add_matrix(PA1, E, depth - 1, rp, w.dM, dst, nLm, D::NIN, 0, cp1, 1);
-        Col cf1[1] = {{w.sF1[0], nullptr, (long)eLm, D::MH, 0, 192}};
-        add_matrix(FU1, E, depth - 1, rp, w.dM, src, nLm, D::NIN, D::DM, cf1, 1);
-      }
-    } else {
-    {  // edge_update: x[l][dst] 96 | x[l][src] 96 | e[l] 64 | att 64
-      Col c[4] = {{w.x[0], dst, (long)nLx, D::DX, 0, 96}, {w.x[0], src, (long)nLx, D::DX, 0, 96},
-                  {w.e[0], nullptr, (long)eLe, D::DE, 0, 64}, {w.att, nullptr, 0, 64, 0, 64}};
-      add_matrix(EU0, E, depth, rp, w.GdH1, nullptr, eL1, D::EH1, 0, c, 4);
+      jb.act[2] = jb.act[0];
+      jb.wcol[0] = 0; jb.wcol[1] = 64; jb.wrow = 0; jb.write_bias = 1; jb.shape = WGM_256_128;
+      jb.rows = E; jb.nvar = depth; jb.rows_per_task = rp; jb.NP = ls.NP; jb.KP = ls.KP; jb.slab = ls.slab;
+      coop_jobs.push_back(jb);
+      Col cx[1] = {{w.x[0], nullptr, (long)nLx, D::DX, 0, 96}};
+      add_block(w.vlin[VL_EU0XI], N, depth, rn, w.dT, nullptr, tLs, HC::GW, HC::OA, cx, 1, false);
+      add_block(w.vlin[VL_EU0XJ], N, depth, rn, w.dT, nullptr, tLs, HC::GW, HC::OB, cx, 1, false);
       Col c1[1] = {{w.sH1[0], nullptr, (long)eL1, D::EH1, 0, 256}};
       add_matrix(EU1, E, depth, rp, w.GdH2, nullptr, eL2, D::EH2, 0, c1, 1);
       Col c2[1] = {{w.sH2[0], nullptr, (long)eL2, D::EH2, 0, 128}};
       add_matrix(EU2, E, depth, rp, w.Gde, nullptr, eLe, D::DE, 0, c2, 1);
     }
-    {  // message stacks (layers 0 .. depth-2): x[l][.] 96 | e[l+1] 64 | x0[.] 96
-      Col cp[3] = {{w.x[0], src, (long)nLx, D::DX, 0, 96}, {w.e[1], nullptr, (long)eLe, D::DE, 0, 64}, {w.x[0], src, 0, D::DX, 0, 96}};
-      add_matrix(PA0, E, depth - 1, rp, w.GdP1, nullptr, eLm, D::MH, 0, cp, 3);
+    {  // message stacks .0 [192, 256] (layers 0 .. depth-2): x[.] 0:96 | e' 96:160 | x0[.] 160:256
+      Col ce[1] = {{w.e[1], nullptr, (long)eLe, D::DE, 0, 64}};
+      Col cx[1] = {{w.x[0], nullptr, (long)nLx, D::DX, 0, 96}};
+      Col c0[1] = {{w.x[0], nullptr, 0, D::DX, 0, 96}};
+      add_block(w.vlin[VL_PA0E], E, depth - 1, rp, w.GdP1, nullptr, eLm, D::MH, 0, ce, 1, true);
+      add_block(w.vlin[VL_PA0X], N, depth - 1, rn, w.dT, nullptr, tLs, HC::GW, HC::OP, cx, 1, false);
+      add_block(w.vlin[VL_PA0X0], N, depth - 1, rn, w.dT, nullptr, tLs, HC::GW, HC::OP, c0, 1, false);
+      add_block(w.vlin[VL_FU0E], E, depth - 1, rp, w.GdF1, nullptr, eLm, D::MH, 0, ce, 1, true);
+      add_block(w.vlin[VL_FU0X], N, depth - 1, rn, w.dT, nullptr, tLs, HC::GW, HC::OF, cx, 1, false);
+      add_block(w.vlin[VL_FU0X0], N, depth - 1, rn, w.dT, nullptr, tLs, HC::GW, HC::OF, c0, 1, false);
       Col cp1[1] = {{w.sP1[0], nullptr, (long)eLm, D::MH, 0, 192}};
       add_matrix(PA1, E, depth - 1, rp, w.dM, dst, nLm, D::NIN, 0, cp1, 1);
-      Col cf[3] = {{w.x[0], dst, (long)nLx, D::DX, 0, 96}, {w.e[1], nullptr, (long)eLe, D::DE, 0, 64}, {w.x[0], dst, 0, D::DX, 0, 96}};
-      add_matrix(FU0, E, depth - 1, rp, w.GdF1, nullptr, eLm, D::MH, 0, cf, 3);
       Col cf1[1] = {{w.sF1[0], nullptr, (long)eLm, D::MH, 0, 192}};
       add_matrix(FU1, E, depth - 1, rp, w.dM, src, nLm, D::NIN, D::DM, cf1, 1);
     }
+    // modality heads on the rows that carry the modality (the LDS-staged kernel spilled ~3,000 VGPRs at these widths)
+    const int rf = kStreamRowsPerTaskFc;
+    if (nl > 0) {
+      Col a1[1] = {{w.fl_a1, nullptr, 0, 192, 0, 192}};
+      add_matrix(FL1, nl, 1, rf, w.gfl_top, nullptr, 0, 128, 0, a1, 1);
+      Col a0[1] = {{in->pointnet_out, nullptr, 0, 256, 0, 256}};
+      add_matrix(FL0, nl, 1, rf, w.gfl1, nullptr, 0, 192, 0, a0, 1);
     }
-    if (w.hoist) {  // modality heads on the rows that carry the modality (the LDS-staged kernel spilled ~3,000 VGPRs at these widths)
-      const int rf = kStreamRowsPerTaskFc;
-      if (nl > 0) {
-        Col a1[1] = {{w.fl_a1, nullptr, 0, 192, 0, 192}};
-        add_matrix(FL1, nl, 1, rf, w.gfl_top, nullptr, 0, 128, 0, a1, 1);
-        Col a0[1] = {{in->pointnet_out, nullptr, 0, 256, 0, 256}};
-        add_matrix(FL0, nl, 1, rf, w.gfl1, nullptr, 0, 192, 0, a0, 1);
-      }
-      if (nr > 0) {
-        Col a2[1] = {{w.fr_a2, nullptr, 0, 128, 0, 128}};
-        add_matrix(FR2, nr, 1, rf, w.gfr_top, nullptr, 0, 64, 0, a2, 1);
-        Col a1[1] = {{w.fr_a1, nullptr, 0, 192, 0, 192}};
-        add_matrix(FR1, nr, 1, rf, w.gfr2, nullptr, 0, 128, 0, a1, 1);
-        Col a0[1] = {{in->radarnet_out, nullptr, 0, 256, 0, 256}};
-        add_matrix(FR0, nr, 1, rf, w.gfr1, nullptr, 0, 192, 0, a0, 1);
-      }
+    if (nr > 0) {
+      Col a2[1] = {{w.fr_a2, nullptr, 0, 128, 0, 128}};
+      add_matrix(FR2, nr, 1, rf, w.gfr_top, nullptr, 0, 64, 0, a2, 1);
+      Col a1[1] = {{w.fr_a1, nullptr, 0, 192, 0, 192}};
+      add_matrix(FR1, nr, 1, rf, w.gfr2, nullptr, 0, 128, 0, a1, 1);
+      Col a0[1] = {{in->radarnet_out, nullptr, 0, 256, 0, 256}};
+      add_matrix(FR0, nr, 1, rf, w.gfr1, nullptr, 0, 192, 0, a0, 1);
     }
     {  // node update (layers 0 .. depth-2)
       Col c0[1] = {{w.M[0], nullptr, (long)nLm, D::NIN, 0, 256}};
@@ -1255,16 +1062,12 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
       add_matrix(CF2, N, depth - 1, rp, w.Gdx, nullptr, nLx, D::DX, 0, c2, 1);
     }
     {  // att_edge_encoder
-      if (w.hoist) {       // .0: edge columns over edges, node columns over nodes (G = the per-node sums dU_i | dU_j)
-        Col ce[1] = {{w.e[0], nullptr, 0, D::DE, 0, 64}};
-        add_block(w.vlin[VL_AT0E], E, 1, rpa, w.dA[3], nullptr, 0, 512, 0, ce, 1, true);
-        Col cs[1] = {{w.s, nullptr, 0, XS, 0, 288}};
-        add_block(w.vlin[VL_AT0I], N, 1, kStreamNodeRowsPerTask, w.dU, nullptr, 0, 1024, 0, cs, 1, false);
-        add_block(w.vlin[VL_AT0J], N, 1, kStreamNodeRowsPerTask, w.dU, nullptr, 0, 1024, 512, cs, 1, false);
-      } else {
-      Col c0[3] = {{w.s, dst, 0, XS, 0, 288}, {w.s, src, 0, XS, 0, 288}, {w.e[0], nullptr, 0, D::DE, 0, 64}};
-      add_matrix(AT0, E, 1, rpa, w.dA[3], nullptr, 0, 512, 0, c0, 3);
-      }
+      // .0: edge columns over edges, node columns over nodes (G = the per-node sums dU_i | dU_j)
+      Col ce[1] = {{w.e[0], nullptr, 0, D::DE, 0, 64}};
+      add_block(w.vlin[VL_AT0E], E, 1, rpa, w.dA[3], nullptr, 0, 512, 0, ce, 1, true);
+      Col cs[1] = {{w.s, nullptr, 0, XS, 0, 288}};
+      add_block(w.vlin[VL_AT0I], N, 1, kStreamNodeRowsPerTaskAtt, w.dU, nullptr, 0, 1024, 0, cs, 1, false);
+      add_block(w.vlin[VL_AT0J], N, 1, kStreamNodeRowsPerTaskAtt, w.dU, nullptr, 0, 1024, 512, cs, 1, false);
       Col c1[1] = {{w.A[0], nullptr, 0, 512, 0, 512}};
       add_matrix(AT1, E, 1, rpa, w.dA[2], nullptr, 0, 384, 0, c1, 1);
       Col c2[1] = {{w.A[1], nullptr, 0, 384, 0, 384}};
@@ -1274,12 +1077,8 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
       Col c4[1] = {{w.A[3], nullptr, 0, 128, 0, 128}};
       add_matrix(AT4, E, 1, rpa, w.da_acc, nullptr, 0, 64, 0, c4, 1);
     }
-    static const bool ws2 = [] { const char* e = getenv("B3D_WS2"); return e ? atoi(e) != 0 : true; }();   // B3D_WS2=0: register-staged form
-    if (ws2 && w.hoist) {    // every job of the hoisted plan has one un-gathered activation segment: LDS-DMA ring form
-      B3D_REQUIRE(wl.launch2(wstream2_kernel, kWs2LdsBytes, w.zrow, w.iota, B3D_K_WGRAD_EDGE) == 0, "wstream2: LDS attribute");
-    } else {
-      wl.launch(w.zrow, B3D_K_WGRAD_EDGE);
-    }
+    // every remaining job has one un-gathered activation segment: LDS-DMA ring form
+    B3D_REQUIRE(wl.launch2(wstream2_kernel, kWs2LdsBytes, w.zrow, w.iota, B3D_K_WGRAD_EDGE) == 0, "wstream2: LDS attribute");
     B3D_REQUIRE(wl.status == 0, "streaming weight gradient: job table overflow (%d jobs, %d tasks)", wl.njobs, wl.total_tasks);
     B3D_TRY(launch_check("wstream_kernel"));
     {
@@ -1332,7 +1131,7 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
     ra.nentries = 0;
     for (int i = 0; i < LIN_COUNT; ++i) {
       LinSlab& ls = w.lin[i];
-      if (w.hoist && (i == EU0 || i == FU0 || i == PA0 || i == AT0)) {
+      if (i == EU0 || i == FU0 || i == PA0 || i == AT0) {
         bool any = false;
         for (int v = 0; v < VL_COUNT; ++v) any = any || (kVl[v].lin == i && w.vlin[v].used);
         if (any) {          // depth == 1: the message stacks receive no gradient (falls through to the zero fill)
@@ -1387,7 +1186,6 @@ static void carve_layer(ClrLayerWs& w, void* ws, size_t ws_bytes, int N, int E, 
   Carver c(ws, ws_bytes);
   memset(&w, 0, sizeof(w));
   const size_t e_ = (size_t)(E > 0 ? E : 1), n_ = (size_t)(N > 0 ? N : 1);
-  w.wp_efwd = c.take<float>(D::EdgeFwdSeq::TOTAL_FLOATS);
   w.wp_nfwd = c.take<float>(D::NodeFwdSeq::TOTAL_FLOATS);
   w.fut = c.take<float>(e_ * D::DM);
   w.past = c.take<float>(e_ * D::DM);

@@ -64,7 +64,6 @@ inline int wg_rows_per_chunk(long rows, int NP, int KP) {
     if (bal > rpc) rpc = bal;
   }
   if (rpc > 8 * kWgRT) rpc = 8 * kWgRT;
-  if (const char* ev = getenv("B3D_WG_RPC")) { long v = atol(ev); if (v >= kWgRT && rows > 4096) rpc = v / kWgRT * kWgRT; }
   return (int)rpc;
 }
 inline int wg_nchunks(long rows, int NP, int KP, long /*launch_weight*/) {

@@ -15,11 +15,8 @@ using HP = Hoist<DimsP>;
 #endif
 constexpr int kNWEdgeH = B3D_NW_EDGE_H;   // wavefronts per workgroup of the hoisted edge kernels (4 = two independent workgroups per CU: measured the same 26 / 30 us per launch)
 
-// Hoisted first layers (b3d_hoist.hpp).  B3D_HOIST=0 selects the unsplit kernels (A/B comparisons).
-static bool hoist_enabled() {
-  static const bool on = [] { const char* e = getenv("B3D_HOIST"); return e ? atoi(e) != 0 : true; }();
-  return on;
-}
+// The model runs with its first layers hoisted to per-node tables (b3d_hoist.hpp); the single-layer operator, whose x / x0
+// come from the caller, runs the unsplit kernels (PoseWs::hoist = false).
 // encoders / classifier, widths padded to multiples of 16
 using SeqEdgeEnc = LayerSeq<L<16, 16>, L<16, 16>, L<16, 32>>;            // 4-8-16-32    pose_gnn.py:29-35
 using SeqNodeEnc = LayerSeq<L<32, 32>, L<32, 48>, L<48, 48>>;            // 19-24-36-48  :37-43
@@ -153,7 +150,7 @@ static void carve(PoseWs& w, void* ws, size_t ws_bytes, int N, int E, int depth,
   w.wp_cls = c.take<float>(SeqCls::TOTAL_FLOATS);
   w.wp_efwd = c.take<float>(D::EdgeFwdSeq::TOTAL_FLOATS);
   w.wp_nfwd = c.take<float>(D::NodeFwdSeq::TOTAL_FLOATS);
-  w.hoist = hoist_enabled() && !(flags & kFlagLayerMode);
+  w.hoist = !(flags & kFlagLayerMode);
   if (w.hoist) {
     w.wp_ne_h = c.take<float>(SeqNodeEncH::TOTAL_FLOATS);
     w.wp_nfwd_h = c.take<float>(NodeFwdHSeq<D>::TOTAL_FLOATS);
@@ -485,8 +482,7 @@ static int mp_weight_grads(PoseWs& w, const MpGradSrc& ms, int N, int E, const i
   narrow(WJ_EE2, ms.de0, D::DE, w.ee_a2, 16);                            // edge_encoder.4  [32,16]
   narrow(WJ_EE1, w.ge2, 16, w.ee_a1, 16);                                // .2  [16,8]
   narrow(WJ_EE0, w.ge1, 16, w.ea_pad, 16);                               // .0  [8,4]
-  static const bool ws2 = [] { const char* e = getenv("B3D_WS2"); return e ? atoi(e) != 0 : true; }();   // B3D_WS2=0: register-staged form
-  if (ws2 && w.hoist) {      // every job of the hoisted plan has one activation segment: LDS-DMA ring form
+  if (w.hoist) {             // every job of the hoisted plan has one activation segment: LDS-DMA ring form
     B3D_REQUIRE(wl.launch2(wstream2_kernel, kWs2LdsBytes, w.zrow, w.iota, B3D_K_WGRAD_EDGE) == 0, "wstream2: LDS attribute");
   } else {
     wl.launch(w.zrow, B3D_K_WGRAD_EDGE);

@@ -177,19 +177,6 @@ def point_feat_train_hip(convs, bns, x: torch.Tensor, trans=None, relu_last: boo
         return y
 
 
-class _FcWorkspace:
-    """Per-module scratch of the fc-head chain: the arrival counter in front of it must be zero on entry and every launch
-    leaves it zero, so it is zero-filled once, when the buffer is (re)allocated."""
-
-    def __init__(self):
-        self.buf = None
-
-    def get(self, nbytes, device):
-        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
-            self.buf = torch.zeros(nbytes, dtype=torch.uint8, device=device)
-        return self.buf
-
-
 def _bn_struct(bn: nn.BatchNorm1d, train: bool, keep: list):
     from . import _lib
     s = _lib.b3d_batchnorm()
@@ -224,10 +211,14 @@ def fc_head_hip(owner: nn.Module, x: torch.Tensor, stages, final_relu: bool = Tr
     b = x.size(0)
     dev = x.device
     stream = _lib.current_stream(dev)
-    ws_owner = owner.__dict__.setdefault("_b3d_fc_ws", _FcWorkspace())
+    # Scratch of the chain (arrival counter + per-row-tile partial statistics).  The counter must be zero on entry and
+    # every launch leaves it zero; it is nevertheless a fresh zero-filled tensor PER CALL: a buffer cached on the module
+    # and replaced when a larger batch arrives is freed while hipGraphs captured earlier still write to it on replay
+    # (found as memory faults of a two-rank run whose first large batch arrived inside a capture), and its zero fill
+    # would be captured, not executed, for the graphs that use it next.
     nmax = max(fc.out_features for fc, _, _, _ in stages)
     nbytes = lib.b3d_fc_bn_workspace_bytes(b, nmax)
-    ws = ws_owner.get(nbytes, dev)
+    ws = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
     keep = []
     in_scale = in_shift = None
     cur = x

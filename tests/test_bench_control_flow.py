@@ -50,3 +50,19 @@ def test_two_ranks_share_the_device_over_gloo():
              timeout=900)
     assert g["n_gpus"] == 2 and g["value"] > 0
     assert g["timed_region"].startswith("hipGraph replay") and "all-reduce" in g["timed_region"], g["timed_region"]
+
+
+def test_perf_guard_flags_a_slower_secondary(tmp_path):
+    """tools/perf_guard.py: +7 % on a secondary workload (round 2's PoseGNN loss) fails, +1 % passes."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = {"ms_per_step": 5.0, "config": {"workload": "w"}, "secondary": {"pose_gnn": {"ms_per_step": 0.92}, "x": {"ms_per_step": 3.8}}}
+    (tmp_path / "base.json").write_text("log line\n" + json.dumps(base) + "\n")
+    for pose, rc in ((0.988, 1), (0.93, 0)):
+        new = json.loads(json.dumps(base))
+        new["secondary"]["pose_gnn"]["ms_per_step"] = pose
+        (tmp_path / "new.json").write_text(json.dumps(new))
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "perf_guard.py"), str(tmp_path / "new.json"),
+                            "--baseline", str(tmp_path / "base.json")], capture_output=True, text=True)
+        assert r.returncode == rc, r.stdout + r.stderr
+        assert ("REGRESSION" in r.stdout) == bool(rc)

@@ -350,17 +350,3 @@ def test_embedding_cache_encodes_each_detection_once():
     m.pointnet.train()
     with pytest.raises(RuntimeError):
         m.encode_modalities(window(0, 50), cache=cache)
-
-
-@pytest.mark.parametrize("env", [{"B3D_WGEMM": "0"}, {"B3D_CLR_HOIST": "0"}])
-def test_alternate_kernel_plans(env):
-    """The build-time / run-time switches that select the older kernel plans (per-wavefront weight gradient, unsplit
-    first layers) are read once per process: the golden forward + backward test again, in a child process."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_clr_hip.py"), "-q", "-x", "-m", "gpu",
-                        "-k", "golden or camera_lidar", "-p", "no:cacheprovider"],
-                       env={**os.environ, **env}, capture_output=True, text=True, timeout=900, cwd=root)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
