@@ -1186,6 +1186,7 @@ static void carve_layer(ClrLayerWs& w, void* ws, size_t ws_bytes, int N, int E, 
   Carver c(ws, ws_bytes);
   memset(&w, 0, sizeof(w));
   const size_t e_ = (size_t)(E > 0 ? E : 1), n_ = (size_t)(N > 0 ? N : 1);
+  w.wp_efwd = c.take<float>(D::EdgeFwdSeq::TOTAL_FLOATS);
   w.wp_nfwd = c.take<float>(D::NodeFwdSeq::TOTAL_FLOATS);
   w.fut = c.take<float>(e_ * D::DM);
   w.past = c.take<float>(e_ * D::DM);
