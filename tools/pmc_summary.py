@@ -4,7 +4,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.defaultdict(lambda: collections.Counter())
 dur = collections.defaultdict(list)
 for d in sys.argv[1:]:
-    for f in glob.glob(d + '/*/*counter_collection.csv'):
+    for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
         for r in csv.DictReader(open(f)):
             n = r['Kernel_Name'].replace('b3d::', '').replace('MPDims<48, 32, 0, 96, 64, 96, 64, 96, 64>', 'P').split('(')[0][:60]
             agg[n][r['Counter_Name']] += float(r['Counter_Value'])
