@@ -126,52 +126,19 @@ __device__ __forceinline__ void wave_argmin(float& d, int& j) {
   }
 }
 
-// Frames larger than kKnnList (the per-wave LDS distance list): distances are recomputed from global
-// memory in every selection round -- the smallest (distance, position) pair strictly after the
-// previous pick, k times.  Rare (a frame of > 1,024 detections), slow, exact.
-template <int D>
-__device__ __forceinline__ void knn_select_big(const float* __restrict__ x, const float (&xc)[D], int c, int b, int nt, int kk,
-                                               const int* __restrict__ order, int* __restrict__ nbr) {
-  const int lane = threadIdx.x & 63;
-  auto sqdist = [&](int q) {
-    float s = 0.f;
-#pragma unroll
-    for (int d = 0; d < D; d += 4) {
-      const v4f v = *reinterpret_cast<const v4f*>(x + (size_t)q * D + d);
-      const float a0 = v.x - xc[d], a1 = v.y - xc[d + 1], a2 = v.z - xc[d + 2], a3 = v.w - xc[d + 3];
-      s = fmaf(a0, a0, s); s = fmaf(a1, a1, s); s = fmaf(a2, a2, s); s = fmaf(a3, a3, s);
-    }
-    return s;
-  };
-  const float INF = __builtin_inff();
-  float ld = -1.f; int lp = -1;
-  int mine = 0;
-  for (int r = 0; r < kk; ++r) {
-    float bd = INF; int bp = 0x7fffffff;
-    for (int p = lane; p < nt; p += 64) {
-      const int q = order[b + p];
-      if (q == c) continue;
-      const float dv = sqdist(q);
-      const bool after = (dv > ld) || (dv == ld && p > lp);
-      if (after && (dv < bd || (dv == bd && p < bp))) { bd = dv; bp = p; }
-    }
-    wave_argmin(bd, bp);
-    if (lane == r) mine = bp;
-    ld = bd; lp = bp;
-  }
-  if (lane < kk) nbr[(size_t)c * kKnnMaxK + lane] = order[b + mine];
-}
-
 // One wavefront per centre, kKnnCentres centres (consecutive in frame order) per workgroup.
 // Candidate rows are staged through LDS in tiles of kKnnTileRows, so a candidate row is fetched from
 // L2 once per workgroup instead of once per centre; each lane computes the squared distance of its
 // candidate to the wave's centre from LDS, the distances of the whole frame stay in a per-wave LDS
-// list, and the k nearest are extracted by k rounds of a wavefront arg-min.  The footprint (4 waves,
+// list, and the k nearest are extracted by k rounds of a wavefront arg-min.  A frame longer than the list (kKnnList
+// positions) is taken in segments: whenever the next tile would not fit, the k nearest of the positions listed so far are
+// extracted and merged with the running k nearest (two sorted lists of <= 32 entries side by side in one wavefront, k
+// more arg-min rounds) -- exact, same (distance, position) order, ~n_t / 960 extra extractions.  The footprint (4 waves,
 // < 45 KB LDS) is chosen so that these workgroups fit on a CU NEXT to a resident edge-phase
 // workgroup (104 KB LDS, 8 waves): the block runs on a side stream underneath the layer it belongs to.
 constexpr int kKnnCentres = 4;
 constexpr int kKnnTileRows = 64;
-constexpr int kKnnList = 1024;        // frame sizes up to this use the tiled kernel
+constexpr int kKnnList = 1024;        // positions in the per-wave LDS distance list (longer frames: several segments)
 template <int D>
 __global__ __launch_bounds__(kKnnCentres * 64) void knn_tile_kernel(const float* __restrict__ x, int N, int k,
                                                                     const int* __restrict__ order,
@@ -195,7 +162,6 @@ __global__ __launch_bounds__(kKnnCentres * 64) void knn_tile_kernel(const float*
   int ub = 0x7fffffff, ue = 0;                            // union of the candidate ranges of the workgroup
 #pragma unroll
   for (int w = 0; w < kKnnCentres; ++w) { ub = min(ub, wb[w]); ue = max(ue, we[w]); }
-  const bool big = nt > kKnnList;                         // does not fit the LDS list: knn_select_big
   float xc[D];
 #pragma unroll
   for (int d = 0; d < D; d += 4) {
@@ -203,6 +169,64 @@ __global__ __launch_bounds__(kKnnCentres * 64) void knn_tile_kernel(const float*
     xc[d] = v.x; xc[d + 1] = v.y; xc[d + 2] = v.z; xc[d + 3] = v.w;
   }
   const float INF = __builtin_inff();
+  const int kk = (k < nt - 1) ? k : (nt - 1);
+  static_assert(kKnnMaxK <= 32, "the merge holds the two sorted lists in the two halves of a wavefront");
+  // Segment state of this wavefront: list entry i is frame position segbase + i; lane r holds the r-th nearest found so
+  // far (distance, position relative to b), INF where there is none yet.
+  int segbase = b;
+  float bestd = INF;
+  int bestp = 0x7fffffff;
+  bool have = false;
+  // k nearest of the listed positions [segbase, upto), merged into (bestd, bestp); the list restarts at `upto`.
+  auto extract = [&](int upto) {
+    const int fill = upto - segbase;
+    if (fill <= 0) return;
+    // The lane's candidates (list entries lane, lane + 64, ...) move to registers; each round is a register scan plus a
+    // DPP wavefront arg-min on (distance bits, position) keys.
+    constexpr int SL = kKnnList / 64;
+    float cd[SL];
+#pragma unroll
+    for (int j = 0; j < SL; ++j) cd[j] = (64 * j + lane < fill) ? dist[wave][64 * j + lane] : INF;
+    float sd = INF;
+    int sp = 0x7fffffff;
+    for (int r = 0; r < kk; ++r) {
+      float bd = INF; int bj = 0;
+#pragma unroll
+      for (int j = 0; j < SL; ++j)
+        if (cd[j] < bd) { bd = cd[j]; bj = j; }
+      unsigned hi = __float_as_uint(bd), lo = (bd < INF) ? (unsigned)(64 * bj + lane) : 0x7fffffffu;
+      wave_min_key(hi, lo);                                 // smallest distance, then smallest position
+      const int bp = (int)lo;
+      if (lane == r && bp != 0x7fffffff) { sd = __uint_as_float(hi); sp = bp + (segbase - b); }   // lane r: the r-th nearest
+      if ((bp & 63) == lane) {
+        const int slot = bp >> 6;
+#pragma unroll
+        for (int j = 0; j < SL; ++j)
+          if (j == slot) cd[j] = INF;
+      }
+    }
+    if (!have) {
+      bestd = sd; bestp = sp; have = true;
+    } else {
+      // lanes 0..31: the running list, lanes 32..63: this segment's list; k rounds take the smallest (distance, position)
+      // (the shuffles run with every lane active: ds_bpermute returns 0 for a source lane that is masked off)
+      const float sdx = __shfl(sd, lane & 31, 64);
+      const int spx = __shfl(sp, lane & 31, 64);
+      float md = lane < 32 ? bestd : sdx;
+      int mp = lane < 32 ? bestp : spx;
+      float nd = INF;
+      int np = 0x7fffffff;
+      for (int r = 0; r < kk; ++r) {
+        unsigned hi = __float_as_uint(md), lo = (md < INF) ? (unsigned)mp : 0x7fffffffu;
+        const unsigned myhi = hi, mylo = lo;
+        wave_min_key(hi, lo);
+        if (lane == r && lo != 0x7fffffffu) { nd = __uint_as_float(hi); np = (int)lo; }
+        if (myhi == hi && mylo == lo) md = INF;              // positions are unique: exactly one lane retires its entry
+      }
+      bestd = nd; bestp = np;
+    }
+    segbase = upto;
+  };
   constexpr int PER = TR * (D / 4) / NT;                  // v4f staged per thread per tile
   static_assert(PER * NT == TR * (D / 4), "tile must divide over the workgroup");
   // Software pipeline: while tile i is evaluated from LDS, the rows of tile i+1 are in flight to
@@ -240,49 +264,22 @@ __global__ __launch_bounds__(kKnnCentres * 64) void knn_tile_kernel(const float*
     __syncthreads();
     load_rows();                                          // tile t0 + TR (indices fetched one tile ago)
     load_idx(t0 + 2 * TR);
+    if (live && t0 > segbase && t0 + TR - segbase > kKnnList) extract(t0 < e ? t0 : e);   // the list cannot take this tile
 #pragma unroll
     for (int u = 0; u < TR / 64; ++u) {
       const int p = t0 + 64 * u + lane;                   // this lane's candidate position
-      if (live && !big && p >= b && p < e) {
+      if (live && p >= b && p < e) {
         const float* row = tile[cur] + (64 * u + lane) * TS;
         float s2 = 0.f;
 #pragma unroll
         for (int d = 0; d < D; ++d) { const float a = row[d] - xc[d]; s2 = fmaf(a, a, s2); }
-        dist[wave][p - b] = (p == pos) ? INF : s2;
+        dist[wave][p - segbase] = (p == pos) ? INF : s2;
       }
     }
   }
   if (!live) return;
-  const int kk = (k < nt - 1) ? k : (nt - 1);
-  if (big) {
-    knn_select_big<D>(x, xc, c, b, nt, kk, order, nbr);
-    if (lane == 0) cnt[c] = kk;
-    return;
-  }
-  // The lane's candidates (positions lane, lane + 64, ...) move to registers; each round is a
-  // register scan plus a DPP wavefront arg-min on (distance bits, position) keys.
-  constexpr int SL = kKnnList / 64;
-  float cd[SL];
-#pragma unroll
-  for (int j = 0; j < SL; ++j) cd[j] = (64 * j + lane < nt) ? dist[wave][64 * j + lane] : INF;
-  int mine = 0;
-  for (int r = 0; r < kk; ++r) {
-    float bd = INF; int bj = 0;
-#pragma unroll
-    for (int j = 0; j < SL; ++j)
-      if (cd[j] < bd) { bd = cd[j]; bj = j; }
-    unsigned hi = __float_as_uint(bd), lo = (bd < INF) ? (unsigned)(64 * bj + lane) : 0x7fffffffu;
-    wave_min_key(hi, lo);                                   // smallest distance, then smallest position
-    const int bp = (int)lo;
-    if (lane == r) mine = bp;                               // lane r keeps the r-th nearest
-    if ((bp & 63) == lane) {
-      const int slot = bp >> 6;
-#pragma unroll
-      for (int j = 0; j < SL; ++j)
-        if (j == slot) cd[j] = INF;
-    }
-  }
-  if (lane < kk) nbr[(size_t)c * kKnnMaxK + lane] = order[b + mine];
+  extract(e);
+  if (lane < kk) nbr[(size_t)c * kKnnMaxK + lane] = order[b + bestp];
   if (lane == 0) cnt[c] = kk > 0 ? kk : 0;
 }
 

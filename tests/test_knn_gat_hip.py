@@ -9,7 +9,9 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("dim,frames", [(48, [130, 70, 19, 1, 300]), (96, [90, 21, 64]),
-                                        (48, [1100, 40])])          # > 1,024 nodes: the global-memory selection path
+                                        (48, [1100, 40]),            # > 1,024 positions: two list segments
+                                        (96, [2500, 1030, 7]),        # three segments; a frame just over the list
+                                        (96, [4800])])                # --scaling strong at N = 1: 16 graphs' frames merged
 def test_knn_gat_matches_oracle(dim, frames):
     from batch3dmot_amd import _lib
     from batch3dmot_amd.pose_gnn import GATConvParams
@@ -37,7 +39,22 @@ def test_knn_gat_matches_oracle(dim, frames):
             continue
         ref_nbr = idx[ei[0]].view(idx.numel(), kk)      # neighbours of centre j, ascending distance
         got = nbr[idx][:, :kk]
-        # identical neighbour SETS (ordering may differ on float ties only)
-        assert torch.equal(torch.sort(got, 1).values, torch.sort(ref_nbr, 1).values)
+        # identical neighbour SETS (ordering may differ on float ties only).  In a frame of thousands of detections a
+        # few centres have their k-th and (k+1)-th neighbour closer together than fp32 resolves (two fp32 evaluations
+        # of the same distance differ in the last bit): such a row may hold the other one of the pair -- checked in
+        # float64, and rare (the small frames have none).
+        same = (torch.sort(got, 1).values == torch.sort(ref_nbr, 1).values).all(1)
+        bad = torch.nonzero(~same).squeeze(1)
+        assert bad.numel() <= max(0, idx.numel() // 1000), (int(bad.numel()), int(idx.numel()))
+        inv = torch.full((n,), -1, dtype=torch.long)
+        inv[idx] = torch.arange(idx.numel())
+        for j in bad.tolist():
+            g_only = sorted(set(got[j].tolist()) - set(ref_nbr[j].tolist()))
+            r_only = sorted(set(ref_nbr[j].tolist()) - set(got[j].tolist()))
+            assert len(g_only) == len(r_only) == 1, (j, g_only, r_only)
+            c64 = xt[j].double()
+            dg = float(((x[g_only[0]].double() - c64) ** 2).sum())
+            dr = float(((x[r_only[0]].double() - c64) ** 2).sum())
+            assert abs(dg - dr) <= 2e-6 * dr, (j, dg, dr)
         yt = ora(xt, ei)
-        torch.testing.assert_close(y[idx], yt, rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(y[idx][same], yt[same], rtol=1e-4, atol=1e-5)
