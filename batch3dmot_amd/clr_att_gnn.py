@@ -269,6 +269,11 @@ class GNN(nn.Module):
         self.keep_workspace = False
         self._last_workspace = None
         self.mask_stream = None         # see modality_rows()
+        # True (default): the three frozen encoders of a forward run side by side -- ResNetAE (vector-ALU convolutions) and
+        # RadarNet on two side streams under PointNet (MFMA-bound point stacks) on the caller's stream, joined before the
+        # first kernel that reads their outputs.  Same kernels, same bits; see encode_modalities().
+        self.encoder_streams = True
+        self._enc_streams = {}
         self._grad_sink = None          # set by optim.FlatAdam: backward writes gradients into its flat buffer
 
     def _hip_params(self):
@@ -315,8 +320,25 @@ class GNN(nn.Module):
             return self._encode_cached(data, cache, node_ids)
         img_feats, lidar_feats, radar_feats = data.img_feats, data.lidar_feats, data.radar_feats
         lidar_nodes, radar_nodes = rows if rows is not None else self.modality_rows(data)
+        # The encoders do not depend on each other: with `encoder_streams` the camera and radar encoders are enqueued on
+        # two side streams (forked from, and joined back into, the caller's stream: inside a stream capture they become
+        # parallel branches of the graph).  The Python call order -- and with it the order in which the Dropout layers
+        # draw from the generator -- is the sequential one.  No record_stream: every use of a side stream starts by waiting
+        # for the caller's stream, so a block of a side stream's pool is never reused while an earlier consumer reads it.
+        dev = img_feats.device
+        side = None
+        if self.encoder_streams and img_feats.is_cuda:
+            side = self._enc_streams.get(dev)
+            if side is None:
+                side = self._enc_streams[dev] = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
+            cur = torch.cuda.current_stream(dev)
+            side[0].wait_stream(cur)
+            side[1].wait_stream(cur)
+        import contextlib
+        on = (lambda i: torch.cuda.stream(side[i])) if side is not None else (lambda i: contextlib.nullcontext())
         with torch.no_grad():
-            x_img = self.resnet.encode(img_feats).float().contiguous()
+            with on(0):
+                x_img = self.resnet.encode(img_feats).float().contiguous()
             if lidar_nodes.numel() < 2:
                 self.pointnet.eval()
                 self.fc_lidar_encoder.eval()
@@ -324,8 +346,13 @@ class GNN(nn.Module):
             if radar_nodes.numel() < 2:
                 self.radarnet.eval()
                 self.fc_radar_encoder.eval()
-            radarnet_out = self.radarnet.forward_feat(radar_feats[radar_nodes].view(-1, 4, 64)).float().contiguous()
-        return x_img, pointnet_out, lidar_nodes.to(torch.int32).contiguous(), radarnet_out, radar_nodes.to(torch.int32).contiguous()
+            with on(1):
+                radarnet_out = self.radarnet.forward_feat(radar_feats[radar_nodes].view(-1, 4, 64)).float().contiguous()
+            lidar_i32, radar_i32 = lidar_nodes.to(torch.int32).contiguous(), radar_nodes.to(torch.int32).contiguous()
+        if side is not None:
+            cur.wait_stream(side[0])
+            cur.wait_stream(side[1])
+        return x_img, pointnet_out, lidar_i32, radarnet_out, radar_i32
 
     def _encode_cached(self, data, cache: "EmbeddingCache", node_ids):
         if self.resnet.training or self.pointnet.training or self.radarnet.training:

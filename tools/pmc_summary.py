@@ -6,13 +6,13 @@ dur = collections.defaultdict(list)
 for d in sys.argv[1:]:
     for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
         for r in csv.DictReader(open(f)):
-            n = r['Kernel_Name'].replace('b3d::', '').replace('MPDims<48, 32, 0, 96, 64, 96, 64, 96, 64>', 'P').split('(')[0][:60]
+            n = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('b3d::', '').replace('MPDims<48, 32, 0, 96, 64, 96, 64, 96, 64>', 'P').split('(')[0][:60]
             agg[n][r['Counter_Name']] += float(r['Counter_Value'])
             cnt[n][r['Counter_Name']] += 1
             if 'Start_Timestamp' in r and r['Counter_Name'] == 'GRBM_GUI_ACTIVE':
                 dur[n].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
 names = sorted(agg, key=lambda n: -sum(agg[n].values()))
-for n in names[:16]:
+for n in names[:40]:
     c = agg[n]
     parts = [f"{k}={c[k] / cnt[n][k]:.4g}" for k in sorted(c)]
     extra = ""
