@@ -13,6 +13,7 @@
 // partials in a slab, added in tile order in float64): bitwise reproducible.
 #include "b3d_common.hpp"
 #include "b3d_launch.hpp"
+#include "b3d_dev.hpp"
 
 namespace b3d {
 namespace {
@@ -20,9 +21,17 @@ namespace {
 // 64 x 64 tiles, EIGHT wavefronts (two per SIMD), a 32 x 16 block each: a 2,100 x 512 layer is 264 workgroups, about one per CU, and
 // a single wavefront per SIMD ran at a third of the MFMA rate (LDS and barrier waits with nobody to cover them); 32 x 32 tiles
 // (four workgroups per CU) doubled the operand traffic and were slower still.
-constexpr int kTM = 64, kTN = 64, kTK = 32, kFcThreads = 512;
-constexpr int kLd = kTK + 2;     // [row][k] tiles, pitch 34 dwords: bank = 2 row + k -- the ds_read_b32 of a 16x16x4 operand (16 rows x
-                                 // 2 k per 32-lane group) and the staging ds_write_b64 (2 rows x 8 k-quads per 16-lane group) are conflict-free
+//
+// Products are bf16x6 (b3d_dev.hpp): both operands are split exactly into three bf16 pieces WHILE THEY ARE STAGED -- the LDS tiles
+// are three [row][k] bf16 images each -- and a 32-wide k group of a 16 x 16 block is six v_mfma_f32_16x16x32_bf16 (96 cycles)
+// instead of eight v_mfma_f32_16x16x4_f32 (256 cycles); 64 k per barrier instead of 32.  The exact-fp32 form of this kernel sat
+// at 19 % MFMA-busy and 52 us for [1,500 x 1,024] . [1,024 x 512]: one barrier per 16 MFMAs of a wavefront.
+constexpr int kTM = 64, kTN = 64, kTK = 64, kFcThreads = 512;
+constexpr int kPitch = kTK / 2 + 4;          // dwords per tile row: 64 bf16 + 16 bytes.  144 B rows: the ds_read_b128 of an operand fragment
+                                             // (16 rows x 16 B per 16-lane group) touches every bank once (144 i mod 256 = 16 (9 i mod 16))
+constexpr int kPiece = kTM * kPitch;         // dwords of one piece image
+constexpr int kTileDw = 3 * kPiece;          // one operand tile: three pieces
+constexpr int kFcLdsBytes = 2 * 2 * kTileDw * 4;   // x and w tiles, double buffered: 110,592 B
 
 struct FcArgs {
   const float* x;        // [B, K]
@@ -49,35 +58,36 @@ struct FcArgs {
 // hipcc wait vmcnt(0) behind every one of them, i.e. no tile was ever in flight under the MFMAs)
 template <bool AFFINE>
 __global__ __launch_bounds__(kFcThreads) void fc_kernel(const FcArgs a) {
-  __shared__ __attribute__((aligned(16))) float As[2][kTM * kLd];
-  __shared__ __attribute__((aligned(16))) float Bs[2][kTN * kLd];
+  extern __shared__ __attribute__((aligned(16))) unsigned fc_lds[];
+  unsigned* const As = fc_lds;                 // [2][3 pieces][kTM][kPitch]
+  unsigned* const Bs = fc_lds + 2 * kTileDw;
   __shared__ float colsum[2][2][kTN];       // [row half][sum | sum of squares][column]
-  constexpr int HS = kTM / (kFcThreads / 8);    // staging passes (64 rows each)
+  constexpr int HS = kTM / (kFcThreads / 16);   // staging passes (32 rows each)
   __shared__ int s_last;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wr = wave >> 2, wc = wave & 3;                   // 2 x 4 wavefronts, 32 x 16 outputs each
   // XCD-aware tile order (blocks b and b + 8 share an XCD and its L2): the column tiles of one row tile run on ONE XCD, next to
   // each other in time, so a row tile of x is fetched into one L2 once (with x = blockIdx.x, y = blockIdx.y every row tile was read
-  // by all eight XCDs: 8 x the input through the Infinity Cache, 74 -> see profiles/r03_*).  Speed only: any placement is correct.
+  // by all eight XCDs: 8 x the input through the Infinity Cache).  Speed only: any placement is correct.
   const int nct = (a.N + kTN - 1) / kTN, nrt = (a.B + kTM - 1) / kTM;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int rt = (slot / nct) * 8 + xcd, ct = slot % nct;
   if (rt >= nrt) return;               // padding of the last round (not counted by the arrival counter)
   const int m0 = rt * kTM, n0 = ct * kTN;
   const int li = lane & 15, lk = lane >> 4;
-  // staging: thread t moves one float4 (4 consecutive k) of row t / 8 of each tile
-  const int sr = tid >> 3, sk = (tid & 7) * 4;
-  // Three register sets: the tile of chunk kc is loaded during chunk kc - 3 (a chunk is ~0.4 us of MFMAs, an HBM round trip several
-  // times that: with one chunk of distance the kernel ran at a quarter of the MFMA rate), staged at the end of chunk kc - 1.
-  // Loads are unconditional (indices clamped, values zeroed by a select when they are staged): nothing consumes a loaded value
-  // before its tile is staged, two chunks later.
+  // staging: thread t moves one float4 (4 consecutive k) of row t / 16 (+ 32 per pass) of each tile
+  const int sr = tid >> 4, sq = tid & 15, sk = sq * 4;
+  // Three register sets: the tile of chunk kc is loaded during chunk kc - 3 (a chunk is a fraction of a microsecond of MFMAs, an
+  // HBM round trip several times that), staged at the end of chunk kc - 1.  Loads are unconditional (indices clamped, values
+  // zeroed by a select when they are staged): nothing consumes a loaded value before its tile is staged, two chunks later --
+  // a run-time test around the loads made hipcc wait vmcnt(0) behind every one of them.
   v4f ax[3][HS], bx[3][HS], sc[3], sh[3];
   int rA[HS], rB[HS];
   bool okA[HS], okB[HS];
 #pragma unroll
   for (int h = 0; h < HS; ++h) {
-    rA[h] = min(m0 + sr + 64 * h, a.B - 1); rB[h] = min(n0 + sr + 64 * h, a.N - 1);
-    okA[h] = m0 + sr + 64 * h < a.B; okB[h] = n0 + sr + 64 * h < a.N;
+    rA[h] = min(m0 + sr + 32 * h, a.B - 1); rB[h] = min(n0 + sr + 32 * h, a.N - 1);
+    okA[h] = m0 + sr + 32 * h < a.B; okB[h] = n0 + sr + 32 * h < a.N;
   }
   auto load = [&](int k0, v4f (&axs)[HS], v4f (&bxs)[HS], v4f& scs, v4f& shs) {
     const int k = min(k0 + sk, a.K - 4);
@@ -91,25 +101,42 @@ __global__ __launch_bounds__(kFcThreads) void fc_kernel(const FcArgs a) {
       shs = *reinterpret_cast<const v4f*>(a.in_shift + k);
     }
   };
+  typedef unsigned u2v __attribute__((ext_vector_type(2)));
+  // x = p0 + p1 + p2 exactly (truncation split, b3d_dev.hpp); a dword holds elements 2 d (low half) and 2 d + 1
+  auto put = [&](unsigned* dst, const v4f x) {
+    const float f[4] = {x.x, x.y, x.z, x.w};
+    unsigned h[4], m[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      h[i] = __float_as_uint(f[i]);
+      const float r1 = f[i] - __uint_as_float(h[i] & 0xffff0000u);
+      m[i] = __float_as_uint(r1);
+      l[i] = __float_as_uint(r1 - __uint_as_float(m[i] & 0xffff0000u));
+    }
+    *reinterpret_cast<u2v*>(dst) = u2v{__builtin_amdgcn_perm(h[1], h[0], 0x07060302u), __builtin_amdgcn_perm(h[3], h[2], 0x07060302u)};
+    *reinterpret_cast<u2v*>(dst + kPiece) = u2v{__builtin_amdgcn_perm(m[1], m[0], 0x07060302u), __builtin_amdgcn_perm(m[3], m[2], 0x07060302u)};
+    *reinterpret_cast<u2v*>(dst + 2 * kPiece) = u2v{__builtin_amdgcn_perm(l[1], l[0], 0x07060302u), __builtin_amdgcn_perm(l[3], l[2], 0x07060302u)};
+  };
   auto stage = [&](int buf, int k0, const v4f (&axs)[HS], const v4f (&bxs)[HS], const v4f& scs, const v4f& shs) {
     const bool kok = k0 + sk < a.K;
+    const v4f zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int h = 0; h < HS; ++h) {
-      typedef float v2f __attribute__((ext_vector_type(2)));
       v4f v = axs[h];
       if constexpr (AFFINE) {
         v.x = relu1(fmaf(v.x, scs.x, shs.x)); v.y = relu1(fmaf(v.y, scs.y, shs.y));
         v.z = relu1(fmaf(v.z, scs.z, shs.z)); v.w = relu1(fmaf(v.w, scs.w, shs.w));
       }
-      const bool oa = okA[h] && kok, ob = okB[h] && kok;
-      const v4f u = bxs[h];
-      float* pa = &As[buf][(sr + 64 * h) * kLd + sk];
-      *reinterpret_cast<v2f*>(pa) = v2f{oa ? v.x : 0.f, oa ? v.y : 0.f};
-      *reinterpret_cast<v2f*>(pa + 2) = v2f{oa ? v.z : 0.f, oa ? v.w : 0.f};
-      float* pb = &Bs[buf][(sr + 64 * h) * kLd + sk];
-      *reinterpret_cast<v2f*>(pb) = v2f{ob ? u.x : 0.f, ob ? u.y : 0.f};
-      *reinterpret_cast<v2f*>(pb + 2) = v2f{ob ? u.z : 0.f, ob ? u.w : 0.f};
+      put(As + buf * kTileDw + (sr + 32 * h) * kPitch + 2 * sq, (okA[h] && kok) ? v : zero);
+      put(Bs + buf * kTileDw + (sr + 32 * h) * kPitch + 2 * sq, (okB[h] && kok) ? bxs[h] : zero);
     }
+  };
+  auto frag = [&](const unsigned* p) {                      // this lane's 8 k of one row, three pieces
+    Bf3 f;
+    f.p0 = __builtin_bit_cast(bf8, *reinterpret_cast<const u4v*>(p));
+    f.p1 = __builtin_bit_cast(bf8, *reinterpret_cast<const u4v*>(p + kPiece));
+    f.p2 = __builtin_bit_cast(bf8, *reinterpret_cast<const u4v*>(p + 2 * kPiece));
+    return f;
   };
   v4f acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};     // rows 32 wr + {0..15}, {16..31}
   const int nk = (a.K + kTK - 1) / kTK;
@@ -125,13 +152,14 @@ __global__ __launch_bounds__(kFcThreads) void fc_kernel(const FcArgs a) {
       if (kc >= nk) break;
       const int buf = kc & 1;
       load((kc + 3) * kTK, ax[u], bx[u], sc[u], sh[u]);      // set u held chunk kc, which is in LDS
-      const float* A = &As[buf][(32 * wr + li) * kLd + lk];
-      const float* Bt = &Bs[buf][(16 * wc + li) * kLd + lk];
+      const unsigned* A = As + buf * kTileDw + (32 * wr + li) * kPitch + 4 * lk;
+      const unsigned* Bt = Bs + buf * kTileDw + (16 * wc + li) * kPitch + 4 * lk;
 #pragma unroll
-      for (int ks = 0; ks < kTK / 4; ++ks) {
-        const float b = Bt[ks * 4];
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[ks * 4], b, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[16 * kLd + ks * 4], b, acc1, 0, 0, 0);
+      for (int kg = 0; kg < kTK / 32; ++kg) {
+        const Bf3 bw = frag(Bt + 16 * kg);
+        const Bf3 a0 = frag(A + 16 * kg), a1 = frag(A + 16 * kPitch + 16 * kg);
+        acc0 = bf_mfma6(a0, bw, acc0);
+        acc1 = bf_mfma6(a1, bw, acc1);
       }
       if (kc + 1 < nk) stage(buf ^ 1, (kc + 1) * kTK, ax[(u + 1) % 3], bx[(u + 1) % 3], sc[(u + 1) % 3], sh[(u + 1) % 3]);
       __syncthreads();
@@ -277,8 +305,13 @@ extern "C" int b3d_fc_bn_forward(const float* x, int32_t B, int32_t K, const flo
   }
   const int nrt = (B + kTM - 1) / kTM, nct = (N + kTN - 1) / kTN;
   const dim3 grid((unsigned)((nrt + 7) / 8 * 8 * nct));                // row tiles padded to whole rounds of the eight XCDs
-  if (in_scale) hipLaunchKernelGGL(fc_kernel<true>, grid, dim3(kFcThreads), 0, stream, a);
-  else hipLaunchKernelGGL(fc_kernel<false>, grid, dim3(kFcThreads), 0, stream, a);
+  if (in_scale) {
+    B3D_TRY(set_lds_cached(reinterpret_cast<const void*>(fc_kernel<true>), kFcLdsBytes));
+    hipLaunchKernelGGL(fc_kernel<true>, grid, dim3(kFcThreads), kFcLdsBytes, stream, a);
+  } else {
+    B3D_TRY(set_lds_cached(reinterpret_cast<const void*>(fc_kernel<false>), kFcLdsBytes));
+    hipLaunchKernelGGL(fc_kernel<false>, grid, dim3(kFcThreads), kFcLdsBytes, stream, a);
+  }
   return launch_check("fc_kernel");
 }
 
