@@ -213,3 +213,31 @@ def test_non_finite_and_extreme_inputs(kind, case):
         ok = ~bad_w
         scale = want[ok].abs().max(1, keepdim=True).values.clamp_min(1e-6)   # per row: the huge rows do not hide the others
         assert float(((have[ok] - want[ok]).abs() / scale).max()) < 1e-4, name
+
+
+def test_layer_builds_the_graph_structure_once_per_edge_index_tensor():
+    """Repeated applications to the same edge_index tensor (a model's gnn_depth iterations) share one CSR / CSC build and
+    one endpoint validation; an in-place edit of the tensor, or another tensor, rebuilds."""
+    from batch3dmot_amd.pose_gnn import CausalMessagePassing
+    dev = torch.device("cuda:0")
+    d = _graph(60, 5, 3)
+    m = CausalMessagePassing().to(dev)
+    g = torch.Generator().manual_seed(4)
+    N, E = d.pose_feats.size(0), d.edge_index.size(1)
+    x, x0, e = (torch.randn(N, 48, generator=g).to(dev), torch.randn(N, 48, generator=g).to(dev), torch.randn(E, 32, generator=g).to(dev))
+    ei = d.edge_index.to(dev)
+    with torch.no_grad():
+        a = m(x, ei, e, x0)
+        g1 = m._b3d_graph_cache[2]
+        b = m(x, ei, e, x0)
+        assert m._b3d_graph_cache[2] is g1 and torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        ei[0, 0] = ei[0, 1]                       # in place: the version counter moves
+        m(x, ei, e, x0)
+        assert m._b3d_graph_cache[2] is not g1
+        g2 = m._b3d_graph_cache[2]
+        m(x, ei.clone(), e, x0)
+        assert m._b3d_graph_cache[2] is not g2
+        bad = ei.clone()
+        bad[1, 3] = N + 7
+        with pytest.raises(ValueError):
+            m(x, bad, e, x0)
