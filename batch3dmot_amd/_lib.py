@@ -79,7 +79,8 @@ class b3d_clr_grads(C.Structure):        # same layout minus knn_conv
 class b3d_clr_inputs(C.Structure):
     _fields_ = [("pose_feats", C.c_void_p), ("edge_attr", C.c_void_p), ("node_timestamps", C.c_void_p),
                 ("x_img", C.c_void_p), ("pointnet_out", C.c_void_p), ("lidar_nodes", C.c_void_p), ("n_lidar", C.c_int32),
-                ("radarnet_out", C.c_void_p), ("radar_nodes", C.c_void_p), ("n_radar", C.c_int32)]
+                ("radarnet_out", C.c_void_p), ("radar_nodes", C.c_void_p), ("n_radar", C.c_int32),
+                ("encoders_ready", C.c_void_p)]
 
 
 _lib: Optional[C.CDLL] = None

@@ -117,7 +117,7 @@ def _clr_struct(cls, t):
 class _GNNFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, graph, pose_feats, edge_attr, node_timestamps, x_img, pointnet_out, lidar_nodes,
-                radarnet_out, radar_nodes, training, *params):
+                radarnet_out, radar_nodes, training, ready, *params):
         lib = _lib.load()
         dev = pose_feats.device
         N, E = graph.N, graph.E
@@ -144,6 +144,8 @@ class _GNNFunction(torch.autograd.Function):
         inp.x_img = x_img.data_ptr()
         inp.pointnet_out, inp.lidar_nodes, inp.n_lidar = (pointnet_out.data_ptr() if nl else None), (lidar_nodes.data_ptr() if nl else None), nl
         inp.radarnet_out, inp.radar_nodes, inp.n_radar = (radarnet_out.data_ptr() if nr else None), (radar_nodes.data_ptr() if nr else None), nr
+        # event behind the frozen encoders (GNN._encode): the forward waits for it right before it reads their outputs
+        inp.encoders_ready = ready.cuda_event if ready is not None else None
         prob = torch.empty((E, 1), dtype=torch.float32, device=dev)
         x_sens = torch.empty((N, 288), dtype=torch.float32, device=dev)
         _lib.check(lib.b3d_clr_forward(C.byref(w), C.byref(graph.c), C.byref(inp), module.depth, flags, ws.data_ptr(), nbytes,
@@ -152,7 +154,7 @@ class _GNNFunction(torch.autograd.Function):
         ctx.module, ctx.graph, ctx.ws, ctx.nbytes, ctx.flags = module, graph, ws, nbytes, flags
         ctx.ws_owner = _lib.Workspace(ws, defer)
         ctx.inp, ctx.keep = inp, (gat, pose_feats, edge_attr, node_timestamps, x_img, pointnet_out,
-                                                      lidar_nodes, radarnet_out, radar_nodes)
+                                                      lidar_nodes, radarnet_out, radar_nodes, ready)
         module._last_workspace = (ws, nbytes, flags, N, E, nl, nr) if module.keep_workspace else None
         return prob, x_sens
 
@@ -177,8 +179,8 @@ class _GNNFunction(torch.autograd.Function):
         ctx.ws_owner.joined()              # backward joined the library's side stream into this stream
         if sink is not None:
             sink.deposited()
-            return (None,) * (11 + len(params))
-        return (None,) * 11 + tuple(grads)
+            return (None,) * (12 + len(params))
+        return (None,) * 12 + tuple(grads)
 
 
 class EmbeddingCache:
@@ -318,42 +320,67 @@ class GNN(nn.Module):
         (default: ``data.global_node_timestamps[:, 0]``, graph_data.py:190)."""
         if cache is not None:
             return self._encode_cached(data, cache, node_ids)
+        return self._encode(data, rows, join=True)[0]
+
+    def _encode(self, data, rows, join: bool):
+        """(outputs of encode_modalities, event or None).  ``join=False`` (used by ``forward``): nothing is joined back into
+        the caller's stream -- PointNet, too, runs on a side stream, and the returned event (recorded behind all three
+        encoders) is handed to ``b3d_clr_forward`` (``b3d_clr_inputs.encoders_ready``), which waits for it only after the
+        part of the forward that does not read encoder outputs: weight images, edge / node encoder, layer 0's per-node table
+        and the first k-NN block run on the caller's stream WHILE the encoders run."""
         img_feats, lidar_feats, radar_feats = data.img_feats, data.lidar_feats, data.radar_feats
         lidar_nodes, radar_nodes = rows if rows is not None else self.modality_rows(data)
         # The encoders do not depend on each other: with `encoder_streams` the camera and radar encoders are enqueued on a
         # side stream (forked from, and joined back into, the caller's stream: inside a stream capture a parallel branch of
-        # the graph) next to PointNet -- the longest of the three -- on the caller's stream.  One side stream for both:
-        # with a stream of its own RadarNet's branch started late in the replay (behind PointNet's kernels) and ended on
-        # the critical path; behind ResNetAE it is done well before PointNet (4.87 -> 4.75 ms per step).  The Python call
-        # order -- and with it the order in which the Dropout layers draw from the generator -- is the sequential one.
-        # No record_stream: every use of the side stream starts by waiting for the caller's stream, so a block of its pool
-        # is never reused while an earlier consumer reads it.
+        # the graph) next to PointNet -- the longest of the three.  One side stream for ResNetAE and RadarNet: with a stream
+        # of its own RadarNet's branch started late in the replay (behind PointNet's kernels) and ended on the critical
+        # path; behind ResNetAE it is done well before PointNet (4.87 -> 4.75 ms per step).  The Python call order -- and
+        # with it the order in which the Dropout layers draw from the generator -- is the sequential one.  No
+        # record_stream: every use of a side stream starts by waiting for the caller's stream, so a block of its pool is
+        # never reused while an earlier consumer reads it.
         dev = img_feats.device
-        side = None
+        side = pn = None
         if self.encoder_streams and img_feats.is_cuda:
-            side = self._enc_streams.get(dev)
-            if side is None:
-                side = self._enc_streams[dev] = torch.cuda.Stream(dev)
+            streams = self._enc_streams.get(dev)
+            if streams is None:
+                streams = self._enc_streams[dev] = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
             cur = torch.cuda.current_stream(dev)
+            side = streams[0]
             side.wait_stream(cur)
+            if not join:
+                pn = streams[1]
+                pn.wait_stream(cur)
         import contextlib
-        on_side = (lambda: torch.cuda.stream(side)) if side is not None else contextlib.nullcontext
+        on = lambda st: torch.cuda.stream(st) if st is not None else contextlib.nullcontext()
         with torch.no_grad():
-            with on_side():
+            with on(side):
                 x_img = self.resnet.encode(img_feats).float().contiguous()
             if lidar_nodes.numel() < 2:
                 self.pointnet.eval()
                 self.fc_lidar_encoder.eval()
-            pointnet_out = self.pointnet.forward_feat(lidar_feats[lidar_nodes].view(-1, 3, 128)).float().contiguous()
+            with on(pn):
+                pointnet_out = self.pointnet.forward_feat(lidar_feats[lidar_nodes].view(-1, 3, 128)).float().contiguous()
             if radar_nodes.numel() < 2:
                 self.radarnet.eval()
                 self.fc_radar_encoder.eval()
-            with on_side():
+            with on(side):
                 radarnet_out = self.radarnet.forward_feat(radar_feats[radar_nodes].view(-1, 4, 64)).float().contiguous()
             lidar_i32, radar_i32 = lidar_nodes.to(torch.int32).contiguous(), radar_nodes.to(torch.int32).contiguous()
-        if side is not None:
+        ready = None
+        if pn is not None:
+            # The row ids were produced on another stream (modality_rows: the mask stream) and are read by gathers on the
+            # side streams; nothing joins those into the caller's stream before this function returns and drops its
+            # references, so the allocator must be told (without this the NEXT step's compaction, which waits for nobody,
+            # reused the block while this step's RadarNet gather had not run yet: run-to-run differences in its statistics).
+            if not torch.cuda.is_current_stream_capturing():
+                lidar_nodes.record_stream(pn)
+                radar_nodes.record_stream(side)
+            pn.wait_stream(side)                     # one event behind all three
+            ready = torch.cuda.Event()
+            ready.record(pn)
+        elif side is not None:
             cur.wait_stream(side)
-        return x_img, pointnet_out, lidar_i32, radarnet_out, radar_i32
+        return (x_img, pointnet_out, lidar_i32, radarnet_out, radar_i32), ready
 
     def _encode_cached(self, data, cache: "EmbeddingCache", node_ids):
         if self.resnet.training or self.pointnet.training or self.radarnet.training:
@@ -399,7 +426,14 @@ class GNN(nn.Module):
             raise ValueError("empty graph: the reference's callers skip these (predict.py:179-180)")
         edge_attr = edge_attr.to(torch.float64).contiguous()
         node_timestamps = node_timestamps.to(torch.int64).contiguous()
-        x_img, pointnet_out, lidar_nodes, radarnet_out, radar_nodes = encoded if encoded is not None else self.encode_modalities(data, rows=rows)
+        ready = None
+        if encoded is None:
+            # Forward-only calls (no_grad: predict.py:172-196) hand the join to b3d_clr_forward, which runs the part that
+            # does not read encoder outputs underneath the encoders (+3.5 % windows per second at 2,000 / 20,000); in a
+            # training step the same overlap measured 1.6 % SLOWER (the train-mode statistics kernels of the point stacks
+            # and the forward prefix get in each other's way), so there the encoders are joined first.
+            encoded, ready = self._encode(data, rows, join=torch.is_grad_enabled())
+        x_img, pointnet_out, lidar_nodes, radarnet_out, radar_nodes = encoded
         graph = getattr(data, "_b3d_graph", None)
         if graph is None or graph.N != pose_feats.size(0) or graph.E != edge_index.size(1) \
                 or graph._keep.data_ptr() != edge_index.data_ptr():
@@ -413,4 +447,4 @@ class GNN(nn.Module):
             _lib.require_cuda(p, "parameter", torch.float32)
         training = torch.is_grad_enabled() and any(p.requires_grad for p in params)
         return _GNNFunction.apply(self, graph, pose_feats, edge_attr, node_timestamps, x_img, pointnet_out, lidar_nodes,
-                                  radarnet_out, radar_nodes, training, *params)
+                                  radarnet_out, radar_nodes, training, ready, *params)

@@ -587,6 +587,42 @@ extern "C" int b3d_clr_forward(const b3d_clr_weights* pw, const b3d_graph* g, co
                 "b3d_clr_forward: knn_conv pointers are required with B3D_FLAG_RUN_DEAD_KNN");
   B3D_TRY(pack_all(pw, w, tr, (flags & B3D_FLAG_RUN_DEAD_KNN) != 0, stream));
 
+  // ---- the part that does not read the frozen encoders' outputs: edge / node encoder, layer 0's per-node table, the
+  //      first k-NN block (x[0]); the encoders may still be running on other streams (b3d_clr_inputs::encoders_ready) ----
+  {  // edge encoder: edge_attr.float() -> 4-16-32-64 (:123)
+    ChainFwdArgs<LoadEdgeAttrF64, StoreAligned<4>> a;
+    memset(&a, 0, sizeof(a));
+    a.rows = E; a.in.ptr = in->edge_attr; a.out = StoreAligned<4>{w.e[0], nullptr, D::DE, 0};
+    a.save_in = w.ea_pad; a.save[0] = w.ee_a1; a.save[1] = w.ee_a2; a.wpack = w.wp_ee;
+    B3D_TRY(launch_rows<kNWEdge>(chain_fwd_kernel<SeqEE, 0x3u, LoadEdgeAttrF64, StoreAligned<4>, kNWEdge>, "edge_encoder", a, E, stream, B3D_K_OTHER, chain_lds<SeqEE>()));
+  }
+  {  // node encoder 19-48-96 (:174-176)
+    ChainFwdArgs<LoadUnaligned<19>, StoreAligned<6>> a;
+    memset(&a, 0, sizeof(a));
+    a.rows = N; a.in.ptr = in->pose_feats; a.out = StoreAligned<6>{w.x[0], nullptr, D::DX, 0};
+    a.save_in = w.pose_pad; a.save[0] = w.ne_a1; a.wpack = w.wp_ne;
+    B3D_TRY(launch_rows<kNWNode>(chain_fwd_kernel<SeqNE, 0x1u, LoadUnaligned<19>, StoreAligned<6>, kNWNode>, "node_encoder", a, N, stream, B3D_K_OTHER, chain_lds<SeqNE>()));
+  }
+  // x0 terms of the future / past columns (once per forward) + the per-node table of layer 0
+  NodeProj0Args a;
+  a.N = N; a.x0 = w.x[0]; a.T0 = w.T0; a.T = w.T; a.wpack = w.wp_proj0;
+  B3D_TRY(launch_node_split<DB>(node_proj0_split_kernel<DB>, "node_proj0", a, N, stream, B3D_K_OTHER));
+  Side* knn_side = nullptr;
+  auto knn_block = [&](int l) -> int {                         // the discarded k-NN + GAT block on x[l] (:180-184)
+    B3D_REQUIRE(in->node_timestamps != nullptr, "node_timestamps required with B3D_FLAG_RUN_DEAD_KNN");
+    hipStream_t ks = stream;
+    if (!(flags & B3D_FLAG_SINGLE_STREAM)) {
+      if (!knn_side) B3D_TRY(side_get(0, &knn_side));
+      B3D_TRY(side_fork(stream, knn_side));                // x[l] is complete on `stream` here
+      ks = knn_side->s;
+    }
+    // on the launch stream the block reads GATConv.lin(x[l]) from the per-node table
+    const bool pre = ks == stream;
+    return knn_gat_block<D::DX>(w.knn, w.x[l], in->node_timestamps, N, pw->knn_conv, 20, ks, pre ? w.T + HC::OG : nullptr, HC::TW);
+  };
+  if (flags & B3D_FLAG_RUN_DEAD_KNN) B3D_TRY(knn_block(0));
+  if (in->encoders_ready) B3D_HIP_CHECK(hipStreamWaitEvent(stream, (hipEvent_t)in->encoders_ready, 0));
+
   // ---- x_sens = x_img | x_lidar | x_radar; rows without a modality stay zero (:127-141,172) ------
   B3D_HIP_CHECK(hipMemsetAsync(w.xsens, 0, (size_t)N * XS * sizeof(float), stream));
   hipLaunchKernelGGL(copy_cols_kernel, dim3(((long)N * 96 + 255) / 256), dim3(256), 0, stream, in->x_img, 96, w.xsens, XS, 0, N, 96);
@@ -616,13 +652,6 @@ extern "C" int b3d_clr_forward(const b3d_clr_weights* pw, const b3d_graph* g, co
   B3D_TRY(affine_fwd<128>(w, 1, N, 96, 64, stream));
   B3D_TRY(affine_fwd<64>(w, 2, N, 224, 0, stream));
 
-  {  // edge encoder: edge_attr.float() -> 4-16-32-64 (:123)
-    ChainFwdArgs<LoadEdgeAttrF64, StoreAligned<4>> a;
-    memset(&a, 0, sizeof(a));
-    a.rows = E; a.in.ptr = in->edge_attr; a.out = StoreAligned<4>{w.e[0], nullptr, D::DE, 0};
-    a.save_in = w.ea_pad; a.save[0] = w.ee_a1; a.save[1] = w.ee_a2; a.wpack = w.wp_ee;
-    B3D_TRY(launch_rows<kNWEdge>(chain_fwd_kernel<SeqEE, 0x3u, LoadEdgeAttrF64, StoreAligned<4>, kNWEdge>, "edge_encoder", a, E, stream, B3D_K_OTHER, chain_lds<SeqEE>()));
-  }
   {  // att_edge_encoder( s[dst] | s[src] | e ) 640-512-384-256-128-64 (:161-164)
     B3D_TRY(node_linear<SeqAttU>("att_node_linear", w.s, XS, 0, w.U, 1024, N, w.wp_attU, stream, B3D_K_ATT_FWD));
     Att0FwdArgs fa;
@@ -633,31 +662,8 @@ extern "C" int b3d_clr_forward(const b3d_clr_weights* pw, const b3d_graph* g, co
     B3D_TRY((wide<SeqAT3, true, true>("att_edge_encoder.6", LoadAligned<16>{w.A[2], nullptr, 256, 0}, E, w.A[3], 128, 0, nullptr, w.wp_at[3], stream)));
     B3D_TRY((wide<SeqAT4, false, true>("att_edge_encoder.8", LoadAligned<8>{w.A[3], nullptr, 128, 0}, E, w.att, 64, 0, nullptr, w.wp_at[4], stream)));
   }
-  {  // node encoder 19-48-96 (:174-176)
-    ChainFwdArgs<LoadUnaligned<19>, StoreAligned<6>> a;
-    memset(&a, 0, sizeof(a));
-    a.rows = N; a.in.ptr = in->pose_feats; a.out = StoreAligned<6>{w.x[0], nullptr, D::DX, 0};
-    a.save_in = w.pose_pad; a.save[0] = w.ne_a1; a.wpack = w.wp_ne;
-    B3D_TRY(launch_rows<kNWNode>(chain_fwd_kernel<SeqNE, 0x1u, LoadUnaligned<19>, StoreAligned<6>, kNWNode>, "node_encoder", a, N, stream, B3D_K_OTHER, chain_lds<SeqNE>()));
-  }
-  // x0 terms of the future / past columns (once per forward) + the per-node table of layer 0
-  NodeProj0Args a;
-  a.N = N; a.x0 = w.x[0]; a.T0 = w.T0; a.T = w.T; a.wpack = w.wp_proj0;
-  B3D_TRY(launch_node_split<DB>(node_proj0_split_kernel<DB>, "node_proj0", a, N, stream, B3D_K_OTHER));
-  Side* knn_side = nullptr;
   for (int l = 0; l < depth; ++l) {
-    if ((flags & B3D_FLAG_RUN_DEAD_KNN) && (l % 2 == 0)) {
-      B3D_REQUIRE(in->node_timestamps != nullptr, "node_timestamps required with B3D_FLAG_RUN_DEAD_KNN");
-      hipStream_t ks = stream;
-      if (!(flags & B3D_FLAG_SINGLE_STREAM)) {
-        if (!knn_side) B3D_TRY(side_get(0, &knn_side));
-        B3D_TRY(side_fork(stream, knn_side));              // x[l] is complete on `stream` here
-        ks = knn_side->s;
-      }
-      // on the launch stream the block reads GATConv.lin(x[l]) from the per-node table
-      const bool pre = ks == stream;
-      B3D_TRY(knn_gat_block<D::DX>(w.knn, w.x[l], in->node_timestamps, N, pw->knn_conv, 20, ks, pre ? w.T + HC::OG : nullptr, HC::TW));
-    }
+    if ((flags & B3D_FLAG_RUN_DEAD_KNN) && l > 0 && (l % 2 == 0)) B3D_TRY(knn_block(l));
     NodeFwdArgs na;
     memset(&na, 0, sizeof(na));
     na.N = N; na.dst_ptr = g->dst_ptr; na.dst_perm = g->dst_perm; na.src_ptr = g->src_ptr; na.src_perm = g->src_perm;

@@ -187,6 +187,12 @@ typedef struct b3d_clr_inputs {
   const float* radarnet_out;        /* [n_radar,256] */
   const int32_t* radar_nodes;       /* [n_radar] */
   int32_t n_radar;
+  void* encoders_ready;             /* optional hipEvent_t, recorded by the caller once x_img / pointnet_out / radarnet_out are
+                                       complete (on whatever streams produced them).  b3d_clr_forward waits for it on `stream`
+                                       right before its first read of the three -- AFTER the part of the forward that does not
+                                       need them (weight images, edge / node encoder, layer 0's per-node table, the first k-NN
+                                       block), so the frozen encoders can still be running on other streams when it is called.
+                                       NULL: the three are complete in `stream` order.  Ignored by b3d_clr_backward. */
 } b3d_clr_inputs;
 
 size_t b3d_clr_workspace_bytes(int32_t N, int32_t E, int32_t n_lidar, int32_t n_radar, int32_t depth, uint32_t flags);
