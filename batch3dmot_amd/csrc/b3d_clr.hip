@@ -82,18 +82,12 @@ static const LinDim kDims[LIN_COUNT] = {
 // rows the layer is applied to: 0 = edges, 1 = nodes, 2 = lidar rows, 3 = radar rows
 static const int kRowKind[LIN_COUNT] = {0, 0, 0, 1, 1, 0, 0, 0, 0, 2, 2, 3, 3, 3, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0,
                                         0, 0, 0, 0, 0, 0, 0, 1, 1, 1};
-#ifndef B3D_RP
-#define B3D_RP 768
-#define B3D_RPA 1536
-#endif
-constexpr int kStreamRowsPerTask = B3D_RP;       // message-passing stacks (x up to 6 layer variants)
-#ifndef B3D_RN
-#define B3D_RN 128
-#define B3D_RNA 512
-#endif
-constexpr int kStreamNodeRowsPerTask = B3D_RN;   // hoisted first layers: node columns contract over N rows x depth layers
-constexpr int kStreamNodeRowsPerTaskAtt = B3D_RNA;  // att_edge_encoder.0's node columns: one variant, a [512, 288] partial per task
-constexpr int kStreamRowsPerTaskAtt = B3D_RPA;   // att_edge_encoder (one variant)
+// Rows per weight-gradient task (measured on the benchmark batch: 512 / 1,024 / 64 / 64 in round 2; larger tasks = fewer,
+// smaller slab sets -- 175 instead of 340 MB per step -- at the same load balance)
+constexpr int kStreamRowsPerTask = 768;          // message-passing stacks (x up to 6 layer variants)
+constexpr int kStreamNodeRowsPerTask = 128;      // hoisted first layers: node columns contract over N rows x depth layers
+constexpr int kStreamNodeRowsPerTaskAtt = 512;   // att_edge_encoder.0's node columns: one variant, a [512, 288] partial per task
+constexpr int kStreamRowsPerTaskAtt = 1536;      // att_edge_encoder (one variant)
 
 // column blocks of the hoisted first-layer gradients: (linear, first column, width, rows contracted over edges?)
 enum { VL_EU0XI, VL_EU0XJ, VL_EU0E, VL_FU0X, VL_FU0E, VL_FU0X0, VL_PA0X, VL_PA0E, VL_PA0X0, VL_AT0I, VL_AT0J, VL_AT0E, VL_COUNT };
