@@ -114,6 +114,9 @@ def _clr_struct(cls, t):
     return s
 
 
+_ENC_STREAMS = {}
+
+
 class _GNNFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, graph, pose_feats, edge_attr, node_timestamps, x_img, pointnet_out, lidar_nodes,
@@ -275,7 +278,6 @@ class GNN(nn.Module):
         # RadarNet, on a side stream under PointNet (MFMA-bound point stacks) on the caller's stream, joined before the
         # first kernel that reads their outputs.  Same kernels, same bits; see encode_modalities().
         self.encoder_streams = True
-        self._enc_streams = {}
         self._grad_sink = None          # set by optim.FlatAdam: backward writes gradients into its flat buffer
 
     def _hip_params(self):
@@ -341,9 +343,9 @@ class GNN(nn.Module):
         dev = img_feats.device
         side = pn = None
         if self.encoder_streams and img_feats.is_cuda:
-            streams = self._enc_streams.get(dev)
-            if streams is None:
-                streams = self._enc_streams[dev] = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
+            streams = _ENC_STREAMS.get(dev)          # per device, shared by all models of the process (a module attribute would
+            if streams is None:                      # make the module impossible to deepcopy / pickle once it has run)
+                streams = _ENC_STREAMS[dev] = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
             cur = torch.cuda.current_stream(dev)
             side = streams[0]
             side.wait_stream(cur)

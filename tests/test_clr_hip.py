@@ -350,3 +350,20 @@ def test_embedding_cache_encodes_each_detection_once():
     m.pointnet.train()
     with pytest.raises(RuntimeError):
         m.encode_modalities(window(0, 50), cache=cache)
+
+
+def test_model_is_copyable_after_a_forward():
+    """The side streams of the encoder phase live outside the module: a model that has run can be deep-copied and pickled
+    (checkpoint code does both), and the copy computes the same scores."""
+    import copy
+    import pickle
+    dev = torch.device("cuda:0")
+    g = load_golden("g2_clr.pt")
+    data = data_from(g["data"]).to(dev)
+    m = _model(g["salt"], dev)
+    with torch.no_grad():
+        out, _ = m(data)
+        m2 = copy.deepcopy(m)
+        pickle.dumps(m)
+        out2, _ = m2(data)
+    assert torch.equal(out, out2)
