@@ -101,3 +101,72 @@ def make_optimizer(gnn, lr: float = 1e-4, weight_decay: float = 1e-4, betas=(0.9
         from .optim import FlatAdam
         return FlatAdam(gnn, lr=lr, weight_decay=weight_decay, betas=betas, capturable=capturable)
     return torch.optim.Adam(params, lr=lr, weight_decay=weight_decay, betas=betas)
+
+
+class EncodeAhead:
+    """The frozen encoders of the NEXT batch underneath the current batch's training step.
+
+    ``GNN.forward`` runs ResNetAE / PointNet / RadarNet first and the message passing after them (clr_att_gnn.py:107-141,
+    :143-188).  The encoders are frozen (clr_att_gnn.py:26-33): nothing an optimizer step changes feeds them, so batch
+    k + 1 can be encoded while batch k is still in its forward / backward / Adam -- the usual prefetch, one stage deeper
+    than the loader's H2D copy.  Results are those of the sequential loop bit for bit: the encoders see the batches in
+    the same order (train-mode BatchNorm: running statistics; Dropout: the generator's draw order -- the GNN itself draws
+    nothing), only earlier.
+
+        ahead = EncodeAhead(gnn)
+        ahead.launch(batches[0])
+        for k, batch in enumerate(batches):
+            encoded = ahead.take(batch)                      # joins the side stream into the current one
+            if k + 1 < len(batches):
+                ahead.launch(batches[k + 1])                 # runs under the step below
+            train_step(gnn, batch, optimizer, forward_kwargs={"encoded": encoded})
+
+    One side stream, the three encoders one after the other on it (they have a whole step of time).  ``static`` (a tuple of
+    preallocated tensors shaped like ``encode_modalities``' result) makes ``launch`` write there -- what a hipGraph-captured
+    step needs; without it the outputs are fresh tensors, recorded on the consuming stream by ``take``."""
+
+    def __init__(self, gnn):
+        self.gnn = gnn
+        self.stream = None
+        self.pending = None
+
+    def launch(self, data, rows=None, static=None):
+        if self.pending is not None:
+            raise RuntimeError("EncodeAhead.launch: the previous batch was never taken")
+        dev = data.pose_feats.device
+        if self.stream is None or self.stream.device != dev:
+            self.stream = torch.cuda.Stream(dev)
+        cur = torch.cuda.current_stream(dev)
+        self.stream.wait_stream(cur)
+        if rows is None:
+            rows = self.gnn.modality_rows(data)              # (on the caller's side: the counts are shapes)
+        keep = self.gnn.encoder_streams
+        self.gnn.encoder_streams = False                     # one branch: no forks inside the side stream
+        try:
+            with torch.cuda.stream(self.stream):
+                out = self.gnn.encode_modalities(data, rows=rows)
+                if static is not None:
+                    for dst, src in zip(static, out):
+                        if dst.shape != src.shape:
+                            raise ValueError(f"EncodeAhead: static buffer {tuple(dst.shape)} vs encoder output {tuple(src.shape)}")
+                        dst.copy_(src)
+                    out = static
+                if not torch.cuda.is_current_stream_capturing():
+                    for t in rows:
+                        t.record_stream(self.stream)          # produced elsewhere, read by this stream's gathers
+        finally:
+            self.gnn.encoder_streams = keep
+        self.pending = (data, out, static is not None)
+        return out
+
+    def take(self, data):
+        if self.pending is None or self.pending[0] is not data:
+            raise RuntimeError("EncodeAhead.take: this batch was not the one launched")
+        _, out, is_static = self.pending
+        self.pending = None
+        cur = torch.cuda.current_stream(data.pose_feats.device)
+        cur.wait_stream(self.stream)
+        if not is_static and not torch.cuda.is_current_stream_capturing():
+            for t in out:
+                t.record_stream(cur)
+        return out

@@ -195,3 +195,44 @@ def test_train_mode_step_matches_reference_golden(name):
     for n, w in g["after_digest"].items():
         assert abs(have[n]["norm"] - w["norm"]) <= 2e-6 * max(w["norm"], 1e-6), n
         torch.testing.assert_close(have[n]["head"], w["head"], rtol=1e-5, atol=2e-7)
+
+
+def test_encode_ahead_equals_the_sequential_loop_bitwise():
+    """train_step.EncodeAhead: the frozen encoders of batch k + 1 enqueued on a side stream under the step of batch k.  Train
+    mode, Dropout ACTIVE: losses, parameters, BatchNorm statistics and counters after four steps are bit-equal to the loop
+    that encodes inside forward (same order of batches through the encoders, same order of generator draws)."""
+    from batch3dmot_amd import encoders, synth
+    from batch3dmot_amd.clr_att_gnn import GNN
+    from batch3dmot_amd.train_step import EncodeAhead, make_optimizer, train_step
+    dev = torch.device("cuda:0")
+    batches = [synth.make_batch(2, 150, 900, first_graph_idx=700 + 2 * i, modalities=True).to(dev) for i in range(4)]
+
+    def run(pipelined):
+        m = GNN(encoders.ResNetAE(), encoders.PointNetClassifier(k=7), encoders.RadarNetClassifier(k=7))
+        seeded_fill_(m, 31)
+        m = m.to(dev).train()
+        torch.manual_seed(7)
+        torch.cuda.manual_seed(7)
+        opt = make_optimizer(m)
+        losses = []
+        ahead = EncodeAhead(m) if pipelined else None
+        if pipelined:
+            ahead.launch(batches[0])
+        for k, b in enumerate(batches):
+            kw = None
+            if pipelined:
+                kw = {"encoded": ahead.take(b)}
+                if k + 1 < len(batches):
+                    ahead.launch(batches[k + 1])
+            loss, _, _ = train_step(m, b, opt, batch_size=2, loss_kind="cb", logits=False, forward_kwargs=kw)
+            losses.append(float(loss))
+        torch.cuda.synchronize()
+        return losses, {k: v.detach().clone() for k, v in m.state_dict().items()}
+
+    l_seq, s_seq = run(False)
+    l_pipe, s_pipe = run(True)
+    assert l_seq == l_pipe
+    changed = 0
+    for k in s_seq:
+        assert torch.equal(s_seq[k], s_pipe[k]), k
+    assert len({round(x, 6) for x in l_seq}) == 4             # four different batches, four losses
