@@ -203,6 +203,8 @@ class Workload:
         self.edges = [b.edge_index.size(1) for b in self.pool]
         self.enc = None
         self.rows_static = None
+        self.ahead = None
+        self.enc_static = None
         if kind == "clr":
             rows = [self.model.modality_rows(b) for b in self.pool]
             self.nl = sum(int(r[0].numel()) for r in rows) / len(rows)
@@ -211,6 +213,18 @@ class Workload:
                 self.enc = [self.model.encode_modalities(b, rows=r) for b, r in zip(self.pool, rows)]
             else:
                 self.rows_static = [(r[0].clone(), r[1].clone()) for r in rows]
+                if getattr(args, "encode_ahead", False):
+                    # train_step.EncodeAhead: the frozen encoders of pool batch k + 1 run on a side stream under the step of
+                    # batch k and leave their outputs in static buffers (a captured step needs fixed addresses); batch 0 is
+                    # encoded here, once, in front of everything.  Same encoder passes, same order, same bits as encoding
+                    # inside forward (tests/test_timed_config.py).
+                    from batch3dmot_amd.train_step import EncodeAhead
+                    self.ahead = EncodeAhead(self.model)
+                    f32, i32 = dict(dtype=torch.float32, device=dev), dict(dtype=torch.int32, device=dev)
+                    self.enc_static = [(torch.zeros(self.n_nodes, 96, **f32), torch.zeros(r[0].numel(), 256, **f32), torch.zeros(r[0].numel(), **i32),
+                                        torch.zeros(r[1].numel(), 256, **f32), torch.zeros(r[1].numel(), **i32)) for r in rows]
+                    self.ahead.launch(self.pool[0], rows=self.rows_static[0], static=self.enc_static[0])
+                    self.ahead.take(self.pool[0])
 
     def _run(self, i, kwargs):
         from batch3dmot_amd.train_step import train_step
@@ -233,6 +247,8 @@ class Workload:
         k = i % len(self.pool)
         if self.enc is not None:
             ret = self._run_fb(i, {"encoded": self.enc[k]})
+        elif self.ahead is not None:
+            ret = self._ahead_step(i, self._run_fb, self.rows_static[(k + 1) % len(self.pool)])
         elif self.rows_static is not None:
             ret = self._run_fb(i, {"rows": self.rows_static[k]})
         else:
@@ -243,15 +259,26 @@ class Workload:
     def opt_step(self):
         self.opt.step()
 
+    def _ahead_step(self, i, run, rows_next):
+        """Step i with the encoders of the NEXT pool batch underneath it: fork (side stream) -> encoders(k + 1) into their static
+        buffers | step(k) on the outputs the previous step left for batch k -> join."""
+        k, kn = i % len(self.pool), (i + 1) % len(self.pool)
+        self.ahead.launch(self.pool[kn], rows=rows_next, static=self.enc_static[kn])
+        ret = run(i, {"encoded": self.enc_static[k]})
+        self.ahead.take(self.pool[kn])
+        return ret
+
     def step(self, i):
         if self.enc is not None:
             return self._run(i, {"encoded": self.enc[i % len(self.pool)]})
+        if self.ahead is not None:
+            return self._ahead_step(i, self._run, None)       # rows of the next batch: masks + compaction inside launch()
         return self._run(i, None)
 
     def pre(self, i):
         if self.rows_static is None:
             return
-        k = i % len(self.pool)
+        k = (i + (1 if self.ahead is not None else 0)) % len(self.pool)   # the batch whose encoders run in this step
         li, ri = self.model.modality_rows(self.pool[k])           # masks + compaction, every step
         sl, sr = self.rows_static[k]
         if li.numel() != sl.numel() or ri.numel() != sr.numel():
@@ -263,6 +290,8 @@ class Workload:
         k = i % len(self.pool)
         if self.enc is not None:
             ret = self._run(i, {"encoded": self.enc[k]})
+        elif self.ahead is not None:
+            ret = self._ahead_step(i, self._run, self.rows_static[(k + 1) % len(self.pool)])
         elif self.rows_static is not None:
             ret = self._run(i, {"rows": self.rows_static[k]})
         else:
@@ -276,6 +305,8 @@ class Workload:
                     + (" + flat RCCL grad all-reduce" if world > 1 else "") + ")")
         enc = ("frozen ResNetAE / PointNet / RadarNet encoders in train mode inside the step" if self.encoders == "frozen"
                else "encoder outputs precomputed")
+        if self.ahead is not None:
+            enc += " (one encoder pass per step, enqueued for the NEXT pool batch on a side stream under this batch's step: train_step.EncodeAhead)"
         name = "camera+LiDAR+radar" if self.modalities == "clr" else "camera+LiDAR (radar rows all zero)"
         return (name + " GNN (clr_att_gnn) depth 6, training step (modality masks + " + enc
                 + " + CSR/CSC build + fwd + cb-BCE + bwd + Adam" + (" + flat RCCL grad all-reduce of 5.24 MB" if world > 1 else "") + ")")
@@ -373,11 +404,12 @@ def snapshot(wl):
     st = {"exp_avg": o.exp_avg.clone(), "exp_avg_sq": o.exp_avg_sq.clone(),
           "step_dev": o.step_dev.clone() if getattr(o, "step_dev", None) is not None else None,
           "step_count": o.step_count, "fresh": o.fresh}
-    return sd, st, torch.cuda.get_rng_state(wl.dev)
+    enc = [tuple(t.clone() for t in slot) for slot in wl.enc_static] if getattr(wl, "enc_static", None) else None
+    return sd, st, torch.cuda.get_rng_state(wl.dev), enc
 
 
 def restore(wl, snap):
-    sd, st, rng = snap
+    sd, st, rng, enc = snap
     o = wl.opt
     torch.cuda.synchronize()
     with torch.no_grad():
@@ -388,6 +420,11 @@ def restore(wl, snap):
         if st["step_dev"] is not None:
             o.step_dev.copy_(st["step_dev"])
     o.step_count, o.fresh = st["step_count"], st["fresh"]
+    if enc is not None:                                          # encoder outputs waiting for their step (EncodeAhead)
+        with torch.no_grad():
+            for slot, saved in zip(wl.enc_static, enc):
+                for dst, src in zip(slot, saved):
+                    dst.copy_(src)
     torch.cuda.set_rng_state(rng, wl.dev)
     torch.cuda.synchronize()
 
@@ -395,7 +432,8 @@ def restore(wl, snap):
 def state_digest(wl):
     """Flat copies of what `snapshot` covers, for bitwise comparisons (tests/test_timed_config.py)."""
     sd = wl.model.state_dict()
-    return {**{"model." + k: v.detach().clone() for k, v in sd.items()},
+    enc = {f"encode_ahead.{i}.{j}": t.clone() for i, slot in enumerate(getattr(wl, "enc_static", None) or []) for j, t in enumerate(slot)}
+    return {**enc, **{"model." + k: v.detach().clone() for k, v in sd.items()},
             "adam.exp_avg": wl.opt.exp_avg.clone(), "adam.exp_avg_sq": wl.opt.exp_avg_sq.clone(),
             **({"adam.step": wl.opt.step_dev.clone()} if getattr(wl.opt, "step_dev", None) is not None else {})}
 
@@ -639,6 +677,11 @@ def main():
     ap.add_argument("--no-dead-knn", action="store_true",
                     help="skip the k-NN + GAT block whose result the reference discards (secondary figure)")
     ap.add_argument("--no-graph", action="store_true", help="enqueue every step eagerly")
+    ap.add_argument("--encode-ahead", action="store_true",
+                    help="train_step.EncodeAhead: the frozen encoders of the NEXT pool batch on a side stream under the current step "
+                         "(default: every batch is encoded inside its own forward; the default run reports this mode as a secondary -- "
+                         "with two kernels sharing the GPU a per-launch duration is no longer a property of the kernel, so the roofline "
+                         "figures are taken in the sequential mode)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary figures of the default N = 1 run")
     ap.add_argument("--ramp-ms", type=float, default=250.0, help="untimed clock ramp in front of the timed region (0 = none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -686,10 +729,12 @@ def main():
     if (world == 1 and rank == 0 and not args.no_secondary and args.model == "clr" and args.encoders == "frozen"
             and args.modalities == "clr" and args.scaling == "weak"):
         secondary = {}
-        for key, kind, enc, mod in (("clr_encoders_precomputed", "clr", "precomputed", "clr"), ("camera_lidar", "clr", "frozen", "cl"),
+        for key, kind, enc, mod in (("clr_encode_ahead", "clr", "frozen", "clr"), ("clr_encoders_precomputed", "clr", "precomputed", "clr"),
+                                    ("camera_lidar", "clr", "frozen", "cl"),
                                     ("camera_lidar_encoders_precomputed", "clr", "precomputed", "cl"), ("pose_gnn", "pose", "frozen", "clr")):
             try:
-                w2 = Workload(kind, dev, rank, world, args, encoders=enc, modalities=mod)
+                a2 = argparse.Namespace(**{**vars(args), "encode_ahead": key == "clr_encode_ahead"})
+                w2 = Workload(kind, dev, rank, world, a2, encoders=enc, modalities=mod)
                 k2 = max(10, args.steps // 2)
                 m2 = measure(w2, args, world, dist, k2, max(3, args.warmup // 2), 60.0, use_graph=not args.no_graph)
                 secondary[key] = {"workload": w2.describe(world), "value": round(m2["edges"] / m2["dt"], 1), "unit": "edges/s",

@@ -27,11 +27,12 @@ def _bench_workload(kind, encoders="frozen"):
     import bench
     dev = torch.device("cuda:0")
     torch.cuda.set_stream(torch.cuda.Stream(dev))            # bench.main(): nothing runs on the legacy NULL stream
-    args = argparse.Namespace(no_dead_knn=False)
-    return bench, bench.Workload(kind, dev, 0, 1, args, encoders=encoders)
+    ahead = encoders == "frozen+ahead"                        # bench.py --encode-ahead (its `clr_encode_ahead` secondary)
+    args = argparse.Namespace(no_dead_knn=False, encode_ahead=ahead)
+    return bench, bench.Workload(kind, dev, 0, 1, args, encoders="frozen" if ahead else encoders)
 
 
-@pytest.mark.parametrize("kind,encoders", [("clr", "frozen"), ("clr", "precomputed"), ("pose", "frozen")])
+@pytest.mark.parametrize("kind,encoders", [("clr", "frozen"), ("clr", "frozen+ahead"), ("clr", "precomputed"), ("pose", "frozen")])
 def test_captured_replay_equals_eager_bitwise(kind, encoders):
     bench, wl = _bench_workload(kind, encoders)
     K = 4
