@@ -101,9 +101,7 @@ int side_get(int idx, Side** out) {
   SideSet& set = g_sides[dev];
   if (!set.made[idx]) {
     Side n{};
-    int prio_low = 0, prio_high = 0;                       // background work: lowest priority
-    B3D_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
-    B3D_HIP_CHECK(hipStreamCreateWithPriority(&n.s, hipStreamNonBlocking, prio_low));
+    B3D_HIP_CHECK(hipStreamCreateWithFlags(&n.s, hipStreamNonBlocking));
     B3D_HIP_CHECK(hipEventCreateWithFlags(&n.ev_fork, hipEventDisableTiming));
     B3D_HIP_CHECK(hipEventCreateWithFlags(&n.ev_join, hipEventDisableTiming));
     set.sd[idx] = n;
