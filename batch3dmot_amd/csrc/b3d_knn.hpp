@@ -229,31 +229,28 @@ __global__ __launch_bounds__(kKnnCentres * 64) void knn_tile_kernel(const float*
   };
   constexpr int PER = TR * (D / 4) / NT;                  // v4f staged per thread per tile
   static_assert(PER * NT == TR * (D / 4), "tile must divide over the workgroup");
-  // Software pipeline: while tile i is evaluated from LDS, the rows of tile i+1 are in flight to
-  // registers and the gather indices of tile i+2 are being fetched.
+  // Software pipeline, two tiles deep: while tile i is evaluated from LDS, the rows of tiles i+1 and i+2 are in flight to two
+  // register sets and the gather indices of tile i+3 are being fetched (a tile step is ~0.3 us of LDS reads and FMAs, the
+  // index -> row chain two dependent L2 round trips: with one tile in flight the launch was a latency chain).  Loads are
+  // unconditional (positions past the end of the union range read a clamped row nobody evaluates): a test around a load
+  // makes hipcc drain every load in flight behind it.
   int ridx[PER];
-  v4f v[PER];
+  v4f va[PER], vb[PER];
   auto load_idx = [&](int t0) {
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
       const int r = (threadIdx.x + j * NT) / (D / 4);
-      ridx[j] = (t0 + r < ue) ? order[t0 + r] : -1;
+      ridx[j] = order[min(t0 + r, N - 1)];
     }
   };
-  auto load_rows = [&]() {
+  auto load_rows = [&](v4f (&v)[PER]) {
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
-      const int i = threadIdx.x + j * NT;
-      const int c4 = i % (D / 4);
-      v[j] = v4f{0.f, 0.f, 0.f, 0.f};
-      if (ridx[j] >= 0) v[j] = *reinterpret_cast<const v4f*>(x + (size_t)ridx[j] * D + 4 * c4);
+      const int c4 = (threadIdx.x + j * NT) % (D / 4);
+      v[j] = *reinterpret_cast<const v4f*>(x + (size_t)ridx[j] * D + 4 * c4);
     }
   };
-  load_idx(ub);
-  load_rows();
-  load_idx(ub + TR);
-  int cur = 0;
-  for (int t0 = ub; t0 < ue; t0 += TR, cur ^= 1) {
+  auto tile_step = [&](int t0, int cur, v4f (&v)[PER]) {      // rows of tile t0 (in v) -> LDS; v <- rows of tile t0 + 2 TR; evaluate
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
       const int i = threadIdx.x + j * NT;
@@ -262,8 +259,8 @@ __global__ __launch_bounds__(kKnnCentres * 64) void knn_tile_kernel(const float*
       dst[0] = v[j].x; dst[1] = v[j].y; dst[2] = v[j].z; dst[3] = v[j].w;
     }
     __syncthreads();
-    load_rows();                                          // tile t0 + TR (indices fetched one tile ago)
-    load_idx(t0 + 2 * TR);
+    load_rows(v);                                         // tile t0 + 2 TR (indices fetched one step ago)
+    load_idx(t0 + 3 * TR);
     if (live && t0 > segbase && t0 + TR - segbase > kKnnList) extract(t0 < e ? t0 : e);   // the list cannot take this tile
 #pragma unroll
     for (int u = 0; u < TR / 64; ++u) {
@@ -276,6 +273,16 @@ __global__ __launch_bounds__(kKnnCentres * 64) void knn_tile_kernel(const float*
         dist[wave][p - segbase] = (p == pos) ? INF : s2;
       }
     }
+  };
+  load_idx(ub);
+  load_rows(va);
+  load_idx(ub + TR);
+  load_rows(vb);
+  load_idx(ub + 2 * TR);
+  for (int t0 = ub; t0 < ue; t0 += 2 * TR) {
+    tile_step(t0, 0, va);
+    if (t0 + TR >= ue) break;
+    tile_step(t0 + TR, 1, vb);
   }
   if (!live) return;
   extract(e);
