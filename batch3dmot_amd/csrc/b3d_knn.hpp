@@ -151,6 +151,8 @@ __global__ __launch_bounds__(kKnnCentres * 64) void knn_tile_kernel(const float*
   __shared__ float tile[2][TR * TS];                      // double buffered: one barrier per tile
   __shared__ float dist[kKnnCentres][kKnnList];
   __shared__ int wb[kKnnCentres], we[kKnnCentres];
+  __shared__ float pickd[kKnnCentres][32];               // the k survivors of a selection (b3d_knn.hpp: extract), one per lane
+  __shared__ int pickp[kKnnCentres][32];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int pos = blockIdx.x * kKnnCentres + wave;        // position in frame order
   const bool live = pos < N;
@@ -178,32 +180,88 @@ __global__ __launch_bounds__(kKnnCentres * 64) void knn_tile_kernel(const float*
   int bestp = 0x7fffffff;
   bool have = false;
   // k nearest of the listed positions [segbase, upto), merged into (bestd, bestp); the list restarts at `upto`.
-  auto extract = [&](int upto) {
+  auto extract = [&](int upto) __attribute__((always_inline)) {
     const int fill = upto - segbase;
     if (fill <= 0) return;
-    // The lane's candidates (list entries lane, lane + 64, ...) move to registers; each round is a register scan plus a
-    // DPP wavefront arg-min on (distance bits, position) keys.
+    // The lane's candidates (list entries lane, lane + 64, ...) move to registers.
     constexpr int SL = kKnnList / 64;
     float cd[SL];
 #pragma unroll
     for (int j = 0; j < SL; ++j) cd[j] = (64 * j + lane < fill) ? dist[wave][64 * j + lane] : INF;
+    // Selection by threshold (round 3; k rounds of scan + arg-min before: ~2,400 vector instructions per centre, the largest
+    // part of this kernel).  (1) The `want`-th smallest distance V by bisection on the float BITS (non-negative floats order
+    // like unsigned integers): a step is one compare per list register, the count is ballots + scalar popcounts.  (2)
+    // Exactly `want` survivors: everything below V, and of the entries equal to V those with the smallest positions (a
+    // second bisection, on the position, only if V is tied beyond what is needed).  (3) Survivors compacted through LDS,
+    // one per lane.  (4) A bitonic sort of the <= 32 (distance, position) keys across lanes 0..31 leaves the r-th nearest
+    // in lane r -- the same order the rounds produced.
+    unsigned cb[SL];
+#pragma unroll
+    for (int j = 0; j < SL; ++j) cb[j] = __float_as_uint(cd[j]);
+    auto count = [&](auto pred) __attribute__((always_inline)) {   // entries of the whole list that satisfy pred(j)
+      int c = 0;
+#pragma unroll
+      for (int j = 0; j < SL; ++j) c += __popcll(__ballot(pred(j)));
+      return c;
+    };
+    const unsigned kInfBits = 0x7f800000u;
+    const int navail = count([&](int j) { return cb[j] < kInfBits; });
+    const int want = kk < navail ? kk : navail;
     float sd = INF;
     int sp = 0x7fffffff;
-    for (int r = 0; r < kk; ++r) {
-      float bd = INF; int bj = 0;
+    if (want > 0) {
+      unsigned mn = 0xffffffffu, mx = 0u;
 #pragma unroll
-      for (int j = 0; j < SL; ++j)
-        if (cd[j] < bd) { bd = cd[j]; bj = j; }
-      unsigned hi = __float_as_uint(bd), lo = (bd < INF) ? (unsigned)(64 * bj + lane) : 0x7fffffffu;
-      wave_min_key(hi, lo);                                 // smallest distance, then smallest position
-      const int bp = (int)lo;
-      if (lane == r && bp != 0x7fffffff) { sd = __uint_as_float(hi); sp = bp + (segbase - b); }   // lane r: the r-th nearest
-      if ((bp & 63) == lane) {
-        const int slot = bp >> 6;
+      for (int j = 0; j < SL; ++j) { mn = min(mn, cb[j]); mx = max(mx, cb[j] < kInfBits ? cb[j] : 0u); }
 #pragma unroll
-        for (int j = 0; j < SL; ++j)
-          if (j == slot) cd[j] = INF;
+      for (int off = 32; off >= 1; off >>= 1) { mn = min(mn, (unsigned)__shfl_xor((int)mn, off, 64)); mx = max(mx, (unsigned)__shfl_xor((int)mx, off, 64)); }
+      unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)mn), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)mx);
+      while (lo < hi) {                                        // smallest V with count(<= V) >= want
+        const unsigned mid = lo + ((hi - lo) >> 1);
+        if (count([&](int j) { return cb[j] <= mid; }) >= want) hi = mid; else lo = mid + 1;
       }
+      const unsigned V = lo;
+      const int need_eq = want - count([&](int j) { return cb[j] < V; });      // >= 1
+      int ilim = 0x7fffffff;                                   // largest list index taken among the entries equal to V
+      if (count([&](int j) { return cb[j] == V; }) > need_eq) {
+        int il = 0, ih = kKnnList - 1;
+        while (il < ih) {
+          const int im = (il + ih) >> 1;
+          if (count([&](int j) { return cb[j] == V && 64 * j + lane <= im; }) >= need_eq) ih = im; else il = im + 1;
+        }
+        ilim = il;
+      }
+      // compaction: survivor number (entries of earlier registers) + (earlier lanes of this register)
+      int base = 0;
+#pragma unroll
+      for (int j = 0; j < SL; ++j) {
+        const bool sel = cb[j] < V || (cb[j] == V && 64 * j + lane <= ilim);
+        const unsigned long long m = __ballot(sel);
+        if (sel) {
+          const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+          pickd[wave][slot] = cd[j];
+          pickp[wave][slot] = 64 * j + lane;
+        }
+        base += __popcll(m);
+      }
+      float kd = INF;
+      int kp = 0x7fffffff;
+      if (lane < want) { kd = pickd[wave][lane]; kp = pickp[wave][lane]; }
+      // bitonic sort, ascending in (distance, position), over lanes 0..31 (lanes >= want hold +inf keys and stay behind)
+#pragma unroll
+      for (int ksz = 2; ksz <= 32; ksz <<= 1) {
+#pragma unroll
+        for (int st = ksz >> 1; st >= 1; st >>= 1) {
+          const float od = __shfl_xor(kd, st, 64);
+          const int op = __shfl_xor(kp, st, 64);
+          const bool up = (lane & ksz) == 0;                   // this block sorts ascending
+          const bool lower = (lane & st) == 0;                 // this lane keeps the smaller key of the pair (if ascending)
+          const bool o_less = (od < kd) || (od == kd && op < kp);
+          const bool take = (up == lower) ? o_less : !o_less && !(od == kd && op == kp);
+          if (take) { kd = od; kp = op; }
+        }
+      }
+      if (lane < want) { sd = kd; sp = kp + (segbase - b); }
     }
     if (!have) {
       bestd = sd; bestp = sp; have = true;
@@ -250,7 +308,7 @@ __global__ __launch_bounds__(kKnnCentres * 64) void knn_tile_kernel(const float*
       v[j] = *reinterpret_cast<const v4f*>(x + (size_t)ridx[j] * D + 4 * c4);
     }
   };
-  auto tile_step = [&](int t0, int cur, v4f (&v)[PER]) {      // rows of tile t0 (in v) -> LDS; v <- rows of tile t0 + 2 TR; evaluate
+  auto tile_step = [&](int t0, int cur, v4f (&v)[PER]) __attribute__((always_inline)) {      // rows of tile t0 (in v) -> LDS; v <- rows of tile t0 + 2 TR; evaluate
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
       const int i = threadIdx.x + j * NT;
