@@ -825,10 +825,29 @@ def main_infer(args, dev, rank, world, dist):
     rows = [model.modality_rows(b) for b in pool] if clr else None
     edges = [b.edge_index.size(1) for b in pool]
 
+    ahead = None
+    if clr and args.encode_ahead:
+        # train_step.EncodeAhead in a serving loop: the encoders of the NEXT window on a side stream under this window's GNN
+        # forward (one encoder pass and one forward per window, as in the sequential loop; static output buffers per pool window)
+        from batch3dmot_amd.train_step import EncodeAhead
+        ahead = EncodeAhead(model)
+        f32, i32 = dict(dtype=torch.float32, device=dev), dict(dtype=torch.int32, device=dev)
+        enc_static = [(torch.zeros(2000, 96, **f32), torch.zeros(r[0].numel(), 256, **f32), torch.zeros(r[0].numel(), **i32),
+                       torch.zeros(r[1].numel(), 256, **f32), torch.zeros(r[1].numel(), **i32)) for r in rows]
+        with torch.no_grad():
+            ahead.launch(pool[0], rows=rows[0], static=enc_static[0])
+            ahead.take(pool[0])
+
     def window(k):
         b = pool[k]
         if hasattr(b, "_b3d_graph"):
             del b._b3d_graph                     # the CSR/CSC build is part of every window
+        if ahead is not None:
+            kn = (k + 1) % len(pool)
+            ahead.launch(pool[kn], rows=rows[kn], static=enc_static[kn])
+            out = model(b, encoded=enc_static[k])
+            ahead.take(pool[kn])
+            return out
         return model(b, rows=rows[k]) if clr else model(b)
 
     with torch.no_grad():
@@ -893,6 +912,8 @@ def main_infer(args, dev, rank, world, dist):
     dtm, tot = reduce_over_ranks({"dt": dt, "edges": my_edges}, dev, world, dist)
     if rank == 0:
         name = "camera+LiDAR+radar GNN (clr_att_gnn), eval-mode encoders inside" if clr else "poses-only PoseGNN"
+        if ahead is not None:
+            name += " (the encoders of window k + 1 on a side stream under the forward of window k: train_step.EncodeAhead)"
         print(json.dumps({
             "metric": "edges/sec (forward only) on nuScenes-shaped detection graphs", "value": round(tot / dtm, 1), "unit": "edges/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dtm / args.steps, 4),

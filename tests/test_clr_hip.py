@@ -311,6 +311,13 @@ def test_inference_path_at_serving_size(dead_knn):
         torch.cuda.synchronize()
     assert torch.equal(co, go) and torch.equal(cs, gs)
     assert go.shape == (win.edge_index.size(1), 1) and 19000 <= go.shape[0] <= 21000
+    # bench.py --mode infer --encode-ahead: the encoders launched ahead on a side stream give the same bits
+    from batch3dmot_amd.train_step import EncodeAhead
+    ahead = EncodeAhead(m)
+    with torch.no_grad():
+        ahead.launch(b, rows=rows)
+        ao, as_ = m(b, encoded=ahead.take(b))
+    assert torch.equal(ao, go) and torch.equal(as_, gs)
 
 
 def test_embedding_cache_encodes_each_detection_once():
