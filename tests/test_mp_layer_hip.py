@@ -160,7 +160,7 @@ def test_clr_layer_forward_backward_match_oracle(n, k):
 
 
 @pytest.mark.parametrize("kind", ["p", "clr"])
-@pytest.mark.parametrize("case", ["inf", "nan", "huge", "denormal"])
+@pytest.mark.parametrize("case", ["inf", "nan", "huge", "denormal", "mixed"])
 def test_non_finite_and_extreme_inputs(kind, case):
     """Edge values through the bf16x6 layers (three-way bf16 split of every operand, six piece products).
 
@@ -193,6 +193,10 @@ def test_non_finite_and_extreme_inputs(kind, case):
     elif case == "huge":
         x[5, 3] = 3e38
         e[7, 2] = -3e38
+    elif case == "mixed":                                   # magnitudes 1e-20 .. 1e20 inside one row, alternating signs
+        mags = 10.0 ** torch.linspace(-20, 20, de)
+        e[7] = mags * torch.tensor([1.0, -1.0]).repeat(de // 2)
+        x[5, : dx // 2] = (10.0 ** torch.linspace(-15, 15, dx // 2))
     else:
         e[7] = 1e-40
         x[5, :8] = -3e-39
