@@ -55,3 +55,29 @@ def test_product_path_has_no_cpu_fallback():
     for f in ("pose_gnn.py", "_lib.py", "data.py", "synth.py"):
         txt = open(os.path.join(ROOT, "batch3dmot_amd", f)).read()
         assert "oracle" not in txt.replace("the oracle", ""), f
+
+
+def test_ctypes_structs_have_the_layout_of_the_header(tmp_path):
+    """include/b3d.h compiled by the host C compiler: sizeof of every struct the ctypes stub mirrors, and the offset of the last
+    field of the ones that grew (b3d_clr_inputs.encoders_ready), must equal what batch3dmot_amd/_lib.py declares -- a field added
+    on one side only would shift every pointer behind it without any symbol changing."""
+    import ctypes as C
+    import shutil
+    import subprocess
+    from batch3dmot_amd import _lib
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc is None:
+        pytest.skip("no host C compiler")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = ["b3d_graph", "b3d_linear", "b3d_gat", "b3d_batchnorm", "b3d_mp_weights", "b3d_pose_weights", "b3d_pose_grads",
+             "b3d_mha", "b3d_clr_weights", "b3d_clr_grads", "b3d_clr_inputs"]
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "b3d.h"\nint main(void) {\n'
+                   + "".join(f'  printf("{n} %zu\\n", sizeof({n}));\n' for n in names)
+                   + '  printf("b3d_clr_inputs.encoders_ready %zu\\n", offsetof(b3d_clr_inputs, encoders_ready));\n  return 0;\n}\n')
+    exe = tmp_path / "sizes"
+    subprocess.run([cc, "-I", os.path.join(root, "include"), str(src), "-o", str(exe)], check=True)
+    out = dict(line.split() for line in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines())
+    for n in names:
+        assert int(out[n]) == C.sizeof(getattr(_lib, n)), n
+    assert int(out["b3d_clr_inputs.encoders_ready"]) == _lib.b3d_clr_inputs.encoders_ready.offset
