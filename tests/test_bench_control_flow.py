@@ -50,6 +50,11 @@ def test_two_ranks_share_the_device_over_gloo():
              timeout=900)
     assert g["n_gpus"] == 2 and g["value"] > 0
     assert g["timed_region"].startswith("hipGraph replay") and "all-reduce" in g["timed_region"], g["timed_region"]
+    # ... and with the encoders of the next batch enqueued under the step (train_step.EncodeAhead inside graph A)
+    a = _run(["--backend", "gloo", "--all-ranks-on-device-0", "--steps", "4", "--warmup", "1", "--ramp-ms", "0", "--no-cpu-baseline",
+              "--encode-ahead"], timeout=900)
+    assert a["n_gpus"] == 2 and a["value"] > 0 and a["timed_region"].startswith("hipGraph replay")
+    assert "EncodeAhead" in a["config"]["workload"]
 
 
 def test_perf_guard_flags_a_slower_secondary(tmp_path):
