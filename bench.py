@@ -661,6 +661,31 @@ ROOFLINE_NOTE = ("roofline.kernel = the SURVEY.md 8a kernel family (message pass
                  "rocprofv3 durations, profiles/).  traffic: HBM bytes per launch from rocprofv3 PMC passes (see traffic_source).")
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start `torch.distributed.run` with N ranks of this same command as a
+    CHILD process (train_resnet_ae_ddp.py:288-290 self-spawns with mp.spawn) and exit with its code; rank 0 of the child
+    prints the JSON line on the stdout this process was given.  Called before anything initialises the GPU in this
+    process -- a process that has touched the GPU must never be replaced by another program -- and the parent makes no
+    GPU call at all (torch.cuda.device_count() does not initialise the runtime on this image)."""
+    import socket
+    import subprocess
+    if "--stub-cpu" not in sys.argv and "--all-ranks-on-device-0" not in sys.argv:
+        have = torch.cuda.device_count()
+        if have < n:
+            raise SystemExit(f"--gpus {n}: only {have} GPU(s) visible")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL across processes needs it on this stack
+    env.setdefault("OMP_NUM_THREADS", "8")
+    rc = subprocess.call(cmd, env=env)
+    if rc:
+        raise SystemExit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -693,8 +718,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world == 1 and args.gpus > 1:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args.gpus)            # nothing of this process has touched the GPU yet
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     import torch.distributed as dist
     if args.stub_cpu:
         return main_stub(args, rank, world, dist)

@@ -31,6 +31,19 @@ def test_two_rank_control_flow_on_cpu():
     assert d["untimed_clock_ramp_steps"] == 8 and d["value"] > 0
 
 
+def test_gpus_n_without_a_launcher_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (the command shape of the driver's N = 1 run): the
+    process starts the two ranks itself as children and relays rank 0's single JSON line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stub-cpu", "--steps", "5", "--warmup", "2"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["edges_summed_over_ranks"] == 2 * (120 + 130 + 100 + 110 + 120)
+
+
 def test_single_process_stub():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--stub-cpu", "--steps", "3", "--warmup", "1"],
                        capture_output=True, text=True, timeout=300, cwd=ROOT)
