@@ -37,10 +37,13 @@ class FlatGradSync:
     def world_size(self) -> int:
         return dist.get_world_size(self.group) if dist.is_initialized() else 1
 
-    def sync(self, force: bool = False) -> None:
+    def sync(self, force: bool = False, force_collective: bool = False) -> None:
         """grad <- mean over ranks.  Call between backward() and optimizer.step().  ``force``: reduce the flat buffer
-        even if no backward has been seen to write it (the backward ran inside a replayed hipGraph)."""
-        if self.world_size == 1:
+        even if no backward has been seen to write it (the backward ran inside a replayed hipGraph).
+        ``force_collective``: issue the collective in a process group of ONE rank too (mean over one rank: the values must
+        not change) -- how a 1-GPU box executes RCCL's all-reduce on the launch stream between two hipGraph replays,
+        the sequence every rank of an N-GPU run goes through (tests/test_rccl_single_rank.py)."""
+        if self.world_size == 1 and not (force_collective and dist.is_initialized()):
             return
         if self.flat_opt is not None and (force or not self.flat_opt.fresh):
             g = self.flat_opt.flat_grad
