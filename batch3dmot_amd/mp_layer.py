@@ -137,18 +137,32 @@ def mp_layer_forward(module, kind: str, x: torch.Tensor, edge_index: torch.Tenso
     return _MPLayerFunction.apply(kind, graph, training, x, initial_x, edge_attr, att_edge_attr, *params)
 
 
+# id(module) -> (key, weakref to the edge_index tensor, _lib.Graph, build event, build stream).  Kept OFF the module: a
+# _lib.Graph holds a ctypes struct with pointers, which copy.deepcopy / torch.save of the module cannot pickle; the entry goes
+# away with the module (weakref.finalize).
+_GRAPH_CACHE: dict = {}
+
+
 def _graph_for(module, edge_index: torch.Tensor, n: int):
     """CSR / CSC structure of ``edge_index``, built (and its endpoints validated: one blocking 4-byte read-back) once per
     edge_index TENSOR: a model that applies the layer ``gnn_depth`` times to the same graph pays for one build.  The entry
-    is keyed by the tensor object, its storage, shape and in-place version counter, and lives on the module.  Not used
-    inside a stream capture (a structure built there exists only once that graph has been replayed)."""
+    is keyed by the tensor object, its storage, shape and in-place version counter.  A structure built on one stream and
+    reused from another is ordered by the build's event.  Not used inside a stream capture (a structure built there exists
+    only once that graph has been replayed)."""
     import weakref
     if torch.cuda.is_current_stream_capturing():
         return _lib.Graph(edge_index.contiguous(), n)
     key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), tuple(edge_index.stride()), n)
-    hit = module.__dict__.get("_b3d_graph_cache")
+    cur = torch.cuda.current_stream(edge_index.device)
+    hit = _GRAPH_CACHE.get(id(module))
     if hit is not None and hit[0] == key and hit[1]() is edge_index:
+        if hit[4] != cur:
+            cur.wait_event(hit[3])
         return hit[2]
     graph = _lib.Graph(edge_index.contiguous(), n)
-    module.__dict__["_b3d_graph_cache"] = (key, weakref.ref(edge_index), graph)
+    ev = torch.cuda.Event()
+    ev.record(cur)
+    if id(module) not in _GRAPH_CACHE:
+        weakref.finalize(module, _GRAPH_CACHE.pop, id(module), None)
+    _GRAPH_CACHE[id(module)] = (key, weakref.ref(edge_index), graph, ev, cur)
     return graph

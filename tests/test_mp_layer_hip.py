@@ -222,6 +222,7 @@ def test_non_finite_and_extreme_inputs(kind, case):
 def test_layer_builds_the_graph_structure_once_per_edge_index_tensor():
     """Repeated applications to the same edge_index tensor (a model's gnn_depth iterations) share one CSR / CSC build and
     one endpoint validation; an in-place edit of the tensor, or another tensor, rebuilds."""
+    from batch3dmot_amd import mp_layer
     from batch3dmot_amd.pose_gnn import CausalMessagePassing
     dev = torch.device("cuda:0")
     d = _graph(60, 5, 3)
@@ -232,16 +233,36 @@ def test_layer_builds_the_graph_structure_once_per_edge_index_tensor():
     ei = d.edge_index.to(dev)
     with torch.no_grad():
         a = m(x, ei, e, x0)
-        g1 = m._b3d_graph_cache[2]
+        g1 = mp_layer._GRAPH_CACHE[id(m)][2]
         b = m(x, ei, e, x0)
-        assert m._b3d_graph_cache[2] is g1 and torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        assert mp_layer._GRAPH_CACHE[id(m)][2] is g1 and torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
         ei[0, 0] = ei[0, 1]                       # in place: the version counter moves
         m(x, ei, e, x0)
-        assert m._b3d_graph_cache[2] is not g1
-        g2 = m._b3d_graph_cache[2]
+        assert mp_layer._GRAPH_CACHE[id(m)][2] is not g1
+        g2 = mp_layer._GRAPH_CACHE[id(m)][2]
         m(x, ei.clone(), e, x0)
-        assert m._b3d_graph_cache[2] is not g2
+        assert mp_layer._GRAPH_CACHE[id(m)][2] is not g2
         bad = ei.clone()
         bad[1, 3] = N + 7
         with pytest.raises(ValueError):
             m(x, bad, e, x0)
+
+    # the cache lives outside the module (a _lib.Graph holds ctypes pointers): a layer that has run can be copied and
+    # pickled, a structure built on one stream is usable from another, and the entry dies with the module
+    import copy, gc, pickle
+    with torch.no_grad():
+        want = m(x, ei, e, x0)
+        m2 = copy.deepcopy(m)
+        pickle.dumps(m)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            got = m(x, ei, e, x0)
+        torch.cuda.current_stream().wait_stream(side)
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+        got2 = m2(x, ei, e, x0)
+        assert torch.equal(got2[0], want[0])
+    key = id(m)
+    del m, got, want
+    gc.collect()
+    assert key not in mp_layer._GRAPH_CACHE
