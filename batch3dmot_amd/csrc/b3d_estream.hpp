@@ -55,6 +55,13 @@ struct Seq {
   __host__ __device__ static constexpr int bias_off(int li) { int c = 0; for (int i = 0; i < li; ++i) c += n(i); return c; }   // floats
   static constexpr int NSTEPS = first_step(NL), NCH = NSTEPS / kChunkSteps, NBIAS = bias_off(NL);
   static_assert(NSTEPS % kChunkSteps == 0 && NCH % kSlots == 0, "whole chunks; the slot of a chunk must not depend on the tile");
+  // the hook tables (b3d_edge2.hpp) place a layer's loads / stores in front of ITS first chunk: every layer starts a chunk
+  __host__ __device__ static constexpr bool layers_start_chunks() {
+    for (int i = 0; i < NL; ++i)
+      if (first_step(i) % kChunkSteps != 0) return false;
+    return true;
+  }
+  static_assert(layers_start_chunks(), "a layer boundary inside a chunk: FwdHooks / BwdHooks::before(first_chunk(li)) would be mis-attributed");
   // chunk that holds the first step of layer li (hook tables)
   __host__ __device__ static constexpr int first_chunk(int li) { return first_step(li) / kChunkSteps; }
   static constexpr int WEIGHT_BYTES = NSTEPS * kStepBytes;

@@ -81,3 +81,14 @@ def test_ctypes_structs_have_the_layout_of_the_header(tmp_path):
     for n in names:
         assert int(out[n]) == C.sizeof(getattr(_lib, n)), n
     assert int(out["b3d_clr_inputs.encoders_ready"]) == _lib.b3d_clr_inputs.encoders_ready.offset
+
+
+def test_counted_vmcnt_waits_match_the_shipped_isa():
+    """tools/audit_vmcnt.py on the built library: every rendezvous of the fragment-streamed edge kernels waits for at most
+    as many younger vector-memory instructions as the code object really holds behind the last LDS-DMA piece, and those
+    kernels use no scratch."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "audit_vmcnt.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("violations 0") >= 4 and r.stdout.strip().endswith("OK"), r.stdout
