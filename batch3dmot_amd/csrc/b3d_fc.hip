@@ -5,12 +5,13 @@
 //     y = mask * ( act_in(x) . W^T + b )          act_in(x) = relu(x * in_scale + in_shift)  (the producer's BatchNorm + ReLU,
 //                                                  applied while the tile is staged; identity for the first Linear)
 //
-// with the per-column sum and sum of squares of y accumulated on the way out, from which the LAST workgroup to finish forms
+// with the per-column sum and squared deviations of y accumulated on the way out, from which the LAST workgroup to finish forms
 // this layer's BatchNorm affine (batch statistics in train mode, running statistics in eval mode) and updates the running
 // statistics as nn.BatchNorm1d does.  BatchNorm, ReLU and Dropout never run as kernels of their own, the normalised
 // activations never exist in memory; a final elementwise kernel (b3d_affine_relu) materialises the last activation.
-// Exact fp32: v_mfma_f32_16x16x4_f32 (bitwise an fmaf chain over k).  Statistics are summed in a fixed order (per-tile
-// partials in a slab, added in tile order in float64): bitwise reproducible.
+// Products are bf16x6 (below): fp32-class accuracy, NOT bitwise an fp32 fmaf chain, and a +-inf input gives NaN (inf - inf in the
+// exact split) where torch's Linear gives +-inf.  Statistics: per-tile (sum, M2 about the tile mean) in a slab, combined in tile
+// order in float64 (Chan): bitwise reproducible, and as well conditioned as torch's Welford for badly centred activations.
 #include "b3d_common.hpp"
 #include "b3d_launch.hpp"
 #include "b3d_dev.hpp"
@@ -166,7 +167,8 @@ __global__ __launch_bounds__(kFcThreads) void fc_kernel(const FcArgs a) {
     }
   }
   // ---- epilogue: D of block bi: row = m0 + 32 wr + 16 bi + 4 lk + reg, column = n0 + 16 wc + li ----
-  float cs = 0.f, cq = 0.f;                                  // this lane's partial sums of its column
+  float cs = 0.f;                                            // this lane's partial sum of its column
+  float vals[8];                                             // ... and its eight outputs (zero where the row or column does not exist)
   {
     const int n = n0 + 16 * wc + li;
     const bool nok = n < a.N;
@@ -178,24 +180,43 @@ __global__ __launch_bounds__(kFcThreads) void fc_kernel(const FcArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = m0 + 32 * wr + 16 * bi + 4 * lk + r;
+        float v = 0.f;
         if (row < a.B && nok) {
-          float v = acc[r] + bv;
+          v = acc[r] + bv;
           if (a.mask) v *= a.mask[(size_t)row * a.N + n];
           v += av;
           a.y[(size_t)row * a.N + n] = v;
           cs += v;
-          cq = fmaf(v, v, cq);
         }
+        vals[4 * bi + r] = v;
       }
     }
   }
   if (!a.gamma) return;
-  // column sums in a fixed order: the four row groups of a wavefront (lanes li + 16 lk), then the two row halves
+  // Per-tile column statistics as (sum, M2 = sum of squared deviations from the TILE's mean) -- E[y^2] - E[y]^2 of fp32 sums cancels
+  // when |mean| >> std -- in a fixed order: the four row groups of a wavefront (lanes li + 16 lk), then the two row halves.
   {
-    float s = cs, q = cq;
-    s += __shfl_xor(s, 16, 64); q += __shfl_xor(q, 16, 64);
-    s += __shfl_xor(s, 32, 64); q += __shfl_xor(q, 32, 64);
-    if (lk == 0) { colsum[wr][0][16 * wc + li] = s; colsum[wr][1][16 * wc + li] = q; }
+    float s = cs;
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    if (lk == 0) colsum[wr][0][16 * wc + li] = s;
+  }
+  __syncthreads();
+  {
+    const int rows_here = min(kTM, a.B - m0);
+    const float tmean = (colsum[0][0][16 * wc + li] + colsum[1][0][16 * wc + li]) / (float)rows_here;
+    float q = 0.f;
+#pragma unroll
+    for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + 32 * wr + 16 * bi + 4 * lk + r;
+        const float dv = vals[4 * bi + r] - tmean;
+        q = row < a.B ? fmaf(dv, dv, q) : q;
+      }
+    q += __shfl_xor(q, 16, 64);
+    q += __shfl_xor(q, 32, 64);
+    if (lk == 0) colsum[wr][1][16 * wc + li] = q;
   }
   __syncthreads();
   if (tid < 2 * kTN) {
@@ -223,15 +244,18 @@ __global__ __launch_bounds__(kFcThreads) void fc_kernel(const FcArgs a) {
   for (int n = tid; n < a.N; n += kFcThreads) {
     float mean, var;
     if (a.train) {
-      double s = 0.0, q = 0.0;
-      for (int t = 0; t < nrt; ++t) {
-        s += (double)a.part[((size_t)t * 2) * a.N + n];
-        q += (double)a.part[((size_t)t * 2 + 1) * a.N + n];
-      }
+      // Chan's combination of the per-tile (count, sum, M2) in float64, tile order
+      double s = 0.0;
+      for (int t = 0; t < nrt; ++t) s += (double)a.part[((size_t)t * 2) * a.N + n];
       const double cnt = (double)a.B;
       const double m = s / cnt;
-      double v = q / cnt - m * m;
-      if (v < 0.0) v = 0.0;
+      double m2 = 0.0;
+      for (int t = 0; t < nrt; ++t) {
+        const double nt = (double)min(kTM, a.B - t * kTM);
+        const double dm = (double)a.part[((size_t)t * 2) * a.N + n] / nt - m;
+        m2 += (double)a.part[((size_t)t * 2 + 1) * a.N + n] + nt * dm * dm;
+      }
+      double v = m2 / cnt;
       mean = (float)m; var = (float)v;
       if (a.running_mean) {
         const double mom = a.momentum >= 0.f ? (double)a.momentum : 1.0 / (double)nbt_after;

@@ -1152,14 +1152,17 @@ def cpu_baseline(wl: Workload):
 
     # SURVEY.md 8d asks for os.cpu_count() threads and for 1 thread.  A short sweep (1 warm-up + 2 steps each) shows where this
     # graph size stops scaling on the box's cores; the sample proper runs at the fastest setting of the sweep.
-    sweep = {}
+    sweep, t_sweep = {}, time.perf_counter()
     for t in sorted({min(16, cores), min(64, cores), cores}):
+        if time.perf_counter() - t_sweep > 40.0:              # bounded: the line must not wait minutes for an oversubscribed point
+            sweep[t] = None
+            continue
         try:
             sweep[t] = round(run(t, wl.pool_cpu, 1, 2)[0], 1)
         except Exception:                                     # a thread count the host refuses must not cost the line
             pass
-    if sweep:
-        threads = max(sweep, key=lambda t: sweep[t])
+    if any(v_ for v_ in sweep.values()):
+        threads = max((t for t in sweep if sweep[t]), key=lambda t: sweep[t])
     # SURVEY.md 8d protocol, bounded to ~1 minute of CPU work: >= 2 warm-up steps, median of >= 10 (40 for the small model)
     if wl.kind == "pose":
         v, dt = run(threads, wl.pool_cpu, 5, 40)

@@ -349,7 +349,10 @@ int b3d_resnet_encode(const b3d_linear* conv, const b3d_batchnorm* bn, const flo
  * num_batches_tracked updated as nn.BatchNorm1d does; summed in a fixed order, bitwise reproducible), from the running statistics
  * in eval mode.  The first 256 bytes of the (256-byte aligned) workspace are an arrival counter that must be ZERO on entry; the
  * launch leaves it zero (b3d_fc_ticket_init zeroes it for a fresh workspace).  b3d_affine_relu: out = relu(y * scale + shift),
- * the last activation of a chain.  Exact fp32 (v_mfma_f32_16x16x4_f32). */
+ * the last activation of a chain.  Products are bf16x6 (exact three-way bf16 split of both operands, six of the nine piece
+ * products on v_mfma_f32_16x16x32_bf16, fp32 accumulation): fp32-class accuracy (~3e-7 relative), not bitwise an fp32 fmaf chain;
+ * a +-inf input yields NaN (inf - inf in the split) where torch's Linear yields +-inf.  Batch variance: per-tile sums of squared
+ * deviations from the tile mean, combined in float64 (no E[y^2] - E[y]^2 cancellation). */
 size_t b3d_fc_bn_workspace_bytes(int32_t B, int32_t N);
 int b3d_fc_ticket_init(void* workspace, size_t workspace_bytes, b3d_stream stream);
 int b3d_fc_bn_forward(const float* x, int32_t B, int32_t K, const float* w, const float* bias, int32_t N,
