@@ -45,6 +45,8 @@ class CausalMessagePassing(nn.Module):
 def modality_present(feats: torch.Tensor) -> torch.Tensor:
     """clr_att_gnn.py:107-121: node n has the modality iff the sum of its row is non-zero."""
     n = feats.size(0)
+    if n == 0:
+        return torch.empty(0, dtype=torch.bool, device=feats.device)
     f = feats.reshape(n, -1).contiguous()
     _lib.require_cuda(f, "modality features", torch.float32)
     has = torch.empty(n, dtype=torch.uint8, device=f.device)
@@ -58,6 +60,11 @@ def modality_row_ids(feats: torch.Tensor) -> torch.Tensor:
     the presence mask, then a one-workgroup ballot / scan compaction).  The count is a shape: one read-back, on the
     current stream."""
     n = feats.size(0)
+    if n == 0:                                        # empty batch: no rows (reshape(0, -1) cannot infer the width)
+        return torch.empty(0, dtype=torch.int64, device=feats.device)
+    if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("modality_row_ids reads the row count back to the host and cannot run inside a stream capture: "
+                           "pass rows=modality_rows(data) computed in front of it")
     f = feats.reshape(n, -1).contiguous()
     _lib.require_cuda(f, "modality features", torch.float32)
     has = torch.empty(max(n, 1), dtype=torch.uint8, device=f.device)
@@ -435,6 +442,16 @@ class GNN(nn.Module):
             # training step the same overlap measured 1.6 % SLOWER (the train-mode statistics kernels of the point stacks
             # and the forward prefix get in each other's way), so there the encoders are joined first.
             encoded, ready = self._encode(data, rows, join=torch.is_grad_enabled())
+        try:
+            return self._forward_encoded(data, encoded, ready, pose_feats, edge_index, edge_attr, node_timestamps)
+        except BaseException:
+            # the encoders may still be running on the side streams (join=False): nothing below joined them, and the caller
+            # is about to drop the tensors they read -- order the caller's stream behind them before the error travels up
+            if ready is not None:
+                torch.cuda.current_stream(pose_feats.device).wait_event(ready)
+            raise
+
+    def _forward_encoded(self, data, encoded, ready, pose_feats, edge_index, edge_attr, node_timestamps):
         x_img, pointnet_out, lidar_nodes, radarnet_out, radar_nodes = encoded
         graph = getattr(data, "_b3d_graph", None)
         if graph is None or graph.N != pose_feats.size(0) or graph.E != edge_index.size(1) \

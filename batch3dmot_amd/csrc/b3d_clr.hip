@@ -88,11 +88,6 @@ constexpr int kStreamRowsPerTask = 768;          // message-passing stacks (x up
 constexpr int kStreamNodeRowsPerTask = 128;      // hoisted first layers: node columns contract over N rows x depth layers
 constexpr int kStreamNodeRowsPerTaskAtt = 512;   // att_edge_encoder.0's node columns: one variant, a [512, 288] partial per task
 constexpr int kStreamRowsPerTaskAtt = 1536;      // att_edge_encoder (one variant)
-// Round 4: the per-edge matrices of the message-passing stacks take their weight gradient LAYER BY LAYER, right behind the layer's
-// edge_bwd on a side stream (its G tensors and activations are then L2 / Infinity-Cache hits instead of an end-of-step HBM
-// sweep, and the launch runs underneath the node kernels of the next layer, which leave a quarter of the CUs idle); a launch
-// holds one layer variant, so its tasks are longer in rows and the slab set (re-read and re-written by every layer) smaller.
-constexpr int kLayerRowsPerTask = 1024;
 
 // column blocks of the hoisted first-layer gradients: (linear, first column, width, rows contracted over edges?)
 enum { VL_EU0XI, VL_EU0XJ, VL_EU0E, VL_FU0X, VL_FU0E, VL_FU0X0, VL_PA0X, VL_PA0E, VL_PA0X0, VL_AT0I, VL_AT0J, VL_AT0E, VL_COUNT };
@@ -135,21 +130,11 @@ struct Ws {
   size_t bytes;
   bool ok;
 };
-constexpr int kTableCap = 640, kTaskCap = 65536;
-constexpr int kLayerJobsCap = 16;                 // jobs of one per-layer weight-gradient launch (7 at the model's widths)
+constexpr int kTableCap = 320, kTaskCap = 32768;
 
 constexpr int kStreamRowsPerTaskFc = 128;     // modality heads: a few thousand rows
 static bool is_fc(int lin) { return lin >= FL0 && lin <= FR2; }
 static bool is_streamed(int lin) { return lin >= AT0 || is_fc(lin); }   // att_edge_encoder, message passing, fc heads
-static bool is_layerwise(int lin) { return lin == EU1 || lin == EU2 || lin == PA1 || lin == FU1; }
-static int layer_rows_per_task() {
-  static const int v = [] {
-    const char* e = getenv("B3D_WG_LAYER_RPT");          // tuning aid (tools/): must not change between workspace query and use
-    const int r = e ? atoi(e) : 0;
-    return (r >= 128 && r % 32 == 0) ? r : kLayerRowsPerTask;
-  }();
-  return v;
-}
 
 static void carve(Ws& w, void* ws, size_t ws_bytes, int N, int E, int nl, int nr, int depth, uint32_t flags) {
   Carver c(ws, ws_bytes);
@@ -268,7 +253,7 @@ static void carve(Ws& w, void* ws, size_t ws_bytes, int N, int E, int nl, int nr
       ls.N = kDims[i].N; ls.K = kDims[i].K; ls.NP = pad16(ls.N); ls.KP = pad16(ls.K);
       const long rows = kRowKind[i] == 0 ? E : kRowKind[i] == 1 ? N : kRowKind[i] == 2 ? nl : nr;
       if (is_streamed(i)) {
-        const int rpt = is_fc(i) ? kStreamRowsPerTaskFc : (i <= AT4) ? kStreamRowsPerTaskAtt : is_layerwise(i) ? layer_rows_per_task() : kStreamRowsPerTask;
+        const int rpt = is_fc(i) ? kStreamRowsPerTaskFc : (i <= AT4) ? kStreamRowsPerTaskAtt : kStreamRowsPerTask;
         ls.nchunks = (int)((rows + rpt - 1) / rpt);
         if (ls.nchunks < 1) ls.nchunks = 1;
       } else {
@@ -281,7 +266,7 @@ static void carve(Ws& w, void* ws, size_t ws_bytes, int N, int E, int nl, int nr
       LinSlab& ls = w.vlin[v];
       ls.N = kDims[kVl[v].lin].N; ls.K = kVl[v].width; ls.NP = pad16(ls.N); ls.KP = pad16(ls.K);
       const long rows = kVl[v].on_edges ? E : N;
-      const int rpt = kVl[v].on_edges ? (kVl[v].lin == AT0 ? kStreamRowsPerTaskAtt : layer_rows_per_task())
+      const int rpt = kVl[v].on_edges ? (kVl[v].lin == AT0 ? kStreamRowsPerTaskAtt : kStreamRowsPerTask)
                                       : (kVl[v].lin == AT0 ? kStreamNodeRowsPerTaskAtt : kStreamNodeRowsPerTask);
       ls.nchunks = (int)((rows + rpt - 1) / rpt);
       if (ls.nchunks < 1) ls.nchunks = 1;
@@ -741,173 +726,6 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
     WgJob j0 = make_job(w.lin[C0], E, seg(w.gc1, nullptr, 32, 0, 32)); add_act(j0, seg(w.e[depth], nullptr, D::DE, 0, D::DE)); smallE.jobs[smallE.njobs++] = j0;
   }
 
-  // ---- weight-gradient job builder (the launches are issued further down: per layer behind each edge_bwd, the rest at the end) --
-  // The cooperative bf16x6 kernel (b3d_wgemm.hpp) takes every block it has a shape for; the per-wavefront streaming kernel
-  // (b3d_wstream2.hpp) keeps the rest.  The device tables are carved into one slice per launch.
-  hipLaunchKernelGGL(iota_kernel, dim3(((E > N ? E : N) + 255) / 256), dim3(256), 0, stream, w.iota, E > N ? E : N);
-  B3D_TRY(launch_check("iota_kernel"));
-  B3D_HIP_CHECK(hipMemsetAsync(w.zrow, 0, 256 * sizeof(float), stream));
-  const int* iota = w.iota;
-  int table_used = 0, tasks_used = 0;                       // slices handed out so far
-  auto slice = [&](WsLauncher& L, int jobs, int tasks, hipStream_t st) -> int {
-    B3D_REQUIRE(table_used + jobs <= kTableCap && tasks_used + tasks <= kTaskCap,
-                "weight gradient: job table overflow (%d + %d jobs, %d + %d tasks)", table_used, jobs, tasks_used, tasks);
-    L.begin(w.ws_table + table_used, jobs, w.ws_task_job + tasks_used, tasks, st);
-    table_used += jobs; tasks_used += tasks;
-    return B3D_OK;
-  };
-  struct Col { const float* p; const int* idx; long vstride; int stride; int col0; int width; };   // activation columns
-  // Cooperative decomposition: column groups of <= 256 per activation segment, row groups chosen per column group
-  // from the compiled shapes; false (nothing added) if some pair has none.
-  auto col_groups = [](int width, int* out) -> int {
-    switch (width) {
-      case 512: out[0] = 256; out[1] = 256; return 2;
-      case 384: out[0] = 256; out[1] = 128; return 2;
-      case 288: out[0] = 192; out[1] = 96; return 2;
-      case 256: case 192: case 128: case 96: case 64: out[0] = width; return 1;
-      default: return 0;
-    }
-  };
-  auto row_groups = [](int n, int kg, int* out) -> int {
-    int k = 0;
-    if (kg <= 96) {
-      while (n >= 256) { out[k++] = 256; n -= 256; }
-      while (n >= 192) { out[k++] = 192; n -= 192; }
-      if (n == 128 && kg == 96) { out[k++] = 128; n = 0; }
-    } else if (kg == 128) {
-      if (n % 192 == 0) while (n > 0) { out[k++] = 192; n -= 192; }
-      while (n >= 128) { out[k++] = 128; n -= 128; }
-      if (n == 96 || n == 64) { out[k++] = n; n = 0; }
-    } else {
-      while (n >= 128) { out[k++] = 128; n -= 128; }
-    }
-    return n == 0 ? k : -1;
-  };
-  auto add_block_coop = [&](std::vector<WsJob>& out, LinSlab& ls, long rows, int nvar, int rpt, const float* gp, const int* gidx, long gvs,
-                            int gstride, int gcol0, const Col* cols, int ncols, bool with_bias, bool accumulate) -> bool {
-    WsJob jobs[48];
-    int nj = 0;
-    int wcol = 0;
-    for (int ci = 0; ci < ncols; ++ci) {
-      if (cols[ci].idx) return false;                      // gathered activations: streaming kernel
-      if ((uintptr_t)cols[ci].p % 16 != 0 || cols[ci].stride % 4 != 0 || cols[ci].col0 % 4 != 0 || cols[ci].vstride % 4 != 0) return false;
-      int cg[4];
-      int ncg = col_groups(cols[ci].width, cg);
-      if (ncg == 0) return false;
-      int c0 = 0;
-      for (int k = 0; k < ncg; ++k) {
-        int kgs[4] = {cg[k], 0, 0, 0}, nk = 1;
-        int rg[8];
-        int nr = row_groups(ls.N, cg[k], rg);
-        if (nr < 0 && cg[k] > 128) {                       // 192 x 256 and the like: narrower column groups
-          nk = 0;
-          for (int left = cg[k]; left > 0;) { const int t = left >= 128 ? 128 : left; kgs[nk++] = t; left -= t; }
-        }
-        for (int kk = 0; kk < nk; ++kk) {
-          nr = row_groups(ls.N, kgs[kk], rg);
-          if (nr < 0) return false;
-          int g0 = 0;
-          for (int r = 0; r < nr; ++r) {
-            const int shape = wgm_shape(rg[r], kgs[kk]);
-            if (shape < 0 || nj == 48) return false;
-            WsJob jb;
-            memset(&jb, 0, sizeof(jb));
-            jb.g.ptr = gp; jb.g.idx = gidx ? gidx : iota; jb.g.vstride = gvs; jb.g.stride = gstride; jb.g.col0 = gcol0 + g0;
-            jb.act[0].ptr = cols[ci].p; jb.act[0].idx = iota; jb.act[0].vstride = cols[ci].vstride;
-            jb.act[0].stride = cols[ci].stride; jb.act[0].col0 = cols[ci].col0 + c0;
-            jb.act[1] = jb.act[0]; jb.act[2] = jb.act[0];
-            jb.wcol[0] = wcol + c0; jb.wrow = g0;
-            jb.write_bias = (with_bias && ci == 0 && c0 == 0) ? 1 : 0;     // the first column group of every row group
-            jb.accumulate = accumulate ? 1 : 0;
-            jb.shape = shape;
-            jb.rows = (int)rows; jb.nvar = nvar; jb.rows_per_task = rpt;
-            jb.NP = ls.NP; jb.KP = ls.KP; jb.slab = ls.slab;
-            if (gidx && shape != WGM_128_192) return false;             // the only compiled gathered shape
-            jobs[nj++] = jb;
-            g0 += rg[r];
-          }
-          c0 += kgs[kk];
-        }
-      }
-      wcol += cols[ci].width;
-    }
-    for (int j = 0; j < nj; ++j) out.push_back(jobs[j]);
-    return true;
-  };
-  // One workgroup per task, dispatched in task order as CUs free up: longest tasks first, or the 60 us tasks of
-  // att_edge_encoder (last in plan order) start when the rest of the chip has run dry.  Cost of a task ~ its 32-row
-  // steps times the bytes of a step.
-  auto launch_coop = [&](std::vector<WsJob>& jobs, WsLauncher& L, const char* what) -> int {
-    auto cost = [](const WsJob& j) {
-      static const int wd[WGM_SHAPES] = {384, 320, 256, 192, 320, 352, 256, 288, 224, 320, 224, 384};
-      const long rows = j.rows < j.rows_per_task ? j.rows : j.rows_per_task;
-      return ((rows + kWgmRows - 1) / kWgmRows) * (long)j.nvar * wd[j.shape];
-    };
-    std::stable_sort(jobs.begin(), jobs.end(), [&](const WsJob& x, const WsJob& y) { return cost(x) > cost(y); });
-    for (const WsJob& j : jobs) L.add(j);
-    L.flush();
-    B3D_REQUIRE(L.status == 0, "cooperative weight gradient (%s): job table overflow (%d jobs, %d tasks)", what, L.njobs, L.total_tasks);
-    if (L.total_tasks > 0) {
-      B3D_TRY(set_lds(wgemm_kernel, kWgmLdsBytes));
-      ProfScope ps(B3D_K_WGRAD_EDGE, L.stream);
-      hipLaunchKernelGGL(wgemm_kernel, dim3((unsigned)(L.total_tasks < 2048 ? L.total_tasks : 2048)), dim3(kWgmThreads), kWgmLdsBytes,
-                         L.stream, (const WsJob*)L.table, (const int*)L.task_job, L.total_tasks, w.iota);
-      B3D_TRY(launch_check("wgemm_kernel"));
-    }
-    return B3D_OK;
-  };
-  // Where the weight-gradient launches go: a library side stream (B3D_WGRAD_OVERLAP=0: the caller's stream, same order)
-  const bool wg_overlap = [] { const char* e = getenv("B3D_WGRAD_OVERLAP"); return !(e && e[0] == '0'); }();
-  Side* wg_side = nullptr;
-  hipStream_t wg_stream = stream;
-  if (wg_overlap) {
-    B3D_TRY(side_get(1, &wg_side));
-    wg_stream = wg_side->s;
-  }
-  auto wg_fork = [&]() -> int { return wg_overlap ? side_fork(stream, wg_side) : B3D_OK; };
-  const int rpl = layer_rows_per_task();
-  const int layer_tasks_cap = kLayerJobsCap * (int)((E + rpl - 1) / rpl + 1);
-  // Layer l's per-edge matrices (edge_update .0[e | att] .2 .4, create_*_msgs .0[e'] .2), one layer variant, accumulated over the
-  // layers in the slabs: first written by the first layer that reaches them (backward order), added to by the others.
-  auto layer_wgrad = [&](int l) -> int {
-    std::vector<WsJob> jobs;
-    jobs.reserve(kLayerJobsCap);
-    const bool msgs = (l < depth - 1);
-    const bool acc_eu = (l != depth - 1), acc_msg = (l != depth - 2);
-    {  // edge_update.0 [256, 320], columns e 192:256 | att 256:320: one job over both sources (GdH1 is read once)
-      LinSlab& ls = w.vlin[VL_EU0E];
-      ls.used = true;
-      WsJob jb;
-      memset(&jb, 0, sizeof(jb));
-      jb.g.ptr = w.GdH1 + l * eL1; jb.g.idx = iota; jb.g.vstride = 0; jb.g.stride = D::EH1; jb.g.col0 = 0;
-      jb.act[0].ptr = w.e[l]; jb.act[0].idx = iota; jb.act[0].vstride = 0; jb.act[0].stride = D::DE; jb.act[0].col0 = 0;
-      jb.act[1].ptr = w.att; jb.act[1].idx = iota; jb.act[1].vstride = 0; jb.act[1].stride = 64; jb.act[1].col0 = 0;
-      jb.act[2] = jb.act[0];
-      jb.wcol[0] = 0; jb.wcol[1] = 64; jb.wrow = 0; jb.write_bias = 1; jb.accumulate = acc_eu ? 1 : 0; jb.shape = WGM_256_128;
-      jb.rows = E; jb.nvar = 1; jb.rows_per_task = rpl; jb.NP = ls.NP; jb.KP = ls.KP; jb.slab = ls.slab;
-      jobs.push_back(jb);
-    }
-    bool ok = true;
-    auto mat = [&](LinSlab& ls, const float* gp, const int* gidx, int gstride, int gcol0, const float* ap, int astride, int awidth, bool acc) {
-      ls.used = true;
-      Col c[1] = {{ap, nullptr, 0, astride, 0, awidth}};
-      ok = ok && add_block_coop(jobs, ls, E, 1, rpl, gp, gidx, 0, gstride, gcol0, c, 1, true, acc);
-    };
-    mat(w.lin[EU1], w.GdH2 + l * eL2, nullptr, D::EH2, 0, w.sH1[l], D::EH1, 256, acc_eu);
-    mat(w.lin[EU2], w.Gde + l * eLe, nullptr, D::DE, 0, w.sH2[l], D::EH2, 128, acc_eu);
-    if (msgs) {
-      mat(w.vlin[VL_PA0E], w.GdP1 + l * eLm, nullptr, D::MH, 0, w.e[l + 1], D::DE, 64, acc_msg);
-      mat(w.vlin[VL_FU0E], w.GdF1 + l * eLm, nullptr, D::MH, 0, w.e[l + 1], D::DE, 64, acc_msg);
-      mat(w.lin[PA1], w.dM + l * nLm, dst, D::NIN, 0, w.sP1[l], D::MH, 192, acc_msg);
-      mat(w.lin[FU1], w.dM + l * nLm, src, D::NIN, D::DM, w.sF1[l], D::MH, 192, acc_msg);
-    }
-    B3D_REQUIRE(ok && (int)jobs.size() <= kLayerJobsCap, "per-layer weight gradient: a block has no cooperative shape");
-    WsLauncher L;
-    B3D_TRY(slice(L, kLayerJobsCap, layer_tasks_cap, wg_stream));
-    B3D_TRY(wg_fork());                                    // the layer's G tensors are complete on `stream` here
-    return launch_coop(jobs, L, "layer");
-  };
-
   // ---- message-passing layers, last to first (data gradients; G tensors kept per layer) -------------
   bool dx0_first = true, da_first = true;
   // hoisted first layers: per-node gradient of T from layer `lay`'s first-layer gradients (kept per layer: weight gradient)
@@ -961,7 +779,6 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
     }
     da_first = false;
     cur ^= 1;
-    B3D_TRY(layer_wgrad(l));
   }
   // layer 0's (dx | dx0) for the node encoder
   B3D_TRY(listsum(0));
@@ -1025,19 +842,130 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
 
   }
 
-  // ---- remaining streamed weight gradients: node columns of the hoisted first layers, node update, fc heads, att_edge_encoder ----
+  // ---- encoders ----------------------------------------------------------------------------------------
+  // node encoder (x = initial_x): running d initial_x + layer 0's (dx | dx0)
+  using In = LoadNodeEncGradH<6>;
+  ChainBwdArgs<In, StoreNone> a;
+  memset(&a, 0, sizeof(a));
+  a.rows = N;
+  a.in = In{nullptr, dx0_first ? nullptr : w.dx0_acc, w.gx};
+  a.gtop = w.gn_top; a.act[0] = w.ne_a1; a.gsave[0] = w.gn1; a.wpack = w.wp_neT;
+  B3D_TRY(launch_rows<kNWNode>(chain_bwd_kernel<SeqNET, In, StoreNone, kNWNode>, "node_encoder_bwd", a, N, stream, B3D_K_OTHER, chain_lds<SeqNET>()));
+  WgJob n1 = make_job(w.lin[NE1], N, seg(w.gn_top, nullptr, 96, 0, 96)); add_act(n1, seg(w.ne_a1, nullptr, 48, 0, 48)); smallN.jobs[smallN.njobs++] = n1;
+  WgJob n0 = make_job(w.lin[NE0], N, seg(w.gn1, nullptr, 48, 0, 48)); add_act(n0, seg(w.pose_pad, nullptr, 32, 0, 19)); smallN.jobs[smallN.njobs++] = n0;
+  {  // edge encoder: e[0] feeds layer 0 AND att_edge_encoder (columns 576:640 of its input)
+    using In = LoadAdd2<4>;
+    ChainBwdArgs<In, StoreNone> a;
+    memset(&a, 0, sizeof(a));
+    a.rows = E;
+    a.in = In{w.de[cur], D::DE, 0, w.de0, 64, 0, nullptr};
+    a.gtop = w.ge_top; a.act[0] = w.ee_a2; a.act[1] = w.ee_a1; a.gsave[0] = w.ge2; a.gsave[1] = w.ge1; a.wpack = w.wp_eeT;
+    B3D_TRY(launch_rows<kNWEdge>(chain_bwd_kernel<SeqEET, In, StoreNone, kNWEdge>, "edge_encoder_bwd", a, E, stream, B3D_K_OTHER, chain_lds<SeqEET>()));
+    WgJob e2 = make_job(w.lin[EE2], E, seg(w.ge_top, nullptr, 64, 0, 64)); add_act(e2, seg(w.ee_a2, nullptr, 32, 0, 32)); smallE.jobs[smallE.njobs++] = e2;
+    WgJob e1 = make_job(w.lin[EE1], E, seg(w.ge2, nullptr, 32, 0, 32)); add_act(e1, seg(w.ee_a1, nullptr, 16, 0, 16)); smallE.jobs[smallE.njobs++] = e1;
+    WgJob e0 = make_job(w.lin[EE0], E, seg(w.ge1, nullptr, 16, 0, 16)); add_act(e0, seg(w.ea_pad, nullptr, 16, 0, 4)); smallE.jobs[smallE.njobs++] = e0;
+  }
+  B3D_TRY((launch_wgrad<8, 1>(smallE, stream, B3D_K_WGRAD_OTHER)));
+  B3D_TRY((launch_wgrad<8, 1>(smallN, stream, B3D_K_WGRAD_OTHER)));
+
+  // ---- streamed weight gradients: message-passing stacks (all layers) + att_edge_encoder -------------
   {
+    // The cooperative bf16x6 kernel (b3d_wgemm.hpp) takes every block it has a shape for; the per-wavefront streaming kernel
+    // (b3d_wstream2.hpp) keeps the rest.  Both share the device tables, split in halves.
     WsLauncher wl, wlc;
-    std::vector<WsJob> coop_jobs;                // added to wlc longest task first
+    std::vector<WsJob> coop_jobs;                // added to wlc longest task first (below)
     coop_jobs.reserve(128);
-    B3D_TRY(slice(wl, 128, 8192, wg_stream));
-    B3D_TRY(slice(wlc, 128, 8192, wg_stream));
+    const int jobs_c = kTableCap / 2, tasks_c = kTaskCap / 2;
+    wl.begin(w.ws_table, kTableCap - jobs_c, w.ws_task_job, kTaskCap - tasks_c, stream);
+    wlc.begin(w.ws_table + (kTableCap - jobs_c), jobs_c, w.ws_task_job + (kTaskCap - tasks_c), tasks_c, stream);
+    hipLaunchKernelGGL(iota_kernel, dim3(((E > N ? E : N) + 255) / 256), dim3(256), 0, stream, w.iota, E > N ? E : N);
+    B3D_TRY(launch_check("iota_kernel"));
+    B3D_HIP_CHECK(hipMemsetAsync(w.zrow, 0, 256 * sizeof(float), stream));
+    const int* iota = w.iota;
+    struct Col { const float* p; const int* idx; long vstride; int stride; int col0; int width; };   // activation columns
+    // Every (64-row group of G) x (<= 96-column group of an activation segment) pair is one job.
+    // Cooperative decomposition: column groups of <= 256 per activation segment, row groups chosen per column group
+    // from the compiled shapes; false (nothing added) if some pair has none.
+    auto col_groups = [](int width, int* out) -> int {
+      switch (width) {
+        case 512: out[0] = 256; out[1] = 256; return 2;
+        case 384: out[0] = 256; out[1] = 128; return 2;
+        case 288: out[0] = 192; out[1] = 96; return 2;
+        case 256: case 192: case 128: case 96: case 64: out[0] = width; return 1;
+        default: return 0;
+      }
+    };
+    auto row_groups = [](int n, int kg, int* out) -> int {
+      int k = 0;
+      if (kg <= 96) {
+        while (n >= 256) { out[k++] = 256; n -= 256; }
+        while (n >= 192) { out[k++] = 192; n -= 192; }
+        if (n == 128 && kg == 96) { out[k++] = 128; n = 0; }
+      } else if (kg == 128) {
+        if (n % 192 == 0) while (n > 0) { out[k++] = 192; n -= 192; }
+        while (n >= 128) { out[k++] = 128; n -= 128; }
+        if (n == 96 || n == 64) { out[k++] = n; n = 0; }
+      } else {
+        while (n >= 128) { out[k++] = 128; n -= 128; }
+      }
+      return n == 0 ? k : -1;
+    };
+    auto add_block_coop = [&](LinSlab& ls, long rows, int nvar, int rpt, const float* gp, const int* gidx, long gvs, int gstride,
+                              int gcol0, const Col* cols, int ncols, bool with_bias) -> bool {
+      WsJob jobs[48];
+      int nj = 0;
+      int wcol = 0;
+      for (int ci = 0; ci < ncols; ++ci) {
+        if (cols[ci].idx) return false;                      // gathered activations: streaming kernel
+        if ((uintptr_t)cols[ci].p % 16 != 0 || cols[ci].stride % 4 != 0 || cols[ci].col0 % 4 != 0 || cols[ci].vstride % 4 != 0) return false;
+        int cg[4];
+        int ncg = col_groups(cols[ci].width, cg);
+        if (ncg == 0) return false;
+        int c0 = 0;
+        for (int k = 0; k < ncg; ++k) {
+          int kgs[4] = {cg[k], 0, 0, 0}, nk = 1;
+          int rg[8];
+          int nr = row_groups(ls.N, cg[k], rg);
+          if (nr < 0 && cg[k] > 128) {                       // 192 x 256 and the like: narrower column groups
+            nk = 0;
+            for (int left = cg[k]; left > 0;) { const int t = left >= 128 ? 128 : left; kgs[nk++] = t; left -= t; }
+          }
+          for (int kk = 0; kk < nk; ++kk) {
+            nr = row_groups(ls.N, kgs[kk], rg);
+            if (nr < 0) return false;
+            int g0 = 0;
+            for (int r = 0; r < nr; ++r) {
+              const int shape = wgm_shape(rg[r], kgs[kk]);
+              if (shape < 0 || nj == 48) return false;
+              WsJob jb;
+              memset(&jb, 0, sizeof(jb));
+              jb.g.ptr = gp; jb.g.idx = gidx ? gidx : iota; jb.g.vstride = gvs; jb.g.stride = gstride; jb.g.col0 = gcol0 + g0;
+              jb.act[0].ptr = cols[ci].p; jb.act[0].idx = iota; jb.act[0].vstride = cols[ci].vstride;
+              jb.act[0].stride = cols[ci].stride; jb.act[0].col0 = cols[ci].col0 + c0;
+              jb.act[1] = jb.act[0]; jb.act[2] = jb.act[0];
+              jb.wcol[0] = wcol + c0; jb.wrow = g0;
+              jb.write_bias = (with_bias && ci == 0 && c0 == 0) ? 1 : 0;     // the first column group of every row group
+              jb.shape = shape;
+              jb.rows = (int)rows; jb.nvar = nvar; jb.rows_per_task = rpt;
+              jb.NP = ls.NP; jb.KP = ls.KP; jb.slab = ls.slab;
+              if (gidx && shape != WGM_128_192) return false;             // the only compiled gathered shape
+              jobs[nj++] = jb;
+              g0 += rg[r];
+            }
+            c0 += kgs[kk];
+          }
+        }
+        wcol += cols[ci].width;
+      }
+      for (int j = 0; j < nj; ++j) coop_jobs.push_back(jobs[j]);
+      return true;
+    };
     auto add_block = [&](LinSlab& ls, long rows, int nvar, int rpt, const float* gp, const int* gidx, long gvs, int gstride, int gcol0,
                          const Col* cols, int ncols, bool with_bias) {
       if (nvar <= 0) return;
       ls.used = true;
       if (((uintptr_t)gp % 16 == 0) && gstride % 4 == 0 && gcol0 % 4 == 0 &&
-          add_block_coop(coop_jobs, ls, rows, nvar, rpt, gp, gidx, gvs, gstride, gcol0, cols, ncols, with_bias, false))
+          add_block_coop(ls, rows, nvar, rpt, gp, gidx, gvs, gstride, gcol0, cols, ncols, with_bias))
         return;
       bool first_job_of_group = true;
       for (int g0 = 0; g0 < ls.N; g0 += 64) {
@@ -1072,21 +1000,46 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
       add_block(w.lin[lin], rows, nvar, rpt, gp, gidx, gvs, gstride, gcol0, cols, ncols, true);
     };
     const int rp = kStreamRowsPerTask, rpa = kStreamRowsPerTaskAtt;
-    // First layers: the node columns contract over NODES (G = column blocks of dT); the per-edge columns went layer by layer.
+    // First layers: per-edge columns contract over edges, node columns over NODES (G = column blocks of dT).
     const int rn = kStreamNodeRowsPerTask;
     const long tLs = (long)N * HC::GW;
-    {  // edge_update.0 [256, 320]: x[dst] 0:96 | x[src] 96:192
+    {  // edge_update.0 [256, 320]: x[dst] 0:96 | x[src] 96:192 | e 192:256 | att 256:320
+      Col ce[2] = {{w.e[0], nullptr, (long)eLe, D::DE, 0, 64}, {w.att, nullptr, 0, 64, 0, 64}};
+      // one job over both sources: GdH1 (256 wide, the bulk of the bytes) is read once
+      LinSlab& ls = w.vlin[VL_EU0E];
+      ls.used = true;
+      WsJob jb;
+      memset(&jb, 0, sizeof(jb));
+      jb.g.ptr = w.GdH1; jb.g.idx = iota; jb.g.vstride = eL1; jb.g.stride = D::EH1; jb.g.col0 = 0;
+      for (int k = 0; k < 2; ++k) {
+        jb.act[k].ptr = ce[k].p; jb.act[k].idx = iota; jb.act[k].vstride = ce[k].vstride; jb.act[k].stride = ce[k].stride; jb.act[k].col0 = 0;
+      }
+      jb.act[2] = jb.act[0];
+      jb.wcol[0] = 0; jb.wcol[1] = 64; jb.wrow = 0; jb.write_bias = 1; jb.shape = WGM_256_128;
+      jb.rows = E; jb.nvar = depth; jb.rows_per_task = rp; jb.NP = ls.NP; jb.KP = ls.KP; jb.slab = ls.slab;
+      coop_jobs.push_back(jb);
       Col cx[1] = {{w.x[0], nullptr, (long)nLx, D::DX, 0, 96}};
       add_block(w.vlin[VL_EU0XI], N, depth, rn, w.dT, nullptr, tLs, HC::GW, HC::OA, cx, 1, false);
       add_block(w.vlin[VL_EU0XJ], N, depth, rn, w.dT, nullptr, tLs, HC::GW, HC::OB, cx, 1, false);
+      Col c1[1] = {{w.sH1[0], nullptr, (long)eL1, D::EH1, 0, 256}};
+      add_matrix(EU1, E, depth, rp, w.GdH2, nullptr, eL2, D::EH2, 0, c1, 1);
+      Col c2[1] = {{w.sH2[0], nullptr, (long)eL2, D::EH2, 0, 128}};
+      add_matrix(EU2, E, depth, rp, w.Gde, nullptr, eLe, D::DE, 0, c2, 1);
     }
-    {  // message stacks .0 [192, 256] (layers 0 .. depth-2): x[.] 0:96 | x0[.] 160:256
+    {  // message stacks .0 [192, 256] (layers 0 .. depth-2): x[.] 0:96 | e' 96:160 | x0[.] 160:256
+      Col ce[1] = {{w.e[1], nullptr, (long)eLe, D::DE, 0, 64}};
       Col cx[1] = {{w.x[0], nullptr, (long)nLx, D::DX, 0, 96}};
       Col c0[1] = {{w.x[0], nullptr, 0, D::DX, 0, 96}};
+      add_block(w.vlin[VL_PA0E], E, depth - 1, rp, w.GdP1, nullptr, eLm, D::MH, 0, ce, 1, true);
       add_block(w.vlin[VL_PA0X], N, depth - 1, rn, w.dT, nullptr, tLs, HC::GW, HC::OP, cx, 1, false);
       add_block(w.vlin[VL_PA0X0], N, depth - 1, rn, w.dT, nullptr, tLs, HC::GW, HC::OP, c0, 1, false);
+      add_block(w.vlin[VL_FU0E], E, depth - 1, rp, w.GdF1, nullptr, eLm, D::MH, 0, ce, 1, true);
       add_block(w.vlin[VL_FU0X], N, depth - 1, rn, w.dT, nullptr, tLs, HC::GW, HC::OF, cx, 1, false);
       add_block(w.vlin[VL_FU0X0], N, depth - 1, rn, w.dT, nullptr, tLs, HC::GW, HC::OF, c0, 1, false);
+      Col cp1[1] = {{w.sP1[0], nullptr, (long)eLm, D::MH, 0, 192}};
+      add_matrix(PA1, E, depth - 1, rp, w.dM, dst, nLm, D::NIN, 0, cp1, 1);
+      Col cf1[1] = {{w.sF1[0], nullptr, (long)eLm, D::MH, 0, 192}};
+      add_matrix(FU1, E, depth - 1, rp, w.dM, src, nLm, D::NIN, D::DM, cf1, 1);
     }
     // modality heads on the rows that carry the modality (the LDS-staged kernel spilled ~3,000 VGPRs at these widths)
     const int rf = kStreamRowsPerTaskFc;
@@ -1128,39 +1081,32 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
       Col c4[1] = {{w.A[3], nullptr, 0, 128, 0, 128}};
       add_matrix(AT4, E, 1, rpa, w.da_acc, nullptr, 0, 64, 0, c4, 1);
     }
-    B3D_TRY(wg_fork());                                      // everything these jobs read is complete on `stream` here
-    // every remaining streaming job has one un-gathered activation segment: LDS-DMA ring form
+    // every remaining job has one un-gathered activation segment: LDS-DMA ring form
     B3D_REQUIRE(wl.launch2(wstream2_kernel, kWs2LdsBytes, w.zrow, w.iota, B3D_K_WGRAD_EDGE) == 0, "wstream2: LDS attribute");
     B3D_REQUIRE(wl.status == 0, "streaming weight gradient: job table overflow (%d jobs, %d tasks)", wl.njobs, wl.total_tasks);
     B3D_TRY(launch_check("wstream_kernel"));
-    B3D_TRY(launch_coop(coop_jobs, wlc, "tail"));
+    {
+      // One workgroup per task, dispatched in task order as CUs free up: longest tasks first, or the 60 us tasks of
+      // att_edge_encoder (last in plan order) start when the rest of the chip has run dry.  Cost of a task ~ its 32-row
+      // steps times the bytes of a step.
+      auto cost = [](const WsJob& j) {
+        static const int w[WGM_SHAPES] = {384, 320, 256, 192, 320, 352, 256, 288, 224, 320, 224, 384};
+        const long rows = j.rows < j.rows_per_task ? j.rows : j.rows_per_task;
+        return ((rows + kWgmRows - 1) / kWgmRows) * (long)j.nvar * w[j.shape];
+      };
+      std::stable_sort(coop_jobs.begin(), coop_jobs.end(), [&](const WsJob& a, const WsJob& b) { return cost(a) > cost(b); });
+      for (const WsJob& j : coop_jobs) wlc.add(j);
+    }
+    wlc.flush();
+    B3D_REQUIRE(wlc.status == 0, "cooperative weight gradient: job table overflow (%d jobs, %d tasks)", wlc.njobs, wlc.total_tasks);
+    if (wlc.total_tasks > 0) {
+      B3D_TRY(set_lds(wgemm_kernel, kWgmLdsBytes));
+      ProfScope ps(B3D_K_WGRAD_EDGE, stream);
+      hipLaunchKernelGGL(wgemm_kernel, dim3((unsigned)(wlc.total_tasks < 2048 ? wlc.total_tasks : 2048)), dim3(kWgmThreads), kWgmLdsBytes,
+                         stream, (const WsJob*)wlc.table, (const int*)wlc.task_job, wlc.total_tasks, w.iota);
+      B3D_TRY(launch_check("wgemm_kernel"));
+    }
   }
-  // ---- encoders ----------------------------------------------------------------------------------------
-  // node encoder (x = initial_x): running d initial_x + layer 0's (dx | dx0)
-  using In = LoadNodeEncGradH<6>;
-  ChainBwdArgs<In, StoreNone> a;
-  memset(&a, 0, sizeof(a));
-  a.rows = N;
-  a.in = In{nullptr, dx0_first ? nullptr : w.dx0_acc, w.gx};
-  a.gtop = w.gn_top; a.act[0] = w.ne_a1; a.gsave[0] = w.gn1; a.wpack = w.wp_neT;
-  B3D_TRY(launch_rows<kNWNode>(chain_bwd_kernel<SeqNET, In, StoreNone, kNWNode>, "node_encoder_bwd", a, N, stream, B3D_K_OTHER, chain_lds<SeqNET>()));
-  WgJob n1 = make_job(w.lin[NE1], N, seg(w.gn_top, nullptr, 96, 0, 96)); add_act(n1, seg(w.ne_a1, nullptr, 48, 0, 48)); smallN.jobs[smallN.njobs++] = n1;
-  WgJob n0 = make_job(w.lin[NE0], N, seg(w.gn1, nullptr, 48, 0, 48)); add_act(n0, seg(w.pose_pad, nullptr, 32, 0, 19)); smallN.jobs[smallN.njobs++] = n0;
-  {  // edge encoder: e[0] feeds layer 0 AND att_edge_encoder (columns 576:640 of its input)
-    using In = LoadAdd2<4>;
-    ChainBwdArgs<In, StoreNone> a;
-    memset(&a, 0, sizeof(a));
-    a.rows = E;
-    a.in = In{w.de[cur], D::DE, 0, w.de0, 64, 0, nullptr};
-    a.gtop = w.ge_top; a.act[0] = w.ee_a2; a.act[1] = w.ee_a1; a.gsave[0] = w.ge2; a.gsave[1] = w.ge1; a.wpack = w.wp_eeT;
-    B3D_TRY(launch_rows<kNWEdge>(chain_bwd_kernel<SeqEET, In, StoreNone, kNWEdge>, "edge_encoder_bwd", a, E, stream, B3D_K_OTHER, chain_lds<SeqEET>()));
-    WgJob e2 = make_job(w.lin[EE2], E, seg(w.ge_top, nullptr, 64, 0, 64)); add_act(e2, seg(w.ee_a2, nullptr, 32, 0, 32)); smallE.jobs[smallE.njobs++] = e2;
-    WgJob e1 = make_job(w.lin[EE1], E, seg(w.ge2, nullptr, 32, 0, 32)); add_act(e1, seg(w.ee_a1, nullptr, 16, 0, 16)); smallE.jobs[smallE.njobs++] = e1;
-    WgJob e0 = make_job(w.lin[EE0], E, seg(w.ge1, nullptr, 16, 0, 16)); add_act(e0, seg(w.ea_pad, nullptr, 16, 0, 4)); smallE.jobs[smallE.njobs++] = e0;
-  }
-  B3D_TRY((launch_wgrad<8, 1>(smallE, stream, B3D_K_WGRAD_OTHER)));
-  B3D_TRY((launch_wgrad<8, 1>(smallN, stream, B3D_K_WGRAD_OTHER)));
-  if (wg_overlap) B3D_TRY(side_join(wg_side, stream));
 
   // ---- slabs -> parameter gradients -----------------------------------------------------------------------
   {

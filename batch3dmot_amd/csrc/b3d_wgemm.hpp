@@ -251,8 +251,7 @@ __device__ __attribute__((noinline)) void wgm_task(const WsJob& job, int chunk, 
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int rowf = job.wrow + 16 * (wr * MBW + a) + 4 * qq + j;
-        float* d = slab + (size_t)rowf * job.KP + colf;
-        *d = job.accumulate ? *d + vv[j] : vv[j];
+        slab[(size_t)rowf * job.KP + colf] = vv[j];
       }
     }
   }
@@ -270,8 +269,7 @@ __device__ __attribute__((noinline)) void wgm_task(const WsJob& job, int chunk, 
       float s = 0.f;
 #pragma unroll
       for (int r = 0; r < RG; ++r) s += colsum[r * NG + i];
-      float* d = slab + (size_t)job.NP * job.KP + job.wrow + i;
-      *d = job.accumulate ? *d + s : s;
+      slab[(size_t)job.NP * job.KP + job.wrow + i] = s;
     }
   }
 }

@@ -41,7 +41,6 @@ struct WsJob {
   int wcol[3];           // column of dW where each segment's features start
   int wrow;              // row of dW where this job's gradient features start
   int write_bias;        // exactly one of the jobs that share a slab writes the bias gradient
-  int accumulate;        // add to the slab instead of overwriting it (an earlier launch of this backward wrote it: b3d_wgemm.hpp)
   int shape;             // index into the compiled shape list
   int rows;
   int nvar;              // layer variants accumulated into the same partial
