@@ -193,52 +193,195 @@ class _GNNFunction(torch.autograd.Function):
         return (None,) * 12 + tuple(grads)
 
 
-class EmbeddingCache:
-    """Encoder outputs of the detections seen so far, keyed by global node id.  Device
-    tables that grow by doubling; ``clear()`` between scenes (ids are per scene, predict.py:595-611)."""
+def _first_k(mask: torch.Tensor, k: int) -> torch.Tensor:
+    """Ascending positions of the first ``k`` True entries of ``mask`` -- ``torch.nonzero(mask)[:k]`` without its read-back of
+    the result's size (``k`` is known to the caller)."""
+    return torch.argsort(~mask, stable=True)[:k]
 
-    def __init__(self, capacity: int = 4096):
-        self.capacity = capacity
+
+class EmbeddingCache:
+    """Encoder outputs of the detections of a scene, keyed by global node id: every detection is
+    encoded ONCE per scene instead of once per window it appears in -- with the reference's stride-1 windows of
+    ``batch_size_graph`` frames (predict.py:172) up to 5x fewer encoder rows.  ``clear()`` between scenes (ids are per scene,
+    predict.py:595-611).
+
+    Round 4: everything lives on the device.  ``ids`` is a SORTED int64 table, a lookup is ``torch.searchsorted``; the encoder
+    outputs are dense tables in id order (rows without the modality are zero) beside two presence masks.  No Python
+    dictionary, no per-detection loop; the host reads back sizes only -- one synchronisation per ``add`` (how many ids are
+    new and how many of those carry LiDAR / radar points: the encoder batches' shapes), one per ``window`` (how many of its
+    rows carry them: the shapes ``b3d_clr_forward`` takes), or, through ``add_windows`` / ``windows``, three per SCENE."""
+
+    def __init__(self, capacity: int = 0):
+        self.capacity = capacity            # kept for the round-3 signature; tables are sized by their content
         self.clear()
 
     def clear(self):
-        self.rows = {}
+        self.ids = None                     # [U] int64, ascending
         self.img = self.lidar = self.radar = self.has_lidar = self.has_radar = None
         self.hits = self.misses = 0
+        self.encoder_rows = {"img": 0, "lidar": 0, "radar": 0}
 
     def __len__(self):
-        return len(self.rows)
+        return 0 if self.ids is None else int(self.ids.numel())
 
-    def _reserve(self, n, like_img, dev):
-        if self.img is None:
-            cap = max(self.capacity, n)
-            self.img = torch.zeros(cap, like_img.size(1), device=dev)
-            self.lidar = torch.zeros(cap, 256, device=dev)
-            self.radar = torch.zeros(cap, 256, device=dev)
-            self.has_lidar = torch.zeros(cap, dtype=torch.bool, device=dev)
-            self.has_radar = torch.zeros(cap, dtype=torch.bool, device=dev)
-        need = len(self.rows) + n
-        if need > self.img.size(0):
-            cap = max(need, 2 * self.img.size(0))
-            for name in ("img", "lidar", "radar", "has_lidar", "has_radar"):
-                old = getattr(self, name)
-                new = torch.zeros((cap,) + tuple(old.shape[1:]), dtype=old.dtype, device=old.device)
-                new[: old.size(0)] = old
-                setattr(self, name, new)
+    # ---- lookups --------------------------------------------------------------------------------------------------------
+    def rows_of(self, node_ids: torch.Tensor):
+        """(row of every id in the tables, hit mask); a miss has an arbitrary valid row."""
+        if self.ids is None or self.ids.numel() == 0:
+            return torch.zeros_like(node_ids), torch.zeros_like(node_ids, dtype=torch.bool)
+        pos = torch.searchsorted(self.ids, node_ids).clamp_(max=self.ids.numel() - 1)
+        return pos, self.ids[pos] == node_ids
 
-    def append(self, ids, x_img, has_l, li, l_out, has_r, ri, r_out):
-        n0 = len(self.rows)
-        self._reserve(len(ids), x_img, x_img.device)
-        sl = slice(n0, n0 + len(ids))
-        self.img[sl] = x_img
-        self.has_lidar[sl] = has_l
-        self.has_radar[sl] = has_r
-        if l_out is not None:
-            self.lidar[n0 + li] = l_out
-        if r_out is not None:
-            self.radar[n0 + ri] = r_out
-        for k, gid in enumerate(ids):
-            self.rows[gid] = n0 + k
+    # ---- filling ----------------------------------------------------------------------------------------------------------
+    def add(self, model: "GNN", node_ids: torch.Tensor, img_feats, lidar_feats, radar_feats, chunk: int = 8192):
+        """Encode the detections of ``node_ids`` (int64, on the device; duplicates allowed) that the tables do not hold yet."""
+        if model.resnet.training or model.pointnet.training or model.radarnet.training:
+            raise RuntimeError("the embedding cache needs the encoders in eval mode: in train mode their BatchNorm "
+                               "statistics depend on which rows share a batch")
+        dev = node_ids.device
+        m = node_ids.numel()
+        if m == 0:
+            return
+        # first occurrence of every distinct id of the request, in id order; drop those the tables hold
+        uniq, inv = torch.unique(node_ids, return_inverse=True)
+        first = torch.full((uniq.numel(),), m, dtype=torch.long, device=dev).scatter_reduce_(0, inv, torch.arange(m, device=dev), "amin")
+        _, hit = self.rows_of(uniq)
+        new = ~hit
+        lid_rows = lidar_feats.reshape(m, -1)
+        rad_rows = radar_feats.reshape(m, -1)
+        has_l = modality_present(lidar_feats)[first] & new
+        has_r = modality_present(radar_feats)[first] & new
+        n_new, n_l, n_r = (int(v) for v in torch.stack([new.sum(), has_l.sum(), has_r.sum()]).tolist())      # the one read-back
+        self.hits += m - n_new
+        self.misses += n_new
+        if n_new == 0:
+            return
+        sel = _first_k(new, n_new)                                   # positions in `uniq` of the new ids, ascending = id order
+        src = first[sel]                                             # their rows in the request
+        img = torch.empty((n_new, 96), dtype=torch.float32, device=dev)
+        lidar = torch.zeros((n_new, 256), dtype=torch.float32, device=dev)
+        radar = torch.zeros((n_new, 256), dtype=torch.float32, device=dev)
+        hl, hr = has_l[sel], has_r[sel]
+        li, ri = _first_k(hl, n_l), _first_k(hr, n_r)                 # rows of the NEW block that carry the modality
+        with torch.no_grad():
+            for c0 in range(0, n_new, chunk):
+                img[c0:c0 + chunk] = model.resnet.encode(img_feats[src[c0:c0 + chunk]]).float()
+            for c0 in range(0, n_l, chunk):
+                rr = li[c0:c0 + chunk]
+                lidar[rr] = model.pointnet.forward_feat(lid_rows[src[rr]].view(-1, 3, 128)).float()
+            for c0 in range(0, n_r, chunk):
+                rr = ri[c0:c0 + chunk]
+                radar[rr] = model.radarnet.forward_feat(rad_rows[src[rr]].view(-1, 4, 64)).float()
+        self.encoder_rows["img"] += n_new
+        self.encoder_rows["lidar"] += n_l
+        self.encoder_rows["radar"] += n_r
+        new_ids = uniq[sel]
+        if self.ids is None or self.ids.numel() == 0:
+            self.ids, self.img, self.lidar, self.radar, self.has_lidar, self.has_radar = new_ids, img, lidar, radar, hl, hr
+            return
+        # merge two sorted id lists: one stable sort of the concatenation (old ids first), tables permuted alike
+        ids = torch.cat([self.ids, new_ids])
+        order = torch.argsort(ids, stable=True)
+        self.ids = ids[order]
+        self.img = torch.cat([self.img, img])[order]
+        self.lidar = torch.cat([self.lidar, lidar])[order]
+        self.radar = torch.cat([self.radar, radar])[order]
+        self.has_lidar = torch.cat([self.has_lidar, hl])[order]
+        self.has_radar = torch.cat([self.has_radar, hr])[order]
+
+    def add_windows(self, model: "GNN", windows, ids_of=None):
+        """All windows of a scene in one ``add``: only the rows a window contributes for the FIRST time are gathered, so the
+        request is the scene's detections once, not five times (two read-backs for the whole scene)."""
+        ids_of = ids_of or window_node_ids
+        dev = windows[0].pose_feats.device
+        gids = [ids_of(w).to(dev) for w in windows]
+        sizes = [int(g.numel()) for g in gids]
+        allg = torch.cat(gids)
+        m = allg.numel()
+        uniq, inv = torch.unique(allg, return_inverse=True)
+        first = torch.full((uniq.numel(),), m, dtype=torch.long, device=dev).scatter_reduce_(0, inv, torch.arange(m, device=dev), "amin")
+        pos = torch.sort(first).values                               # first occurrences in concatenation (= window) order
+        off = [0]
+        for n_ in sizes:
+            off.append(off[-1] + n_)
+        bounds = torch.searchsorted(pos, torch.tensor(off, device=dev)).tolist()          # read-back 1 of the scene
+        idx = [pos[bounds[k]:bounds[k + 1]] - off[k] for k in range(len(windows))]       # rows of window k nobody held before
+        live = [k for k in range(len(windows)) if bounds[k + 1] > bounds[k]]
+        pick = lambda name: torch.cat([getattr(windows[k], name)[idx[k]] for k in live])          # noqa: E731
+        self.add(model, allg[pos], pick("img_feats"), pick("lidar_feats"), pick("radar_feats"))
+
+    # ---- reading --------------------------------------------------------------------------------------------------------
+    def window(self, node_ids: torch.Tensor, counts=None):
+        """The ``encoded`` tuple of ``GNN.forward`` for the detections ``node_ids`` (all must be cached).  ``counts``: (rows with
+        LiDAR, rows with radar) if the caller already holds them (``windows``); otherwise one read-back."""
+        rows, hit = self.rows_of(node_ids)
+        hl, hr = self.has_lidar[rows], self.has_radar[rows]
+        if counts is None:
+            n_l, n_r, n_hit = (int(v) for v in torch.stack([hl.sum(), hr.sum(), hit.sum()]).tolist())
+            if n_hit != node_ids.numel():
+                raise KeyError(f"{node_ids.numel() - n_hit} detections of this window are not in the embedding cache")
+        else:
+            n_l, n_r = counts
+        ln, rn = _first_k(hl, n_l), _first_k(hr, n_r)
+        return (self.img[rows].contiguous(), self.lidar[rows[ln]].contiguous(), ln.to(torch.int32).contiguous(),
+                self.radar[rows[rn]].contiguous(), rn.to(torch.int32).contiguous())
+
+    def scene_tables(self, list_of_node_ids):
+        """The encoder outputs of ALL windows of a scene back to back, with ONE read-back (the LiDAR / radar row counts of every
+        window together): a dict with ``img`` [M, 96] (window after window), ``lidar`` [NL, 256] / ``radar`` [NR, 256] (the rows
+        that carry the modality, same order), ``lidar_nodes`` / ``radar_nodes`` (their node index INSIDE their window, int32),
+        ``off`` / ``loff`` / ``roff`` (host lists: where window k starts in each).  A run of consecutive windows is a slice."""
+        dev = self.ids.device
+        sizes = [int(i.numel()) for i in list_of_node_ids]
+        if not sizes or min(sizes) == 0:
+            raise ValueError("scene_tables: every window needs at least one detection")
+        off = [0]
+        for n_ in sizes:
+            off.append(off[-1] + n_)
+        allg = torch.cat([i.to(dev) for i in list_of_node_ids])
+        m = allg.numel()
+        rows, hit = self.rows_of(allg)
+        hl, hr = self.has_lidar[rows], self.has_radar[rows]
+        offt = torch.tensor(off, device=dev)
+        cl, cr = torch.cumsum(hl, 0), torch.cumsum(hr, 0)
+        zero = torch.zeros(1, dtype=cl.dtype, device=dev)
+        ends = offt[1:] - 1
+        vals = torch.cat([torch.cat([zero, cl[ends]]), torch.cat([zero, cr[ends]]), (~hit).sum().reshape(1)]).tolist()     # the read-back
+        w = len(sizes)
+        loff, roff, miss = [int(v) for v in vals[:w + 1]], [int(v) for v in vals[w + 1:2 * w + 2]], int(vals[-1])
+        if miss:
+            raise KeyError(f"{miss} detections of these windows are not in the embedding cache")
+        win_start = torch.repeat_interleave(offt[:-1], torch.tensor(sizes, device=dev), output_size=m)
+        pl, pr = _first_k(hl, loff[-1]), _first_k(hr, roff[-1])       # positions (concatenation order) of the rows with the modality
+        return {"img": self.img[rows], "lidar": self.lidar[rows[pl]], "radar": self.radar[rows[pr]],
+                "lidar_nodes": (pl - win_start[pl]).to(torch.int32), "radar_nodes": (pr - win_start[pr]).to(torch.int32),
+                "off": off, "loff": loff, "roff": roff}
+
+    @staticmethod
+    def tables_slice(t, k0: int, k1: int):
+        """The ``encoded`` tuple of ``GNN.forward`` for windows k0 .. k1-1 of ``scene_tables`` scored as ONE disjoint-union graph."""
+        o, lo, ro = t["off"], t["loff"], t["roff"]
+        ln, rn = t["lidar_nodes"][lo[k0]:lo[k1]], t["radar_nodes"][ro[k0]:ro[k1]]
+        if k1 - k0 > 1:                                              # node indices of the union graph: + the window's offset in it
+            dev = ln.device
+            starts = torch.tensor([o[k] - o[k0] for k in range(k0, k1)], dtype=torch.int32, device=dev)
+            ln = ln + torch.repeat_interleave(starts, torch.tensor([lo[k + 1] - lo[k] for k in range(k0, k1)], device=dev), output_size=lo[k1] - lo[k0])
+            rn = rn + torch.repeat_interleave(starts, torch.tensor([ro[k + 1] - ro[k] for k in range(k0, k1)], device=dev), output_size=ro[k1] - ro[k0])
+        return (t["img"][o[k0]:o[k1]], t["lidar"][lo[k0]:lo[k1]], ln.contiguous(), t["radar"][ro[k0]:ro[k1]], rn.contiguous())
+
+    def windows(self, list_of_node_ids):
+        """``window`` for every window of a scene with ONE read-back (``scene_tables``)."""
+        t = self.scene_tables(list_of_node_ids)
+        return [self.tables_slice(t, k, k + 1) for k in range(len(list_of_node_ids))]
+
+
+def window_node_ids(data) -> torch.Tensor:
+    """Global (scene-level) ids of a window's detections: ``data.global_ids`` if present, else the first column of
+    ``data.global_node_timestamps`` (utils/graph_data.py:190)."""
+    g = getattr(data, "global_ids", None)
+    if g is None:
+        g = data.global_node_timestamps[:, 0]
+    return g.to(torch.int64)
 
 
 class GNN(nn.Module):
@@ -392,31 +535,11 @@ class GNN(nn.Module):
         return (x_img, pointnet_out, lidar_i32, radarnet_out, radar_i32), ready
 
     def _encode_cached(self, data, cache: "EmbeddingCache", node_ids):
-        if self.resnet.training or self.pointnet.training or self.radarnet.training:
-            raise RuntimeError("the embedding cache needs the encoders in eval mode: in train mode their BatchNorm "
-                               "statistics depend on which rows share a batch")
         if node_ids is None:
-            node_ids = data.global_node_timestamps[:, 0]
-        ids = [int(v) for v in node_ids.tolist()]
-        dev = data.pose_feats.device
-        new_local = [i for i, gid in enumerate(ids) if gid not in cache.rows]
-        if new_local:
-            sel = torch.tensor(new_local, dtype=torch.long, device=dev)
-            lidar_new, radar_new = data.lidar_feats[sel], data.radar_feats[sel]
-            has_l, has_r = modality_present(lidar_new), modality_present(radar_new)
-            with torch.no_grad():
-                x_img = self.resnet.encode(data.img_feats[sel]).float()
-                li, ri = torch.nonzero(has_l).squeeze(1), torch.nonzero(has_r).squeeze(1)
-                l_out = self.pointnet.forward_feat(lidar_new[li].view(-1, 3, 128)).float() if li.numel() else None
-                r_out = self.radarnet.forward_feat(radar_new[ri].view(-1, 4, 64)).float() if ri.numel() else None
-            cache.append([ids[i] for i in new_local], x_img, has_l, li, l_out, has_r, ri, r_out)
-        cache.hits += len(ids) - len(new_local)
-        cache.misses += len(new_local)
-        rows = torch.tensor([cache.rows[g] for g in ids], dtype=torch.long, device=dev)
-        lidar_nodes = torch.nonzero(cache.has_lidar[rows]).squeeze(1)
-        radar_nodes = torch.nonzero(cache.has_radar[rows]).squeeze(1)
-        return (cache.img[rows].contiguous(), cache.lidar[rows[lidar_nodes]].contiguous(), lidar_nodes.to(torch.int32).contiguous(),
-                cache.radar[rows[radar_nodes]].contiguous(), radar_nodes.to(torch.int32).contiguous())
+            node_ids = window_node_ids(data)
+        node_ids = node_ids.to(device=data.pose_feats.device, dtype=torch.int64)
+        cache.add(self, node_ids, data.img_feats, data.lidar_feats, data.radar_feats)
+        return cache.window(node_ids)
 
     def forward(self, data, encoded=None, rows=None):
         """``encoded``: the result of ``encode_modalities(data)`` (precomputed encoder outputs); ``rows``: the result

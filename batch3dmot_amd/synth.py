@@ -50,7 +50,10 @@ def cb_scaling_factor(cls_name: str) -> float:
 
 def make_graph(num_nodes: int = 1500, target_edges: Optional[int] = None, k: int = 40,
                frames: int = 5, graph_idx: int = 0, window_start: int = 0,
-               modalities: bool = False, lidar_frac: float = 0.7, radar_frac: float = 0.25) -> Data:
+               modalities: bool = False, lidar_frac: float = 0.7, radar_frac: float = 0.25,
+               max_frame_gap: Optional[int] = None) -> Data:
+    """``max_frame_gap``: candidate edges reach at most this many frames back (a whole SCENE built in one call, whose 5-frame
+    windows -- ``scene_windows`` -- then hold the edges a per-window construction would give them)."""
     g = torch.Generator().manual_seed(SEED_BASE + graph_idx)
     n_t = num_nodes // frames
     # ---- synthetic tracks: objects observed in most frames, constant velocity + noise ----------
@@ -91,7 +94,7 @@ def make_graph(num_nodes: int = 1500, target_edges: Optional[int] = None, k: int
     for t in range(1, frames):
         for c in range(7):
             cur = torch.nonzero((rel == t) & (cls == c)).squeeze(1)
-            past = torch.nonzero((rel < t) & (cls == c)).squeeze(1)
+            past = torch.nonzero((rel < t) & (cls == c) & ((rel >= t - max_frame_gap) if max_frame_gap else (rel < t))).squeeze(1)
             if cur.numel() == 0 or past.numel() == 0:
                 continue
             d3 = torch.cdist(pos[cur], pos[past])
@@ -188,6 +191,14 @@ def scene_windows(scene: Data, frames: int, per_frame: int, size: int = 5):
         w.global_ids = torch.arange(lo, hi)
         out.append(w)
     return out
+
+
+def make_scene(frames: int = 40, per_frame: int = 400, k: int = 14, scene_idx: int = 0, modalities: bool = True, window: int = 5):
+    """A synthetic scene of ``frames`` frames x ``per_frame`` detections whose ``window``-frame windows (stride 1, predict.py:172)
+    have ~``window * per_frame`` nodes and ~10 edges per node: returns (scene Data, list of window Data with ``global_ids``)."""
+    scene = make_graph(frames * per_frame, None, k=k, frames=frames, graph_idx=7000 + scene_idx, modalities=modalities,
+                       max_frame_gap=window - 1)
+    return scene, scene_windows(scene, frames, per_frame, size=window)
 
 
 def write_window_files(stem, seed, n_per_frame=12, global_offset=1000):

@@ -738,6 +738,9 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to exercise the N > 1 path on one GPU)")
     ap.add_argument("--all-ranks-on-device-0", action="store_true", help="testing aid for the N > 1 path on a 1-GPU box (with --backend gloo)")
     ap.add_argument("--stub-cpu", action="store_true", help="testing aid: run this file's control flow with a stub workload on the CPU (gloo)")
+    ap.add_argument("--scene", action="store_true",
+                    help="--mode infer: scene-level inference (predict_post.predict_scene: embedding cache, window mean, greedy flux, "
+                         "tracks) on a synthetic 24-frame scene, cached against uncached")
     ap.add_argument("--force-collective", action="store_true",
                     help="N = 1 only: initialise the process group with ONE rank and run the N > 1 timed region (forward + backward "
                          "graph | flat all-reduce on the launch stream | optimizer graph) -- executes RCCL next to the captured graphs "
@@ -815,6 +818,11 @@ def main():
         except Exception as exc:
             secondary["infer_clr"] = {"error": f"{type(exc).__name__}: {str(exc)[:200]}"}
         torch.cuda.empty_cache()
+        try:
+            secondary["infer_scene_clr"] = infer_scene_measure(a3, dev, rank, 3)
+        except Exception as exc:
+            secondary["infer_scene_clr"] = {"error": f"{type(exc).__name__}: {str(exc)[:200]}"}
+        torch.cuda.empty_cache()
 
     if rank == 0:
         e_avg = m["edges"] / args.steps
@@ -874,7 +882,59 @@ def main():
         dist.destroy_process_group()
 
 
+def infer_scene_measure(args, dev, rank, steps, frames=24, per_frame=400):
+    """Scene-level inference (predict.py:143-259 for one scene): `predict_post.predict_scene` over the stride-1 windows of a
+    synthetic scene of `frames` x `per_frame` detections (5-frame windows of 2,000 nodes / ~20,000 edges) -- every detection
+    encoded once per scene through the device-table EmbeddingCache, window forwards, window mean, thresholds, greedy flux and
+    track clustering -- against the same pass with the encoders inside every window's forward (the reference's way).  Eager
+    launches (window shapes differ), host synchronisations included; a step = one scene."""
+    from batch3dmot_amd import encoders as enc_mod, synth
+    from batch3dmot_amd.clr_att_gnn import GNN
+    from batch3dmot_amd.predict_post import predict_scene
+    torch.manual_seed(5621)
+    model = GNN(enc_mod.ResNetAE(), enc_mod.PointNetClassifier(k=7), enc_mod.RadarNetClassifier(k=7)).to(dev).eval()
+    model.run_dead_knn = not args.no_dead_knn
+    scene, wins = synth.make_scene(frames=frames, per_frame=per_frame, k=20, scene_idx=rank, modalities=True)
+    wins = [w.to(dev) for w in wins]
+    node_cls = (scene.node_classes.long() - 1).to(dev)
+    names = list(synth.CLASSES)
+    edges = float(sum(w.edge_index.size(1) for w in wins))
+    rows_windows = sum(w.pose_feats.size(0) for w in wins)
+    out = {}
+    for key, use_cache, wpf in (("cached", True, 8), ("uncached", False, 8), ("cached_one_window_per_forward", True, 1),
+                                ("uncached_one_window_per_forward", False, 1)):
+        r = None
+        for _ in range(2):
+            r = predict_scene(model, wins, node_cls, names, cache=use_cache, windows_per_forward=wpf)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r = predict_scene(model, wins, node_cls, names, cache=use_cache, windows_per_forward=wpf)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        out[key] = {"ms_per_scene": round(1e3 * dt, 3), "ms_per_window": round(1e3 * dt / len(wins), 4), "edges_per_s": round(edges / dt, 1),
+                    "kept_edges": int(r["kept_pairs"].size(0)), "tracks": len(r["tracks"]),
+                    "encoder_rows": (dict(r["cache"].encoder_rows) if r["cache"] is not None else {"img": rows_windows})}
+    return {"metric": "edges/sec (forward only), scene-level inference with post-processing", "unit": "edges/s",
+            "value": out["cached"]["edges_per_s"], "value_uncached": out["uncached"]["edges_per_s"],
+            "speedup_from_cache": round(out["uncached"]["ms_per_scene"] / out["cached"]["ms_per_scene"], 3),
+            "config": {"workload": f"predict_post.predict_scene: scene of {frames} frames x {per_frame} detections, {len(wins)} stride-1 windows of "
+                                   f"{wins[0].pose_feats.size(0)} nodes / ~{int(edges / len(wins))} edges (predict.py:143-259,262-375), eager launches",
+                       "detections": int(scene.pose_feats.size(0)), "window_rows_total": rows_windows, "windows": len(wins),
+                       "dead_knn_gat_block_executed": bool(model.run_dead_knn)},
+            "cached": out["cached"], "uncached": out["uncached"],
+            "one_window_per_forward": {"cached": out["cached_one_window_per_forward"], "uncached": out["uncached_one_window_per_forward"]},
+            "windows_per_forward": 8, "steps": steps, "library_sha16": lib_sha16()}
+
+
 def main_infer(args, dev, rank, world, dist):
+    if getattr(args, "scene", False):
+        line = infer_scene_measure(args, dev, rank, max(2, args.steps // 10))
+        if rank == 0:
+            print(json.dumps(line))
+        if world > 1:
+            dist.destroy_process_group()
+        return
     line = infer_measure(args, dev, rank, world, dist, args.steps, args.warmup, cpu=(world == 1 and not args.no_cpu_baseline))
     if rank == 0:
         print(json.dumps(line))

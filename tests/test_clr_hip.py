@@ -340,7 +340,7 @@ def test_embedding_cache_encodes_each_detection_once():
         w.global_node_timestamps = torch.stack([gid.float(), pool.node_timestamps[lo:hi].float()], 1)
         return w.to(dev)
 
-    cache = EmbeddingCache(capacity=64)                                    # forces the tables to grow
+    cache = EmbeddingCache()
     spans = [(0, 120), (40, 160), (80, n)]
     for lo, hi in spans:
         w = window(lo, hi)

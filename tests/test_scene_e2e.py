@@ -83,3 +83,50 @@ def test_hip_model_and_hip_post_processing_reproduce_the_reference_indices(name)
             scores.append(s)
     pairs, sc = _flatten(wins, scores)
     _same_indices(greedy_edges_hip(pairs.to(dev), sc.to(dev), g["node_cls"].to(dev), g["class_names"], g["thresholds"]), g)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["g6_scene_pose.pt", "g6_scene_clr.pt"])
+def test_predict_scene_with_the_embedding_cache_reproduces_the_reference_indices(name):
+    """`predict_post.predict_scene` -- windows -> model (every detection encoded once per scene: the device-table EmbeddingCache)
+    -> window mean -> thresholds -> greedy flux -> tracks -- on the reference-generated scene: the kept-edge set and the
+    arg-max indices are the reference's with the cache ON, the per-edge means equal those of the uncached run, and every greedy
+    edge lies on exactly one track."""
+    from batch3dmot_amd import encoders
+    from batch3dmot_amd.clr_att_gnn import GNN
+    from batch3dmot_amd.pose_gnn import PoseGNN
+    from batch3dmot_amd.predict_post import predict_scene
+    dev = torch.device("cuda:0")
+    g = load_golden(name)
+    clr = g["kind"] == "clr"
+    m = GNN(encoders.ResNetAE(), encoders.PointNetClassifier(k=7), encoders.RadarNetClassifier(k=7)) if clr else PoseGNN()
+    seeded_fill_(m, g["salt"])
+    m = _calibrate(m, g).to(dev).eval()
+    wins = [w.to(dev) for w in _windows(g)]
+    for w, raw in zip(wins, _windows(g)):
+        w.global_ids = raw.global_ids.to(dev)
+    r = predict_scene(m, wins, g["node_cls"].to(dev), g["class_names"], g["thresholds"], cache=True)
+    _same_indices(r, g)
+    plain = predict_scene(m, wins, g["node_cls"].to(dev), g["class_names"], g["thresholds"], cache=False, tracks=False)
+    assert torch.equal(plain["kept_pairs"], r["kept_pairs"])
+    torch.testing.assert_close(plain["kept_scores"], r["kept_scores"], rtol=0, atol=1e-6)
+    if clr:
+        n_scene = int(g["node_cls"].numel())
+        c = r["cache"]
+        assert len(c) == n_scene and c.encoder_rows["img"] == n_scene            # one encoder row per DETECTION, not per window row
+        assert sum(w.pose_feats.size(0) for w in wins) > 2 * n_scene              # ... where the windows hold each several times
+    on_track = [int(v) for t in r["tracks"] for v in t]
+    assert len(on_track) == len(set(on_track)) and len(r["tracks"]) > 0          # a detection lies on at most one track
+    # the array form of the track step equals create_trajectories on the reference's list form
+    from batch3dmot_amd.predict_post import create_trajectories
+    pe = [((int(a), int(b)), float(s_)) for (a, b), s_ in zip(r["pred_edge_pairs"].tolist(), r["pred_edge_scores"].tolist())]
+    cls_l = g["node_cls"].tolist()
+    nodes_d = {v: {"category_name": g["class_names"][cls_l[v]]} for v in sorted({x for e, _ in pe for x in e})}
+    want = create_trajectories(pe, nodes_d, {c: g["thresholds"][c] for c in g["class_names"]})
+    got = predict_scene(m, wins, g["node_cls"].to(dev), g["class_names"], g["thresholds"], cache=True,
+                        join_score={c: g["thresholds"][c] for c in g["class_names"]})["tracks"]
+    assert [list(map(int, t)) for t in got] == want
+    # one forward per window (the reference's way) and eight windows per forward give the same scores
+    single = predict_scene(m, wins, g["node_cls"].to(dev), g["class_names"], g["thresholds"], cache=True, tracks=False, windows_per_forward=1)
+    assert torch.equal(single["kept_pairs"], r["kept_pairs"])
+    torch.testing.assert_close(single["kept_scores"], r["kept_scores"], rtol=0, atol=1e-6)
