@@ -37,6 +37,10 @@ class b3d_gat(C.Structure):
     _fields_ = [("lin", C.c_void_p), ("att_src", C.c_void_p), ("att_dst", C.c_void_p), ("bias", C.c_void_p)]
 
 
+class b3d_gat_grad(C.Structure):
+    _fields_ = [("lin", C.c_void_p), ("att_src", C.c_void_p), ("att_dst", C.c_void_p), ("bias", C.c_void_p)]
+
+
 class b3d_batchnorm(C.Structure):
     _fields_ = [("gamma", C.c_void_p), ("beta", C.c_void_p), ("running_mean", C.c_void_p), ("running_var", C.c_void_p),
                 ("num_batches_tracked", C.c_void_p), ("momentum", C.c_float), ("eps", C.c_float)]
@@ -135,6 +139,11 @@ def load() -> C.CDLL:
     lib.b3d_knn_gat_forward.restype = C.c_int
     lib.b3d_knn_gat_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(b3d_gat),
                                         C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.b3d_knn_gat_backward_workspace_bytes.restype = C.c_size_t
+    lib.b3d_knn_gat_backward_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
+    lib.b3d_knn_gat_backward.restype = C.c_int
+    lib.b3d_knn_gat_backward.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(b3d_gat), C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(b3d_gat_grad), C.c_void_p]
     lib.b3d_edge_loss_workspace_bytes.restype = C.c_size_t
     lib.b3d_edge_loss_workspace_bytes.argtypes = [C.c_int32]
     lib.b3d_edge_loss.restype = C.c_int
@@ -358,6 +367,61 @@ def knn_gat(x: torch.Tensor, node_timestamps: torch.Tensor, conv, k: int = 20):
     check(lib.b3d_knn_gat_forward(x.data_ptr(), ts.data_ptr(), n, d, k, C.byref(g), ws.data_ptr(), nbytes,
                                   nbr.data_ptr(), cnt.data_ptr(), y.data_ptr(), current_stream(x.device)), "b3d_knn_gat_forward")
     return nbr, cnt, y
+
+
+class _KnnGatFunction(torch.autograd.Function):
+    """y = GATConv(x, knn_graph(x) per frame) with gradients (``b3d_knn_gat_forward`` / ``b3d_knn_gat_backward``); the neighbour
+    selection carries no gradient."""
+
+    @staticmethod
+    def forward(ctx, x, ts, k, lin, att_src, att_dst, bias):
+        lib = load()
+        n, d = x.shape
+        keep = [lin.detach().contiguous(), att_src.detach().reshape(-1).contiguous(), att_dst.detach().reshape(-1).contiguous(),
+                bias.detach().contiguous()]
+        g = b3d_gat()
+        g.lin, g.att_src, g.att_dst, g.bias = (t.data_ptr() for t in keep)
+        xc = x.detach().contiguous()
+        nbytes = lib.b3d_knn_gat_workspace_bytes(n, d)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        nbr = torch.empty((n, 32), dtype=torch.int32, device=x.device)
+        cnt = torch.empty(n, dtype=torch.int32, device=x.device)
+        y = torch.empty((n, d), dtype=torch.float32, device=x.device)
+        check(lib.b3d_knn_gat_forward(xc.data_ptr(), ts.data_ptr(), n, d, k, C.byref(g), ws.data_ptr(), nbytes,
+                                      nbr.data_ptr(), cnt.data_ptr(), y.data_ptr(), current_stream(x.device)), "b3d_knn_gat_forward")
+        ctx.k = k
+        ctx.shapes = (att_src.shape, att_dst.shape)
+        ctx.save_for_backward(xc, nbr, cnt, *keep)
+        ctx.mark_non_differentiable(nbr, cnt)
+        return y, nbr, cnt
+
+    @staticmethod
+    def backward(ctx, d_y, _d_nbr, _d_cnt):
+        lib = load()
+        x, nbr, cnt, lin, att_src, att_dst, bias = ctx.saved_tensors
+        n, d = x.shape
+        g = b3d_gat()
+        g.lin, g.att_src, g.att_dst, g.bias = lin.data_ptr(), att_src.data_ptr(), att_dst.data_ptr(), bias.data_ptr()
+        d_y = d_y.contiguous().float()
+        d_x = torch.empty_like(x)
+        grads = [torch.empty_like(lin), torch.empty_like(att_src), torch.empty_like(att_dst), torch.empty_like(bias)]
+        gg = b3d_gat_grad()
+        gg.lin, gg.att_src, gg.att_dst, gg.bias = (t.data_ptr() for t in grads)
+        nbytes = lib.b3d_knn_gat_backward_workspace_bytes(n, d, ctx.k)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        check(lib.b3d_knn_gat_backward(x.data_ptr(), n, d, ctx.k, C.byref(g), nbr.data_ptr(), cnt.data_ptr(), d_y.data_ptr(),
+                                       ws.data_ptr(), nbytes, d_x.data_ptr(), C.byref(gg), current_stream(x.device)),
+              "b3d_knn_gat_backward")
+        return d_x, None, None, grads[0], grads[1].reshape(ctx.shapes[0]), grads[2].reshape(ctx.shapes[1]), grads[3]
+
+
+def knn_gat_conv(x: torch.Tensor, node_timestamps: torch.Tensor, conv, k: int = 20, return_graph: bool = False):
+    """Differentiable frame-wise k-NN + GATConv (reference pose_gnn.py:74-80 with the result USED: ``knn_writeback``): ``y`` [N,D]
+    with gradients to ``x`` and to ``conv``'s parameters (``GATConvParams``).  D = 48 or 96."""
+    require_cuda(x, "x", torch.float32)
+    ts = node_timestamps.to(torch.int64).contiguous()
+    y, nbr, cnt = _KnnGatFunction.apply(x, ts, int(k), conv.lin_src.weight, conv.att_src, conv.att_dst, conv.bias)
+    return (y, nbr, cnt) if return_graph else y
 
 
 class Workspace:

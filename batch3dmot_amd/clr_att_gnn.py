@@ -429,6 +429,48 @@ class GNN(nn.Module):
         # first kernel that reads their outputs.  Same kernels, same bits; see encode_modalities().
         self.encoder_streams = True
         self._grad_sink = None          # set by optim.FlatAdam: backward writes gradients into its flat buffer
+        # Non-reference: True USES the k-NN + GAT block's result (layers 0, 2, 4; clr_att_gnn.py:178-184 computes and drops it)
+        # and trains ``knn_conv``: see _forward_writeback
+        self.knn_writeback = False
+        self._last_knn = None
+
+    def _forward_writeback(self, data, encoded=None, rows=None):
+        """``knn_writeback=True``: the layer loop in Python over the library's operators -- frozen encoders (HIP), the k-NN + GAT
+        block with its backward (``_lib.knn_gat_conv``), the CausalMessagePassing layer operator (``mp_layer``) -- with the
+        small dense parts (modality heads, the per-node ``out_proj(v_proj(.))`` of the one-key attention, att_edge_encoder,
+        edge / node encoder, classifier) as PyTorch-ROCm modules.  The whole-model entry point cannot be used: the per-node
+        tables of its hoisted first layers are produced from the x the block would replace."""
+        pose_feats, edge_index, node_timestamps = data.pose_feats, data.edge_index, data.node_timestamps
+        _lib.require_cuda(pose_feats, "data.pose_feats", torch.float32)
+        if edge_index.size(1) == 0 or pose_feats.size(0) == 0:
+            raise ValueError("empty graph: the reference's callers skip these (predict.py:179-180)")
+        n = pose_feats.size(0)
+        if encoded is None:
+            encoded = self._encode(data, rows, join=True)[0]
+        x_img, pointnet_out, lidar_nodes, radarnet_out, radar_nodes = encoded
+        e = self.edge_encoder(data.edge_attr.float())
+        x_lidar = x_img.new_zeros((n, 128))
+        x_radar = x_img.new_zeros((n, 64))
+        if lidar_nodes.numel():
+            x_lidar = x_lidar.index_copy(0, lidar_nodes.long(), self.fc_lidar_encoder(pointnet_out))
+        if radar_nodes.numel():
+            x_radar = x_radar.index_copy(0, radar_nodes.long(), self.fc_radar_encoder(radarnet_out))
+
+        def one_key(att, x, d):            # MultiheadAttention with ONE key: softmax == 1, the output is out_proj(v_proj(value))
+            v = torch.nn.functional.linear(x, att.in_proj_weight[2 * d:], att.in_proj_bias[2 * d:])
+            return att.out_proj(v)
+        s = torch.cat([one_key(self.r2r_att, x_radar, 64), one_key(self.l2l_att, x_lidar, 128), one_key(self.c2c_att, x_img, 96)], 1)
+        att = self.att_edge_encoder(torch.cat([s[edge_index[1]], s[edge_index[0]], e], 1))     # x_sens_i | x_sens_j | edge_attr
+        x_sens = torch.cat([x_img, x_lidar, x_radar], 1)
+        x0 = self.node_encoder(pose_feats)
+        x = x0
+        self._last_knn = []
+        for i in range(self.depth):
+            if i % 2 == 0:
+                x, nbr, cnt = _lib.knn_gat_conv(x.contiguous(), node_timestamps, self.knn_conv, 20, return_graph=True)
+                self._last_knn.append((nbr, cnt))
+            x, e = self.message_passing(x.contiguous(), edge_index, e.contiguous(), x0.contiguous(), att.contiguous())
+        return self.edge_classifier(e), x_sens
 
     def _hip_params(self):
         """Parameters whose gradients ``backward`` of the HIP path produces, in C-ABI struct order."""
@@ -547,6 +589,8 @@ class GNN(nn.Module):
         if not self.use_attention:
             raise NotImplementedError("use_attention=False is a shape error in the reference "
                                       "(clr_att_gnn.py:166-170 vs :82)")
+        if self.knn_writeback:
+            return self._forward_writeback(data, encoded=encoded, rows=rows)
         pose_feats, edge_index, edge_attr, node_timestamps = (data.pose_feats, data.edge_index, data.edge_attr,
                                                               data.node_timestamps)
         _lib.require_cuda(pose_feats, "data.pose_feats", torch.float32)

@@ -196,12 +196,39 @@ class PoseGNN(nn.Module):
         self.keep_workspace = False
         self._last_workspace = None
         self._grad_sink = None          # set by optim.FlatAdam: backward writes gradients into its flat buffer
+        # Non-reference: True USES the k-NN + GAT block's result (x <- GATConv(x, knn_graph(x)) per frame in layers 0, 2, 4: what
+        # pose_gnn.py:74-80 computes and drops) and trains ``knn_conv``.  See _forward_writeback.
+        self.knn_writeback = False
+        self._last_knn = None           # writeback mode: the (nbr, cnt) of every block of the last forward (tests)
 
     def _hip_params(self):
         """Parameters whose gradients ``backward`` of the HIP path produces, in C-ABI struct order."""
         return _param_list(self)
 
+    def _forward_writeback(self, data):
+        """``knn_writeback=True``: a layer loop in Python over the library's operators -- the frame-wise k-NN + GAT block with its
+        backward (``_lib.knn_gat_conv``: b3d_knn_gat_forward / _backward) and the CausalMessagePassing layer operator (``mp_layer``:
+        b3d_pose_layer_forward / _backward) -- with the three small encoder / classifier MLPs (4-8-16-32, 19-24-36-48,
+        32-16-8-4-1) as PyTorch-ROCm modules.  The whole-model entry point cannot be used: the per-node tables of its hoisted first
+        layers are produced by the previous layer's node kernel from the x the block would replace."""
+        pose_feats, edge_index, node_timestamps = data.pose_feats, data.edge_index, data.node_timestamps
+        _lib.require_cuda(pose_feats, "data.pose_feats", torch.float32)
+        if edge_index.size(1) == 0 or pose_feats.size(0) == 0:
+            raise ValueError("empty graph: the reference's callers skip these (predict.py:179-180)")
+        e = self.edge_encoder(data.edge_attr.float())
+        x0 = self.node_encoder(pose_feats)
+        x = x0
+        self._last_knn = []
+        for i in range(self.depth):
+            if i % 2 == 0:
+                x, nbr, cnt = _lib.knn_gat_conv(x.contiguous(), node_timestamps, self.knn_conv, 20, return_graph=True)
+                self._last_knn.append((nbr, cnt))
+            x, e = self.message_passing(x.contiguous(), edge_index, e.contiguous(), x0.contiguous())
+        return self.edge_classifier(e), x0
+
     def forward(self, data):
+        if self.knn_writeback:
+            return self._forward_writeback(data)
         pose_feats, edge_index, edge_attr, node_timestamps, _batch = (
             data.pose_feats, data.edge_index, data.edge_attr, data.node_timestamps,
             getattr(data, "batch", None))

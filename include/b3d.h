@@ -255,6 +255,17 @@ int b3d_knn_gat_forward(const float* x, const int64_t* node_timestamps, int32_t 
                         const b3d_gat* gat /* host */, void* workspace, size_t workspace_bytes,
                         int32_t* out_nbr, int32_t* out_cnt, float* out_y, b3d_stream stream);
 
+/* Backward of the block for `knn_writeback=True` (the mode in which its result is used; the reference drops it, pose_gnn.py:80:
+ * SURVEY.md Appendix A.3, section 8b's b3d_gat_bwd).  x [N,D] and `gat` as given to the forward, nbr / cnt as the forward returned
+ * them (no gradient flows through the neighbour selection), d_y [N,D].  Outputs: d_x [N,D] (may be NULL) and the parameter
+ * gradients (each may be NULL): lin [D,D], att_src / att_dst / bias [D].  Fixed summation order (CSC lists of the k-NN graph by
+ * b3d_graph_build, column sums in node order): bitwise reproducible.  D = 48 or 96, 1 <= k <= 32 (the forward's k). */
+typedef struct b3d_gat_grad { float* lin; float* att_src; float* att_dst; float* bias; } b3d_gat_grad;
+size_t b3d_knn_gat_backward_workspace_bytes(int32_t N, int32_t D, int32_t k);
+int b3d_knn_gat_backward(const float* x, int32_t N, int32_t D, int32_t k, const b3d_gat* gat /* host */, const int32_t* nbr,
+                         const int32_t* cnt, const float* d_y, void* workspace, size_t workspace_bytes, float* d_x,
+                         const b3d_gat_grad* grads /* host */, b3d_stream stream);
+
 /* ---- fused edge loss of the training loop (train.py:136-141) ----------------------------------------
  *   loss = scale * mean_i( w_i * BCE(out_i, y_i) ),   d_out_i = d loss / d out_i,   scale = 1/batch_size
  * out [E] float32: probabilities (torch.nn.BCELoss semantics incl. the -100 log clamp) or, with

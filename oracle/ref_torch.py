@@ -154,6 +154,25 @@ def _dead_knn_block(x, node_timestamps, knn_conv, k=20):
     return outs
 
 
+def _knn_block_writeback(x, node_timestamps, knn_conv, k=20, graph=None):
+    """The block with its result USED (non-reference ``knn_writeback``: SURVEY.md Appendix A.3): x[ts == t] <- GATConv(x_t,
+    knn_graph(x_t)).  ``graph``: (nbr [N,32], cnt [N]) neighbour lists to use instead of recomputing the k-NN graph (tests hand
+    over the lists the HIP forward chose, so that a near-tie in the distances cannot make the two sides differ)."""
+    out = x.clone()
+    if graph is not None:
+        nbr, cnt = graph
+        j = torch.arange(nbr.size(1))[None, :]
+        live = j < cnt.long()[:, None]
+        centre = torch.arange(x.size(0))[:, None].expand_as(nbr)
+        ei = torch.stack([nbr.long()[live], centre[live]])
+        return knn_conv(x, ei)
+    for t in torch.unique(node_timestamps).tolist():
+        m = node_timestamps == t
+        x_t = x[m]
+        out[m] = knn_conv(x_t, knn_graph(x_t, k))
+    return out
+
+
 # --------------------------------------------------------------------------------------
 # PoseGNN
 # --------------------------------------------------------------------------------------
@@ -161,10 +180,12 @@ class PoseGNN(nn.Module):
     """pose_gnn.py:24-86."""
 
     def __init__(self, gnn_depth=6, edge_dim=16, node_dim=19, mp_type: str = "attention",
-                 run_dead_knn: bool = True):
+                 run_dead_knn: bool = True, knn_writeback: bool = False):
         super().__init__()
         self.depth = gnn_depth
         self.run_dead_knn = run_dead_knn
+        self.knn_writeback = knn_writeback       # non-reference: use the block's result
+        self.knn_graphs = None                   # optional list of (nbr, cnt), one per block, instead of recomputed k-NN graphs
         self.edge_encoder = _mlp([4, 8, 16, 32], inplace_relu=True)     # :29-35
         self.node_encoder = _mlp([19, 24, 36, 48])                       # :37-43
         self.edge_classifier = _mlp([32, 16, 8, 4, 1])                   # :45-53
@@ -179,7 +200,9 @@ class PoseGNN(nn.Module):
         x = self.node_encoder(pose_feats)                                # :69
         x_enc = x
         for i in range(self.depth):
-            if i % 2 == 0 and self.run_dead_knn:
+            if i % 2 == 0 and self.knn_writeback:
+                x = _knn_block_writeback(x, node_timestamps, self.knn_conv, graph=self.knn_graphs[i // 2] if self.knn_graphs else None)
+            elif i % 2 == 0 and self.run_dead_knn:
                 _dead_knn_block(x, node_timestamps, self.knn_conv)       # :75-80
             x, edge_attr = self.message_passing(x, edge_index, edge_attr, initial_x)  # :83
             if capture is not None:
@@ -196,11 +219,13 @@ class GNN(nn.Module):
 
     def __init__(self, img_encoder, lidar_encoder, radar_encoder, use_attention=True,
                  gnn_depth=6, edge_dim=64, node_dim=179, run_dead_knn: bool = True,
-                 loop_masks: bool = True):
+                 loop_masks: bool = True, knn_writeback: bool = False):
         super().__init__()
         self.depth = gnn_depth
         self.use_attention = use_attention
         self.run_dead_knn = run_dead_knn
+        self.knn_writeback = knn_writeback       # non-reference: use the k-NN + GAT block's result
+        self.knn_graphs = None
         self.loop_masks = loop_masks
         self.resnet, self.pointnet, self.radarnet = img_encoder, lidar_encoder, radar_encoder
         for enc in (self.resnet, self.pointnet, self.radarnet):          # the oracle keeps the reference's operation order:
@@ -287,7 +312,9 @@ class GNN(nn.Module):
         if capture is not None:
             capture.append(("att_edge_attr", att_edge_attr))
         for i in range(self.depth):                                      # :178-186
-            if i % 2 == 0 and self.run_dead_knn:
+            if i % 2 == 0 and self.knn_writeback:
+                x = _knn_block_writeback(x, node_timestamps, self.knn_conv, graph=self.knn_graphs[i // 2] if self.knn_graphs else None)
+            elif i % 2 == 0 and self.run_dead_knn:
                 _dead_knn_block(x, node_timestamps, self.knn_conv)
             x, edge_attr = self.message_passing(x, edge_index, edge_attr, initial_x, att_edge_attr)
             if capture is not None:
