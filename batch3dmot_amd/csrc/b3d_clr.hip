@@ -38,8 +38,17 @@ using HC = Hoist<DB>;
 // per-wavefront LDS-DMA kernel (b3d_wstream2.hpp) for the shapes it has no tile for.  The unsplit kernels of b3d_mp.hpp
 // serve the single-layer operator at the end of this file.
 using ES = es::EdgeSeqs<DB>;
-// rows of every per-edge workspace buffer: the fragment-streamed kernels store whole 64-row tiles
-static size_t edge_rows(int E) { return ((size_t)(E > 0 ? E : 1) + 63) / 64 * 64; }
+// fragment-streamed edge kernels: one workgroup of es::kWaves wavefronts per es::kTileRows-row tile
+template <class Kern, class Args>
+static int launch_es(Kern kernel, const char* name, const Args& a, long rows, hipStream_t stream, int family, int lds_bytes) {
+  if (rows <= 0) return B3D_OK;
+  B3D_TRY(set_lds(kernel, lds_bytes));
+  ProfScope ps(family, stream);
+  hipLaunchKernelGGL(kernel, dim3(grid_for_tiles(rows, es::kTileRows)), dim3(es::kWaves * 64), lds_bytes, stream, a);
+  return launch_check(name);
+}
+// rows of every per-edge workspace buffer: the fragment-streamed kernels store whole tiles (64 or 128 rows)
+static size_t edge_rows(int E) { return ((size_t)(E > 0 ? E : 1) + es::kTileRows - 1) / es::kTileRows * es::kTileRows; }
 constexpr int XS = 288;                                                  // x_sens / s width (96 + 128 + 64)
 using SeqEE = LayerSeq<L<16, 16>, L<16, 32>, L<32, 64>>;                 // 4-16-32-64          :35-41
 using SeqNE = LayerSeq<L<32, 48>, L<48, 96>>;                            // 19-48-96            :43-47
@@ -667,8 +676,8 @@ extern "C" int b3d_clr_forward(const b3d_clr_weights* pw, const b3d_graph* g, co
     ea.E = E; ea.src = g->src; ea.dst = g->dst; ea.T = w.T; ea.e_in = w.e[l]; ea.a_in = w.att;
     ea.e_out = w.e[l + 1]; ea.fut = w.fut; ea.past = w.past;
     ea.sH1 = w.sH1[l]; ea.sH2 = w.sH2[l]; ea.sF1 = w.sF1[l]; ea.sP1 = w.sP1[l]; ea.wpack = w.wp_efwd2;
-    if (tr) B3D_TRY(launch_rows<es::kWaves>(es::edge_fwd_kernel<DB, true>, "edge_fwd", ea, E, stream, B3D_K_EDGE_FWD, ES::Fwd::LDS_BYTES));
-    else B3D_TRY(launch_rows<es::kWaves>(es::edge_fwd_kernel<DB, false>, "edge_fwd", ea, E, stream, B3D_K_EDGE_FWD, ES::Fwd::LDS_BYTES));
+    if (tr) B3D_TRY(launch_es(es::edge_fwd_kernel<DB, true>, "edge_fwd", ea, E, stream, B3D_K_EDGE_FWD, ES::Fwd::LDS_BYTES));
+    else B3D_TRY(launch_es(es::edge_fwd_kernel<DB, false>, "edge_fwd", ea, E, stream, B3D_K_EDGE_FWD, ES::Fwd::LDS_BYTES));
     if (l + 1 < depth) {                                   // + the per-node table the next layer's edge phase gathers
       na.wpack = w.wp_nfwd_h; na.T = w.T; na.T0 = w.T0;
       B3D_TRY((launch_node_split<DB, kNodeWavesWide>(mp_node_fwd_split_h_kernel<DB>, "mp_node_fwd", na, N, stream, B3D_K_NODE_FWD)));
@@ -772,10 +781,10 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
     eb.GdF1 = w.GdF1 + l * eLm; eb.GdP1 = w.GdP1 + l * eLm;
     if (msgs) {
       eb.wpack = w.wp_ebwd2;
-      B3D_TRY(launch_rows<es::kWaves>(es::edge_bwd_kernel<DB, true>, "edge_bwd", eb, E, stream, B3D_K_EDGE_BWD, ES::Bwd::LDS_BYTES));
+      B3D_TRY(launch_es(es::edge_bwd_kernel<DB, true>, "edge_bwd", eb, E, stream, B3D_K_EDGE_BWD, ES::Bwd::LDS_BYTES));
     } else {                                                 // last layer: its node output is not used (only e feeds the classifier)
       eb.wpack = w.wp_ebwd_nm2;
-      B3D_TRY(launch_rows<es::kWaves>(es::edge_bwd_kernel<DB, false>, "edge_bwd_last", eb, E, stream, B3D_K_EDGE_BWD, ES::BwdNoMsg::LDS_BYTES));
+      B3D_TRY(launch_es(es::edge_bwd_kernel<DB, false>, "edge_bwd_last", eb, E, stream, B3D_K_EDGE_BWD, ES::BwdNoMsg::LDS_BYTES));
     }
     da_first = false;
     cur ^= 1;

@@ -29,23 +29,24 @@ struct EdgeSeqs {
 };
 
 // ---- forward -----------------------------------------------------------------------------------------------------------------
-// loads / stores in front of the first chunk of layers 1 .. 6, per wavefront (16 rows: one 16-byte access per 16-feature block)
+// loads / stores in front of the first chunk of layers 1 .. 6, per wavefront (kRB row blocks of 16 rows: one 16-byte access per
+// 16-feature block and row block)
 template <class D, bool TRAIN>
 struct FwdHooks {
   using S = typename EdgeSeqs<D>::Fwd;
   __host__ __device__ static constexpr int before(int ci) {
     constexpr int H1B = D::EH1 / 16, H2B = D::EH2 / 16, EB = D::DE / 16, MHB = D::MH / 16, DMB = D::DM / 16, SV = TRAIN ? 1 : 0;
-    return ci == S::first_chunk(1) ? SV * H1B + MHB          // sH1 store, T[dst] future rows
-         : ci == S::first_chunk(2) ? SV * H2B + MHB          // sH2 store, T[src] past rows
-         : ci == S::first_chunk(3) ? EB                      // e' store
-         : ci == S::first_chunk(4) ? SV * MHB                // sF1 store
-         : ci == S::first_chunk(5) ? DMB                     // fut store
-         : ci == S::first_chunk(6) ? SV * MHB : 0;           // sP1 store
+    return kRB * (ci == S::first_chunk(1) ? SV * H1B + MHB          // sH1 store, T[dst] future rows
+                : ci == S::first_chunk(2) ? SV * H2B + MHB          // sH2 store, T[src] past rows
+                : ci == S::first_chunk(3) ? EB                      // e' store
+                : ci == S::first_chunk(4) ? SV * MHB                // sF1 store
+                : ci == S::first_chunk(5) ? DMB                     // fut store
+                : ci == S::first_chunk(6) ? SV * MHB : 0);          // sP1 store
   }
 };
 
 template <class D, bool TRAIN>
-__global__ __launch_bounds__(kWaves * 64, 2) void edge_fwd_kernel(const EdgeFwdHArgs a) {
+__global__ __launch_bounds__(kWaves * 64, kWgPerCu) void edge_fwd_kernel(const EdgeFwdHArgs a) {
   extern __shared__ __attribute__((aligned(16))) char es_smem[];
   using H = Hoist<D>;
   using S = typename EdgeSeqs<D>::Fwd;
@@ -61,73 +62,82 @@ __global__ __launch_bounds__(kWaves * 64, 2) void edge_fwd_kernel(const EdgeFwdH
   frag_load2(st.base + lane * 16, st.cur0, st.cur1);       // chunk 0 is complete (Ring::start)
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const bool more = tile + (int)gridDim.x < ntiles;
-    const unsigned row = (unsigned)tile * (unsigned)kTileRows + ring.wave * 16 + (lane & 15);
-    const unsigned rc = row < (unsigned)a.E ? row : (unsigned)a.E - 1u;         // rows past the end compute on the last edge
-    const unsigned s = (unsigned)a.src[rc], d = (unsigned)a.dst[rc];
-    v4f ein[EB + AB];
-    {
-      v4f e0[EB], a0[AB];
-      load_row<EB>(a.e_in, rc, D::DE, 0, e0);
-      load_row<AB>(a.a_in, rc, D::DA, 0, a0);
+    unsigned row[kRB], rc[kRB], s[kRB], d[kRB];
 #pragma unroll
-      for (int b = 0; b < EB; ++b) ein[b] = e0[b];
-#pragma unroll
-      for (int b = 0; b < AB; ++b) ein[EB + b] = a0[b];
+    for (int rb = 0; rb < kRB; ++rb) {
+      row[rb] = (unsigned)tile * (unsigned)kTileRows + (ring.wave * kRB + rb) * 16 + (lane & 15);
+      rc[rb] = row[rb] < (unsigned)a.E ? row[rb] : (unsigned)a.E - 1u;         // rows past the end compute on the last edge
+      s[rb] = (unsigned)a.src[rc[rb]]; d[rb] = (unsigned)a.dst[rc[rb]];
     }
-    v4f h1[H1B];
+    v4f ein[kRB][EB + AB];
     {
-      v4f tb[H1B];
-      load_row<H1B>(a.T, d, H::TW, H::OA, h1);
-      load_row<H1B>(a.T, s, H::TW, H::OB, tb);
+      v4f e0[kRB][EB], a0[kRB][AB];
+      load_rows<EB>(a.e_in, rc, D::DE, 0, e0);
+      load_rows<AB>(a.a_in, rc, D::DA, 0, a0);
 #pragma unroll
-      for (int b = 0; b < H1B; ++b) h1[b] += tb[b];
+      for (int rb = 0; rb < kRB; ++rb) {
+#pragma unroll
+        for (int b = 0; b < EB; ++b) ein[rb][b] = e0[rb][b];
+#pragma unroll
+        for (int b = 0; b < AB; ++b) ein[rb][EB + b] = a0[rb][b];
+      }
+    }
+    v4f h1[kRB][H1B];
+    {
+      v4f tb[kRB][H1B];
+      load_rows<H1B>(a.T, d, H::TW, H::OA, h1);
+      load_rows<H1B>(a.T, s, H::TW, H::OB, tb);
+#pragma unroll
+      for (int rb = 0; rb < kRB; ++rb)
+#pragma unroll
+        for (int b = 0; b < H1B; ++b) h1[rb][b] += tb[rb][b];
     }
     // ---- edge_update ----
     {
-      Bf3 x0[(EB + AB) / 2];
+      Bf3 x0[kRB][(EB + AB) / 2];
       split_blocks<EB + AB>(ein, x0);
       layer<S, 0, true, false, true>(ring, more, st, x0, h1);
     }
-    if constexpr (TRAIN) store_row<H1B>(a.sH1, row, D::EH1, h1);
-    v4f fi[MHB];
-    load_row<MHB>(a.T, d, H::TW, H::OF, fi);
-    v4f h2[H2B];
+    if constexpr (TRAIN) store_rows<H1B>(a.sH1, row, D::EH1, h1);
+    v4f fi[kRB][MHB];
+    load_rows<MHB>(a.T, d, H::TW, H::OF, fi);
+    v4f h2[kRB][H2B];
     {
-      Bf3 x1[H1B / 2];
+      Bf3 x1[kRB][H1B / 2];
       split_blocks<H1B>(h1, x1);
       layer<S, 1, true, true, false>(ring, more, st, x1, h2);
     }
-    if constexpr (TRAIN) store_row<H2B>(a.sH2, row, D::EH2, h2);
-    v4f pi[MHB];
-    load_row<MHB>(a.T, s, H::TW, H::OP, pi);
-    v4f en[EB];
+    if constexpr (TRAIN) store_rows<H2B>(a.sH2, row, D::EH2, h2);
+    v4f pi[kRB][MHB];
+    load_rows<MHB>(a.T, s, H::TW, H::OP, pi);
+    v4f en[kRB][EB];
     {
-      Bf3 x2[H2B / 2];
+      Bf3 x2[kRB][H2B / 2];
       split_blocks<H2B>(h2, x2);
       layer<S, 2, false, true, false>(ring, more, st, x2, en);
     }
-    store_row<EB>(a.e_out, row, D::DE, en);
-    Bf3 xe[EB / 2];
+    store_rows<EB>(a.e_out, row, D::DE, en);
+    Bf3 xe[kRB][EB / 2];
     split_blocks<EB>(en, xe);
     // ---- create_future_msgs ----
     layer<S, 3, true, false, true>(ring, more, st, xe, fi);
-    if constexpr (TRAIN) store_row<MHB>(a.sF1, row, D::MH, fi);
+    if constexpr (TRAIN) store_rows<MHB>(a.sF1, row, D::MH, fi);
     {
-      v4f mo[DMB];
-      Bf3 x4[MHB / 2];
+      v4f mo[kRB][DMB];
+      Bf3 x4[kRB][MHB / 2];
       split_blocks<MHB>(fi, x4);
       layer<S, 4, false, true, false>(ring, more, st, x4, mo);
-      store_row<DMB>(a.fut, row, D::DM, mo);
+      store_rows<DMB>(a.fut, row, D::DM, mo);
     }
     // ---- create_past_msgs ----
     layer<S, 5, true, false, true>(ring, more, st, xe, pi);
-    if constexpr (TRAIN) store_row<MHB>(a.sP1, row, D::MH, pi);
+    if constexpr (TRAIN) store_rows<MHB>(a.sP1, row, D::MH, pi);
     {
-      v4f mo[DMB];
-      Bf3 x6[MHB / 2];
+      v4f mo[kRB][DMB];
+      Bf3 x6[kRB][MHB / 2];
       split_blocks<MHB>(pi, x6);
       layer<S, 6, false, true, false>(ring, more, st, x6, mo);
-      store_row<DMB>(a.past, row, D::DM, mo);
+      store_rows<DMB>(a.past, row, D::DM, mo);
     }
   }
 }
@@ -139,19 +149,20 @@ struct BwdHooks {
   __host__ __device__ static constexpr int before(int ci) {
     constexpr int H1B = D::EH1 / 16, H2B = D::EH2 / 16, EB = D::DE / 16, AB = D::DA / 16, MHB = D::MH / 16;
     if (MSGS)
-      return ci == S::first_chunk(1) ? MHB + MHB + D::DM / 16  // GdP1 store, sF1 load, dM[src] load
-           : ci == S::first_chunk(3) ? MHB + H2B               // GdF1 store, sH2 load
-           : ci == S::first_chunk(4) ? EB + H1B                // Gde store, sH1 load
-           : ci == S::first_chunk(5) ? H2B                     // GdH2 store
-           : ci == S::first_chunk(6) ? H1B + AB : 0;           // GdH1 store, running d att load
-    return ci == S::first_chunk(1) ? H2B : ci == S::first_chunk(2) ? H1B + AB : 0;
+      return kRB * (ci == S::first_chunk(1) ? MHB + D::DM / 16        // GdP1 store, dM[src] load
+                  : ci == S::first_chunk(2) ? MHB                     // sF1 load (behind layer 1: its registers are free then)
+                  : ci == S::first_chunk(3) ? MHB + H2B               // GdF1 store, sH2 load
+                  : ci == S::first_chunk(4) ? EB                      // Gde store
+                  : ci == S::first_chunk(5) ? H2B + H1B               // GdH2 store, sH1 load (a layer ahead of its use)
+                  : ci == S::first_chunk(6) ? H1B + AB : 0);          // GdH1 store, running d att load
+    return kRB * (ci == S::first_chunk(1) ? H2B + H1B : ci == S::first_chunk(2) ? H1B + AB : 0);    // GdH2 store + sH1 load; GdH1 store + d att load
   }
 };
 
 // Data gradient of the edge phase without the node columns of the three first layers (those are contracted per node from
 // the segment sums of GdH1 / GdF1 / GdP1: node_listsum_kernel + node_bwd_g_kernel).
 template <class D, bool MSGS>
-__global__ __launch_bounds__(kWaves * 64, 2) void edge_bwd_kernel(const EdgeBwdHArgs a) {
+__global__ __launch_bounds__(kWaves * 64, kWgPerCu) void edge_bwd_kernel(const EdgeBwdHArgs a) {
   extern __shared__ __attribute__((aligned(16))) char es_smem[];
   using S = typename BwdHooks<D, MSGS>::S;
   static_assert(D::DA > 0, "camera+LiDAR+radar widths (e | att columns)");
@@ -167,86 +178,97 @@ __global__ __launch_bounds__(kWaves * 64, 2) void edge_bwd_kernel(const EdgeBwdH
   frag_load2(st.base + lane * 16, st.cur0, st.cur1);
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const bool more = tile + (int)gridDim.x < ntiles;
-    const unsigned row = (unsigned)tile * (unsigned)kTileRows + ring.wave * 16 + (lane & 15);
-    const unsigned rc = row < (unsigned)a.E ? row : (unsigned)a.E - 1u;
-    v4f de[EB];
-    load_row<EB>(a.de_out, rc, D::DE, 0, de);
-    v4f act2[H2B], act1[H1B];
+    unsigned row[kRB], rc[kRB];
+#pragma unroll
+    for (int rb = 0; rb < kRB; ++rb) {
+      row[rb] = (unsigned)tile * (unsigned)kTileRows + (ring.wave * kRB + rb) * 16 + (lane & 15);
+      rc[rb] = row[rb] < (unsigned)a.E ? row[rb] : (unsigned)a.E - 1u;
+    }
+    v4f de[kRB][EB];
+    load_rows<EB>(a.de_out, rc, D::DE, 0, de);
+    v4f act2[kRB][H2B], act1[kRB][H1B];
     if constexpr (MSGS) {
-      const unsigned s = (unsigned)a.src[rc], d = (unsigned)a.dst[rc];
-      v4f dmp[DMB], dmf[DMB], actp[MHB], actf[MHB];
-      load_row<DMB>(a.dM, d, 2 * D::DM, 0, dmp);             // past messages were summed at dst
-      load_row<MHB>(a.sP1, rc, D::MH, 0, actp);
-      v4f dh[MHB], dee[EB];
+      unsigned s[kRB], d[kRB];
+#pragma unroll
+      for (int rb = 0; rb < kRB; ++rb) { s[rb] = (unsigned)a.src[rc[rb]]; d[rb] = (unsigned)a.dst[rc[rb]]; }
+      v4f dmp[kRB][DMB], dmf[kRB][DMB], actp[kRB][MHB], actf[kRB][MHB];
+      load_rows<DMB>(a.dM, d, 2 * D::DM, 0, dmp);             // past messages were summed at dst
+      load_rows<MHB>(a.sP1, rc, D::MH, 0, actp);
+      v4f dh[kRB][MHB], dee[kRB][EB];
       {
-        Bf3 x0[DMB / 2];
+        Bf3 x0[kRB][DMB / 2];
         split_blocks<DMB>(dmp, x0);
         layer<S, 0, false, false, false>(ring, more, st, x0, dh);
       }
       relu_bwd_blocks<MHB>(dh, actp);
-      store_row<MHB>(a.GdP1, row, D::MH, dh);
-      load_row<MHB>(a.sF1, rc, D::MH, 0, actf);
-      load_row<DMB>(a.dM, s, 2 * D::DM, D::DM, dmf);         // future messages were summed at src (needed a layer from here)
+      store_rows<MHB>(a.GdP1, row, D::MH, dh);
+      load_rows<DMB>(a.dM, s, 2 * D::DM, D::DM, dmf);         // future messages were summed at src (needed a layer from here)
       {
-        Bf3 x1[MHB / 2];
+        Bf3 x1[kRB][MHB / 2];
         split_blocks<MHB>(dh, x1);
         layer<S, 1, false, false, false>(ring, more, st, x1, dee);
       }
+      load_rows<MHB>(a.sF1, rc, D::MH, 0, actf);
 #pragma unroll
-      for (int b = 0; b < EB; ++b) de[b] += dee[b];
+      for (int rb = 0; rb < kRB; ++rb)
+#pragma unroll
+        for (int b = 0; b < EB; ++b) de[rb][b] += dee[rb][b];
       {
-        Bf3 x2[DMB / 2];
+        Bf3 x2[kRB][DMB / 2];
         split_blocks<DMB>(dmf, x2);
         layer<S, 2, false, false, false>(ring, more, st, x2, dh);
       }
       relu_bwd_blocks<MHB>(dh, actf);
-      store_row<MHB>(a.GdF1, row, D::MH, dh);
-      load_row<H2B>(a.sH2, rc, D::EH2, 0, act2);
+      store_rows<MHB>(a.GdF1, row, D::MH, dh);
+      load_rows<H2B>(a.sH2, rc, D::EH2, 0, act2);
       {
-        Bf3 x3[MHB / 2];
+        Bf3 x3[kRB][MHB / 2];
         split_blocks<MHB>(dh, x3);
         layer<S, 3, false, false, false>(ring, more, st, x3, dee);
       }
 #pragma unroll
-      for (int b = 0; b < EB; ++b) de[b] += dee[b];
-      store_row<EB>(a.Gde, row, D::DE, de);
-      load_row<H1B>(a.sH1, rc, D::EH1, 0, act1);
+      for (int rb = 0; rb < kRB; ++rb)
+#pragma unroll
+        for (int b = 0; b < EB; ++b) de[rb][b] += dee[rb][b];
+      store_rows<EB>(a.Gde, row, D::DE, de);
     } else {
-      load_row<H2B>(a.sH2, rc, D::EH2, 0, act2);
-      load_row<H1B>(a.sH1, rc, D::EH1, 0, act1);
-      store_row<EB>(a.Gde, row, D::DE, de);
+      load_rows<H2B>(a.sH2, rc, D::EH2, 0, act2);
+      store_rows<EB>(a.Gde, row, D::DE, de);
     }
-    v4f d2[H2B], d1[H1B], dein[EB + AB];
+    v4f d2[kRB][H2B], d1[kRB][H1B], dein[kRB][EB + AB];
     {
-      Bf3 x4[EB / 2];
+      Bf3 x4[kRB][EB / 2];
       split_blocks<EB>(de, x4);
       layer<S, L0 + 0, false, false, false>(ring, more, st, x4, d2);
     }
     relu_bwd_blocks<H2B>(d2, act2);
-    store_row<H2B>(a.GdH2, row, D::EH2, d2);
+    store_rows<H2B>(a.GdH2, row, D::EH2, d2);
+    load_rows<H1B>(a.sH1, rc, D::EH1, 0, act1);             // needed behind the next layer (128 registers: not earlier)
     {
-      Bf3 x5[H2B / 2];
+      Bf3 x5[kRB][H2B / 2];
       split_blocks<H2B>(d2, x5);
       layer<S, L0 + 1, false, false, false>(ring, more, st, x5, d1);
     }
     relu_bwd_blocks<H1B>(d1, act1);
-    store_row<H1B>(a.GdH1, row, D::EH1, d1);
-    v4f prev[AB];
-    load_row<AB>(a.da_acc, rc, D::DA, 0, prev);
+    store_rows<H1B>(a.GdH1, row, D::EH1, d1);
+    v4f prev[kRB][AB];
+    load_rows<AB>(a.da_acc, rc, D::DA, 0, prev);
     {
-      Bf3 x6[H1B / 2];
+      Bf3 x6[kRB][H1B / 2];
       split_blocks<H1B>(d1, x6);
       layer<S, L0 + 2, false, false, false>(ring, more, st, x6, dein);
     }
     {
-      v4f o[EB];
+      v4f o[kRB][EB], da[kRB][AB];
 #pragma unroll
-      for (int b = 0; b < EB; ++b) o[b] = dein[b];
-      store_row<EB>(a.de_in, row, D::DE, o);
-      v4f da[AB];
+      for (int rb = 0; rb < kRB; ++rb) {
 #pragma unroll
-      for (int b = 0; b < AB; ++b) da[b] = a.da_first ? dein[EB + b] : dein[EB + b] + prev[b];   // (always loaded: a fixed number of loads)
-      store_row<AB>(a.da_acc, row, D::DA, da);
+        for (int b = 0; b < EB; ++b) o[rb][b] = dein[rb][b];
+#pragma unroll
+        for (int b = 0; b < AB; ++b) da[rb][b] = a.da_first ? dein[rb][EB + b] : dein[rb][EB + b] + prev[rb][b];   // (always loaded: a fixed number of loads)
+      }
+      store_rows<EB>(a.de_in, row, D::DE, o);
+      store_rows<AB>(a.da_acc, row, D::DA, da);
     }
   }
 }

@@ -29,7 +29,19 @@
 namespace b3d {
 namespace es {
 
-constexpr int kWaves = 4, kTileRows = kWaves * 16;          // 64 rows per workgroup, two workgroups per CU
+// A wavefront carries kRB 16-row blocks through the stack.  kRB = 1 (shipped): 16 rows per wavefront, 64-row tiles, TWO workgroups
+// per CU (two wavefronts of different workgroups share a SIMD and cover each other's waits).  kRB = 2 (round-4 experiment, -DB3D_ES_RB=2):
+// 32 rows per wavefront, 128-row tiles, ONE workgroup per CU with the whole 512-register budget per wavefront -- every weight
+// fragment read from LDS feeds four MFMA chains, half the fragment reads and half the L2 -> LDS weight stream per edge, 0 spills
+// (446 - 509 registers), ISA audit clean -- and 13 - 16 % SLOWER (forward 454 vs 400 us per step of six launches, backward 491 vs
+// 422: profiles/r04_e_edge_rowblocks_ab.txt): with one wavefront per SIMD nothing covers the rendezvous, the LDS latencies and the
+// ~880 v_accvgpr moves per tile.  The limiter of these kernels is the per-SIMD dependency chain, not LDS bandwidth.
+#ifndef B3D_ES_RB
+#define B3D_ES_RB 1
+#endif
+constexpr int kRB = B3D_ES_RB;
+constexpr int kWaves = 4, kTileRows = kWaves * 16 * kRB;    // rows per workgroup
+constexpr int kWgPerCu = kRB == 1 ? 2 : 1;
 constexpr int kChunkSteps = 4, kStepBytes = 6144, kChunkBytes = kChunkSteps * kStepBytes, kSlots = 3;
 constexpr int kPiecesPerWave = kChunkBytes / 1024 / kWaves;  // 6
 
@@ -70,7 +82,7 @@ struct Seq {
   static constexpr int TOTAL_FLOATS = TOTAL_BYTES / 4;
   static constexpr int LDS_BYTES = kSlots * kChunkBytes + BIAS_BYTES;
   static_assert(BIAS_BYTES == 4096 || BIAS_BYTES == 8192, "bias DMA: one or two pieces per wavefront");
-  static_assert(LDS_BYTES <= 80 * 1024, "two workgroups per CU");
+  static_assert(LDS_BYTES <= 80 * 1024, "two workgroups per CU (kRB = 1)");
 };
 
 // ---- LDS-DMA from inline asm ---------------------------------------------------------------------------------------------
@@ -172,33 +184,30 @@ __device__ __forceinline__ Bf3 frag_load(unsigned addr) {          // addr: this
   return f;
 }
 __device__ __forceinline__ void frag_load2(unsigned addr, Bf3& f0, Bf3& f1) { f0 = frag_load(addr); f1 = frag_load(addr + 3072); }
-// two independent chains, interleaved; smallest terms first (as bf_mfma6)
-__device__ __forceinline__ void mfma12(const Bf3& w0, const Bf3& w1, const Bf3& x, v4f& a0, v4f& a1) {
-  a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0.p0, x.p2, a0, 0, 0, 0);
-  a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1.p0, x.p2, a1, 0, 0, 0);
-  a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0.p1, x.p1, a0, 0, 0, 0);
-  a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1.p1, x.p1, a1, 0, 0, 0);
-  a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0.p2, x.p0, a0, 0, 0, 0);
-  a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1.p2, x.p0, a1, 0, 0, 0);
-  a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0.p0, x.p1, a0, 0, 0, 0);
-  a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1.p0, x.p1, a1, 0, 0, 0);
-  a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0.p1, x.p0, a0, 0, 0, 0);
-  a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1.p1, x.p0, a1, 0, 0, 0);
-  a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0.p0, x.p0, a0, 0, 0, 0);
-  a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1.p0, x.p0, a1, 0, 0, 0);
+// 2 kRB independent chains (output blocks 2 p, 2 p + 1 x the wavefront's row blocks), interleaved; smallest terms first (as
+// bf_mfma6)
+template <int KS>
+__device__ __forceinline__ void mfma_step(const Bf3& w0, const Bf3& w1, const Bf3 (&x)[kRB][KS], int ks, v4f (&a0)[kRB], v4f (&a1)[kRB]) {
+#define B3D_ES_PROD(WP, XP)                                                                                   \
+  _Pragma("unroll") for (int rb = 0; rb < kRB; ++rb) {                                                         \
+    a0[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0.WP, x[rb][ks].XP, a0[rb], 0, 0, 0);                   \
+    a1[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1.WP, x[rb][ks].XP, a1[rb], 0, 0, 0);                   \
+  }
+  B3D_ES_PROD(p0, p2) B3D_ES_PROD(p1, p1) B3D_ES_PROD(p2, p0) B3D_ES_PROD(p0, p1) B3D_ES_PROD(p1, p0) B3D_ES_PROD(p0, p0)
+#undef B3D_ES_PROD
 }
 
 // State of the step loop, carried across layers (everything else is compile-time).
 struct StepState {
   unsigned base;     // LDS address of the current chunk
   Bf3 cur0, cur1;    // fragments of the current step (output blocks 2 p, 2 p + 1)
-  v4f acc0, acc1;
+  v4f acc0[kRB], acc1[kRB];
 };
 
 // One step of layer LI: 32 inputs (group ks) against the output blocks 2 ob, 2 ob + 1.  io[b] holds the initial value (INIT) on
 // entry of a block and the activation on exit.
 template <class S, int LI, int ST, bool RELU, bool BIAS, bool INIT, class RingT>
-__device__ __forceinline__ void step(RingT& ring, bool more, StepState& st, const Bf3 (&x)[S::k(LI) / 32], v4f (&io)[S::n(LI) / 16]) {
+__device__ __forceinline__ void step(RingT& ring, bool more, StepState& st, const Bf3 (&x)[kRB][S::k(LI) / 32], v4f (&io)[kRB][S::n(LI) / 16]) {
   constexpr int KS = S::k(LI) / 32;
   constexpr int ob = ST / KS, ks = ST % KS;
   constexpr int GST = S::first_step(LI) + ST;                    // step of the tile
@@ -215,35 +224,46 @@ __device__ __forceinline__ void step(RingT& ring, bool more, StepState& st, cons
       a0 = *(lds_v4f_p)(size_t)ba;
       a1 = *(lds_v4f_p)(size_t)(ba + 64);
     }
-    if constexpr (INIT) { a0 += io[2 * ob]; a1 += io[2 * ob + 1]; }
-    st.acc0 = a0; st.acc1 = a1;
+#pragma unroll
+    for (int rb = 0; rb < kRB; ++rb) {
+      st.acc0[rb] = a0; st.acc1[rb] = a1;
+      if constexpr (INIT) { st.acc0[rb] += io[rb][2 * ob]; st.acc1[rb] += io[rb][2 * ob + 1]; }
+    }
   }
-  // the LDS reads of the NEXT step are issued in front of this step's twelve MFMAs (hipcc otherwise sinks them next to their use)
+  // the LDS reads of the NEXT step are issued in front of this step's MFMAs (hipcc otherwise sinks them next to their use)
   Bf3 n0 = st.cur0, n1 = st.cur1;
   if constexpr (IN_CHUNK + 1 < kChunkSteps) frag_load2(st.base + (IN_CHUNK + 1) * kStepBytes + ring.lane * 16, n0, n1);
   else if constexpr (CJ + 1 < S::NCH) frag_load2(ring.template slot_addr<CJ + 1>() + ring.lane * 16, n0, n1);
   else { if (more) frag_load2(ring.template slot_addr<0>() + ring.lane * 16, n0, n1); }
   __builtin_amdgcn_sched_barrier(0);
-  mfma12(st.cur0, st.cur1, x[ks], st.acc0, st.acc1);
+  mfma_step<KS>(st.cur0, st.cur1, x, ks, st.acc0, st.acc1);
   __builtin_amdgcn_sched_barrier(0);
   st.cur0 = n0; st.cur1 = n1;
-  if constexpr (ks == KS - 1) { io[2 * ob] = RELU ? relu4(st.acc0) : st.acc0; io[2 * ob + 1] = RELU ? relu4(st.acc1) : st.acc1; }
+  if constexpr (ks == KS - 1) {
+#pragma unroll
+    for (int rb = 0; rb < kRB; ++rb) {
+      io[rb][2 * ob] = RELU ? relu4(st.acc0[rb]) : st.acc0[rb];
+      io[rb][2 * ob + 1] = RELU ? relu4(st.acc1[rb]) : st.acc1[rb];
+    }
+  }
 }
 template <class S, int LI, bool RELU, bool BIAS, bool INIT, class RingT, int... ST>
-__device__ __forceinline__ void layer_impl(RingT& ring, bool more, const Bf3 (&x)[S::k(LI) / 32], v4f (&io)[S::n(LI) / 16],
+__device__ __forceinline__ void layer_impl(RingT& ring, bool more, const Bf3 (&x)[kRB][S::k(LI) / 32], v4f (&io)[kRB][S::n(LI) / 16],
                                            StepState& st, std::integer_sequence<int, ST...>) {
   (step<S, LI, ST, RELU, BIAS, INIT>(ring, more, st, x, io), ...);
 }
-// io = act(W . x (+ b) (+ io))
+// io = act(W . x (+ b) (+ io)) for every row block of the wavefront
 template <class S, int LI, bool RELU, bool BIAS, bool INIT, class RingT>
-__device__ __forceinline__ void layer(RingT& ring, bool more, StepState& st, const Bf3 (&x)[S::k(LI) / 32], v4f (&io)[S::n(LI) / 16]) {
+__device__ __forceinline__ void layer(RingT& ring, bool more, StepState& st, const Bf3 (&x)[kRB][S::k(LI) / 32], v4f (&io)[kRB][S::n(LI) / 16]) {
   layer_impl<S, LI, RELU, BIAS, INIT>(ring, more, x, io, st, std::make_integer_sequence<int, S::steps(LI)>{});
 }
 
 template <int NB>
-__device__ __forceinline__ void split_blocks(const v4f (&a)[NB], Bf3 (&x)[NB / 2]) {
+__device__ __forceinline__ void split_blocks(const v4f (&a)[kRB][NB], Bf3 (&x)[kRB][NB / 2]) {
 #pragma unroll
-  for (int c = 0; c < NB / 2; ++c) x[c] = bf_split(a[2 * c], a[2 * c + 1]);
+  for (int rb = 0; rb < kRB; ++rb)
+#pragma unroll
+    for (int c = 0; c < NB / 2; ++c) x[rb][c] = bf_split(a[rb][2 * c], a[rb][2 * c + 1]);
 }
 // Row tables are addressed as (uniform base pointer) + (32-bit byte offset): one VGPR per row and table, and hipcc selects
 // the saddr form of global_load / global_store (no 64-bit address arithmetic, no address pairs to keep alive).  Unconditional.
@@ -262,14 +282,27 @@ __device__ __forceinline__ void store_row(float* __restrict__ base, unsigned row
   for (int b = 0; b < NB; ++b) *reinterpret_cast<v4f*>(reinterpret_cast<char*>(base) + off + 64u * b) = src[b];
 }
 template <int NB>
-__device__ __forceinline__ void relu_bwd_blocks(v4f (&g)[NB], const v4f (&act)[NB]) {
+__device__ __forceinline__ void relu_bwd_blocks(v4f (&g)[kRB][NB], const v4f (&act)[kRB][NB]) {
 #pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    g[b].x = act[b].x > 0.f ? g[b].x : 0.f;
-    g[b].y = act[b].y > 0.f ? g[b].y : 0.f;
-    g[b].z = act[b].z > 0.f ? g[b].z : 0.f;
-    g[b].w = act[b].w > 0.f ? g[b].w : 0.f;
-  }
+  for (int rb = 0; rb < kRB; ++rb)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      g[rb][b].x = act[rb][b].x > 0.f ? g[rb][b].x : 0.f;
+      g[rb][b].y = act[rb][b].y > 0.f ? g[rb][b].y : 0.f;
+      g[rb][b].z = act[rb][b].z > 0.f ? g[rb][b].z : 0.f;
+      g[rb][b].w = act[rb][b].w > 0.f ? g[rb][b].w : 0.f;
+    }
+}
+// the same row table access for every row block of the wavefront
+template <int NB>
+__device__ __forceinline__ void load_rows(const float* __restrict__ base, const unsigned (&row)[kRB], int stride, int col0, v4f (&dst)[kRB][NB]) {
+#pragma unroll
+  for (int rb = 0; rb < kRB; ++rb) load_row<NB>(base, row[rb], stride, col0, dst[rb]);
+}
+template <int NB>
+__device__ __forceinline__ void store_rows(float* __restrict__ base, const unsigned (&row)[kRB], int stride, const v4f (&src)[kRB][NB]) {
+#pragma unroll
+  for (int rb = 0; rb < kRB; ++rb) store_row<NB>(base, row[rb], stride, src[rb]);
 }
 
 }  // namespace es
