@@ -11,4 +11,11 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${TAG}_pmc_write
 cd $R
 # HBM bytes per launch per family -> gpurun_out/${TAG}_traffic.json (copy to profiles/traffic_pmc.json: bench.py reads it by workload key)
 python tools/pmc_traffic.py clr:frozen:knn1 gpurun_out/${TAG}_pmc_fetch gpurun_out/${TAG}_pmc_write gpurun_out/${TAG}_traffic.json gpurun_out/${TAG}_pmc_traffic.txt > /dev/null
+# the same two counter passes for the inference workload (BASELINE.json configs[4]; bench.py --mode infer, eager) -> key clr:infer:knn1
+cd /tmp
+IARGS="--mode infer --steps 1 --warmup 4 --no-cpu-baseline --no-graph"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${TAG}_pmc_fetch_infer -o f -- python3 $R/bench.py $IARGS > /dev/null 2> $R/gpurun_out/${TAG}_pmc_fetch_infer.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${TAG}_pmc_write_infer -o w -- python3 $R/bench.py $IARGS > /dev/null 2> $R/gpurun_out/${TAG}_pmc_write_infer.err
+cd $R
+python tools/pmc_traffic.py clr:infer:knn1 gpurun_out/${TAG}_pmc_fetch_infer gpurun_out/${TAG}_pmc_write_infer gpurun_out/${TAG}_traffic.json gpurun_out/${TAG}_pmc_traffic_infer.txt > /dev/null
 ls gpurun_out/${TAG}_prof gpurun_out/${TAG}_pmc_fetch gpurun_out/${TAG}_pmc_write | head -20
