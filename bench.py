@@ -188,6 +188,7 @@ class Workload:
             self.work = ClrWork
             self.model = GNN(enc_mod.ResNetAE(), enc_mod.PointNetClassifier(k=7), enc_mod.RadarNetClassifier(k=7)).to(dev)
             self.model.mask_stream = torch.cuda.Stream(dev)     # inputs are resident: the masks need not queue behind the previous step
+            # (a high-priority stream for the masks was measured: 4.75 -> 7.9 ms per step -- stream priorities slow the whole replay here)
             self.logits = False
         self.model.run_dead_knn = not args.no_dead_knn
         self.model.single_stream = True
@@ -281,6 +282,7 @@ class Workload:
     def pre(self, i):
         if self.rows_static is None:
             return
+        # (measured in round 4: skipping this stage altogether does not change the step -- 4.72 ms either way -- it runs under the previous replay)
         k = (i + (1 if self.ahead is not None else 0)) % len(self.pool)   # the batch whose encoders run in this step
         li, ri = self.model.modality_rows(self.pool[k])           # masks + compaction, every step
         sl, sr = self.rows_static[k]
