@@ -141,6 +141,175 @@ struct Ws {
 };
 constexpr int kTableCap = 320, kTaskCap = 32768;
 
+// ---- weight-gradient job builder shared by the model's backward and the standalone layer's ------------------------------------
+// The cooperative bf16x6 kernel (b3d_wgemm.hpp) takes every block it has a shape for; the per-wavefront streaming kernel
+// (b3d_wstream2.hpp) keeps the rest.  Both share the device tables, split in halves.
+struct Col { const float* p; const int* idx; long vstride; int stride; int col0; int width; };   // activation columns
+struct WgBuilder {
+  const int* iota = nullptr;
+  WsLauncher wl, wlc;
+  std::vector<WsJob> coop;                       // added to wlc longest task first (launch)
+  void begin(WsJob* table, int table_cap, int* task_job, int task_cap, const int* iota_, hipStream_t stream) {
+    iota = iota_;
+    const int jobs_c = table_cap / 2, tasks_c = task_cap / 2;
+    wl.begin(table, table_cap - jobs_c, task_job, task_cap - tasks_c, stream);
+    wlc.begin(table + (table_cap - jobs_c), jobs_c, task_job + (task_cap - tasks_c), tasks_c, stream);
+    coop.clear();
+    coop.reserve(128);
+  }
+  // Cooperative decomposition: column groups of <= 256 per activation segment, row groups chosen per column group
+  // from the compiled shapes; false (nothing added) if some pair has none.
+  static int col_groups(int width, int* out) {
+    switch (width) {
+      case 512: out[0] = 256; out[1] = 256; return 2;
+      case 384: out[0] = 256; out[1] = 128; return 2;
+      case 288: out[0] = 192; out[1] = 96; return 2;
+      case 256: case 192: case 128: case 96: case 64: out[0] = width; return 1;
+      default: return 0;
+    }
+  }
+  static int row_groups(int n, int kg, int* out) {
+    int k = 0;
+    if (kg <= 96) {
+      while (n >= 256) { out[k++] = 256; n -= 256; }
+      while (n >= 192) { out[k++] = 192; n -= 192; }
+      if (n == 128 && kg == 96) { out[k++] = 128; n = 0; }
+    } else if (kg == 128) {
+      if (n % 192 == 0) while (n > 0) { out[k++] = 192; n -= 192; }
+      while (n >= 128) { out[k++] = 128; n -= 128; }
+      if (n == 96 || n == 64) { out[k++] = n; n = 0; }
+    } else {
+      while (n >= 128) { out[k++] = 128; n -= 128; }
+    }
+    return n == 0 ? k : -1;
+  }
+  bool add_block_coop(LinSlab& ls, long rows, int nvar, int rpt, const float* gp, const int* gidx, long gvs, int gstride,
+                      int gcol0, const Col* cols, int ncols, bool with_bias) {
+    WsJob jobs[48];
+    int nj = 0;
+    int wcol = 0;
+    for (int ci = 0; ci < ncols; ++ci) {
+      if (cols[ci].idx) return false;                      // gathered activations: streaming kernel
+      if ((uintptr_t)cols[ci].p % 16 != 0 || cols[ci].stride % 4 != 0 || cols[ci].col0 % 4 != 0 || cols[ci].vstride % 4 != 0) return false;
+      int cg[4];
+      int ncg = col_groups(cols[ci].width, cg);
+      if (ncg == 0) return false;
+      int c0 = 0;
+      for (int k = 0; k < ncg; ++k) {
+        int kgs[4] = {cg[k], 0, 0, 0}, nk = 1;
+        int rg[8];
+        int nr = row_groups(ls.N, cg[k], rg);
+        if (nr < 0 && cg[k] > 128) {                       // 192 x 256 and the like: narrower column groups
+          nk = 0;
+          for (int left = cg[k]; left > 0;) { const int t = left >= 128 ? 128 : left; kgs[nk++] = t; left -= t; }
+        }
+        for (int kk = 0; kk < nk; ++kk) {
+          nr = row_groups(ls.N, kgs[kk], rg);
+          if (nr < 0) return false;
+          int g0 = 0;
+          for (int r = 0; r < nr; ++r) {
+            const int shape = wgm_shape(rg[r], kgs[kk]);
+            if (shape < 0 || nj == 48) return false;
+            WsJob jb;
+            memset(&jb, 0, sizeof(jb));
+            jb.g.ptr = gp; jb.g.idx = gidx ? gidx : iota; jb.g.vstride = gvs; jb.g.stride = gstride; jb.g.col0 = gcol0 + g0;
+            jb.act[0].ptr = cols[ci].p; jb.act[0].idx = iota; jb.act[0].vstride = cols[ci].vstride;
+            jb.act[0].stride = cols[ci].stride; jb.act[0].col0 = cols[ci].col0 + c0;
+            jb.act[1] = jb.act[0]; jb.act[2] = jb.act[0];
+            jb.wcol[0] = wcol + c0; jb.wrow = g0;
+            jb.write_bias = (with_bias && ci == 0 && c0 == 0) ? 1 : 0;     // the first column group of every row group
+            jb.shape = shape;
+            jb.rows = (int)rows; jb.nvar = nvar; jb.rows_per_task = rpt;
+            jb.NP = ls.NP; jb.KP = ls.KP; jb.slab = ls.slab;
+            if (gidx && shape != WGM_128_192) return false;             // the only compiled gathered shape
+            jobs[nj++] = jb;
+            g0 += rg[r];
+          }
+          c0 += kgs[kk];
+        }
+      }
+      wcol += cols[ci].width;
+    }
+    for (int j = 0; j < nj; ++j) coop.push_back(jobs[j]);
+    return true;
+  }
+  void add_block(LinSlab& ls, long rows, int nvar, int rpt, const float* gp, const int* gidx, long gvs, int gstride, int gcol0,
+                 const Col* cols, int ncols, bool with_bias) {
+    if (nvar <= 0) return;
+    ls.used = true;
+    if (((uintptr_t)gp % 16 == 0) && gstride % 4 == 0 && gcol0 % 4 == 0 &&
+        add_block_coop(ls, rows, nvar, rpt, gp, gidx, gvs, gstride, gcol0, cols, ncols, with_bias))
+      return;
+    bool first_job_of_group = true;
+    for (int g0 = 0; g0 < ls.N; g0 += 64) {
+      const int gw = (ls.N - g0 >= 64) ? 64 : ls.N - g0;       // 64, or the 32-row tail of a 96-row matrix
+      int wcol = 0;
+      first_job_of_group = with_bias;
+      for (int ci = 0; ci < ncols; ++ci) {
+        for (int c0 = 0; c0 < cols[ci].width;) {
+          int cw = cols[ci].width - c0;           // column groups of 96 or 64: 128 -> 64+64, 256 -> 96+96+64
+          cw = (cw == 128 || cw < 96) ? 64 : 96;
+          WsJob jb;
+          memset(&jb, 0, sizeof(jb));
+          jb.g.ptr = gp; jb.g.idx = gidx ? gidx : iota; jb.g.vstride = gvs; jb.g.stride = gstride; jb.g.col0 = gcol0 + g0;
+          jb.act[0].ptr = cols[ci].p; jb.act[0].idx = cols[ci].idx ? cols[ci].idx : iota; jb.act[0].vstride = cols[ci].vstride;
+          jb.act[0].stride = cols[ci].stride; jb.act[0].col0 = cols[ci].col0 + c0;
+          jb.act[1] = jb.act[0]; jb.act[2] = jb.act[0];
+          jb.wcol[0] = wcol + c0; jb.wcol[1] = 0; jb.wcol[2] = 0; jb.wrow = g0;
+          jb.write_bias = first_job_of_group ? 1 : 0;
+          first_job_of_group = false;
+          jb.shape = (gw == 64) ? (cw == 96 ? WS_64_96 : WS_64_64) : WS_32_64;   // 32-row tail only with 64-col groups
+          jb.rows = (int)rows; jb.nvar = nvar; jb.rows_per_task = rpt;
+          jb.NP = ls.NP; jb.KP = ls.KP; jb.slab = ls.slab;
+          wl.add(jb);
+          c0 += cw;
+        }
+        wcol += cols[ci].width;
+      }
+    }
+  }
+  // edge_update.0's per-edge columns [e | att]: one job over both sources (GdH1, the bulk of the bytes, is read once)
+  void add_eu0_edge_columns(LinSlab& ls, long rows, int nvar, int rpt, const float* gdh1, long gvs, int gstride, const float* e, long evs,
+                            int estride, const float* att) {
+    ls.used = true;
+    WsJob jb;
+    memset(&jb, 0, sizeof(jb));
+    jb.g.ptr = gdh1; jb.g.idx = iota; jb.g.vstride = gvs; jb.g.stride = gstride; jb.g.col0 = 0;
+    jb.act[0].ptr = e; jb.act[0].idx = iota; jb.act[0].vstride = evs; jb.act[0].stride = estride; jb.act[0].col0 = 0;
+    jb.act[1].ptr = att; jb.act[1].idx = iota; jb.act[1].vstride = 0; jb.act[1].stride = 64; jb.act[1].col0 = 0;
+    jb.act[2] = jb.act[0];
+    jb.wcol[0] = 0; jb.wcol[1] = 64; jb.wrow = 0; jb.write_bias = 1; jb.shape = WGM_256_128;
+    jb.rows = (int)rows; jb.nvar = nvar; jb.rows_per_task = rpt; jb.NP = ls.NP; jb.KP = ls.KP; jb.slab = ls.slab;
+    coop.push_back(jb);
+  }
+  int launch(const float* zrow, hipStream_t stream) {
+    // every streaming job has one un-gathered activation segment: LDS-DMA ring form
+    B3D_REQUIRE(wl.launch2(wstream2_kernel, kWs2LdsBytes, zrow, iota, B3D_K_WGRAD_EDGE) == 0, "wstream2: LDS attribute");
+    B3D_REQUIRE(wl.status == 0, "streaming weight gradient: job table overflow (%d jobs, %d tasks)", wl.njobs, wl.total_tasks);
+    B3D_TRY(launch_check("wstream_kernel"));
+    // One workgroup per task, dispatched in task order as CUs free up: longest tasks first, or the 60 us tasks of
+    // att_edge_encoder (last in plan order) start when the rest of the chip has run dry.  Cost of a task ~ its 32-row
+    // steps times the bytes of a step.
+    auto cost = [](const WsJob& j) {
+      static const int w[WGM_SHAPES] = {384, 320, 256, 192, 320, 352, 256, 288, 224, 320, 224, 384};
+      const long rows = j.rows < j.rows_per_task ? j.rows : j.rows_per_task;
+      return ((rows + kWgmRows - 1) / kWgmRows) * (long)j.nvar * w[j.shape];
+    };
+    std::stable_sort(coop.begin(), coop.end(), [&](const WsJob& a, const WsJob& b) { return cost(a) > cost(b); });
+    for (const WsJob& j : coop) wlc.add(j);
+    wlc.flush();
+    B3D_REQUIRE(wlc.status == 0, "cooperative weight gradient: job table overflow (%d jobs, %d tasks)", wlc.njobs, wlc.total_tasks);
+    if (wlc.total_tasks > 0) {
+      B3D_TRY(set_lds(wgemm_kernel, kWgmLdsBytes));
+      ProfScope ps(B3D_K_WGRAD_EDGE, stream);
+      hipLaunchKernelGGL(wgemm_kernel, dim3((unsigned)(wlc.total_tasks < 2048 ? wlc.total_tasks : 2048)), dim3(kWgmThreads), kWgmLdsBytes,
+                         stream, (const WsJob*)wlc.table, (const int*)wlc.task_job, wlc.total_tasks, iota);
+      B3D_TRY(launch_check("wgemm_kernel"));
+    }
+    return B3D_OK;
+  }
+};
+
 constexpr int kStreamRowsPerTaskFc = 128;     // modality heads: a few thousand rows
 static bool is_fc(int lin) { return lin >= FL0 && lin <= FR2; }
 static bool is_streamed(int lin) { return lin >= AT0 || is_fc(lin); }   // att_edge_encoder, message passing, fc heads
@@ -879,154 +1048,25 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
 
   // ---- streamed weight gradients: message-passing stacks (all layers) + att_edge_encoder -------------
   {
-    // The cooperative bf16x6 kernel (b3d_wgemm.hpp) takes every block it has a shape for; the per-wavefront streaming kernel
-    // (b3d_wstream2.hpp) keeps the rest.  Both share the device tables, split in halves.
-    WsLauncher wl, wlc;
-    std::vector<WsJob> coop_jobs;                // added to wlc longest task first (below)
-    coop_jobs.reserve(128);
-    const int jobs_c = kTableCap / 2, tasks_c = kTaskCap / 2;
-    wl.begin(w.ws_table, kTableCap - jobs_c, w.ws_task_job, kTaskCap - tasks_c, stream);
-    wlc.begin(w.ws_table + (kTableCap - jobs_c), jobs_c, w.ws_task_job + (kTaskCap - tasks_c), tasks_c, stream);
     hipLaunchKernelGGL(iota_kernel, dim3(((E > N ? E : N) + 255) / 256), dim3(256), 0, stream, w.iota, E > N ? E : N);
     B3D_TRY(launch_check("iota_kernel"));
     B3D_HIP_CHECK(hipMemsetAsync(w.zrow, 0, 256 * sizeof(float), stream));
-    const int* iota = w.iota;
-    struct Col { const float* p; const int* idx; long vstride; int stride; int col0; int width; };   // activation columns
-    // Every (64-row group of G) x (<= 96-column group of an activation segment) pair is one job.
-    // Cooperative decomposition: column groups of <= 256 per activation segment, row groups chosen per column group
-    // from the compiled shapes; false (nothing added) if some pair has none.
-    auto col_groups = [](int width, int* out) -> int {
-      switch (width) {
-        case 512: out[0] = 256; out[1] = 256; return 2;
-        case 384: out[0] = 256; out[1] = 128; return 2;
-        case 288: out[0] = 192; out[1] = 96; return 2;
-        case 256: case 192: case 128: case 96: case 64: out[0] = width; return 1;
-        default: return 0;
-      }
-    };
-    auto row_groups = [](int n, int kg, int* out) -> int {
-      int k = 0;
-      if (kg <= 96) {
-        while (n >= 256) { out[k++] = 256; n -= 256; }
-        while (n >= 192) { out[k++] = 192; n -= 192; }
-        if (n == 128 && kg == 96) { out[k++] = 128; n = 0; }
-      } else if (kg == 128) {
-        if (n % 192 == 0) while (n > 0) { out[k++] = 192; n -= 192; }
-        while (n >= 128) { out[k++] = 128; n -= 128; }
-        if (n == 96 || n == 64) { out[k++] = n; n = 0; }
-      } else {
-        while (n >= 128) { out[k++] = 128; n -= 128; }
-      }
-      return n == 0 ? k : -1;
-    };
-    auto add_block_coop = [&](LinSlab& ls, long rows, int nvar, int rpt, const float* gp, const int* gidx, long gvs, int gstride,
-                              int gcol0, const Col* cols, int ncols, bool with_bias) -> bool {
-      WsJob jobs[48];
-      int nj = 0;
-      int wcol = 0;
-      for (int ci = 0; ci < ncols; ++ci) {
-        if (cols[ci].idx) return false;                      // gathered activations: streaming kernel
-        if ((uintptr_t)cols[ci].p % 16 != 0 || cols[ci].stride % 4 != 0 || cols[ci].col0 % 4 != 0 || cols[ci].vstride % 4 != 0) return false;
-        int cg[4];
-        int ncg = col_groups(cols[ci].width, cg);
-        if (ncg == 0) return false;
-        int c0 = 0;
-        for (int k = 0; k < ncg; ++k) {
-          int kgs[4] = {cg[k], 0, 0, 0}, nk = 1;
-          int rg[8];
-          int nr = row_groups(ls.N, cg[k], rg);
-          if (nr < 0 && cg[k] > 128) {                       // 192 x 256 and the like: narrower column groups
-            nk = 0;
-            for (int left = cg[k]; left > 0;) { const int t = left >= 128 ? 128 : left; kgs[nk++] = t; left -= t; }
-          }
-          for (int kk = 0; kk < nk; ++kk) {
-            nr = row_groups(ls.N, kgs[kk], rg);
-            if (nr < 0) return false;
-            int g0 = 0;
-            for (int r = 0; r < nr; ++r) {
-              const int shape = wgm_shape(rg[r], kgs[kk]);
-              if (shape < 0 || nj == 48) return false;
-              WsJob jb;
-              memset(&jb, 0, sizeof(jb));
-              jb.g.ptr = gp; jb.g.idx = gidx ? gidx : iota; jb.g.vstride = gvs; jb.g.stride = gstride; jb.g.col0 = gcol0 + g0;
-              jb.act[0].ptr = cols[ci].p; jb.act[0].idx = iota; jb.act[0].vstride = cols[ci].vstride;
-              jb.act[0].stride = cols[ci].stride; jb.act[0].col0 = cols[ci].col0 + c0;
-              jb.act[1] = jb.act[0]; jb.act[2] = jb.act[0];
-              jb.wcol[0] = wcol + c0; jb.wrow = g0;
-              jb.write_bias = (with_bias && ci == 0 && c0 == 0) ? 1 : 0;     // the first column group of every row group
-              jb.shape = shape;
-              jb.rows = (int)rows; jb.nvar = nvar; jb.rows_per_task = rpt;
-              jb.NP = ls.NP; jb.KP = ls.KP; jb.slab = ls.slab;
-              if (gidx && shape != WGM_128_192) return false;             // the only compiled gathered shape
-              jobs[nj++] = jb;
-              g0 += rg[r];
-            }
-            c0 += kgs[kk];
-          }
-        }
-        wcol += cols[ci].width;
-      }
-      for (int j = 0; j < nj; ++j) coop_jobs.push_back(jobs[j]);
-      return true;
-    };
+    WgBuilder wb;
+    wb.begin(w.ws_table, kTableCap, w.ws_task_job, kTaskCap, w.iota, stream);
     auto add_block = [&](LinSlab& ls, long rows, int nvar, int rpt, const float* gp, const int* gidx, long gvs, int gstride, int gcol0,
                          const Col* cols, int ncols, bool with_bias) {
-      if (nvar <= 0) return;
-      ls.used = true;
-      if (((uintptr_t)gp % 16 == 0) && gstride % 4 == 0 && gcol0 % 4 == 0 &&
-          add_block_coop(ls, rows, nvar, rpt, gp, gidx, gvs, gstride, gcol0, cols, ncols, with_bias))
-        return;
-      bool first_job_of_group = true;
-      for (int g0 = 0; g0 < ls.N; g0 += 64) {
-        const int gw = (ls.N - g0 >= 64) ? 64 : ls.N - g0;       // 64, or the 32-row tail of a 96-row matrix
-        int wcol = 0;
-        first_job_of_group = with_bias;
-        for (int ci = 0; ci < ncols; ++ci) {
-          for (int c0 = 0; c0 < cols[ci].width;) {
-            int cw = cols[ci].width - c0;           // column groups of 96 or 64: 128 -> 64+64, 256 -> 96+96+64
-            cw = (cw == 128 || cw < 96) ? 64 : 96;
-            WsJob jb;
-            memset(&jb, 0, sizeof(jb));
-            jb.g.ptr = gp; jb.g.idx = gidx ? gidx : iota; jb.g.vstride = gvs; jb.g.stride = gstride; jb.g.col0 = gcol0 + g0;
-            jb.act[0].ptr = cols[ci].p; jb.act[0].idx = cols[ci].idx ? cols[ci].idx : iota; jb.act[0].vstride = cols[ci].vstride;
-            jb.act[0].stride = cols[ci].stride; jb.act[0].col0 = cols[ci].col0 + c0;
-            jb.act[1] = jb.act[0]; jb.act[2] = jb.act[0];
-            jb.wcol[0] = wcol + c0; jb.wcol[1] = 0; jb.wcol[2] = 0; jb.wrow = g0;
-            jb.write_bias = first_job_of_group ? 1 : 0;
-            first_job_of_group = false;
-            jb.shape = (gw == 64) ? (cw == 96 ? WS_64_96 : WS_64_64) : WS_32_64;   // 32-row tail only with 64-col groups
-            jb.rows = (int)rows; jb.nvar = nvar; jb.rows_per_task = rpt;
-            jb.NP = ls.NP; jb.KP = ls.KP; jb.slab = ls.slab;
-            wl.add(jb);
-            c0 += cw;
-          }
-          wcol += cols[ci].width;
-        }
-      }
+      wb.add_block(ls, rows, nvar, rpt, gp, gidx, gvs, gstride, gcol0, cols, ncols, with_bias);
     };
     auto add_matrix = [&](int lin, long rows, int nvar, int rpt, const float* gp, const int* gidx, long gvs, int gstride, int gcol0,
                           const Col* cols, int ncols) {
-      add_block(w.lin[lin], rows, nvar, rpt, gp, gidx, gvs, gstride, gcol0, cols, ncols, true);
+      wb.add_block(w.lin[lin], rows, nvar, rpt, gp, gidx, gvs, gstride, gcol0, cols, ncols, true);
     };
     const int rp = kStreamRowsPerTask, rpa = kStreamRowsPerTaskAtt;
     // First layers: per-edge columns contract over edges, node columns over NODES (G = column blocks of dT).
     const int rn = kStreamNodeRowsPerTask;
     const long tLs = (long)N * HC::GW;
     {  // edge_update.0 [256, 320]: x[dst] 0:96 | x[src] 96:192 | e 192:256 | att 256:320
-      Col ce[2] = {{w.e[0], nullptr, (long)eLe, D::DE, 0, 64}, {w.att, nullptr, 0, 64, 0, 64}};
-      // one job over both sources: GdH1 (256 wide, the bulk of the bytes) is read once
-      LinSlab& ls = w.vlin[VL_EU0E];
-      ls.used = true;
-      WsJob jb;
-      memset(&jb, 0, sizeof(jb));
-      jb.g.ptr = w.GdH1; jb.g.idx = iota; jb.g.vstride = eL1; jb.g.stride = D::EH1; jb.g.col0 = 0;
-      for (int k = 0; k < 2; ++k) {
-        jb.act[k].ptr = ce[k].p; jb.act[k].idx = iota; jb.act[k].vstride = ce[k].vstride; jb.act[k].stride = ce[k].stride; jb.act[k].col0 = 0;
-      }
-      jb.act[2] = jb.act[0];
-      jb.wcol[0] = 0; jb.wcol[1] = 64; jb.wrow = 0; jb.write_bias = 1; jb.shape = WGM_256_128;
-      jb.rows = E; jb.nvar = depth; jb.rows_per_task = rp; jb.NP = ls.NP; jb.KP = ls.KP; jb.slab = ls.slab;
-      coop_jobs.push_back(jb);
+      wb.add_eu0_edge_columns(w.vlin[VL_EU0E], E, depth, rp, w.GdH1, eL1, D::EH1, w.e[0], (long)eLe, D::DE, w.att);
       Col cx[1] = {{w.x[0], nullptr, (long)nLx, D::DX, 0, 96}};
       add_block(w.vlin[VL_EU0XI], N, depth, rn, w.dT, nullptr, tLs, HC::GW, HC::OA, cx, 1, false);
       add_block(w.vlin[VL_EU0XJ], N, depth, rn, w.dT, nullptr, tLs, HC::GW, HC::OB, cx, 1, false);
@@ -1090,31 +1130,7 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
       Col c4[1] = {{w.A[3], nullptr, 0, 128, 0, 128}};
       add_matrix(AT4, E, 1, rpa, w.da_acc, nullptr, 0, 64, 0, c4, 1);
     }
-    // every remaining job has one un-gathered activation segment: LDS-DMA ring form
-    B3D_REQUIRE(wl.launch2(wstream2_kernel, kWs2LdsBytes, w.zrow, w.iota, B3D_K_WGRAD_EDGE) == 0, "wstream2: LDS attribute");
-    B3D_REQUIRE(wl.status == 0, "streaming weight gradient: job table overflow (%d jobs, %d tasks)", wl.njobs, wl.total_tasks);
-    B3D_TRY(launch_check("wstream_kernel"));
-    {
-      // One workgroup per task, dispatched in task order as CUs free up: longest tasks first, or the 60 us tasks of
-      // att_edge_encoder (last in plan order) start when the rest of the chip has run dry.  Cost of a task ~ its 32-row
-      // steps times the bytes of a step.
-      auto cost = [](const WsJob& j) {
-        static const int w[WGM_SHAPES] = {384, 320, 256, 192, 320, 352, 256, 288, 224, 320, 224, 384};
-        const long rows = j.rows < j.rows_per_task ? j.rows : j.rows_per_task;
-        return ((rows + kWgmRows - 1) / kWgmRows) * (long)j.nvar * w[j.shape];
-      };
-      std::stable_sort(coop_jobs.begin(), coop_jobs.end(), [&](const WsJob& a, const WsJob& b) { return cost(a) > cost(b); });
-      for (const WsJob& j : coop_jobs) wlc.add(j);
-    }
-    wlc.flush();
-    B3D_REQUIRE(wlc.status == 0, "cooperative weight gradient: job table overflow (%d jobs, %d tasks)", wlc.njobs, wlc.total_tasks);
-    if (wlc.total_tasks > 0) {
-      B3D_TRY(set_lds(wgemm_kernel, kWgmLdsBytes));
-      ProfScope ps(B3D_K_WGRAD_EDGE, stream);
-      hipLaunchKernelGGL(wgemm_kernel, dim3((unsigned)(wlc.total_tasks < 2048 ? wlc.total_tasks : 2048)), dim3(kWgmThreads), kWgmLdsBytes,
-                         stream, (const WsJob*)wlc.table, (const int*)wlc.task_job, wlc.total_tasks, w.iota);
-      B3D_TRY(launch_check("wgemm_kernel"));
-    }
+    B3D_TRY(wb.launch(w.zrow, stream));
   }
 
   // ---- slabs -> parameter gradients -----------------------------------------------------------------------
@@ -1175,36 +1191,47 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
 }
 
 // ---- standalone CausalMessagePassing layer, camera+LiDAR+radar widths (clr_att_gnn.py:227-356) --------------
-// forward(x, edge_index, edge_attr, initial_x, att_edge_attr) -> (x', e') and its backward, as an operator of its own (the
-// model entry points above run the hoisted plan over all layers; a single layer with caller-provided x / x0 runs the
-// unsplit kernels: there is no previous node kernel to produce the per-node table).
+// forward(x, edge_index, edge_attr, initial_x, att_edge_attr) -> (x', e') and its backward, as an operator of its own.  Since round 4
+// it runs the model's plan: the node columns of the three first layers evaluated per NODE (a per-node table T from the caller's
+// x / initial_x: node_proj0_split_kernel), the fragment-streamed edge kernels (b3d_edge2.hpp), per-node gradient sums
+// (node_listsum + node_bwd_g) and the cooperative weight gradient -- the round-1 unsplit kernels (75 / 138 spilled registers at
+// these widths) are gone.  Caller tensors have exactly E rows; the edge kernels store whole tiles, so their outputs go through
+// padded workspace buffers and the E valid rows are copied out.
 namespace b3d {
 namespace clr {
-constexpr int kLayerTableCap = 96, kLayerTaskCap = 16384;
+constexpr int kLayerTableCap = 160, kLayerTaskCap = 16384;
 enum { LL_EU0, LL_EU1, LL_EU2, LL_PA0, LL_PA1, LL_FU0, LL_FU1, LL_CF0, LL_CF1, LL_CF2, LL_COUNT };
 static const int kLayerLin[LL_COUNT] = {EU0, EU1, EU2, PA0, PA1, FU0, FU1, CF0, CF1, CF2};
+constexpr int kLayerVl = 9;                        // the first nine column blocks of kVl: edge_update.0, create_*_msgs.0
 struct ClrLayerWs {
-  float *wp_efwd, *wp_nfwd, *wp_ebwd, *wp_nbwd, *fut, *past;
+  float *wp_proj0, *wp_efwd2, *wp_nfwd, *wp_ebwd2, *wp_gproj, *wp_nbwd;
+  float *T, *T0, *e_out, *fut, *past;
   float *sH1, *sH2, *sF1, *sP1, *M, *nH1, *nH2;
-  float *dM, *GdH1, *GdH2, *Gde, *GdF1, *GdP1, *GnH2, *GnH1, *gdst, *gsrc, *de_tmp, *da_tmp, *zero_e, *zero_n;
+  float *dM, *GdH1, *GdH2, *Gde, *GdF1, *GdP1, *GnH2, *GnH1, *dT, *gx, *de_in, *da, *zero_e, *zero_n;
   float* zrow;
   int* iota;
   WsJob* ws_table;
   int* ws_task_job;
   LinSlab lin[LL_COUNT];
+  LinSlab vlin[kLayerVl];
   size_t bytes;
   bool ok;
 };
 static void carve_layer(ClrLayerWs& w, void* ws, size_t ws_bytes, int N, int E, bool tr) {
   Carver c(ws, ws_bytes);
   memset(&w, 0, sizeof(w));
-  const size_t e_ = (size_t)(E > 0 ? E : 1), n_ = (size_t)(N > 0 ? N : 1);
-  w.wp_efwd = c.take<float>(D::EdgeFwdSeq::TOTAL_FLOATS);
+  const size_t e_ = edge_rows(E), n_ = (size_t)(N > 0 ? N : 1);
+  w.wp_proj0 = c.take<float>(Proj0Seq2<DB>::TOTAL_FLOATS);
+  w.wp_efwd2 = c.take<float>(ES::Fwd::TOTAL_FLOATS);
   w.wp_nfwd = c.take<float>(D::NodeFwdSeq::TOTAL_FLOATS);
+  w.T = c.take<float>(n_ * HC::TW);
+  w.T0 = c.take<float>(n_ * 2 * DB::MH);
+  w.e_out = c.take<float>(e_ * D::DE);
   w.fut = c.take<float>(e_ * D::DM);
   w.past = c.take<float>(e_ * D::DM);
   if (tr) {
-    w.wp_ebwd = c.take<float>(D::EdgeBwdSeq::TOTAL_FLOATS);
+    w.wp_ebwd2 = c.take<float>(ES::Bwd::TOTAL_FLOATS);
+    w.wp_gproj = c.take<float>(HC::GradProjSeq::TOTAL_FLOATS);
     w.wp_nbwd = c.take<float>(D::NodeBwdSeq::TOTAL_FLOATS);
     w.sH1 = c.take<float>(e_ * D::EH1); w.sH2 = c.take<float>(e_ * D::EH2); w.sF1 = c.take<float>(e_ * D::MH); w.sP1 = c.take<float>(e_ * D::MH);
     w.M = c.take<float>(n_ * D::NIN); w.nH1 = c.take<float>(n_ * D::NH1); w.nH2 = c.take<float>(n_ * D::NH2);
@@ -1212,8 +1239,9 @@ static void carve_layer(ClrLayerWs& w, void* ws, size_t ws_bytes, int N, int E, 
     w.GdH1 = c.take<float>(e_ * D::EH1); w.GdH2 = c.take<float>(e_ * D::EH2); w.Gde = c.take<float>(e_ * D::DE);
     w.GdF1 = c.take<float>(e_ * D::MH); w.GdP1 = c.take<float>(e_ * D::MH);
     w.GnH2 = c.take<float>(n_ * D::NH2); w.GnH1 = c.take<float>(n_ * D::NH1);
-    w.gdst = c.take<float>(e_ * 2 * D::DX); w.gsrc = c.take<float>(e_ * 2 * D::DX);
-    w.de_tmp = c.take<float>(e_ * D::DE); w.da_tmp = c.take<float>(e_ * D::DA); w.zero_e = c.take<float>(e_ * D::DE); w.zero_n = c.take<float>(n_ * D::DX);
+    w.dT = c.take<float>(n_ * HC::GW); w.gx = c.take<float>(n_ * 2 * D::DX);
+    w.de_in = c.take<float>(e_ * D::DE); w.da = c.take<float>(e_ * D::DA);
+    w.zero_e = c.take<float>(e_ * D::DE); w.zero_n = c.take<float>(n_ * D::DX);
     w.zrow = c.take<float>(256);
     w.iota = c.take<int>((size_t)(E > N ? E : N) + 64);
     w.ws_table = c.take<WsJob>(kLayerTableCap);
@@ -1228,59 +1256,74 @@ static void carve_layer(ClrLayerWs& w, void* ws, size_t ws_bytes, int N, int E, 
       ls.slab = c.take<float>(wg_slab_floats(ls.nchunks, ls.NP, ls.KP));
       ls.used = false;
     }
+    for (int v = 0; v < kLayerVl; ++v) {
+      LinSlab& ls = w.vlin[v];
+      ls.N = kDims[kVl[v].lin].N; ls.K = kVl[v].width; ls.NP = pad16(ls.N); ls.KP = pad16(ls.K);
+      const long rows = kVl[v].on_edges ? E : N;
+      const int rpt = kVl[v].on_edges ? kStreamRowsPerTask : kStreamNodeRowsPerTask;
+      ls.nchunks = (int)((rows + rpt - 1) / rpt);
+      if (ls.nchunks < 1) ls.nchunks = 1;
+      ls.slab = c.take<float>(wg_slab_floats(ls.nchunks, ls.NP, ls.KP));
+      ls.used = false;
+    }
   }
   w.bytes = c.off + 256;
   w.ok = c.ok();
 }
 static int pack_layer(const b3d_mp_weights* mw, ClrLayerWs& w, bool tr, hipStream_t stream) {
   const b3d_linear* stacks[] = {mw->edge_update, mw->create_future_msgs, mw->create_past_msgs, mw->combine_future_past};
-  const int first[] = {EU0, FU0, PA0, CF0}, cnt[] = {3, 2, 2, 3};
-  PackDesc d[32];
-  int n = 0, li = 0;
+  const int cnt[] = {3, 2, 2, 3};
   for (int s = 0; s < 4; ++s)
-    for (int i = 0; i < cnt[s]; ++i) {
-      const b3d_linear& l = stacks[s][i];
-      B3D_REQUIRE(l.w && l.b, "CausalMessagePassing layer: null weight/bias pointer (stack %d layer %d)", s, i);
-      const LinDim dim = kDims[first[s] + i];
-      if (s < 3) d[n++] = pack_desc<D::EdgeFwdSeq>(li++, w.wp_efwd, l.w, l.b, dim.N, dim.K, false);
-      else d[n++] = pack_desc<D::NodeFwdSeq>(i, w.wp_nfwd, l.w, l.b, dim.N, dim.K, false);
-    }
+    for (int i = 0; i < cnt[s]; ++i)
+      B3D_REQUIRE(stacks[s][i].w && stacks[s][i].b, "CausalMessagePassing layer: null weight/bias pointer (stack %d layer %d)", s, i);
+  constexpr int DX = DB::DX, DE = DB::DE, EIN = DB::EIN, MIN = DB::MIN, H1 = DB::EH1, MH = DB::MH;
+  const b3d_linear &eu0 = mw->edge_update[0], &fu0 = mw->create_future_msgs[0], &pa0 = mw->create_past_msgs[0];
+  PackDesc d[48];
+  int n = 0;
+  // per-node table T = (eu0[:, x_i] x + b | eu0[:, x_j] x | fu0[:, x] x + fu0[:, x0] x0 + b | pa0[:, x] x + pa0[:, x0] x0 + b | 0)
+  d[n++] = pack_slice<Proj0Seq2<DB>>(0, w.wp_proj0, fu0.w + DX + DE, nullptr, MH, DX, MIN, 0, MH, false);    // x0 columns
+  d[n++] = pack_slice<Proj0Seq2<DB>>(0, w.wp_proj0, pa0.w + DX + DE, nullptr, MH, DX, MIN, MH, MH, false);
+  d[n++] = pack_slice<Proj0Seq2<DB>>(1, w.wp_proj0, eu0.w, eu0.b, H1, DX, EIN, HC::OA, H1, false);
+  d[n++] = pack_slice<Proj0Seq2<DB>>(1, w.wp_proj0, eu0.w + DX, nullptr, H1, DX, EIN, HC::OB, H1, false);
+  d[n++] = pack_slice<Proj0Seq2<DB>>(1, w.wp_proj0, fu0.w, fu0.b, MH, DX, MIN, HC::OF, MH, false);
+  d[n++] = pack_slice<Proj0Seq2<DB>>(1, w.wp_proj0, pa0.w, pa0.b, MH, DX, MIN, HC::OP, MH, false);
+  d[n++] = pack_slice<Proj0Seq2<DB>>(1, w.wp_proj0, nullptr, nullptr, DX, DX, DX, HC::OG, DX, false);         // (the k-NN block's columns: unused)
+  for (int i = 0; i < 3; ++i)
+    d[n++] = pack_desc<D::NodeFwdSeq>(i, w.wp_nfwd, mw->combine_future_past[i].w, mw->combine_future_past[i].b, kDims[CF0 + i].N, kDims[CF0 + i].K, false);
   if (tr) {
-    auto T = [&](auto tag, int li2, float* base, const b3d_linear& l, int lin) {
-      using S = decltype(tag);
-      d[n++] = pack_desc<S>(li2, base, l.w, nullptr, kDims[lin].K, kDims[lin].N, true);
-    };
-    using EB = D::EdgeBwdSeq;
-    T(EB{}, 0, w.wp_ebwd, mw->create_past_msgs[1], PA1); T(EB{}, 1, w.wp_ebwd, mw->create_past_msgs[0], PA0);
-    T(EB{}, 2, w.wp_ebwd, mw->create_future_msgs[1], FU1); T(EB{}, 3, w.wp_ebwd, mw->create_future_msgs[0], FU0);
-    T(EB{}, 4, w.wp_ebwd, mw->edge_update[2], EU2); T(EB{}, 5, w.wp_ebwd, mw->edge_update[1], EU1); T(EB{}, 6, w.wp_ebwd, mw->edge_update[0], EU0);
     using NB = D::NodeBwdSeq;
-    T(NB{}, 0, w.wp_nbwd, mw->combine_future_past[2], CF2); T(NB{}, 1, w.wp_nbwd, mw->combine_future_past[1], CF1);
-    T(NB{}, 2, w.wp_nbwd, mw->combine_future_past[0], CF0);
+    for (int i = 0; i < 3; ++i)
+      d[n++] = pack_desc<NB>(i, w.wp_nbwd, mw->combine_future_past[2 - i].w, nullptr, kDims[CF2 - i].K, kDims[CF2 - i].N, true);
+    using GP = HC::GradProjSeq;
+    d[n++] = pack_slice<GP>(0, w.wp_gproj, eu0.w, nullptr, DX, H1, EIN, 0, DX, true);
+    d[n++] = pack_slice<GP>(1, w.wp_gproj, eu0.w + DX, nullptr, DX, H1, EIN, 0, DX, true);
+    d[n++] = pack_slice<GP>(2, w.wp_gproj, fu0.w, nullptr, DX, MH, MIN, 0, DX, true);
+    d[n++] = pack_slice<GP>(2, w.wp_gproj, fu0.w + DX + DE, nullptr, DX, MH, MIN, DX, DX, true);
+    d[n++] = pack_slice<GP>(3, w.wp_gproj, pa0.w, nullptr, DX, MH, MIN, 0, DX, true);
+    d[n++] = pack_slice<GP>(3, w.wp_gproj, pa0.w + DX + DE, nullptr, DX, MH, MIN, DX, DX, true);
   }
-  return pack_images(d, n, stream);
-}
-// d x[n] = sum over edges with dst == n of gdst[., 0:DX] + sum over edges with src == n of gsrc[., 0:DX]; d x0 from DX:2DX
-struct NodeGradArgsC {
-  int N;
-  const int *dst_ptr, *dst_perm, *src_ptr, *src_perm;
-  const float *gdst, *gsrc;
-  float *d_x, *d_x0;
-};
-__global__ __launch_bounds__(256) void node_grad_gather_c_kernel(const NodeGradArgsC a) {
-  constexpr int XB = D::DX / 16;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long row = ((long)blockIdx.x * 4 + wave) * 16 + (lane & 15);
-  const bool valid = row < a.N;
-  v4f g[2 * XB];
-#pragma unroll
-  for (int b = 0; b < 2 * XB; ++b) g[b] = v4f{0.f, 0.f, 0.f, 0.f};
-  if (valid) {
-    segment_sum<2 * XB>(a.gdst, 2 * D::DX, 0, a.dst_perm, a.dst_ptr[row], a.dst_ptr[row + 1], g);
-    segment_sum<2 * XB>(a.gsrc, 2 * D::DX, 0, a.src_perm, a.src_ptr[row], a.src_ptr[row + 1], g);
+  B3D_TRY(pack_images(d, n, stream));
+  FragDesc f[kFragMax];
+  int m = 0;
+  using FS = ES::Fwd;
+  f[m++] = frag_desc<FS>(0, w.wp_efwd2, eu0.w + 2 * DX, nullptr, EIN, false);
+  f[m++] = frag_desc<FS>(1, w.wp_efwd2, mw->edge_update[1].w, mw->edge_update[1].b, kDims[EU1].K, false);
+  f[m++] = frag_desc<FS>(2, w.wp_efwd2, mw->edge_update[2].w, mw->edge_update[2].b, kDims[EU2].K, false);
+  f[m++] = frag_desc<FS>(3, w.wp_efwd2, fu0.w + DX, nullptr, MIN, false);
+  f[m++] = frag_desc<FS>(4, w.wp_efwd2, mw->create_future_msgs[1].w, mw->create_future_msgs[1].b, kDims[FU1].K, false);
+  f[m++] = frag_desc<FS>(5, w.wp_efwd2, pa0.w + DX, nullptr, MIN, false);
+  f[m++] = frag_desc<FS>(6, w.wp_efwd2, mw->create_past_msgs[1].w, mw->create_past_msgs[1].b, kDims[PA1].K, false);
+  if (tr) {
+    using BS = ES::Bwd;
+    f[m++] = frag_desc<BS>(0, w.wp_ebwd2, mw->create_past_msgs[1].w, nullptr, kDims[PA1].K, true);
+    f[m++] = frag_desc<BS>(1, w.wp_ebwd2, pa0.w + DX, nullptr, MIN, true);
+    f[m++] = frag_desc<BS>(2, w.wp_ebwd2, mw->create_future_msgs[1].w, nullptr, kDims[FU1].K, true);
+    f[m++] = frag_desc<BS>(3, w.wp_ebwd2, fu0.w + DX, nullptr, MIN, true);
+    f[m++] = frag_desc<BS>(4, w.wp_ebwd2, mw->edge_update[2].w, nullptr, kDims[EU2].K, true);
+    f[m++] = frag_desc<BS>(5, w.wp_ebwd2, mw->edge_update[1].w, nullptr, kDims[EU1].K, true);
+    f[m++] = frag_desc<BS>(6, w.wp_ebwd2, eu0.w + 2 * DX, nullptr, EIN, true);
   }
-  if (a.d_x) store_row<XB>(a.d_x, row, D::DX, 0, valid, g);
-  if (a.d_x0) store_row<XB>(a.d_x0, row, D::DX, 0, valid, g + XB);
+  return pack_frags(f, m, stream);
 }
 }  // namespace clr
 }  // namespace b3d
@@ -1303,18 +1346,23 @@ extern "C" int b3d_clr_layer_forward(const b3d_mp_weights* mw, const b3d_graph* 
   carve_layer(w, workspace, workspace_bytes, N, E, tr);
   if (!w.ok) return fail(B3D_ERR_WORKSPACE, "b3d_clr_layer_forward: workspace %zu < %zu bytes", workspace_bytes, w.bytes);
   B3D_TRY(pack_layer(mw, w, tr, stream));
-  EdgeFwdArgs ea;
+  NodeProj0Args pa;
+  pa.N = N; pa.x0 = x0; pa.x = x; pa.T0 = w.T0; pa.T = w.T; pa.wpack = w.wp_proj0;
+  B3D_TRY(launch_node_split<DB>(node_proj0_split_kernel<DB>, "node_proj0", pa, N, stream, B3D_K_OTHER));
+  EdgeFwdHArgs ea;
   memset(&ea, 0, sizeof(ea));
-  ea.E = E; ea.src = g->src; ea.dst = g->dst; ea.x = x; ea.x0 = x0; ea.e_in = e; ea.a_in = att;
-  ea.e_out = e_new; ea.fut = w.fut; ea.past = w.past; ea.wpack = w.wp_efwd;
-  if (tr) { ea.sH1 = w.sH1; ea.sH2 = w.sH2; ea.sF1 = w.sF1; ea.sP1 = w.sP1; }
-  B3D_TRY(launch_rows<kNWEdge>(mp_edge_fwd_kernel<D, kNWEdge>, "mp_edge_fwd", ea, E, stream, B3D_K_EDGE_FWD));
+  ea.E = E; ea.src = g->src; ea.dst = g->dst; ea.T = w.T; ea.e_in = e; ea.a_in = att;
+  ea.e_out = w.e_out; ea.fut = w.fut; ea.past = w.past;
+  ea.sH1 = w.sH1; ea.sH2 = w.sH2; ea.sF1 = w.sF1; ea.sP1 = w.sP1; ea.wpack = w.wp_efwd2;
+  if (tr) B3D_TRY(launch_es(es::edge_fwd_kernel<DB, true>, "edge_fwd", ea, E, stream, B3D_K_EDGE_FWD, ES::Fwd::LDS_BYTES));
+  else B3D_TRY(launch_es(es::edge_fwd_kernel<DB, false>, "edge_fwd", ea, E, stream, B3D_K_EDGE_FWD, ES::Fwd::LDS_BYTES));
+  B3D_HIP_CHECK(hipMemcpyAsync(e_new, w.e_out, (size_t)E * D::DE * sizeof(float), hipMemcpyDeviceToDevice, stream));
   NodeFwdArgs na;
   memset(&na, 0, sizeof(na));
   na.N = N; na.dst_ptr = g->dst_ptr; na.dst_perm = g->dst_perm; na.src_ptr = g->src_ptr; na.src_perm = g->src_perm;
   na.past = w.past; na.fut = w.fut; na.x_out = x_new; na.wpack = w.wp_nfwd;
   if (tr) { na.M = w.M; na.sH1 = w.nH1; na.sH2 = w.nH2; }
-  B3D_TRY(launch_node_split<D>(mp_node_fwd_split_kernel<D>, "mp_node_fwd", na, N, stream, B3D_K_NODE_FWD));
+  B3D_TRY((launch_node_split<D, kNodeWavesWide>(mp_node_fwd_split_kernel<D, kNodeWavesWide>, "mp_node_fwd", na, N, stream, B3D_K_NODE_FWD)));
   return B3D_OK;
 }
 
@@ -1338,91 +1386,99 @@ extern "C" int b3d_clr_layer_backward(const b3d_mp_weights* mw, const b3d_graph*
   nb.g_direct = d_x_new;
   nb.sH1 = w.nH1; nb.sH2 = w.nH2; nb.dM = w.dM; nb.GdH2 = w.GnH2; nb.GdH1 = w.GnH1; nb.wpack = w.wp_nbwd;
   B3D_TRY(launch_node_split<D>(mp_node_bwd_split_kernel<D>, "mp_node_bwd", nb, N, stream, B3D_K_NODE_BWD));
-  EdgeBwdArgs eb;
+  EdgeBwdHArgs eb;
   memset(&eb, 0, sizeof(eb));
   eb.E = E; eb.src = g->src; eb.dst = g->dst; eb.dM = w.dM;
-  eb.de_out = d_e_new; eb.de_in = d_e ? d_e : w.de_tmp;
+  eb.de_out = d_e_new; eb.de_in = w.de_in;
   eb.sH1 = w.sH1; eb.sH2 = w.sH2; eb.sF1 = w.sF1; eb.sP1 = w.sP1;
-  eb.da_acc = d_att ? d_att : w.da_tmp; eb.da_first = 1;
-  eb.gdst = w.gdst; eb.gsrc = w.gsrc;
+  eb.da_acc = w.da; eb.da_first = 1;
   eb.GdH1 = w.GdH1; eb.GdH2 = w.GdH2; eb.Gde = w.Gde; eb.GdF1 = w.GdF1; eb.GdP1 = w.GdP1;
-  eb.wpack = w.wp_ebwd;
-  B3D_TRY(launch_rows<kNWEdge>(mp_edge_bwd_kernel<D, true, kNWEdge>, "mp_edge_bwd", eb, E, stream, B3D_K_EDGE_BWD));
-  if (d_x || d_x0) {
-    NodeGradArgsC ng{N, g->dst_ptr, g->dst_perm, g->src_ptr, g->src_perm, w.gdst, w.gsrc, d_x, d_x0};
-    hipLaunchKernelGGL(node_grad_gather_c_kernel, dim3((N + 63) / 64), dim3(256), 0, stream, ng);
-    B3D_TRY(launch_check("node_grad_gather_c_kernel"));
+  eb.wpack = w.wp_ebwd2;
+  B3D_TRY(launch_es(es::edge_bwd_kernel<DB, true>, "edge_bwd", eb, E, stream, B3D_K_EDGE_BWD, ES::Bwd::LDS_BYTES));
+  if (d_e) B3D_HIP_CHECK(hipMemcpyAsync(d_e, w.de_in, (size_t)E * D::DE * sizeof(float), hipMemcpyDeviceToDevice, stream));
+  if (d_att) B3D_HIP_CHECK(hipMemcpyAsync(d_att, w.da, (size_t)E * D::DA * sizeof(float), hipMemcpyDeviceToDevice, stream));
+  {  // per-node sums of the first-layer gradients, then (dx | dx0) = (node columns)^T . dT
+    NodeGradProjArgs ga;
+    memset(&ga, 0, sizeof(ga));
+    ga.N = N; ga.dst_ptr = g->dst_ptr; ga.dst_perm = g->dst_perm; ga.src_ptr = g->src_ptr; ga.src_perm = g->src_perm;
+    ga.GdH1 = w.GdH1; ga.GdF1 = w.GdF1; ga.GdP1 = w.GdP1; ga.dT = w.dT;
+    const long tasks = (long)((N + 15) / 16) * ListSumGeom<DB>::TASKS;
+    {
+      ProfScope ps(B3D_K_NODE_BWD, stream);
+      hipLaunchKernelGGL(node_listsum_kernel<DB>, dim3((unsigned)((tasks + 3) / 4)), dim3(256), 0, stream, ga);
+    }
+    B3D_TRY(launch_check("node_listsum_kernel"));
+    NodeBwdGArgs ng;
+    memset(&ng, 0, sizeof(ng));
+    ng.N = N; ng.dT = w.dT; ng.gx = w.gx; ng.wpack = w.wp_gproj;
+    B3D_TRY(set_lds(node_bwd_g_kernel<DB, false>, NodeBwdGLds<DB>::BYTES));
+    {
+      ProfScope ps(B3D_K_NODE_BWD, stream);
+      hipLaunchKernelGGL((node_bwd_g_kernel<DB, false>), dim3((N + 15) / 16), dim3(kNodeBwdGWaves * 64), NodeBwdGLds<DB>::BYTES, stream, ng);
+    }
+    B3D_TRY(launch_check("node_bwd_g_kernel"));
+    const unsigned gb = (unsigned)(((long)N * D::DX + 255) / 256);
+    if (d_x) hipLaunchKernelGGL(copy_cols_kernel, dim3(gb), dim3(256), 0, stream, (const float*)w.gx, 2 * D::DX, d_x, D::DX, 0, N, D::DX);
+    if (d_x0) hipLaunchKernelGGL(copy_cols_kernel, dim3(gb), dim3(256), 0, stream, (const float*)w.gx + D::DX, 2 * D::DX, d_x0, D::DX, 0, N, D::DX);
+    B3D_TRY(launch_check("copy_cols_kernel"));
   }
-  // ---- weight gradients: one streaming launch over the ten Linear layers ---------------------------------------------
+  // ---- weight gradients: one cooperative launch over the ten Linear layers (the model's job plan, one layer variant) -------------
   {
-    WsLauncher wl;
-    wl.begin(w.ws_table, kLayerTableCap, w.ws_task_job, kLayerTaskCap, stream);
     hipLaunchKernelGGL(iota_kernel, dim3(((E > N ? E : N) + 255) / 256), dim3(256), 0, stream, w.iota, E > N ? E : N);
     B3D_TRY(launch_check("iota_kernel"));
     B3D_HIP_CHECK(hipMemsetAsync(w.zrow, 0, 256 * sizeof(float), stream));
-    const int* iota = w.iota;
+    WgBuilder wb;
+    wb.begin(w.ws_table, kLayerTableCap, w.ws_task_job, kLayerTaskCap, w.iota, stream);
+    const int rp = kStreamRowsPerTask, rn = kStreamNodeRowsPerTask;
     const int* src = g->src;
     const int* dst = g->dst;
-    struct Col { const float* p; const int* idx; int stride; int width; };
-    auto add = [&](int ll, long rows, const float* gp, const int* gidx, int gstride, int gcol0, const Col* cols, int ncols) {
-      LinSlab& ls = w.lin[ll];
-      ls.used = true;
-      for (int g0 = 0; g0 < ls.N; g0 += 64) {
-        const int gw = (ls.N - g0 >= 64) ? 64 : ls.N - g0;
-        int wcol = 0;
-        bool first = true;
-        for (int ci = 0; ci < ncols; ++ci) {
-          for (int c0 = 0; c0 < cols[ci].width;) {
-            int cw = cols[ci].width - c0;
-            cw = (cw == 128 || cw < 96) ? 64 : 96;
-            WsJob jb;
-            memset(&jb, 0, sizeof(jb));
-            jb.g.ptr = gp; jb.g.idx = gidx ? gidx : iota; jb.g.vstride = 0; jb.g.stride = gstride; jb.g.col0 = gcol0 + g0;
-            jb.act[0].ptr = cols[ci].p; jb.act[0].idx = cols[ci].idx ? cols[ci].idx : iota; jb.act[0].vstride = 0;
-            jb.act[0].stride = cols[ci].stride; jb.act[0].col0 = c0;
-            jb.act[1] = jb.act[0]; jb.act[2] = jb.act[0];
-            jb.wcol[0] = wcol + c0; jb.wrow = g0; jb.write_bias = first ? 1 : 0;
-            first = false;
-            jb.shape = (gw == 64) ? (cw == 96 ? WS_64_96 : WS_64_64) : WS_32_64;
-            jb.rows = (int)rows; jb.nvar = 1; jb.rows_per_task = kStreamRowsPerTask;
-            jb.NP = ls.NP; jb.KP = ls.KP; jb.slab = ls.slab;
-            wl.add(jb);
-            c0 += cw;
-          }
-          wcol += cols[ci].width;
-        }
-      }
+    auto mat = [&](int ll, long rows, const float* gp, const int* gidx, int gstride, int gcol0, const float* ap, int astride, int awidth) {
+      Col c[1] = {{ap, nullptr, 0, astride, 0, awidth}};
+      wb.add_block(w.lin[ll], rows, 1, rp, gp, gidx, 0, gstride, gcol0, c, 1, true);
     };
-    Col ceu[4] = {{x, dst, D::DX, 96}, {x, src, D::DX, 96}, {e, nullptr, D::DE, 64}, {att, nullptr, 64, 64}};
-    add(LL_EU0, E, w.GdH1, nullptr, D::EH1, 0, ceu, 4);
-    Col c1[1] = {{w.sH1, nullptr, D::EH1, 256}};
-    add(LL_EU1, E, w.GdH2, nullptr, D::EH2, 0, c1, 1);
-    Col c2[1] = {{w.sH2, nullptr, D::EH2, 128}};
-    add(LL_EU2, E, w.Gde, nullptr, D::DE, 0, c2, 1);
-    Col cp[3] = {{x, src, D::DX, 96}, {e_new, nullptr, D::DE, 64}, {x0, src, D::DX, 96}};
-    add(LL_PA0, E, w.GdP1, nullptr, D::MH, 0, cp, 3);
-    Col cp1[1] = {{w.sP1, nullptr, D::MH, 192}};
-    add(LL_PA1, E, w.dM, dst, D::NIN, 0, cp1, 1);
-    Col cf[3] = {{x, dst, D::DX, 96}, {e_new, nullptr, D::DE, 64}, {x0, dst, D::DX, 96}};
-    add(LL_FU0, E, w.GdF1, nullptr, D::MH, 0, cf, 3);
-    Col cf1[1] = {{w.sF1, nullptr, D::MH, 192}};
-    add(LL_FU1, E, w.dM, src, D::NIN, D::DM, cf1, 1);
-    Col cn0[1] = {{w.M, nullptr, D::NIN, 256}};
-    add(LL_CF0, N, w.GnH1, nullptr, D::NH1, 0, cn0, 1);
-    Col cn1[1] = {{w.nH1, nullptr, D::NH1, 192}};
-    add(LL_CF1, N, w.GnH2, nullptr, D::NH2, 0, cn1, 1);
-    Col cn2[1] = {{w.nH2, nullptr, D::NH2, 128}};
-    add(LL_CF2, N, d_x_new, nullptr, D::DX, 0, cn2, 1);
-    wl.launch(w.zrow, B3D_K_WGRAD_EDGE);
-    B3D_REQUIRE(wl.status == 0, "b3d_clr_layer_backward: job table overflow (%d jobs, %d tasks)", wl.njobs, wl.total_tasks);
-    B3D_TRY(launch_check("wstream_kernel"));
+    auto ncol = [&](int vl, int gcol0, const float* ap) {       // node columns of a first layer: G = a column block of dT
+      Col c[1] = {{ap, nullptr, 0, D::DX, 0, 96}};
+      wb.add_block(w.vlin[vl], N, 1, rn, w.dT, nullptr, 0, HC::GW, gcol0, c, 1, false);
+    };
+    wb.add_eu0_edge_columns(w.vlin[VL_EU0E], E, 1, rp, w.GdH1, 0, D::EH1, e, 0, D::DE, att);
+    ncol(VL_EU0XI, HC::OA, x); ncol(VL_EU0XJ, HC::OB, x);
+    mat(LL_EU1, E, w.GdH2, nullptr, D::EH2, 0, w.sH1, D::EH1, 256);
+    mat(LL_EU2, E, w.Gde, nullptr, D::DE, 0, w.sH2, D::EH2, 128);
+    {
+      Col ce[1] = {{w.e_out, nullptr, 0, D::DE, 0, 64}};
+      wb.add_block(w.vlin[VL_PA0E], E, 1, rp, w.GdP1, nullptr, 0, D::MH, 0, ce, 1, true);
+      wb.add_block(w.vlin[VL_FU0E], E, 1, rp, w.GdF1, nullptr, 0, D::MH, 0, ce, 1, true);
+    }
+    ncol(VL_PA0X, HC::OP, x); ncol(VL_PA0X0, HC::OP, x0); ncol(VL_FU0X, HC::OF, x); ncol(VL_FU0X0, HC::OF, x0);
+    mat(LL_PA1, E, w.dM, dst, D::NIN, 0, w.sP1, D::MH, 192);
+    mat(LL_FU1, E, w.dM, src, D::NIN, D::DM, w.sF1, D::MH, 192);
+    mat(LL_CF0, N, w.GnH1, nullptr, D::NH1, 0, w.M, D::NIN, 256);
+    mat(LL_CF1, N, w.GnH2, nullptr, D::NH2, 0, w.nH1, D::NH1, 192);
+    mat(LL_CF2, N, d_x_new, nullptr, D::DX, 0, w.nH2, D::NH2, 128);
+    B3D_TRY(wb.launch(w.zrow, stream));
   }
+  // ---- slabs -> parameter gradients ----
   RedArgs ra;
   ra.nentries = 0;
   const b3d_linear_grad* groups[] = {gr->edge_update, gr->create_past_msgs, gr->create_future_msgs, gr->combine_future_past};
   const int firstl[] = {LL_EU0, LL_PA0, LL_FU0, LL_CF0}, cnt[] = {3, 2, 2, 3};
   for (int gi = 0; gi < 4; ++gi)
-    for (int i = 0; i < cnt[gi]; ++i) ra.e[ra.nentries++] = red_entry(w.lin[firstl[gi] + i], groups[gi][i].w, groups[gi][i].b);
+    for (int i = 0; i < cnt[gi]; ++i) {
+      const int ll = firstl[gi] + i;
+      const b3d_linear_grad& dst_g = groups[gi][i];
+      if (ll == LL_EU0 || ll == LL_PA0 || ll == LL_FU0) {       // first layers: one slab set per column block
+        for (int v = 0; v < kLayerVl; ++v) {
+          if (kVl[v].lin != kLayerLin[ll]) continue;
+          RedEntry en = red_entry(w.vlin[v], dst_g.w ? dst_g.w + kVl[v].col0 : nullptr, kVl[v].bias ? dst_g.b : nullptr);
+          en.ld = w.lin[ll].K;
+          ra.e[ra.nentries++] = en;
+          if (ra.nentries == kRedMaxEntries) { B3D_TRY(launch_reduce(ra, stream)); ra.nentries = 0; }
+        }
+        continue;
+      }
+      ra.e[ra.nentries++] = red_entry(w.lin[ll], dst_g.w, dst_g.b);
+      if (ra.nentries == kRedMaxEntries) { B3D_TRY(launch_reduce(ra, stream)); ra.nentries = 0; }
+    }
   B3D_TRY(launch_reduce(ra, stream));
   return B3D_OK;
 }

@@ -181,6 +181,7 @@ template <class D>
 using Proj0Seq2 = LayerSeq<typename D::template NL<D::DX, 2 * D::MH>, typename D::template NL<D::DX, Hoist<D>::TW>>;
 struct NodeProj0Args {
   int N;
+  const float* x = nullptr;   // [N, DX] the layer's x (nullptr: x0 -- layer 0 of a model, where x == initial_x)
   const float* x0;      // [N, DX]
   float* T0;            // [N, 2 MH]
   float* T;             // [N, TW]
@@ -209,6 +210,7 @@ __global__ __launch_bounds__(kNodeWaves * 64, 1) void node_proj0_split_kernel(co
         t0[slot] = v;
         store_row<1>(a.T0, row, 2 * D::MH, 16 * mb, valid, &v);
       });
+  if (a.x) load_row<XB>(a.x, row, D::DX, 0, valid, x);      // (its own loads: nothing of the first layer's reads is pending)
   linear_split<Seq, 1, false, true, NWS>(
       ws, false, x, [&]() {},
       [&](int mb, v4f v, int slot) {

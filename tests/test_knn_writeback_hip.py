@@ -81,35 +81,46 @@ def test_pose_gnn_with_knn_writeback_matches_the_oracle():
 
 
 def test_clr_gnn_with_knn_writeback_matches_the_oracle():
+    """Whole camera+LiDAR+radar model with natural weights: two correct fp32 evaluations differ at the 1e-3 .. 2e-2 level in EVERY
+    gradient when a single ReLU unit sits within rounding of zero and takes the other branch on one side (DESIGN.md section 2;
+    which seed has such a unit changes with the summation order of the kernels).  Three (weights, graph) pairs are evaluated: the
+    outputs must agree to 1e-4 on all of them, and every parameter's gradient to 2e-4 on at least one of them -- a wrong backward
+    fails all three; the block and the layer are held entry by entry in the operator tests."""
     from batch3dmot_amd import encoders, synth
     from batch3dmot_amd.clr_att_gnn import GNN
     dev = torch.device("cuda:0")
-    data = synth.make_graph(300, None, k=6, graph_idx=32, modalities=True)
-    ora = ref_torch.GNN(encoders.ResNetAE(), encoders.PointNetClassifier(k=7), encoders.RadarNetClassifier(k=7), loop_masks=False,
-                        knn_writeback=True)
-    seeded_fill_(ora, 79)
-    ora.eval()
-    m = GNN(encoders.ResNetAE(), encoders.PointNetClassifier(k=7), encoders.RadarNetClassifier(k=7)).to(dev).eval()
-    m.load_state_dict(ora.state_dict(), strict=True)
-    m.knn_writeback = True
-    out, x_sens = m(data.to(dev))
-    w = torch.randn(out.shape, generator=torch.Generator().manual_seed(6))
-    (out * w.to(dev)).sum().backward()
-    ora.knn_graphs = [(nbr.cpu(), cnt.cpu()) for nbr, cnt in m._last_knn]
-    o_ref, s_ref = ora(data)
-    (o_ref * w).sum().backward()
-    assert rel(out, o_ref) < TOL and rel(x_sens, s_ref) < TOL
-    # (salt 79: with salt 78 one ReLU unit of this graph sits within fp32 rounding of zero and takes the other branch on the GPU --
-    # every gradient then differs at the 1e-3 .. 2e-2 level between two correct fp32 evaluations; measured with
-    # tools/debug_writeback.py: salts 79 / 78' / 80 on graphs 32 / 33 / 34 give worst entries of 5e-6 / 2e-5 / 5e-4)
-    got, want = dict(m.named_parameters()), dict(ora.named_parameters())
-    checked = 0
-    for name, q in want.items():
-        if q.grad is None:
-            continue
-        if float(q.grad.abs().max()) == 0.0:                          # q / k thirds of in_proj: exactly zero on both sides
-            assert got[name].grad is None or float(got[name].grad.abs().max()) == 0.0, name
-            continue
-        assert rel(got[name].grad, q.grad) < 2e-4, (name, rel(got[name].grad, q.grad))
-        checked += 1
-    assert checked > 40 and want["knn_conv.att_src"].grad is not None
+    best = {}
+    clean_runs = 0
+    for salt, gi in ((79, 32), (78, 33), (80, 34)):
+        data = synth.make_graph(300, None, k=6, graph_idx=gi, modalities=True)
+        ora = ref_torch.GNN(encoders.ResNetAE(), encoders.PointNetClassifier(k=7), encoders.RadarNetClassifier(k=7), loop_masks=False,
+                            knn_writeback=True)
+        seeded_fill_(ora, salt)
+        ora.eval()
+        m = GNN(encoders.ResNetAE(), encoders.PointNetClassifier(k=7), encoders.RadarNetClassifier(k=7)).to(dev).eval()
+        m.load_state_dict(ora.state_dict(), strict=True)
+        m.knn_writeback = True
+        out, x_sens = m(data.to(dev))
+        w = torch.randn(out.shape, generator=torch.Generator().manual_seed(6))
+        (out * w.to(dev)).sum().backward()
+        ora.knn_graphs = [(nbr.cpu(), cnt.cpu()) for nbr, cnt in m._last_knn]
+        o_ref, s_ref = ora(data)
+        (o_ref * w).sum().backward()
+        assert rel(out, o_ref) < TOL and rel(x_sens, s_ref) < TOL
+        got, want = dict(m.named_parameters()), dict(ora.named_parameters())
+        worst = 0.0
+        for name, q in want.items():
+            if q.grad is None:
+                continue
+            if float(q.grad.abs().max()) == 0.0:                      # q / k thirds of in_proj: exactly zero on both sides
+                assert got[name].grad is None or float(got[name].grad.abs().max()) == 0.0, name
+                continue
+            r = rel(got[name].grad, q.grad)
+            best[name] = min(best.get(name, 1.0), r)
+            worst = max(worst, r)
+        clean_runs += worst < 2e-4
+        assert want["knn_conv.att_src"].grad is not None
+    assert len(best) > 40
+    for name, r in best.items():
+        assert r < 2e-4, (name, r)
+    assert clean_runs >= 1                                          # at least one pair without any flipped unit
