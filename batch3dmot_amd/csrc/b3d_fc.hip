@@ -27,7 +27,12 @@ namespace {
 // are three [row][k] bf16 images each -- and a 32-wide k group of a 16 x 16 block is six v_mfma_f32_16x16x32_bf16 (96 cycles)
 // instead of eight v_mfma_f32_16x16x4_f32 (256 cycles); 64 k per barrier instead of 32.  The exact-fp32 form of this kernel sat
 // at 19 % MFMA-busy and 52 us for [1,500 x 1,024] . [1,024 x 512]: one barrier per 16 MFMAs of a wavefront.
-constexpr int kTM = 64, kTN = 64, kTK = 64, kFcThreads = 512;
+// (B3D_FC_TK=32: 61 KB of LDS, two workgroups per CU -- measured in round 4: no change of the step, 4.71 vs 4.69 - 4.70 ms)
+#ifndef B3D_FC_TK
+#define B3D_FC_TK 64
+#endif
+constexpr int kTM = 64, kTN = 64, kTK = B3D_FC_TK, kFcThreads = 512;
+constexpr int kTPR = kTK / 4, kRPP = kFcThreads / kTPR;          // staging: threads per tile row, rows per pass
 constexpr int kPitch = kTK / 2 + 4;          // dwords per tile row: 64 bf16 + 16 bytes.  144 B rows: the ds_read_b128 of an operand fragment
                                              // (16 rows x 16 B per 16-lane group) touches every bank once (144 i mod 256 = 16 (9 i mod 16))
 constexpr int kPiece = kTM * kPitch;         // dwords of one piece image
@@ -58,12 +63,12 @@ struct FcArgs {
 // AFFINE: the producer's BatchNorm + ReLU is applied to x while it is staged (compile-time: a run-time test around the loads made
 // hipcc wait vmcnt(0) behind every one of them, i.e. no tile was ever in flight under the MFMAs)
 template <bool AFFINE>
-__global__ __launch_bounds__(kFcThreads) void fc_kernel(const FcArgs a) {
+__global__ __launch_bounds__(kFcThreads, kTK == 32 ? 2 : 1) void fc_kernel(const FcArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned fc_lds[];
   unsigned* const As = fc_lds;                 // [2][3 pieces][kTM][kPitch]
   unsigned* const Bs = fc_lds + 2 * kTileDw;
   __shared__ float colsum[2][2][kTN];       // [row half][sum | sum of squares][column]
-  constexpr int HS = kTM / (kFcThreads / 16);   // staging passes (32 rows each)
+  constexpr int HS = kTM / kRPP;                // staging passes (kRPP rows each)
   __shared__ int s_last;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wr = wave >> 2, wc = wave & 3;                   // 2 x 4 wavefronts, 32 x 16 outputs each
@@ -77,7 +82,7 @@ __global__ __launch_bounds__(kFcThreads) void fc_kernel(const FcArgs a) {
   const int m0 = rt * kTM, n0 = ct * kTN;
   const int li = lane & 15, lk = lane >> 4;
   // staging: thread t moves one float4 (4 consecutive k) of row t / 16 (+ 32 per pass) of each tile
-  const int sr = tid >> 4, sq = tid & 15, sk = sq * 4;
+  const int sr = tid / kTPR, sq = tid % kTPR, sk = sq * 4;
   // Three register sets: the tile of chunk kc is loaded during chunk kc - 3 (a chunk is a fraction of a microsecond of MFMAs, an
   // HBM round trip several times that), staged at the end of chunk kc - 1.  Loads are unconditional (indices clamped, values
   // zeroed by a select when they are staged): nothing consumes a loaded value before its tile is staged, two chunks later --
@@ -87,8 +92,8 @@ __global__ __launch_bounds__(kFcThreads) void fc_kernel(const FcArgs a) {
   bool okA[HS], okB[HS];
 #pragma unroll
   for (int h = 0; h < HS; ++h) {
-    rA[h] = min(m0 + sr + 32 * h, a.B - 1); rB[h] = min(n0 + sr + 32 * h, a.N - 1);
-    okA[h] = m0 + sr + 32 * h < a.B; okB[h] = n0 + sr + 32 * h < a.N;
+    rA[h] = min(m0 + sr + kRPP * h, a.B - 1); rB[h] = min(n0 + sr + kRPP * h, a.N - 1);
+    okA[h] = m0 + sr + kRPP * h < a.B; okB[h] = n0 + sr + kRPP * h < a.N;
   }
   auto load = [&](int k0, v4f (&axs)[HS], v4f (&bxs)[HS], v4f& scs, v4f& shs) {
     const int k = min(k0 + sk, a.K - 4);
@@ -128,8 +133,8 @@ __global__ __launch_bounds__(kFcThreads) void fc_kernel(const FcArgs a) {
         v.x = relu1(fmaf(v.x, scs.x, shs.x)); v.y = relu1(fmaf(v.y, scs.y, shs.y));
         v.z = relu1(fmaf(v.z, scs.z, shs.z)); v.w = relu1(fmaf(v.w, scs.w, shs.w));
       }
-      put(As + buf * kTileDw + (sr + 32 * h) * kPitch + 2 * sq, (okA[h] && kok) ? v : zero);
-      put(Bs + buf * kTileDw + (sr + 32 * h) * kPitch + 2 * sq, (okB[h] && kok) ? bxs[h] : zero);
+      put(As + buf * kTileDw + (sr + kRPP * h) * kPitch + 2 * sq, (okA[h] && kok) ? v : zero);
+      put(Bs + buf * kTileDw + (sr + kRPP * h) * kPitch + 2 * sq, (okB[h] && kok) ? bxs[h] : zero);
     }
   };
   auto frag = [&](const unsigned* p) {                      // this lane's 8 k of one row, three pieces
