@@ -931,7 +931,20 @@ def infer_scene_measure(args, dev, rank, steps, frames=24, per_frame=400):
 
 def main_infer(args, dev, rank, world, dist):
     if getattr(args, "scene", False):
+        # scenes shard over the ranks (predict.py:595-611 walks the scenes one after the other; they share nothing): every rank
+        # runs its own scene, no collective on the data path; the line sums the ranks' rates over the slowest rank's time
+        if world > 1:
+            dist.barrier()
         line = infer_scene_measure(args, dev, rank, max(2, args.steps // 10))
+        if world > 1:
+            t = torch.tensor([line["cached"]["ms_per_scene"], line["uncached"]["ms_per_scene"]], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            edges = torch.tensor([line["value"] * line["cached"]["ms_per_scene"] * 1e-3], dtype=torch.float64, device=dev)   # edges of this rank's scene
+            dist.all_reduce(edges, op=dist.ReduceOp.SUM)
+            line["value"] = round(float(edges) / (float(t[0]) * 1e-3), 1)
+            line["value_uncached"] = round(float(edges) / (float(t[1]) * 1e-3), 1)
+            line["n_gpus"] = world
+            line["config"]["parallelism"] = f"scenes sharded over {world} ranks (no collective on the data path)"
         if rank == 0:
             print(json.dumps(line))
         if world > 1:
