@@ -228,15 +228,19 @@ __global__ __launch_bounds__(kFcThreads, kTK == 32 ? 2 : 1) void fc_kernel(const
     const int st = tid / kTN, c = tid % kTN, n = n0 + c;
     if (n < a.N) a.part[((size_t)rt * 2 + st) * a.N + n] = colsum[0][st][c] + colsum[1][st][c];
   }
-  // last workgroup: batch statistics -> affine of this layer's BatchNorm (MI355X_MICROARCH.md hand-off: drained stores, barrier,
-  // one lane's agent-scope release in front of the ticket; one acquire on the last workgroup in front of its reads)
+  // The last workgroup OF A COLUMN TILE to finish forms the BatchNorm affine of its 64 columns (MI355X_MICROARCH.md hand-off: drained
+  // stores, barrier, one lane's agent-scope release in front of the ticket; one acquire on the last workgroup in front of its reads).
+  // (Until round 4 the last workgroup of the LAUNCH did all N columns, one thread per column walking the row tiles twice with one
+  // dependent L2 round trip per tile: a 15 - 25 us single-workgroup tail behind every layer -- 38 us for a 132-workgroup launch whose
+  // workgroups live 16 us.)  Here: thread (c, g) = (tid % 64, wavefront g) takes the row tiles t = g, g + 8, ... of column n0 + c --
+  // four or five independent loads per pass -- and the eight partials of a column are added in wavefront order.
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned t = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int last = (t == (unsigned)(nrt * nct) - 1u) ? 1 : 0;
+    const unsigned t = __hip_atomic_fetch_add(a.ticket + 1 + ct, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = (t == (unsigned)nrt - 1u) ? 1 : 0;
     if (last) {
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -245,23 +249,40 @@ __global__ __launch_bounds__(kFcThreads, kTK == 32 ? 2 : 1) void fc_kernel(const
   }
   __syncthreads();
   if (!s_last) return;
-  const long long nbt_after = a.nbt ? *a.nbt + 1 : 1;
-  for (int n = tid; n < a.N; n += kFcThreads) {
-    float mean, var;
-    if (a.train) {
-      // Chan's combination of the per-tile (count, sum, M2) in float64, tile order
-      double s = 0.0;
-      for (int t = 0; t < nrt; ++t) s += (double)a.part[((size_t)t * 2) * a.N + n];
-      const double cnt = (double)a.B;
-      const double m = s / cnt;
-      double m2 = 0.0;
-      for (int t = 0; t < nrt; ++t) {
+  double* const red = reinterpret_cast<double*>(fc_lds);      // [8][64] (the operand tiles are done with)
+  const int c = tid & 63, g = tid >> 6, n = n0 + c;
+  const bool nok = n < a.N;
+  const long long nbt_after = a.nbt ? *a.nbt + 1 : 1;          // (written only after EVERY column tile has been finalised, below)
+  const double cnt = (double)a.B;
+  double m = 0.0, m2 = 0.0;
+  if (a.train) {
+    // Chan's combination of the per-tile (count, sum, M2) in float64: the mean first, then the squared deviations about it
+    double s = 0.0;
+    if (nok)
+      for (int t = g; t < nrt; t += 8) s += (double)a.part[((size_t)t * 2) * a.N + n];
+    red[g * 64 + c] = s;
+    __syncthreads();
+    s = 0.0;
+#pragma unroll
+    for (int gg = 0; gg < 8; ++gg) s += red[gg * 64 + c];
+    m = s / cnt;
+    __syncthreads();
+    double q = 0.0;
+    if (nok)
+      for (int t = g; t < nrt; t += 8) {
         const double nt = (double)min(kTM, a.B - t * kTM);
         const double dm = (double)a.part[((size_t)t * 2) * a.N + n] / nt - m;
-        m2 += (double)a.part[((size_t)t * 2 + 1) * a.N + n] + nt * dm * dm;
+        q += (double)a.part[((size_t)t * 2 + 1) * a.N + n] + nt * dm * dm;
       }
-      double v = m2 / cnt;
-      mean = (float)m; var = (float)v;
+    red[g * 64 + c] = q;
+    __syncthreads();
+#pragma unroll
+    for (int gg = 0; gg < 8; ++gg) m2 += red[gg * 64 + c];
+  }
+  if (g == 0 && nok) {
+    float mean, var;
+    if (a.train) {
+      mean = (float)m; var = (float)(m2 / cnt);
       if (a.running_mean) {
         const double mom = a.momentum >= 0.f ? (double)a.momentum : 1.0 / (double)nbt_after;
         const double unbiased = (double)var * (cnt / (cnt > 1.0 ? cnt - 1.0 : 1.0));
@@ -275,10 +296,20 @@ __global__ __launch_bounds__(kFcThreads, kTK == 32 ? 2 : 1) void fc_kernel(const
     a.out_scale[n] = sc;
     a.out_shift[n] = a.beta[n] - mean * sc;
   }
+  // num_batches_tracked moves once per call, after the last column tile has read it; both tickets are re-armed for the next call
+  // (stream order)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) {
-    if (a.train && a.nbt) *a.nbt = nbt_after;
-    *a.ticket = 0u;                                          // re-armed for the next call (stream order)
+    a.ticket[1 + ct] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned t = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == (unsigned)nct - 1u) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      if (a.train && a.nbt) *a.nbt = nbt_after;
+      a.ticket[0] = 0u;
+    }
   }
 }
 
@@ -333,6 +364,7 @@ extern "C" int b3d_fc_bn_forward(const float* x, int32_t B, int32_t K, const flo
     a.out_scale = out_scale; a.out_shift = out_shift;
   }
   const int nrt = (B + kTM - 1) / kTM, nct = (N + kTN - 1) / kTN;
+  B3D_REQUIRE(nct <= 63, "b3d_fc_bn_forward: N %d > 4032 columns (one arrival counter per 64-column tile in the workspace header)", (int)N);
   const dim3 grid((unsigned)((nrt + 7) / 8 * 8 * nct));                // row tiles padded to whole rounds of the eight XCDs
   if (in_scale) {
     B3D_TRY(set_lds_cached(reinterpret_cast<const void*>(fc_kernel<true>), kFcLdsBytes));
