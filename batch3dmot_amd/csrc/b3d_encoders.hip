@@ -415,6 +415,29 @@ __device__ __forceinline__ void load_point(const MomArgs& a, int P, int cloud, i
   }
 }
 
+// The same point in two halves for software pipelining: raw loads (unconditional: clamped channel, a stand-in address when there
+// is no transform -- a branch or a loop around a load makes hipcc drain vmcnt(0) behind it) and the arithmetic that consumes them.
+struct RawPoint { float x[4]; float tr[9]; };
+__device__ __forceinline__ void load_point_raw(const MomArgs& a, int P, int cloud, int p, RawPoint& r) {
+  const float* xp = a.x + ((long)cloud * a.C) * P + p;
+  const int cmax = a.C - 1;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) r.x[c] = xp[(long)(c < cmax ? c : cmax) * P];
+  const float* tr = a.trans ? a.trans + (long)cloud * 9 : a.x;          // (a.x: 9 readable floats, values unused)
+#pragma unroll
+  for (int i = 0; i < 9; ++i) r.tr[i] = tr[i];
+}
+__device__ __forceinline__ void finish_point(const MomArgs& a, const RawPoint& r, float (&f)[4]) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) f[c] = c < a.C ? r.x[c] : 0.f;
+  if (a.trans) {
+    const float x0 = f[0], x1 = f[1], x2 = f[2];
+    f[0] = x0 * r.tr[0] + x1 * r.tr[3] + x2 * r.tr[6];
+    f[1] = x0 * r.tr[1] + x1 * r.tr[4] + x2 * r.tr[7];
+    f[2] = x0 * r.tr[2] + x1 * r.tr[5] + x2 * r.tr[8];
+  }
+}
+
 __global__ __launch_bounds__(256) void point_moments_in_kernel(const MomArgs a, int P) {
   __shared__ float red[4][20];
   float acc[20];
@@ -442,9 +465,13 @@ __global__ __launch_bounds__(256) void point_moments_in_kernel(const MomArgs a, 
   if (threadIdx.x < 20) a.part[blockIdx.x * 20 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
+// Round 4: EIGHT wavefronts per workgroup (two per SIMD) and the next tile's point loaded under the current tile's 20 MFMAs --
+// with four wavefronts and the load in front of each tile's first MFMA the launch was a chain of exposed global round trips
+// (57 us for 270 k points whose MFMAs take ~5 us).
+constexpr int kMomWaves = 8;
 template <int P>
-__global__ __launch_bounds__(256) void point_moments_h1_kernel(const MomArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];      // [4 wavefronts][kMomRow]
+__global__ __launch_bounds__(kMomWaves * 64) void point_moments_h1_kernel(const MomArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];      // [4][kMomRow]: wavefronts w and w + 4 share an image
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int n = lane & 15, q = lane >> 4;
   float wv[4], bv[4];
@@ -461,10 +488,20 @@ __global__ __launch_bounds__(256) void point_moments_h1_kernel(const MomArgs a) 
     for (int j = 0; j < 4; ++j) sec[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
   constexpr int TPC = P / 16;
   const long tiles = (long)a.B * TPC;
-  for (long tile = (long)blockIdx.x * 4 + wave; tile < tiles; tile += (long)gridDim.x * 4) {
+  const long stride = (long)gridDim.x * kMomWaves;
+  long tile = (long)blockIdx.x * kMomWaves + wave;
+  RawPoint raw;
+  {
+    const long t0 = tile < tiles ? tile : 0;
+    load_point_raw(a, P, (int)(t0 / TPC), (int)(t0 % TPC) * 16 + n, raw);
+  }
+  for (; tile < tiles; tile += stride) {
     float f[4];
-    load_point(a, P, (int)(tile / TPC), (int)(tile % TPC) * 16 + n, f);
+    finish_point(a, raw, f);
     const float xa = q == 0 ? f[0] : q == 1 ? f[1] : q == 2 ? f[2] : f[3];     // A operand: x[point n][channel q]
+    const long nxt = tile + stride < tiles ? tile + stride : tile;             // (the last tile is loaded again: no branch around loads)
+    load_point_raw(a, P, (int)(nxt / TPC), (int)(nxt % TPC) * 16 + n, raw);    // consumed at the top of the next iteration
+    __builtin_amdgcn_sched_barrier(0);                                         // (hipcc otherwise sinks these loads below the MFMAs)
     v4f h[4];
 #pragma unroll
     for (int bi = 0; bi < 4; ++bi) {
@@ -476,21 +513,35 @@ __global__ __launch_bounds__(256) void point_moments_h1_kernel(const MomArgs a) 
 #pragma unroll
       for (int bj = 0; bj < 4; ++bj) sec[bi][bj] = mfma4(h[bi], h[bj], sec[bi][bj]);
   }
-  float* mine = smem + wave * kMomRow;
+  // Wavefronts w and w + 4 share an LDS image (66 KB per workgroup instead of 133 KB: the launch has to find room next to the
+  // kernels of the other encoder streams): w < 4 stores, then w >= 4 adds its own values onto the same addresses.
+  float* mine = smem + (wave & 3) * kMomRow;
 #pragma unroll
-  for (int bi = 0; bi < 4; ++bi) {
+  for (int half = 0; half < 2; ++half) {
+    if ((wave >> 2) == half) {
 #pragma unroll
-    for (int bj = 0; bj < 4; ++bj) {                          // element [16 bi + 4 q + j][16 bj + n]
-      float* d = mine + (16 * bi + 4 * q) * kMomK + 16 * bj + n;
-      d[0] = sec[bi][bj].x; d[kMomK] = sec[bi][bj].y; d[2 * kMomK] = sec[bi][bj].z; d[3 * kMomK] = sec[bi][bj].w;
+      for (int bi = 0; bi < 4; ++bi) {
+#pragma unroll
+        for (int bj = 0; bj < 4; ++bj) {                      // element [16 bi + 4 q + j][16 bj + n]
+          float* d = mine + (16 * bi + 4 * q) * kMomK + 16 * bj + n;
+          if (half == 0) {
+            d[0] = sec[bi][bj].x; d[kMomK] = sec[bi][bj].y; d[2 * kMomK] = sec[bi][bj].z; d[3 * kMomK] = sec[bi][bj].w;
+          } else {
+            d[0] += sec[bi][bj].x; d[kMomK] += sec[bi][bj].y; d[2 * kMomK] += sec[bi][bj].z; d[3 * kMomK] += sec[bi][bj].w;
+          }
+        }
+        float v = sm[bi];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (q == 0) {
+          if (half == 0) mine[kMomK * kMomK + 16 * bi + n] = v;
+          else mine[kMomK * kMomK + 16 * bi + n] += v;
+        }
+      }
     }
-    float v = sm[bi];
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
-    if (q == 0) mine[kMomK * kMomK + 16 * bi + n] = v;
+    __syncthreads();
   }
-  __syncthreads();
-  for (int i = threadIdx.x; i < kMomRow; i += 256)
+  for (int i = threadIdx.x; i < kMomRow; i += kMomWaves * 64)
     a.part[(long)blockIdx.x * kMomRow + i] = (smem[i] + smem[kMomRow + i]) + (smem[2 * kMomRow + i] + smem[3 * kMomRow + i]);
 }
 
@@ -543,15 +594,20 @@ extern "C" int b3d_point_moments(const b3d_linear* fold1, const float* x, const 
     hipLaunchKernelGGL(point_moments_finish_kernel, dim3(2), dim3(1024), 0, stream, a.part, kMomGrid, 4, (int)C, count, mu, second);
   } else {
     constexpr int lds = 4 * kMomRow * (int)sizeof(float);
+    // ~4 tiles of 16 points per wavefront: a small batch (radar: 757 clouds x 64 points) is a third of the chip, not 256 workgroups
+    // whose only work is writing a 64 x 64 partial each
+    const long tiles = (long)B * (P / 16);
+    long grid = (tiles + 4 * kMomWaves - 1) / (4 * kMomWaves);
+    grid = grid < 16 ? 16 : grid > kMomGrid ? kMomGrid : grid;
     if (P == 128) {
       B3D_TRY(set_lds(point_moments_h1_kernel<128>, lds));
-      hipLaunchKernelGGL(point_moments_h1_kernel<128>, dim3(kMomGrid), dim3(256), lds, stream, a);
+      hipLaunchKernelGGL(point_moments_h1_kernel<128>, dim3((unsigned)grid), dim3(kMomWaves * 64), lds, stream, a);
     } else {
       B3D_TRY(set_lds(point_moments_h1_kernel<64>, lds));
-      hipLaunchKernelGGL(point_moments_h1_kernel<64>, dim3(kMomGrid), dim3(256), lds, stream, a);
+      hipLaunchKernelGGL(point_moments_h1_kernel<64>, dim3((unsigned)grid), dim3(kMomWaves * 64), lds, stream, a);
     }
     B3D_TRY(launch_check("point_moments_h1_kernel"));
-    hipLaunchKernelGGL(point_moments_finish_kernel, dim3((kMomRow + 15) / 16), dim3(1024), 0, stream, a.part, kMomGrid, kMomK, kMomK,
+    hipLaunchKernelGGL(point_moments_finish_kernel, dim3((kMomRow + 15) / 16), dim3(1024), 0, stream, a.part, (int)grid, kMomK, kMomK,
                        count, mu, second);
   }
   return launch_check("point_moments_finish_kernel");
@@ -623,6 +679,7 @@ __global__ __launch_bounds__(256) void bn_fold_moments_kernel(const BnFoldArgs a
 }
 
 // last layer: per-cloud max / min / sum / sum of squares of the raw conv output -> batch statistics -> y = BN(max or min)
+constexpr int kBnMinMaxChunks = 64;     // row chunks of the statistics pass (a multiple of 8)
 struct BnMinMaxArgs {
   const float *vmax, *vmin, *vsum, *vsq;   // [B, F]
   int B, F, relu;
@@ -635,13 +692,23 @@ struct BnMinMaxArgs {
   int chunks;
   float* y;                                // [B, F]
 };
+// (round 4: 64 row chunks instead of 32 and four independent row loads per iteration -- the two launches were 21 + 30 us of
+// dependent L2 round trips on 128 workgroups for 26 MB of traffic)
 __global__ __launch_bounds__(256) void bn_minmax_partial_kernel(const BnMinMaxArgs a) {
   const int f = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
   if (f >= a.F) return;
   const int per = (a.B + a.chunks - 1) / a.chunks;
   const int b0 = c * per, b1 = min(a.B, b0 + per);
   double s = 0.0, q = 0.0;
-  for (int b = b0; b < b1; ++b) { s += (double)a.vsum[(size_t)b * a.F + f]; q += (double)a.vsq[(size_t)b * a.F + f]; }
+  int b = b0;
+  for (; b + 4 <= b1; b += 4) {
+    float vs[4], vq[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { vs[u] = a.vsum[(size_t)(b + u) * a.F + f]; vq[u] = a.vsq[(size_t)(b + u) * a.F + f]; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { s += (double)vs[u]; q += (double)vq[u]; }
+  }
+  for (; b < b1; ++b) { s += (double)a.vsum[(size_t)b * a.F + f]; q += (double)a.vsq[(size_t)b * a.F + f]; }
   a.part[((size_t)c * 2 + 0) * a.F + f] = s;
   a.part[((size_t)c * 2 + 1) * a.F + f] = q;
 }
@@ -649,7 +716,13 @@ __global__ __launch_bounds__(256) void bn_minmax_apply_kernel(const BnMinMaxArgs
   const int f = blockIdx.x * 256 + threadIdx.x;
   if (f >= a.F) return;
   double s = 0.0, q = 0.0;
-  for (int c = 0; c < a.chunks; ++c) { s += a.part[((size_t)c * 2 + 0) * a.F + f]; q += a.part[((size_t)c * 2 + 1) * a.F + f]; }
+  for (int c = 0; c < a.chunks; c += 8) {                    // (chunks is a multiple of 8: sixteen independent loads per round trip)
+    double ps[8], pq[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { ps[u] = a.part[((size_t)(c + u) * 2 + 0) * a.F + f]; pq[u] = a.part[((size_t)(c + u) * 2 + 1) * a.F + f]; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { s += ps[u]; q += pq[u]; }
+  }
   const double mean = s / (double)a.count;
   double var = q / (double)a.count - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -662,10 +735,22 @@ __global__ __launch_bounds__(256) void bn_minmax_apply_kernel(const BnMinMaxArgs
   }
   const int per = (a.B + gridDim.y - 1) / gridDim.y;
   const int b0 = blockIdx.y * per, b1 = min(a.B, b0 + per);
-  for (int b = b0; b < b1; ++b) {
+  const float* const ext_of = scale > 0.0 ? a.vmax : a.vmin;  // max over the points of an increasing map, min of a decreasing one
+  int b = b0;
+  for (; b + 4 <= b1; b += 4) {
+    float e[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) e[u] = ext_of[(size_t)(b + u) * a.F + f];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float v = (float)((double)e[u] * scale + shift);
+      if (a.relu) v = relu1(v);
+      a.y[(size_t)(b + u) * a.F + f] = v;
+    }
+  }
+  for (; b < b1; ++b) {
     const size_t o = (size_t)b * a.F + f;
-    const double ext = scale > 0.0 ? (double)a.vmax[o] : (double)a.vmin[o];
-    float v = (float)(ext * scale + shift);
+    float v = (float)((double)ext_of[o] * scale + shift);
     if (a.relu) v = relu1(v);
     a.y[o] = v;
   }
@@ -692,7 +777,7 @@ extern "C" int b3d_bn_fold_moments(const double* mu, const double* second, int32
   return B3D_OK;
 }
 
-extern "C" size_t b3d_bn_minmax_workspace_bytes(int32_t F) { return (size_t)32 * 2 * (size_t)F * sizeof(double) + 256; }
+extern "C" size_t b3d_bn_minmax_workspace_bytes(int32_t F) { return (size_t)kBnMinMaxChunks * 2 * (size_t)F * sizeof(double) + 256; }
 
 extern "C" int b3d_bn_minmax_apply(const float* vmax, const float* vmin, const float* vsum, const float* vsq, int32_t B, int32_t F,
                                    int64_t count, const float* gamma, const float* beta, float* running_mean, float* running_var,
@@ -703,11 +788,11 @@ extern "C" int b3d_bn_minmax_apply(const float* vmax, const float* vmin, const f
   B3D_REQUIRE(B >= 1 && F >= 1 && count >= 1, "b3d_bn_minmax_apply: B %d, F %d", (int)B, (int)F);
   if (workspace_bytes < b3d_bn_minmax_workspace_bytes(F)) return fail(B3D_ERR_WORKSPACE, "b3d_bn_minmax_apply: workspace too small");
   BnMinMaxArgs a{vmax, vmin, vsum, vsq, B, F, relu, (long long)count, gamma, beta, running_mean, running_var,
-                 (long long*)num_batches_tracked, momentum, eps, (double*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255), 32, y};
+                 (long long*)num_batches_tracked, momentum, eps, (double*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255), kBnMinMaxChunks, y};
   const unsigned fb = (unsigned)((F + 255) / 256);
-  hipLaunchKernelGGL(bn_minmax_partial_kernel, dim3(fb, 32), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(bn_minmax_partial_kernel, dim3(fb, kBnMinMaxChunks), dim3(256), 0, stream, a);
   B3D_TRY(launch_check("bn_minmax_partial_kernel"));
-  hipLaunchKernelGGL(bn_minmax_apply_kernel, dim3(fb, 32), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(bn_minmax_apply_kernel, dim3(fb, 128), dim3(256), 0, stream, a);
   B3D_TRY(launch_check("bn_minmax_apply_kernel"));
   if (num_batches_tracked && momentum < 0.f) {
     hipLaunchKernelGGL(bn_tick_kernel, dim3(1), dim3(1), 0, stream, (long long*)num_batches_tracked);
