@@ -1153,14 +1153,14 @@ def infer_measure(args, dev, rank, world, dist, steps, warmup, cpu=True):
 def infer_cpu_baseline(args, pool_cpu, clr):
     """The oracle's forward (oracle/ref_torch.py; eval mode, no_grad, encoders inside, the discarded k-NN + GAT block included)
     on the host cores over the same pool windows: bounded sample, median per-window time."""
-    from oracle import ref_torch                 # checker / baseline only
+    from oracle import ref_encoders, ref_torch   # checker / baseline only
     from batch3dmot_amd import encoders as enc_mod
     model_name, cores = host_info()
     threads = min(16, cores)
     torch.set_num_threads(threads)
     torch.manual_seed(5621)
     if clr:
-        mm = ref_torch.GNN(enc_mod.ResNetAE(), enc_mod.PointNetClassifier(k=7), enc_mod.RadarNetClassifier(k=7),
+        mm = ref_torch.GNN(ref_encoders.ResNetAE(), ref_encoders.PointNetClassifier(k=7), ref_encoders.RadarNetClassifier(k=7),
                            run_dead_knn=not args.no_dead_knn, loop_masks=False).eval()
     else:
         mm = ref_torch.PoseGNN(run_dead_knn=not args.no_dead_knn).eval()
@@ -1228,7 +1228,7 @@ def cpu_baseline(wl: Workload):
     """The oracle (oracle/ref_torch.py, pinned against the reference sources) timed on the host: the same batches, the
     same step (masks, encoders in train mode, forward incl. the discarded k-NN + GAT block, loss, backward, Adam).
     Bounded sample: a few steps at the fastest thread count, plus one 1-thread figure on a smaller sample."""
-    from oracle import ref_torch                 # checker / baseline only
+    from oracle import ref_encoders, ref_torch   # checker / baseline only
     from batch3dmot_amd import encoders as enc_mod, synth
     model_name, cores = host_info()
     threads = min(16, cores)                     # replaced by the fastest setting of the sweep below
@@ -1238,7 +1238,7 @@ def cpu_baseline(wl: Workload):
         if wl.kind == "pose":
             mm = ref_torch.PoseGNN(run_dead_knn=True)
         else:
-            mm = ref_torch.GNN(enc_mod.ResNetAE(), enc_mod.PointNetClassifier(k=7), enc_mod.RadarNetClassifier(k=7),
+            mm = ref_torch.GNN(ref_encoders.ResNetAE(), ref_encoders.PointNetClassifier(k=7), ref_encoders.RadarNetClassifier(k=7),
                                run_dead_knn=True, loop_masks=False)
         oo = torch.optim.Adam([p for p in mm.parameters() if p.requires_grad], lr=1e-4, weight_decay=1e-4, betas=(0.9, 0.999))
         return mm, oo

@@ -32,7 +32,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference"
 sys.path.insert(0, ROOT)
 
-from oracle import ref_torch  # noqa: E402
+from oracle import ref_encoders, ref_torch  # noqa: E402
 from oracle.seeded import seeded_fill_, grad_digest  # noqa: E402
 from batch3dmot_amd import synth  # noqa: E402
 from batch3dmot_amd.data import Data, collate  # noqa: E402
@@ -217,8 +217,7 @@ def _build_clr(ref, salt):
 
 
 def _build_clr_oracle(salt):
-    from batch3dmot_amd import encoders
-    m = ref_torch.GNN(encoders.ResNetAE(), encoders.PointNetClassifier(k=7), encoders.RadarNetClassifier(k=7))
+    m = ref_torch.GNN(ref_encoders.ResNetAE(), ref_encoders.PointNetClassifier(k=7), ref_encoders.RadarNetClassifier(k=7))
     seeded_fill_(m, salt)
     return m
 
@@ -625,6 +624,50 @@ def golden_tracks(path):
     print(path)
 
 
+
+ENCODER_INPUTS = {"ResNetAE": (3, 32, 32), "PointNetClassifier": (3, 128), "RadarNetClassifier": (4, 64)}
+
+
+def encoder_input(name, rows=6, seed=77):
+    g = torch.Generator().manual_seed(seed + len(name))
+    shape = (rows,) + ENCODER_INPUTS[name]
+    return torch.rand(shape, generator=g) if name == "ResNetAE" else torch.randn(shape, generator=g)
+
+
+def golden_encoders(ref, path, salt=51):
+    """The reference's OWN encoder modules (resnet_fully_conv.py, pointnet.py, radarnet.py) on seeded weights and inputs: eval-mode
+    output, train-mode output (batch-statistics BatchNorm; Dropout p = 0, its mask is not part of the contract) and every
+    BatchNorm buffer after the train-mode call.  oracle/ref_encoders.py must reproduce them; asserted here bit for bit, and by
+    tests/test_oracle_encoders.py from the committed fixture."""
+    out = {"salt": salt}
+    for name, mod in (("ResNetAE", ref.resnet), ("PointNetClassifier", ref.pointnet), ("RadarNetClassifier", ref.radarnet)):
+        make = (lambda m=mod, n=name: getattr(m, n)()) if name == "ResNetAE" else (lambda m=mod, n=name: getattr(m, n)(k=7))
+        rm = make()
+        mine = getattr(ref_encoders, name)() if name == "ResNetAE" else getattr(ref_encoders, name)(k=7)
+        seeded_fill_(rm, salt)
+        mine.load_state_dict(rm.state_dict(), strict=True)
+        x = encoder_input(name)
+        rec = {}
+        for mode in ("eval", "train"):
+            for m in (rm, mine):
+                getattr(m, mode)()
+                if name != "ResNetAE":
+                    m.dropout.p = 0.0
+            with torch.no_grad():
+                a = rm.encode(x) if name == "ResNetAE" else rm.forward_feat(x)
+                b = mine.encode(x) if name == "ResNetAE" else mine.forward_feat(x)
+            assert torch.equal(a, b), (name, mode, float((a - b).abs().max()))
+            rec[mode] = a.clone()
+        sa, sb = rm.state_dict(), mine.state_dict()
+        for k in sa:
+            assert torch.equal(sa[k], sb[k]), (name, k)
+        rec["buffers_after_train"] = {k: v.clone() for k, v in sa.items() if "running_" in k or "num_batches" in k}
+        out[name] = rec
+        print(f"{path}: {name} eval |out|max {rec['eval'].abs().max():.3f}, train |out|max {rec['train'].abs().max():.3f}, "
+              f"{len(rec['buffers_after_train'])} BatchNorm buffers; oracle/ref_encoders.py == reference, bit for bit")
+    torch.save(out, path)
+
+
 def main():
     """python oracle/make_golden.py [name-prefix ...]: all fixtures, or those whose file name starts with a prefix."""
     ref = load_reference()
@@ -646,6 +689,7 @@ def main():
         ("g8_tracks.pt", lambda p: golden_tracks(p)),
         ("g6_scene_pose.pt", lambda p: golden_scene(ref, p, kind="pose", graph_idx=400, salt=30)),
         ("g6_scene_clr.pt", lambda p: golden_scene(ref, p, kind="clr", graph_idx=440, salt=31)),
+        ("g10_encoders.pt", lambda p: golden_encoders(ref, p)),
     ]
     for name, fn in jobs:
         if not only or any(name.startswith(o) for o in only):

@@ -228,8 +228,10 @@ class GNN(nn.Module):
         self.knn_graphs = None
         self.loop_masks = loop_masks
         self.resnet, self.pointnet, self.radarnet = img_encoder, lidar_encoder, radar_encoder
-        for enc in (self.resnet, self.pointnet, self.radarnet):          # the oracle keeps the reference's operation order:
-            for mod in enc.modules():                                    # no BatchNorm folding, no HIP kernels
+        # The encoders come from oracle/ref_encoders.py (plain PyTorch, nothing of the product).  Should a caller hand over the
+        # product's classes instead, they are pinned to the reference's operation order: no BatchNorm folding, no HIP kernels.
+        for enc in (self.resnet, self.pointnet, self.radarnet):
+            for mod in enc.modules():
                 mod.use_hip = False
                 mod.fold_bn = False
         for enc in (self.resnet, self.pointnet, self.radarnet):          # :26-33

@@ -144,8 +144,8 @@ def test_use_attention_false_is_rejected():
 
 def _oracle_pair(salt, dev):
     from batch3dmot_amd import encoders
-    from oracle import ref_torch
-    ora = ref_torch.GNN(encoders.ResNetAE(), encoders.PointNetClassifier(k=7), encoders.RadarNetClassifier(k=7),
+    from oracle import ref_encoders, ref_torch
+    ora = ref_torch.GNN(ref_encoders.ResNetAE(), ref_encoders.PointNetClassifier(k=7), ref_encoders.RadarNetClassifier(k=7),
                         run_dead_knn=False, loop_masks=False)
     seeded_fill_(ora, salt)
     ora.eval()

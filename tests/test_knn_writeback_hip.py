@@ -4,7 +4,7 @@ lists the HIP forward chose, so a near-tie between two distances cannot make the
 import pytest
 import torch
 
-from oracle import ref_torch
+from oracle import ref_encoders, ref_torch
 from oracle.seeded import seeded_fill_
 
 pytestmark = pytest.mark.gpu
@@ -93,7 +93,7 @@ def test_clr_gnn_with_knn_writeback_matches_the_oracle():
     clean_runs = 0
     for salt, gi in ((79, 32), (78, 33), (80, 34)):
         data = synth.make_graph(300, None, k=6, graph_idx=gi, modalities=True)
-        ora = ref_torch.GNN(encoders.ResNetAE(), encoders.PointNetClassifier(k=7), encoders.RadarNetClassifier(k=7), loop_masks=False,
+        ora = ref_torch.GNN(ref_encoders.ResNetAE(), ref_encoders.PointNetClassifier(k=7), ref_encoders.RadarNetClassifier(k=7), loop_masks=False,
                             knn_writeback=True)
         seeded_fill_(ora, salt)
         ora.eval()

@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from conftest import load_golden, data_from
-from oracle import ref_torch
+from oracle import ref_encoders, ref_torch
 from oracle.seeded import seeded_fill_, grad_digest
 from batch3dmot_amd import encoders
 
@@ -50,7 +50,7 @@ def test_pose_dead_knn_has_no_effect():
 
 
 def _clr(salt):
-    m = ref_torch.GNN(encoders.ResNetAE(), encoders.PointNetClassifier(k=7), encoders.RadarNetClassifier(k=7))
+    m = ref_torch.GNN(ref_encoders.ResNetAE(), ref_encoders.PointNetClassifier(k=7), ref_encoders.RadarNetClassifier(k=7))
     seeded_fill_(m, salt)
     return m.eval()
 

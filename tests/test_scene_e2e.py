@@ -41,11 +41,11 @@ def _same_indices(r, g):
 def test_oracle_and_torch_post_processing_reproduce_the_reference_indices(name):
     from batch3dmot_amd import encoders
     from batch3dmot_amd.predict_post import greedy_edges
-    from oracle import ref_torch
+    from oracle import ref_encoders, ref_torch
     g = load_golden(name)
     assert min(g["margins"]) > 1e-4
     if g["kind"] == "clr":
-        m = ref_torch.GNN(encoders.ResNetAE(), encoders.PointNetClassifier(k=7), encoders.RadarNetClassifier(k=7), run_dead_knn=False)
+        m = ref_torch.GNN(ref_encoders.ResNetAE(), ref_encoders.PointNetClassifier(k=7), ref_encoders.RadarNetClassifier(k=7), run_dead_knn=False)
     else:
         m = ref_torch.PoseGNN(run_dead_knn=False)
     seeded_fill_(m, g["salt"])

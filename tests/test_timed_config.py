@@ -85,8 +85,8 @@ def _train_pair(salt, dev):
     (pointnet.py:190, radarnet.py:62) neutralised on both sides, its mask is not part of the contract."""
     from batch3dmot_amd import encoders
     from batch3dmot_amd.clr_att_gnn import GNN
-    from oracle import ref_torch
-    ora = ref_torch.GNN(encoders.ResNetAE(), encoders.PointNetClassifier(k=7), encoders.RadarNetClassifier(k=7),
+    from oracle import ref_encoders, ref_torch
+    ora = ref_torch.GNN(ref_encoders.ResNetAE(), ref_encoders.PointNetClassifier(k=7), ref_encoders.RadarNetClassifier(k=7),
                         run_dead_knn=False, loop_masks=False)
     seeded_fill_(ora, salt)
     m = GNN(encoders.ResNetAE(), encoders.PointNetClassifier(k=7), encoders.RadarNetClassifier(k=7))
