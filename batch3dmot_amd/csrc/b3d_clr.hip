@@ -5,6 +5,9 @@
 #include "b3d_knn.hpp"
 #include "b3d_wstream.hpp"
 #include "b3d_wstream2.hpp"
+#ifndef B3D_NW_HEAD
+#define B3D_NW_HEAD 4
+#endif
 #include "b3d_wgemm.hpp"
 #include <algorithm>
 #include <vector>
@@ -93,6 +96,10 @@ static const int kRowKind[LIN_COUNT] = {0, 0, 0, 1, 1, 0, 0, 0, 0, 2, 2, 3, 3, 3
                                         0, 0, 0, 0, 0, 0, 0, 1, 1, 1};
 // Rows per weight-gradient task (measured on the benchmark batch: 512 / 1,024 / 64 / 64 in round 2; larger tasks = fewer,
 // smaller slab sets -- 175 instead of 340 MB per step -- at the same load balance)
+// fc_lidar_encoder / fc_radar_encoder (256-192-128(-64) on the 2,100 / 750 rows that carry the modality): ~0.5 MB of bf16x3 weight
+// images per workgroup.  With one wavefront per workgroup (kNWNode: right for the 19-48-96 node encoder) that stream passes through
+// ONE loader wavefront -- ~25 GB/s, 20 us of a 25 us launch; four wavefronts load it four times faster for four 16-row tiles.
+constexpr int kNWHead = B3D_NW_HEAD;
 constexpr int kStreamRowsPerTask = 768;          // message-passing stacks (x up to 6 layer variants)
 constexpr int kStreamNodeRowsPerTask = 128;      // hoisted first layers: node columns contract over N rows x depth layers
 constexpr int kStreamNodeRowsPerTaskAtt = 512;   // att_edge_encoder.0's node columns: one variant, a [512, 288] partial per task
@@ -806,7 +813,7 @@ extern "C" int b3d_clr_forward(const b3d_clr_weights* pw, const b3d_graph* g, co
     memset(&a, 0, sizeof(a));
     a.rows = nl; a.in = In{in->pointnet_out, nullptr, 256, 0}; a.out = Out{w.xsens, in->lidar_nodes, XS, 96};
     a.save[0] = w.fl_a1; a.wpack = w.wp_fl;
-    B3D_TRY(launch_rows<kNWNode>(chain_fwd_kernel<SeqFL, 0x1u, In, Out, kNWNode>, "fc_lidar_encoder", a, nl, stream, B3D_K_OTHER, chain_lds<SeqFL>()));
+    B3D_TRY(launch_rows<kNWHead>(chain_fwd_kernel<SeqFL, 0x1u, In, Out, kNWHead>, "fc_lidar_encoder", a, nl, stream, B3D_K_OTHER, chain_lds<SeqFL>()));
   }
   if (nr > 0) {  // fc_radar_encoder 256-192-128-64
     using In = LoadAligned<16>;
@@ -815,7 +822,7 @@ extern "C" int b3d_clr_forward(const b3d_clr_weights* pw, const b3d_graph* g, co
     memset(&a, 0, sizeof(a));
     a.rows = nr; a.in = In{in->radarnet_out, nullptr, 256, 0}; a.out = Out{w.xsens, in->radar_nodes, XS, 224};
     a.save[0] = w.fr_a1; a.save[1] = w.fr_a2; a.wpack = w.wp_fr;
-    B3D_TRY(launch_rows<kNWNode>(chain_fwd_kernel<SeqFR, 0x3u, In, Out, kNWNode>, "fc_radar_encoder", a, nr, stream, B3D_K_OTHER, chain_lds<SeqFR>()));
+    B3D_TRY(launch_rows<kNWHead>(chain_fwd_kernel<SeqFR, 0x3u, In, Out, kNWHead>, "fc_radar_encoder", a, nr, stream, B3D_K_OTHER, chain_lds<SeqFR>()));
   }
   B3D_HIP_CHECK(hipMemcpyAsync(out_x_sens, w.xsens, (size_t)N * XS * sizeof(float), hipMemcpyDeviceToDevice, stream));
 
@@ -1007,7 +1014,7 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
     memset(&a, 0, sizeof(a));
     a.rows = nl; a.in = In{w.dxs, XS, 96, d_x_sens, XS, 96, in->lidar_nodes};
     a.gtop = w.gfl_top; a.act[0] = w.fl_a1; a.gsave[0] = w.gfl1; a.wpack = w.wp_flT;
-    B3D_TRY(launch_rows<kNWNode>(chain_bwd_kernel<SeqFLT, In, StoreNone, kNWNode>, "fc_lidar_encoder_bwd", a, nl, stream, B3D_K_OTHER, chain_lds<SeqFLT>()));
+    B3D_TRY(launch_rows<kNWHead>(chain_bwd_kernel<SeqFLT, In, StoreNone, kNWHead>, "fc_lidar_encoder_bwd", a, nl, stream, B3D_K_OTHER, chain_lds<SeqFLT>()));
 
   }
   if (nr > 0) {  // fc_radar_encoder
@@ -1016,7 +1023,7 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
     memset(&a, 0, sizeof(a));
     a.rows = nr; a.in = In{w.dxs, XS, 224, d_x_sens, XS, 224, in->radar_nodes};
     a.gtop = w.gfr_top; a.act[0] = w.fr_a2; a.act[1] = w.fr_a1; a.gsave[0] = w.gfr2; a.gsave[1] = w.gfr1; a.wpack = w.wp_frT;
-    B3D_TRY(launch_rows<kNWNode>(chain_bwd_kernel<SeqFRT, In, StoreNone, kNWNode>, "fc_radar_encoder_bwd", a, nr, stream, B3D_K_OTHER, chain_lds<SeqFRT>()));
+    B3D_TRY(launch_rows<kNWHead>(chain_bwd_kernel<SeqFRT, In, StoreNone, kNWHead>, "fc_radar_encoder_bwd", a, nr, stream, B3D_K_OTHER, chain_lds<SeqFRT>()));
 
   }
 

@@ -38,11 +38,18 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a) {
 // Step counter on the device (for hipGraph-captured training steps: a captured launch replays its arguments,
 // so the bias corrections cannot come from a host integer).
 __global__ __launch_bounds__(256) void adam_dev_kernel(AdamArgs a, const long long* __restrict__ step, float lr) {
+  // the bias corrections once per workgroup (two float64 pow per THREAD were most of this launch: 21 us for 1.3 M parameters)
+  __shared__ float s_corr[2];
+  if (threadIdx.x == 0) {
+    const double t = (double)(*step + 1);
+    const double bc1 = 1.0 - pow((double)a.beta1, t), bc2 = 1.0 - pow((double)a.beta2, t);
+    s_corr[0] = (float)((double)lr / bc1);
+    s_corr[1] = (float)sqrt(bc2);
+  }
+  __syncthreads();
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.n) return;
-  const double t = (double)(*step + 1);
-  const double bc1 = 1.0 - pow((double)a.beta1, t), bc2 = 1.0 - pow((double)a.beta2, t);
-  const float step_size = (float)((double)lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+  const float step_size = s_corr[0], bc2_sqrt = s_corr[1];
   float p = a.p[i];
   float g = a.g[i];
   if (a.weight_decay != 0.f) g = __fmaf_rn(p, a.weight_decay, g);
