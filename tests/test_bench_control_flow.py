@@ -70,6 +70,15 @@ def test_two_ranks_share_the_device_over_gloo():
     assert "EncodeAhead" in a["config"]["workload"]
 
 
+@pytest.mark.gpu
+def test_scene_inference_shards_scenes_over_two_ranks():
+    """bench.py --mode infer --scene at N = 2 (two ranks on device 0 over gloo): every rank scores its own scene, the line carries
+    the sum of the ranks' edges over the slowest rank's time, no collective on the data path."""
+    d = _run(["--backend", "gloo", "--all-ranks-on-device-0", "--mode", "infer", "--scene", "--steps", "20", "--no-cpu-baseline"], timeout=900)
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["value_uncached"] > 0
+    assert "scenes sharded over 2 ranks" in d["config"]["parallelism"]
+
+
 def test_perf_guard_flags_a_slower_secondary(tmp_path):
     """tools/perf_guard.py: +7 % on a secondary workload (round 2's PoseGNN loss) fails, +1 % passes."""
     import json, subprocess, sys
