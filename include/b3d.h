@@ -358,8 +358,9 @@ int b3d_resnet_encode(const b3d_linear* conv, const b3d_batchnorm* bn, const flo
  * caller's), add [N] (STN3d's flattened identity); each may be NULL.  With `bn` the launch also produces THIS layer's BatchNorm
  * affine out_scale / out_shift [N]: from the batch statistics of y in train mode (`train` != 0, B > 1; running statistics and
  * num_batches_tracked updated as nn.BatchNorm1d does; summed in a fixed order, bitwise reproducible), from the running statistics
- * in eval mode.  The first 256 bytes of the (256-byte aligned) workspace are an arrival counter that must be ZERO on entry; the
- * launch leaves it zero (b3d_fc_ticket_init zeroes it for a fresh workspace).  b3d_affine_relu: out = relu(y * scale + shift),
+ * in eval mode.  The first 256 bytes of the (256-byte aligned) workspace are arrival counters (one per 64-column tile of y, plus one
+ * for the launch: N <= 4032) that must be ZERO on entry; the launch leaves them zero (b3d_fc_ticket_init zeroes them for a fresh
+ * workspace).  b3d_affine_relu: out = relu(y * scale + shift),
  * the last activation of a chain.  Products are bf16x6 (exact three-way bf16 split of both operands, six of the nine piece
  * products on v_mfma_f32_16x16x32_bf16, fp32 accumulation): fp32-class accuracy (~3e-7 relative), not bitwise an fp32 fmaf chain;
  * a +-inf input yields NaN (inf - inf in the split) where torch's Linear yields +-inf.  Batch variance: per-tile sums of squared
