@@ -21,6 +21,7 @@
 // kernel (BatchNorm + add + ReLU of the last block) and the running-statistics update of all nine BatchNorms.
 #include "b3d_common.hpp"
 #include "b3d_launch.hpp"
+#include "b3d_dev.hpp"
 
 namespace b3d {
 namespace {
@@ -38,6 +39,16 @@ __host__ __device__ constexpr int conv_off(int i) { int o = 0; for (int k = 0; k
 constexpr int kWeightFloats = conv_off(kConvs);
 __host__ __device__ constexpr int bn_off(int i) { int o = 0; for (int k = 0; k < i; ++k) o += kBnC[k]; return o; }
 constexpr int kBnChannels = bn_off(kBns);                              // 504
+// Matrix-core form of a convolution (round 4): out[c][pixel] = sum_k W[c][k] col[k][pixel], k = (ci, ky, kx) in the weight's own
+// order, as v_mfma_f32_16x16x32_bf16 tiles with W as the first operand (16 output channels x 32 k) and the im2col columns as the
+// second (32 k x 16 pixels), bf16x6 products (b3d_dev.hpp).  The weights are split ONCE into operand fragments: for k-step ks and
+// channel tile ct, piece p: 64 lanes x 16 bytes, lane l = (channel 16 ct + l % 16, k = 32 ks + 8 (l / 16) + 0..7).
+__host__ __device__ constexpr int conv_kdim(int i) { return kCin[i] * kKer[i] * kKer[i]; }
+__host__ __device__ constexpr int conv_ksteps(int i) { return (conv_kdim(i) + 31) / 32; }
+__host__ __device__ constexpr int conv_ctiles(int i) { return (kCout[i] + 15) / 16; }
+__host__ __device__ constexpr int frag_u4(int i) { return conv_ksteps(i) * conv_ctiles(i) * 3 * 64; }
+__host__ __device__ constexpr int frag_off(int i) { int o = 0; for (int k = 0; k < i; ++k) o += frag_u4(k); return o; }
+constexpr int kFragU4 = frag_off(kConvs);
 constexpr int kResThreads = 1024, kResWaves = 16;                      // every phase kernel
 constexpr int kResMaxGrid = 512;                                       // persistent workgroups of a phase, at most
 
@@ -51,6 +62,7 @@ struct ResArgs {
   int N, train;
   const float* x;          // [N, 3, 32, 32]
   const float* w;          // packed weights: conv i at conv_off(i), [ci][ky][kx][co]
+  const u4v* wfrag;        // bf16x3 operand fragments of every convolution: conv i at frag_off(i) (see conv_kdim above)
   const float* bias[kConvs];
   BnDev bn[kBns];
   double* sums;            // [kBnChannels][2]  batch sums, written by the LAST workgroup of the producing phase
@@ -68,6 +80,34 @@ __global__ __launch_bounds__(256) void resnet_pack_kernel(const PackW p) {
   for (int t = blockIdx.x * 256 + threadIdx.x; t < n; t += gridDim.x * 256) {
     const int co = t % co_n, k = t / co_n;
     p.dst[conv_off(i) + t] = p.src[i][(long)co * inner + k];
+  }
+}
+
+// fragments of all convolutions: one thread per (conv, k-step, channel tile, lane)
+__global__ __launch_bounds__(256) void resnet_pack_frag_kernel(const PackW p, u4v* __restrict__ dst) {
+  const int i = blockIdx.y;
+  const int KD = conv_kdim(i), KST = conv_ksteps(i), CT = conv_ctiles(i), CO = kCout[i];
+  for (int t = blockIdx.x * 256 + threadIdx.x; t < KST * CT * 64; t += gridDim.x * 256) {
+    const int lane = t & 63, ct = (t >> 6) % CT, ks = (t >> 6) / CT;
+    const int c = 16 * ct + (lane & 15), k0 = 32 * ks + 8 * (lane >> 4);
+    unsigned h[8], m[8], l[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float w = (c < CO && k0 + j < KD) ? p.src[i][(long)c * KD + k0 + j] : 0.f;
+      h[j] = __float_as_uint(w);
+      const float r1 = w - __uint_as_float(h[j] & 0xffff0000u);
+      m[j] = __float_as_uint(r1);
+      l[j] = __float_as_uint(r1 - __uint_as_float(m[j] & 0xffff0000u));
+    }
+    u4v q0, q1, q2;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      q0[d] = __builtin_amdgcn_perm(h[2 * d + 1], h[2 * d], 0x07060302u);
+      q1[d] = __builtin_amdgcn_perm(m[2 * d + 1], m[2 * d], 0x07060302u);
+      q2[d] = __builtin_amdgcn_perm(l[2 * d + 1], l[2 * d], 0x07060302u);
+    }
+    u4v* o = dst + frag_off(i) + ((size_t)(ks * CT + ct) * 3) * 64 + lane;
+    o[0] = q0; o[64] = q1; o[128] = q2;
   }
 }
 
@@ -277,6 +317,185 @@ __device__ __forceinline__ void conv_finish(const ResArgs& a, int img0, const fl
 }
 
 
+// ---- convolution on the matrix cores -----------------------------------------------------------------------------------------
+// LDS of one convolution: koff[32 KST] (tile offset of tap k: (ci HP + ky) HP + kx; 0 behind the last tap, where the weights are
+// zero), wbuf[2][CT * 192] u4v (the weight fragments of the current and the next k-step, shared by all wavefronts), and in train
+// mode wstat[waves][2 COUT] (per-wavefront sums: every address has ONE writer, the rows are added in wavefront order).
+template <int CI, int HP>
+__device__ __forceinline__ void conv_koff_fill(int* koff) {
+  constexpr int K = kKer[CI], KD = conv_kdim(CI), KST = conv_ksteps(CI);
+  for (int k = threadIdx.x; k < 32 * KST; k += blockDim.x) {
+    int o = 0;
+    if (k < KD) { const int ci = k / (K * K), r = k - ci * (K * K), ky = r / K, kx = r - ky * K; o = (ci * HP + ky) * HP + kx; }
+    koff[k] = o;
+  }
+}
+__device__ __forceinline__ Bf3 split8(const float (&v)[8]) {
+  unsigned h[8], m[8], l[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    h[j] = __float_as_uint(v[j]);
+    const float r1 = v[j] - __uint_as_float(h[j] & 0xffff0000u);
+    m[j] = __float_as_uint(r1);
+    l[j] = __float_as_uint(r1 - __uint_as_float(m[j] & 0xffff0000u));
+  }
+  u4v q0, q1, q2;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    q0[d] = __builtin_amdgcn_perm(h[2 * d + 1], h[2 * d], 0x07060302u);
+    q1[d] = __builtin_amdgcn_perm(m[2 * d + 1], m[2 * d], 0x07060302u);
+    q2[d] = __builtin_amdgcn_perm(l[2 * d + 1], l[2 * d], 0x07060302u);
+  }
+  return Bf3{__builtin_bit_cast(bf8, q0), __builtin_bit_cast(bf8, q1), __builtin_bit_cast(bf8, q2)};
+}
+// One convolution of a crop group.  Wavefront w takes the pixel tiles w, w + NW, ... (16 consecutive (crop, pixel) pairs each; at
+// most TPW of them) and ALL channel tiles, so that the im2col fragment of a (tile, k-step) -- 8 gathered LDS words per lane, split
+// into three bf16 pieces -- is built once.  Every k-step: the weight fragments of step ks + 1 travel global -> registers under the
+// MFMAs of step ks and are parked in the other half of wbuf behind them; ONE barrier per k-step.
+// S: stride; OFF: 0 for a padded convolution (pad 1), 1 for an unpadded one; HO: output height = width.
+// z == nullptr: the raw output (+ bias) goes to the LDS tile `ztile` [crop][COUT][ZP][ZP] at (+1, +1) instead (P0's first layer).
+template <int CI, int HP, int S, int OFF, int HO, int CROPS, int NTS, int CSPLIT = 1, int ZP = 0>
+__device__ __forceinline__ void conv_mfma(const ResArgs& a, int img0, const float* tiles, const int* koff, u4v* wbuf, const float* bias,
+                                          float* z, float* wstat, float* ztile = nullptr) {
+  constexpr int CIN = kCin[CI], COUT = kCout[CI], KST = conv_ksteps(CI), CT = conv_ctiles(CI);
+  constexpr int PIX = HO * HO, NT = (CROPS * PIX + 15) / 16, TPW = (NT + NTS - 1) / NTS, FR = CT * 192;
+  constexpr int NW = NTS, CTW = CT / CSPLIT;                 // pixel-tile slots; channel tiles per wavefront
+  static_assert(CT % CSPLIT == 0, "channel tiles divide over the channel groups");
+  const int wave_id = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63, n = lane & 15, kq = lane >> 4;
+  // wavefront -> (pixel-tile slot, channel group); wavefronts past NTS * CSPLIT only take part in the barriers and the weight loads
+  const bool computes = wave_id < NTS * CSPLIT;
+  const int wave = computes ? wave_id % NTS : 0, ct0 = computes ? (wave_id / NTS) * CTW : 0;
+  const u4v* wf = a.wfrag + frag_off(CI);
+  // this lane's pixel (as the column of the second operand) in each of its tiles
+  const float* base[TPW];
+  bool act[TPW];
+  int imv[TPW], pxv[TPW];
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    const int gp = (wave + NW * i) * 16 + n;
+    act[i] = wave + NW * i < NT && gp < CROPS * PIX;
+    const int im = act[i] ? gp / PIX : 0, px = act[i] ? gp % PIX : 0;
+    imv[i] = im; pxv[i] = px;
+    base[i] = tiles + im * (CIN * HP * HP) + ((px / HO) * S + OFF) * HP + (px % HO) * S + OFF;
+  }
+  v4f acc[TPW][CTW];
+#pragma unroll
+  for (int i = 0; i < TPW; ++i)
+#pragma unroll
+    for (int ct = 0; ct < CTW; ++ct) acc[i][ct] = v4f{0.f, 0.f, 0.f, 0.f};
+  constexpr int LPT = (FR + kResThreads - 1) / kResThreads;  // fragment words per thread and k-step (6 channel tiles: 1,152 words)
+  auto wload = [&](int ks, u4v (&r)[LPT]) {
+#pragma unroll
+    for (int u = 0; u < LPT; ++u) {
+      const int t = threadIdx.x + u * kResThreads;
+      r[u] = (t < FR && ks < KST) ? wf[(size_t)ks * FR + t] : u4v{0u, 0u, 0u, 0u};
+    }
+  };
+  auto wstore = [&](int ks, const u4v (&r)[LPT]) {
+#pragma unroll
+    for (int u = 0; u < LPT; ++u) {
+      const int t = threadIdx.x + u * kResThreads;
+      if (t < FR && ks < KST) wbuf[(ks & 1) * FR + t] = r[u];
+    }
+  };
+  u4v pre[LPT], pre2[LPT];
+  wload(0, pre);
+  wstore(0, pre);
+  // software pipeline: the weight fragments of step ks + 2 are in flight (registers) during step ks, the tile offsets of step ks + 2
+  // and the gathered tile words of step ks + 1 are fetched under the split + MFMAs of step ks
+  wload(1, pre);
+  auto offsets = [&](int ks, int4& o0, int4& o1) {
+    const int kk = ks < KST ? ks : KST - 1;
+    o0 = *reinterpret_cast<const int4*>(koff + 32 * kk + 8 * kq);
+    o1 = *reinterpret_cast<const int4*>(koff + 32 * kk + 8 * kq + 4);
+  };
+  auto gather = [&](const int4& o0, const int4& o1, float (&v)[TPW][8]) {
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+      const float* b = base[i];
+      v[i][0] = b[o0.x]; v[i][1] = b[o0.y]; v[i][2] = b[o0.z]; v[i][3] = b[o0.w];
+      v[i][4] = b[o1.x]; v[i][5] = b[o1.y]; v[i][6] = b[o1.z]; v[i][7] = b[o1.w];
+    }
+  };
+  int4 oa, ob;
+  float vc[TPW][8];
+  offsets(0, oa, ob);
+  gather(oa, ob, vc);
+  offsets(1, oa, ob);
+  __syncthreads();
+#ifdef RN_NOCONV
+  if (false)
+#endif
+#pragma unroll 1
+  for (int ks = 0; ks < KST; ++ks) {
+    const u4v* cur = wbuf + (ks & 1) * FR;
+    wload(ks + 2, pre2);
+    float vn[TPW][8];
+    gather(oa, ob, vn);                                      // step ks + 1 (the last step gathers its own taps again: unused)
+    offsets(ks + 2, oa, ob);
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+      if (computes && wave + NW * i < NT) {                  // wave-uniform
+        const Bf3 col = split8(vc[i]);
+#pragma unroll
+        for (int ct = 0; ct < CTW; ++ct) {
+          Bf3 w;
+          w.p0 = __builtin_bit_cast(bf8, cur[((ct0 + ct) * 3 + 0) * 64 + lane]);
+          w.p1 = __builtin_bit_cast(bf8, cur[((ct0 + ct) * 3 + 1) * 64 + lane]);
+          w.p2 = __builtin_bit_cast(bf8, cur[((ct0 + ct) * 3 + 2) * 64 + lane]);
+          acc[i][ct] = bf_mfma6(w, col, acc[i][ct]);
+        }
+      }
+    }
+    wstore(ks + 1, pre);
+#pragma unroll
+    for (int u = 0; u < LPT; ++u) pre[u] = pre2[u];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) vc[i][j] = vn[i][j];
+    __syncthreads();
+  }
+  // D: lane (n, kq) holds channels 16 ct + 4 kq + r of pixel n
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    if (computes && wave + NW * i < NT) {
+      const bool valid = act[i] && img0 + imv[i] < a.N;
+#pragma unroll
+      for (int ct = 0; ct < CTW; ++ct) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = 16 * (ct0 + ct) + 4 * kq + r;
+          {
+            const bool cok = c < COUT;
+            const float val = cok ? acc[i][ct][r] + bias[c] : 0.f;
+            if constexpr (ZP > 0) {
+              if (act[i] && cok) ztile[(imv[i] * COUT + c) * (ZP * ZP) + (pxv[i] / HO + 1) * ZP + (pxv[i] % HO) + 1] = val;
+            } else {
+              if (valid && cok) z[((long)(img0 + imv[i]) * COUT + c) * PIX + pxv[i]] = val;
+              if (a.train) {
+                const float sv = valid ? val : 0.f;
+                const float s1 = row_sum16(sv), s2 = row_sum16(sv * sv);
+                if (n == 0 && cok) { wstat[wave_id * (2 * COUT) + 2 * c] += s1; wstat[wave_id * (2 * COUT) + 2 * c + 1] += s2; }
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+}
+// stat[i] = sum over the wavefront rows of wstat, in wavefront order (call behind a barrier; one more before stat is read)
+template <int COUT, int NW>
+__device__ __forceinline__ void wstat_reduce(const float* wstat, float* stat) {
+  for (int i = threadIdx.x; i < 2 * COUT; i += blockDim.x) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s += wstat[w * (2 * COUT) + i];
+    stat[i] = s;
+  }
+}
+
 // ---- P0: conv -> block1.conv1 (+ statistics) and block1.downsample (+ statistics): 2 crops, 16 wavefronts ------------------
 constexpr int kP0Crops = 2;
 constexpr int kP0X = 3 * 34 * 34, kP0A = 12 * 18 * 18;
@@ -358,133 +577,162 @@ __device__ __forceinline__ void stage_tiles(const ResArgs& a, int img0, const fl
   }
 }
 
-// P1: block1.conv2 24 -> 24, k4 s2 p1, 8 -> 4.  4 crops; 4 groups of 6 channels x 4 slices of 6 input channels.
-constexpr int kP1Crops = 4;
-constexpr int kP1Tiles = kP1Crops * 24 * 100, kP1Part = 4 * kP1Crops * 24 * 16;
-constexpr int kP1Lds = (kP1Tiles + kP1Part + 48 + 48) * 4;
+// P1: block1.conv2 24 -> 24, k4 s2 p1, 8 -> 4, on the matrix cores: 12 crops per workgroup = 12 pixel tiles (one per wavefront,
+// four wavefronts only load weights); K = 384 in 12 k-steps, 2 channel tiles.
+constexpr int kP1Crops = 12;
+constexpr int kP1Tiles = kP1Crops * 24 * 100;
+constexpr int kP1Lds = kP1Tiles * 4 + 2 * conv_ctiles(2) * 192 * 16 + 32 * conv_ksteps(2) * 4 + (48 + 48 + kResWaves * 48) * 4;
 __global__ __launch_bounds__(kResThreads) void resnet_p1_kernel(const ResArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* tiles = smem;
-  float* part = tiles + kP1Tiles;
-  float* aff = part + kP1Part;
+  u4v* wbuf = reinterpret_cast<u4v*>(tiles + kP1Tiles);
+  int* koff = reinterpret_cast<int*>(wbuf + 2 * conv_ctiles(2) * 192);
+  float* aff = reinterpret_cast<float*>(koff + 32 * conv_ksteps(2));
   float* stat = aff + 48;
+  float* wstat = stat + 48;
   for (int i = threadIdx.x; i < kP1Tiles; i += kResThreads) tiles[i] = 0.f;
-  for (int i = threadIdx.x; i < 48; i += kResThreads) stat[i] = 0.f;
+  for (int i = threadIdx.x; i < 48 + kResWaves * 48; i += kResThreads) stat[i] = 0.f;
+  conv_koff_fill<2, 10>(koff);
   __syncthreads();
   bn_affine_to_lds(a, 0, aff);
-  const int wave = uniform(threadIdx.x >> 6);
   const int groups = (a.N + kP1Crops - 1) / kP1Crops;
   for (int g = blockIdx.x; g < groups; g += gridDim.x) {
     const int img0 = g * kP1Crops;
     __syncthreads();
     stage_tiles<kP1Crops, 24, 8, 10, kResThreads>(a, img0, a.z1, aff, nullptr, nullptr, tiles);
     __syncthreads();
-    conv_part<24, 10, 4, 2, 0, 4, 24, 6, 16, kP1Crops, 4>(tiles, a.w + conv_off(2), part, wave & 3, wave >> 2);
-    __syncthreads();
-    conv_finish<4, 24, 16, kP1Crops, 4>(a, img0, part, a.bias[2], a.z2, stat, wave, kResWaves);
+    conv_mfma<2, 10, 2, 0, 4, kP1Crops, 12>(a, img0, tiles, koff, wbuf, a.bias[2], a.z2, wstat);
   }
-  if (a.train) { __syncthreads(); stat_flush(a, 1, stat, reinterpret_cast<double*>(smem)); }
+  if (a.train) {
+    __syncthreads();
+    wstat_reduce<24, kResWaves>(wstat, stat);
+    __syncthreads();
+    stat_flush(a, 1, stat, reinterpret_cast<double*>(smem));
+  }
 }
 
-// P2: y1 = relu(bn2(z2) + bn_d(zd1)); block2.conv1 24 -> 48 k3 s1 p1 and block2.downsample 24 -> 48 k1, 4 -> 4.
-// 4 crops; 4 groups of 12 channels x 4 slices of 6 input channels (both convolutions).
-constexpr int kP2Crops = 4;
-constexpr int kP2Tiles = kP2Crops * 24 * 36, kP2Part = 4 * kP2Crops * 48 * 16;
-constexpr int kP2Lds = (kP2Tiles + kP2Part + 48 + 48 + 96 + 96) * 4;
+// P2: y1 = relu(bn2(z2) + bn_d(zd1)); block2.conv1 24 -> 48 k3 s1 p1 and block2.downsample 24 -> 48 k1, 4 -> 4, on the matrix
+// cores: 16 crops = 16 pixel tiles, one per wavefront; K = 216 in 7 k-steps and K = 24 in one; 3 channel tiles.
+constexpr int kP2Crops = 16;
+constexpr int kP2Tiles = kP2Crops * 24 * 36;
+constexpr int kP2Lds = kP2Tiles * 4 + 2 * 3 * 192 * 16 + 32 * (conv_ksteps(4) + conv_ksteps(6)) * 4 + (48 + 48 + 96 + 96 + 2 * kResWaves * 96) * 4;
 __global__ __launch_bounds__(kResThreads) void resnet_p2_kernel(const ResArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* tiles = smem;
-  float* part = tiles + kP2Tiles;
-  float* affA = part + kP2Part;
+  u4v* wbuf = reinterpret_cast<u4v*>(tiles + kP2Tiles);
+  int* koff1 = reinterpret_cast<int*>(wbuf + 2 * 3 * 192);
+  int* koffd = koff1 + 32 * conv_ksteps(4);
+  float* affA = reinterpret_cast<float*>(koffd + 32 * conv_ksteps(6));
   float* affB = affA + 48;
   float* stat1 = affB + 48;
   float* statd = stat1 + 96;
+  float* wstat1 = statd + 96;
+  float* wstatd = wstat1 + kResWaves * 96;
   for (int i = threadIdx.x; i < kP2Tiles; i += kResThreads) tiles[i] = 0.f;
-  for (int i = threadIdx.x; i < 192; i += kResThreads) stat1[i] = 0.f;
+  for (int i = threadIdx.x; i < 192 + 2 * kResWaves * 96; i += kResThreads) stat1[i] = 0.f;
+  conv_koff_fill<4, 6>(koff1);
+  conv_koff_fill<6, 6>(koffd);
   __syncthreads();
   bn_affine_to_lds(a, 1, affA);
   bn_affine_to_lds(a, 2, affB);
-  const int wave = uniform(threadIdx.x >> 6);
   const int groups = (a.N + kP2Crops - 1) / kP2Crops;
   for (int g = blockIdx.x; g < groups; g += gridDim.x) {
     const int img0 = g * kP2Crops;
     __syncthreads();
     stage_tiles<kP2Crops, 24, 4, 6, kResThreads>(a, img0, a.z2, affA, a.zd1, affB, tiles);
     __syncthreads();
-    conv_part<24, 6, 3, 1, 0, 4, 48, 12, 16, kP2Crops, 4>(tiles, a.w + conv_off(4), part, wave & 3, wave >> 2);
-    __syncthreads();
-    conv_finish<4, 48, 16, kP2Crops, 4>(a, img0, part, a.bias[4], a.z3, stat1, wave, kResWaves);
-    __syncthreads();
-    conv_part<24, 6, 1, 1, 1, 4, 48, 12, 16, kP2Crops, 4>(tiles, a.w + conv_off(6), part, wave & 3, wave >> 2);
-    __syncthreads();
-    conv_finish<4, 48, 16, kP2Crops, 4>(a, img0, part, a.bias[6], a.zd2, statd, wave, kResWaves);
+    conv_mfma<4, 6, 1, 0, 4, kP2Crops, 16>(a, img0, tiles, koff1, wbuf, a.bias[4], a.z3, wstat1);
+    conv_mfma<6, 6, 1, 1, 4, kP2Crops, 16>(a, img0, tiles, koffd, wbuf, a.bias[6], a.zd2, wstatd);
   }
-  if (a.train) { __syncthreads(); stat_flush(a, 3, stat1, reinterpret_cast<double*>(smem)); stat_flush(a, 5, statd, reinterpret_cast<double*>(smem)); }
+  if (a.train) {
+    __syncthreads();
+    wstat_reduce<48, kResWaves>(wstat1, stat1);
+    wstat_reduce<48, kResWaves>(wstatd, statd);
+    __syncthreads();
+    stat_flush(a, 3, stat1, reinterpret_cast<double*>(smem));
+    stat_flush(a, 5, statd, reinterpret_cast<double*>(smem));
+  }
 }
 
-// P3: block2.conv2 48 -> 48 k3 s1 p1 on relu(bn1(z3)).  4 crops; 4 groups of 12 channels x 4 slices of 12 input channels.
-constexpr int kP3Crops = 4;
-constexpr int kP3Tiles = kP3Crops * 48 * 36, kP3Part = 4 * kP3Crops * 48 * 16;
-constexpr int kP3Lds = (kP3Tiles + kP3Part + 96 + 96) * 4;
+// P3: block2.conv2 48 -> 48 k3 s1 p1 on relu(bn1(z3)), on the matrix cores: 16 crops per workgroup = 16 pixel tiles, one per
+// wavefront; K = 432 in 14 k-steps, 3 channel tiles.
+constexpr int kP3Crops = 16;
+constexpr int kP3Tiles = kP3Crops * 48 * 36;
+constexpr int kP3Lds = kP3Tiles * 4 + 2 * conv_ctiles(5) * 192 * 16 + 32 * conv_ksteps(5) * 4 + (96 + 96 + kResWaves * 96) * 4;
 __global__ __launch_bounds__(kResThreads) void resnet_p3_kernel(const ResArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* tiles = smem;
-  float* part = tiles + kP3Tiles;
-  float* aff = part + kP3Part;
+  u4v* wbuf = reinterpret_cast<u4v*>(tiles + kP3Tiles);
+  int* koff = reinterpret_cast<int*>(wbuf + 2 * conv_ctiles(5) * 192);
+  float* aff = reinterpret_cast<float*>(koff + 32 * conv_ksteps(5));
   float* stat = aff + 96;
+  float* wstat = stat + 96;
   for (int i = threadIdx.x; i < kP3Tiles; i += kResThreads) tiles[i] = 0.f;
-  for (int i = threadIdx.x; i < 96; i += kResThreads) stat[i] = 0.f;
+  for (int i = threadIdx.x; i < 96 + kResWaves * 96; i += kResThreads) stat[i] = 0.f;
+  conv_koff_fill<5, 6>(koff);
   __syncthreads();
   bn_affine_to_lds(a, 3, aff);
-  const int wave = uniform(threadIdx.x >> 6);
   const int groups = (a.N + kP3Crops - 1) / kP3Crops;
   for (int g = blockIdx.x; g < groups; g += gridDim.x) {
     const int img0 = g * kP3Crops;
     __syncthreads();
+#ifndef RN_NOSTAGE
     stage_tiles<kP3Crops, 48, 4, 6, kResThreads>(a, img0, a.z3, aff, nullptr, nullptr, tiles);
+#endif
     __syncthreads();
-    conv_part<48, 6, 3, 1, 0, 4, 48, 12, 16, kP3Crops, 4>(tiles, a.w + conv_off(5), part, wave & 3, wave >> 2);
-    __syncthreads();
-    conv_finish<4, 48, 16, kP3Crops, 4>(a, img0, part, a.bias[5], a.z4, stat, wave, kResWaves);
+    conv_mfma<5, 6, 1, 0, 4, kP3Crops, kResWaves>(a, img0, tiles, koff, wbuf, a.bias[5], a.z4, wstat);
   }
-  if (a.train) { __syncthreads(); stat_flush(a, 4, stat, reinterpret_cast<double*>(smem)); }
+  if (a.train) {
+    __syncthreads();
+    wstat_reduce<48, kResWaves>(wstat, stat);
+    __syncthreads();
+    stat_flush(a, 4, stat, reinterpret_cast<double*>(smem));
+  }
 }
 
-// P4: y2 = relu(bn2(z4) + bn_d(zd2)); block3.conv1 48 -> 96 k3 s2 p1 (4 -> 2) and block3.downsample 48 -> 96 k3 s2 p0 (4 -> 1).
-// 16 crops in 5x5 tiles (no tap reaches the bottom / right border), lane <-> (crop, pixel of the 2x2 output); 8 groups of
-// 12 channels x 2 slices of 24 input channels.
+// P4: y2 = relu(bn2(z4) + bn_d(zd2)); block3.conv1 48 -> 96 k3 s2 p1 (4 -> 2) and block3.downsample 48 -> 96 k3 s2 p0 (4 -> 1), on
+// the matrix cores.  16 crops in 5x5 tiles (no tap reaches the bottom / right border): conv1 = 64 pixels = 4 pixel tiles x 3 groups of
+// 2 channel tiles (12 wavefronts), downsample = 16 pixels = 1 pixel tile x 6 channel tiles (6 wavefronts); K = 432 in 14 k-steps.
 constexpr int kP4Crops = 16;
-constexpr int kP4Tiles = kP4Crops * 48 * 25, kP4Part = 2 * kP4Crops * 96 * 4;
-constexpr int kP4Lds = (kP4Tiles + kP4Part + 96 + 96 + 192 + 192) * 4;
+constexpr int kP4Tiles = kP4Crops * 48 * 25;
+constexpr int kP4Lds = kP4Tiles * 4 + 2 * 6 * 192 * 16 + 32 * (conv_ksteps(7) + conv_ksteps(9)) * 4 + (96 + 96 + 192 + 192 + 2 * kResWaves * 192) * 4;
+static_assert(kP4Lds <= 160 * 1024, "LDS of one CU");
 __global__ __launch_bounds__(kResThreads) void resnet_p4_kernel(const ResArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* tiles = smem;
-  float* part = tiles + kP4Tiles;
-  float* affA = part + kP4Part;
+  u4v* wbuf = reinterpret_cast<u4v*>(tiles + kP4Tiles);
+  int* koff1 = reinterpret_cast<int*>(wbuf + 2 * 6 * 192);
+  int* koffd = koff1 + 32 * conv_ksteps(7);
+  float* affA = reinterpret_cast<float*>(koffd + 32 * conv_ksteps(9));
   float* affB = affA + 96;
   float* stat1 = affB + 96;
   float* statd = stat1 + 192;
+  float* wstat1 = statd + 192;
+  float* wstatd = wstat1 + kResWaves * 192;
   for (int i = threadIdx.x; i < kP4Tiles; i += kResThreads) tiles[i] = 0.f;
-  for (int i = threadIdx.x; i < 384; i += kResThreads) stat1[i] = 0.f;
+  for (int i = threadIdx.x; i < 384 + 2 * kResWaves * 192; i += kResThreads) stat1[i] = 0.f;
+  conv_koff_fill<7, 5>(koff1);
+  conv_koff_fill<9, 5>(koffd);
   __syncthreads();
   bn_affine_to_lds(a, 4, affA);
   bn_affine_to_lds(a, 5, affB);
-  const int wave = uniform(threadIdx.x >> 6);
   const int groups = (a.N + kP4Crops - 1) / kP4Crops;
   for (int g = blockIdx.x; g < groups; g += gridDim.x) {
     const int img0 = g * kP4Crops;
     __syncthreads();
     stage_tiles<kP4Crops, 48, 4, 5, kResThreads>(a, img0, a.z4, affA, a.zd2, affB, tiles);
     __syncthreads();
-    conv_part<48, 5, 3, 2, 0, 2, 96, 12, 4, kP4Crops, 2>(tiles, a.w + conv_off(7), part, wave & 7, wave >> 3);
-    __syncthreads();
-    conv_finish<2, 96, 4, kP4Crops, 2>(a, img0, part, a.bias[7], a.z5, stat1, wave, kResWaves);
-    __syncthreads();
-    conv_part<48, 5, 3, 2, 1, 1, 96, 12, 4, kP4Crops, 2>(tiles, a.w + conv_off(9), part, wave & 7, wave >> 3);
-    __syncthreads();
-    conv_finish<1, 96, 4, kP4Crops, 2>(a, img0, part, a.bias[9], a.zd3, statd, wave, kResWaves);
+    conv_mfma<7, 5, 2, 0, 2, kP4Crops, 4, 3>(a, img0, tiles, koff1, wbuf, a.bias[7], a.z5, wstat1);
+    conv_mfma<9, 5, 2, 1, 1, kP4Crops, 1, 6>(a, img0, tiles, koffd, wbuf, a.bias[9], a.zd3, wstatd);
   }
-  if (a.train) { __syncthreads(); stat_flush(a, 6, stat1, reinterpret_cast<double*>(smem)); stat_flush(a, 8, statd, reinterpret_cast<double*>(smem)); }
+  if (a.train) {
+    __syncthreads();
+    wstat_reduce<96, kResWaves>(wstat1, stat1);
+    wstat_reduce<96, kResWaves>(wstatd, statd);
+    __syncthreads();
+    stat_flush(a, 6, stat1, reinterpret_cast<double*>(smem));
+    stat_flush(a, 8, statd, reinterpret_cast<double*>(smem));
+  }
 }
 
 // P5: block3.conv2 96 -> 96 k3 s2 p1 on relu(bn1(z5)), 2 -> 1: only the taps (1..2, 1..2) meet the 2x2 input, a 384-wide
@@ -584,8 +832,8 @@ using namespace b3d;
 
 extern "C" size_t b3d_resnet_encode_workspace_bytes(int32_t N) {
   if (N < 0) N = 0;
-  return 256 + (size_t)kWeightFloats * 4 + 256 + (size_t)kBnChannels * 2 * 8 + 64 + 256 + (size_t)kResMaxGrid * 2 * kBnChannels * 4 + 256
-         + (size_t)N * kActFloatsPerCrop * 4 + 64;
+  return 256 + (size_t)kWeightFloats * 4 + 256 + (size_t)kFragU4 * 16 + 256 + (size_t)kBnChannels * 2 * 8 + 64 + 256
+         + (size_t)kResMaxGrid * 2 * kBnChannels * 4 + 256 + (size_t)N * kActFloatsPerCrop * 4 + 64;
 }
 
 extern "C" int b3d_resnet_encode(const b3d_linear* conv, const b3d_batchnorm* bn, const float* x, int32_t N, int32_t train,
@@ -605,11 +853,12 @@ extern "C" int b3d_resnet_encode(const b3d_linear* conv, const b3d_batchnorm* bn
   auto align = [](uintptr_t p) { return (p + 255) & ~(uintptr_t)255; };
   uintptr_t p = align((uintptr_t)workspace);
   float* wp = (float*)p; p = align(p + (size_t)kWeightFloats * 4);
+  u4v* wfrag = (u4v*)p; p = align(p + (size_t)kFragU4 * 16);
   double* sums = (double*)p; p = align(p + (size_t)kBnChannels * 16 + 64);      // + the arrival counters behind the sums
   float* part = (float*)p; p = align(p + (size_t)kResMaxGrid * 2 * kBnChannels * 4);
   float* act = (float*)p;
   ResArgs a;
-  a.N = N; a.train = train ? 1 : 0; a.x = x; a.w = wp; a.sums = sums; a.part = part; a.tickets = (unsigned*)(sums + 2 * kBnChannels); a.out = out;
+  a.N = N; a.train = train ? 1 : 0; a.x = x; a.w = wp; a.wfrag = wfrag; a.sums = sums; a.part = part; a.tickets = (unsigned*)(sums + 2 * kBnChannels); a.out = out;
   for (int i = 0; i < kConvs; ++i) a.bias[i] = (const float*)conv[i].b;
   for (int i = 0; i < kBns; ++i) {
     a.bn[i].gamma = bn[i].gamma; a.bn[i].beta = bn[i].beta;
@@ -631,6 +880,8 @@ extern "C" int b3d_resnet_encode(const b3d_linear* conv, const b3d_batchnorm* bn
   pw.dst = wp;
   hipLaunchKernelGGL(resnet_pack_kernel, dim3(16, kConvs), dim3(256), 0, stream, pw);
   B3D_TRY(launch_check("resnet_pack_kernel"));
+  hipLaunchKernelGGL(resnet_pack_frag_kernel, dim3(8, kConvs), dim3(256), 0, stream, pw, wfrag);
+  B3D_TRY(launch_check("resnet_pack_frag_kernel"));
   if (train) B3D_HIP_CHECK(hipMemsetAsync(sums, 0, (size_t)kBnChannels * 16 + 64, stream));
   // persistent workgroups (as many as are resident at once): the tile zero fill and the BatchNorm affine are per workgroup
   auto grid = [&](int crops, int resident = kResMaxGrid) { const int g = (N + crops - 1) / crops; return dim3((unsigned)(g < resident ? g : resident)); };

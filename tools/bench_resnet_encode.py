@@ -6,7 +6,8 @@ import time
 
 import torch
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from batch3dmot_amd import encoders  # noqa: E402
 
 
