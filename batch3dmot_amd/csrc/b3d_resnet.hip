@@ -10,15 +10,23 @@
 //   * stages its input crops into zero-bordered LDS tiles, applying the producer's BatchNorm (scale / shift formed from
 //     the batch sums the previous phase accumulated, or from the running statistics in eval mode), the residual add and
 //     the ReLU on the way -- BatchNorm / ReLU / add never run as kernels of their own;
-//   * evaluates its convolutions as direct convolutions on the vector ALUs: lanes <-> (crop, output pixel), a
-//     wavefront <-> a group of output channels, so that the weights are wave-uniform and arrive through the scalar
-//     cache (s_load, v_fmac with an SGPR operand); one LDS read of an input value feeds all channels of the group;
-//   * writes the RAW convolution outputs and accumulates their per-channel sum and sum of squares (wavefront reduction
-//     -> LDS -> a per-workgroup row of partial sums -> added in block order by the last workgroup to arrive: bitwise
-//     reproducible).
-// Phases (crops per workgroup): P0 conv + block1.conv1 + block1.downsample (2), P1 block1.conv2 (4), P2 block2.conv1 +
-// downsample (4), P3 block2.conv2 (4), P4 block3.conv1 + downsample (16), P5 block3.conv2 (64), then the output
+//   * evaluates its convolutions on the MATRIX CORES (round 4; rounds 1-3: direct convolutions on the vector ALUs with the weights
+//     in SGPRs, 0 % MFMA, 0.42 ms for 3,000 crops and a chain of dependent scalar-load round trips per input channel): an
+//     implicit GEMM out[c][pixel] = sum_k W[c][k] col[k][pixel] with k = (ci, ky, kx) in the weight's own order, as
+//     v_mfma_f32_16x16x32_bf16 tiles in the bf16x6 form of b3d_dev.hpp (fp32-class accuracy).  The weights are split once per call
+//     into operand fragments (resnet_pack_frag_kernel) and travel global -> registers -> a two-slot LDS buffer one k-step ahead,
+//     shared by the 16 wavefronts; a wavefront owns 16 (crop, pixel) pairs, gathers the 8 tile words of its im2col fragment per
+//     k-step from LDS through a per-convolution tap-offset table, splits them into three bf16 pieces and issues 6 MFMAs per
+//     16 output channels; one barrier per k-step;
+//   * writes the RAW convolution outputs and accumulates their per-channel sum and sum of squares (16-lane DPP reduction ->
+//     one row of sums per WAVEFRONT in LDS, every address with a single writer -> rows added in wavefront order -> a
+//     per-workgroup row of partial sums -> added in block order by the last workgroup to arrive: bitwise reproducible).
+// Phases (crops per workgroup): P0 conv + block1.conv1 + block1.downsample (2), P1 block1.conv2 (12), P2 block2.conv1 +
+// downsample (16), P3 block2.conv2 (16), P4 block3.conv1 + downsample (16), P5 block3.conv2 (16), then the output
 // kernel (BatchNorm + add + ReLU of the last block) and the running-statistics update of all nine BatchNorms.
+// Measured alone on 3,000 crops (tools/resnet_phase_times.sh): 119 + 27 + 30 + 31 + 49 + 18 us (VALU form: 125 + 36 + 46 + 60 + 65 + 35);
+// what is left per k-step is the split of the gathered words on the vector ALUs (~100 instructions per wavefront, 16 wavefronts
+// per CU) and, per phase, ~10 us of launch + tile zero fill + BatchNorm affine + statistics hand-off.
 #include "b3d_common.hpp"
 #include "b3d_launch.hpp"
 #include "b3d_dev.hpp"
@@ -34,16 +42,17 @@ constexpr int kCout[kConvs] = {12, 24, 24, 24, 48, 48, 48, 96, 96, 96};
 constexpr int kKer[kConvs] = {4, 4, 4, 5, 3, 3, 1, 3, 3, 3};
 constexpr int kBnC[kBns] = {24, 24, 24, 48, 48, 48, 96, 96, 96};
 constexpr int kBnPix[kBns] = {64, 16, 16, 16, 16, 16, 4, 1, 1};        // output pixels per crop behind each BatchNorm
-__host__ __device__ constexpr int conv_floats(int i) { return kCin[i] * kKer[i] * kKer[i] * kCout[i]; }
-__host__ __device__ constexpr int conv_off(int i) { int o = 0; for (int k = 0; k < i; ++k) o += conv_floats(k); return o; }
-constexpr int kWeightFloats = conv_off(kConvs);
 __host__ __device__ constexpr int bn_off(int i) { int o = 0; for (int k = 0; k < i; ++k) o += kBnC[k]; return o; }
 constexpr int kBnChannels = bn_off(kBns);                              // 504
 // Matrix-core form of a convolution (round 4): out[c][pixel] = sum_k W[c][k] col[k][pixel], k = (ci, ky, kx) in the weight's own
 // order, as v_mfma_f32_16x16x32_bf16 tiles with W as the first operand (16 output channels x 32 k) and the im2col columns as the
 // second (32 k x 16 pixels), bf16x6 products (b3d_dev.hpp).  The weights are split ONCE into operand fragments: for k-step ks and
 // channel tile ct, piece p: 64 lanes x 16 bytes, lane l = (channel 16 ct + l % 16, k = 32 ks + 8 (l / 16) + 0..7).
-__host__ __device__ constexpr int conv_kdim(int i) { return kCin[i] * kKer[i] * kKer[i]; }
+// (block3.conv2, i = 8, is a k3 s2 p1 convolution of a 2 x 2 input to ONE output pixel: only the taps (1..2, 1..2) meet the input, so
+// its k runs over (ci, y, x) of the 2 x 2 input -- 384 instead of 864.)
+__host__ __device__ constexpr int conv_kdim(int i) { return i == 8 ? kCin[8] * 4 : kCin[i] * kKer[i] * kKer[i]; }
+// index of tap k of convolution i inside a torch weight row [ci][ky][kx]
+__host__ __device__ constexpr int conv_tap_index(int i, int k) { return i == 8 ? ((k >> 2) * 9 + (1 + ((k >> 1) & 1)) * 3 + 1 + (k & 1)) : k; }
 __host__ __device__ constexpr int conv_ksteps(int i) { return (conv_kdim(i) + 31) / 32; }
 __host__ __device__ constexpr int conv_ctiles(int i) { return (kCout[i] + 15) / 16; }
 __host__ __device__ constexpr int frag_u4(int i) { return conv_ksteps(i) * conv_ctiles(i) * 3 * 64; }
@@ -61,7 +70,6 @@ struct BnDev {
 struct ResArgs {
   int N, train;
   const float* x;          // [N, 3, 32, 32]
-  const float* w;          // packed weights: conv i at conv_off(i), [ci][ky][kx][co]
   const u4v* wfrag;        // bf16x3 operand fragments of every convolution: conv i at frag_off(i) (see conv_kdim above)
   const float* bias[kConvs];
   BnDev bn[kBns];
@@ -72,17 +80,7 @@ struct ResArgs {
   float* out;              // [N, 96]
 };
 
-// ---- weight transposition [co][ci][ky][kx] -> [ci][ky][kx][co] ------------------------------------------------------------
-struct PackW { const float* src[kConvs]; float* dst; };
-__global__ __launch_bounds__(256) void resnet_pack_kernel(const PackW p) {
-  const int i = blockIdx.y;
-  const int n = conv_floats(i), co_n = kCout[i], inner = kCin[i] * kKer[i] * kKer[i];
-  for (int t = blockIdx.x * 256 + threadIdx.x; t < n; t += gridDim.x * 256) {
-    const int co = t % co_n, k = t / co_n;
-    p.dst[conv_off(i) + t] = p.src[i][(long)co * inner + k];
-  }
-}
-
+struct PackW { const float* src[kConvs]; };
 // fragments of all convolutions: one thread per (conv, k-step, channel tile, lane)
 __global__ __launch_bounds__(256) void resnet_pack_frag_kernel(const PackW p, u4v* __restrict__ dst) {
   const int i = blockIdx.y;
@@ -93,7 +91,7 @@ __global__ __launch_bounds__(256) void resnet_pack_frag_kernel(const PackW p, u4
     unsigned h[8], m[8], l[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float w = (c < CO && k0 + j < KD) ? p.src[i][(long)c * KD + k0 + j] : 0.f;
+      const float w = (c < CO && k0 + j < KD) ? p.src[i][(long)c * (kCin[i] * kKer[i] * kKer[i]) + conv_tap_index(i, k0 + j)] : 0.f;
       h[j] = __float_as_uint(w);
       const float r1 = w - __uint_as_float(h[j] & 0xffff0000u);
       m[j] = __float_as_uint(r1);
@@ -144,17 +142,6 @@ __device__ __forceinline__ float row_sum16(float v) {
   v += dpp_mov<0x122>(v);
   v += dpp_mov<0x121>(v);
   return v;
-}
-typedef unsigned u2r __attribute__((ext_vector_type(2)));
-// stat[2 c] += sum over the wavefront of v, stat[2 c + 1] += sum of v^2 (v already 0 on lanes that do not count)
-__device__ __forceinline__ void stat_add(float* stat, int c, float v) {
-  const float s = row_sum16(v), q = row_sum16(v * v);
-  const u2r r = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(q), false, false);
-  const float e = __uint_as_float(r.x) + __uint_as_float(r.y);       // lanes 0..31: s of rows {0,2} / {1,3}; 32..63: q
-  const u2r t = __builtin_amdgcn_permlane16_swap(__float_as_uint(e), __float_as_uint(e), false, false);
-  const float f = __uint_as_float(t.x) + __uint_as_float(t.y);
-  const int lane = threadIdx.x & 63;
-  if ((lane & 31) == 0) atomicAdd(&stat[2 * c + (lane >> 5)], f);
 }
 // Batch sums in a FIXED order (the result must not depend on which workgroup arrives first: no float or double atomics
 // across workgroups).  Every workgroup parks its partial sums in its own row of `part`; the workgroup whose ticket is the
@@ -214,108 +201,7 @@ __device__ __forceinline__ void stat_flush(const ResArgs& a, int b, const float*
   __syncthreads();                                  // s_last is reused by a second flush of the same kernel
 }
 
-// ---- direct convolution on the lanes ----------------------------------------------------------------------------------------
-// in: this lane's first input element (LDS tile of its crop, channel 0, top-left tap); HP x WP: the padded tile.
-// w: the wave-uniform weights [CIN][K][K][COUT] already offset to the first channel of the group.
-// The weights are read through the CONSTANT address space: with a wave-uniform address that selects scalar loads (s_load_dwordxN
-// into SGPRs, which the FMAs take as an operand); as plain global loads every lane fetched the same 16 bytes into VGPRs and the
-// loop was bound by the vector-memory return path.  (The packed weights are written by an earlier kernel of the stream.)
-typedef const __attribute__((address_space(4))) float* cfloat_p;
-template <int CIN, int HP, int WP, int K, int CG, int COUT>
-__device__ __forceinline__ void conv_acc(const float* __restrict__ in, const float* __restrict__ w_, float (&acc)[CG]) {
-  cfloat_p w = (cfloat_p)w_;
-#pragma unroll 1
-  for (int ci = 0; ci < CIN; ++ci) {
-#pragma unroll
-    for (int ky = 0; ky < K; ++ky) {
-#pragma unroll
-      for (int kx = 0; kx < K; ++kx) {
-        const float v = in[(ci * HP + ky) * WP + kx];
-        cfloat_p wk = w + ((ci * K + ky) * K + kx) * COUT;
-#pragma unroll
-        for (int j = 0; j < CG; ++j) acc[j] = fmaf(wk[j], v, acc[j]);
-      }
-    }
-  }
-}
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
-
-// What these kernels live on is the LENGTH OF THE CHAIN of scalar-load round trips in a wavefront: the weights of a tap
-// arrive by s_load (L2: 20-330 KB of weights do not stay in the 16 KB scalar cache), ~100 SGPRs hold at most one input
-// channel's taps for 12 output channels, so every input channel costs 2-3 dependent round trips of ~0.4 us that nothing
-// inside the wavefront hides -- and more wavefronts per CU only run more such chains side by side.  First version
-// (every wavefront 4 crops x ALL output channels, 110 KB of tiles, one wavefront per SIMD): 0.92 ms; output channels
-// split over the wavefronts of a workgroup: 0.45 ms, each phase still lasting (input channels x 3) round trips.  Now
-// the INPUT channels are split as well: 16 wavefronts per workgroup = (output-channel groups) x (input-channel
-// slices), the partial sums of the slices meet in LDS (plain stores into per-slice buffers, summed in a fixed order,
-// so the result does not depend on timing) and a short second pass adds the bias, writes the raw output and
-// accumulates the BatchNorm statistics.
-
-// partial convolution of input channels [ci0, ci0 + NCI) -- see conv_acc
-template <int NCI, int HP, int WP, int K, int CG, int COUT>
-__device__ __forceinline__ void conv_acc_slice(const float* __restrict__ in, const float* __restrict__ w_, int ci0, float (&acc)[CG]) {
-  cfloat_p w = (cfloat_p)w_ + (long)ci0 * K * K * COUT;
-  in += ci0 * HP * WP;
-#pragma unroll 1
-  for (int ci = 0; ci < NCI; ++ci) {
-#pragma unroll
-    for (int ky = 0; ky < K; ++ky) {
-#pragma unroll
-      for (int kx = 0; kx < K; ++kx) {
-        const float v = in[(ci * HP + ky) * WP + kx];
-        cfloat_p wk = w + ((ci * K + ky) * K + kx) * COUT;
-#pragma unroll
-        for (int j = 0; j < CG; ++j) acc[j] = fmaf(wk[j], v, acc[j]);
-      }
-    }
-  }
-}
-
-// One convolution, first pass: lanes <-> (crop, output pixel); this wavefront takes output channels CG cg .. and input
-// channels (CIN / KS) ks ..; partial sums -> part[ks][crop][channel][pixel].
-// HO: output height = width; S: stride; OFF: 0 for a padded convolution (pad 1), 1 for an unpadded one (the window starts at
-// the tile's interior); LPC: lanes per crop (>= HO * HO; the others idle); CROPS: crops of the tile.
-template <int CIN, int HP, int K, int S, int OFF, int HO, int COUT, int CG, int LPC, int CROPS, int KS>
-__device__ __forceinline__ void conv_part(const float* tiles, const float* w, float* part, int cg, int ks) {
-  constexpr int PIX = HO * HO, NCI = CIN / KS;
-  static_assert(CIN % KS == 0 && COUT % CG == 0, "slices divide the channels");
-  const int lane = threadIdx.x & 63;
-  const int im = lane / LPC, px = lane % LPC;
-  const bool active = px < PIX && im < CROPS;
-  const int oy = active ? px / HO : 0, ox = active ? px % HO : 0;
-  const float* in = tiles + (active ? im : 0) * CIN * HP * HP + (oy * S + OFF) * HP + ox * S + OFF;
-  const int c0 = uniform(cg * CG);
-  float acc[CG];
-#pragma unroll
-  for (int j = 0; j < CG; ++j) acc[j] = 0.f;
-  conv_acc_slice<NCI, HP, HP, K, CG, COUT>(in, w + c0, uniform(ks * NCI), acc);
-  if (active) {
-    float* o = part + ((ks * CROPS + im) * COUT + c0) * PIX + px;
-#pragma unroll
-    for (int j = 0; j < CG; ++j) o[j * PIX] = acc[j];
-  }
-}
-// second pass (behind a barrier): channel c by wavefront c % nwaves; bias, raw output, statistics
-template <int HO, int COUT, int LPC, int CROPS, int KS>
-__device__ __forceinline__ void conv_finish(const ResArgs& a, int img0, const float* part, const float* bias, float* z, float* stat,
-                                            int wave, int nwaves) {
-  constexpr int PIX = HO * HO;
-  const int lane = threadIdx.x & 63;
-  const int im = lane / LPC, px = lane % LPC;
-  const bool active = px < PIX && im < CROPS;
-  const bool valid = active && img0 + im < a.N;
-  for (int c = wave; c < COUT; c += nwaves) {
-    float v = 0.f;
-    if (active) {
-      v = bias[c];
-#pragma unroll
-      for (int k = 0; k < KS; ++k) v += part[((k * CROPS + im) * COUT + c) * PIX + px];
-    }
-    if (valid) z[((long)(img0 + im) * COUT + c) * PIX + px] = v;
-    if (a.train) stat_add(stat, c, valid ? v : 0.f);
-  }
-}
-
 
 // ---- convolution on the matrix cores -----------------------------------------------------------------------------------------
 // LDS of one convolution: koff[32 KST] (tile offset of tap k: (ci HP + ky) HP + kx; 0 behind the last tap, where the weights are
@@ -326,7 +212,10 @@ __device__ __forceinline__ void conv_koff_fill(int* koff) {
   constexpr int K = kKer[CI], KD = conv_kdim(CI), KST = conv_ksteps(CI);
   for (int k = threadIdx.x; k < 32 * KST; k += blockDim.x) {
     int o = 0;
-    if (k < KD) { const int ci = k / (K * K), r = k - ci * (K * K), ky = r / K, kx = r - ky * K; o = (ci * HP + ky) * HP + kx; }
+    if (k < KD) {
+      if constexpr (CI == 8) o = k;                          // rows [ci][2][2] of the 2 x 2 input
+      else { const int ci = k / (K * K), r = k - ci * (K * K), ky = r / K, kx = r - ky * K; o = (ci * HP + ky) * HP + kx; }
+    }
     koff[k] = o;
   }
 }
@@ -354,10 +243,10 @@ __device__ __forceinline__ Bf3 split8(const float (&v)[8]) {
 // MFMAs of step ks and are parked in the other half of wbuf behind them; ONE barrier per k-step.
 // S: stride; OFF: 0 for a padded convolution (pad 1), 1 for an unpadded one; HO: output height = width.
 // z == nullptr: the raw output (+ bias) goes to the LDS tile `ztile` [crop][COUT][ZP][ZP] at (+1, +1) instead (P0's first layer).
-template <int CI, int HP, int S, int OFF, int HO, int CROPS, int NTS, int CSPLIT = 1, int ZP = 0>
+template <int CI, int HP, int S, int OFF, int HO, int CROPS, int NTS, int CSPLIT = 1, int ZP = 0, int TSTRIDE = kCin[CI] * HP * HP>
 __device__ __forceinline__ void conv_mfma(const ResArgs& a, int img0, const float* tiles, const int* koff, u4v* wbuf, const float* bias,
                                           float* z, float* wstat, float* ztile = nullptr) {
-  constexpr int CIN = kCin[CI], COUT = kCout[CI], KST = conv_ksteps(CI), CT = conv_ctiles(CI);
+  constexpr int COUT = kCout[CI], KST = conv_ksteps(CI), CT = conv_ctiles(CI);
   constexpr int PIX = HO * HO, NT = (CROPS * PIX + 15) / 16, TPW = (NT + NTS - 1) / NTS, FR = CT * 192;
   constexpr int NW = NTS, CTW = CT / CSPLIT;                 // pixel-tile slots; channel tiles per wavefront
   static_assert(CT % CSPLIT == 0, "channel tiles divide over the channel groups");
@@ -376,7 +265,7 @@ __device__ __forceinline__ void conv_mfma(const ResArgs& a, int img0, const floa
     act[i] = wave + NW * i < NT && gp < CROPS * PIX;
     const int im = act[i] ? gp / PIX : 0, px = act[i] ? gp % PIX : 0;
     imv[i] = im; pxv[i] = px;
-    base[i] = tiles + im * (CIN * HP * HP) + ((px / HO) * S + OFF) * HP + (px % HO) * S + OFF;
+    base[i] = tiles + im * TSTRIDE + ((px / HO) * S + OFF) * HP + (px % HO) * S + OFF;
   }
   v4f acc[TPW][CTW];
 #pragma unroll
@@ -410,6 +299,7 @@ __device__ __forceinline__ void conv_mfma(const ResArgs& a, int img0, const floa
     o1 = *reinterpret_cast<const int4*>(koff + 32 * kk + 8 * kq + 4);
   };
   auto gather = [&](const int4& o0, const int4& o1, float (&v)[TPW][8]) {
+    if (!computes) return;                                   // (wave-uniform: the other wavefronts only move weight fragments)
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
       const float* b = base[i];
@@ -418,7 +308,7 @@ __device__ __forceinline__ void conv_mfma(const ResArgs& a, int img0, const floa
     }
   };
   int4 oa, ob;
-  float vc[TPW][8];
+  float vc[TPW][8] = {};
   offsets(0, oa, ob);
   gather(oa, ob, vc);
   offsets(1, oa, ob);
@@ -430,7 +320,7 @@ __device__ __forceinline__ void conv_mfma(const ResArgs& a, int img0, const floa
   for (int ks = 0; ks < KST; ++ks) {
     const u4v* cur = wbuf + (ks & 1) * FR;
     wload(ks + 2, pre2);
-    float vn[TPW][8];
+    float vn[TPW][8] = {};
     gather(oa, ob, vn);                                      // step ks + 1 (the last step gathers its own taps again: unused)
     offsets(ks + 2, oa, ob);
 #pragma unroll
@@ -496,62 +386,50 @@ __device__ __forceinline__ void wstat_reduce(const float* wstat, float* stat) {
   }
 }
 
-// ---- P0: conv -> block1.conv1 (+ statistics) and block1.downsample (+ statistics): 2 crops, 16 wavefronts ------------------
+// ---- P0: conv -> block1.conv1 (+ statistics) and block1.downsample (+ statistics): 2 crops, 16 wavefronts, matrix cores --------
+// conv 3 -> 12 k4 s2 p1 (32 -> 16): 512 pixels = 32 pixel tiles, two per wavefront, K = 48 in 2 k-steps, its output (+ bias) lands
+// in the zero-bordered LDS tile a0; block1.conv1 12 -> 24 k4 s2 p1 (16 -> 8): 8 pixel tiles x 2 channel tiles = 16 wavefronts,
+// K = 192; block1.downsample 12 -> 24 k5 s3 p0 (16 -> 4): 2 pixel tiles x 2 channel tiles = 4 wavefronts, K = 300.
 constexpr int kP0Crops = 2;
 constexpr int kP0X = 3 * 34 * 34, kP0A = 12 * 18 * 18;
-constexpr int kP0Part = 2 * kP0Crops * 24 * 64;                       // block1.conv1: 2 input-channel slices
-static_assert(kP0Part <= kP0Crops * kP0X, "the partial sums reuse the input tiles (dead once conv has run)");
-constexpr int kP0Lds = (kP0Crops * (kP0X + kP0A) + 2 * 24 * 2) * 4;
+constexpr int kP0Lds = kP0Crops * (kP0X + kP0A) * 4 + 2 * 2 * 192 * 16 + 32 * (conv_ksteps(0) + conv_ksteps(1) + conv_ksteps(3)) * 4
+                       + (2 * 48 + 2 * kResWaves * 48) * 4;
 __global__ __launch_bounds__(kResThreads) void resnet_p0_kernel(const ResArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* xin = smem;                               // [2][3][34][34]
   float* a0 = xin + kP0Crops * kP0X;               // [2][12][18][18]
-  float* part = xin;                               // partial sums of the slices: over the input tiles, dead by then
-  float* st1 = a0 + kP0Crops * kP0A;               // [24][2] block1.bn1
+  u4v* wbuf = reinterpret_cast<u4v*>(a0 + kP0Crops * kP0A);
+  int* koff0 = reinterpret_cast<int*>(wbuf + 2 * 2 * 192);
+  int* koff1 = koff0 + 32 * conv_ksteps(0);
+  int* koffd = koff1 + 32 * conv_ksteps(1);
+  float* st1 = reinterpret_cast<float*>(koffd + 32 * conv_ksteps(3));   // [24][2] block1.bn1
   float* std_ = st1 + 48;                          // [24][2] block1.downsample
+  float* wst1 = std_ + 48;
+  float* wstd = wst1 + kResWaves * 48;
   for (int i = threadIdx.x; i < kP0Crops * (kP0X + kP0A); i += kResThreads) smem[i] = 0.f;
-  for (int i = threadIdx.x; i < 96; i += kResThreads) st1[i] = 0.f;
-  const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const float* w0 = a.w + conv_off(0);
+  for (int i = threadIdx.x; i < 96 + 2 * kResWaves * 48; i += kResThreads) st1[i] = 0.f;
+  conv_koff_fill<0, 34>(koff0);
+  conv_koff_fill<1, 18>(koff1);
+  conv_koff_fill<3, 18>(koffd);
   const int groups = (a.N + kP0Crops - 1) / kP0Crops;
   for (int g = blockIdx.x; g < groups; g += gridDim.x) {
     const int img0 = g * kP0Crops;
     __syncthreads();                               // the previous pass is done with the tiles (and the zero fill is visible)
-    if (g != (int)blockIdx.x) {                    // the partial sums of the previous pass lie over the zero borders
-      for (int i = threadIdx.x; i < kP0Crops * kP0X; i += kResThreads) xin[i] = 0.f;
-      __syncthreads();
-    }
     for (int i = threadIdx.x; i < kP0Crops * 3 * 1024; i += kResThreads) {
       const int im = i / 3072, r = i - im * 3072, c = r >> 10, y = (r >> 5) & 31, xx = r & 31;
       const float v = img0 + im < a.N ? a.x[(long)(img0 + im) * 3072 + r] : 0.f;
       xin[im * kP0X + (c * 34 + y + 1) * 34 + xx + 1] = v;
     }
     __syncthreads();
-    {                                              // conv: 3 -> 12, k4 s2 p1, 32 -> 16; wavefront <-> (crop, 4 output rows, 6 channels)
-      const int im = wave >> 3, oy = 4 * ((wave >> 1) & 3) + (lane >> 4), ox = lane & 15, c0 = uniform(6 * (wave & 1));
-      float acc[6];
-#pragma unroll
-      for (int j = 0; j < 6; ++j) acc[j] = a.bias[0][c0 + j];
-      conv_acc<3, 34, 34, 4, 6, 12>(xin + im * kP0X + (oy * 2) * 34 + ox * 2, w0 + c0, acc);
-#pragma unroll
-      for (int j = 0; j < 6; ++j) a0[im * kP0A + ((c0 + j) * 18 + oy + 1) * 18 + ox + 1] = acc[j];
-    }
-    __syncthreads();
-    // block1.conv1: 12 -> 24, k4 s2 p1, 16 -> 8: lanes <-> the 64 pixels of ONE crop, wavefront <-> (crop, 6 channels, 6 input channels)
-    {
-      const int im = wave >> 3, cg = (wave >> 1) & 3, ks = wave & 1;
-      conv_part<12, 18, 4, 2, 0, 8, 24, 6, 64, 1, 2>(a0 + im * kP0A, a.w + conv_off(1), part + im * (2 * 24 * 64), cg, ks);
-    }
-    __syncthreads();
-    for (int im = 0; im < kP0Crops; ++im)
-      conv_finish<8, 24, 64, 1, 2>(a, img0 + im, part + im * (2 * 24 * 64), a.bias[1], a.z1, st1, wave, kResWaves);
-    __syncthreads();
-    // block1.downsample: 12 -> 24, k5 s3 p0, 16 -> 4: lanes <-> (crop, pixel) (32 of 64), wavefront <-> (3 channels, 6 input channels)
-    conv_part<12, 18, 5, 3, 1, 4, 24, 3, 16, kP0Crops, 2>(a0, a.w + conv_off(3), part, wave >> 1, wave & 1);
-    __syncthreads();
-    conv_finish<4, 24, 16, kP0Crops, 2>(a, img0, part, a.bias[3], a.zd1, std_, wave, kResWaves);
+    conv_mfma<0, 34, 2, 0, 16, kP0Crops, 16, 1, 18>(a, img0, xin, koff0, wbuf, a.bias[0], nullptr, nullptr, a0);
+    __syncthreads();                               // a0 is complete
+    conv_mfma<1, 18, 2, 0, 8, kP0Crops, 8, 2>(a, img0, a0, koff1, wbuf, a.bias[1], a.z1, wst1);
+    conv_mfma<3, 18, 3, 1, 4, kP0Crops, 2, 2>(a, img0, a0, koffd, wbuf, a.bias[3], a.zd1, wstd);
   }
   if (a.train) {
+    __syncthreads();
+    wstat_reduce<24, kResWaves>(wst1, st1);
+    wstat_reduce<24, kResWaves>(wstd, std_);
     __syncthreads();
     stat_flush(a, 0, st1, reinterpret_cast<double*>(smem));
     stat_flush(a, 2, std_, reinterpret_cast<double*>(smem));
@@ -736,21 +614,21 @@ __global__ __launch_bounds__(kResThreads) void resnet_p4_kernel(const ResArgs a)
 }
 
 // P5: block3.conv2 96 -> 96 k3 s2 p1 on relu(bn1(z5)), 2 -> 1: only the taps (1..2, 1..2) meet the 2x2 input, a 384-wide
-// matrix-vector product per crop.  64 crops (lane <-> crop, rows of 385 floats: conflict-free); 8 groups of 12 channels x
-// 2 slices of 48 input channels.
-constexpr int kP5Crops = 64, kP5Row = 385, kP5Threads = kResThreads;
-constexpr int kP5PartRow = 97;                                        // odd: lane <-> crop rows on distinct banks
-constexpr int kP5Part = 2 * kP5Crops * kP5PartRow;
-constexpr int kP5Lds = (kP5Crops * kP5Row + kP5Part + 192 + 192) * 4;
+// matrix-vector product per crop; on the matrix cores with the crops as the pixel dimension: 16 crops per workgroup = ONE pixel tile,
+// six wavefronts take one channel tile each; K = 384 in 12 k-steps.  Rows of 388 floats: the 16 crops of a tile on distinct banks.
+constexpr int kP5Crops = 16, kP5Row = 388, kP5Threads = kResThreads;
+constexpr int kP5Lds = kP5Crops * kP5Row * 4 + 2 * 6 * 192 * 16 + 32 * conv_ksteps(8) * 4 + (192 + 192 + kResWaves * 192) * 4;
 __global__ __launch_bounds__(kP5Threads) void resnet_p5_kernel(const ResArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* rows = smem;
-  float* part = rows + kP5Crops * kP5Row;
-  float* aff = part + kP5Part;
+  u4v* wbuf = reinterpret_cast<u4v*>(rows + kP5Crops * kP5Row);
+  int* koff = reinterpret_cast<int*>(wbuf + 2 * 6 * 192);
+  float* aff = reinterpret_cast<float*>(koff + 32 * conv_ksteps(8));
   float* stat = aff + 192;
-  for (int i = threadIdx.x; i < 192; i += kP5Threads) stat[i] = 0.f;
+  float* wstat = stat + 192;
+  for (int i = threadIdx.x; i < 192 + kResWaves * 192; i += kP5Threads) stat[i] = 0.f;
+  conv_koff_fill<8, 2>(koff);
   bn_affine_to_lds(a, 6, aff);
-  const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int groups = (a.N + kP5Crops - 1) / kP5Crops;
   for (int g = blockIdx.x; g < groups; g += gridDim.x) {
     const int img0 = g * kP5Crops;
@@ -762,35 +640,14 @@ __global__ __launch_bounds__(kP5Threads) void resnet_p5_kernel(const ResArgs a) 
       rows[im * kP5Row + r] = v;
     }
     __syncthreads();
-    {
-      const int c0 = uniform(12 * (wave & 7)), ks = wave >> 3, ci0 = uniform(48 * ks);
-      const float* in = rows + lane * kP5Row + ci0 * 4;
-      cfloat_p w = (cfloat_p)(a.w + conv_off(8)) + (long)ci0 * 9 * 96;
-      float acc[12];
-#pragma unroll
-      for (int j = 0; j < 12; ++j) acc[j] = 0.f;
-#pragma unroll 1
-      for (int ci = 0; ci < 48; ++ci) {
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-          const float v = in[ci * 4 + p];
-          cfloat_p wk = w + ((ci * 3 + 1 + (p >> 1)) * 3 + 1 + (p & 1)) * 96 + c0;
-#pragma unroll
-          for (int j = 0; j < 12; ++j) acc[j] = fmaf(wk[j], v, acc[j]);
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < 12; ++j) part[(ks * kP5Crops + lane) * kP5PartRow + c0 + j] = acc[j];
-    }
-    __syncthreads();
-    const bool valid = img0 + lane < a.N;
-    for (int c = wave; c < 96; c += kResWaves) {
-      const float v = a.bias[8][c] + part[lane * kP5PartRow + c] + part[(kP5Crops + lane) * kP5PartRow + c];
-      if (valid) a.z6[(long)(img0 + lane) * 96 + c] = v;
-      if (a.train) stat_add(stat, c, valid ? v : 0.f);
-    }
+    conv_mfma<8, 2, 1, 0, 1, kP5Crops, 1, 6, 0, kP5Row>(a, img0, rows, koff, wbuf, a.bias[8], a.z6, wstat);
   }
-  if (a.train) { __syncthreads(); stat_flush(a, 7, stat, reinterpret_cast<double*>(smem)); }
+  if (a.train) {
+    __syncthreads();
+    wstat_reduce<96, kResWaves>(wstat, stat);
+    __syncthreads();
+    stat_flush(a, 7, stat, reinterpret_cast<double*>(smem));
+  }
 }
 
 // out = relu(bn2(z6) + bn_d(zd3)); in train mode block 0.. also update the running statistics of all nine BatchNorms
@@ -832,7 +689,7 @@ using namespace b3d;
 
 extern "C" size_t b3d_resnet_encode_workspace_bytes(int32_t N) {
   if (N < 0) N = 0;
-  return 256 + (size_t)kWeightFloats * 4 + 256 + (size_t)kFragU4 * 16 + 256 + (size_t)kBnChannels * 2 * 8 + 64 + 256
+  return 256 + (size_t)kFragU4 * 16 + 256 + (size_t)kBnChannels * 2 * 8 + 64 + 256
          + (size_t)kResMaxGrid * 2 * kBnChannels * 4 + 256 + (size_t)N * kActFloatsPerCrop * 4 + 64;
 }
 
@@ -852,13 +709,12 @@ extern "C" int b3d_resnet_encode(const b3d_linear* conv, const b3d_batchnorm* bn
   if (N == 0) return B3D_OK;
   auto align = [](uintptr_t p) { return (p + 255) & ~(uintptr_t)255; };
   uintptr_t p = align((uintptr_t)workspace);
-  float* wp = (float*)p; p = align(p + (size_t)kWeightFloats * 4);
   u4v* wfrag = (u4v*)p; p = align(p + (size_t)kFragU4 * 16);
   double* sums = (double*)p; p = align(p + (size_t)kBnChannels * 16 + 64);      // + the arrival counters behind the sums
   float* part = (float*)p; p = align(p + (size_t)kResMaxGrid * 2 * kBnChannels * 4);
   float* act = (float*)p;
   ResArgs a;
-  a.N = N; a.train = train ? 1 : 0; a.x = x; a.w = wp; a.wfrag = wfrag; a.sums = sums; a.part = part; a.tickets = (unsigned*)(sums + 2 * kBnChannels); a.out = out;
+  a.N = N; a.train = train ? 1 : 0; a.x = x; a.wfrag = wfrag; a.sums = sums; a.part = part; a.tickets = (unsigned*)(sums + 2 * kBnChannels); a.out = out;
   for (int i = 0; i < kConvs; ++i) a.bias[i] = (const float*)conv[i].b;
   for (int i = 0; i < kBns; ++i) {
     a.bn[i].gamma = bn[i].gamma; a.bn[i].beta = bn[i].beta;
@@ -877,9 +733,6 @@ extern "C" int b3d_resnet_encode(const b3d_linear* conv, const b3d_batchnorm* bn
   a.z6 = act;
   PackW pw;
   for (int i = 0; i < kConvs; ++i) pw.src[i] = (const float*)conv[i].w;
-  pw.dst = wp;
-  hipLaunchKernelGGL(resnet_pack_kernel, dim3(16, kConvs), dim3(256), 0, stream, pw);
-  B3D_TRY(launch_check("resnet_pack_kernel"));
   hipLaunchKernelGGL(resnet_pack_frag_kernel, dim3(8, kConvs), dim3(256), 0, stream, pw, wfrag);
   B3D_TRY(launch_check("resnet_pack_frag_kernel"));
   if (train) B3D_HIP_CHECK(hipMemsetAsync(sums, 0, (size_t)kBnChannels * 16 + 64, stream));
