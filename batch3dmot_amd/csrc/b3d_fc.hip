@@ -12,6 +12,7 @@
 // Products are bf16x6 (below): fp32-class accuracy, NOT bitwise an fp32 fmaf chain, and a +-inf input gives NaN (inf - inf in the
 // exact split) where torch's Linear gives +-inf.  Statistics: per-tile (sum, M2 about the tile mean) in a slab, combined in tile
 // order in float64 (Chan): bitwise reproducible, and as well conditioned as torch's Welford for badly centred activations.
+#include <cstdlib>
 #include "b3d_common.hpp"
 #include "b3d_launch.hpp"
 #include "b3d_dev.hpp"
@@ -27,17 +28,20 @@ namespace {
 // are three [row][k] bf16 images each -- and a 32-wide k group of a 16 x 16 block is six v_mfma_f32_16x16x32_bf16 (96 cycles)
 // instead of eight v_mfma_f32_16x16x4_f32 (256 cycles); 64 k per barrier instead of 32.  The exact-fp32 form of this kernel sat
 // at 19 % MFMA-busy and 52 us for [1,500 x 1,024] . [1,024 x 512]: one barrier per 16 MFMAs of a wavefront.
-// (B3D_FC_TK=32: 61 KB of LDS, two workgroups per CU -- measured in round 4: no change of the step, 4.71 vs 4.69 - 4.70 ms)
-#ifndef B3D_FC_TK
-#define B3D_FC_TK 64
-#endif
-constexpr int kTM = 64, kTN = 64, kTK = B3D_FC_TK, kFcThreads = 512;
-constexpr int kTPR = kTK / 4, kRPP = kFcThreads / kTPR;          // staging: threads per tile row, rows per pass
-constexpr int kPitch = kTK / 2 + 4;          // dwords per tile row: 64 bf16 + 16 bytes.  144 B rows: the ds_read_b128 of an operand fragment
-                                             // (16 rows x 16 B per 16-lane group) touches every bank once (144 i mod 256 = 16 (9 i mod 16))
-constexpr int kPiece = kTM * kPitch;         // dwords of one piece image
-constexpr int kTileDw = 3 * kPiece;          // one operand tile: three pieces
-constexpr int kFcLdsBytes = 2 * 2 * kTileDw * 4;   // x and w tiles, double buffered: 110,592 B
+constexpr int kTM = 64, kTN = 64, kFcThreads = 512, kFcCus = 256;
+// TK: k per barrier.  64: 110 KB of LDS, one workgroup per CU -- the form of every launch that fits the chip in one round; 32: 61 KB, two
+// workgroups per CU -- for the launches with more tiles than CUs (a 2,100 x 512 layer is 264 tiles: at one workgroup per CU the last 8
+// ran as a second round, 53 us for a 22 us workgroup).
+template <int TK>
+struct FcGeo {
+  static constexpr int kTK = TK;
+  static constexpr int kTPR = TK / 4, kRPP = kFcThreads / kTPR;   // staging: threads per tile row, rows per pass
+  static constexpr int kPitch = TK / 2 + 4;   // dwords per tile row: TK bf16 + 16 bytes.  144 B (80 B) rows: the ds_read_b128 of an operand
+                                              // fragment (16 rows x 16 B per 16-lane group) touches every bank once
+  static constexpr int kPiece = kTM * kPitch; // dwords of one piece image
+  static constexpr int kTileDw = 3 * kPiece;  // one operand tile: three pieces
+  static constexpr int kLdsBytes = 2 * 2 * kTileDw * 4;   // x and w tiles, double buffered: 110,592 B (61,440 B)
+};
 
 struct FcArgs {
   const float* x;        // [B, K]
@@ -62,8 +66,10 @@ struct FcArgs {
 
 // AFFINE: the producer's BatchNorm + ReLU is applied to x while it is staged (compile-time: a run-time test around the loads made
 // hipcc wait vmcnt(0) behind every one of them, i.e. no tile was ever in flight under the MFMAs)
-template <bool AFFINE>
-__global__ __launch_bounds__(kFcThreads, kTK == 32 ? 2 : 1) void fc_kernel(const FcArgs a) {
+template <bool AFFINE, int TK>
+__global__ __launch_bounds__(kFcThreads, TK == 32 ? 2 : 1) void fc_kernel(const FcArgs a) {
+  using G = FcGeo<TK>;
+  constexpr int kTK = G::kTK, kTPR = G::kTPR, kRPP = G::kRPP, kPitch = G::kPitch, kPiece = G::kPiece, kTileDw = G::kTileDw;
   extern __shared__ __attribute__((aligned(16))) unsigned fc_lds[];
   unsigned* const As = fc_lds;                 // [2][3 pieces][kTM][kPitch]
   unsigned* const Bs = fc_lds + 2 * kTileDw;
@@ -366,13 +372,16 @@ extern "C" int b3d_fc_bn_forward(const float* x, int32_t B, int32_t K, const flo
   const int nrt = (B + kTM - 1) / kTM, nct = (N + kTN - 1) / kTN;
   B3D_REQUIRE(nct <= 63, "b3d_fc_bn_forward: N %d > 4032 columns (one arrival counter per 64-column tile in the workspace header)", (int)N);
   const dim3 grid((unsigned)((nrt + 7) / 8 * 8 * nct));                // row tiles padded to whole rounds of the eight XCDs
-  if (in_scale) {
-    B3D_TRY(set_lds_cached(reinterpret_cast<const void*>(fc_kernel<true>), kFcLdsBytes));
-    hipLaunchKernelGGL(fc_kernel<true>, grid, dim3(kFcThreads), kFcLdsBytes, stream, a);
-  } else {
-    B3D_TRY(set_lds_cached(reinterpret_cast<const void*>(fc_kernel<false>), kFcLdsBytes));
-    hipLaunchKernelGGL(fc_kernel<false>, grid, dim3(kFcThreads), kFcLdsBytes, stream, a);
-  }
+  // more tiles than CUs: the 61 KB form, two workgroups per CU, keeps the launch to one round
+  static const bool force64 = getenv("B3D_FC_TK64") != nullptr;    // A/B switch for tools/: always the 110 KB form
+  const bool small = nrt * nct > kFcCus && !force64;
+  auto go = [&](auto kern, int lds) -> int {
+    B3D_TRY(set_lds_cached(reinterpret_cast<const void*>(kern), lds));
+    hipLaunchKernelGGL(kern, grid, dim3(kFcThreads), lds, stream, a);
+    return B3D_OK;
+  };
+  if (in_scale) B3D_TRY(small ? go(fc_kernel<true, 32>, FcGeo<32>::kLdsBytes) : go(fc_kernel<true, 64>, FcGeo<64>::kLdsBytes));
+  else B3D_TRY(small ? go(fc_kernel<false, 32>, FcGeo<32>::kLdsBytes) : go(fc_kernel<false, 64>, FcGeo<64>::kLdsBytes));
   return launch_check("fc_kernel");
 }
 
