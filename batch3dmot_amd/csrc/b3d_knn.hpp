@@ -145,10 +145,13 @@ __global__ __launch_bounds__(kKnnCentres * 64) void knn_tile_kernel(const float*
                                                                     const int* __restrict__ fbeg,
                                                                     const int* __restrict__ fend,
                                                                     int* __restrict__ nbr, int* __restrict__ cnt) {
-  constexpr int TS = D + 1;                               // padded tile row (bank spread)
+  // padded tile row: 16-byte aligned rows whose 16-lane groups start on distinct banks (100 l mod 64 and 52 l mod 64 are 16 different
+  // multiples of 4 for l = 0..15), so a lane reads its candidate row as ds_read_b128 -- with D + 1 floats per row (rounds 1-3) every
+  // FMA of the distance had its own 4-byte LDS read and the kernel was bound by LDS instruction issue
+  constexpr int TS = D + 4;
   constexpr int TR = kKnnTileRows;                        // candidate rows per tile
   constexpr int NT = kKnnCentres * 64;
-  __shared__ float tile[2][TR * TS];                      // double buffered: one barrier per tile
+  __shared__ __attribute__((aligned(16))) float tile[2][TR * TS];   // double buffered: one barrier per tile
   __shared__ float dist[kKnnCentres][kKnnList];
   __shared__ int wb[kKnnCentres], we[kKnnCentres];
   __shared__ float pickd[kKnnCentres][32];               // the k survivors of a selection (b3d_knn.hpp: extract), one per lane
@@ -313,8 +316,7 @@ __global__ __launch_bounds__(kKnnCentres * 64) void knn_tile_kernel(const float*
     for (int j = 0; j < PER; ++j) {
       const int i = threadIdx.x + j * NT;
       const int r = i / (D / 4), c4 = i - r * (D / 4);
-      float* dst = tile[cur] + r * TS + 4 * c4;
-      dst[0] = v[j].x; dst[1] = v[j].y; dst[2] = v[j].z; dst[3] = v[j].w;
+      *reinterpret_cast<v4f*>(tile[cur] + r * TS + 4 * c4) = v[j];
     }
     __syncthreads();
     load_rows(v);                                         // tile t0 + 2 TR (indices fetched one step ago)
@@ -327,7 +329,13 @@ __global__ __launch_bounds__(kKnnCentres * 64) void knn_tile_kernel(const float*
         const float* row = tile[cur] + (64 * u + lane) * TS;
         float s2 = 0.f;
 #pragma unroll
-        for (int d = 0; d < D; ++d) { const float a = row[d] - xc[d]; s2 = fmaf(a, a, s2); }
+        for (int d = 0; d < D; d += 4) {                    // (the same fmaf chain, feature by feature)
+          const v4f r4 = *reinterpret_cast<const v4f*>(row + d);
+          float a = r4.x - xc[d]; s2 = fmaf(a, a, s2);
+          a = r4.y - xc[d + 1]; s2 = fmaf(a, a, s2);
+          a = r4.z - xc[d + 2]; s2 = fmaf(a, a, s2);
+          a = r4.w - xc[d + 3]; s2 = fmaf(a, a, s2);
+        }
         dist[wave][p - segbase] = (p == pos) ? INF : s2;
       }
     }
