@@ -298,7 +298,13 @@ struct RedArgs {
 // per slab, still 8 slabs in flight (a plain scalar loop here -- it held the BIAS quads in round 2 -- walks the slabs one
 // load latency at a time: 450 slabs / 8 threads x 4 elements x ~0.4 us was the whole 80 us of the PoseGNN launch).  The
 // partials meet in LDS and are added in a fixed order.  Bitwise reproducible.
-constexpr int kRedQuads = 64, kRedParts = 8;
+// (round 4: 128 quads x 4 parts -- 64 x 8 took 75 + 17 us for the two launches of the camera+LiDAR+radar step, 128 x 4 takes 52 + 13;
+// 256 x 2: 91 + 14, 256 x 1: 130 + 15: fewer, longer per-thread chains lose more than the smaller prologue share gains)
+#ifndef B3D_RED_QUADS
+#define B3D_RED_QUADS 128
+#define B3D_RED_PARTS 4
+#endif
+constexpr int kRedQuads = B3D_RED_QUADS, kRedParts = B3D_RED_PARTS;
 static __global__ __launch_bounds__(kRedQuads * kRedParts) void wgrad_reduce_kernel(const RedArgs a) {
   __shared__ v4f part[kRedParts][kRedQuads];
   const int el = threadIdx.x % kRedQuads, sub = threadIdx.x / kRedQuads;
@@ -331,7 +337,17 @@ static __global__ __launch_bounds__(kRedQuads * kRedParts) void wgrad_reduce_ker
 #pragma unroll
       for (int u = 0; u < 8; ++u) s += t[u];
     }
-    for (; c < e.nchunks; c += kRedParts) s += *reinterpret_cast<const v4f*>(src + (size_t)c * cs);
+    // the rest (every entry of the camera+LiDAR+radar step: 21 or 41 slabs are fewer than 8 x kRedParts): up to eight loads in flight
+    // again -- clamped slab index, the value of a slab past the end replaced by zero -- instead of one dependent round trip per
+    // slab (round 4: this loop was the whole 80 us of the launch); same slabs in the same order
+    if (c < e.nchunks) {
+      v4f t[8];
+      const int last = e.nchunks - 1;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int cc = c + u * kRedParts; t[u] = *reinterpret_cast<const v4f*>(src + (size_t)(cc < last ? cc : last) * cs); }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) if (c + u * kRedParts < e.nchunks) s += t[u];
+    }
   } else if (live) {
     long off[4];
 #pragma unroll
