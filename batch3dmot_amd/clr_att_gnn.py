@@ -606,7 +606,7 @@ class GNN(nn.Module):
         if encoded is None:
             # Forward-only calls (no_grad: predict.py:172-196) hand the join to b3d_clr_forward, which runs the part that
             # does not read encoder outputs underneath the encoders (+3.5 % windows per second at 2,000 / 20,000); in a
-            # training step the same overlap measured 1.6 % SLOWER (the train-mode statistics kernels of the point stacks
+            # training step the same overlap measured 1.6 % SLOWER in round 3 and 1.0 % slower in round 4 (the train-mode statistics kernels of the point stacks
             # and the forward prefix get in each other's way), so there the encoders are joined first.
             encoded, ready = self._encode(data, rows, join=torch.is_grad_enabled())
         try:
