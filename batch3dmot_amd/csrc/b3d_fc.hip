@@ -12,7 +12,6 @@
 // Products are bf16x6 (below): fp32-class accuracy, NOT bitwise an fp32 fmaf chain, and a +-inf input gives NaN (inf - inf in the
 // exact split) where torch's Linear gives +-inf.  Statistics: per-tile (sum, M2 about the tile mean) in a slab, combined in tile
 // order in float64 (Chan): bitwise reproducible, and as well conditioned as torch's Welford for badly centred activations.
-#include <cstdlib>
 #include "b3d_common.hpp"
 #include "b3d_launch.hpp"
 #include "b3d_dev.hpp"
@@ -373,8 +372,7 @@ extern "C" int b3d_fc_bn_forward(const float* x, int32_t B, int32_t K, const flo
   B3D_REQUIRE(nct <= 63, "b3d_fc_bn_forward: N %d > 4032 columns (one arrival counter per 64-column tile in the workspace header)", (int)N);
   const dim3 grid((unsigned)((nrt + 7) / 8 * 8 * nct));                // row tiles padded to whole rounds of the eight XCDs
   // more tiles than CUs: the 61 KB form, two workgroups per CU, keeps the launch to one round
-  static const bool force64 = getenv("B3D_FC_TK64") != nullptr;    // A/B switch for tools/: always the 110 KB form
-  const bool small = nrt * nct > kFcCus && !force64;
+  const bool small = nrt * nct > kFcCus;
   auto go = [&](auto kern, int lds) -> int {
     B3D_TRY(set_lds_cached(reinterpret_cast<const void*>(kern), lds));
     hipLaunchKernelGGL(kern, grid, dim3(kFcThreads), lds, stream, a);

@@ -313,9 +313,6 @@ __device__ __forceinline__ void conv_mfma(const ResArgs& a, int img0, const floa
   gather(oa, ob, vc);
   offsets(1, oa, ob);
   __syncthreads();
-#ifdef RN_NOCONV
-  if (false)
-#endif
 #pragma unroll 1
   for (int ks = 0; ks < KST; ++ks) {
     const u4v* cur = wbuf + (ks & 1) * FR;
@@ -554,9 +551,7 @@ __global__ __launch_bounds__(kResThreads) void resnet_p3_kernel(const ResArgs a)
   for (int g = blockIdx.x; g < groups; g += gridDim.x) {
     const int img0 = g * kP3Crops;
     __syncthreads();
-#ifndef RN_NOSTAGE
     stage_tiles<kP3Crops, 48, 4, 6, kResThreads>(a, img0, a.z3, aff, nullptr, nullptr, tiles);
-#endif
     __syncthreads();
     conv_mfma<5, 6, 1, 0, 4, kP3Crops, kResWaves>(a, img0, tiles, koff, wbuf, a.bias[5], a.z4, wstat);
   }
