@@ -19,9 +19,9 @@ typedef __attribute__((address_space(3))) float lds_float;
 constexpr int kRows = 32, kNG = 128, kKG = 256, kW = kNG + kKG;
 constexpr int kPitch = ((kW / 2 - 8 + 63) / 64) * 64 + 8;        // dwords
 constexpr int kPiece = kRows * kPitch, kBuf = 3 * kPiece;
-constexpr int kLdsBytes = 2 * kBuf * 4;
+constexpr int kLdsBytes = 2 * kBuf * 4 + 256;     // + stamps of the flag-synchronised form
 
-enum { READS = 1, MFMA = 2, SPLIT = 4, WRITES = 8, BARRIER = 16, PRIO = 32, FUSED = 64, READS_AHEAD = 128 };
+enum { READS = 1, MFMA = 2, SPLIT = 4, WRITES = 8, BARRIER = 16, PRIO = 32, FUSED = 64, FLAGS = 128 };
 
 __device__ __forceinline__ bf8 frag(const lds_float* img, int lane_off, int cd) {
   auto* p0 = (__attribute__((address_space(3))) s4*)(img + lane_off + cd);
@@ -168,6 +168,38 @@ __global__ __launch_bounds__(512, 1) void phase_kernel(float* out, int steps, fl
       if constexpr (MODE & BARRIER) __syncthreads();
       if (wave < MULT || MULT == 8) compute(lds + (t & 1) * kBuf);
     }
+  } else if constexpr ((MODE & FLAGS) != 0) {
+    // No barrier: stamps in LDS.  full[b][w] = last step loader wavefront w has completely staged into buffer b (+1);
+    // done[b][m] = last step multiplier wavefront m has completely READ out of buffer b (+1).  A wavefront's LDS operations are
+    // executed in order, so data written before a stamp is visible to whoever has seen the stamp.
+    volatile int* full = reinterpret_cast<volatile int*>(lds_raw + 2 * kBuf);        // [2][4]
+    volatile int* done = full + 8;                                                     // [2][4]
+    if (tid < 16) const_cast<int*>(full)[tid] = 0;
+    __syncthreads();
+    auto wait4 = [&](volatile int* st, int want) {
+      while (true) {
+        const int a0 = st[0], a1 = st[1], a2 = st[2], a3 = st[3];
+        if (min(min(a0, a1), min(a2, a3)) >= want) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+    };
+    if (loader && !mult) {
+      const int lw = wave - 4;
+      for (int t = 0; t < steps; ++t) {
+        const int b = t & 1;
+        if (t >= 2) wait4(done + 4 * b, t - 1);             // the multipliers are done reading step t - 2 (stamp t - 1)
+        stage(lds + b * kBuf, t);
+        __builtin_amdgcn_s_waitcnt(0xc07f);                 // lgkmcnt(0): this wavefront's tile words are in LDS
+        if (lane == 0) full[4 * b + lw] = t + 1;
+      }
+    } else if (mult) {
+      for (int t = 0; t < steps; ++t) {
+        const int b = t & 1;
+        wait4(full + 4 * b, t + 1);
+        compute(lds + b * kBuf);
+        if (lane == 0) done[4 * b + wave] = t + 1;          // (behind the step's last fragment read in program order)
+      }
+    }
   } else if (loader && !mult) {
     for (int t = 0; t < steps; ++t) {
       if constexpr (MODE & (SPLIT | WRITES)) stage(lds + ((t + 1) & 1) * kBuf, t);
@@ -223,6 +255,7 @@ int main() {
   run<SPLIT | WRITES | READS | MFMA, 4>("4 + 4: everything, no barrier", out, steps);
   run<SPLIT | WRITES | READS | MFMA | BARRIER, 4>("4 + 4: everything + barrier per step (v3's form)", out, steps);
   run<SPLIT | WRITES | READS | MFMA | BARRIER | PRIO, 4>("4 + 4: everything + barrier, multipliers at s_setprio 2", out, steps);
+  run<SPLIT | WRITES | READS | MFMA | FLAGS, 4>("4 + 4: everything, LDS stamps instead of the barrier (loaders run ahead)", out, steps);
   run<SPLIT | MFMA, 4>("4 + 4: split beside MFMAs only (no LDS traffic)", out, steps);
   run<WRITES | MFMA, 4>("4 + 4: LDS writes beside MFMAs only", out, steps);
   run<WRITES | READS, 4>("4 + 4: LDS writes beside fragment reads (no VALU work, no MFMA)", out, steps);
