@@ -142,3 +142,22 @@ def test_predict_post_oracle_matches_reference():
     kept, pred, succ = ref_torch.greedy_flux(g["node_cls"].numel(), pairs.tolist(), avg.tolist(), thr.tolist())
     assert torch.equal(pairs[kept], g["kept_pairs"])
     assert pred == g["pred"].tolist() and succ == g["succ"].tolist()
+
+
+def test_post_adam_tolerance_accepts_the_golden_and_rejects_a_missing_or_reversed_update():
+    """conftest.assert_adam_heads_close (the check the GPU training-step tests apply to the weights after Adam): the golden
+    against itself passes; weights that never moved, and weights that moved the wrong way, fail."""
+    from conftest import assert_adam_heads_close
+    from batch3dmot_amd import encoders
+    from batch3dmot_amd.clr_att_gnn import GNN
+    g = load_golden("g9_train_mode_step.pt")
+    m = GNN(encoders.ResNetAE(), encoders.PointNetClassifier(k=7), encoders.RadarNetClassifier(k=7))
+    seeded_fill_(m, g["salt"])
+    before = {n: p.detach().reshape(-1)[:8].double().clone() for n, p in m.named_parameters() if p.requires_grad}
+    gold = g["after_digest"]
+    assert_adam_heads_close(before, gold, gold, lr=1e-4)
+    stuck = {n: {"head": before[n]} for n in gold}
+    reversed_ = {n: {"head": 2 * before[n] - gold[n]["head"]} for n in gold}
+    for bad in (stuck, reversed_):
+        with pytest.raises(AssertionError):
+            assert_adam_heads_close(before, bad, gold, lr=1e-4)
