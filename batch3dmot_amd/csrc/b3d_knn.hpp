@@ -219,14 +219,21 @@ __global__ __launch_bounds__(kKnnCentres * 64) void knn_tile_kernel(const float*
 #pragma unroll
       for (int off = 32; off >= 1; off >>= 1) { mn = min(mn, (unsigned)__shfl_xor((int)mn, off, 64)); mx = max(mx, (unsigned)__shfl_xor((int)mx, off, 64)); }
       unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)mn), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)mx);
-      while (lo < hi) {                                        // smallest V with count(<= V) >= want
+      // smallest V with count(<= V) >= want.  (Round 4) The walk stops as soon as a probe has EXACTLY `want` entries at or below it
+      // -- any such value separates the survivors, it need not be the want-th distance itself: ~log2(entries x spread) probes
+      // instead of one per bit of the range; only a tie across the want-th place runs to the end and into the position bisection.
+      bool cut = false;
+      unsigned thr = 0u;
+      while (lo < hi) {
         const unsigned mid = lo + ((hi - lo) >> 1);
-        if (count([&](int j) { return cb[j] <= mid; }) >= want) hi = mid; else lo = mid + 1;
+        const int cle = count([&](int j) { return cb[j] <= mid; });
+        if (cle == want) { cut = true; thr = mid; break; }
+        if (cle > want) hi = mid; else lo = mid + 1;
       }
-      const unsigned V = lo;
-      const int need_eq = want - count([&](int j) { return cb[j] < V; });      // >= 1
-      int ilim = 0x7fffffff;                                   // largest list index taken among the entries equal to V
-      if (count([&](int j) { return cb[j] == V; }) > need_eq) {
+      const unsigned V = cut ? thr + 1u : lo;                  // survivors: everything below V (+ entries equal to V up to ilim)
+      const int need_eq = cut ? 0 : want - count([&](int j) { return cb[j] < V; });      // >= 1 without a clean cut
+      int ilim = cut ? -1 : 0x7fffffff;                        // largest list index taken among the entries equal to V
+      if (!cut && count([&](int j) { return cb[j] == V; }) > need_eq) {
         int il = 0, ih = kKnnList - 1;
         while (il < ih) {
           const int im = (il + ih) >> 1;
