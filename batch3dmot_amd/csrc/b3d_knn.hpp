@@ -148,7 +148,7 @@ __global__ __launch_bounds__(kKnnCentres * 64) void knn_tile_kernel(const float*
   // padded tile row: 16-byte aligned rows whose 16-lane groups start on distinct banks (100 l mod 64 and 52 l mod 64 are 16 different
   // multiples of 4 for l = 0..15), so a lane reads its candidate row as ds_read_b128 -- with D + 1 floats per row (rounds 1-3) every
   // FMA of the distance had its own 4-byte LDS read and the kernel was bound by LDS instruction issue
-  constexpr int TS = D + 4;
+  constexpr int TS = D + 4;                               // (D = 48, PoseGNN: 33.6 us against 35.4 with D + 1 floats per row)
   constexpr int TR = kKnnTileRows;                        // candidate rows per tile
   constexpr int NT = kKnnCentres * 64;
   __shared__ __attribute__((aligned(16))) float tile[2][TR * TS];   // double buffered: one barrier per tile

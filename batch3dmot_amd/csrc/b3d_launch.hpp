@@ -106,7 +106,10 @@ inline int launch_reduce(RedArgs& a, hipStream_t stream) {
   }
   a.total = total;
   if (total == 0) return B3D_OK;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + kRedQuads - 1) / kRedQuads), dim3(kRedQuads * kRedParts), 0, stream, a);
+  int most = 0;
+  for (int i = 0; i < a.nentries; ++i) most = a.e[i].nchunks > most ? a.e[i].nchunks : most;
+  if (most > 64) hipLaunchKernelGGL((wgrad_reduce_kernel<64, 8>), dim3((total + 63) / 64), dim3(512), 0, stream, a);
+  else hipLaunchKernelGGL((wgrad_reduce_kernel<128, 4>), dim3((total + 127) / 128), dim3(512), 0, stream, a);
   return launch_check("wgrad_reduce_kernel");
 }
 

@@ -298,13 +298,10 @@ struct RedArgs {
 // per slab, still 8 slabs in flight (a plain scalar loop here -- it held the BIAS quads in round 2 -- walks the slabs one
 // load latency at a time: 450 slabs / 8 threads x 4 elements x ~0.4 us was the whole 80 us of the PoseGNN launch).  The
 // partials meet in LDS and are added in a fixed order.  Bitwise reproducible.
-// (round 4: 128 quads x 4 parts -- 64 x 8 took 75 + 17 us for the two launches of the camera+LiDAR+radar step, 128 x 4 takes 52 + 13;
-// 256 x 2: 91 + 14, 256 x 1: 130 + 15: fewer, longer per-thread chains lose more than the smaller prologue share gains)
-#ifndef B3D_RED_QUADS
-#define B3D_RED_QUADS 128
-#define B3D_RED_PARTS 4
-#endif
-constexpr int kRedQuads = B3D_RED_QUADS, kRedParts = B3D_RED_PARTS;
+// Geometry by slab count (round 4): few slabs per entry (the camera+LiDAR+radar step: 21 or 41) -> 128 quads x 4 parts (64 x 8 took
+// 75 + 17 us for its two launches, 128 x 4 takes 52 + 13; 256 x 2: 91 + 14, 256 x 1: 130 + 15); hundreds of slabs (PoseGNN: ~450) ->
+// 64 x 8, twice the slabs in flight per quad (128 x 4 took 29 us there against 23).
+template <int kRedQuads, int kRedParts>
 static __global__ __launch_bounds__(kRedQuads * kRedParts) void wgrad_reduce_kernel(const RedArgs a) {
   __shared__ v4f part[kRedParts][kRedQuads];
   const int el = threadIdx.x % kRedQuads, sub = threadIdx.x / kRedQuads;
