@@ -106,9 +106,10 @@ inline int launch_reduce(RedArgs& a, hipStream_t stream) {
   }
   a.total = total;
   if (total == 0) return B3D_OK;
-  int most = 0;
-  for (int i = 0; i < a.nentries; ++i) most = a.e[i].nchunks > most ? a.e[i].nchunks : most;
-  if (most > 64) hipLaunchKernelGGL((wgrad_reduce_kernel<64, 8>), dim3((total + 63) / 64), dim3(512), 0, stream, a);
+  // slabs per output quad, averaged over the launch (a launch is mostly made of its largest matrices)
+  double weighted = 0.0;
+  for (int i = 0; i < a.nentries; ++i) weighted += (double)a.e[i].nchunks * ((a.e[i].N * a.e[i].K + a.e[i].N + 3) / 4);
+  if (weighted / total > 64.0) hipLaunchKernelGGL((wgrad_reduce_kernel<64, 8>), dim3((total + 63) / 64), dim3(512), 0, stream, a);
   else hipLaunchKernelGGL((wgrad_reduce_kernel<128, 4>), dim3((total + 127) / 128), dim3(512), 0, stream, a);
   return launch_check("wgrad_reduce_kernel");
 }
