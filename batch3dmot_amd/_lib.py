@@ -66,6 +66,10 @@ class b3d_mha(C.Structure):
                 ("out_proj_bias", C.c_void_p)]
 
 
+class b3d_mlp_desc(C.Structure):
+    _fields_ = [("n_layers", C.c_int32), ("widths", C.c_int32 * 6), ("relu_mask", C.c_uint32), ("final_sigmoid", C.c_int32)]
+
+
 class b3d_clr_weights(C.Structure):
     _fields_ = [("edge_encoder", b3d_linear * 3), ("node_encoder", b3d_linear * 2), ("edge_classifier", b3d_linear * 4),
                 ("fc_lidar_encoder", b3d_linear * 2), ("fc_radar_encoder", b3d_linear * 3),
@@ -241,6 +245,27 @@ def load() -> C.CDLL:
     lib.b3d_prof_pair_overhead_us.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
     lib.b3d_features.restype = C.c_uint32
     lib.b3d_features.argtypes = []
+    lib.b3d_mlp_workspace_bytes.restype = C.c_size_t
+    lib.b3d_mlp_workspace_bytes.argtypes = [C.POINTER(b3d_mlp_desc), C.c_int64, C.c_uint32]
+    lib.b3d_mlp_forward.restype = C.c_int
+    lib.b3d_mlp_forward.argtypes = [C.POINTER(b3d_mlp_desc), C.POINTER(b3d_linear), C.c_void_p, C.c_int64, C.c_uint32, C.c_void_p,
+                                    C.c_size_t, C.c_void_p, C.c_void_p]
+    lib.b3d_mlp_backward_scratch_bytes.restype = C.c_size_t
+    lib.b3d_mlp_backward_scratch_bytes.argtypes = [C.POINTER(b3d_mlp_desc), C.c_int64]
+    lib.b3d_mlp_backward.restype = C.c_int
+    lib.b3d_mlp_backward.argtypes = [C.POINTER(b3d_mlp_desc), C.POINTER(b3d_linear), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                     C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(b3d_linear), C.c_void_p]
+    lib.b3d_xattn_node_affine_workspace_bytes.restype = C.c_size_t
+    lib.b3d_xattn_node_affine_workspace_bytes.argtypes = [C.c_int64, C.c_int32, C.c_uint32]
+    lib.b3d_xattn_node_affine_forward.restype = C.c_int
+    lib.b3d_xattn_node_affine_forward.argtypes = [C.POINTER(b3d_mha), C.c_int32, C.c_void_p, C.c_int64, C.c_uint32, C.c_void_p,
+                                                  C.c_size_t, C.c_void_p, C.c_void_p]
+    lib.b3d_xattn_node_affine_scratch_bytes.restype = C.c_size_t
+    lib.b3d_xattn_node_affine_scratch_bytes.argtypes = [C.c_int64, C.c_int32]
+    lib.b3d_xattn_node_affine_backward.restype = C.c_int
+    lib.b3d_xattn_node_affine_backward.argtypes = [C.POINTER(b3d_mha), C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                                   C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(b3d_mha),
+                                                   C.c_void_p]
     _lib = lib
     return lib
 
@@ -355,6 +380,9 @@ def knn_gat(x: torch.Tensor, node_timestamps: torch.Tensor, conv, k: int = 20):
     lib = load()
     n, d = x.shape
     ts = node_timestamps.to(torch.int64).contiguous()
+    require_cuda(ts, "node_timestamps", torch.int64)
+    if ts.device != x.device or ts.numel() != n:
+        raise ValueError(f"node_timestamps must hold one int64 per row of x on {x.device}, got {tuple(ts.shape)} on {ts.device}")
     g = b3d_gat()
     keep = [conv.lin_src.weight.detach().contiguous(), conv.att_src.detach().reshape(-1).contiguous(),
             conv.att_dst.detach().reshape(-1).contiguous(), conv.bias.detach().contiguous()]
@@ -403,6 +431,8 @@ class _KnnGatFunction(torch.autograd.Function):
         g = b3d_gat()
         g.lin, g.att_src, g.att_dst, g.bias = lin.data_ptr(), att_src.data_ptr(), att_dst.data_ptr(), bias.data_ptr()
         d_y = d_y.contiguous().float()
+        if d_y.data_ptr() % 16:                      # the kernels read d_y with 16-byte loads
+            d_y = d_y.clone()
         d_x = torch.empty_like(x)
         grads = [torch.empty_like(lin), torch.empty_like(att_src), torch.empty_like(att_dst), torch.empty_like(bias)]
         gg = b3d_gat_grad()
@@ -420,8 +450,162 @@ def knn_gat_conv(x: torch.Tensor, node_timestamps: torch.Tensor, conv, k: int = 
     with gradients to ``x`` and to ``conv``'s parameters (``GATConvParams``).  D = 48 or 96."""
     require_cuda(x, "x", torch.float32)
     ts = node_timestamps.to(torch.int64).contiguous()
+    require_cuda(ts, "node_timestamps", torch.int64)
+    if ts.device != x.device or ts.numel() != x.size(0):
+        raise ValueError(f"node_timestamps must hold one int64 per row of x on {x.device}, got {tuple(ts.shape)} on {ts.device}")
     y, nbr, cnt = _KnnGatFunction.apply(x, ts, int(k), conv.lin_src.weight, conv.att_src, conv.att_dst, conv.bias)
     return (y, nbr, cnt) if return_graph else y
+
+
+def _mlp_desc(widths, relu_mask: int, final_sigmoid: bool) -> b3d_mlp_desc:
+    d = b3d_mlp_desc()
+    d.n_layers = len(widths) - 1
+    for i, w in enumerate(widths):
+        d.widths[i] = int(w)
+    d.relu_mask = int(relu_mask)
+    d.final_sigmoid = 1 if final_sigmoid else 0
+    return d
+
+
+class _MlpFunction(torch.autograd.Function):
+    """``nn.Sequential(Linear, ReLU, ..., [Sigmoid])`` as ``b3d_mlp_forward`` / ``b3d_mlp_backward``."""
+
+    @staticmethod
+    def forward(ctx, x, relu_mask, final_sigmoid, *wb):
+        lib = load()
+        n_layers = len(wb) // 2
+        ws_ = wb[0::2]
+        widths = [int(ws_[0].size(1))] + [int(w.size(0)) for w in ws_]
+        if x.dim() != 2 or x.size(1) != widths[0]:
+            raise ValueError(f"mlp: input must be [rows, {widths[0]}], got {tuple(x.shape)}")
+        xc = x.detach().contiguous()
+        keep = [t.detach().contiguous() for t in wb]
+        for t in keep:
+            require_cuda(t, "mlp parameter", torch.float32)
+        rows = int(xc.size(0))
+        d = _mlp_desc(widths, relu_mask, final_sigmoid)
+        layers = (b3d_linear * n_layers)()
+        for l in range(n_layers):
+            layers[l].w, layers[l].b = keep[2 * l].data_ptr(), keep[2 * l + 1].data_ptr()
+        training = torch.is_grad_enabled() and (x.requires_grad or any(t.requires_grad for t in wb))
+        flags = B3D_FLAG_TRAINING if training else 0
+        nbytes = lib.b3d_mlp_workspace_bytes(C.byref(d), rows, flags)
+        if nbytes == 0:
+            raise ValueError(f"mlp: unsupported stack {widths}")
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        y = torch.empty((rows, widths[-1]), dtype=torch.float32, device=x.device)
+        check(lib.b3d_mlp_forward(C.byref(d), layers, xc.data_ptr(), rows, flags, ws.data_ptr(), nbytes, y.data_ptr(),
+                                  current_stream(x.device)), "b3d_mlp_forward")
+        ctx.d, ctx.ws, ctx.nbytes, ctx.training = d, ws, nbytes, training
+        ctx.save_for_backward(xc, y, *keep)
+        return y
+
+    @staticmethod
+    def backward(ctx, d_y):
+        lib = load()
+        if not ctx.training:
+            raise RuntimeError("backward through an mlp forward that ran without gradient tracking")
+        xc, y, *keep = ctx.saved_tensors
+        n_layers = len(keep) // 2
+        rows = int(xc.size(0))
+        layers = (b3d_linear * n_layers)()
+        grads = (b3d_linear * n_layers)()
+        out = [torch.empty_like(t) for t in keep]
+        for l in range(n_layers):
+            layers[l].w, layers[l].b = keep[2 * l].data_ptr(), keep[2 * l + 1].data_ptr()
+            grads[l].w, grads[l].b = out[2 * l].data_ptr(), out[2 * l + 1].data_ptr()
+        d_y = d_y.contiguous().float()
+        d_x = torch.empty_like(xc) if ctx.needs_input_grad[0] else None
+        sbytes = lib.b3d_mlp_backward_scratch_bytes(C.byref(ctx.d), rows)
+        scratch = torch.empty(sbytes, dtype=torch.uint8, device=xc.device)
+        check(lib.b3d_mlp_backward(C.byref(ctx.d), layers, xc.data_ptr(), y.data_ptr(), rows, ctx.ws.data_ptr(), ctx.nbytes,
+                                   scratch.data_ptr(), sbytes, d_y.data_ptr(), ptr(d_x), grads, current_stream(xc.device)),
+              "b3d_mlp_backward")
+        return (d_x, None, None, *out)
+
+
+def mlp(seq, x: torch.Tensor) -> torch.Tensor:
+    """``seq(x)`` for an ``nn.Sequential`` of Linear / ReLU (/ trailing Sigmoid) modules through the library's MLP operator
+    (``b3d_mlp_forward`` / ``_backward``), differentiable in ``x`` and in the Linear parameters."""
+    from torch import nn
+    require_cuda(x, "x", torch.float32)
+    lins, relu_mask, sigmoid = [], 0, False
+    for m in seq:
+        if isinstance(m, nn.Linear):
+            if sigmoid:
+                raise ValueError("mlp: a Linear behind the Sigmoid")
+            if m.bias is None:
+                raise ValueError("mlp: Linear layers without bias are not supported")
+            lins.append(m)
+        elif isinstance(m, nn.ReLU):
+            if not lins:
+                raise ValueError("mlp: ReLU in front of the first Linear")
+            relu_mask |= 1 << (len(lins) - 1)
+        elif isinstance(m, nn.Sigmoid):
+            sigmoid = True
+        else:
+            raise ValueError(f"mlp: unsupported module {type(m).__name__}")
+    if not 1 <= len(lins) <= 5:
+        raise ValueError(f"mlp: {len(lins)} Linear layers (1..5 supported)")
+    wb = [t for m in lins for t in (m.weight, m.bias)]
+    return _MlpFunction.apply(x, relu_mask, sigmoid, *wb)
+
+
+class _XattnFunction(torch.autograd.Function):
+    """``nn.MultiheadAttention`` with one query and one key per edge == ``out_proj(v_proj(value))`` per node
+    (``b3d_xattn_node_affine_*``; clr_att_gnn.py:143-159)."""
+
+    @staticmethod
+    def forward(ctx, x, in_w, in_b, out_w, out_b):
+        lib = load()
+        d = int(out_w.size(0))
+        if x.dim() != 2 or x.size(1) != d or tuple(in_w.shape) != (3 * d, d):
+            raise ValueError(f"xattn: x {tuple(x.shape)}, in_proj_weight {tuple(in_w.shape)}, embed dim {d}")
+        xc = x.detach().contiguous()
+        keep = [t.detach().contiguous() for t in (in_w, in_b, out_w, out_b)]
+        for t in keep:
+            require_cuda(t, "attention parameter", torch.float32)
+        att = b3d_mha()
+        att.in_proj_weight, att.in_proj_bias, att.out_proj_weight, att.out_proj_bias = (t.data_ptr() for t in keep)
+        n = int(xc.size(0))
+        training = torch.is_grad_enabled() and (x.requires_grad or any(t.requires_grad for t in (in_w, in_b, out_w, out_b)))
+        flags = B3D_FLAG_TRAINING if training else 0
+        nbytes = lib.b3d_xattn_node_affine_workspace_bytes(n, d, flags)
+        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=x.device)
+        y = torch.empty((n, d), dtype=torch.float32, device=x.device)
+        check(lib.b3d_xattn_node_affine_forward(C.byref(att), d, xc.data_ptr(), n, flags, ws.data_ptr(), nbytes, y.data_ptr(),
+                                                current_stream(x.device)), "b3d_xattn_node_affine_forward")
+        ctx.dim, ctx.ws, ctx.nbytes, ctx.training = d, ws, nbytes, training
+        ctx.save_for_backward(xc, y, *keep)
+        return y
+
+    @staticmethod
+    def backward(ctx, d_y):
+        lib = load()
+        if not ctx.training:
+            raise RuntimeError("backward through an xattn forward that ran without gradient tracking")
+        xc, y, *keep = ctx.saved_tensors
+        d, n = ctx.dim, int(xc.size(0))
+        att = b3d_mha()
+        att.in_proj_weight, att.in_proj_bias, att.out_proj_weight, att.out_proj_bias = (t.data_ptr() for t in keep)
+        out = [torch.empty_like(t) for t in keep]
+        g = b3d_mha()
+        g.in_proj_weight, g.in_proj_bias, g.out_proj_weight, g.out_proj_bias = (t.data_ptr() for t in out)
+        d_y = d_y.contiguous().float()
+        d_x = torch.empty_like(xc) if ctx.needs_input_grad[0] else None
+        sbytes = lib.b3d_xattn_node_affine_scratch_bytes(n, d)
+        scratch = torch.empty(sbytes, dtype=torch.uint8, device=xc.device)
+        check(lib.b3d_xattn_node_affine_backward(C.byref(att), d, xc.data_ptr(), y.data_ptr(), n, ctx.ws.data_ptr(), ctx.nbytes,
+                                                 scratch.data_ptr(), sbytes, d_y.data_ptr(), ptr(d_x), C.byref(g),
+                                                 current_stream(xc.device)), "b3d_xattn_node_affine_backward")
+        return (d_x, *out)
+
+
+def xattn_node_affine(att, x: torch.Tensor) -> torch.Tensor:
+    """What ``att(query, key, value)`` returns when every query has ONE key (clr_att_gnn.py:143-159), for the value rows
+    ``x`` [N, D]: ``att.out_proj(v_proj(x))``, differentiable; the query / key thirds of ``in_proj`` get zero gradients."""
+    require_cuda(x, "x", torch.float32)
+    return _XattnFunction.apply(x, att.in_proj_weight, att.in_proj_bias, att.out_proj.weight, att.out_proj.bias)
 
 
 class Workspace:

@@ -436,10 +436,13 @@ class GNN(nn.Module):
 
     def _forward_writeback(self, data, encoded=None, rows=None):
         """``knn_writeback=True``: the layer loop in Python over the library's operators -- frozen encoders (HIP), the k-NN + GAT
-        block with its backward (``_lib.knn_gat_conv``), the CausalMessagePassing layer operator (``mp_layer``) -- with the
-        small dense parts (modality heads, the per-node ``out_proj(v_proj(.))`` of the one-key attention, att_edge_encoder,
-        edge / node encoder, classifier) as PyTorch-ROCm modules.  The whole-model entry point cannot be used: the per-node
-        tables of its hoisted first layers are produced from the x the block would replace."""
+        block with its backward (``_lib.knn_gat_conv``), the CausalMessagePassing layer operator (``mp_layer``), the dense
+        stacks (modality heads, att_edge_encoder, edge / node encoder, classifier) through ``_lib.mlp`` (b3d_mlp_forward /
+        _backward) and the one-key attention's per-node ``out_proj(v_proj(.))`` through ``_lib.xattn_node_affine``
+        (b3d_xattn_node_affine_*): no ``nn.Linear`` / ``nn.MultiheadAttention`` forward runs.  PyTorch keeps the index plumbing
+        (row scatters of the modality heads, the per-edge gather + concatenation in front of att_edge_encoder).  The whole-model
+        entry point cannot be used: the per-node tables of its hoisted first layers are produced from the x the block would
+        replace."""
         pose_feats, edge_index, node_timestamps = data.pose_feats, data.edge_index, data.node_timestamps
         _lib.require_cuda(pose_feats, "data.pose_feats", torch.float32)
         if edge_index.size(1) == 0 or pose_feats.size(0) == 0:
@@ -448,21 +451,19 @@ class GNN(nn.Module):
         if encoded is None:
             encoded = self._encode(data, rows, join=True)[0]
         x_img, pointnet_out, lidar_nodes, radarnet_out, radar_nodes = encoded
-        e = self.edge_encoder(data.edge_attr.float())
+        e = _lib.mlp(self.edge_encoder, data.edge_attr.float().contiguous())
         x_lidar = x_img.new_zeros((n, 128))
         x_radar = x_img.new_zeros((n, 64))
         if lidar_nodes.numel():
-            x_lidar = x_lidar.index_copy(0, lidar_nodes.long(), self.fc_lidar_encoder(pointnet_out))
+            x_lidar = x_lidar.index_copy(0, lidar_nodes.long(), _lib.mlp(self.fc_lidar_encoder, pointnet_out.contiguous()))
         if radar_nodes.numel():
-            x_radar = x_radar.index_copy(0, radar_nodes.long(), self.fc_radar_encoder(radarnet_out))
-
-        def one_key(att, x, d):            # MultiheadAttention with ONE key: softmax == 1, the output is out_proj(v_proj(value))
-            v = torch.nn.functional.linear(x, att.in_proj_weight[2 * d:], att.in_proj_bias[2 * d:])
-            return att.out_proj(v)
-        s = torch.cat([one_key(self.r2r_att, x_radar, 64), one_key(self.l2l_att, x_lidar, 128), one_key(self.c2c_att, x_img, 96)], 1)
-        att = self.att_edge_encoder(torch.cat([s[edge_index[1]], s[edge_index[0]], e], 1))     # x_sens_i | x_sens_j | edge_attr
+            x_radar = x_radar.index_copy(0, radar_nodes.long(), _lib.mlp(self.fc_radar_encoder, radarnet_out.contiguous()))
+        # MultiheadAttention with ONE key: softmax == 1, the output is out_proj(v_proj(value)) of the value's node
+        s = torch.cat([_lib.xattn_node_affine(self.r2r_att, x_radar), _lib.xattn_node_affine(self.l2l_att, x_lidar),
+                       _lib.xattn_node_affine(self.c2c_att, x_img.contiguous())], 1)
+        att = _lib.mlp(self.att_edge_encoder, torch.cat([s[edge_index[1]], s[edge_index[0]], e], 1))     # x_sens_i | x_sens_j | edge_attr
         x_sens = torch.cat([x_img, x_lidar, x_radar], 1)
-        x0 = self.node_encoder(pose_feats)
+        x0 = _lib.mlp(self.node_encoder, pose_feats)
         x = x0
         self._last_knn = []
         for i in range(self.depth):
@@ -470,7 +471,7 @@ class GNN(nn.Module):
                 x, nbr, cnt = _lib.knn_gat_conv(x.contiguous(), node_timestamps, self.knn_conv, 20, return_graph=True)
                 self._last_knn.append((nbr, cnt))
             x, e = self.message_passing(x.contiguous(), edge_index, e.contiguous(), x0.contiguous(), att.contiguous())
-        return self.edge_classifier(e), x_sens
+        return _lib.mlp(self.edge_classifier, e.contiguous()), x_sens
 
     def _hip_params(self):
         """Parameters whose gradients ``backward`` of the HIP path produces, in C-ABI struct order."""

@@ -27,7 +27,7 @@ namespace {
 // are three [row][k] bf16 images each -- and a 32-wide k group of a 16 x 16 block is six v_mfma_f32_16x16x32_bf16 (96 cycles)
 // instead of eight v_mfma_f32_16x16x4_f32 (256 cycles); 64 k per barrier instead of 32.  The exact-fp32 form of this kernel sat
 // at 19 % MFMA-busy and 52 us for [1,500 x 1,024] . [1,024 x 512]: one barrier per 16 MFMAs of a wavefront.
-constexpr int kTM = 64, kTN = 64, kFcThreads = 512, kFcCus = 256;
+constexpr int kTM = 64, kTN = 64, kFcThreads = 512;
 // TK: k per barrier.  64: 110 KB of LDS, one workgroup per CU -- the form of every launch that fits the chip in one round; 32: 61 KB, two
 // workgroups per CU -- for the launches with more tiles than CUs (a 2,100 x 512 layer is 264 tiles: at one workgroup per CU the last 8
 // ran as a second round, 53 us for a 22 us workgroup).
@@ -372,7 +372,16 @@ extern "C" int b3d_fc_bn_forward(const float* x, int32_t B, int32_t K, const flo
   B3D_REQUIRE(nct <= 63, "b3d_fc_bn_forward: N %d > 4032 columns (one arrival counter per 64-column tile in the workspace header)", (int)N);
   const dim3 grid((unsigned)((nrt + 7) / 8 * 8 * nct));                // row tiles padded to whole rounds of the eight XCDs
   // more tiles than CUs: the 61 KB form, two workgroups per CU, keeps the launch to one round
-  const bool small = nrt * nct > kFcCus;
+  static int cus_of[64] = {};                                          // compute units per device ordinal (0 = not asked yet)
+  int dev = 0;
+  B3D_HIP_CHECK(hipGetDevice(&dev));
+  if (dev >= 0 && dev < 64 && cus_of[dev] == 0) {
+    int cus = 0;
+    B3D_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    cus_of[dev] = cus > 0 ? cus : 256;
+  }
+  const int n_cus = (dev >= 0 && dev < 64) ? cus_of[dev] : 256;
+  const bool small = nrt * nct > n_cus;
   auto go = [&](auto kern, int lds) -> int {
     B3D_TRY(set_lds_cached(reinterpret_cast<const void*>(kern), lds));
     hipLaunchKernelGGL(kern, grid, dim3(kFcThreads), lds, stream, a);

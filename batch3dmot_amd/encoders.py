@@ -3,12 +3,24 @@
 ``GNN.__init__`` receives three encoder modules and freezes them (reference
 clr_att_gnn.py:17-33); the hot path only calls ``img_encoder.encode``,
 ``lidar_encoder.forward_feat`` and ``radar_encoder.forward_feat`` (clr_att_gnn.py:125,131,139).
-In eval mode (inference; training keeps them frozen but in train mode, where BatchNorm uses batch
-statistics) the point-wise conv-BN-ReLU stacks + max-pool of PointNet (both the STN and the feature
-trunk) and RadarNet -- 96 % of their arithmetic -- run as ONE HIP launch each (``b3d_point_feat``,
-csrc/b3d_encoders.hip); the small fully connected heads, ResNetAE and the train-mode path stay on
-PyTorch-ROCm (MIOpen / rocBLAS).  ``module.use_hip = False`` forces the PyTorch path.  The classes below restate the three architectures with the reference's parameter names
-so that reference checkpoints load (``resnet.*``, ``pointnet.*``, ``radarnet.*`` keys):
+For GPU inputs all three run in the HIP kernels of ``libb3d_hip.so``, in eval mode (inference) AND in the
+frozen train mode a training step holds them in (BatchNorm on batch statistics, running statistics
+updated, Dropout live):
+
+* point-wise conv-BN-ReLU stacks + max-pool of PointNet (STN and trunk) and RadarNet: ``b3d_point_feat`` /
+  ``b3d_point_feat_stats`` + the BatchNorm bookkeeping launches (csrc/b3d_encoders.hip);
+* their fully connected heads: one ``b3d_fc_bn_forward`` launch per Linear (csrc/b3d_fc.hip);
+* ``ResNetAE.encode``: six implicit-GEMM phase kernels (``b3d_resnet_encode``, csrc/b3d_resnet.hip).
+
+**No silent fallback.**  The PyTorch modules below exist for CPU tensors (checkpoint handling, the restatement
+the tests compare with) and for callers that opt out explicitly (``module.use_hip = False``, e.g. to train an
+encoder itself: the HIP path has no autograd).  A GPU input that the HIP path cannot take -- autograd through
+unfrozen encoder parameters, a crop that is not 3x32x32, a single row in train mode -- raises ``RuntimeError``
+with the reason instead of quietly running MIOpen / rocBLAS; ``path_counts()`` reports which branch every call
+took (the GPU tests assert on it).
+
+The classes restate the three architectures with the reference's parameter names so that reference checkpoints
+load (``resnet.*``, ``pointnet.*``, ``radarnet.*`` keys):
 
 * ``ResNetAE.encode``            models/resnet_fully_conv.py:56-161   3x32x32 -> 96
 * ``PointNetClassifier.forward_feat`` models/pointnet.py:9-57,111-192  3x128 -> 256
@@ -19,9 +31,42 @@ hot path never calls are declared too (unused) so ``load_state_dict(strict=True)
 """
 from __future__ import annotations
 
+import collections
+
 import torch
 from torch import nn
 import torch.nn.functional as F
+
+# (stage, "hip" | "torch") -> calls since the last reset; see path_counts()
+_PATHS: "collections.Counter" = collections.Counter()
+
+
+def path_counts(reset: bool = False) -> dict:
+    """{(stage, "hip" | "torch"): calls} of every encoder stage evaluated since the last reset."""
+    out = dict(_PATHS)
+    if reset:
+        _PATHS.clear()
+    return out
+
+
+def _route(module: nn.Module, stage: str, x: torch.Tensor, blocker) -> bool:
+    """True: the HIP kernels take this call.  False: the PyTorch modules do -- only for CPU tensors or an explicit
+    ``module.use_hip = False``.  A GPU input the HIP path cannot take (``blocker``: the reason, or None) raises."""
+    if not x.is_cuda or not getattr(module, "use_hip", True):
+        _PATHS[(stage, "torch")] += 1
+        return False
+    if blocker is not None:
+        raise RuntimeError(f"{type(module).__name__} ({stage}): {blocker}.  The HIP path cannot take this call and there is no "
+                           "silent fallback; set `module.use_hip = False` on the encoder to run the PyTorch modules "
+                           "(MIOpen / rocBLAS) deliberately.")
+    _PATHS[(stage, "hip")] += 1
+    return True
+
+
+def _autograd_blocker(module: nn.Module, x: torch.Tensor):
+    if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in module.parameters())):
+        return "autograd is on and the input or a parameter requires a gradient (the HIP encoders are forward-only: the GNN holds them frozen, clr_att_gnn.py:26-33)"
+    return None
 
 
 def _fold(layer: nn.Module, bn: nn.Module):
@@ -196,12 +241,20 @@ def _bn_struct(bn: nn.BatchNorm1d, train: bool, keep: list):
     return s
 
 
+def _draw_dropout_mask(b: int, n: int, p: float, dev) -> torch.Tensor:
+    """The [b, n] Dropout mask (0 or 1 / (1 - p)) of one fc-head stage: ONE torch call on a tensor of ones, so the draw comes
+    from torch's Philox stream exactly as ``nn.Dropout`` on a [b, n] input would take it.  Tests that pin the HIP path against
+    masks the reference drew (tests/golden/g11_*) substitute this function."""
+    return F.dropout(torch.ones(b, n, dtype=torch.float32, device=dev), p, True)
+
+
 def fc_head_hip(owner: nn.Module, x: torch.Tensor, stages, final_relu: bool = True):
     """A chain of Linear (+ BatchNorm1d + ReLU) stages on [B, K] rows, one HIP launch per Linear (``b3d_fc_bn_forward``):
     every launch applies the PREVIOUS stage's BatchNorm + ReLU while it reads its input, multiplies an optional Dropout
     mask into its output and accumulates the batch statistics its own BatchNorm needs -- BatchNorm / ReLU / Dropout
     never run as kernels of their own.  ``stages``: list of ``(fc, bn or None, dropout or None, add or None)``; a stage without ``bn``
-    must be the last one.  Train mode (``bn.training``): batch statistics, running statistics updated as torch does; the
+    must be the last one.  A Linear may have at most 4,032 outputs (one arrival counter per 64-column tile in the 256-byte
+    workspace header; the encoders' widest is 512).  Train mode (``bn.training``): batch statistics, running statistics updated as torch does; the
     Dropout mask is drawn by ONE torch call on a tensor of ones (the Philox stream stays torch's).  No autograd (frozen)."""
     import ctypes as C
     from . import _lib
@@ -232,7 +285,7 @@ def fc_head_hip(owner: nn.Module, x: torch.Tensor, stages, final_relu: bool = Tr
             train = bool(bn.training) if bn is not None else False
             mask = None
             if dropout is not None and dropout.training and dropout.p > 0:
-                mask = F.dropout(torch.ones(b, n, dtype=torch.float32, device=dev), dropout.p, True)
+                mask = _draw_dropout_mask(b, n, float(dropout.p), dev)
             y = torch.empty(b, n, dtype=torch.float32, device=dev)
             sc = torch.empty(n, dtype=torch.float32, device=dev) if bn is not None else None
             sh = torch.empty(n, dtype=torch.float32, device=dev) if bn is not None else None
@@ -254,30 +307,26 @@ def fc_head_hip(owner: nn.Module, x: torch.Tensor, stages, final_relu: bool = Tr
     return cur
 
 
-def _use_hip_fc(module: nn.Module, x: torch.Tensor, bns) -> bool:
-    """HIP fc-head chain: GPU rows, no autograd (frozen or no_grad), and -- in train mode -- more than one row."""
-    if not (x.is_cuda and getattr(module, "use_hip", True) and x.size(0) > 0 and _no_autograd(module, x)):
-        return False
-    return not any(bn.training for bn in bns) or x.size(0) > 1
+def _stack_blocker(module: nn.Module, x: torch.Tensor):
+    """Why the HIP point stack cannot take ``x`` [B, C, P] (None: it can).  Eval mode needs no autograd through it; train mode
+    additionally frozen parameters (batch statistics without a backward) and more than one point."""
+    if x.size(0) == 0:
+        return "empty batch"
+    if module.training:
+        if x.size(0) * x.size(2) <= 1:
+            return "train-mode BatchNorm needs more than one value per channel"
+        if x.requires_grad or any(p.requires_grad for p in module.parameters()):
+            return "train mode with unfrozen parameters (the HIP encoders are forward-only: the GNN holds them frozen, clr_att_gnn.py:26-33)"
+        return None
+    return _autograd_blocker(module, x)
 
 
-def _use_hip(module: nn.Module, x: torch.Tensor) -> bool:
-    return x.is_cuda and not module.training and getattr(module, "use_hip", True)
-
-
-def _use_hip_train(module: nn.Module, x: torch.Tensor) -> bool:
-    """Train mode with frozen parameters (how the GNN holds its encoders, clr_att_gnn.py:26-33): no autograd needed."""
-    return (x.is_cuda and module.training and getattr(module, "use_hip", True) and x.size(0) * x.size(2) > 1
-            and not any(p.requires_grad for p in module.parameters()) and not x.requires_grad)
-
-
-def _no_autograd(module: nn.Module, x: torch.Tensor) -> bool:
-    return not torch.is_grad_enabled() or not (x.requires_grad or any(p.requires_grad for p in module.parameters()))
-
-
-def _use_hip_resnet_train(module: nn.Module, x: torch.Tensor) -> bool:
-    return (x.is_cuda and module.training and getattr(module, "use_hip", True) and x.size(0) > 1
-            and not any(p.requires_grad for p in module.parameters()) and not x.requires_grad)
+def _fc_blocker(module: nn.Module, x: torch.Tensor, bns):
+    if x.size(0) == 0:
+        return "empty batch"
+    if any(bn.training for bn in bns) and x.size(0) <= 1:
+        return "train-mode BatchNorm needs more than one row"
+    return _autograd_blocker(module, x)
 
 
 def resnet_encode_hip(m: "ResNetAE", x: torch.Tensor) -> torch.Tensor:
@@ -386,9 +435,19 @@ class ResNetAE(nn.Module):
             nn.ConvTranspose2d(12, 3, 4, stride=2, padding=1), nn.Sigmoid())
 
     def encode(self, x):
-        if x.dim() == 4 and tuple(x.shape[1:]) == (3, 32, 32) and x.size(0) > 0 and (
-                (_use_hip(self, x) and _no_autograd(self, x)) or _use_hip_resnet_train(self, x)):
-            return resnet_encode_hip(self, x)          # the crop size the GNN feeds (other sizes: the PyTorch modules below)
+        why = None
+        if x.dim() != 4 or tuple(x.shape[1:]) != (3, 32, 32):
+            why = f"crops are [N, 3, 32, 32] (the size the GNN feeds), got {tuple(x.shape)}"
+        elif x.size(0) == 0:
+            why = "empty batch"
+        elif self.training and x.size(0) <= 1:
+            why = "train-mode BatchNorm needs more than one crop"
+        elif self.training and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            why = "train mode with unfrozen parameters (the HIP encoders are forward-only: the GNN holds them frozen, clr_att_gnn.py:26-33)"
+        elif not self.training:
+            why = _autograd_blocker(self, x)
+        if _route(self, "resnet.encode", x, why):
+            return resnet_encode_hip(self, x)
         out = self.res_block3(self.res_block2(self.res_block1(self.conv(x))))
         return out.view(out.size(0), -1)
 
@@ -403,16 +462,15 @@ class _STN3d(nn.Module):
 
     def forward(self, x):
         b = x.size(0)
-        if _use_hip(self, x) and b > 0:
-            x = point_feat_hip((self.conv1, self.conv2, self.conv3), (self.bn1, self.bn2, self.bn3), x, relu_last=True)
-        elif _use_hip_train(self, x):
-            x = point_feat_train_hip((self.conv1, self.conv2, self.conv3), (self.bn1, self.bn2, self.bn3), x, relu_last=True)
+        if _route(self, "stn.points", x, _stack_blocker(self, x)):
+            stack = point_feat_train_hip if self.training else point_feat_hip
+            x = stack((self.conv1, self.conv2, self.conv3), (self.bn1, self.bn2, self.bn3), x, relu_last=True)
         else:
             x = F.relu(self.bn1(self.conv1(x)))
             x = F.relu(self.bn2(self.conv2(x)))
             x = F.relu(self.bn3(self.conv3(x)))
             x = torch.max(x, 2, keepdim=True)[0].view(-1, 1024)
-        if _use_hip_fc(self, x, (self.bn4, self.bn5)):
+        if _route(self, "stn.fc", x, _fc_blocker(self, x, (self.bn4, self.bn5))):
             iden = torch.eye(3, dtype=torch.float32, device=x.device).view(9)
             x = fc_head_hip(self, x, [(self.fc1, self.bn4, None, None), (self.fc2, self.bn5, None, None), (self.fc3, None, None, iden)])
             return x.view(-1, 3, 3)
@@ -432,10 +490,9 @@ class _PointNetFeat(nn.Module):
 
     def forward(self, x):
         trans = self.stn(x)
-        if _use_hip(self, x) and x.size(0) > 0:          # the bmm is applied while the kernel loads the points
-            return point_feat_hip((self.conv1, self.conv2, self.conv3), (self.bn1, self.bn2, self.bn3), x, trans=trans)
-        if _use_hip_train(self, x):
-            return point_feat_train_hip((self.conv1, self.conv2, self.conv3), (self.bn1, self.bn2, self.bn3), x, trans=trans)
+        if _route(self, "pointnet.points", x, _stack_blocker(self, x)):          # the bmm is applied while the kernel loads the points
+            stack = point_feat_train_hip if self.training else point_feat_hip
+            return stack((self.conv1, self.conv2, self.conv3), (self.bn1, self.bn2, self.bn3), x, trans=trans)
         x = torch.bmm(x.transpose(2, 1), trans).transpose(2, 1)
         x = F.relu(self.bn1(self.conv1(x)))
         x = F.relu(self.bn2(self.conv2(x)))
@@ -455,7 +512,7 @@ class PointNetClassifier(nn.Module):
 
     def forward_feat(self, x):
         x = self.feat(x)
-        if _use_hip_fc(self, x, (self.bn1, self.bn2)):
+        if _route(self, "pointnet.fc", x, _fc_blocker(self, x, (self.bn1, self.bn2))):
             return fc_head_hip(self, x, [(self.fc1, self.bn1, None, None), (self.fc2, self.bn2, self.dropout, None)])
         x = F.relu(_fc_bn(self.fc1, self.bn1, x))
         if not _fold_on(self.bn2):
@@ -470,10 +527,9 @@ class _RadarNetFeat(nn.Module):
         self.bn1, self.bn2, self.bn3 = nn.BatchNorm1d(64), nn.BatchNorm1d(128), nn.BatchNorm1d(1024)
 
     def forward(self, x):
-        if _use_hip(self, x) and x.size(0) > 0:
-            return point_feat_hip((self.conv1, self.conv2, self.conv3), (self.bn1, self.bn2, self.bn3), x)
-        if _use_hip_train(self, x):
-            return point_feat_train_hip((self.conv1, self.conv2, self.conv3), (self.bn1, self.bn2, self.bn3), x)
+        if _route(self, "radarnet.points", x, _stack_blocker(self, x)):
+            stack = point_feat_train_hip if self.training else point_feat_hip
+            return stack((self.conv1, self.conv2, self.conv3), (self.bn1, self.bn2, self.bn3), x)
         x = F.relu(self.bn1(self.conv1(x)))
         x = F.relu(self.bn2(self.conv2(x)))
         x = self.bn3(self.conv3(x))
@@ -490,7 +546,7 @@ class RadarNetClassifier(nn.Module):
 
     def forward_feat(self, x):
         x = self.feat(x)
-        if _use_hip_fc(self, x, (self.bn1, self.bn2)):
+        if _route(self, "radarnet.fc", x, _fc_blocker(self, x, (self.bn1, self.bn2))):
             return fc_head_hip(self, x, [(self.fc1, self.bn1, None, None), (self.fc2, self.bn2, self.dropout, None)])
         x = F.relu(_fc_bn(self.fc1, self.bn1, x))
         if not _fold_on(self.bn2):

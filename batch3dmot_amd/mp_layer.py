@@ -158,6 +158,10 @@ def _graph_for(module, edge_index: torch.Tensor, n: int):
     if hit is not None and hit[0] == key and hit[1]() is edge_index:
         if hit[4] != cur:
             cur.wait_event(hit[3])
+            # the structure's storage belongs to the BUILD stream's pool: tell the caching allocator that this stream reads it
+            # too, or a replaced / dropped entry could be handed out again on the build stream while kernels enqueued here
+            # still walk it
+            hit[2].ws.record_stream(cur)
         return hit[2]
     graph = _lib.Graph(edge_index.contiguous(), n)
     ev = torch.cuda.Event()

@@ -207,16 +207,17 @@ class PoseGNN(nn.Module):
 
     def _forward_writeback(self, data):
         """``knn_writeback=True``: a layer loop in Python over the library's operators -- the frame-wise k-NN + GAT block with its
-        backward (``_lib.knn_gat_conv``: b3d_knn_gat_forward / _backward) and the CausalMessagePassing layer operator (``mp_layer``:
-        b3d_pose_layer_forward / _backward) -- with the three small encoder / classifier MLPs (4-8-16-32, 19-24-36-48,
-        32-16-8-4-1) as PyTorch-ROCm modules.  The whole-model entry point cannot be used: the per-node tables of its hoisted first
-        layers are produced by the previous layer's node kernel from the x the block would replace."""
+        backward (``_lib.knn_gat_conv``: b3d_knn_gat_forward / _backward), the CausalMessagePassing layer operator (``mp_layer``:
+        b3d_pose_layer_forward / _backward) and the three small encoder / classifier MLPs (4-8-16-32, 19-24-36-48,
+        32-16-8-4-1) through the library's MLP operator (``_lib.mlp``: b3d_mlp_forward / _backward); no ``nn.Linear`` runs.  The
+        whole-model entry point cannot be used: the per-node tables of its hoisted first layers are produced by the previous
+        layer's node kernel from the x the block would replace."""
         pose_feats, edge_index, node_timestamps = data.pose_feats, data.edge_index, data.node_timestamps
         _lib.require_cuda(pose_feats, "data.pose_feats", torch.float32)
         if edge_index.size(1) == 0 or pose_feats.size(0) == 0:
             raise ValueError("empty graph: the reference's callers skip these (predict.py:179-180)")
-        e = self.edge_encoder(data.edge_attr.float())
-        x0 = self.node_encoder(pose_feats)
+        e = _lib.mlp(self.edge_encoder, data.edge_attr.float().contiguous())
+        x0 = _lib.mlp(self.node_encoder, pose_feats)
         x = x0
         self._last_knn = []
         for i in range(self.depth):
@@ -224,7 +225,7 @@ class PoseGNN(nn.Module):
                 x, nbr, cnt = _lib.knn_gat_conv(x.contiguous(), node_timestamps, self.knn_conv, 20, return_graph=True)
                 self._last_knn.append((nbr, cnt))
             x, e = self.message_passing(x.contiguous(), edge_index, e.contiguous(), x0.contiguous())
-        return self.edge_classifier(e), x0
+        return _lib.mlp(self.edge_classifier, e.contiguous()), x0
 
     def forward(self, data):
         if self.knn_writeback:

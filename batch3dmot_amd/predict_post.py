@@ -208,13 +208,16 @@ def predict_scene(model, windows, node_class: torch.Tensor, class_names: Sequenc
     cache_obj = None
     if isinstance(model, GNN) and cache is not False:
         cache_obj = cache if isinstance(cache, EmbeddingCache) else EmbeddingCache()
-        was_training = model.training
+        # every module's own flag is restored: `model.train(was_training)` would put a sub-module the caller (or the sticky
+        # `.eval()` switch of clr_att_gnn.py:128-139) had left in eval mode back into train mode
+        modes = [(mod, mod.training) for mod in model.modules()]
         model.eval()
         try:
             cache_obj.add_windows(model, wins, ids_of=ids_of)
             tables = cache_obj.scene_tables(gids)
         finally:
-            model.train(was_training)
+            for mod, flag in modes:
+                mod.training = flag
     pairs, scores = [], []
     with torch.no_grad():
         for b0 in range(0, len(wins), max(1, windows_per_forward)):

@@ -13,8 +13,13 @@ from __future__ import annotations
 
 from typing import Optional
 
+import collections
+
 import torch
 import torch.nn.functional as F
+
+# which implementation every step took: {"fused_loss" | "torch_loss", "flat_adam" | "torch_optimizer"} -> steps (tests assert on it)
+PATHS: "collections.Counter" = collections.Counter()
 
 
 def edge_loss(out: torch.Tensor, data, batch_size: int, loss_kind: str = "cb", logits: bool = False):
@@ -61,7 +66,9 @@ def forward_backward(gnn, data, optimizer, batch_size: int = 2, loss_kind: str =
     eager between the two replays."""
     out, aux = gnn(data, **forward_kwargs) if forward_kwargs else gnn(data)
     if fused_loss is None:
-        fused_loss = out.is_cuda
+        fused_loss = out.is_cuda                # GPU scores: always b3d_edge_loss; the torch form only on request (fused_loss=False)
+    PATHS["fused_loss" if fused_loss else "torch_loss"] += 1
+    PATHS["flat_adam" if hasattr(optimizer, "flat_grad") else "torch_optimizer"] += 1
     if hasattr(optimizer, "flat_grad"):
         optimizer.zero_grad()                   # optim.FlatAdam: lazy (the backward overwrites the flat buffer)
     else:
@@ -97,6 +104,13 @@ def make_optimizer(gnn, lr: float = 1e-4, weight_decay: float = 1e-4, betas=(0.9
     if flat is None:
         hip = list(gnn._hip_params()) if hasattr(gnn, "_hip_params") else []
         flat = bool(hip) and all(p.is_cuda and p.requires_grad for p in hip)
+        if hip and not flat and any(p.is_cuda for p in hip):
+            # no silent fallback: a GPU-resident HIP model whose Linear stacks are not all trainable cannot use the one-launch
+            # Adam (its flat buffer IS the backward's gradient storage)
+            frozen = sum(1 for p in hip if not p.requires_grad)
+            raise RuntimeError(f"make_optimizer: {frozen} of the {len(hip)} parameters the HIP backward writes are frozen (or not on the "
+                               "GPU), so optim.FlatAdam (b3d_adam_step) cannot own their gradients; pass flat=False to use "
+                               "torch.optim.Adam deliberately")
     if flat:
         from .optim import FlatAdam
         return FlatAdam(gnn, lr=lr, weight_decay=weight_decay, betas=betas, capturable=capturable)

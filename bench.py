@@ -170,8 +170,13 @@ class Workload:
     `captured(i)`: the same step split into the part that cannot be captured into a hipGraph (runs eagerly in front of
     every replay and feeds it) and the part that can."""
 
-    def __init__(self, kind, dev, rank, world, args, encoders="frozen", graphs=2, modalities="clr"):
+    def __init__(self, kind, dev, rank, world, args, encoders="frozen", graphs=2, modalities="clr", ap_metrics=False):
         from batch3dmot_amd import encoders as enc_mod, synth
+        # train.py:143-150 computes the average precision of the scores (overall + one per class: 8 torchmetrics calls, each a
+        # sort and a host read) inside every iteration; with ap_metrics the step runs the one-call device form of it
+        # (b3d_average_precision; the values stay on the device -- the reference reads them for its progress bar only)
+        self.ap_metrics = ap_metrics
+        self.ap_ret = {}
         from batch3dmot_amd.dist import FlatGradSync
         from batch3dmot_amd.train_step import make_optimizer
         self.kind, self.dev, self.encoders = kind, dev, encoders
@@ -235,8 +240,13 @@ class Workload:
         b = self.pool[i % len(self.pool)]
         if hasattr(b, "_b3d_graph"):
             del b._b3d_graph                     # the CSR/CSC build is part of every step
-        return train_step(self.model, b, self.opt, batch_size=self.graphs, loss_kind="cb", logits=self.logits, grad_sync=self.sync,
-                          forward_kwargs=kwargs)
+        ret = train_step(self.model, b, self.opt, batch_size=self.graphs, loss_kind="cb", logits=self.logits, grad_sync=self.sync,
+                         forward_kwargs=kwargs)
+        if self.ap_metrics:
+            from batch3dmot_amd import metrics
+            scores = torch.sigmoid(ret[1]) if self.logits else ret[1]
+            self.ap_ret[i % len(self.pool)] = metrics._run(scores, b.y, b.edge_classes, 7)
+        return ret
 
     def _run_fb(self, i, kwargs):
         from batch3dmot_amd.train_step import forward_backward
@@ -314,7 +324,8 @@ class Workload:
             enc += " (one encoder pass per step, enqueued for the NEXT pool batch on a side stream under this batch's step: train_step.EncodeAhead)"
         name = "camera+LiDAR+radar" if self.modalities == "clr" else "camera+LiDAR (radar rows all zero)"
         return (name + " GNN (clr_att_gnn) depth 6, training step (modality masks + " + enc
-                + " + CSR/CSC build + fwd + cb-BCE + bwd + Adam" + (" + flat RCCL grad all-reduce of 5.24 MB" if world > 1 else "") + ")")
+                + " + CSR/CSC build + fwd + cb-BCE + bwd + Adam" + (" + flat RCCL grad all-reduce of 5.24 MB" if world > 1 else "")
+                + (" + average precision of the scores, overall and per class, as train.py:143-150 (b3d_average_precision)" if self.ap_metrics else "") + ")")
 
 
 class StubWorkload:
@@ -665,8 +676,19 @@ def roofline_of(dom, kd, alg, exe, byts, pair_us, traffic, traffic_src):
     if traffic_src:
         src = dict(traffic_src)
         src["matches_this_library"] = (traffic_src.get("lib_sha16") == lib_sha16())
+    tr = (traffic or {}).get(dom)
+    us = kd["avg_us"]
+    both = {"mfma": {"achieved_tflops": kd["executed_tflops"], "peak_tflops": kd["mfma_peak_tflops"],
+                     "frac": round(kd["executed_tflops"] / kd["mfma_peak_tflops"], 4),
+                     "numerator": "executed fp32-equivalent FLOPs of the family per step",
+                     "denominator": "MFMA peak of the instructions it runs (157.3 exact-fp32, 2500 / 6 = 416.7 bf16x6, combined harmonically)"},
+            "hbm": {"achieved_gbs": kd["algorithmic_gbs"], "peak_gbs": PEAK_HBM_GBS, "frac": round(kd["algorithmic_gbs"] / PEAK_HBM_GBS, 4),
+                    "numerator": "bytes of the operands this launch is handed, each counted once (DESIGN.md section 4 kernel table)",
+                    "denominator": "8 TB/s HBM3E peak",
+                    "measured_traffic_gbs": round(tr / (us * 1e-6) / 1e9, 1) if tr else None,
+                    "measured_traffic_frac": round(tr / (us * 1e-6) / 1e9 / PEAK_HBM_GBS, 4) if tr else None}}
     return {"kernel": dom, "bound": BOUND[dom], "achieved": achieved, "peak": peak, "unit": unit,
-            "frac": round(achieved / peak, 4), "traffic": (traffic or {}).get(dom), "traffic_source": src,
+            "frac": round(achieved / peak, 4), "traffic": tr, "traffic_source": src, "both_roofs": both,
             "avg_launch_us": kd["avg_us"], "event_pair_overhead_us_subtracted": round(pair_us, 2),
             "launches_per_step": lps,
             "executed_flops_per_launch": exe[dom] / lps, "algorithmic_flops_per_launch": alg[dom] / lps,
@@ -685,7 +707,29 @@ ROOFLINE_NOTE = ("roofline.kernel = the SURVEY.md 8a kernel family (message pass
                  "harmonically by the kernel's share of each.  algorithmic_* count the reference's per-edge FLOPs (SURVEY.md 8d) "
                  "over the same time.  Durations: HIP event pairs on the launch stream around each launch of the family in an "
                  "eager pass of the same K steps, minus half the cost of a pair around an empty kernel (calibrated against "
-                 "rocprofv3 durations, profiles/).  traffic: HBM bytes per launch from rocprofv3 PMC passes (see traffic_source).")
+                 "rocprofv3 durations, profiles/).  traffic: HBM bytes per launch from rocprofv3 PMC passes (see traffic_source).  "
+                 "`bound` names the NEARER roof; `both_roofs` gives the fraction of the matrix pipes and of HBM for the same launch, "
+                 "each with its numerator and denominator.  The cooperative weight gradient (wgrad_edge) saturates neither: its "
+                 "time is the staging chain of a 32-row step (split to bf16 pieces, LDS writes, barrier, transposed fragment reads, "
+                 "MFMAs, barrier -- DESIGN.md section 4), HBM being the nearer roof by measured traffic.")
+
+
+def workload_roofline(wl, m, args, steps):
+    """(roofline of the path family with the most device time, the family table, (alg, exe, byts, traffic, traffic_src)) of one
+    measured workload."""
+    from batch3dmot_amd import _lib
+    e_avg = m["edges"] / steps
+    hoist = _lib.features()
+    kw = dict(n=wl.n_nodes, e=e_avg, depth=wl.model.depth)
+    if wl.kind == "clr":
+        kw.update(hoist_mp=bool(hoist.get("clr_hoist_mp")), hoist_att=bool(hoist.get("clr_hoist_att")), nl=wl.nl, nr=wl.nr)
+    alg, exe, byts, bf = wl.work.families(**kw)
+    kernels = family_table(m["fam"], steps, alg, exe, byts, bf, m["pair_us"])
+    dom = m["dom"] or max((k for k in kernels if k in PATH_FAMILIES), key=lambda k: kernels[k]["us_per_step"])
+    workload_key = f"{wl.kind}:{wl.encoders if wl.kind == 'clr' else 'na'}:knn{int(bool(wl.model.run_dead_knn))}"
+    traffic, traffic_src = load_traffic(workload_key)
+    roofline = roofline_of(dom, kernels[dom], alg, exe, byts, m["pair_us"], traffic, traffic_src)
+    return roofline, kernels, (alg, exe, byts, bf, traffic, traffic_src)
 
 
 def spawn_ranks(n):
@@ -795,12 +839,13 @@ def main():
     if (world == 1 and rank == 0 and not args.no_secondary and args.model == "clr" and args.encoders == "frozen"
             and args.modalities == "clr" and args.scaling == "weak"):
         secondary = {}
-        for key, kind, enc, mod in (("clr_encode_ahead", "clr", "frozen", "clr"), ("clr_encoders_precomputed", "clr", "precomputed", "clr"),
+        for key, kind, enc, mod in (("clr_encode_ahead", "clr", "frozen", "clr"), ("clr_with_ap_metrics", "clr", "frozen", "clr"),
+                                    ("clr_encoders_precomputed", "clr", "precomputed", "clr"),
                                     ("camera_lidar", "clr", "frozen", "cl"),
                                     ("camera_lidar_encoders_precomputed", "clr", "precomputed", "cl"), ("pose_gnn", "pose", "frozen", "clr")):
             try:
-                a2 = argparse.Namespace(**{**vars(args), "encode_ahead": key == "clr_encode_ahead"})
-                w2 = Workload(kind, dev, rank, world, a2, encoders=enc, modalities=mod)
+                a2 = argparse.Namespace(**{**vars(args), "encode_ahead": key == "clr_encode_ahead", "model": kind})
+                w2 = Workload(kind, dev, rank, world, a2, encoders=enc, modalities=mod, ap_metrics=(key == "clr_with_ap_metrics"))
                 k2 = max(10, args.steps // 2)
                 m2 = measure(w2, args, world, dist, k2, max(3, args.warmup // 2), 60.0, use_graph=not args.no_graph)
                 secondary[key] = {"workload": w2.describe(world), "value": round(m2["edges"] / m2["dt"], 1), "unit": "edges/s",
@@ -808,6 +853,8 @@ def main():
                                   "ms_per_step_median": round(m2["step_ms"][len(m2["step_ms"]) // 2], 4),
                                   "timed_region": "hipGraph replay" if m2["graphs"] else "eager",
                                   "replay_vs_eager_loss": m2["loss_check"]}
+                if key == "pose_gnn":                              # BASELINE.md section 4 quotes this model's ceilings: its own roofline
+                    secondary[key]["roofline"], secondary[key]["kernels"] = workload_roofline(w2, m2, a2, k2)[:2]
                 del w2
             except Exception as exc:                                # a secondary figure must never cost the headline
                 secondary[key] = {"error": f"{type(exc).__name__}: {str(exc)[:200]}"}
@@ -828,18 +875,8 @@ def main():
 
     if rank == 0:
         e_avg = m["edges"] / args.steps
-        depth = wl.model.depth
-        hoist = _lib.features()
-        kw = dict(n=wl.n_nodes, e=e_avg, depth=depth)
-        if args.model == "clr":
-            kw.update(hoist_mp=bool(hoist.get("clr_hoist_mp")), hoist_att=bool(hoist.get("clr_hoist_att")), nl=wl.nl, nr=wl.nr)
-        alg, exe, byts, bf = wl.work.families(**kw)
+        roofline, kernels, (alg, exe, byts, bf, traffic, traffic_src) = workload_roofline(wl, m, args, args.steps)
         kernels_warmup = family_table(m["fam_all"], args.warmup, alg, exe, byts, bf, m["pair_us"]) if m["fam_all"] else {}
-        kernels = family_table(m["fam"], args.steps, alg, exe, byts, bf, m["pair_us"])
-        dom = m["dom"] or max((k for k in kernels if k in PATH_FAMILIES), key=lambda k: kernels[k]["us_per_step"])
-        workload_key = f"{args.model}:{args.encoders if args.model == 'clr' else 'na'}:knn{int(not args.no_dead_knn)}"
-        traffic, traffic_src = load_traffic(workload_key)
-        roofline = roofline_of(dom, kernels[dom], alg, exe, byts, m["pair_us"], traffic, traffic_src)
         roofline["note"] = ROOFLINE_NOTE
         roofline_enc = None
         if "point_feat" in kernels and "point_feat" in alg:

@@ -238,6 +238,46 @@ int b3d_clr_layer_backward(const b3d_mp_weights* weights, const b3d_graph* g, co
                            size_t workspace_bytes, const float* d_x_new, const float* d_e_new, float* d_x, float* d_x0,
                            float* d_e, float* d_att_edge_attr, const b3d_mp_grads* grads, b3d_stream stream);
 
+/* ---- row-wise MLP stacks as a standalone operator (b3d_mlp_fwd/bwd) -----------------------------------
+ * Replaces nn.Sequential(Linear, ReLU, Linear, ...[, Sigmoid]).forward and its autograd for the reference's small stacks:
+ * edge_encoder / node_encoder / edge_classifier (pose_gnn.py:29-53, clr_att_gnn.py:35-58), fc_lidar_encoder /
+ * fc_radar_encoder (clr_att_gnn.py:60-72), att_edge_encoder (clr_att_gnn.py:81-91).  The whole-model entry points run the
+ * same stacks inside their fused kernels; these are for callers that drive the layers themselves (GNN.knn_writeback).
+ * x [rows, widths[0]] -> y [rows, widths[n_layers]], dense row-major fp32; layers[l] = {w [widths[l+1], widths[l]], b or NULL}.
+ * Exact-fp32 matrix instruction (v_mfma_f32_16x16x4_f32, bitwise an fmaf chain); weight gradients summed over fixed row
+ * chunks in chunk order (bitwise reproducible, no float atomics).
+ * forward: with B3D_FLAG_TRAINING the hidden activations stay in `workspace` for backward (pass it on untouched).
+ * backward: x and y as the forward saw / produced them, d_y [rows, widths[n_layers]]; d_x may be NULL; grads[l].w / .b are
+ * OVERWRITTEN (each may be NULL); `scratch` (b3d_mlp_backward_scratch_bytes) is free after the call.  rows == 0: zero gradients. */
+typedef struct b3d_mlp_desc {
+  int32_t n_layers;          /* 1..5 Linear layers */
+  int32_t widths[6];         /* widths[0] = input features, widths[l+1] = outputs of layer l; each 1..1024 */
+  uint32_t relu_mask;        /* bit l: a ReLU follows layer l */
+  int32_t final_sigmoid;     /* != 0: a Sigmoid follows the last layer (clr_att_gnn.py:57) */
+} b3d_mlp_desc;
+size_t b3d_mlp_workspace_bytes(const b3d_mlp_desc* d /* host */, int64_t rows, uint32_t flags);
+int b3d_mlp_forward(const b3d_mlp_desc* d /* host */, const b3d_linear* layers /* host array of device pointers */,
+                    const float* x, int64_t rows, uint32_t flags, void* workspace, size_t workspace_bytes, float* y,
+                    b3d_stream stream);
+size_t b3d_mlp_backward_scratch_bytes(const b3d_mlp_desc* d /* host */, int64_t rows);
+int b3d_mlp_backward(const b3d_mlp_desc* d, const b3d_linear* layers, const float* x, const float* y, int64_t rows,
+                     void* workspace, size_t workspace_bytes, void* scratch, size_t scratch_bytes, const float* d_y,
+                     float* d_x, const b3d_linear_grad* grads /* host */, b3d_stream stream);
+
+/* ---- the one-key cross-edge attention per NODE (b3d_xattn_node_affine) -------------------------------
+ * clr_att_gnn.py:143-159 calls nn.MultiheadAttention(D, 2 heads) with ONE query and ONE key per edge: the softmax over a
+ * single key is 1, so the module's output is out_proj(v_proj(value)) and depends on the value's node only.
+ * y [N,D] = out_proj(in_proj[2D:3D] x + in_proj_bias[2D:3D]).  Backward fills d_x (may be NULL) and `grads` (every field may
+ * be NULL): the query / key thirds of in_proj_weight / in_proj_bias receive exact zeros, as autograd gives them.
+ * Workspace / scratch as for b3d_mlp_*. */
+size_t b3d_xattn_node_affine_workspace_bytes(int64_t N, int32_t D, uint32_t flags);
+int b3d_xattn_node_affine_forward(const b3d_mha* att /* host */, int32_t D, const float* x, int64_t N, uint32_t flags,
+                                  void* workspace, size_t workspace_bytes, float* y, b3d_stream stream);
+size_t b3d_xattn_node_affine_scratch_bytes(int64_t N, int32_t D);
+int b3d_xattn_node_affine_backward(const b3d_mha* att, int32_t D, const float* x, const float* y, int64_t N, void* workspace,
+                                   size_t workspace_bytes, void* scratch, size_t scratch_bytes, const float* d_y, float* d_x,
+                                   const b3d_mha_grad* grads /* host */, b3d_stream stream);
+
 /* Same update with the step counter on the device (`*step_dev` = number of steps taken so far, incremented by
  * the call): for training steps captured into a hipGraph, where a by-value `step` would be replayed. */
 int b3d_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,

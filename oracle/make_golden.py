@@ -307,20 +307,70 @@ def golden_train_step(ref, path, num_nodes=60, k=6, graph_idx=300, salt=20):
     print(f"{path}: loss={loss.item():.6f}")
 
 
-def golden_train_mode_step(ref, path, num_nodes=60, k=6, graph_idx=900, lidar_frac=0.7, radar_frac=0.25, salt=40):
+class DropoutTape:
+    """Records (replay=None) or replays the masks of every ``torch.nn.functional.dropout`` call made inside the ``with`` block.
+    Recording draws the mask as ``dropout(ones_like(input))`` -- the same Philox draw for the same shape -- and returns
+    ``input * mask``; that this IS what the unhooked function returns for the same generator state is asserted on every call."""
+
+    def __init__(self, replay=None):
+        self.masks = [] if replay is None else None
+        self.replay = list(replay) if replay is not None else None
+
+    def __enter__(self):
+        import torch.nn.functional as F
+        self.F, self.real = F, F.dropout
+
+        def hooked(input, p=0.5, training=True, inplace=False):
+            if not training or p == 0.0:
+                return input
+            if self.replay is not None:
+                mask = self.replay.pop(0)
+                assert mask.shape == input.shape, (mask.shape, input.shape)
+                return input * mask
+            state = torch.get_rng_state()
+            want = self.real(input.clone(), p, True, False)
+            torch.set_rng_state(state)
+            mask = self.real(torch.ones_like(input), p, True, False)
+            assert torch.equal(input * mask, want), "dropout(ones) * input != dropout(input)"
+            self.masks.append(mask.clone())
+            return input * mask
+        F.dropout = hooked
+        return self
+
+    def __exit__(self, *exc):
+        self.F.dropout = self.real
+        return False
+
+
+def golden_train_mode_step(ref, path, num_nodes=60, k=6, graph_idx=900, lidar_frac=0.7, radar_frac=0.25, salt=40, dropout_live=False):
     """The training step as train.py runs it: the model in .train() -- clr_att_gnn.py:26-33 freezes the encoders'
     PARAMETERS but leaves them in train mode, so their BatchNorms use batch statistics and update their running
     statistics (pointnet.py:188-192, radarnet.py:60-64, resnet_fully_conv.py:42-82), and fewer than two rows of a
     modality flip that encoder to eval for good (clr_att_gnn.py:128-130,136-138).  Dropout (pointnet.py:190,
-    radarnet.py:62) is neutralised (p = 0): its mask is torch's Philox stream, not part of the contract."""
+    radarnet.py:62): neutralised (p = 0) in g9 / g9b; LIVE (p = 0.3, as the reference trains) with ``dropout_live`` (g11):
+    the masks the reference's run drew are recorded (DropoutTape) and stored with the fixture, the restatement and the HIP
+    path are fed the same masks."""
     graphs = [synth.make_graph(num_nodes, None, k=k, graph_idx=graph_idx + i, modalities=True,
                                lidar_frac=lidar_frac, radar_frac=radar_frac) for i in range(2)]
     data = collate(graphs)
+    tape = {"masks": None}
 
     def run(model):
+        if not dropout_live:
+            return run_(model)
+        torch.manual_seed(salt)
+        with DropoutTape(replay=tape["masks"]) as t:
+            r = run_(model)
+        if tape["masks"] is None:
+            tape["masks"] = t.masks
+            assert len(t.masks) == 2 and all(float((m_ == 0).float().mean()) > 0.15 for m_ in t.masks), "two live Dropout layers expected"
+        return r
+
+    def run_(model):
         model.train()
-        model.pointnet.dropout.p = 0.0
-        model.radarnet.dropout.p = 0.0
+        if not dropout_live:
+            model.pointnet.dropout.p = 0.0
+            model.radarnet.dropout.p = 0.0
         opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-4, betas=(0.9, 0.999))
         gt = data.y.float()
         out, x_sens = model.forward(data)
@@ -351,8 +401,9 @@ def golden_train_mode_step(ref, path, num_nodes=60, k=6, graph_idx=900, lidar_fr
     torch.save({"data": _data_dict(data), "salt": salt, "out": out, "x_sens": x_sens, "loss": loss,
                 "grad_digest": grad_digest(grads), "after_digest": grad_digest(after), "running_stats": stats, "modes": modes,
                 "lidar_rows": int((data.lidar_feats.reshape(n, -1).sum(1) != 0).sum()),
-                "radar_rows": int((data.radar_feats.reshape(n, -1).sum(1) != 0).sum())}, path)
-    print(f"{path}: loss={loss.item():.6f} modes={modes}")
+                "radar_rows": int((data.radar_feats.reshape(n, -1).sum(1) != 0).sum()),
+                **({"dropout_masks": tape["masks"], "dropout_p": 0.3} if dropout_live else {})}, path)
+    print(f"{path}: loss={loss.item():.6f} modes={modes}" + (f" dropout masks {[tuple(m_.shape) for m_ in tape['masks']]}" if dropout_live else ""))
 
 
 def golden_predict_post(path):
@@ -684,6 +735,7 @@ def main():
         ("g9_train_mode_step.pt", lambda p: golden_train_mode_step(ref, p)),
         ("g9b_train_mode_one_radar_row.pt", lambda p: golden_train_mode_step(ref, p, num_nodes=40, k=5, graph_idx=920, lidar_frac=0.6,
                                                                               radar_frac=0.013, salt=41)),
+        ("g11_train_mode_dropout_live.pt", lambda p: golden_train_mode_step(ref, p, num_nodes=50, k=5, graph_idx=940, salt=42, dropout_live=True)),
         ("g4_predict_post.pt", lambda p: golden_predict_post(p)),
         ("g7_loader.pt", lambda p: golden_loader(p)),
         ("g8_tracks.pt", lambda p: golden_tracks(p)),

@@ -12,8 +12,17 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+
+def _free_port():
+    """A TCP port nobody holds right now (bound to port 0, read back, released): two suites on one machine cannot collide the
+    way a pid-derived port can."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
 def _run(extra, nproc=2, timeout=600):
-    port = 29700 + (os.getpid() % 1500)
+    port = _free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc)] + extra
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT)

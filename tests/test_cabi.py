@@ -45,6 +45,29 @@ def test_null_arguments_are_rejected_not_crashed():
     assert st == -1
 
 
+def test_mlp_operator_descriptor_validation():
+    """b3d_mlp_* / b3d_xattn_node_affine_* (SURVEY.md 8b families): size queries and descriptor checks run without a GPU."""
+    lib = _lib.load()
+    for s in ("b3d_mlp_forward", "b3d_mlp_backward", "b3d_xattn_node_affine_forward", "b3d_xattn_node_affine_backward"):
+        assert hasattr(lib, s), s
+    d = _lib._mlp_desc([640, 512, 384, 256, 128, 64], 0b01111, False)
+    inf, tr = lib.b3d_mlp_workspace_bytes(C.byref(d), 30000, 0), lib.b3d_mlp_workspace_bytes(C.byref(d), 30000, _lib.B3D_FLAG_TRAINING)
+    assert 0 < inf < tr and tr >= 30000 * (512 + 384 + 256 + 128) * 4
+    assert lib.b3d_mlp_backward_scratch_bytes(C.byref(d), 30000) >= 2 * 30000 * 640 * 4
+    bad = _lib._mlp_desc([64, 2000], 0, False)                          # width out of range
+    assert lib.b3d_mlp_workspace_bytes(C.byref(bad), 10, 0) == 0
+    layers = (_lib.b3d_linear * 1)()
+    assert lib.b3d_mlp_forward(C.byref(bad), layers, None, 10, 0, None, 0, None, None) == -1
+    assert b"widths" in lib.b3d_last_error()
+    both = _lib._mlp_desc([8, 4], 0b1, True)                            # ReLU and Sigmoid behind the last layer
+    assert lib.b3d_mlp_forward(C.byref(both), layers, None, 10, 0, None, 0, None, None) == -1
+    ok = _lib._mlp_desc([8, 4], 0, False)
+    assert lib.b3d_mlp_forward(C.byref(ok), layers, None, 10, 0, None, 0, None, None) == -1 and b"null" in lib.b3d_last_error()
+    assert lib.b3d_xattn_node_affine_workspace_bytes(3000, 96, _lib.B3D_FLAG_TRAINING) >= 3000 * 96 * 4
+    att = _lib.b3d_mha()
+    assert lib.b3d_xattn_node_affine_forward(C.byref(att), 96, None, 10, 0, None, 0, None, None) == -1
+
+
 def test_product_path_has_no_cpu_fallback():
     import torch
     from batch3dmot_amd import synth
@@ -70,7 +93,7 @@ def test_ctypes_structs_have_the_layout_of_the_header(tmp_path):
         pytest.skip("no host C compiler")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     names = ["b3d_graph", "b3d_linear", "b3d_gat", "b3d_batchnorm", "b3d_mp_weights", "b3d_pose_weights", "b3d_pose_grads",
-             "b3d_mha", "b3d_clr_weights", "b3d_clr_grads", "b3d_clr_inputs"]
+             "b3d_mha", "b3d_clr_weights", "b3d_clr_grads", "b3d_clr_inputs", "b3d_mlp_desc"]
     src = tmp_path / "sizes.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "b3d.h"\nint main(void) {\n'
                    + "".join(f'  printf("{n} %zu\\n", sizeof({n}));\n' for n in names)

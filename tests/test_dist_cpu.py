@@ -11,6 +11,15 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+
+def _free_port():
+    """A TCP port nobody holds right now (bound to port 0, read back, released): two suites on one machine cannot collide the
+    way a pid-derived port can."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
 def _worker(rank, world, port, ret):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -57,7 +66,7 @@ def test_flat_allreduce_equals_single_process_gradient():
     from oracle.seeded import seeded_fill_
     mgr = mp.Manager()
     ret = mgr.dict()
-    port = 29500 + (os.getpid() % 2000)
+    port = _free_port()
     mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
     assert set(ret.keys()) == {0, 1}
     for n in ret[0]:

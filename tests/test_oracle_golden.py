@@ -132,6 +132,44 @@ def test_train_mode_step_oracle_matches_reference(name):
     _digest_close(grad_digest(after), g["after_digest"], rtol=1e-6)
 
 
+def test_train_mode_step_with_live_dropout_oracle_matches_reference():
+    """g11: the same step with Dropout LIVE (p = 0.3, pointnet.py:190 / radarnet.py:62, as train.py runs it).  The fixture holds
+    the masks the reference's run drew (oracle/make_golden.py: DropoutTape); the restatement is fed the same masks."""
+    g = load_golden("g11_train_mode_dropout_live.pt")
+    data = data_from(g["data"])
+    masks = [m_.clone() for m_ in g["dropout_masks"]]
+    assert len(masks) == 2 and masks[0].shape == (g["lidar_rows"], 256) and masks[1].shape == (g["radar_rows"], 256)
+    keep = 1.0 / (1.0 - g["dropout_p"])
+    for m_ in masks:
+        assert bool(((m_ == 0) | ((m_ - keep).abs() < 1e-6)).all()) and 0.2 < float((m_ == 0).float().mean()) < 0.4
+    m = _clr(g["salt"])
+    m.train()
+    import torch.nn.functional as F
+    real = F.dropout
+
+    def replay(input, p=0.5, training=True, inplace=False):
+        if not training or p == 0.0:
+            return input
+        mk = masks.pop(0)
+        assert mk.shape == input.shape
+        return input * mk
+    F.dropout = replay
+    try:
+        opt = torch.optim.Adam(m.parameters(), lr=1e-4, weight_decay=1e-4, betas=(0.9, 0.999))
+        loss, out, x_sens = ref_torch.train_step(m, data, opt, batch_size=2, loss_kind="cb")
+    finally:
+        F.dropout = real
+    assert not masks                                             # both Dropout layers ran
+    torch.testing.assert_close(out, g["out"], rtol=0, atol=2e-6)
+    torch.testing.assert_close(x_sens, g["x_sens"], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(loss, g["loss"], rtol=1e-5, atol=0)
+    bufs = dict(m.named_buffers())
+    for n, v in g["running_stats"].items():
+        torch.testing.assert_close(bufs[n].double(), v.double(), rtol=1e-5, atol=1e-6)
+    after = {n: p.detach() for n, p in m.named_parameters() if p.requires_grad}
+    _digest_close(grad_digest(after), g["after_digest"], rtol=1e-6)
+
+
 def test_predict_post_oracle_matches_reference():
     g = load_golden("g4_predict_post.pt")
     pairs, present, scores = g["pairs"], g["present"], g["scores"]

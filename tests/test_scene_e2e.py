@@ -130,3 +130,14 @@ def test_predict_scene_with_the_embedding_cache_reproduces_the_reference_indices
     single = predict_scene(m, wins, g["node_cls"].to(dev), g["class_names"], g["thresholds"], cache=True, tracks=False, windows_per_forward=1)
     assert torch.equal(single["kept_pairs"], r["kept_pairs"])
     torch.testing.assert_close(single["kept_scores"], r["kept_scores"], rtol=0, atol=1e-6)
+    if clr:
+        # the cache fill switches the model to eval and must hand every module back in ITS mode: a parent in train mode with an
+        # encoder the sticky switch (clr_att_gnn.py:128-139) had left in eval stays exactly so
+        m.train()
+        m.radarnet.eval()
+        m.fc_radar_encoder.eval()
+        again = predict_scene(m, wins, g["node_cls"].to(dev), g["class_names"], g["thresholds"], cache=True, tracks=False)
+        assert m.training and m.pointnet.training and m.resnet.training and not m.radarnet.training and not m.fc_radar_encoder.training
+        assert not any(mod.training for mod in m.radarnet.modules())
+        assert torch.equal(again["kept_pairs"], r["kept_pairs"])
+        m.eval()

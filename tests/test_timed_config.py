@@ -161,12 +161,13 @@ def test_sticky_eval_switch_inside_a_training_step():
     assert rel(out.reshape(-1), r_out.reshape(-1)) < TOL
 
 
-@pytest.mark.parametrize("name", ["g9_train_mode_step.pt", "g9b_train_mode_one_radar_row.pt"])
-def test_train_mode_step_matches_reference_golden(name):
+@pytest.mark.parametrize("name", ["g9_train_mode_step.pt", "g9b_train_mode_one_radar_row.pt", "g11_train_mode_dropout_live.pt"])
+def test_train_mode_step_matches_reference_golden(name, monkeypatch):
     """The same step against the REFERENCE's own train-mode run (oracle/make_golden.py:golden_train_mode_step executes
-    clr_att_gnn.py / pointnet.py / radarnet.py / resnet_fully_conv.py in .train(), Dropout p = 0): scores, loss, x_sens,
+    clr_att_gnn.py / pointnet.py / radarnet.py / resnet_fully_conv.py in .train()): scores, loss, x_sens,
     the encoders' BatchNorm running statistics, which sub-modules ended in eval mode (g9b: one radar row), and every
-    trainable weight after Adam."""
+    trainable weight after Adam.  g9 / g9b: Dropout p = 0.  g11: Dropout LIVE (p = 0.3, pointnet.py:190 / radarnet.py:62) --
+    the fixture holds the masks the reference's run drew and the HIP fc heads (b3d_fc_bn_forward's `mask`) are fed the same."""
     from conftest import assert_adam_heads_close, data_from, load_golden
     from batch3dmot_amd import encoders
     from batch3dmot_amd.clr_att_gnn import GNN
@@ -177,12 +178,26 @@ def test_train_mode_step_matches_reference_golden(name):
     m = GNN(encoders.ResNetAE(), encoders.PointNetClassifier(k=7), encoders.RadarNetClassifier(k=7))
     seeded_fill_(m, g["salt"])
     m = m.to(dev).train()
-    m.pointnet.dropout.p = 0.0
-    m.radarnet.dropout.p = 0.0
+    masks = None
+    if "dropout_masks" in g:
+        masks = [mk.to(dev) for mk in g["dropout_masks"]]
+
+        def recorded(b, n, p, device):
+            mk = masks.pop(0)
+            assert tuple(mk.shape) == (b, n) and abs(p - g["dropout_p"]) < 1e-12
+            return mk.contiguous()
+        monkeypatch.setattr(encoders, "_draw_dropout_mask", recorded)
+    else:
+        m.pointnet.dropout.p = 0.0
+        m.radarnet.dropout.p = 0.0
     opt = make_optimizer(m)
     before = {n: p.detach().reshape(-1)[:8].double().cpu().clone() for n, p in m.named_parameters() if p.requires_grad}
+    encoders.path_counts(reset=True)
     loss, out, x_sens = train_step(m, data, opt, batch_size=2, loss_kind="cb", logits=False)
     torch.cuda.synchronize()
+    assert masks is None or not masks                         # g11: both Dropout layers consumed their recorded mask
+    took = encoders.path_counts()
+    assert took and all(kind == "hip" for (_, kind) in took), took    # every encoder stage ran in the HIP kernels
     assert rel(out.reshape(-1), g["out"].reshape(-1)) < TOL and rel(x_sens, g["x_sens"]) < TOL
     assert abs(float(loss) - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
     assert {"pointnet": m.pointnet.training, "radarnet": m.radarnet.training, "resnet": m.resnet.training,

@@ -21,7 +21,20 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+
+
+def _find_objdump():
+    """llvm-objdump of the ROCm toolchain: $ROCM_PATH / $HIP_PATH / /opt/rocm, then PATH."""
+    for root in (os.environ.get("ROCM_PATH"), os.environ.get("HIP_PATH"), "/opt/rocm"):
+        if root:
+            for sub in ("lib/llvm/bin", "llvm/bin", "bin"):
+                c = os.path.join(root, sub, "llvm-objdump")
+                if os.path.exists(c):
+                    return c
+    return shutil.which("llvm-objdump")
+
+
+OBJDUMP = _find_objdump()
 VMEM = re.compile(r"^(global_load|global_store|global_atomic|buffer_load|buffer_store|buffer_atomic|flat_load|flat_store|flat_atomic|scratch_load|scratch_store)")
 KERNELS = ("edge_fwd_kernel", "edge_bwd_kernel")
 
@@ -68,15 +81,30 @@ def audit(name, ins):
     return res, scratch
 
 
+def demangle(name):
+    tool = shutil.which("c++filt") or shutil.which("llvm-cxxfilt") or (OBJDUMP and os.path.join(os.path.dirname(OBJDUMP), "llvm-cxxfilt"))
+    if tool and os.path.exists(tool):
+        return subprocess.run([tool, name], capture_output=True, text=True).stdout.strip() or name
+    return name
+
+
 def main():
+    """A LINT of the shipped ISA, not a proof of race freedom: the scan is linear (loop back-edges are not followed) and counts
+    instructions by mnemonic."""
     lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "batch3dmot_amd", "libb3d_hip.so")
+    if OBJDUMP is None:
+        print("audit_vmcnt: llvm-objdump not found (looked under $ROCM_PATH, $HIP_PATH, /opt/rocm and on PATH): the ISA audit cannot run")
+        return 2
+    if not os.path.exists(lib):
+        print(f"audit_vmcnt: {lib} not found (build it first: make -C batch3dmot_amd/csrc)")
+        return 2
     bad = found = 0
     with tempfile.TemporaryDirectory() as tmp:
         for co in code_objects(lib, tmp):
             for name, ins in functions(co).items():
-                if not any(k in name for k in KERNELS) or "es" not in name:
+                if not any(k in name for k in KERNELS) or "N3b3d2es" not in name:       # namespace b3d::es, mangled
                     continue
-                dem = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip().split("(")[0]
+                dem = demangle(name).split("(")[0]
                 dem = re.sub(r"b3d::MPDims<[^>]*>", "D", dem)
                 res, scratch = audit(name, ins)
                 dmas = sum(1 for s in ins if s.startswith("global_load_lds"))
