@@ -205,8 +205,15 @@ def load() -> C.CDLL:
     lib.b3d_fc_bn_workspace_bytes.argtypes = [C.c_int32, C.c_int32]
     lib.b3d_fc_bn_forward.restype = C.c_int
     lib.b3d_fc_bn_forward.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
-                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.b3d_affine.restype = C.c_int
+    lib.b3d_affine.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.b3d_point_stack_train_workspace_bytes.restype = C.c_size_t
+    lib.b3d_point_stack_train_workspace_bytes.argtypes = [C.c_int32]
+    lib.b3d_point_stack_train.restype = C.c_int
+    lib.b3d_point_stack_train.argtypes = [C.POINTER(b3d_linear), C.POINTER(b3d_batchnorm), C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                          C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.b3d_fc_ticket_init.restype = C.c_int
     lib.b3d_fc_ticket_init.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
     lib.b3d_affine_relu.restype = C.c_int
@@ -471,7 +478,7 @@ class _MlpFunction(torch.autograd.Function):
     """``nn.Sequential(Linear, ReLU, ..., [Sigmoid])`` as ``b3d_mlp_forward`` / ``b3d_mlp_backward``."""
 
     @staticmethod
-    def forward(ctx, x, relu_mask, final_sigmoid, *wb):
+    def forward(ctx, x, relu_mask, final_sigmoid, training, *wb):
         lib = load()
         n_layers = len(wb) // 2
         ws_ = wb[0::2]
@@ -487,8 +494,7 @@ class _MlpFunction(torch.autograd.Function):
         layers = (b3d_linear * n_layers)()
         for l in range(n_layers):
             layers[l].w, layers[l].b = keep[2 * l].data_ptr(), keep[2 * l + 1].data_ptr()
-        training = torch.is_grad_enabled() and (x.requires_grad or any(t.requires_grad for t in wb))
-        flags = B3D_FLAG_TRAINING if training else 0
+        flags = B3D_FLAG_TRAINING if training else 0           # (decided by the caller: grad mode is off inside Function.forward)
         nbytes = lib.b3d_mlp_workspace_bytes(C.byref(d), rows, flags)
         if nbytes == 0:
             raise ValueError(f"mlp: unsupported stack {widths}")
@@ -521,7 +527,7 @@ class _MlpFunction(torch.autograd.Function):
         check(lib.b3d_mlp_backward(C.byref(ctx.d), layers, xc.data_ptr(), y.data_ptr(), rows, ctx.ws.data_ptr(), ctx.nbytes,
                                    scratch.data_ptr(), sbytes, d_y.data_ptr(), ptr(d_x), grads, current_stream(xc.device)),
               "b3d_mlp_backward")
-        return (d_x, None, None, *out)
+        return (d_x, None, None, None, *out)
 
 
 def mlp(seq, x: torch.Tensor) -> torch.Tensor:
@@ -548,7 +554,8 @@ def mlp(seq, x: torch.Tensor) -> torch.Tensor:
     if not 1 <= len(lins) <= 5:
         raise ValueError(f"mlp: {len(lins)} Linear layers (1..5 supported)")
     wb = [t for m in lins for t in (m.weight, m.bias)]
-    return _MlpFunction.apply(x, relu_mask, sigmoid, *wb)
+    training = torch.is_grad_enabled() and (x.requires_grad or any(t.requires_grad for t in wb))
+    return _MlpFunction.apply(x, relu_mask, sigmoid, training, *wb)
 
 
 class _XattnFunction(torch.autograd.Function):
@@ -556,7 +563,7 @@ class _XattnFunction(torch.autograd.Function):
     (``b3d_xattn_node_affine_*``; clr_att_gnn.py:143-159)."""
 
     @staticmethod
-    def forward(ctx, x, in_w, in_b, out_w, out_b):
+    def forward(ctx, x, training, in_w, in_b, out_w, out_b):
         lib = load()
         d = int(out_w.size(0))
         if x.dim() != 2 or x.size(1) != d or tuple(in_w.shape) != (3 * d, d):
@@ -568,7 +575,6 @@ class _XattnFunction(torch.autograd.Function):
         att = b3d_mha()
         att.in_proj_weight, att.in_proj_bias, att.out_proj_weight, att.out_proj_bias = (t.data_ptr() for t in keep)
         n = int(xc.size(0))
-        training = torch.is_grad_enabled() and (x.requires_grad or any(t.requires_grad for t in (in_w, in_b, out_w, out_b)))
         flags = B3D_FLAG_TRAINING if training else 0
         nbytes = lib.b3d_xattn_node_affine_workspace_bytes(n, d, flags)
         ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=x.device)
@@ -598,14 +604,16 @@ class _XattnFunction(torch.autograd.Function):
         check(lib.b3d_xattn_node_affine_backward(C.byref(att), d, xc.data_ptr(), y.data_ptr(), n, ctx.ws.data_ptr(), ctx.nbytes,
                                                  scratch.data_ptr(), sbytes, d_y.data_ptr(), ptr(d_x), C.byref(g),
                                                  current_stream(xc.device)), "b3d_xattn_node_affine_backward")
-        return (d_x, *out)
+        return (d_x, None, *out)
 
 
 def xattn_node_affine(att, x: torch.Tensor) -> torch.Tensor:
     """What ``att(query, key, value)`` returns when every query has ONE key (clr_att_gnn.py:143-159), for the value rows
     ``x`` [N, D]: ``att.out_proj(v_proj(x))``, differentiable; the query / key thirds of ``in_proj`` get zero gradients."""
     require_cuda(x, "x", torch.float32)
-    return _XattnFunction.apply(x, att.in_proj_weight, att.in_proj_bias, att.out_proj.weight, att.out_proj.bias)
+    ps = (att.in_proj_weight, att.in_proj_bias, att.out_proj.weight, att.out_proj.bias)
+    training = torch.is_grad_enabled() and (x.requires_grad or any(t.requires_grad for t in ps))
+    return _XattnFunction.apply(x, training, *ps)
 
 
 class Workspace:

@@ -80,7 +80,9 @@ static_assert(PointSeq::layer_chunks(0) == 1 && PointSeq::layer_chunks(1) == 1 &
               "point_pass is written for a one-chunk fp32 first layer and bf16x3 images after it");
 
 // One group of 8 * 16 * T points: T tiles per wavefront.
-template <int P, int T, bool STATS>
+// STATS: 0 = eval (maximum only), 1 = maximum, minimum, sum, sum of squares, 2 = maximum, sum, sum of squares (the caller has
+// folded sign(gamma) of the last BatchNorm into the last layer, b3d_point_stack_train: the minimum is never needed)
+template <int P, int T, int STATS>
 struct PointPass {
   static constexpr int WPC = P / (16 * T);                   // wavefronts per cloud
   static constexpr int CPW = 8 / WPC;                        // clouds per group
@@ -101,14 +103,15 @@ struct PointPass {
 #pragma unroll
       for (int t = 1; t < WPC; ++t) {
         vmax = fmaxf(vmax, src[t * F]);
-        vmin = fminf(vmin, src[(8 + t) * F]);
+        if constexpr (STATS == 1) vmin = fminf(vmin, src[(8 + t) * F]);
         vsum += src[(16 + t) * F];
         vsq += src[(24 + t) * F];
       }
       const int c = cloud0 + cl;
       if (c < a.B) {
         const long o = (long)c * kPointFeat + chunk * F + feat;
-        a.out[o] = vmax; a.out_min[o] = vmin; a.out_sum[o] = vsum; a.out_sq[o] = vsq;
+        a.out[o] = vmax; a.out_sum[o] = vsum; a.out_sq[o] = vsq;
+        if constexpr (STATS == 1) a.out_min[o] = vmin;
       }
     }
   }
@@ -119,37 +122,38 @@ struct PointPass {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int m = lane & 15, q = lane >> 4;
     const float* w = ws.template acquire<PointSeq, 2 + CH>(more);
-    if constexpr (STATS && CH > 0) combine(a, xpart, cloud0, CH - 1);   // behind this chunk's barrier: every partial is there
+    if constexpr (STATS != 0 && CH > 0) combine(a, xpart, cloud0, CH - 1);   // behind this chunk's barrier: every partial is there
     constexpr int nb = (kPointFeat - CH * F < F ? kPointFeat - CH * F : F) / 16;
     const float* wrow = w + m * S3 + 4 * q;
     const float* wbias = w + m * S3 + bias_col(128, true);   // bias of feature m of a block
     // where this lane's finished values go: lanes 0..31 hold maximum | sum, lanes 32..63 minimum (negated) | sum of squares
     float* mm;
     float* ss = nullptr;
-    if constexpr (STATS) {
+    if constexpr (STATS != 0) {
       mm = xpart + (CH & 1) * 4 * 8 * F + (lane >> 5) * 8 * F + wave * F + m;
       ss = mm + 16 * F;
     } else {
       mm = xpart + wave * kPointFeat + CH * F + m;
     }
-    const unsigned flip = (STATS && lane >= 32) ? 0x80000000u : 0u;
+    const unsigned flip = (STATS == 1 && lane >= 32) ? 0x80000000u : 0u;
     auto epilogue = [&](int lb, const v4f (&acc)[T]) {
       float mx = acc[0].x;
       mx = fmaxf(mx, acc[0].y); mx = fmaxf(mx, acc[0].z); mx = fmaxf(mx, acc[0].w);
 #pragma unroll
       for (int t = 1; t < T; ++t) { mx = fmaxf(mx, acc[t].x); mx = fmaxf(mx, acc[t].y); mx = fmaxf(mx, acc[t].z); mx = fmaxf(mx, acc[t].w); }
-      if constexpr (STATS) {
+      if constexpr (STATS != 0) {
         float mn = acc[0].x, sm = acc[0].x, sq = acc[0].x * acc[0].x;
-        mn = fminf(mn, acc[0].y); mn = fminf(mn, acc[0].z); mn = fminf(mn, acc[0].w);
+        if constexpr (STATS == 1) { mn = fminf(mn, acc[0].y); mn = fminf(mn, acc[0].z); mn = fminf(mn, acc[0].w); }
         sm += acc[0].y; sm += acc[0].z; sm += acc[0].w;
         sq = fmaf(acc[0].y, acc[0].y, sq); sq = fmaf(acc[0].z, acc[0].z, sq); sq = fmaf(acc[0].w, acc[0].w, sq);
 #pragma unroll
         for (int t = 1; t < T; ++t) {
-          mn = fminf(mn, acc[t].x); mn = fminf(mn, acc[t].y); mn = fminf(mn, acc[t].z); mn = fminf(mn, acc[t].w);
+          if constexpr (STATS == 1) { mn = fminf(mn, acc[t].x); mn = fminf(mn, acc[t].y); mn = fminf(mn, acc[t].z); mn = fminf(mn, acc[t].w); }
           sm += acc[t].x; sm += acc[t].y; sm += acc[t].z; sm += acc[t].w;
           sq = fmaf(acc[t].x, acc[t].x, sq); sq = fmaf(acc[t].y, acc[t].y, sq); sq = fmaf(acc[t].z, acc[t].z, sq); sq = fmaf(acc[t].w, acc[t].w, sq);
         }
-        const float r = quarter_reduce2<true>(mx, -mn);
+        // (STATS == 2: lanes 32..63 park a second copy of the maximum in the plane the minimum would use; nobody reads it)
+        const float r = STATS == 1 ? quarter_reduce2<true>(mx, -mn) : quarter_reduce2<true>(mx, mx);
         mm[lb * 16] = __uint_as_float(__float_as_uint(r) ^ flip);
         ss[lb * 16] = quarter_reduce2<false>(sm, sq);
       } else {
@@ -268,7 +272,7 @@ struct PointPass {
     }
     layer3(ws, more, a, xpart, cloud0, x3, std::make_integer_sequence<int, NCH3>{});
     __syncthreads();
-    if constexpr (STATS) {
+    if constexpr (STATS != 0) {
       combine(a, xpart, cloud0, NCH3 - 1);
     } else {
       for (int f = threadIdx.x; f < CPW * kPointFeat; f += 512) {
@@ -287,7 +291,7 @@ struct PointPass {
 };
 
 // items 0 .. n_wide-1: groups of two tiles per wavefront; then n_narrow groups of one tile per wavefront
-template <int P, bool STATS>
+template <int P, int STATS>
 __global__ __launch_bounds__(512, 1) void point_feat_kernel(const PointFeatArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   using Wide = PointPass<P, 2, STATS>;
@@ -313,7 +317,7 @@ extern "C" size_t b3d_point_feat_workspace_bytes(void) { return (size_t)PointSeq
 
 static int point_feat_launch(const b3d_linear* conv, const float* x, const float* trans, int32_t B, int32_t C, int32_t P,
                              int32_t relu_last, void* workspace, size_t workspace_bytes, float* out, float* out_min,
-                             float* out_sum, float* out_sq, hipStream_t stream);
+                             float* out_sum, float* out_sq, hipStream_t stream, const float* sign3 = nullptr);
 
 extern "C" int b3d_point_feat(const b3d_linear* conv, const float* x, const float* trans, int32_t B, int32_t C, int32_t P,
                               int32_t relu_last, void* workspace, size_t workspace_bytes, float* out, b3d_stream stream_) {
@@ -329,9 +333,11 @@ extern "C" int b3d_point_feat_stats(const b3d_linear* conv, const float* x, cons
                            (hipStream_t)stream_);
 }
 
+// out_sum without out_min: the three-quantity form (STATS 2); sign3 [1024] or nullptr: rows of the last layer's image (weights and
+// bias) are negated where sign3 < 0
 static int point_feat_launch(const b3d_linear* conv, const float* x, const float* trans, int32_t B, int32_t C, int32_t P,
                              int32_t relu_last, void* workspace, size_t workspace_bytes, float* out, float* out_min,
-                             float* out_sum, float* out_sq, hipStream_t stream) {
+                             float* out_sum, float* out_sq, hipStream_t stream, const float* sign3) {
   B3D_REQUIRE(conv && workspace && (B == 0 || (x && out)), "b3d_point_feat: null argument");
   B3D_REQUIRE(conv[0].w && conv[1].w && conv[2].w && conv[0].b && conv[1].b && conv[2].b, "b3d_point_feat: null layer");
   B3D_REQUIRE(B >= 0 && C >= 1 && C <= 4 && (P == 64 || P == 128), "b3d_point_feat: B %d, C %d, P %d (C <= 4, P 64 or 128)", B, C, P);
@@ -343,11 +349,12 @@ static int point_feat_launch(const b3d_linear* conv, const float* x, const float
   d[0] = pack_desc<PointSeq>(0, wp, (const float*)conv[0].w, (const float*)conv[0].b, 64, C, false);
   d[1] = pack_desc<PointSeq>(1, wp, (const float*)conv[1].w, (const float*)conv[1].b, 128, 64, false);
   d[2] = pack_desc<PointSeq>(2, wp, (const float*)conv[2].w, (const float*)conv[2].b, 1024, 128, false);
+  d[2].row_sign = sign3;
   B3D_TRY(pack_images(d, 3, stream));
   PointFeatArgs a;
   a.x = x; a.trans = trans; a.B = B; a.C = C; a.relu_last = relu_last; a.out = out; a.wpack = wp;
   a.out_min = out_min; a.out_sum = out_sum; a.out_sq = out_sq;
-  const bool stats = out_min != nullptr;
+  const int stats = out_min != nullptr ? 1 : (out_sum != nullptr ? 2 : 0);
   // 256-point groups; when the last round of them over the CUs would be less than half full, its clouds go as 128-point
   // groups instead (twice as many workgroups share the tail)
   const int cpw_wide = 256 / P, cpw_narrow = 128 / P;
@@ -372,10 +379,12 @@ static int point_feat_launch(const b3d_linear* conv, const float* x, const float
     ProfScope ps(B3D_K_POINT_FEAT, stream);                                                           \
     hipLaunchKernelGGL((point_feat_kernel<PP, ST>), dim3(groups), dim3(512), kPointLds, stream, a);   \
   } while (0)
-  if (P == 128 && stats) B3D_POINT_LAUNCH(128, true);
-  else if (P == 128) B3D_POINT_LAUNCH(128, false);
-  else if (stats) B3D_POINT_LAUNCH(64, true);
-  else B3D_POINT_LAUNCH(64, false);
+  if (P == 128 && stats == 1) B3D_POINT_LAUNCH(128, 1);
+  else if (P == 128 && stats == 2) B3D_POINT_LAUNCH(128, 2);
+  else if (P == 128) B3D_POINT_LAUNCH(128, 0);
+  else if (stats == 1) B3D_POINT_LAUNCH(64, 1);
+  else if (stats == 2) B3D_POINT_LAUNCH(64, 2);
+  else B3D_POINT_LAUNCH(64, 0);
 #undef B3D_POINT_LAUNCH
   return launch_check("point_feat_kernel");
 }
@@ -809,4 +818,422 @@ extern "C" int b3d_bn_minmax_apply(const float* vmax, const float* vmin, const f
     B3D_TRY(launch_check("bn_tick_kernel"));
   }
   return B3D_OK;
+}
+
+
+// ---- the train-mode point stack as ONE call (b3d_point_stack_train) --------------------------------------------------------
+// Round 5.  The sequence above (input moments -> finish -> fold -> h1 moments -> finish -> fold -> pack -> point_feat_stats ->
+// minmax partial -> minmax apply: ten launches per stack, thirty per training step, each a chain of a few dependent L2 round trips)
+// with
+//   * the first layer's statistics finished and folded by the LAST workgroup of the input-moments launch (C <= 4: twenty sums and
+//     64 channels of a 4 x 4 quadratic form -- no launch of their own);
+//   * the 64 x 64 second moments of h1 on v_mfma_f32_16x16x32_bf16 (bf16x6, two 16-point tiles per instruction group: 96 matrix
+//     instructions of 16 cycles per 32 points instead of 128 of 32 cycles on the exact-fp32 form);
+//   * sign(gamma) of the last BatchNorm folded into the last convolution (exact), so that the running MAXIMUM serves either sign
+//     of the scale: the minimum is neither computed nor stored;
+//   * no "apply" pass: the call returns the per-cloud extremes and the batch's BatchNorm as a per-feature affine map
+//     (out_scale >= 0, out_shift), which the consumer -- the first Linear of the head, b3d_fc_bn_forward -- applies while it stages
+//     its input.
+namespace b3d {
+namespace {
+
+constexpr int kStackTickets = 16;        // unsigned words at the head of the workspace: [0] input moments, [1 + fb] statistics
+
+struct StackInArgs {
+  MomArgs m;
+  int P;
+  const float *W1, *b1, *gamma, *beta;
+  float *running_mean, *running_var;
+  long long* nbt;
+  float momentum, eps;
+  long long count;
+  float *wf, *bf;            // [64, C], [64]: the first layer with the batch's BatchNorm folded in
+  unsigned* ticket;
+};
+
+__device__ __forceinline__ bool last_arriver(unsigned* ticket, unsigned expected, int* s_flag) {
+  // MI355X_MICROARCH.md hand-off: every storing wave drains, workgroup barrier, one lane's agent-scope release in front of the
+  // ticket; the last arriver acquires before it reads the others' partials
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = (t == expected - 1u) ? 1 : 0;
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    *s_flag = last;
+  }
+  __syncthreads();
+  return *s_flag != 0;
+}
+
+__global__ __launch_bounds__(256) void stack_moments_in_kernel(const StackInArgs a) {
+  __shared__ float red[4][20];
+  __shared__ double part[12][20];
+  __shared__ double fin[20];
+  __shared__ int s_last;
+  float acc[20];
+#pragma unroll
+  for (int i = 0; i < 20; ++i) acc[i] = 0.f;
+  const int P = a.P;
+  const long n = (long)a.m.B * P;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    float f[4];
+    load_point(a.m, P, (int)(i / P), (int)(i % P), f);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[4 * r + c] = fmaf(f[r], f[c], acc[4 * r + c]);
+      acc[16 + r] += f[r];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 20; ++i) {
+    float v = acc[i];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][i] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 20) a.m.part[blockIdx.x * 20 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  if (!last_arriver(a.ticket, gridDim.x, &s_last)) return;
+  // ---- the last workgroup: sums over the workgroups' partials (float64, fixed order), then the first layer's BatchNorm ----
+  const int rows = (int)gridDim.x;
+  if (threadIdx.x < 240) {
+    const int c = threadIdx.x % 20, g = threadIdx.x / 20;
+    double s = 0.0;
+    for (int r = g; r < rows; r += 12) s += (double)a.m.part[r * 20 + c];
+    part[g][c] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 20) {
+    double s = 0.0;
+#pragma unroll
+    for (int g = 0; g < 12; ++g) s += part[g][threadIdx.x];
+    fin[threadIdx.x] = s / (double)a.count;            // [0..15] = E[x_r x_c], [16..19] = E[x_r]
+  }
+  __syncthreads();
+  const long long nbt_before = a.nbt ? *a.nbt : 0;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int o = threadIdx.x, C = a.m.C;
+    const float* w = a.W1 + o * C;
+    double mean = (double)a.b1[o], var = 0.0;
+    for (int i = 0; i < C; ++i) {
+      double t = 0.0;
+      for (int j = 0; j < C; ++j) t += (fin[4 * i + j] - fin[16 + i] * fin[16 + j]) * (double)w[j];
+      mean += (double)w[i] * fin[16 + i];
+      var += (double)w[i] * t;
+    }
+    if (var < 0.0) var = 0.0;
+    const float meanf = (float)mean, varf = (float)var;
+    const float scale = a.gamma[o] / sqrtf(varf + a.eps);
+    const float shift = a.beta[o] - meanf * scale;
+    for (int i = 0; i < C; ++i) a.wf[o * C + i] = w[i] * scale;
+    a.bf[o] = a.b1[o] * scale + shift;
+    bn_track(a.running_mean, a.running_var, o, mean, var, a.count, a.momentum, nbt_before + 1);
+  }
+  if (threadIdx.x == 0) {
+    if (a.nbt) *a.nbt = nbt_before + 1;
+    *a.ticket = 0u;                                      // re-armed for the next call (stream order)
+  }
+}
+
+// 64 x 64 second moments and the mean of h1 = relu(W1' x + b1') over all points, bf16x6.  A wavefront takes PAIRS of 16-point
+// tiles: h1 of either tile comes out of one exact-fp32 MFMA per 16 features with a lane's four accumulator values on four POINTS
+// of one feature; the two tiles' values of a lane are the eight k-slots of a v_mfma_f32_16x16x32_bf16 operand (k = points), the
+// same fragment serving as either argument of h1^T h1.
+template <int P>
+__global__ __launch_bounds__(kMomWaves * 64) void stack_moments_h1_kernel(const MomArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];      // [4][kMomRow]: wavefronts w and w + 4 share an image
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n = lane & 15, q = lane >> 4;
+  float wv[4], bv[4];
+#pragma unroll
+  for (int bi = 0; bi < 4; ++bi) {
+    wv[bi] = q < a.C ? a.w1[(16 * bi + n) * a.C + q] : 0.f;
+    bv[bi] = a.b1[16 * bi + n];
+  }
+  v4f sec[4][4];
+  float sm[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sec[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
+  constexpr int PPC = P / 32;                                  // tile pairs per cloud
+  const long pairs = (long)a.B * PPC;
+  const long stride = (long)gridDim.x * kMomWaves;
+  long pr = (long)blockIdx.x * kMomWaves + wave;
+  RawPoint ra, rb;
+  {
+    const long t0 = pr < pairs ? pr : 0;
+    const int cloud = (int)(t0 / PPC), p0 = (int)(t0 % PPC) * 32 + n;
+    load_point_raw(a, P, cloud, p0, ra);
+    load_point_raw(a, P, cloud, p0 + 16, rb);
+  }
+  for (; pr < pairs; pr += stride) {
+    float fa[4], fb[4];
+    finish_point(a, ra, fa);
+    finish_point(a, rb, fb);
+    const float xa = q == 0 ? fa[0] : q == 1 ? fa[1] : q == 2 ? fa[2] : fa[3];
+    const float xb = q == 0 ? fb[0] : q == 1 ? fb[1] : q == 2 ? fb[2] : fb[3];
+    const long nxt = pr + stride < pairs ? pr + stride : pr;        // (the last pair is loaded again: no branch around loads)
+    {
+      const int cloud = (int)(nxt / PPC), p0 = (int)(nxt % PPC) * 32 + n;
+      load_point_raw(a, P, cloud, p0, ra);
+      load_point_raw(a, P, cloud, p0 + 16, rb);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    Bf3 op[4];
+#pragma unroll
+    for (int bi = 0; bi < 4; ++bi) {
+      const v4f bias = v4f{bv[bi], bv[bi], bv[bi], bv[bi]};
+      const v4f ha = relu4(__builtin_amdgcn_mfma_f32_16x16x4f32(xa, wv[bi], bias, 0, 0, 0));
+      const v4f hb = relu4(__builtin_amdgcn_mfma_f32_16x16x4f32(xb, wv[bi], bias, 0, 0, 0));
+      sm[bi] += ((ha.x + ha.y) + (ha.z + ha.w)) + ((hb.x + hb.y) + (hb.z + hb.w));
+      op[bi] = bf_split(ha, hb);
+    }
+#pragma unroll
+    for (int bi = 0; bi < 4; ++bi)
+#pragma unroll
+      for (int bj = 0; bj < 4; ++bj) sec[bi][bj] = bf_mfma6(op[bi], op[bj], sec[bi][bj]);
+  }
+  float* mine = smem + (wave & 3) * kMomRow;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    if ((wave >> 2) == half) {
+#pragma unroll
+      for (int bi = 0; bi < 4; ++bi) {
+#pragma unroll
+        for (int bj = 0; bj < 4; ++bj) {                      // element [16 bi + 4 q + j][16 bj + n]
+          float* d = mine + (16 * bi + 4 * q) * kMomK + 16 * bj + n;
+          if (half == 0) {
+            d[0] = sec[bi][bj].x; d[kMomK] = sec[bi][bj].y; d[2 * kMomK] = sec[bi][bj].z; d[3 * kMomK] = sec[bi][bj].w;
+          } else {
+            d[0] += sec[bi][bj].x; d[kMomK] += sec[bi][bj].y; d[2 * kMomK] += sec[bi][bj].z; d[3 * kMomK] += sec[bi][bj].w;
+          }
+        }
+        float v = sm[bi];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (q == 0) {
+          if (half == 0) mine[kMomK * kMomK + 16 * bi + n] = v;
+          else mine[kMomK * kMomK + 16 * bi + n] += v;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < kMomRow; i += kMomWaves * 64)
+    a.part[(long)blockIdx.x * kMomRow + i] = (smem[i] + smem[kMomRow + i]) + (smem[2 * kMomRow + i] + smem[3 * kMomRow + i]);
+}
+
+// Statistics of the last layer from the per-cloud sums (float64), one launch: row chunks -> partials; the LAST workgroup of each
+// 256-feature block forms mean / variance, updates the running statistics and writes the batch's BatchNorm as an affine map of the
+// sign-folded extreme: out_scale = |gamma| / sqrt(var + eps) >= 0, out_shift = beta - |gamma| mean' / sqrt(var + eps) with
+// mean' = sign(gamma) mean (the statistics arrive for z' = sign(gamma) z; var(z') = var(z)).
+struct StackStatArgs {
+  const float *vsum, *vsq;                 // [B, F] of z'
+  int B, F;
+  long long count;
+  const float *gamma, *beta;
+  float *running_mean, *running_var;
+  long long* nbt;
+  float momentum, eps;
+  double* part;                            // [chunks][2][F]
+  int chunks;
+  float *out_scale, *out_shift;            // [F]
+  unsigned* ticket;                        // [1 + feature block] per-block arrival counters, [1 + fb count] = launch counter
+};
+__global__ __launch_bounds__(256) void stack_stats_kernel(const StackStatArgs a) {
+  __shared__ int s_last;
+  const int f = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+  const int per = (a.B + a.chunks - 1) / a.chunks;
+  const int b0 = c * per, b1 = min(a.B, b0 + per);
+  if (f < a.F) {
+    double s = 0.0, q = 0.0;
+    int b = b0;
+    for (; b + 4 <= b1; b += 4) {
+      float vs[4], vq[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { vs[u] = a.vsum[(size_t)(b + u) * a.F + f]; vq[u] = a.vsq[(size_t)(b + u) * a.F + f]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { s += (double)vs[u]; q += (double)vq[u]; }
+    }
+    for (; b < b1; ++b) { s += (double)a.vsum[(size_t)b * a.F + f]; q += (double)a.vsq[(size_t)b * a.F + f]; }
+    a.part[((size_t)c * 2 + 0) * a.F + f] = s;
+    a.part[((size_t)c * 2 + 1) * a.F + f] = q;
+  }
+  if (!last_arriver(a.ticket + 1 + blockIdx.x, (unsigned)a.chunks, &s_last)) return;
+  const long long nbt_before = a.nbt ? *a.nbt : 0;
+  if (f < a.F) {
+    double s = 0.0, q = 0.0;
+    for (int cc = 0; cc < a.chunks; cc += 8) {                 // (chunks is a multiple of 8: sixteen independent loads per round trip)
+      double ps[8], pq[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { ps[u] = a.part[((size_t)(cc + u) * 2 + 0) * a.F + f]; pq[u] = a.part[((size_t)(cc + u) * 2 + 1) * a.F + f]; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s += ps[u]; q += pq[u]; }
+    }
+    const double meanp = s / (double)a.count;                  // of z' = sign(gamma) z
+    double var = q / (double)a.count - meanp * meanp;
+    if (var < 0.0) var = 0.0;
+    const double g = (double)a.gamma[f];
+    const double sgn = g < 0.0 ? -1.0 : 1.0;
+    const double scale = (g < 0.0 ? -g : g) / sqrt(var + (double)a.eps);
+    a.out_scale[f] = (float)scale;
+    a.out_shift[f] = (float)((double)a.beta[f] - meanp * scale);
+    bn_track(a.running_mean, a.running_var, f, (double)(float)(sgn * meanp), (double)(float)var, a.count, a.momentum, nbt_before + 1);
+  }
+  // the counter moves once, after every feature block has read it
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    a.ticket[1 + blockIdx.x] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned t = __hip_atomic_fetch_add(a.ticket + 1 + gridDim.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == gridDim.x - 1u) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      if (a.nbt) *a.nbt = nbt_before + 1;
+      a.ticket[1 + gridDim.x] = 0u;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void affine_kernel(const float* __restrict__ y, const float* __restrict__ scale,
+                                                     const float* __restrict__ shift, long total, int N, int relu, float* __restrict__ out) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int n = (int)(i % N);
+    const float v = fmaf(y[i], scale[n], shift[n]);
+    out[i] = relu ? relu1(v) : v;
+  }
+}
+
+struct StackWs {
+  unsigned* ticket;          // [kStackTickets]: caller's, zero on entry, left zero
+  float* mom_part;           // [kMomGrid][kMomRow]
+  double *mu, *second;       // [64], [64 x 64]
+  float *wf1, *bf1, *wf2, *bf2;
+  float *vsum, *vsq;         // [B, 1024]
+  double* stat_part;         // [kBnMinMaxChunks][2][1024]
+  float* images;             // PointSeq
+};
+bool carve_stack(StackWs& w, void* ws, size_t bytes, int B, size_t* need) {
+  Carver c(ws, bytes);
+  w.mom_part = c.take<float>((size_t)kMomGrid * kMomRow);
+  w.mu = c.take<double>(64);
+  w.second = c.take<double>(64 * 64);
+  w.wf1 = c.take<float>(64 * 4);
+  w.bf1 = c.take<float>(64);
+  w.wf2 = c.take<float>(128 * 64);
+  w.bf2 = c.take<float>(128);
+  w.vsum = c.take<float>((size_t)B * kPointFeat);
+  w.vsq = c.take<float>((size_t)B * kPointFeat);
+  w.stat_part = c.take<double>((size_t)kBnMinMaxChunks * 2 * kPointFeat);
+  w.images = c.take<float>((size_t)PointSeq::TOTAL_FLOATS + 64);
+  if (need) *need = c.off + 256;
+  return c.ok();
+}
+
+}  // namespace
+}  // namespace b3d
+
+extern "C" size_t b3d_point_stack_train_workspace_bytes(int32_t B) {
+  if (B < 0) B = 0;
+  StackWs w{};
+  size_t need = 0;
+  carve_stack(w, nullptr, 0, B, &need);
+  return need;
+}
+
+extern "C" int b3d_point_stack_train(const b3d_linear* conv, const b3d_batchnorm* bn, const float* x, const float* trans, int32_t B,
+                                     int32_t C, int32_t P, void* tickets, void* workspace, size_t workspace_bytes, float* ext,
+                                     float* out_scale, float* out_shift, b3d_stream stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  B3D_REQUIRE(conv && bn && x && tickets && workspace && ext && out_scale && out_shift, "b3d_point_stack_train: null argument");
+  B3D_REQUIRE(B >= 1 && (long long)B * P > 1 && C >= 1 && C <= 4 && (P == 64 || P == 128),
+              "b3d_point_stack_train: B %d, C %d, P %d (more than one point, C <= 4, P 64 or 128)", (int)B, (int)C, (int)P);
+  B3D_REQUIRE(!trans || C == 3, "b3d_point_stack_train: the input transform is 3x3");
+  for (int i = 0; i < 3; ++i) {
+    B3D_REQUIRE(conv[i].w && conv[i].b && bn[i].gamma && bn[i].beta, "b3d_point_stack_train: layer %d: null parameter", i);
+    B3D_REQUIRE((bn[i].running_mean == nullptr) == (bn[i].running_var == nullptr), "b3d_point_stack_train: running statistics come as a pair");
+  }
+  StackWs w{};
+  if (!carve_stack(w, workspace, workspace_bytes, B, nullptr)) return fail(B3D_ERR_WORKSPACE, "b3d_point_stack_train: workspace too small");
+  w.ticket = (unsigned*)tickets;
+  const long long count = (long long)B * P;
+  // 1. input moments, their sums and the first layer's BatchNorm: one launch
+  {
+    StackInArgs a;
+    memset(&a, 0, sizeof(a));
+    a.m.x = x; a.m.trans = trans; a.m.B = B; a.m.C = C; a.m.part = w.mom_part;
+    a.P = P;
+    a.W1 = (const float*)conv[0].w; a.b1 = (const float*)conv[0].b; a.gamma = bn[0].gamma; a.beta = bn[0].beta;
+    a.running_mean = bn[0].running_mean; a.running_var = bn[0].running_var; a.nbt = (long long*)bn[0].num_batches_tracked;
+    a.momentum = bn[0].momentum; a.eps = bn[0].eps; a.count = count;
+    a.wf = w.wf1; a.bf = w.bf1; a.ticket = w.ticket;
+    long grid = ((long)B * P + 1023) / 1024;                   // >= 4 points per thread
+    grid = grid < 1 ? 1 : grid > kMomGrid ? kMomGrid : grid;
+    hipLaunchKernelGGL(stack_moments_in_kernel, dim3((unsigned)grid), dim3(256), 0, stream, a);
+    B3D_TRY(launch_check("stack_moments_in_kernel"));
+  }
+  // 2. second moments of h1 (bf16x6), 3. their sums, 4. the second layer's BatchNorm
+  {
+    MomArgs a;
+    a.x = x; a.trans = trans; a.B = B; a.C = C; a.w1 = w.wf1; a.b1 = w.bf1; a.part = w.mom_part;
+    constexpr int lds = 4 * kMomRow * (int)sizeof(float);
+    const long pairs = (long)B * (P / 32);
+    long grid = (pairs + 2 * kMomWaves - 1) / (2 * kMomWaves);  // ~2 pairs (64 points) per wavefront at least
+    grid = grid < 16 ? 16 : grid > kMomGrid ? kMomGrid : grid;
+    if (P == 128) {
+      B3D_TRY(set_lds(stack_moments_h1_kernel<128>, lds));
+      hipLaunchKernelGGL(stack_moments_h1_kernel<128>, dim3((unsigned)grid), dim3(kMomWaves * 64), lds, stream, a);
+    } else {
+      B3D_TRY(set_lds(stack_moments_h1_kernel<64>, lds));
+      hipLaunchKernelGGL(stack_moments_h1_kernel<64>, dim3((unsigned)grid), dim3(kMomWaves * 64), lds, stream, a);
+    }
+    B3D_TRY(launch_check("stack_moments_h1_kernel"));
+    hipLaunchKernelGGL(point_moments_finish_kernel, dim3((kMomRow + 15) / 16), dim3(1024), 0, stream, (const float*)w.mom_part, (int)grid,
+                       kMomK, kMomK, count, w.mu, w.second);
+    B3D_TRY(launch_check("point_moments_finish_kernel"));
+    B3D_TRY(b3d_bn_fold_moments(w.mu, w.second, 64, (const float*)conv[1].w, (const float*)conv[1].b, 128, bn[1].gamma, bn[1].beta,
+                                bn[1].running_mean, bn[1].running_var, bn[1].num_batches_tracked, bn[1].momentum, bn[1].eps, count,
+                                w.wf2, w.bf2, stream_));
+  }
+  // 5. images + the three layers over all points: per cloud the maximum, sum and sum of squares of z' = sign(gamma3) conv3(h2)
+  {
+    b3d_linear folded[3] = {{w.wf1, w.bf1}, {w.wf2, w.bf2}, {conv[2].w, conv[2].b}};
+    B3D_TRY(point_feat_launch(folded, x, trans, B, C, P, 0, w.images, ((size_t)PointSeq::TOTAL_FLOATS + 64) * sizeof(float), ext, nullptr,
+                              w.vsum, w.vsq, stream, bn[2].gamma));
+  }
+  // 6. the last layer's statistics -> out_scale / out_shift (+ running statistics)
+  {
+    StackStatArgs a;
+    memset(&a, 0, sizeof(a));
+    a.vsum = w.vsum; a.vsq = w.vsq; a.B = B; a.F = kPointFeat; a.count = count;
+    a.gamma = bn[2].gamma; a.beta = bn[2].beta; a.running_mean = bn[2].running_mean; a.running_var = bn[2].running_var;
+    a.nbt = (long long*)bn[2].num_batches_tracked; a.momentum = bn[2].momentum; a.eps = bn[2].eps;
+    a.part = w.stat_part; a.chunks = kBnMinMaxChunks; a.out_scale = out_scale; a.out_shift = out_shift; a.ticket = w.ticket;
+    static_assert(2 + kPointFeat / 256 <= kStackTickets, "ticket words");
+    hipLaunchKernelGGL(stack_stats_kernel, dim3(kPointFeat / 256, kBnMinMaxChunks), dim3(256), 0, stream, a);
+    B3D_TRY(launch_check("stack_stats_kernel"));
+  }
+  return B3D_OK;
+}
+
+extern "C" int b3d_affine(const float* y, const float* scale, const float* shift, int32_t B, int32_t N, int32_t relu, float* out,
+                          b3d_stream stream_) {
+  B3D_REQUIRE(B >= 0 && N > 0, "b3d_affine: bad shape");
+  if (B == 0) return B3D_OK;
+  B3D_REQUIRE(y && scale && shift && out, "b3d_affine: null argument");
+  const long total = (long)B * N;
+  long blocks = (total + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(affine_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, y, scale, shift, total, N, (int)relu, out);
+  return launch_check("affine_kernel");
 }

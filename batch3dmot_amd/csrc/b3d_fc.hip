@@ -63,9 +63,10 @@ struct FcArgs {
   float *out_scale, *out_shift;   // [N]
 };
 
-// AFFINE: the producer's BatchNorm + ReLU is applied to x while it is staged (compile-time: a run-time test around the loads made
-// hipcc wait vmcnt(0) behind every one of them, i.e. no tile was ever in flight under the MFMAs)
-template <bool AFFINE, int TK>
+// AFFINE: the producer's BatchNorm (1: + ReLU, 2: without -- the point stacks' last BatchNorm in front of fc1, pointnet.py:188,
+// radarnet.py:60) is applied to x while it is staged (compile-time: a run-time test around the loads made hipcc wait vmcnt(0) behind
+// every one of them, i.e. no tile was ever in flight under the MFMAs)
+template <int AFFINE, int TK>
 __global__ __launch_bounds__(kFcThreads, TK == 32 ? 2 : 1) void fc_kernel(const FcArgs a) {
   using G = FcGeo<TK>;
   constexpr int kTK = G::kTK, kTPR = G::kTPR, kRPP = G::kRPP, kPitch = G::kPitch, kPiece = G::kPiece, kTileDw = G::kTileDw;
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(kFcThreads, TK == 32 ? 2 : 1) void fc_kernel(const 
       axs[h] = *reinterpret_cast<const v4f*>(a.x + (size_t)rA[h] * a.K + k);
       bxs[h] = *reinterpret_cast<const v4f*>(a.w + (size_t)rB[h] * a.K + k);
     }
-    if constexpr (AFFINE) {
+    if constexpr (AFFINE != 0) {
       scs = *reinterpret_cast<const v4f*>(a.in_scale + k);
       shs = *reinterpret_cast<const v4f*>(a.in_shift + k);
     }
@@ -134,9 +135,12 @@ __global__ __launch_bounds__(kFcThreads, TK == 32 ? 2 : 1) void fc_kernel(const 
 #pragma unroll
     for (int h = 0; h < HS; ++h) {
       v4f v = axs[h];
-      if constexpr (AFFINE) {
+      if constexpr (AFFINE == 1) {
         v.x = relu1(fmaf(v.x, scs.x, shs.x)); v.y = relu1(fmaf(v.y, scs.y, shs.y));
         v.z = relu1(fmaf(v.z, scs.z, shs.z)); v.w = relu1(fmaf(v.w, scs.w, shs.w));
+      } else if constexpr (AFFINE == 2) {
+        v.x = fmaf(v.x, scs.x, shs.x); v.y = fmaf(v.y, scs.y, shs.y);
+        v.z = fmaf(v.z, scs.z, shs.z); v.w = fmaf(v.w, scs.w, shs.w);
       }
       put(As + buf * kTileDw + (sr + kRPP * h) * kPitch + 2 * sq, (okA[h] && kok) ? v : zero);
       put(Bs + buf * kTileDw + (sr + kRPP * h) * kPitch + 2 * sq, (okB[h] && kok) ? bxs[h] : zero);
@@ -338,7 +342,7 @@ extern "C" size_t b3d_fc_bn_workspace_bytes(int32_t B, int32_t N) {
 }
 
 extern "C" int b3d_fc_bn_forward(const float* x, int32_t B, int32_t K, const float* w, const float* bias, int32_t N,
-                                 const float* in_scale, const float* in_shift, const float* mask, const float* add,
+                                 const float* in_scale, const float* in_shift, int32_t in_relu, const float* mask, const float* add,
                                  const b3d_batchnorm* bn, int32_t train, float* y, float* out_scale, float* out_shift,
                                  void* workspace, size_t workspace_bytes, b3d_stream stream_) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -387,8 +391,9 @@ extern "C" int b3d_fc_bn_forward(const float* x, int32_t B, int32_t K, const flo
     hipLaunchKernelGGL(kern, grid, dim3(kFcThreads), lds, stream, a);
     return B3D_OK;
   };
-  if (in_scale) B3D_TRY(small ? go(fc_kernel<true, 32>, FcGeo<32>::kLdsBytes) : go(fc_kernel<true, 64>, FcGeo<64>::kLdsBytes));
-  else B3D_TRY(small ? go(fc_kernel<false, 32>, FcGeo<32>::kLdsBytes) : go(fc_kernel<false, 64>, FcGeo<64>::kLdsBytes));
+  if (in_scale && in_relu) B3D_TRY(small ? go(fc_kernel<1, 32>, FcGeo<32>::kLdsBytes) : go(fc_kernel<1, 64>, FcGeo<64>::kLdsBytes));
+  else if (in_scale) B3D_TRY(small ? go(fc_kernel<2, 32>, FcGeo<32>::kLdsBytes) : go(fc_kernel<2, 64>, FcGeo<64>::kLdsBytes));
+  else B3D_TRY(small ? go(fc_kernel<0, 32>, FcGeo<32>::kLdsBytes) : go(fc_kernel<0, 64>, FcGeo<64>::kLdsBytes));
   return launch_check("fc_kernel");
 }
 

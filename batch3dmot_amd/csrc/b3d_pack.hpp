@@ -22,6 +22,9 @@ struct PackDesc {
   int partial;       // 1: write only the slice's nrows x K cells (w == nullptr: zeros); other cells belong to other
                      //    descriptors of the same image
   int bf;            // image format of the layer (b3d_dev.hpp): 0 fp32, 1 bf16x3
+  const float* row_sign;   // [N] or nullptr: row r of the image (weights and bias; not for transposed images) is multiplied by
+                           // -1 where row_sign[r] < 0 (exact: the train-mode point stacks fold sign(gamma) of the LAST BatchNorm
+                           // into the last convolution, so that one running maximum serves either sign of the scale)
 };
 
 constexpr int kPackMax = 120;     // 8.5 KB of kernel arguments (the kernarg segment is plain memory on AMD): one launch packs a whole model's images
@@ -45,6 +48,7 @@ inline PackDesc pack_desc(int li, float* base, const float* w, const float* b, i
   d.row0 = 0; d.nrows = d.NP;
   d.col0 = 0; d.partial = 0;
   d.bf = Seq::bf(li) ? 1 : 0;
+  d.row_sign = nullptr;
   return d;
 }
 
@@ -94,7 +98,7 @@ inline PackDesc fill_desc(void* dst, int count, bool iota) {
   d.w = nullptr; d.b = nullptr; d.dst = (float*)dst;
   d.N = count; d.K = 0; d.NP = 0; d.KP = 0;
   d.transposed = iota ? 2 : 3;
-  d.ld = 0; d.row0 = 0; d.nrows = 0; d.col0 = 0; d.partial = 0; d.bf = 0;
+  d.ld = 0; d.row0 = 0; d.nrows = 0; d.col0 = 0; d.partial = 0; d.bf = 0; d.row_sign = nullptr;
   return d;
 }
 

@@ -187,9 +187,10 @@ __global__ void pack_kernel(const PackArgs a) {
     for (int i = 0; i < ch; ++i) off += chunk_floats(d.KP, bf, chunk_nrows(d.KP, d.NP, bf, i));
     return off;
   };
+  auto sign_of = [&](int rl) -> float { return (d.row_sign && !d.transposed && rl < d.N && d.row_sign[rl] < 0.f) ? -1.f : 1.f; };
   auto value = [&](int rl, int c) -> float {                 // element (rl, c) of the slice, zero outside [N, K]
     if (rl >= d.N || c >= d.K || !d.w) return 0.f;
-    return d.transposed ? d.w[(size_t)c * d.ld + rl] : d.w[(size_t)rl * d.ld + c];
+    return d.transposed ? d.w[(size_t)c * d.ld + rl] : d.w[(size_t)rl * d.ld + c] * sign_of(rl);
   };
   if (bf) {
     // bf16x3 image: one thread per PAIR of adjacent columns (they share a dword in each of the three pieces) + one
@@ -206,7 +207,7 @@ __global__ void pack_kernel(const PackArgs a) {
       if (t >= ncol / 2) {                                   // bias (fp32) and padding
         const int k = t - ncol / 2;
         float v = 0.f;
-        if (k == 0 && rl < d.N && d.b && !d.transposed) v = d.b[rl];
+        if (k == 0 && rl < d.N && d.b && !d.transposed) v = d.b[rl] * sign_of(rl);
         dst[base + 3 * d.KP / 2 + k] = __float_as_uint(v);
         continue;
       }
@@ -237,8 +238,8 @@ __global__ void pack_kernel(const PackArgs a) {
     float v = 0.f;
     if (rl < d.N && d.w) {
       if (!d.transposed) {
-        if (c < d.K) v = d.w[(size_t)rl * d.ld + c];
-        else if (c == d.KP && d.b) v = d.b[rl];
+        if (c < d.K) v = d.w[(size_t)rl * d.ld + c] * sign_of(rl);
+        else if (c == d.KP && d.b) v = d.b[rl] * sign_of(rl);
       } else if (c < d.K) {
         // image of W^T: rows = input features of the forward layer, cols = its outputs
         v = d.w[(size_t)c * d.ld + rl];

@@ -22,7 +22,14 @@ namespace b3d {
 
 constexpr int kWgmThreads = 512, kWgmRows = 32, kWgmMaxW = 384;
 __host__ __device__ constexpr int wgm_pitch(int W) { return ((W / 2 - 8 + 63) / 64) * 64 + 8; }     // dwords, >= W / 2, = 8 mod 64
-constexpr int kWgmLdsBytes = 2 * 3 * kWgmRows * wgm_pitch(kWgmMaxW) * 4;
+// 32 x 32 x 16 tiles (B32): the two 16-lane groups of a 32-lane half read the SAME four rows at column blocks 16 apart (8 dwords), so
+// the rows must land 16 banks apart: pitch = 16 (mod 64) dwords -> rows q = 0..3 at banks 16 q, the second column block at + 8
+__host__ __device__ constexpr int wgm_pitch32(int W) { return ((W / 2 - 16 + 63) / 64) * 64 + 16; }
+#ifndef B3D_WGM_B32
+#define B3D_WGM_B32 1          // 1: v_mfma_f32_32x32x16_bf16 for the shapes whose wave grid divides into 32 x 32 blocks
+#endif
+constexpr int kWgmLdsBytes = 2 * 3 * kWgmRows * (B3D_WGM_B32 ? wgm_pitch32(kWgmMaxW) : wgm_pitch(kWgmMaxW)) * 4;
+typedef float v16f __attribute__((ext_vector_type(16)));
 
 // LDS pointers stay in the LDS address space end to end: through a generic float* (a noinline function's argument) every one
 // of the 48 transposed reads of a step paid an address-space cast with its null check (cmp + cndmask + 64-bit add).
@@ -75,9 +82,13 @@ __device__ __forceinline__ bf8 wgm_frag(const lds_float* img, int lane_off /* (4
 }
 
 // not inlined: one register allocation per shape (inlined into the dispatch switch the kernel spilled 164 VGPRs)
-template <int WR, int WC, int MBW, int NBW, bool GATHER>
+// B32: blocks are 32 x 32 (v_mfma_f32_32x32x16_bf16, two per 32-row step and block: half the matrix instructions -- and half of
+// their issue slots, which this kernel is short of: per step a wavefront issues ~170 vector instructions of operand split, ~57 LDS
+// instructions and 96 matrix instructions of the 16 x 16 x 32 form, each of which holds the SIMD's issue port for 8 of its 16 cycles)
+template <int WR, int WC, int MBW, int NBW, bool GATHER, bool B32 = false>
 __device__ __attribute__((noinline)) void wgm_task(const WsJob& job, int chunk, lds_float* lds) {
-  constexpr int NG = 16 * WR * MBW, KG = 16 * WC * NBW, W = NG + KG, PITCH = wgm_pitch(W);
+  constexpr int BS = B32 ? 32 : 16;
+  constexpr int NG = BS * WR * MBW, KG = BS * WC * NBW, W = NG + KG, PITCH = B32 ? wgm_pitch32(W) : wgm_pitch(W);
   constexpr int PIECE = kWgmRows * PITCH, BUF = 3 * PIECE;
   constexpr int G4 = NG / 4, A4 = KG / 4;
   static_assert(WR * WC == 8 && W <= kWgmMaxW && 2 * BUF * 4 <= kWgmLdsBytes, "shape does not fit the workgroup / LDS");
@@ -108,7 +119,8 @@ __device__ __attribute__((noinline)) void wgm_task(const WsJob& job, int chunk, 
   const float* abase = asg.ptr + asg.col0 + (long)(r0 + arow0) * astride + 4 * (second ? ac4 - split4 : ac4);
   const float* gbase = job.g.ptr + job.g.col0 + 4 * gc4 + (GATHER ? 0L : (long)(r0 + grow0) * gstride);
   const int gdst0 = grow0 * PITCH + 2 * gc4, adst0 = arow0 * PITCH + NG / 2 + 2 * ac4;
-  v4f gx[(MBW * NBW <= 9) ? 2 : 1][GLs], ax[(MBW * NBW <= 9) ? 2 : 1][ALs];
+  constexpr bool DEEP = (B32 ? 4 : 1) * MBW * NBW <= 9;      // accumulator registers: 16 per 32 x 32 block, 4 per 16 x 16 block
+  v4f gx[DEEP ? 2 : 1][GLs], ax[DEEP ? 2 : 1][ALs];
   v4f bs = {0.f, 0.f, 0.f, 0.f};
   int gi[GLs];
 #pragma unroll
@@ -169,15 +181,66 @@ __device__ __attribute__((noinline)) void wgm_task(const WsJob& job, int chunk, 
       if (athread && arow0 + RA * i < kWgmRows) put(buf, adst0 + RA * i * PITCH, aq[i]);
   };
 
-  v4f acc[MBW][NBW];
+  using acc_t = std::conditional_t<B32, v16f, v4f>;
+  acc_t acc[MBW][NBW];
 #pragma unroll
   for (int a = 0; a < MBW; ++a)
 #pragma unroll
-    for (int b = 0; b < NBW; ++b) acc[a][b] = zero4;
+    for (int b = 0; b < NBW; ++b) {
+      if constexpr (B32) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+      }
+      else acc[a][b] = zero4;
+    }
 
   const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
-  const int lane_off = (4 * g + q) * PITCH + 2 * p;
+  // 16 x 16 x 32: lane group g takes rows {4g..4g+3} and {16+4g..} as its eight k-slots.  32 x 32 x 16: lane = (m = lane % 32,
+  // kg = lane / 32) takes rows {8 kg .. 8 kg + 7} of a 16-row half; its 16-lane group reads column block (lane / 16) % 2
+  const int lane_off = B32 ? (8 * (lane >> 5) + q) * PITCH + 2 * p + 8 * ((lane >> 4) & 1) : (4 * g + q) * PITCH + 2 * p;
+  auto frag32 = [&](const lds_float* img, int cd) {                 // 8 k-slots (rows) of this lane's column, one piece
+    auto* p0 = (__attribute__((address_space(3))) wgm_s4*)(img + lane_off + cd);
+    auto* p1 = (__attribute__((address_space(3))) wgm_s4*)(img + lane_off + 4 * PITCH + cd);
+    const wgm_s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(p0);
+    const wgm_s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(p1);
+    const wgm_s8 v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    return __builtin_bit_cast(bf8, v);
+  };
+  auto mfma6_32 = [&](const Bf3& x, const Bf3& w, v16f c) {          // smallest terms first, as bf_mfma6
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x.p0, w.p2, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x.p1, w.p1, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x.p2, w.p0, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x.p0, w.p1, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x.p1, w.p0, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x.p0, w.p0, c, 0, 0, 0);
+    return c;
+  };
   auto compute = [&](const lds_float* cur) {
+    if constexpr (B32) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {                                  // rows 16 h .. 16 h + 15 of the step
+        const lds_float* ch = cur + 16 * h * PITCH;
+        Bf3 af[MBW];
+#pragma unroll
+        for (int a = 0; a < MBW; ++a) {
+          const int cd = 16 * (wr * MBW + a);
+          af[a].p0 = frag32(ch, cd);
+          af[a].p1 = frag32(ch + PIECE, cd);
+          af[a].p2 = frag32(ch + 2 * PIECE, cd);
+        }
+#pragma unroll
+        for (int b = 0; b < NBW; ++b) {
+          const int cd = NG / 2 + 16 * (wc * NBW + b);
+          Bf3 bfr;
+          bfr.p0 = frag32(ch, cd);
+          bfr.p1 = frag32(ch + PIECE, cd);
+          bfr.p2 = frag32(ch + 2 * PIECE, cd);
+#pragma unroll
+          for (int a = 0; a < MBW; ++a) acc[a][b] = mfma6_32(af[a], bfr, acc[a][b]);
+        }
+      }
+      return;
+    } else {
     Bf3 af[MBW];
 #pragma unroll
     for (int a = 0; a < MBW; ++a) {
@@ -196,11 +259,11 @@ __device__ __attribute__((noinline)) void wgm_task(const WsJob& job, int chunk, 
 #pragma unroll
       for (int a = 0; a < MBW; ++a) acc[a][b] = bf_mfma6(af[a], bfr, acc[a][b]);
     }
+    }
   };
   // Prefetch depth: rows are fetched TWO steps ahead where the registers allow it (a step of a small shape is far
   // shorter than an HBM round trip); the shapes with 12+ accumulator blocks per wavefront keep one step in flight
   // -- their MFMA phase (>= 1 us) covers most of the latency and a second register set made them spill.
-  constexpr bool DEEP = MBW * NBW <= 9;
   __syncthreads();                                           // the previous task of this workgroup is done with the LDS
   if constexpr (DEEP) {
     // at the top of iteration t, LDS buffer t & 1 holds step t, register set (t + 1) & 1 step t + 1
@@ -241,6 +304,22 @@ __device__ __attribute__((noinline)) void wgm_task(const WsJob& job, int chunk, 
 
   // ---- partial -> slab (row-major [NP][KP], then bias) ---------------------------------------
   float* slab = job.slab + (size_t)chunk * ((size_t)job.NP * job.KP + job.NP);
+  if constexpr (B32) {
+    // register r of lane l of a 32 x 32 block: row 8 (r / 4) + 4 (l / 32) + r % 4, column l % 32
+    const int n = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int a = 0; a < MBW; ++a) {
+#pragma unroll
+      for (int b = 0; b < NBW; ++b) {
+        const int colf = job.wcol[0] + 32 * (wc * NBW + b) + n;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rowf = job.wrow + 32 * (wr * MBW + a) + 8 * (r >> 2) + 4 * hh + (r & 3);
+          slab[(size_t)rowf * job.KP + colf] = acc[a][b][r];
+        }
+      }
+    }
+  } else {
   const int n = lane & 15, qq = lane >> 4;
 #pragma unroll
   for (int a = 0; a < MBW; ++a) {
@@ -254,6 +333,7 @@ __device__ __attribute__((noinline)) void wgm_task(const WsJob& job, int chunk, 
         slab[(size_t)rowf * job.KP + colf] = vv[j];
       }
     }
+  }
   }
   if (job.write_bias) {
     // column sums of G in a FIXED order (no float atomics: the result must not depend on which wavefront arrives first):
@@ -290,6 +370,20 @@ static __global__ __launch_bounds__(kWgmThreads, 1) void wgemm_kernel(const WsJo
     const int chunk = task - job.task_begin;
     const bool gather = job.g.idx != iota;
     switch (job.shape) {
+#if B3D_WGM_B32
+      // shapes whose dW tile divides into 32 x 32 blocks over 8 wavefronts: (wave grid) x (32-blocks per wavefront)
+      case WGM_128_256: wgm_task<2, 4, 2, 2, false, true>(job, chunk, (lds_float*)wgm_lds); break;
+      case WGM_128_192:
+        if (gather) wgm_task<4, 2, 1, 3, true, true>(job, chunk, (lds_float*)wgm_lds);
+        else wgm_task<4, 2, 1, 3, false, true>(job, chunk, (lds_float*)wgm_lds);
+        break;
+      case WGM_128_128: wgm_task<4, 2, 1, 2, false, true>(job, chunk, (lds_float*)wgm_lds); break;
+      case WGM_64_128: wgm_task<2, 4, 1, 1, false, true>(job, chunk, (lds_float*)wgm_lds); break;
+      case WGM_256_64: wgm_task<8, 1, 1, 2, false, true>(job, chunk, (lds_float*)wgm_lds); break;
+      case WGM_256_96: wgm_task<8, 1, 1, 3, false, true>(job, chunk, (lds_float*)wgm_lds); break;
+      case WGM_192_128: wgm_task<2, 4, 3, 1, false, true>(job, chunk, (lds_float*)wgm_lds); break;
+      case WGM_256_128: wgm_task<4, 2, 2, 2, false, true>(job, chunk, (lds_float*)wgm_lds); break;
+#else
       case WGM_128_256: wgm_task<2, 4, 4, 4, false>(job, chunk, (lds_float*)wgm_lds); break;
       case WGM_128_192:
         if (gather) wgm_task<2, 4, 4, 3, true>(job, chunk, (lds_float*)wgm_lds);
@@ -299,12 +393,14 @@ static __global__ __launch_bounds__(kWgmThreads, 1) void wgemm_kernel(const WsJo
       case WGM_64_128: wgm_task<2, 4, 2, 2, false>(job, chunk, (lds_float*)wgm_lds); break;
       case WGM_256_64: wgm_task<8, 1, 2, 4, false>(job, chunk, (lds_float*)wgm_lds); break;
       case WGM_256_96: wgm_task<8, 1, 2, 6, false>(job, chunk, (lds_float*)wgm_lds); break;
+      case WGM_192_128: wgm_task<2, 4, 6, 2, false>(job, chunk, (lds_float*)wgm_lds); break;
+      case WGM_256_128: wgm_task<8, 1, 2, 8, false>(job, chunk, (lds_float*)wgm_lds); break;
+#endif
+      // 12 or 18 blocks of 32 x 32 do not divide over 8 wavefronts: these stay on 16 x 16 x 32
       case WGM_192_64: wgm_task<4, 2, 3, 2, false>(job, chunk, (lds_float*)wgm_lds); break;
       case WGM_192_96: wgm_task<4, 2, 3, 3, false>(job, chunk, (lds_float*)wgm_lds); break;
       case WGM_96_128: wgm_task<2, 4, 3, 2, false>(job, chunk, (lds_float*)wgm_lds); break;
-      case WGM_192_128: wgm_task<2, 4, 6, 2, false>(job, chunk, (lds_float*)wgm_lds); break;
       case WGM_128_96: wgm_task<4, 2, 2, 3, false>(job, chunk, (lds_float*)wgm_lds); break;
-      case WGM_256_128: wgm_task<8, 1, 2, 8, false>(job, chunk, (lds_float*)wgm_lds); break;
       default: break;
     }
   }

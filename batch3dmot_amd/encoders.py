@@ -222,6 +222,73 @@ def point_feat_train_hip(convs, bns, x: torch.Tensor, trans=None, relu_last: boo
         return y
 
 
+def _tickets(owner: nn.Module, dev) -> torch.Tensor:
+    """64 zero bytes of arrival counters per encoder module (``b3d_point_stack_train`` leaves them zero): created once per
+    (module, device), never resized -- hipGraphs captured earlier keep writing to the same words on replay."""
+    t = owner.__dict__.get("_b3d_tickets")
+    if t is None or t.device != dev:
+        t = torch.zeros(16, dtype=torch.int32, device=dev)
+        owner.__dict__["_b3d_tickets"] = t
+    return t
+
+
+def point_stack_train_hip(owner: nn.Module, convs, bns, x: torch.Tensor, trans=None):
+    """The train-mode point stack (conv-BN-ReLU x2, conv-BN, max over the points; BatchNorm on THIS batch's statistics, running
+    statistics updated) in ONE library call (``b3d_point_stack_train``, round 5: seven launches instead of ten composed here).
+    Returns ``(ext [B, 1024], scale [1024], shift [1024])``: the stack's output is ``ext * scale + shift`` (+ ReLU for the STN), an
+    affine map the next Linear applies while it stages its input (``fc_head_hip(in_affine=...)``) or ``_materialize`` writes out."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    x = x.float().contiguous()
+    _lib.require_cuda(x, "point cloud", torch.float32)
+    b, c, p = x.shape
+    dev = x.device
+    keep = []
+
+    def f32(t_):
+        t_ = t_.detach().float().contiguous()
+        _lib.require_cuda(t_, "point stack parameter", torch.float32)
+        keep.append(t_)
+        return t_.data_ptr()
+
+    cl = (_lib.b3d_linear * 3)()
+    bl = (_lib.b3d_batchnorm * 3)()
+    for i, (cv, bn) in enumerate(zip(convs, bns)):
+        cl[i].w, cl[i].b = f32(cv.weight.squeeze(-1)), f32(cv.bias)
+        bl[i].gamma, bl[i].beta = f32(bn.weight), f32(bn.bias)
+        if bn.track_running_stats and bn.running_mean is not None:
+            for t_ in (bn.running_mean, bn.running_var):
+                _lib.require_cuda(t_, "BatchNorm running statistic", torch.float32)
+            _lib.require_cuda(bn.num_batches_tracked, "num_batches_tracked", torch.int64)
+            bl[i].running_mean, bl[i].running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+            bl[i].num_batches_tracked = bn.num_batches_tracked.data_ptr()
+        bl[i].momentum = float(bn.momentum) if bn.momentum is not None else -1.0
+        bl[i].eps = float(bn.eps)
+    t = trans.float().contiguous() if trans is not None else None
+    with torch.no_grad():
+        ext = torch.empty(b, 1024, dtype=torch.float32, device=dev)
+        aff = torch.empty(2, 1024, dtype=torch.float32, device=dev)
+        nbytes = lib.b3d_point_stack_train_workspace_bytes(b)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        _lib.check(lib.b3d_point_stack_train(cl, bl, x.data_ptr(), _lib.ptr(t), b, c, p, _tickets(owner, dev).data_ptr(), ws.data_ptr(),
+                                             nbytes, ext.data_ptr(), aff[0].data_ptr(), aff[1].data_ptr(), _lib.current_stream(dev)),
+                   "b3d_point_stack_train")
+    return ext, aff[0], aff[1]
+
+
+def _materialize(x: torch.Tensor, affine) -> torch.Tensor:
+    """``x`` itself, or -- for a stack output that is still (extremes, scale, shift, relu) -- the activation it stands for."""
+    if affine is None:
+        return x
+    from . import _lib
+    sc, sh, relu = affine
+    out = torch.empty_like(x)
+    _lib.check(_lib.load().b3d_affine(x.data_ptr(), sc.data_ptr(), sh.data_ptr(), x.size(0), x.size(1), int(bool(relu)), out.data_ptr(),
+                                      _lib.current_stream(x.device)), "b3d_affine")
+    return out
+
+
 def _bn_struct(bn: nn.BatchNorm1d, train: bool, keep: list):
     from . import _lib
     s = _lib.b3d_batchnorm()
@@ -248,14 +315,16 @@ def _draw_dropout_mask(b: int, n: int, p: float, dev) -> torch.Tensor:
     return F.dropout(torch.ones(b, n, dtype=torch.float32, device=dev), p, True)
 
 
-def fc_head_hip(owner: nn.Module, x: torch.Tensor, stages, final_relu: bool = True):
+def fc_head_hip(owner: nn.Module, x: torch.Tensor, stages, final_relu: bool = True, in_affine=None):
     """A chain of Linear (+ BatchNorm1d + ReLU) stages on [B, K] rows, one HIP launch per Linear (``b3d_fc_bn_forward``):
     every launch applies the PREVIOUS stage's BatchNorm + ReLU while it reads its input, multiplies an optional Dropout
     mask into its output and accumulates the batch statistics its own BatchNorm needs -- BatchNorm / ReLU / Dropout
     never run as kernels of their own.  ``stages``: list of ``(fc, bn or None, dropout or None, add or None)``; a stage without ``bn``
     must be the last one.  A Linear may have at most 4,032 outputs (one arrival counter per 64-column tile in the 256-byte
     workspace header; the encoders' widest is 512).  Train mode (``bn.training``): batch statistics, running statistics updated as torch does; the
-    Dropout mask is drawn by ONE torch call on a tensor of ones (the Philox stream stays torch's).  No autograd (frozen)."""
+    Dropout mask is drawn by ONE torch call on a tensor of ones (the Philox stream stays torch's).  No autograd (frozen).
+    ``in_affine``: ``(scale [K], shift [K], relu)`` -- the first Linear's input is ``act(x * scale + shift)`` (a train-mode point
+    stack hands over its per-cloud extremes and the batch's last BatchNorm this way, ``point_stack_train_hip``)."""
     import ctypes as C
     from . import _lib
     lib = _lib.load()
@@ -274,6 +343,10 @@ def fc_head_hip(owner: nn.Module, x: torch.Tensor, stages, final_relu: bool = Tr
     ws = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
     keep = []
     in_scale = in_shift = None
+    in_relu = 1
+    if in_affine is not None:
+        in_scale, in_shift = (t_.detach().float().contiguous() for t_ in in_affine[:2])
+        in_relu = int(bool(in_affine[2]))
     cur = x
     with torch.no_grad():
         for i, (fc, bn, dropout, add) in enumerate(stages):
@@ -292,11 +365,11 @@ def fc_head_hip(owner: nn.Module, x: torch.Tensor, stages, final_relu: bool = Tr
             bs = _bn_struct(bn, train, keep) if bn is not None else None
             addv = add.detach().float().contiguous() if add is not None else None
             _lib.check(lib.b3d_fc_bn_forward(cur.data_ptr(), b, k, w.data_ptr(), _lib.ptr(bias), n, _lib.ptr(in_scale), _lib.ptr(in_shift),
-                                             _lib.ptr(mask), _lib.ptr(addv), C.byref(bs) if bs is not None else None, int(train),
+                                             in_relu, _lib.ptr(mask), _lib.ptr(addv), C.byref(bs) if bs is not None else None, int(train),
                                              y.data_ptr(), _lib.ptr(sc), _lib.ptr(sh), ws.data_ptr(), ws.numel(), stream),
                        "b3d_fc_bn_forward")
             keep += [w, bias, mask, addv, cur, in_scale, in_shift]
-            cur, in_scale, in_shift = y, sc, sh
+            cur, in_scale, in_shift, in_relu = y, sc, sh, 1
         if in_scale is not None:                     # the last stage had a BatchNorm: materialise relu(bn(y))
             if not final_relu:
                 raise ValueError("fc head: a trailing BatchNorm without ReLU is not a shape of these encoders")
@@ -307,11 +380,17 @@ def fc_head_hip(owner: nn.Module, x: torch.Tensor, stages, final_relu: bool = Tr
     return cur
 
 
+def _empty(module: nn.Module, x: torch.Tensor, width: int):
+    """An empty batch on the GPU (no row of a batch carries the modality: clr_att_gnn.py:131,139 call the encoder on a [0, C, P]
+    tensor): the result is an empty [0, width] tensor, nothing is launched and no statistic moves -- None otherwise."""
+    if x.is_cuda and x.size(0) == 0 and getattr(module, "use_hip", True):
+        return x.new_zeros((0, width), dtype=torch.float32)
+    return None
+
+
 def _stack_blocker(module: nn.Module, x: torch.Tensor):
     """Why the HIP point stack cannot take ``x`` [B, C, P] (None: it can).  Eval mode needs no autograd through it; train mode
     additionally frozen parameters (batch statistics without a backward) and more than one point."""
-    if x.size(0) == 0:
-        return "empty batch"
     if module.training:
         if x.size(0) * x.size(2) <= 1:
             return "train-mode BatchNorm needs more than one value per channel"
@@ -322,8 +401,6 @@ def _stack_blocker(module: nn.Module, x: torch.Tensor):
 
 
 def _fc_blocker(module: nn.Module, x: torch.Tensor, bns):
-    if x.size(0) == 0:
-        return "empty batch"
     if any(bn.training for bn in bns) and x.size(0) <= 1:
         return "train-mode BatchNorm needs more than one row"
     return _autograd_blocker(module, x)
@@ -436,10 +513,10 @@ class ResNetAE(nn.Module):
 
     def encode(self, x):
         why = None
+        if x.dim() == 4 and _empty(self, x, 96) is not None:
+            return _empty(self, x, 96)
         if x.dim() != 4 or tuple(x.shape[1:]) != (3, 32, 32):
             why = f"crops are [N, 3, 32, 32] (the size the GNN feeds), got {tuple(x.shape)}"
-        elif x.size(0) == 0:
-            why = "empty batch"
         elif self.training and x.size(0) <= 1:
             why = "train-mode BatchNorm needs more than one crop"
         elif self.training and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
@@ -462,9 +539,16 @@ class _STN3d(nn.Module):
 
     def forward(self, x):
         b = x.size(0)
+        affine = None
+        if _empty(self, x, 9) is not None:
+            return _empty(self, x, 9).view(0, 3, 3)
         if _route(self, "stn.points", x, _stack_blocker(self, x)):
-            stack = point_feat_train_hip if self.training else point_feat_hip
-            x = stack((self.conv1, self.conv2, self.conv3), (self.bn1, self.bn2, self.bn3), x, relu_last=True)
+            cb = ((self.conv1, self.conv2, self.conv3), (self.bn1, self.bn2, self.bn3))
+            if self.training:
+                x, sc, sh = point_stack_train_hip(self, *cb, x)
+                affine = (sc, sh, True)                     # relu(bn3(.)) of pointnet.py:40, applied by the consumer
+            else:
+                x = point_feat_hip(*cb, x, relu_last=True)
         else:
             x = F.relu(self.bn1(self.conv1(x)))
             x = F.relu(self.bn2(self.conv2(x)))
@@ -472,8 +556,10 @@ class _STN3d(nn.Module):
             x = torch.max(x, 2, keepdim=True)[0].view(-1, 1024)
         if _route(self, "stn.fc", x, _fc_blocker(self, x, (self.bn4, self.bn5))):
             iden = torch.eye(3, dtype=torch.float32, device=x.device).view(9)
-            x = fc_head_hip(self, x, [(self.fc1, self.bn4, None, None), (self.fc2, self.bn5, None, None), (self.fc3, None, None, iden)])
+            x = fc_head_hip(self, x, [(self.fc1, self.bn4, None, None), (self.fc2, self.bn5, None, None), (self.fc3, None, None, iden)],
+                            in_affine=affine)
             return x.view(-1, 3, 3)
+        x = _materialize(x, affine)
         x = F.relu(_fc_bn(self.fc1, self.bn4, x))
         x = F.relu(_fc_bn(self.fc2, self.bn5, x))
         x = self.fc3(x)
@@ -489,15 +575,25 @@ class _PointNetFeat(nn.Module):
         self.bn1, self.bn2, self.bn3 = nn.BatchNorm1d(64), nn.BatchNorm1d(128), nn.BatchNorm1d(1024)
 
     def forward(self, x):
+        return _materialize(*self.forward_parts(x))
+
+    def forward_parts(self, x):
+        """(features or per-cloud extremes, None or the affine map (scale, shift, relu) that turns the extremes into the features):
+        the train-mode HIP stack leaves its last BatchNorm to the consumer (``point_stack_train_hip``)."""
+        if _empty(self, x, 1024) is not None:
+            return _empty(self, x, 1024), None
         trans = self.stn(x)
         if _route(self, "pointnet.points", x, _stack_blocker(self, x)):          # the bmm is applied while the kernel loads the points
-            stack = point_feat_train_hip if self.training else point_feat_hip
-            return stack((self.conv1, self.conv2, self.conv3), (self.bn1, self.bn2, self.bn3), x, trans=trans)
+            cb = ((self.conv1, self.conv2, self.conv3), (self.bn1, self.bn2, self.bn3))
+            if self.training:
+                ext, sc, sh = point_stack_train_hip(self, *cb, x, trans=trans)
+                return ext, (sc, sh, False)                 # bn3 without ReLU (pointnet.py:158)
+            return point_feat_hip(*cb, x, trans=trans), None
         x = torch.bmm(x.transpose(2, 1), trans).transpose(2, 1)
         x = F.relu(self.bn1(self.conv1(x)))
         x = F.relu(self.bn2(self.conv2(x)))
         x = self.bn3(self.conv3(x))
-        return torch.max(x, 2, keepdim=True)[0].view(-1, 1024)
+        return torch.max(x, 2, keepdim=True)[0].view(-1, 1024), None
 
 
 class PointNetClassifier(nn.Module):
@@ -511,9 +607,12 @@ class PointNetClassifier(nn.Module):
         self.bn1, self.bn2 = nn.BatchNorm1d(512), nn.BatchNorm1d(256)
 
     def forward_feat(self, x):
-        x = self.feat(x)
+        if _empty(self, x, 256) is not None:
+            return _empty(self, x, 256)
+        x, affine = self.feat.forward_parts(x)
         if _route(self, "pointnet.fc", x, _fc_blocker(self, x, (self.bn1, self.bn2))):
-            return fc_head_hip(self, x, [(self.fc1, self.bn1, None, None), (self.fc2, self.bn2, self.dropout, None)])
+            return fc_head_hip(self, x, [(self.fc1, self.bn1, None, None), (self.fc2, self.bn2, self.dropout, None)], in_affine=affine)
+        x = _materialize(x, affine)
         x = F.relu(_fc_bn(self.fc1, self.bn1, x))
         if not _fold_on(self.bn2):
             return F.relu(self.bn2(self.dropout(self.fc2(x))))
@@ -527,13 +626,22 @@ class _RadarNetFeat(nn.Module):
         self.bn1, self.bn2, self.bn3 = nn.BatchNorm1d(64), nn.BatchNorm1d(128), nn.BatchNorm1d(1024)
 
     def forward(self, x):
+        return _materialize(*self.forward_parts(x))
+
+    def forward_parts(self, x):
+        """As ``_PointNetFeat.forward_parts``."""
+        if _empty(self, x, 1024) is not None:
+            return _empty(self, x, 1024), None
         if _route(self, "radarnet.points", x, _stack_blocker(self, x)):
-            stack = point_feat_train_hip if self.training else point_feat_hip
-            return stack((self.conv1, self.conv2, self.conv3), (self.bn1, self.bn2, self.bn3), x)
+            cb = ((self.conv1, self.conv2, self.conv3), (self.bn1, self.bn2, self.bn3))
+            if self.training:
+                ext, sc, sh = point_stack_train_hip(self, *cb, x)
+                return ext, (sc, sh, False)                 # bn3 without ReLU (radarnet.py:35)
+            return point_feat_hip(*cb, x), None
         x = F.relu(self.bn1(self.conv1(x)))
         x = F.relu(self.bn2(self.conv2(x)))
         x = self.bn3(self.conv3(x))
-        return torch.max(x, 2, keepdim=True)[0].view(-1, 1024)
+        return torch.max(x, 2, keepdim=True)[0].view(-1, 1024), None
 
 
 class RadarNetClassifier(nn.Module):
@@ -545,9 +653,12 @@ class RadarNetClassifier(nn.Module):
         self.bn1, self.bn2 = nn.BatchNorm1d(512), nn.BatchNorm1d(256)
 
     def forward_feat(self, x):
-        x = self.feat(x)
+        if _empty(self, x, 256) is not None:
+            return _empty(self, x, 256)
+        x, affine = self.feat.forward_parts(x)
         if _route(self, "radarnet.fc", x, _fc_blocker(self, x, (self.bn1, self.bn2))):
-            return fc_head_hip(self, x, [(self.fc1, self.bn1, None, None), (self.fc2, self.bn2, self.dropout, None)])
+            return fc_head_hip(self, x, [(self.fc1, self.bn1, None, None), (self.fc2, self.bn2, self.dropout, None)], in_affine=affine)
+        x = _materialize(x, affine)
         x = F.relu(_fc_bn(self.fc1, self.bn1, x))
         if not _fold_on(self.bn2):
             return F.relu(self.bn2(self.dropout(self.fc2(x))))

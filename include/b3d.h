@@ -392,9 +392,10 @@ int b3d_resnet_encode(const b3d_linear* conv, const b3d_batchnorm* bn, const flo
 
 /* Fully connected heads of the frozen point encoders (reference batch_3dmot/models/pointnet.py:46-48 STN3d fc1-bn4-relu, fc2-bn5-relu,
  * fc3 + identity; pointnet.py:188-192 and radarnet.py:60-64 forward_feat: fc1-bn1-relu, fc2-dropout-bn2-relu), one launch per Linear:
- *     y [B,N] = mask * ( relu(x * in_scale + in_shift) . w^T + bias ) + add
+ *     y [B,N] = mask * ( act(x * in_scale + in_shift) . w^T + bias ) + add          act = ReLU (in_relu != 0) or the identity
  * x [B,K] (K a multiple of 4), w [N,K] row-major; in_scale / in_shift [K] (both or neither: the PRODUCER's BatchNorm affine, applied
- * with its ReLU while x is read), mask [B,N] (Dropout: 0 or 1 / (1 - p), drawn by the caller so that the random stream stays the
+ * -- with its ReLU if in_relu -- while x is read; in_relu == 0 is the point stacks' last BatchNorm in front of fc1 of
+ * forward_feat, pointnet.py:188 / radarnet.py:60, which has no ReLU), mask [B,N] (Dropout: 0 or 1 / (1 - p), drawn by the caller so that the random stream stays the
  * caller's), add [N] (STN3d's flattened identity); each may be NULL.  With `bn` the launch also produces THIS layer's BatchNorm
  * affine out_scale / out_shift [N]: from the batch statistics of y in train mode (`train` != 0, B > 1; running statistics and
  * num_batches_tracked updated as nn.BatchNorm1d does; summed in a fixed order, bitwise reproducible), from the running statistics
@@ -408,10 +409,12 @@ int b3d_resnet_encode(const b3d_linear* conv, const b3d_batchnorm* bn, const flo
 size_t b3d_fc_bn_workspace_bytes(int32_t B, int32_t N);
 int b3d_fc_ticket_init(void* workspace, size_t workspace_bytes, b3d_stream stream);
 int b3d_fc_bn_forward(const float* x, int32_t B, int32_t K, const float* w, const float* bias, int32_t N,
-                      const float* in_scale, const float* in_shift, const float* mask, const float* add,
+                      const float* in_scale, const float* in_shift, int32_t in_relu, const float* mask, const float* add,
                       const b3d_batchnorm* bn, int32_t train, float* y, float* out_scale, float* out_shift,
                       void* workspace, size_t workspace_bytes, b3d_stream stream);
 int b3d_affine_relu(const float* y, const float* scale, const float* shift, int32_t B, int32_t N, float* out, b3d_stream stream);
+/* out = y * scale + shift (+ ReLU if relu != 0), per column. */
+int b3d_affine(const float* y, const float* scale, const float* shift, int32_t B, int32_t N, int32_t relu, float* out, b3d_stream stream);
 
 /* Mean mu [K] and second moments second [K,K] = E[h h^T] (float64) over all B * P points of the input of a point stack's
  * first layer (fold1 == NULL: h = the point, transformed by `trans` if given, K = C) or of its second layer (fold1 = the first
@@ -438,6 +441,23 @@ int b3d_bn_minmax_apply(const float* vmax, const float* vmin, const float* vsum,
                         int64_t count, const float* gamma, const float* beta, float* running_mean, float* running_var,
                         int64_t* num_batches_tracked, float momentum, float eps, int32_t relu, void* workspace,
                         size_t workspace_bytes, float* y, b3d_stream stream);
+
+/* ---- a whole train-mode point stack in ONE call (round 5) ---------------------------------------------------------------------
+ * conv1d(C,64,1)+BN+ReLU -> conv1d(64,128,1)+BN+ReLU -> conv1d(128,1024,1)+BN -> max over the points, BatchNorm on the statistics of
+ * THIS batch (pointnet.py:23-42 STN3d, :128-160 PointNetfeat, radarnet.py:17-36 RadarNetfeat in .train()); running statistics and
+ * num_batches_tracked of the three BatchNorms updated as nn.BatchNorm1d does.  conv[3]: the RAW convolutions (w [out,in], b);
+ * bn[3]: their BatchNorms.  Seven launches (b3d_point_moments / b3d_bn_fold_moments / b3d_point_feat_stats / b3d_bn_minmax_apply
+ * composed by the caller were ten): the first layer's statistics are finished by the last workgroup of the input-moments launch, the
+ * 64 x 64 moments of the second layer's input accumulate as bf16x6, and sign(gamma) of the LAST BatchNorm is folded into the last
+ * convolution so that only the maximum is tracked.  Outputs: ext [B,1024] = max over the points of sign(gamma3) * conv3(h2), and
+ * the batch's last BatchNorm as an affine map of it:  BN3(.) maximised over the points = ext * out_scale + out_shift (out_scale >= 0;
+ * [1024] each) -- apply it with b3d_affine, or hand the pair to b3d_fc_bn_forward as in_scale / in_shift of the next Linear.
+ * `tickets`: 64 bytes of arrival counters that must be ZERO on entry; the call leaves them zero (stream order), so one zero-filled
+ * buffer per encoder serves every call. */
+size_t b3d_point_stack_train_workspace_bytes(int32_t B);
+int b3d_point_stack_train(const b3d_linear* conv /* host [3] */, const b3d_batchnorm* bn /* host [3] */, const float* x,
+                          const float* trans, int32_t B, int32_t C, int32_t P, void* tickets, void* workspace,
+                          size_t workspace_bytes, float* ext, float* out_scale, float* out_shift, b3d_stream stream);
 
 /* ---- average precision of the edge scores (train.py:18,143-150,188-196) -----------------------------------
  * torchmetrics.functional average_precision(out, gt, pos_label=1) of the whole batch (ap[0]) and of the edges of

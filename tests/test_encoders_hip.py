@@ -78,8 +78,12 @@ def test_train_mode_keeps_the_batch_statistics_path_and_bad_shapes_are_rejected(
     dev = torch.device("cuda:0")
     m = encoders.RadarNetClassifier(k=7).to(dev).train()
     x = _clouds(4, 4, 64, 1, dev)
-    out = m.forward_feat(x)                                              # batch statistics: PyTorch path, no error
-    assert out.shape == (4, 256)
+    with pytest.raises(RuntimeError, match="unfrozen"):                  # trainable parameters in train mode: no silent PyTorch path
+        m.forward_feat(x)
+    for mod in m.modules():
+        mod.use_hip = False                                              # ... the deliberate one
+    out = m.forward_feat(x)
+    assert out.shape == (4, 256) and out.requires_grad
     with pytest.raises(RuntimeError):
         encoders.point_feat_hip((m.feat.conv1, m.feat.conv2, m.feat.conv3), (m.feat.bn1, m.feat.bn2, m.feat.bn3), x)
     m.eval()
