@@ -100,10 +100,16 @@ static const int kRowKind[LIN_COUNT] = {0, 0, 0, 1, 1, 0, 0, 0, 0, 2, 2, 3, 3, 3
 // images per workgroup.  With one wavefront per workgroup (kNWNode: right for the 19-48-96 node encoder) that stream passes through
 // ONE loader wavefront -- ~25 GB/s, 20 us of a 25 us launch; four wavefronts load it four times faster for four 16-row tiles.
 constexpr int kNWHead = B3D_NW_HEAD;
-constexpr int kStreamRowsPerTask = 768;          // message-passing stacks (x up to 6 layer variants)
+#ifndef B3D_RPT_MP
+#define B3D_RPT_MP 768
+#endif
+#ifndef B3D_RPT_ATT
+#define B3D_RPT_ATT 1536
+#endif
+constexpr int kStreamRowsPerTask = B3D_RPT_MP;   // message-passing stacks (x up to 6 layer variants)
 constexpr int kStreamNodeRowsPerTask = 128;      // hoisted first layers: node columns contract over N rows x depth layers
 constexpr int kStreamNodeRowsPerTaskAtt = 512;   // att_edge_encoder.0's node columns: one variant, a [512, 288] partial per task
-constexpr int kStreamRowsPerTaskAtt = 1536;      // att_edge_encoder (one variant)
+constexpr int kStreamRowsPerTaskAtt = B3D_RPT_ATT;   // att_edge_encoder (one variant)
 
 // column blocks of the hoisted first-layer gradients: (linear, first column, width, rows contracted over edges?)
 enum { VL_EU0XI, VL_EU0XJ, VL_EU0E, VL_FU0X, VL_FU0E, VL_FU0X0, VL_PA0X, VL_PA0E, VL_PA0X0, VL_AT0I, VL_AT0J, VL_AT0E, VL_COUNT };

@@ -277,6 +277,16 @@ def point_stack_train_hip(owner: nn.Module, convs, bns, x: torch.Tensor, trans=N
     return ext, aff[0], aff[1]
 
 
+def _train_stack(owner, convs, bns, x, trans, relu_last):
+    """(output or extremes, affine or None) of a train-mode point stack: the one-call form, or -- B3D_OLD_STACK=1, A/B runs of
+    tools/ only -- round 4's composition of ten launches (``point_feat_train_hip``)."""
+    import os
+    if os.environ.get("B3D_OLD_STACK"):
+        return point_feat_train_hip(convs, bns, x, trans=trans, relu_last=relu_last), None
+    ext, sc, sh = point_stack_train_hip(owner, convs, bns, x, trans=trans)
+    return ext, (sc, sh, relu_last)
+
+
 def _materialize(x: torch.Tensor, affine) -> torch.Tensor:
     """``x`` itself, or -- for a stack output that is still (extremes, scale, shift, relu) -- the activation it stands for."""
     if affine is None:
@@ -545,8 +555,7 @@ class _STN3d(nn.Module):
         if _route(self, "stn.points", x, _stack_blocker(self, x)):
             cb = ((self.conv1, self.conv2, self.conv3), (self.bn1, self.bn2, self.bn3))
             if self.training:
-                x, sc, sh = point_stack_train_hip(self, *cb, x)
-                affine = (sc, sh, True)                     # relu(bn3(.)) of pointnet.py:40, applied by the consumer
+                x, affine = _train_stack(self, *cb, x, None, True)     # relu(bn3(.)) of pointnet.py:40, applied by the consumer
             else:
                 x = point_feat_hip(*cb, x, relu_last=True)
         else:
@@ -586,8 +595,7 @@ class _PointNetFeat(nn.Module):
         if _route(self, "pointnet.points", x, _stack_blocker(self, x)):          # the bmm is applied while the kernel loads the points
             cb = ((self.conv1, self.conv2, self.conv3), (self.bn1, self.bn2, self.bn3))
             if self.training:
-                ext, sc, sh = point_stack_train_hip(self, *cb, x, trans=trans)
-                return ext, (sc, sh, False)                 # bn3 without ReLU (pointnet.py:158)
+                return _train_stack(self, *cb, x, trans, False)        # bn3 without ReLU (pointnet.py:158)
             return point_feat_hip(*cb, x, trans=trans), None
         x = torch.bmm(x.transpose(2, 1), trans).transpose(2, 1)
         x = F.relu(self.bn1(self.conv1(x)))
@@ -635,8 +643,7 @@ class _RadarNetFeat(nn.Module):
         if _route(self, "radarnet.points", x, _stack_blocker(self, x)):
             cb = ((self.conv1, self.conv2, self.conv3), (self.bn1, self.bn2, self.bn3))
             if self.training:
-                ext, sc, sh = point_stack_train_hip(self, *cb, x)
-                return ext, (sc, sh, False)                 # bn3 without ReLU (radarnet.py:35)
+                return _train_stack(self, *cb, x, None, False)         # bn3 without ReLU (radarnet.py:35)
             return point_feat_hip(*cb, x), None
         x = F.relu(self.bn1(self.conv1(x)))
         x = F.relu(self.bn2(self.conv2(x)))
