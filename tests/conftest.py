@@ -69,5 +69,30 @@ def assert_adam_heads_close(before, have, want, lr, grad_noise=5e-8, eps=1e-8):
         tol = 2e-7 + 1e-5 * gold.abs() + lr * ((1.0 - r) ** 2 * (grad_noise / eps)).clamp(max=0.5)
         d = (h - gold).abs()
         assert bool((d <= tol).all()), (n, d.tolist(), tol.tolist())
-        tight += int((d <= 0.01 * lr).sum()); tot += d.numel()
+        t_n = int((d <= 0.01 * lr).sum())
+        # per tensor too: a gradient bug confined to one small-gradient tensor must not hide behind the global count
+        assert t_n >= 0.6 * d.numel(), (n, t_n, d.tolist())
+        tight += t_n; tot += d.numel()
     assert tight >= 0.85 * tot, (tight, tot)
+
+
+def assert_grad_digest_close(have, want, tol=1e-4, floor=3e-8):
+    """Pre-Adam gradients against a golden digest (oracle.seeded.grad_digest: norm, projection on a seeded random vector, first
+    8 values per tensor): the norm to `tol`, the projection to `3 tol ||g||` (an entry-wise error of tol max|g| moves it by at most
+    tol max|g| sqrt(n) <= ... in the worst case, far less for uncorrelated rounding), every head entry to `tol` of the tensor's
+    scale -- a wrong sign on a small gradient shows here, where the post-Adam weights only move by a fraction of lr.  `floor`:
+    absolute slack for tensors whose whole gradient is ~1e-5 (fp32 summation order moves single entries by ~1e-8)."""
+    for n, w in want.items():
+        if w is None:
+            assert have.get(n) is None, n
+            continue
+        h = have[n]
+        numel = 1
+        for d_ in w["shape"]:
+            numel *= d_
+        norm = max(w["norm"], 1e-30)
+        assert abs(h["norm"] - w["norm"]) <= tol * norm + floor * numel ** 0.5, (n, h["norm"], w["norm"])
+        assert abs(h["proj"] - w["proj"]) <= 3 * tol * norm + 3 * floor * numel ** 0.5, (n, h["proj"], w["proj"])
+        scale = max(float(w["head"].abs().max()), norm / numel ** 0.5)
+        d = (h["head"] - w["head"]).abs()
+        assert float(d.max()) <= 3 * tol * scale + floor, (n, d.tolist(), scale)

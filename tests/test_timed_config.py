@@ -213,6 +213,10 @@ def test_train_mode_step_matches_reference_golden(name, monkeypatch):
             assert int(bufs[n]) == int(v), n
         else:
             assert rel(bufs[n], v) < 1e-5, (n, rel(bufs[n], v))
+    # the gradients the step wrote (FlatAdam's flat buffer: b3d_adam_step reads it, never writes it) against the reference's
+    from conftest import assert_grad_digest_close
+    assert_grad_digest_close(grad_digest({n: p.grad for n, p in m.named_parameters() if p.requires_grad and p.grad is not None}),
+                             {n: w for n, w in g["grad_digest"].items() if w is not None})
     have = grad_digest({n: p.detach() for n, p in m.named_parameters() if p.requires_grad})
     for n, w in g["after_digest"].items():
         # (an element whose gradient is a few 1e-8 moves by a fraction of lr with the summation order -- conftest.assert_adam_heads_close
