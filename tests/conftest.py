@@ -33,6 +33,16 @@ def data_from(d):
     return Data(**d)
 
 
+WORST = []      # (name, max-norm error, L2 error, entries outside tol, entries) of every comparison that needed the escape clause
+
+
+def pytest_terminal_summary(terminalreporter):
+    if WORST:
+        terminalreporter.write_line("gradient comparisons that exceeded the tight tolerance (ReLU-flip clause, conftest.assert_grad_close):")
+        for name, mx, l2, outside, numel in sorted(WORST, key=lambda r: -r[1])[:12]:
+            terminalreporter.write_line(f"  {name:50s} max {mx:.2e}  L2 {l2:.2e}  outside tol {outside} / {numel}")
+
+
 def assert_grad_close(have, want, name, tol=5e-4, flip_l2=4.0, flip_max=3e-2):
     """Gradient of one parameter against the fp32 CPU oracle on a SMALL graph.
 
@@ -47,11 +57,17 @@ def assert_grad_close(have, want, name, tol=5e-4, flip_l2=4.0, flip_max=3e-2):
     import torch
     a, b = have.detach().double().cpu(), want.detach().double().cpu()
     scale = float(b.abs().max().clamp_min(1e-30))
-    mx = float((a - b).abs().max()) / scale
+    err = (a - b).abs() / scale
+    mx = float(err.max())
     if mx < tol:
         return
+    # a flipped unit touches the rows of ONE edge / node: the entries outside `tol` must be few (a kernel bug moves every row),
+    # their worst below `flip_max`, and the tensor as a whole within the L2 bound
     l2 = float((a - b).norm() / b.norm().clamp_min(1e-30))
-    assert l2 < flip_l2 * tol and mx < flip_max, (name, mx, l2)
+    outside = int((err >= tol).sum())
+    allowed = max(8, int(0.10 * err.numel()))
+    WORST.append((name, mx, l2, outside, err.numel()))
+    assert l2 < flip_l2 * tol and mx < flip_max and outside <= allowed, (name, mx, l2, outside, err.numel())
 
 
 def assert_adam_heads_close(before, have, want, lr, grad_noise=5e-8, eps=1e-8):
