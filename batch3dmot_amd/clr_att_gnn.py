@@ -577,6 +577,26 @@ class GNN(nn.Module):
             cur.wait_stream(side)
         return (x_img, pointnet_out, lidar_i32, radarnet_out, radar_i32), ready
 
+    def _encode_img(self, data):
+        """The camera part of ``_encode`` alone (current stream)."""
+        with torch.no_grad():
+            return self.resnet.encode(data.img_feats).float().contiguous()
+
+    def _encode_points(self, data, rows):
+        """The LiDAR / radar part of ``_encode`` alone (current stream): the sticky ``.eval()`` switch of an encoder that sees fewer
+        than two rows (clr_att_gnn.py:128-130,136-138), PointNet, RadarNet, the int32 row ids."""
+        lidar_nodes, radar_nodes = rows if rows is not None else self.modality_rows(data)
+        with torch.no_grad():
+            if lidar_nodes.numel() < 2:
+                self.pointnet.eval()
+                self.fc_lidar_encoder.eval()
+            pointnet_out = self.pointnet.forward_feat(data.lidar_feats[lidar_nodes].view(-1, 3, 128)).float().contiguous()
+            if radar_nodes.numel() < 2:
+                self.radarnet.eval()
+                self.fc_radar_encoder.eval()
+            radarnet_out = self.radarnet.forward_feat(data.radar_feats[radar_nodes].view(-1, 4, 64)).float().contiguous()
+            return pointnet_out, lidar_nodes.to(torch.int32).contiguous(), radarnet_out, radar_nodes.to(torch.int32).contiguous()
+
     def _encode_cached(self, data, cache: "EmbeddingCache", node_ids):
         if node_ids is None:
             node_ids = window_node_ids(data)

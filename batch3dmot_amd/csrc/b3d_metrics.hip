@@ -183,7 +183,21 @@ __global__ __launch_bounds__(kApWaves * 64) void ap_direct_kernel(const float* _
     for (long long t0 = 0; t0 < E; t0 += kApTile) {
       __syncthreads();                                         // the previous tile has been consumed
       const int n = (int)((E - t0) < kApTile ? (E - t0) : kApTile);
-      for (int i = tid; i < n; i += kApWaves * 64) { ts[i] = scores[t0 + i]; tm[i] = meta[t0 + i]; }
+      for (int i0 = 0; i0 < n; i0 += 4 * kApWaves * 64) {   // eight independent loads per thread and round trip
+        float v[4];
+        unsigned short mm[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + u * kApWaves * 64 + tid;
+          const long long j = t0 + (i < n ? i : 0);
+          v[u] = scores[j]; mm[u] = meta[j];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + u * kApWaves * 64 + tid;
+          if (i < n) { ts[i] = v[u]; tm[i] = mm[u]; }
+        }
+      }
       __syncthreads();
       for (int j0 = 0; j0 < n; j0 += 256) {                    // four independent LDS reads per lane
 #pragma unroll

@@ -60,11 +60,13 @@ def fused_edge_loss(out: torch.Tensor, data, batch_size: int, loss_kind: str = "
 
 
 def forward_backward(gnn, data, optimizer, batch_size: int = 2, loss_kind: str = "cb", logits: bool = False,
-                     fused_loss: Optional[bool] = None, forward_kwargs: Optional[dict] = None):
+                     fused_loss: Optional[bool] = None, forward_kwargs: Optional[dict] = None, after_forward=None):
     """The part of a step in front of the gradient exchange: forward, ``zero_grad``, loss, backward.  Split out so
     that a data-parallel loop can capture it (and ``optimizer.step()``) into hipGraphs and keep only the all-reduce
     eager between the two replays."""
     out, aux = gnn(data, **forward_kwargs) if forward_kwargs else gnn(data)
+    if after_forward is not None:
+        after_forward()                         # e.g. EncodeAhead.launch(next batch): independent work under the backward sweep
     if fused_loss is None:
         fused_loss = out.is_cuda                # GPU scores: always b3d_edge_loss; the torch form only on request (fused_loss=False)
     PATHS["fused_loss" if fused_loss else "torch_loss"] += 1
@@ -83,12 +85,13 @@ def forward_backward(gnn, data, optimizer, batch_size: int = 2, loss_kind: str =
 
 
 def train_step(gnn, data, optimizer, batch_size: int = 2, loss_kind: str = "cb", logits: bool = False,
-               grad_sync: Optional[object] = None, fused_loss: Optional[bool] = None, forward_kwargs: Optional[dict] = None):
+               grad_sync: Optional[object] = None, fused_loss: Optional[bool] = None, forward_kwargs: Optional[dict] = None,
+               after_forward=None):
     """One optimisation step; ``grad_sync`` (batch3dmot_amd.dist.FlatGradSync) averages gradients over
     the ranks of a data-parallel job between backward and the optimizer step.  ``fused_loss``
     (default: on when the model output lives on the GPU) takes loss and d loss/d out from
     ``b3d_edge_loss`` and seeds ``out.backward`` with it."""
-    loss, out, aux = forward_backward(gnn, data, optimizer, batch_size, loss_kind, logits, fused_loss, forward_kwargs)
+    loss, out, aux = forward_backward(gnn, data, optimizer, batch_size, loss_kind, logits, fused_loss, forward_kwargs, after_forward)
     if grad_sync is not None:
         grad_sync.sync()
     optimizer.step()
@@ -135,6 +138,13 @@ class EncodeAhead:
                 ahead.launch(batches[k + 1])                 # runs under the step below
             train_step(gnn, batch, optimizer, forward_kwargs={"encoded": encoded})
 
+    or, placing the parts where the step has room for them (what ``bench.py`` times: the camera encoder under the forward, the two
+    point encoders under the backward sweep, whose node-phase kernels leave a quarter of the CUs idle):
+
+            ahead.launch(nxt, parts="img")
+            train_step(gnn, batch, optimizer, forward_kwargs={"encoded": encoded},
+                       after_forward=lambda: ahead.launch(nxt, parts="points"))
+
     One side stream, the three encoders one after the other on it (they have a whole step of time).  ``static`` (a tuple of
     preallocated tensors shaped like ``encode_modalities``' result) makes ``launch`` write there -- what a hipGraph-captured
     step needs; without it the outputs are fresh tensors, recorded on the consuming stream by ``take``."""
@@ -144,39 +154,55 @@ class EncodeAhead:
         self.stream = None
         self.pending = None
 
-    def launch(self, data, rows=None, static=None):
-        if self.pending is not None:
+    def launch(self, data, rows=None, static=None, parts: str = "all"):
+        """``parts``: "all" (default), or "img" followed -- later in the step -- by "points" for the same batch: the camera encoder
+        and the two point encoders enqueued at different places of the current step (``bench.py``: ResNetAE under the forward,
+        PointNet / RadarNet under the backward sweep)."""
+        if parts not in ("all", "img", "points"):
+            raise ValueError(f"EncodeAhead.launch: parts = {parts!r}")
+        if self.pending is not None and not (parts == "points" and self.pending[0] is data and self.pending[3] == "img"):
             raise RuntimeError("EncodeAhead.launch: the previous batch was never taken")
         dev = data.pose_feats.device
         if self.stream is None or self.stream.device != dev:
             self.stream = torch.cuda.Stream(dev)
         cur = torch.cuda.current_stream(dev)
         self.stream.wait_stream(cur)
-        if rows is None:
+        if rows is None and parts != "img":
             rows = self.gnn.modality_rows(data)              # (on the caller's side: the counts are shapes)
         keep = self.gnn.encoder_streams
         self.gnn.encoder_streams = False                     # one branch: no forks inside the side stream
         try:
             with torch.cuda.stream(self.stream):
-                out = self.gnn.encode_modalities(data, rows=rows)
+                if parts == "all":
+                    out = list(self.gnn.encode_modalities(data, rows=rows))
+                    lo = 0
+                elif parts == "img":
+                    out, lo = [self.gnn._encode_img(data)], 0
+                else:
+                    out, lo = list(self.gnn._encode_points(data, rows)), 1
                 if static is not None:
-                    for dst, src in zip(static, out):
+                    for dst, src in zip(static[lo:lo + len(out)], out):
                         if dst.shape != src.shape:
                             raise ValueError(f"EncodeAhead: static buffer {tuple(dst.shape)} vs encoder output {tuple(src.shape)}")
                         dst.copy_(src)
-                    out = static
-                if not torch.cuda.is_current_stream_capturing():
+                    out = list(static[lo:lo + len(out)])
+                if rows is not None and not torch.cuda.is_current_stream_capturing():
                     for t in rows:
                         t.record_stream(self.stream)          # produced elsewhere, read by this stream's gathers
         finally:
             self.gnn.encoder_streams = keep
-        self.pending = (data, out, static is not None)
-        return out
+        if parts == "points":
+            out = self.pending[1] + out
+        self.pending = (data, out, static is not None, parts)
+        return tuple(out)
 
     def take(self, data):
         if self.pending is None or self.pending[0] is not data:
             raise RuntimeError("EncodeAhead.take: this batch was not the one launched")
-        _, out, is_static = self.pending
+        if self.pending[3] == "img":
+            raise RuntimeError("EncodeAhead.take: only the camera part of this batch was launched")
+        _, out, is_static, _ = self.pending
+        out = tuple(out)
         self.pending = None
         cur = torch.cuda.current_stream(data.pose_feats.device)
         cur.wait_stream(self.stream)

@@ -235,25 +235,26 @@ class Workload:
                     self.ahead.launch(self.pool[0], rows=self.rows_static[0], static=self.enc_static[0])
                     self.ahead.take(self.pool[0])
 
-    def _run(self, i, kwargs):
+    def _run(self, i, kwargs, after_forward=None):
         from batch3dmot_amd.train_step import train_step
         b = self.pool[i % len(self.pool)]
         if hasattr(b, "_b3d_graph"):
             del b._b3d_graph                     # the CSR/CSC build is part of every step
         ret = train_step(self.model, b, self.opt, batch_size=self.graphs, loss_kind="cb", logits=self.logits, grad_sync=self.sync,
-                         forward_kwargs=kwargs)
+                         forward_kwargs=kwargs, after_forward=after_forward)
         if self.ap_metrics:
             from batch3dmot_amd import metrics
             scores = torch.sigmoid(ret[1]) if self.logits else ret[1]
             self.ap_ret[i % len(self.pool)] = metrics._run(scores, b.y, b.edge_classes, 7)
         return ret
 
-    def _run_fb(self, i, kwargs):
+    def _run_fb(self, i, kwargs, after_forward=None):
         from batch3dmot_amd.train_step import forward_backward
         b = self.pool[i % len(self.pool)]
         if hasattr(b, "_b3d_graph"):
             del b._b3d_graph
-        return forward_backward(self.model, b, self.opt, batch_size=self.graphs, loss_kind="cb", logits=self.logits, forward_kwargs=kwargs)
+        return forward_backward(self.model, b, self.opt, batch_size=self.graphs, loss_kind="cb", logits=self.logits, forward_kwargs=kwargs,
+                                after_forward=after_forward)
 
     def captured_fb(self, i):
         """The part of `captured` in front of the gradient exchange (N > 1: graph A; the all-reduce runs eagerly between
@@ -277,8 +278,20 @@ class Workload:
         """Step i with the encoders of the NEXT pool batch underneath it: fork (side stream) -> encoders(k + 1) into their static
         buffers | step(k) on the outputs the previous step left for batch k -> join."""
         k, kn = i % len(self.pool), (i + 1) % len(self.pool)
-        self.ahead.launch(self.pool[kn], rows=rows_next, static=self.enc_static[kn])
-        ret = run(i, {"encoded": self.enc_static[k]})
+        launch = lambda parts="all": self.ahead.launch(self.pool[kn], rows=rows_next, static=self.enc_static[kn], parts=parts)       # noqa: E731
+        # Where the next batch's encoders enter the current step (same work, same bits; A/B on one box, three rounds each, round 5):
+        # everything in front of the forward 4.21 / 4.24 / 4.22 ms, everything behind the forward 4.17 / 4.23 / 4.23, ResNetAE in
+        # front of the forward and the two point encoders behind it ("split") 4.16 / 4.21 / 4.17 -- the backward sweep has the
+        # thinner kernels (node phase: 188 workgroups on 256 CUs) for the fat point stacks to run beside.  B3D_AHEAD_AT overrides.
+        where = os.environ.get("B3D_AHEAD_AT", "split")
+        if where == "backward":
+            ret = run(i, {"encoded": self.enc_static[k]}, launch)
+        elif where == "split":
+            launch("img")
+            ret = run(i, {"encoded": self.enc_static[k]}, lambda: launch("points"))
+        else:
+            launch()
+            ret = run(i, {"encoded": self.enc_static[k]})
         self.ahead.take(self.pool[kn])
         return ret
 
@@ -329,7 +342,8 @@ class Workload:
         enc = ("frozen ResNetAE / PointNet / RadarNet encoders in train mode inside the step" if self.encoders == "frozen"
                else "encoder outputs precomputed")
         if self.ahead is not None:
-            enc += " (one encoder pass per step, enqueued for the NEXT pool batch on a side stream under this batch's step: train_step.EncodeAhead)"
+            enc += (" (one encoder pass per step, enqueued for the NEXT pool batch on a side stream under this batch's step -- ResNetAE under "
+                    "its forward, PointNet / RadarNet under its backward sweep: train_step.EncodeAhead)")
         name = "camera+LiDAR+radar" if self.modalities == "clr" else "camera+LiDAR (radar rows all zero)"
         return (name + " GNN (clr_att_gnn) depth 6, training step (modality masks + " + enc
                 + " + CSR/CSC build + fwd + cb-BCE + bwd + Adam" + (" + flat RCCL grad all-reduce of 5.24 MB" if world > 1 else "")

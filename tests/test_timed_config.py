@@ -250,20 +250,25 @@ def test_encode_ahead_equals_the_sequential_loop_bitwise():
         if pipelined:
             ahead.launch(batches[0])
         for k, b in enumerate(batches):
-            kw = None
+            kw, hook = None, None
             if pipelined:
                 kw = {"encoded": ahead.take(b)}
                 if k + 1 < len(batches):
-                    ahead.launch(batches[k + 1])
-            loss, _, _ = train_step(m, b, opt, batch_size=2, loss_kind="cb", logits=False, forward_kwargs=kw)
+                    nxt = batches[k + 1]
+                    if pipelined == "split":             # bench.py's placement: camera under the forward, point encoders under the backward
+                        ahead.launch(nxt, parts="img")
+                        hook = lambda nxt=nxt: ahead.launch(nxt, parts="points")      # noqa: E731
+                    else:
+                        ahead.launch(nxt)
+            loss, _, _ = train_step(m, b, opt, batch_size=2, loss_kind="cb", logits=False, forward_kwargs=kw, after_forward=hook)
             losses.append(float(loss))
         torch.cuda.synchronize()
         return losses, {k: v.detach().clone() for k, v in m.state_dict().items()}
 
     l_seq, s_seq = run(False)
-    l_pipe, s_pipe = run(True)
-    assert l_seq == l_pipe
-    changed = 0
-    for k in s_seq:
-        assert torch.equal(s_seq[k], s_pipe[k]), k
+    for form in (True, "split"):
+        l_pipe, s_pipe = run(form)
+        assert l_seq == l_pipe, form
+        for k in s_seq:
+            assert torch.equal(s_seq[k], s_pipe[k]), (form, k)
     assert len({round(x, 6) for x in l_seq}) == 4             # four different batches, four losses
