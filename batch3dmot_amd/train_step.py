@@ -160,7 +160,9 @@ class EncodeAhead:
         PointNet / RadarNet under the backward sweep)."""
         if parts not in ("all", "img", "points"):
             raise ValueError(f"EncodeAhead.launch: parts = {parts!r}")
-        if self.pending is not None and not (parts == "points" and self.pending[0] is data and self.pending[3] == "img"):
+        if parts == "points" and (self.pending is None or self.pending[0] is not data or self.pending[3] != "img"):
+            raise RuntimeError("EncodeAhead.launch(parts='points'): launch this batch's camera part (parts='img') first")
+        if self.pending is not None and parts != "points":
             raise RuntimeError("EncodeAhead.launch: the previous batch was never taken")
         dev = data.pose_feats.device
         if self.stream is None or self.stream.device != dev:

@@ -197,6 +197,15 @@ class Workload:
             self.logits = False
         self.model.run_dead_knn = not args.no_dead_knn
         self.model.single_stream = True
+        # The discarded k-NN + GAT block on the library's side stream (forked where x[l] exists, joined at the end of forward):
+        # with the encoders inside forward this only adds jitter (A/B round 5: 4.48 vs 4.50 ms; PoseGNN 0.946 vs 0.963), but in the
+        # encode-ahead step -- where the forward shares the GPU with ResNetAE only -- taking its 190 us off the launch stream's chain
+        # is worth 2.9 % (4.18 -> 4.06 ms, two rounds on one box); postponing the join to the end of backward loses most of it again
+        # (4.13).  B3D_KNN_SIDE=0 / 1 / 2 overrides.
+        knn_side = os.environ.get("B3D_KNN_SIDE", "1" if (kind == "clr" and encoders == "frozen" and getattr(args, "encode_ahead", False)) else "0")
+        if knn_side != "0":
+            self.model.single_stream = False
+            self.model.defer_knn_join = knn_side == "2"
         self.model.train()
         self.opt = make_optimizer(self.model, capturable=True)   # Adam(lr 1e-4, wd 1e-4, betas .9/.999): train.py:106-109
         self.force_collective = bool(getattr(args, "force_collective", False))
@@ -538,15 +547,21 @@ def measure(wl: Workload, args, world, dist, steps, warmup, ramp_ms, use_graph):
     # Warm-up doubles as the instrumented pass: every kernel family is timed with HIP event pairs (diagnostic
     # table) and the family with the largest device time is picked; the TIMED region carries no event pairs.
     trace(f"{wl.kind}/{wl.encoders}: warm-up")
+    # The instrumented warm-up steps run SERIALLY (encoders inside forward): with encode-ahead two streams share the GPU and a
+    # launch's duration is no longer the kernel's own -- the family with the most device time must be picked from undisturbed
+    # durations (the first split-placement run picked the node backward, inflated by the point stacks running beside it).  Two
+    # un-instrumented steps in the timed form follow, so that everything the capture replays has run eagerly once.
     _lib.prof_enable(True)
     for i in range(warmup):
-        wl.step(i)
+        wl.step_serial(i)
     torch.cuda.synchronize()
-    trace("warm-up done")
-    # (with encode-ahead the warm-up table is taken with two streams sharing the GPU: diagnostic only; `kernels` / `roofline`
-    # come from the serial pass behind the timed region)
     fam_all = _lib.prof_read() if warmup > 0 else None
     _lib.prof_enable(False)
+    if getattr(wl, "ahead", None) is not None:
+        for i in range(2):
+            wl.step(i)
+        torch.cuda.synchronize()
+    trace("warm-up done")
     graphs, graph_note, opt_graph = None, None, None
     # N > 1: graph A (forward + backward) | eager all-reduce | graph B (optimizer); --force-collective: the same at N = 1
     split = world > 1 or bool(getattr(wl, "force_collective", False))

@@ -9,6 +9,9 @@ def main():
     path, steps = sys.argv[1], int(sys.argv[2])
     top = int(sys.argv[3]) if len(sys.argv) > 3 else 60
     rows = list(csv.DictReader(open(path)))
+    if steps <= 0:                      # one graph build per executed step: count the steps from it
+        steps = max(int(r["Calls"]) for r in rows if "graph_convert_count" in r["Name"])
+        print(f"(steps executed, from the graph-build launches: {steps})")
     own, other, oneoff = [], [], []
     for r in rows:
         name, calls, total = r["Name"], int(r["Calls"]), float(r["TotalDurationNs"]) / 1e3
