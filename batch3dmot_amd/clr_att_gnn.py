@@ -582,20 +582,29 @@ class GNN(nn.Module):
         with torch.no_grad():
             return self.resnet.encode(data.img_feats).float().contiguous()
 
-    def _encode_points(self, data, rows):
-        """The LiDAR / radar part of ``_encode`` alone (current stream): the sticky ``.eval()`` switch of an encoder that sees fewer
-        than two rows (clr_att_gnn.py:128-130,136-138), PointNet, RadarNet, the int32 row ids."""
-        lidar_nodes, radar_nodes = rows if rows is not None else self.modality_rows(data)
+    def _encode_lidar(self, data, lidar_nodes):
+        """The LiDAR part of ``_encode`` alone (current stream): the sticky ``.eval()`` switch of an encoder that sees fewer than two
+        rows (clr_att_gnn.py:128-130), PointNet, the int32 row ids."""
         with torch.no_grad():
             if lidar_nodes.numel() < 2:
                 self.pointnet.eval()
                 self.fc_lidar_encoder.eval()
-            pointnet_out = self.pointnet.forward_feat(data.lidar_feats[lidar_nodes].view(-1, 3, 128)).float().contiguous()
+            out = self.pointnet.forward_feat(data.lidar_feats[lidar_nodes].view(-1, 3, 128)).float().contiguous()
+            return out, lidar_nodes.to(torch.int32).contiguous()
+
+    def _encode_radar(self, data, radar_nodes):
+        """The radar part of ``_encode`` alone (clr_att_gnn.py:136-139)."""
+        with torch.no_grad():
             if radar_nodes.numel() < 2:
                 self.radarnet.eval()
                 self.fc_radar_encoder.eval()
-            radarnet_out = self.radarnet.forward_feat(data.radar_feats[radar_nodes].view(-1, 4, 64)).float().contiguous()
-            return pointnet_out, lidar_nodes.to(torch.int32).contiguous(), radarnet_out, radar_nodes.to(torch.int32).contiguous()
+            out = self.radarnet.forward_feat(data.radar_feats[radar_nodes].view(-1, 4, 64)).float().contiguous()
+            return out, radar_nodes.to(torch.int32).contiguous()
+
+    def _encode_points(self, data, rows):
+        """LiDAR then radar (the reference's call order: pointnet.py's Dropout draws before radarnet.py's)."""
+        lidar_nodes, radar_nodes = rows if rows is not None else self.modality_rows(data)
+        return self._encode_lidar(data, lidar_nodes) + self._encode_radar(data, radar_nodes)
 
     def _encode_cached(self, data, cache: "EmbeddingCache", node_ids):
         if node_ids is None:

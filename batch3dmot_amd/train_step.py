@@ -154,16 +154,19 @@ class EncodeAhead:
         self.stream = None
         self.pending = None
 
+    _SLOTS = {"img": (0,), "lidar": (1, 2), "radar": (3, 4), "points": (1, 2, 3, 4), "all": (0, 1, 2, 3, 4)}
+
     def launch(self, data, rows=None, static=None, parts: str = "all"):
-        """``parts``: "all" (default), or "img" followed -- later in the step -- by "points" for the same batch: the camera encoder
-        and the two point encoders enqueued at different places of the current step (``bench.py``: ResNetAE under the forward,
-        PointNet / RadarNet under the backward sweep)."""
-        if parts not in ("all", "img", "points"):
+        """``parts``: "all" (default), or several calls for the same batch at different places of the current step -- "img"
+        (ResNetAE), "lidar" (PointNet), "radar" (RadarNet), "points" (= lidar + radar).  The parts may be launched in any order
+        EXCEPT that "lidar" must precede "radar" when Dropout is live (the reference draws PointNet's mask first); ``take`` needs all."""
+        if parts not in self._SLOTS:
             raise ValueError(f"EncodeAhead.launch: parts = {parts!r}")
-        if parts == "points" and (self.pending is None or self.pending[0] is not data or self.pending[3] != "img"):
-            raise RuntimeError("EncodeAhead.launch(parts='points'): launch this batch's camera part (parts='img') first")
-        if self.pending is not None and parts != "points":
-            raise RuntimeError("EncodeAhead.launch: the previous batch was never taken")
+        if self.pending is not None and (self.pending[0] is not data or parts == "all" or any(k in self.pending[1] for k in self._SLOTS[parts])):
+            raise RuntimeError("EncodeAhead.launch: the previous batch was never taken (or this part of the batch was launched already)")
+        if parts == "radar" and not (self.pending is not None and 1 in self.pending[1]) \
+                and self.gnn.radarnet.training and self.gnn.pointnet.training and self.gnn.pointnet.dropout.p > 0:
+            raise RuntimeError("EncodeAhead.launch(parts='radar') in front of 'lidar': the Dropout masks would be drawn in the other order")
         dev = data.pose_feats.device
         if self.stream is None or self.stream.device != dev:
             self.stream = torch.cuda.Stream(dev)
@@ -177,34 +180,39 @@ class EncodeAhead:
             with torch.cuda.stream(self.stream):
                 if parts == "all":
                     out = list(self.gnn.encode_modalities(data, rows=rows))
-                    lo = 0
                 elif parts == "img":
-                    out, lo = [self.gnn._encode_img(data)], 0
+                    out = [self.gnn._encode_img(data)]
+                elif parts == "lidar":
+                    out = list(self.gnn._encode_lidar(data, rows[0]))
+                elif parts == "radar":
+                    out = list(self.gnn._encode_radar(data, rows[1]))
                 else:
-                    out, lo = list(self.gnn._encode_points(data, rows)), 1
+                    out = list(self.gnn._encode_points(data, rows))
+                slots = self._SLOTS[parts]
                 if static is not None:
-                    for dst, src in zip(static[lo:lo + len(out)], out):
+                    for k, src in zip(slots, out):
+                        dst = static[k]
                         if dst.shape != src.shape:
                             raise ValueError(f"EncodeAhead: static buffer {tuple(dst.shape)} vs encoder output {tuple(src.shape)}")
                         dst.copy_(src)
-                    out = list(static[lo:lo + len(out)])
+                    out = [static[k] for k in slots]
                 if rows is not None and not torch.cuda.is_current_stream_capturing():
                     for t in rows:
                         t.record_stream(self.stream)          # produced elsewhere, read by this stream's gathers
         finally:
             self.gnn.encoder_streams = keep
-        if parts == "points":
-            out = self.pending[1] + out
-        self.pending = (data, out, static is not None, parts)
+        have = dict(self.pending[1]) if self.pending is not None else {}
+        have.update(zip(slots, out))
+        self.pending = (data, have, static is not None)
         return tuple(out)
 
     def take(self, data):
         if self.pending is None or self.pending[0] is not data:
             raise RuntimeError("EncodeAhead.take: this batch was not the one launched")
-        if self.pending[3] == "img":
-            raise RuntimeError("EncodeAhead.take: only the camera part of this batch was launched")
-        _, out, is_static, _ = self.pending
-        out = tuple(out)
+        _, have, is_static = self.pending
+        if len(have) != 5:
+            raise RuntimeError(f"EncodeAhead.take: only parts {sorted(have)} of this batch were launched")
+        out = tuple(have[k] for k in range(5))
         self.pending = None
         cur = torch.cuda.current_stream(data.pose_feats.device)
         cur.wait_stream(self.stream)

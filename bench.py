@@ -298,6 +298,12 @@ class Workload:
         elif where == "split":
             launch("img")
             ret = run(i, {"encoded": self.enc_static[k]}, lambda: launch("points"))
+        elif where == "split3":          # experiment: ResNetAE + PointNet under the forward, RadarNet under the backward sweep
+            launch("img"); launch("lidar")
+            ret = run(i, {"encoded": self.enc_static[k]}, lambda: launch("radar"))
+        elif where == "split4":          # experiment: PointNet under the forward, ResNetAE + RadarNet under the backward sweep
+            launch("lidar")
+            ret = run(i, {"encoded": self.enc_static[k]}, lambda: (launch("img"), launch("radar")))
         else:
             launch()
             ret = run(i, {"encoded": self.enc_static[k]})
