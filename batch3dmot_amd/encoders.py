@@ -325,6 +325,23 @@ def _draw_dropout_mask(b: int, n: int, p: float, dev) -> torch.Tensor:
     return F.dropout(torch.ones(b, n, dtype=torch.float32, device=dev), p, True)
 
 
+# Dropout masks drawn AHEAD of the launch that uses them, keyed by the nn.Dropout module: train_step.EncodeAhead enqueues RadarNet in
+# front of PointNet when that fills the step better, and the generator must still be drawn from in the reference's order (PointNet's
+# mask first, pointnet.py:190, then RadarNet's, radarnet.py:62).
+_PREDRAWN: dict = {}
+
+
+def predraw_dropout_mask(dropout: nn.Dropout, b: int, n: int, dev) -> None:
+    """Draw the [b, n] mask ``dropout`` will need NOW (current stream, torch's generator) and park it for the next ``fc_head_hip``
+    stage that uses this module; nothing happens in eval mode or for p = 0."""
+    if dropout.training and dropout.p > 0:
+        _PREDRAWN[id(dropout)] = _draw_dropout_mask(b, n, float(dropout.p), dev)
+
+
+def discard_predrawn_masks() -> None:
+    _PREDRAWN.clear()
+
+
 def fc_head_hip(owner: nn.Module, x: torch.Tensor, stages, final_relu: bool = True, in_affine=None):
     """A chain of Linear (+ BatchNorm1d + ReLU) stages on [B, K] rows, one HIP launch per Linear (``b3d_fc_bn_forward``):
     every launch applies the PREVIOUS stage's BatchNorm + ReLU while it reads its input, multiplies an optional Dropout
@@ -368,7 +385,9 @@ def fc_head_hip(owner: nn.Module, x: torch.Tensor, stages, final_relu: bool = Tr
             train = bool(bn.training) if bn is not None else False
             mask = None
             if dropout is not None and dropout.training and dropout.p > 0:
-                mask = _draw_dropout_mask(b, n, float(dropout.p), dev)
+                mask = _PREDRAWN.pop(id(dropout), None)
+                if mask is None or tuple(mask.shape) != (b, n) or mask.device != dev:
+                    mask = _draw_dropout_mask(b, n, float(dropout.p), dev)
             y = torch.empty(b, n, dtype=torch.float32, device=dev)
             sc = torch.empty(n, dtype=torch.float32, device=dev) if bn is not None else None
             sh = torch.empty(n, dtype=torch.float32, device=dev) if bn is not None else None

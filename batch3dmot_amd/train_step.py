@@ -158,15 +158,13 @@ class EncodeAhead:
 
     def launch(self, data, rows=None, static=None, parts: str = "all"):
         """``parts``: "all" (default), or several calls for the same batch at different places of the current step -- "img"
-        (ResNetAE), "lidar" (PointNet), "radar" (RadarNet), "points" (= lidar + radar).  The parts may be launched in any order
-        EXCEPT that "lidar" must precede "radar" when Dropout is live (the reference draws PointNet's mask first); ``take`` needs all."""
+        (ResNetAE), "lidar" (PointNet), "radar" (RadarNet), "points" (= lidar + radar), in any order; ``take`` needs all of them.
+        When "radar" comes in front of "lidar" with Dropout live, PointNet's mask is drawn first and parked
+        (``encoders.predraw_dropout_mask``): the generator is drawn from in the reference's order whatever the launch order."""
         if parts not in self._SLOTS:
             raise ValueError(f"EncodeAhead.launch: parts = {parts!r}")
         if self.pending is not None and (self.pending[0] is not data or parts == "all" or any(k in self.pending[1] for k in self._SLOTS[parts])):
             raise RuntimeError("EncodeAhead.launch: the previous batch was never taken (or this part of the batch was launched already)")
-        if parts == "radar" and not (self.pending is not None and 1 in self.pending[1]) \
-                and self.gnn.radarnet.training and self.gnn.pointnet.training and self.gnn.pointnet.dropout.p > 0:
-            raise RuntimeError("EncodeAhead.launch(parts='radar') in front of 'lidar': the Dropout masks would be drawn in the other order")
         dev = data.pose_feats.device
         if self.stream is None or self.stream.device != dev:
             self.stream = torch.cuda.Stream(dev)
@@ -185,6 +183,10 @@ class EncodeAhead:
                 elif parts == "lidar":
                     out = list(self.gnn._encode_lidar(data, rows[0]))
                 elif parts == "radar":
+                    if not (self.pending is not None and 1 in self.pending[1]) and rows[0].numel() >= 2:
+                        from . import encoders
+                        pn = self.gnn.pointnet            # its fc2 Dropout acts on [lidar rows, 256] (pointnet.py:190)
+                        encoders.predraw_dropout_mask(pn.dropout, int(rows[0].numel()), pn.fc2.out_features, dev)
                     out = list(self.gnn._encode_radar(data, rows[1]))
                 else:
                     out = list(self.gnn._encode_points(data, rows))

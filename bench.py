@@ -298,6 +298,9 @@ class Workload:
         elif where == "split":
             launch("img")
             ret = run(i, {"encoded": self.enc_static[k]}, lambda: launch("points"))
+        elif where == "split5":          # experiment: ResNetAE + RadarNet under the forward, PointNet under the backward sweep
+            launch("img"); launch("radar")
+            ret = run(i, {"encoded": self.enc_static[k]}, lambda: launch("lidar"))
         elif where == "split3":          # experiment: ResNetAE + PointNet under the forward, RadarNet under the backward sweep
             launch("img"); launch("lidar")
             ret = run(i, {"encoded": self.enc_static[k]}, lambda: launch("radar"))

@@ -258,6 +258,10 @@ def test_encode_ahead_equals_the_sequential_loop_bitwise():
                     if pipelined == "split":             # bench.py's placement: camera under the forward, point encoders under the backward
                         ahead.launch(nxt, parts="img")
                         hook = lambda nxt=nxt: ahead.launch(nxt, parts="points")      # noqa: E731
+                    elif pipelined == "radar_first":     # RadarNet launched in front of PointNet: PointNet's Dropout mask is pre-drawn
+                        ahead.launch(nxt, parts="img")
+                        ahead.launch(nxt, parts="radar")
+                        hook = lambda nxt=nxt: ahead.launch(nxt, parts="lidar")       # noqa: E731
                     else:
                         ahead.launch(nxt)
             loss, _, _ = train_step(m, b, opt, batch_size=2, loss_kind="cb", logits=False, forward_kwargs=kw, after_forward=hook)
@@ -266,7 +270,7 @@ def test_encode_ahead_equals_the_sequential_loop_bitwise():
         return losses, {k: v.detach().clone() for k, v in m.state_dict().items()}
 
     l_seq, s_seq = run(False)
-    for form in (True, "split"):
+    for form in (True, "split", "radar_first"):
         l_pipe, s_pipe = run(form)
         assert l_seq == l_pipe, form
         for k in s_seq:
