@@ -577,28 +577,39 @@ class GNN(nn.Module):
             cur.wait_stream(side)
         return (x_img, pointnet_out, lidar_i32, radarnet_out, radar_i32), ready
 
-    def _encode_img(self, data):
-        """The camera part of ``_encode`` alone (current stream)."""
+    def _encode_img(self, data, out=None):
+        """The camera part of ``_encode`` alone (current stream).  ``out``: a static [N, 96] buffer to write into (HIP encoders)."""
         with torch.no_grad():
+            if out is not None and data.img_feats.is_cuda and getattr(self.resnet, "use_hip", True) and hasattr(self.resnet, "encode") \
+                    and "out" in self.resnet.encode.__code__.co_varnames and data.img_feats.size(0) > 0:
+                return self.resnet.encode(data.img_feats, out=out)
             return self.resnet.encode(data.img_feats).float().contiguous()
 
-    def _encode_lidar(self, data, lidar_nodes):
+    @staticmethod
+    def _feat(enc, x, out):
+        """``enc.forward_feat(x)``, written into ``out`` where the encoder can (the HIP heads of ``batch3dmot_amd.encoders``)."""
+        if out is not None and x.is_cuda and x.size(0) > 0 and getattr(enc, "use_hip", True) \
+                and "out" in enc.forward_feat.__code__.co_varnames and tuple(out.shape) == (x.size(0), 256):
+            return enc.forward_feat(x, out=out)
+        return enc.forward_feat(x).float().contiguous()
+
+    def _encode_lidar(self, data, lidar_nodes, out=None):
         """The LiDAR part of ``_encode`` alone (current stream): the sticky ``.eval()`` switch of an encoder that sees fewer than two
         rows (clr_att_gnn.py:128-130), PointNet, the int32 row ids."""
         with torch.no_grad():
             if lidar_nodes.numel() < 2:
                 self.pointnet.eval()
                 self.fc_lidar_encoder.eval()
-            out = self.pointnet.forward_feat(data.lidar_feats[lidar_nodes].view(-1, 3, 128)).float().contiguous()
+            out = self._feat(self.pointnet, data.lidar_feats[lidar_nodes].view(-1, 3, 128), out)
             return out, lidar_nodes.to(torch.int32).contiguous()
 
-    def _encode_radar(self, data, radar_nodes):
+    def _encode_radar(self, data, radar_nodes, out=None):
         """The radar part of ``_encode`` alone (clr_att_gnn.py:136-139)."""
         with torch.no_grad():
             if radar_nodes.numel() < 2:
                 self.radarnet.eval()
                 self.fc_radar_encoder.eval()
-            out = self.radarnet.forward_feat(data.radar_feats[radar_nodes].view(-1, 4, 64)).float().contiguous()
+            out = self._feat(self.radarnet, data.radar_feats[radar_nodes].view(-1, 4, 64), out)
             return out, radar_nodes.to(torch.int32).contiguous()
 
     def _encode_points(self, data, rows):

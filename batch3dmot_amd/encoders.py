@@ -342,7 +342,33 @@ def discard_predrawn_masks() -> None:
     _PREDRAWN.clear()
 
 
-def fc_head_hip(owner: nn.Module, x: torch.Tensor, stages, final_relu: bool = True, in_affine=None):
+def _fc_workspace(owner: nn.Module, nbytes: int, dev) -> torch.Tensor:
+    """Workspace of ``b3d_fc_bn_forward`` for ``owner``'s head: zero-filled ONCE per (module, power-of-two size bucket, device) and
+    kept for the life of the module -- the launches leave the arrival counters zero, the rest is overwritten by every call.  A
+    bucket is never freed or replaced (hipGraphs captured earlier keep writing to it on replay: a buffer that was swapped for a
+    larger one used to be freed under them), and never CREATED inside a stream capture (its zero fill would be captured instead
+    of executed): there, and for the first call of a new size while capturing, the call gets a fresh zero-filled tensor."""
+    bucket = 1 << max(12, int(nbytes - 1).bit_length())
+    cache = owner.__dict__.setdefault("_b3d_fc_ws", {})
+    t = cache.get((bucket, str(dev)))
+    if t is None:
+        t = torch.zeros(bucket, dtype=torch.uint8, device=dev)
+        if not torch.cuda.is_current_stream_capturing():
+            cache[(bucket, str(dev))] = t
+    return t
+
+
+def _identity9(owner: nn.Module, dev) -> torch.Tensor:
+    """The flattened 3 x 3 identity STN3d adds to its last Linear (pointnet.py:53-56), built once per (module, device)."""
+    t = owner.__dict__.get("_b3d_iden")
+    if t is None or t.device != dev:
+        t = torch.eye(3, dtype=torch.float32, device=dev).view(9).contiguous()
+        if not torch.cuda.is_current_stream_capturing():
+            owner.__dict__["_b3d_iden"] = t
+    return t
+
+
+def fc_head_hip(owner: nn.Module, x: torch.Tensor, stages, final_relu: bool = True, in_affine=None, out=None):
     """A chain of Linear (+ BatchNorm1d + ReLU) stages on [B, K] rows, one HIP launch per Linear (``b3d_fc_bn_forward``):
     every launch applies the PREVIOUS stage's BatchNorm + ReLU while it reads its input, multiplies an optional Dropout
     mask into its output and accumulates the batch statistics its own BatchNorm needs -- BatchNorm / ReLU / Dropout
@@ -360,14 +386,11 @@ def fc_head_hip(owner: nn.Module, x: torch.Tensor, stages, final_relu: bool = Tr
     b = x.size(0)
     dev = x.device
     stream = _lib.current_stream(dev)
-    # Scratch of the chain (arrival counter + per-row-tile partial statistics).  The counter must be zero on entry and
-    # every launch leaves it zero; it is nevertheless a fresh zero-filled tensor PER CALL: a buffer cached on the module
-    # and replaced when a larger batch arrives is freed while hipGraphs captured earlier still write to it on replay
-    # (found as memory faults of a two-rank run whose first large batch arrived inside a capture), and its zero fill
-    # would be captured, not executed, for the graphs that use it next.
+    # Scratch of the chain (arrival counters + per-row-tile partial statistics).  The counters must be zero on entry and every launch
+    # leaves them zero (_fc_workspace): one zero fill per (module, size bucket) for the life of the process, not one per call.
     nmax = max(fc.out_features for fc, _, _, _ in stages)
     nbytes = lib.b3d_fc_bn_workspace_bytes(b, nmax)
-    ws = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+    ws = _fc_workspace(owner, nbytes, dev)
     keep = []
     in_scale = in_shift = None
     in_relu = 1
@@ -402,7 +425,10 @@ def fc_head_hip(owner: nn.Module, x: torch.Tensor, stages, final_relu: bool = Tr
         if in_scale is not None:                     # the last stage had a BatchNorm: materialise relu(bn(y))
             if not final_relu:
                 raise ValueError("fc head: a trailing BatchNorm without ReLU is not a shape of these encoders")
-            out = torch.empty_like(cur)
+            if out is None:
+                out = torch.empty_like(cur)
+            elif out.shape != cur.shape or out.dtype != torch.float32 or not out.is_contiguous() or out.device != cur.device:
+                raise ValueError(f"fc head: out must be a contiguous float32 {tuple(cur.shape)} tensor on {cur.device}")
             _lib.check(lib.b3d_affine_relu(cur.data_ptr(), in_scale.data_ptr(), in_shift.data_ptr(), b, cur.size(1), out.data_ptr(), stream),
                        "b3d_affine_relu")
             cur = out
@@ -435,7 +461,7 @@ def _fc_blocker(module: nn.Module, x: torch.Tensor, bns):
     return _autograd_blocker(module, x)
 
 
-def resnet_encode_hip(m: "ResNetAE", x: torch.Tensor) -> torch.Tensor:
+def resnet_encode_hip(m: "ResNetAE", x: torch.Tensor, out=None) -> torch.Tensor:
     """``ResNetAE.encode`` in six HIP phase kernels (``b3d_resnet_encode``): direct convolutions with the producer's
     BatchNorm / residual add / ReLU applied while the next phase stages its input; in train mode the batch statistics
     are accumulated by the producing phase and the running statistics updated as ``nn.BatchNorm2d`` does.  No autograd
@@ -479,7 +505,10 @@ def resnet_encode_hip(m: "ResNetAE", x: torch.Tensor) -> torch.Tensor:
             raise ValueError("resnet_encode_hip: eval mode needs running statistics")
         bl[i].momentum = float(bn.momentum) if bn.momentum is not None else -1.0
         bl[i].eps = float(bn.eps)
-    out = torch.empty(n, 96, dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty(n, 96, dtype=torch.float32, device=x.device)
+    elif tuple(out.shape) != (n, 96) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != x.device:
+        raise ValueError(f"resnet_encode_hip: out must be a contiguous float32 [{n}, 96] tensor on {x.device}")
     nbytes = lib.b3d_resnet_encode_workspace_bytes(n)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     _lib.check(lib.b3d_resnet_encode(cl, bl, x.data_ptr(), n, int(train), ws.data_ptr(), nbytes, out.data_ptr(),
@@ -540,7 +569,8 @@ class ResNetAE(nn.Module):
             nn.ConvTranspose2d(24, 12, 4, stride=2, padding=1), nn.ReLU(),
             nn.ConvTranspose2d(12, 3, 4, stride=2, padding=1), nn.Sigmoid())
 
-    def encode(self, x):
+    def encode(self, x, out=None):
+        """``out`` (HIP path only): a [N, 96] float32 tensor the embedding is written to."""
         why = None
         if x.dim() == 4 and _empty(self, x, 96) is not None:
             return _empty(self, x, 96)
@@ -553,7 +583,7 @@ class ResNetAE(nn.Module):
         elif not self.training:
             why = _autograd_blocker(self, x)
         if _route(self, "resnet.encode", x, why):
-            return resnet_encode_hip(self, x)
+            return resnet_encode_hip(self, x, out=out)
         out = self.res_block3(self.res_block2(self.res_block1(self.conv(x))))
         return out.view(out.size(0), -1)
 
@@ -583,7 +613,7 @@ class _STN3d(nn.Module):
             x = F.relu(self.bn3(self.conv3(x)))
             x = torch.max(x, 2, keepdim=True)[0].view(-1, 1024)
         if _route(self, "stn.fc", x, _fc_blocker(self, x, (self.bn4, self.bn5))):
-            iden = torch.eye(3, dtype=torch.float32, device=x.device).view(9)
+            iden = _identity9(self, x.device)
             x = fc_head_hip(self, x, [(self.fc1, self.bn4, None, None), (self.fc2, self.bn5, None, None), (self.fc3, None, None, iden)],
                             in_affine=affine)
             return x.view(-1, 3, 3)
@@ -633,12 +663,14 @@ class PointNetClassifier(nn.Module):
         self.dropout = nn.Dropout(p=0.3)
         self.bn1, self.bn2 = nn.BatchNorm1d(512), nn.BatchNorm1d(256)
 
-    def forward_feat(self, x):
+    def forward_feat(self, x, out=None):
+        """``out`` (HIP path only): a [B, 256] float32 tensor the result is written to (a static buffer of a captured step)."""
         if _empty(self, x, 256) is not None:
             return _empty(self, x, 256)
         x, affine = self.feat.forward_parts(x)
         if _route(self, "pointnet.fc", x, _fc_blocker(self, x, (self.bn1, self.bn2))):
-            return fc_head_hip(self, x, [(self.fc1, self.bn1, None, None), (self.fc2, self.bn2, self.dropout, None)], in_affine=affine)
+            return fc_head_hip(self, x, [(self.fc1, self.bn1, None, None), (self.fc2, self.bn2, self.dropout, None)], in_affine=affine,
+                               out=out)
         x = _materialize(x, affine)
         x = F.relu(_fc_bn(self.fc1, self.bn1, x))
         if not _fold_on(self.bn2):
@@ -678,12 +710,14 @@ class RadarNetClassifier(nn.Module):
         self.dropout = nn.Dropout(p=0.3)
         self.bn1, self.bn2 = nn.BatchNorm1d(512), nn.BatchNorm1d(256)
 
-    def forward_feat(self, x):
+    def forward_feat(self, x, out=None):
+        """``out``: as ``PointNetClassifier.forward_feat``."""
         if _empty(self, x, 256) is not None:
             return _empty(self, x, 256)
         x, affine = self.feat.forward_parts(x)
         if _route(self, "radarnet.fc", x, _fc_blocker(self, x, (self.bn1, self.bn2))):
-            return fc_head_hip(self, x, [(self.fc1, self.bn1, None, None), (self.fc2, self.bn2, self.dropout, None)], in_affine=affine)
+            return fc_head_hip(self, x, [(self.fc1, self.bn1, None, None), (self.fc2, self.bn2, self.dropout, None)], in_affine=affine,
+                               out=out)
         x = _materialize(x, affine)
         x = F.relu(_fc_bn(self.fc1, self.bn1, x))
         if not _fold_on(self.bn2):

@@ -176,27 +176,30 @@ class EncodeAhead:
         self.gnn.encoder_streams = False                     # one branch: no forks inside the side stream
         try:
             with torch.cuda.stream(self.stream):
+                st = static if static is not None else (None,) * 5       # the big outputs go straight into their static buffers
                 if parts == "all":
-                    out = list(self.gnn.encode_modalities(data, rows=rows))
+                    out = [self.gnn._encode_img(data, out=st[0])] + list(self.gnn._encode_lidar(data, rows[0], out=st[1])) \
+                        + list(self.gnn._encode_radar(data, rows[1], out=st[3]))
                 elif parts == "img":
-                    out = [self.gnn._encode_img(data)]
+                    out = [self.gnn._encode_img(data, out=st[0])]
                 elif parts == "lidar":
-                    out = list(self.gnn._encode_lidar(data, rows[0]))
+                    out = list(self.gnn._encode_lidar(data, rows[0], out=st[1]))
                 elif parts == "radar":
                     if not (self.pending is not None and 1 in self.pending[1]) and rows[0].numel() >= 2:
                         from . import encoders
                         pn = self.gnn.pointnet            # its fc2 Dropout acts on [lidar rows, 256] (pointnet.py:190)
                         encoders.predraw_dropout_mask(pn.dropout, int(rows[0].numel()), pn.fc2.out_features, dev)
-                    out = list(self.gnn._encode_radar(data, rows[1]))
+                    out = list(self.gnn._encode_radar(data, rows[1], out=st[3]))
                 else:
-                    out = list(self.gnn._encode_points(data, rows))
+                    out = list(self.gnn._encode_lidar(data, rows[0], out=st[1])) + list(self.gnn._encode_radar(data, rows[1], out=st[3]))
                 slots = self._SLOTS[parts]
                 if static is not None:
                     for k, src in zip(slots, out):
                         dst = static[k]
                         if dst.shape != src.shape:
                             raise ValueError(f"EncodeAhead: static buffer {tuple(dst.shape)} vs encoder output {tuple(src.shape)}")
-                        dst.copy_(src)
+                        if src.data_ptr() != dst.data_ptr():
+                            dst.copy_(src)
                     out = [static[k] for k in slots]
                 if rows is not None and not torch.cuda.is_current_stream_capturing():
                     for t in rows:
