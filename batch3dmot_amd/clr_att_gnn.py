@@ -580,16 +580,16 @@ class GNN(nn.Module):
     def _encode_img(self, data, out=None):
         """The camera part of ``_encode`` alone (current stream).  ``out``: a static [N, 96] buffer to write into (HIP encoders)."""
         with torch.no_grad():
-            if out is not None and data.img_feats.is_cuda and getattr(self.resnet, "use_hip", True) and hasattr(self.resnet, "encode") \
-                    and "out" in self.resnet.encode.__code__.co_varnames and data.img_feats.size(0) > 0:
+            if out is not None and data.img_feats.is_cuda and data.img_feats.size(0) > 0 and getattr(self.resnet, "use_hip", True) \
+                    and getattr(self.resnet, "supports_out", False):
                 return self.resnet.encode(data.img_feats, out=out)
             return self.resnet.encode(data.img_feats).float().contiguous()
 
     @staticmethod
     def _feat(enc, x, out):
         """``enc.forward_feat(x)``, written into ``out`` where the encoder can (the HIP heads of ``batch3dmot_amd.encoders``)."""
-        if out is not None and x.is_cuda and x.size(0) > 0 and getattr(enc, "use_hip", True) \
-                and "out" in enc.forward_feat.__code__.co_varnames and tuple(out.shape) == (x.size(0), 256):
+        if out is not None and x.is_cuda and x.size(0) > 0 and getattr(enc, "use_hip", True) and getattr(enc, "supports_out", False) \
+                and tuple(out.shape) == (x.size(0), 256):
             return enc.forward_feat(x, out=out)
         return enc.forward_feat(x).float().contiguous()
 

@@ -551,6 +551,8 @@ def _down(cin, cout, k, s):
 
 
 class ResNetAE(nn.Module):
+    supports_out = True          # encode(x, out=...): the HIP path can write into a caller's buffer (clr_att_gnn.GNN._encode_img)
+
     def __init__(self):
         super().__init__()
         self.conv = nn.Conv2d(3, 12, kernel_size=4, stride=2, padding=1)
@@ -654,6 +656,8 @@ class _PointNetFeat(nn.Module):
 
 
 class PointNetClassifier(nn.Module):
+    supports_out = True          # forward_feat(x, out=...)
+
     def __init__(self, k=7, feature_transform=False):
         super().__init__()
         if feature_transform:
@@ -703,6 +707,8 @@ class _RadarNetFeat(nn.Module):
 
 
 class RadarNetClassifier(nn.Module):
+    supports_out = True          # forward_feat(x, out=...)
+
     def __init__(self, k=2, feature_transform=False):
         super().__init__()
         self.feat = _RadarNetFeat()
