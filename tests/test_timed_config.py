@@ -276,3 +276,37 @@ def test_encode_ahead_equals_the_sequential_loop_bitwise():
         for k in s_seq:
             assert torch.equal(s_seq[k], s_pipe[k]), (form, k)
     assert len({round(x, 6) for x in l_seq}) == 4             # four different batches, four losses
+
+
+def test_encode_ahead_parts_are_checked():
+    """EncodeAhead.launch(parts=...): a batch cannot be taken before all of its parts were launched, a part cannot be launched twice,
+    and the next batch cannot start before the previous one was taken."""
+    from batch3dmot_amd import encoders, synth
+    from batch3dmot_amd.clr_att_gnn import GNN
+    from batch3dmot_amd.train_step import EncodeAhead
+    dev = torch.device("cuda:0")
+    a, b = (synth.make_batch(2, 60, 300, first_graph_idx=900 + 2 * i, modalities=True).to(dev) for i in range(2))
+    m = GNN(encoders.ResNetAE(), encoders.PointNetClassifier(k=7), encoders.RadarNetClassifier(k=7)).to(dev).eval()
+    ahead = EncodeAhead(m)
+    with pytest.raises(ValueError):
+        ahead.launch(a, parts="everything")
+    ahead.launch(a, parts="img")
+    with pytest.raises(RuntimeError, match="only parts"):
+        ahead.take(a)
+    with pytest.raises(RuntimeError):
+        ahead.launch(a, parts="img")                      # twice
+    with pytest.raises(RuntimeError):
+        ahead.launch(b, parts="img")                      # the previous batch was never taken
+    ahead.launch(a, parts="radar")
+    ahead.launch(a, parts="lidar")
+    got = ahead.take(a)
+    with torch.no_grad():
+        want = m.encode_modalities(a)
+    torch.cuda.synchronize()
+    assert len(got) == 5
+    for x, y in zip(got, want):
+        assert torch.equal(x, y)
+    with pytest.raises(RuntimeError):
+        ahead.take(a)                                     # nothing pending
+    ahead.launch(b)                                       # ... and the next batch goes through as a whole
+    assert len(ahead.take(b)) == 5
