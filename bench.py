@@ -615,10 +615,17 @@ def measure(wl: Workload, args, world, dist, steps, warmup, ramp_ms, use_graph):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     marks[0].record()
+    t_each = []
     for i in range(steps):
+        t1 = time.perf_counter()
         timed_step(warmup + i)
         marks[i + 1].record()
-    t_enqueue = time.perf_counter() - t0          # host time to enqueue the K steps (diagnostic)
+        t_each.append(time.perf_counter() - t1)
+    # Host time to enqueue the K steps (diagnostic).  Once ~40-80 ms of work are in flight hipGraphLaunch BLOCKS until the GPU has
+    # retired a step (tools/host_graph_node_cost.py: the host's lead is the same after 40 and after 240 replays), so the mean over
+    # a long loop is the GPU's rate, not the host's cost: the first calls after the synchronize show what a step costs the host.
+    t_enqueue = time.perf_counter() - t0
+    t_first = sorted(t_each[:4])[len(t_each[:4]) // 2] if t_each else 0.0
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -660,7 +667,7 @@ def measure(wl: Workload, args, world, dist, steps, warmup, ramp_ms, use_graph):
     # vs 24.1 us by rocprofv3 with an 11.3 us empty pair, profiles/r02_a_*)
     pair_us = 0.5 * _lib.prof_pair_overhead_us(torch.cuda.current_stream(dev).cuda_stream)
     my_edges = sum(wl.edges[(warmup + i) % pool_n] for i in range(steps))
-    return {"dt": dt, "edges": my_edges, "t_enqueue": t_enqueue, "fam_all": fam_all, "fam": fam, "dom": dom,
+    return {"dt": dt, "edges": my_edges, "t_enqueue": t_enqueue, "t_first": t_first, "fam_all": fam_all, "fam": fam, "dom": dom,
             "graphs": graphs is not None, "graph_note": graph_note, "ramp_steps": ramp_steps, "pair_us": pair_us,
             "step_ms": step_ms, "loss_check": lc}
 
@@ -966,6 +973,7 @@ def main():
                 "kernels": kernels, "kernels_instrumented_warmup": kernels_warmup,
                 "library_sha16": lib_sha16(),
                 "untimed_clock_ramp_steps": m["ramp_steps"], "host_enqueue_ms_per_step": round(1e3 * m["t_enqueue"] / args.steps, 4),
+                "host_enqueue_ms_first_steps_median": round(1e3 * m.get("t_first", 0.0), 4),
                 "timed_region": ("hipGraph replay (one captured training step per pool batch"
                                  + (": forward + backward graph, eager flat all-reduce, optimizer graph" if (world > 1 or args.force_collective) else "")
                                  + ("; the modality masks + row compaction run eagerly in front of each replay and feed it" if wl.rows_static is not None else "")

@@ -18,14 +18,18 @@ def timed(name, fn, steps):
     for i in range(8):
         fn(i)
     torch.cuda.synchronize()
+    each = []
     t0 = time.perf_counter()
     for i in range(steps):
+        t1 = time.perf_counter()
         fn(i)
+        each.append(time.perf_counter() - t1)
     enq = time.perf_counter() - t0
     torch.cuda.synchronize()
     tot = time.perf_counter() - t0
-    print(f"{name:70s} steps {steps:4d}  host {1e3 * enq / steps:7.3f} ms/replay  wall {1e3 * tot / steps:7.3f} ms/replay  "
-          f"host lead at the end {1e3 * (tot - enq):7.2f} ms", flush=True)
+    first, last = sorted(each[:8])[4], sorted(each[-8:])[4]
+    print(f"{name:58s} steps {steps:4d}  host {1e3 * enq / steps:7.3f} ms/replay (median of the first 8: {1e3 * first:6.3f}, of the last 8: "
+          f"{1e3 * last:6.3f})  wall {1e3 * tot / steps:7.3f} ms/replay  host lead at the end {1e3 * (tot - enq):7.2f} ms", flush=True)
 
 
 def tiny_graph(n, branches):
