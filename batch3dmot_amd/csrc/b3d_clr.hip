@@ -134,6 +134,7 @@ struct Ws {
   float *A[4], *att;                 // att_edge_encoder hidden [E,512/384/256/128], output [E,64]
   float *x[16], *e[16];
   float *sH1[16], *sH2[16], *sF1[16], *sP1[16], *M[16], *nH1[16], *nH2[16];
+  float* rmask[16];       // ReLU masks of sH1 | sH2 | sF1 | sP1 (b3d_estream.hpp: 128 bytes per edge and layer)
   float *fut, *past, *c_a1, *c_a2, *c_a3, *prob;
   // backward scratch
   float *de[2], *da_acc, *gdst, *gsrc, *dx0_acc;
@@ -412,6 +413,7 @@ static void carve(Ws& w, void* ws, size_t ws_bytes, int N, int E, int nl, int nr
       for (int l = 0; l < depth; ++l) arr[l] = b ? b + (size_t)l * per : nullptr;
     };
     per_layer(w.sH1, e_ * D::EH1); per_layer(w.sH2, e_ * D::EH2); per_layer(w.sF1, e_ * D::MH); per_layer(w.sP1, e_ * D::MH);
+    per_layer(w.rmask, e_ * es::kMaskFloatsPerRow);
     per_layer(w.M, n_ * D::NIN); per_layer(w.nH1, n_ * D::NH1); per_layer(w.nH2, n_ * D::NH2);
     w.c_a1 = c.take<float>(e_ * 32); w.c_a2 = c.take<float>(e_ * 16); w.c_a3 = c.take<float>(e_ * 16);
     w.de[0] = c.take<float>(e_ * D::DE); w.de[1] = c.take<float>(e_ * D::DE);
@@ -858,6 +860,7 @@ extern "C" int b3d_clr_forward(const b3d_clr_weights* pw, const b3d_graph* g, co
     ea.E = E; ea.src = g->src; ea.dst = g->dst; ea.T = w.T; ea.e_in = w.e[l]; ea.a_in = w.att;
     ea.e_out = w.e[l + 1]; ea.fut = w.fut; ea.past = w.past;
     ea.sH1 = w.sH1[l]; ea.sH2 = w.sH2[l]; ea.sF1 = w.sF1[l]; ea.sP1 = w.sP1[l]; ea.wpack = w.wp_efwd2;
+    ea.rmask = reinterpret_cast<unsigned*>(w.rmask[l]); ea.rmask2 = ea.rmask ? ea.rmask + edge_rows(E) * 16 : nullptr;
     if (tr) B3D_TRY(launch_es(es::edge_fwd_kernel<DB, true>, "edge_fwd", ea, E, stream, B3D_K_EDGE_FWD, ES::Fwd::LDS_BYTES));
     else B3D_TRY(launch_es(es::edge_fwd_kernel<DB, false>, "edge_fwd", ea, E, stream, B3D_K_EDGE_FWD, ES::Fwd::LDS_BYTES));
     if (l + 1 < depth) {                                   // + the per-node table the next layer's edge phase gathers
@@ -958,6 +961,7 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
     eb.dM = msgs ? w.dM + l * nLm : nullptr;
     eb.de_out = w.de[cur]; eb.de_in = w.de[cur ^ 1];
     eb.sH1 = w.sH1[l]; eb.sH2 = w.sH2[l]; eb.sF1 = w.sF1[l]; eb.sP1 = w.sP1[l];
+    eb.rmask = reinterpret_cast<const unsigned*>(w.rmask[l]); eb.rmask2 = eb.rmask + edge_rows(E) * 16;
     eb.da_acc = w.da_acc; eb.da_first = da_first ? 1 : 0;
     eb.GdH1 = w.GdH1 + l * eL1; eb.GdH2 = w.GdH2 + l * eL2; eb.Gde = w.Gde + l * eLe;
     eb.GdF1 = w.GdF1 + l * eLm; eb.GdP1 = w.GdP1 + l * eLm;
@@ -1220,6 +1224,7 @@ struct ClrLayerWs {
   float *wp_proj0, *wp_efwd2, *wp_nfwd, *wp_ebwd2, *wp_gproj, *wp_nbwd;
   float *T, *T0, *e_out, *fut, *past;
   float *sH1, *sH2, *sF1, *sP1, *M, *nH1, *nH2;
+  float* rmask;
   float *dM, *GdH1, *GdH2, *Gde, *GdF1, *GdP1, *GnH2, *GnH1, *dT, *gx, *de_in, *da, *zero_e, *zero_n;
   float* zrow;
   int* iota;
@@ -1247,6 +1252,7 @@ static void carve_layer(ClrLayerWs& w, void* ws, size_t ws_bytes, int N, int E, 
     w.wp_gproj = c.take<float>(HC::GradProjSeq::TOTAL_FLOATS);
     w.wp_nbwd = c.take<float>(D::NodeBwdSeq::TOTAL_FLOATS);
     w.sH1 = c.take<float>(e_ * D::EH1); w.sH2 = c.take<float>(e_ * D::EH2); w.sF1 = c.take<float>(e_ * D::MH); w.sP1 = c.take<float>(e_ * D::MH);
+    w.rmask = c.take<float>(e_ * es::kMaskFloatsPerRow);
     w.M = c.take<float>(n_ * D::NIN); w.nH1 = c.take<float>(n_ * D::NH1); w.nH2 = c.take<float>(n_ * D::NH2);
     w.dM = c.take<float>(n_ * D::NIN);
     w.GdH1 = c.take<float>(e_ * D::EH1); w.GdH2 = c.take<float>(e_ * D::EH2); w.Gde = c.take<float>(e_ * D::DE);
@@ -1367,6 +1373,7 @@ extern "C" int b3d_clr_layer_forward(const b3d_mp_weights* mw, const b3d_graph* 
   ea.E = E; ea.src = g->src; ea.dst = g->dst; ea.T = w.T; ea.e_in = e; ea.a_in = att;
   ea.e_out = w.e_out; ea.fut = w.fut; ea.past = w.past;
   ea.sH1 = w.sH1; ea.sH2 = w.sH2; ea.sF1 = w.sF1; ea.sP1 = w.sP1; ea.wpack = w.wp_efwd2;
+  ea.rmask = reinterpret_cast<unsigned*>(w.rmask); ea.rmask2 = ea.rmask ? ea.rmask + edge_rows(E) * 16 : nullptr;
   if (tr) B3D_TRY(launch_es(es::edge_fwd_kernel<DB, true>, "edge_fwd", ea, E, stream, B3D_K_EDGE_FWD, ES::Fwd::LDS_BYTES));
   else B3D_TRY(launch_es(es::edge_fwd_kernel<DB, false>, "edge_fwd", ea, E, stream, B3D_K_EDGE_FWD, ES::Fwd::LDS_BYTES));
   B3D_HIP_CHECK(hipMemcpyAsync(e_new, w.e_out, (size_t)E * D::DE * sizeof(float), hipMemcpyDeviceToDevice, stream));
@@ -1404,6 +1411,7 @@ extern "C" int b3d_clr_layer_backward(const b3d_mp_weights* mw, const b3d_graph*
   eb.E = E; eb.src = g->src; eb.dst = g->dst; eb.dM = w.dM;
   eb.de_out = d_e_new; eb.de_in = w.de_in;
   eb.sH1 = w.sH1; eb.sH2 = w.sH2; eb.sF1 = w.sF1; eb.sP1 = w.sP1;
+  eb.rmask = reinterpret_cast<const unsigned*>(w.rmask); eb.rmask2 = eb.rmask + edge_rows(E) * 16;
   eb.da_acc = w.da; eb.da_first = 1;
   eb.GdH1 = w.GdH1; eb.GdH2 = w.GdH2; eb.Gde = w.Gde; eb.GdF1 = w.GdF1; eb.GdP1 = w.GdP1;
   eb.wpack = w.wp_ebwd2;

@@ -36,12 +36,12 @@ struct FwdHooks {
   using S = typename EdgeSeqs<D>::Fwd;
   __host__ __device__ static constexpr int before(int ci) {
     constexpr int H1B = D::EH1 / 16, H2B = D::EH2 / 16, EB = D::DE / 16, MHB = D::MH / 16, DMB = D::DM / 16, SV = TRAIN ? 1 : 0;
-    return kRB * (ci == S::first_chunk(1) ? SV * H1B + MHB          // sH1 store, T[dst] future rows
-                : ci == S::first_chunk(2) ? SV * H2B + MHB          // sH2 store, T[src] past rows
+    return kRB * (ci == S::first_chunk(1) ? SV * (H1B + 1) + MHB    // sH1 + its mask store, T[dst] future rows
+                : ci == S::first_chunk(2) ? SV * (H2B + 1) + MHB    // sH2 + mask store, T[src] past rows
                 : ci == S::first_chunk(3) ? EB                      // e' store
-                : ci == S::first_chunk(4) ? SV * MHB                // sF1 store
+                : ci == S::first_chunk(4) ? SV * (MHB + 1)          // sF1 + mask store
                 : ci == S::first_chunk(5) ? DMB                     // fut store
-                : ci == S::first_chunk(6) ? SV * MHB : 0);          // sP1 store
+                : ci == S::first_chunk(6) ? SV * (MHB + 1) : 0);    // sP1 + mask store
   }
 };
 
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(kWaves * 64, kWgPerCu) void edge_fwd_kernel(const E
       split_blocks<EB + AB>(ein, x0);
       layer<S, 0, true, false, true>(ring, more, st, x0, h1);
     }
-    if constexpr (TRAIN) store_rows<H1B>(a.sH1, row, D::EH1, h1);
+    if constexpr (TRAIN) { store_rows<H1B>(a.sH1, row, D::EH1, h1); store_masks<H1B, 0>(a.rmask, row, h1); }
     v4f fi[kRB][MHB];
     load_rows<MHB>(a.T, d, H::TW, H::OF, fi);
     v4f h2[kRB][H2B];
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(kWaves * 64, kWgPerCu) void edge_fwd_kernel(const E
       split_blocks<H1B>(h1, x1);
       layer<S, 1, true, true, false>(ring, more, st, x1, h2);
     }
-    if constexpr (TRAIN) store_rows<H2B>(a.sH2, row, D::EH2, h2);
+    if constexpr (TRAIN) { store_rows<H2B>(a.sH2, row, D::EH2, h2); store_masks<H2B, 2>(a.rmask, row, h2); }
     v4f pi[kRB][MHB];
     load_rows<MHB>(a.T, s, H::TW, H::OP, pi);
     v4f en[kRB][EB];
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(kWaves * 64, kWgPerCu) void edge_fwd_kernel(const E
     split_blocks<EB>(en, xe);
     // ---- create_future_msgs ----
     layer<S, 3, true, false, true>(ring, more, st, xe, fi);
-    if constexpr (TRAIN) store_rows<MHB>(a.sF1, row, D::MH, fi);
+    if constexpr (TRAIN) { store_rows<MHB>(a.sF1, row, D::MH, fi); store_masks<MHB, 0>(a.rmask2, row, fi); }
     {
       v4f mo[kRB][DMB];
       Bf3 x4[kRB][MHB / 2];
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(kWaves * 64, kWgPerCu) void edge_fwd_kernel(const E
     }
     // ---- create_past_msgs ----
     layer<S, 5, true, false, true>(ring, more, st, xe, pi);
-    if constexpr (TRAIN) store_rows<MHB>(a.sP1, row, D::MH, pi);
+    if constexpr (TRAIN) { store_rows<MHB>(a.sP1, row, D::MH, pi); store_masks<MHB, 2>(a.rmask2, row, pi); }
     {
       v4f mo[kRB][DMB];
       Bf3 x6[kRB][MHB / 2];
@@ -150,12 +150,11 @@ struct BwdHooks {
     constexpr int H1B = D::EH1 / 16, H2B = D::EH2 / 16, EB = D::DE / 16, AB = D::DA / 16, MHB = D::MH / 16;
     if (MSGS)
       return kRB * (ci == S::first_chunk(1) ? MHB + D::DM / 16        // GdP1 store, dM[src] load
-                  : ci == S::first_chunk(2) ? MHB                     // sF1 load (behind layer 1: its registers are free then)
-                  : ci == S::first_chunk(3) ? MHB + H2B               // GdF1 store, sH2 load
+                  : ci == S::first_chunk(3) ? MHB + 1                 // GdF1 store, mask plane A load
                   : ci == S::first_chunk(4) ? EB                      // Gde store
-                  : ci == S::first_chunk(5) ? H2B + H1B               // GdH2 store, sH1 load (a layer ahead of its use)
+                  : ci == S::first_chunk(5) ? H2B                     // GdH2 store
                   : ci == S::first_chunk(6) ? H1B + AB : 0);          // GdH1 store, running d att load
-    return kRB * (ci == S::first_chunk(1) ? H2B + H1B : ci == S::first_chunk(2) ? H1B + AB : 0);    // GdH2 store + sH1 load; GdH1 store + d att load
+    return kRB * (ci == S::first_chunk(1) ? H2B : ci == S::first_chunk(2) ? H1B + AB : 0);    // GdH2 store; GdH1 store + d att load
   }
 };
 
@@ -186,21 +185,22 @@ __global__ __launch_bounds__(kWaves * 64, kWgPerCu) void edge_bwd_kernel(const E
     }
     v4f de[kRB][EB];
     load_rows<EB>(a.de_out, rc, D::DE, 0, de);
-    v4f act2[kRB][H2B], act1[kRB][H1B];
+    u4v mka[kRB], mkb[kRB];                                    // the forward's ReLU masks of this lane's values (128 bytes per edge)
+    if constexpr (MSGS) load_mask_plane(a.rmask2, rc, mkb);    // sF1 | sP1
+    else load_mask_plane(a.rmask, rc, mka);                    // sH1 | sH2 (MSGS: behind the message layers)
     if constexpr (MSGS) {
       unsigned s[kRB], d[kRB];
 #pragma unroll
       for (int rb = 0; rb < kRB; ++rb) { s[rb] = (unsigned)a.src[rc[rb]]; d[rb] = (unsigned)a.dst[rc[rb]]; }
-      v4f dmp[kRB][DMB], dmf[kRB][DMB], actp[kRB][MHB], actf[kRB][MHB];
+      v4f dmp[kRB][DMB], dmf[kRB][DMB];
       load_rows<DMB>(a.dM, d, 2 * D::DM, 0, dmp);             // past messages were summed at dst
-      load_rows<MHB>(a.sP1, rc, D::MH, 0, actp);
       v4f dh[kRB][MHB], dee[kRB][EB];
       {
         Bf3 x0[kRB][DMB / 2];
         split_blocks<DMB>(dmp, x0);
         layer<S, 0, false, false, false>(ring, more, st, x0, dh);
       }
-      relu_bwd_blocks<MHB>(dh, actp);
+      relu_bwd_mask<MHB, 2>(dh, mkb);
       store_rows<MHB>(a.GdP1, row, D::MH, dh);
       load_rows<DMB>(a.dM, s, 2 * D::DM, D::DM, dmf);         // future messages were summed at src (needed a layer from here)
       {
@@ -208,7 +208,6 @@ __global__ __launch_bounds__(kWaves * 64, kWgPerCu) void edge_bwd_kernel(const E
         split_blocks<MHB>(dh, x1);
         layer<S, 1, false, false, false>(ring, more, st, x1, dee);
       }
-      load_rows<MHB>(a.sF1, rc, D::MH, 0, actf);
 #pragma unroll
       for (int rb = 0; rb < kRB; ++rb)
 #pragma unroll
@@ -218,9 +217,9 @@ __global__ __launch_bounds__(kWaves * 64, kWgPerCu) void edge_bwd_kernel(const E
         split_blocks<DMB>(dmf, x2);
         layer<S, 2, false, false, false>(ring, more, st, x2, dh);
       }
-      relu_bwd_blocks<MHB>(dh, actf);
+      relu_bwd_mask<MHB, 0>(dh, mkb);
       store_rows<MHB>(a.GdF1, row, D::MH, dh);
-      load_rows<H2B>(a.sH2, rc, D::EH2, 0, act2);
+      load_mask_plane(a.rmask, rc, mka);
       {
         Bf3 x3[kRB][MHB / 2];
         split_blocks<MHB>(dh, x3);
@@ -232,7 +231,6 @@ __global__ __launch_bounds__(kWaves * 64, kWgPerCu) void edge_bwd_kernel(const E
         for (int b = 0; b < EB; ++b) de[rb][b] += dee[rb][b];
       store_rows<EB>(a.Gde, row, D::DE, de);
     } else {
-      load_rows<H2B>(a.sH2, rc, D::EH2, 0, act2);
       store_rows<EB>(a.Gde, row, D::DE, de);
     }
     v4f d2[kRB][H2B], d1[kRB][H1B], dein[kRB][EB + AB];
@@ -241,15 +239,14 @@ __global__ __launch_bounds__(kWaves * 64, kWgPerCu) void edge_bwd_kernel(const E
       split_blocks<EB>(de, x4);
       layer<S, L0 + 0, false, false, false>(ring, more, st, x4, d2);
     }
-    relu_bwd_blocks<H2B>(d2, act2);
+    relu_bwd_mask<H2B, 2>(d2, mka);
     store_rows<H2B>(a.GdH2, row, D::EH2, d2);
-    load_rows<H1B>(a.sH1, rc, D::EH1, 0, act1);             // needed behind the next layer (128 registers: not earlier)
     {
       Bf3 x5[kRB][H2B / 2];
       split_blocks<H2B>(d2, x5);
       layer<S, L0 + 1, false, false, false>(ring, more, st, x5, d1);
     }
-    relu_bwd_blocks<H1B>(d1, act1);
+    relu_bwd_mask<H1B, 0>(d1, mka);
     store_rows<H1B>(a.GdH1, row, D::EH1, d1);
     v4f prev[kRB][AB];
     load_rows<AB>(a.da_acc, rc, D::DA, 0, prev);

@@ -176,12 +176,38 @@ struct Ring {
 // ---- steps ---------------------------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) const u4v* lds_u4v_p;
 typedef __attribute__((address_space(3))) const v4f* lds_v4f_p;
+typedef unsigned u2w __attribute__((ext_vector_type(2)));
+#ifndef B3D_ES_F16
+#define B3D_ES_F16 0
+#endif
+typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+typedef float f2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ Bf3 frag_load(unsigned addr) {          // addr: this lane's 16 bytes of piece 0 of a 16 x 32 block
   Bf3 f;
   f.p0 = __builtin_bit_cast(bf8, *(lds_u4v_p)(size_t)addr);
   f.p1 = __builtin_bit_cast(bf8, *(lds_u4v_p)(size_t)(addr + 1024));
+#if B3D_ES_F16
+  f.p2 = f.p1;
+#else
   f.p2 = __builtin_bit_cast(bf8, *(lds_u4v_p)(size_t)(addr + 2048));
+#endif
   return f;
+}
+// EXPERIMENT (B3D_ES_F16): two fp16 pieces (round-to-nearest value + the fp16 of its exact residual), three products
+__device__ __forceinline__ Bf3 f16_split(const v4f a, const v4f b) {
+  const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  u4v q0, q1;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    const f2v v = {x[2 * d], x[2 * d + 1]};
+    const h2v hi = __builtin_convertvector(v, h2v);
+    const f2v r = v - __builtin_convertvector(hi, f2v);
+    const h2v lo = __builtin_convertvector(r, h2v);
+    q0[d] = __builtin_bit_cast(unsigned, hi);
+    q1[d] = __builtin_bit_cast(unsigned, lo);
+  }
+  return Bf3{__builtin_bit_cast(bf8, q0), __builtin_bit_cast(bf8, q1), __builtin_bit_cast(bf8, q1)};
 }
 __device__ __forceinline__ void frag_load2(unsigned addr, Bf3& f0, Bf3& f1) { f0 = frag_load(addr); f1 = frag_load(addr + 3072); }
 // 2 kRB independent chains (output blocks 2 p, 2 p + 1 x the wavefront's row blocks), interleaved; smallest terms first (as
@@ -193,7 +219,17 @@ __device__ __forceinline__ void mfma_step(const Bf3& w0, const Bf3& w1, const Bf
     a0[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0.WP, x[rb][ks].XP, a0[rb], 0, 0, 0);                   \
     a1[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1.WP, x[rb][ks].XP, a1[rb], 0, 0, 0);                   \
   }
+#if B3D_ES_F16
+#define B3D_ES_PRODH(WP, XP)                                                                                  \
+  _Pragma("unroll") for (int rb = 0; rb < kRB; ++rb) {                                                         \
+    a0[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8v, w0.WP), __builtin_bit_cast(h8v, x[rb][ks].XP), a0[rb], 0, 0, 0);  \
+    a1[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8v, w1.WP), __builtin_bit_cast(h8v, x[rb][ks].XP), a1[rb], 0, 0, 0);  \
+  }
+  B3D_ES_PRODH(p0, p1) B3D_ES_PRODH(p1, p0) B3D_ES_PRODH(p0, p0)
+#undef B3D_ES_PRODH
+#else
   B3D_ES_PROD(p0, p2) B3D_ES_PROD(p1, p1) B3D_ES_PROD(p2, p0) B3D_ES_PROD(p0, p1) B3D_ES_PROD(p1, p0) B3D_ES_PROD(p0, p0)
+#endif
 #undef B3D_ES_PROD
 }
 
@@ -263,7 +299,13 @@ __device__ __forceinline__ void split_blocks(const v4f (&a)[kRB][NB], Bf3 (&x)[k
 #pragma unroll
   for (int rb = 0; rb < kRB; ++rb)
 #pragma unroll
-    for (int c = 0; c < NB / 2; ++c) x[rb][c] = bf_split(a[rb][2 * c], a[rb][2 * c + 1]);
+    for (int c = 0; c < NB / 2; ++c) {
+#if B3D_ES_F16
+      x[rb][c] = f16_split(a[rb][2 * c], a[rb][2 * c + 1]);
+#else
+      x[rb][c] = bf_split(a[rb][2 * c], a[rb][2 * c + 1]);
+#endif
+    }
 }
 // Row tables are addressed as (uniform base pointer) + (32-bit byte offset): one VGPR per row and table, and hipcc selects
 // the saddr form of global_load / global_store (no 64-bit address arithmetic, no address pairs to keep alive).  Unconditional.
@@ -291,6 +333,77 @@ __device__ __forceinline__ void relu_bwd_blocks(v4f (&g)[kRB][NB], const v4f (&a
       g[rb][b].y = act[rb][b].y > 0.f ? g[rb][b].y : 0.f;
       g[rb][b].z = act[rb][b].z > 0.f ? g[rb][b].z : 0.f;
       g[rb][b].w = act[rb][b].w > 0.f ? g[rb][b].w : 0.f;
+    }
+}
+// ---- ReLU masks (round 5) ---------------------------------------------------------------------------------------------------
+// The backward sweep needs of the saved hidden activations only their SIGN pattern (relu'); reading sH1 | sH2 | sF1 | sP1 back
+// cost 3 KB per edge and layer and up to 64 registers per wavefront.  The forward writes, next to the activations (the weight
+// gradient still consumes those), one bit per value: 128 bytes per edge in two planes of 16 bytes per lane (row m, quarter q),
+// both addressed like a 16-float row table ((row * 4 + q) * 16 bytes: no new loop-invariant address register) --
+//   plane A: words 0..1 sH1 (16 blocks), word 2 sH2 (8 blocks);   plane B: words 0..1 sF1 (12 blocks), words 2..3 sP1 (12 blocks);
+// bit 31 - (4 (b & 7) + j) of word b / 8 <-> component j of the lane's block b, set iff the value is > 0 (the test the backward
+// made on the activation itself: -0 and 0 are not).
+constexpr int kMaskFloatsPerRow = 32;                       // both planes
+struct MaskPlanes { unsigned* a; unsigned* b; };
+struct MaskPlanesC { const unsigned* a; const unsigned* b; };
+__device__ __forceinline__ unsigned push_positive(unsigned acc, float v) {
+  float t;
+  asm("v_sub_f32 %0, 0, %1" : "=v"(t) : "v"(v));                   // sign set iff v > 0 (0 - (-0) = +0); not foldable to a negation
+  return __builtin_amdgcn_alignbit(acc, __float_as_uint(t), 31);   // (acc << 1) | sign
+}
+template <int NB>
+__device__ __forceinline__ void relu_mask_words(const v4f (&h)[NB], unsigned (&w)[(NB + 7) / 8]) {
+#pragma unroll
+  for (int wi = 0; wi < (NB + 7) / 8; ++wi) {
+    constexpr int B1 = 8;
+    const int b1 = NB < 8 * wi + B1 ? NB : 8 * wi + B1;
+    unsigned acc = 0u;
+#pragma unroll
+    for (int b = 8 * wi; b < b1; ++b) {                     // first value ends up in the highest bit
+      acc = push_positive(acc, h[b].x); acc = push_positive(acc, h[b].y);
+      acc = push_positive(acc, h[b].z); acc = push_positive(acc, h[b].w);
+    }
+    w[wi] = acc << (32 - 4 * (b1 - 8 * wi));
+  }
+}
+// words [WORD0, WORD0 + ceil(NB / 8)) of the lane's 16 bytes in `plane`
+template <int NB, int WORD0>
+__device__ __forceinline__ void store_masks(unsigned* __restrict__ plane, const unsigned (&row)[kRB], const v4f (&h)[kRB][NB]) {
+  static_assert((NB + 7) / 8 <= 2 && WORD0 + (NB + 7) / 8 <= 4, "one or two words per tensor");
+  const unsigned q = (threadIdx.x & 63) >> 4;
+#pragma unroll
+  for (int rb = 0; rb < kRB; ++rb) {
+    unsigned w[(NB + 7) / 8];
+    relu_mask_words<NB>(h[rb], w);
+    char* p = reinterpret_cast<char*>(plane) + (row[rb] * 16u + 4u * q) * 4u + WORD0 * 4;
+    if constexpr ((NB + 7) / 8 == 2) *reinterpret_cast<u2w*>(p) = u2w{w[0], w[1]};
+    else *reinterpret_cast<unsigned*>(p) = w[0];
+  }
+}
+__device__ __forceinline__ void load_mask_plane(const unsigned* __restrict__ plane, const unsigned (&row)[kRB], u4v (&mk)[kRB]) {
+  const unsigned q = (threadIdx.x & 63) >> 4;
+#pragma unroll
+  for (int rb = 0; rb < kRB; ++rb) mk[rb] = *reinterpret_cast<const u4v*>(reinterpret_cast<const char*>(plane) + (row[rb] * 16u + 4u * q) * 4u);
+}
+// g = mask bit ? g : +0 (what relu_bwd_blocks computes from the activation).  The word is consumed from its highest bit: w + w
+// leaves the bit in the carry (VCC) and the select reads it -- two instructions per value as before, no temporaries (an
+// extract-and-mask form let the scheduler keep dozens of extracted bits alive: 256 registers and spills).
+__device__ __forceinline__ float keep_if_msb(unsigned& w, float g) {
+  asm("v_add_co_u32 %0, vcc, %0, %0\n\tv_cndmask_b32 %1, 0, %1, vcc" : "+v"(w), "+v"(g) : : "vcc");
+  return g;
+}
+template <int NB, int WORD0>
+__device__ __forceinline__ void relu_bwd_mask(v4f (&g)[kRB][NB], const u4v (&mk)[kRB]) {
+#pragma unroll
+  for (int rb = 0; rb < kRB; ++rb)
+#pragma unroll
+    for (int wi = 0; wi < (NB + 7) / 8; ++wi) {
+      unsigned w = mk[rb][WORD0 + wi];
+#pragma unroll
+      for (int b = 8 * wi; b < (NB < 8 * wi + 8 ? NB : 8 * wi + 8); ++b) {
+        g[rb][b].x = keep_if_msb(w, g[rb][b].x); g[rb][b].y = keep_if_msb(w, g[rb][b].y);
+        g[rb][b].z = keep_if_msb(w, g[rb][b].z); g[rb][b].w = keep_if_msb(w, g[rb][b].w);
+      }
     }
 }
 // the same row table access for every row block of the wavefront

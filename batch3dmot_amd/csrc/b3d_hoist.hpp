@@ -87,6 +87,8 @@ struct EdgeFwdHArgs {
   float* sF1;
   float* sP1;
   const float* wpack;  // Hoist::EdgeFwdSeq images
+  unsigned* rmask;     // es::edge_fwd_kernel<D, true> only: ReLU masks (b3d_estream.hpp), plane A: sH1 | sH2, 64 bytes per edge
+  unsigned* rmask2;    //   plane B: sF1 | sP1
 };
 
 template <class D, int NW>
@@ -239,6 +241,8 @@ struct EdgeBwdHArgs {
   float* GdF1;
   float* GdP1;
   const float* wpack;   // Hoist::EdgeBwdSeq / EdgeBwdSeqNoMsg images
+  const unsigned* rmask;   // es::edge_bwd_kernel only: the forward's ReLU masks (instead of reading sH1 .. sP1 back), planes A and B
+  const unsigned* rmask2;
 };
 
 // Data gradient of the edge phase without the node columns of the three first layers: those are

@@ -271,6 +271,12 @@ __global__ __launch_bounds__(256) void pack_frag_kernel(const FragArgs a) {
       const int j = 2 * jp + e;
       const int col = 32 * c + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3);
       const float x = d.transposed ? d.w[(size_t)col * d.ld + row] : d.w[(size_t)row * d.ld + col];
+#if defined(B3D_ES_F16) && B3D_ES_F16
+      const _Float16 hi = (_Float16)x;
+      const _Float16 lo = (_Float16)(x - (float)hi);
+      pc[0] |= (unsigned)__builtin_bit_cast(unsigned short, hi) << (16 * e);
+      pc[1] |= (unsigned)__builtin_bit_cast(unsigned short, lo) << (16 * e);
+#else
       const unsigned xb = __float_as_uint(x);
       const float r1 = x - __uint_as_float(xb & 0xffff0000u);
       const unsigned mb = __float_as_uint(r1);
@@ -278,6 +284,7 @@ __global__ __launch_bounds__(256) void pack_frag_kernel(const FragArgs a) {
       pc[0] |= (xb >> 16) << (16 * e);
       pc[1] |= (mb >> 16) << (16 * e);
       pc[2] |= (__float_as_uint(r2) >> 16) << (16 * e);
+#endif
     }
     const size_t o = (size_t)step * 1536 + half * 768 + lane * 4 + jp;     // dwords
 #pragma unroll
