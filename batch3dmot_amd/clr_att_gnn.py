@@ -55,16 +55,12 @@ def modality_present(feats: torch.Tensor) -> torch.Tensor:
     return has.bool()
 
 
-def modality_row_ids(feats: torch.Tensor) -> torch.Tensor:
-    """``torch.nonzero(modality_present(feats)).squeeze(1)`` (int64, ascending) from two HIP launches (``b3d_modality_rows``:
-    the presence mask, then a one-workgroup ballot / scan compaction).  The count is a shape: one read-back, on the
-    current stream."""
+def _modality_rows_enqueue(feats: torch.Tensor):
+    """The two launches of ``b3d_modality_rows`` on the current stream, nothing read back: (rows [n] int64, count [1] int32), or
+    None for an empty batch."""
     n = feats.size(0)
     if n == 0:                                        # empty batch: no rows (reshape(0, -1) cannot infer the width)
-        return torch.empty(0, dtype=torch.int64, device=feats.device)
-    if torch.cuda.is_current_stream_capturing():
-        raise RuntimeError("modality_row_ids reads the row count back to the host and cannot run inside a stream capture: "
-                           "pass rows=modality_rows(data) computed in front of it")
+        return None
     f = feats.reshape(n, -1).contiguous()
     _lib.require_cuda(f, "modality features", torch.float32)
     has = torch.empty(max(n, 1), dtype=torch.uint8, device=f.device)
@@ -72,7 +68,25 @@ def modality_row_ids(feats: torch.Tensor) -> torch.Tensor:
     count = torch.empty(1, dtype=torch.int32, device=f.device)
     _lib.check(_lib.load().b3d_modality_rows(f.data_ptr(), n, f.size(1), has.data_ptr(), rows.data_ptr(), count.data_ptr(),
                                              _lib.current_stream(f.device)), "b3d_modality_rows")
+    return rows, count
+
+
+def modality_row_ids(feats: torch.Tensor) -> torch.Tensor:
+    """``torch.nonzero(modality_present(feats)).squeeze(1)`` (int64, ascending) from two HIP launches (``b3d_modality_rows``:
+    the presence mask, then a one-workgroup ballot / scan compaction).  The count is a shape: one read-back, on the
+    current stream."""
+    if feats.size(0) == 0:
+        return torch.empty(0, dtype=torch.int64, device=feats.device)
+    if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("modality_row_ids reads the row count back to the host and cannot run inside a stream capture: "
+                           "pass rows=modality_rows(data) computed in front of it")
+    rows, count = _modality_rows_enqueue(feats)
     return rows[: int(count.item())]
+
+
+class PendingRows:
+    """Handle of ``GNN.modality_rows_begin``: the compactions are enqueued, their counts on their way to pinned host memory."""
+    __slots__ = ("parts", "host", "event", "stream", "device")
 
 
 def _param_list(m: "GNN") -> List[torch.Tensor]:
@@ -486,22 +500,55 @@ class GNN(nn.Module):
         waited for, so the caller's stream keeps its queue -- the host can enqueue step k+1 while step k runs.
         A batch from ``graph_data``'s prefetching loader carries the event of its H2D copy (``_b3d_ready_event``) and the
         side stream waits for it; for any other producer the caller guarantees that ``lidar_feats`` / ``radar_feats`` are
-        complete when this is called (resident inputs)."""
+        complete when this is called (resident inputs).
+
+        ``modality_rows_begin`` / ``modality_rows_end`` are the two halves: a loop that begins batch k + 1 BEFORE it launches
+        step k never waits for the counts (HIP multiplexes its streams onto four hardware queues: enqueued behind a running
+        step the side stream's launches wait for that step, and so does the host -- 50 us of idle GPU per step, round 5)."""
         lidar_feats, radar_feats = data.lidar_feats, data.radar_feats
-        ms = self.mask_stream
-        if ms is None or torch.cuda.is_current_stream_capturing():
+        if self.mask_stream is None or torch.cuda.is_current_stream_capturing() or not lidar_feats.is_cuda:
             return modality_row_ids(lidar_feats), modality_row_ids(radar_feats)
-        cur = torch.cuda.current_stream(lidar_feats.device)
+        return self.modality_rows_end(self.modality_rows_begin(data))
+
+    def modality_rows_begin(self, data) -> PendingRows:
+        """Enqueue the masks + compactions of ``data`` (on ``self.mask_stream`` if set) and the copy of the two counts to pinned
+        host memory; nothing waits.  ``modality_rows_end`` returns the row ids."""
+        lidar_feats, radar_feats = data.lidar_feats, data.radar_feats
+        dev = lidar_feats.device
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("modality_rows_begin reads row counts back to the host and cannot run inside a stream capture")
+        cur = torch.cuda.current_stream(dev)
+        ms = self.mask_stream if self.mask_stream is not None else cur
         ev = getattr(data, "_b3d_ready_event", None)      # set by graph_data's prefetching loader: the H2D copy of this batch
         if ev is not None:
             ms.wait_event(ev)
+        h = PendingRows()
+        h.stream, h.device = ms, dev
+        h.host = torch.zeros(2, dtype=torch.int32).pin_memory()
         with torch.cuda.stream(ms):
-            li = modality_row_ids(lidar_feats)      # the count read-back waits for `ms` only
-            ri = modality_row_ids(radar_feats)
-        cur.wait_stream(ms)
-        li.record_stream(cur)
-        ri.record_stream(cur)
-        return li, ri
+            h.parts = (_modality_rows_enqueue(lidar_feats), _modality_rows_enqueue(radar_feats))
+            for j, part in enumerate(h.parts):
+                if part is not None:
+                    h.host[j:j + 1].copy_(part[1], non_blocking=True)
+            h.event = torch.cuda.Event()
+            h.event.record(ms)
+        return h
+
+    def modality_rows_end(self, h: PendingRows):
+        """The row ids of a ``modality_rows_begin``: waits for ITS event only, then orders the caller's stream behind it."""
+        h.event.synchronize()
+        cur = torch.cuda.current_stream(h.device)
+        cur.wait_event(h.event)
+        out = []
+        for j, part in enumerate(h.parts):
+            if part is None:
+                out.append(torch.empty(0, dtype=torch.int64, device=h.device))
+                continue
+            t = part[0][: int(h.host[j])]
+            if h.stream is not cur:
+                t.record_stream(cur)
+            out.append(t)
+        return out[0], out[1]
 
     def encode_modalities(self, data, cache: "Optional[EmbeddingCache]" = None, node_ids=None, rows=None):
         """The frozen, adjacent part (clr_att_gnn.py:107-141): presence masks, ResNet / PointNet /

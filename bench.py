@@ -223,6 +223,7 @@ class Workload:
         self.rows_static = None
         self.ahead = None
         self.enc_static = None
+        self._pending = None
         if kind == "clr":
             rows = [self.model.modality_rows(b) for b in self.pool]
             self.nl = sum(int(r[0].numel()) for r in rows) / len(rows)
@@ -329,11 +330,19 @@ class Workload:
         return self._run(i, None)
 
     def pre(self, i):
+        """The eager prologue of step i: masks + compaction of ONE batch, every step.  Round 5: begun one step ahead -- the
+        launches of the batch step i + 1 needs are enqueued here, in front of replay i, and the counts of the batch THIS step needs
+        (begun in front of replay i - 1) are read and handed to the replay: the host never waits behind a running step
+        (GNN.modality_rows_begin / _end)."""
         if self.rows_static is None:
             return
-        # (measured in round 4: skipping this stage altogether does not change the step -- 4.72 ms either way -- it runs under the previous replay)
-        k = (i + (1 if self.ahead is not None else 0)) % len(self.pool)   # the batch whose encoders run in this step
-        li, ri = self.model.modality_rows(self.pool[k])           # masks + compaction, every step
+        shift = 1 if self.ahead is not None else 0                # the batch whose encoders run in this step
+        k, kn = (i + shift) % len(self.pool), (i + 1 + shift) % len(self.pool)
+        if self._pending is None or self._pending[0] != k:
+            self._pending = (k, self.model.modality_rows_begin(self.pool[k]))
+        nxt = (kn, self.model.modality_rows_begin(self.pool[kn]))
+        li, ri = self.model.modality_rows_end(self._pending[1])
+        self._pending = nxt
         sl, sr = self.rows_static[k]
         if li.numel() != sl.numel() or ri.numel() != sr.numel():
             raise RuntimeError("modality row counts changed under a captured step")
@@ -439,12 +448,20 @@ def capture(wl, split):
     return graphs, opt_graph
 
 
-def run_step(wl, graphs, opt_graph, split, i):
+_SKIP_PRE = os.environ.get("B3D_SKIP_PRE", "0") == "1"      # diagnostic only: the replay without its eager prologue (tools/)
+
+
+def run_step(wl, graphs, opt_graph, split, i, stamps=None):
     """Step i of the timed region: the eager part in front of the replay (`pre`), the replay(s), and at N > 1 the eager
     flat all-reduce between them; or the eager step when nothing was captured."""
     if graphs is not None:
-        wl.pre(i)
+        t0 = time.perf_counter()
+        if not _SKIP_PRE:
+            wl.pre(i)
+        t1 = time.perf_counter()
         graphs[i % len(wl.pool)].replay()
+        if stamps is not None:
+            stamps.append((t1 - t0, time.perf_counter() - t1))
         if split:
             # the flat gradient buffer was written by the replay
             wl.sync.sync(force=True, force_collective=getattr(wl, "force_collective", False))
@@ -588,8 +605,10 @@ def measure(wl: Workload, args, world, dist, steps, warmup, ramp_ms, use_graph):
                 graphs, opt_graph = None, None
                 graph_note = "hipGraph capture failed on another rank; eager timed region"
 
+    stamps = []
+
     def timed_step(i):
-        run_step(wl, graphs, opt_graph, split, i)
+        run_step(wl, graphs, opt_graph, split, i, stamps)
 
     # Clock ramp (untimed): a fresh box idles at ~550 MHz; keep the GPU busy until ramp_ms have passed, the same
     # number of steps on every rank (each holds a collective).
@@ -615,17 +634,17 @@ def measure(wl: Workload, args, world, dist, steps, warmup, ramp_ms, use_graph):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     marks[0].record()
-    t_each = []
+    del stamps[:]
     for i in range(steps):
-        t1 = time.perf_counter()
         timed_step(warmup + i)
         marks[i + 1].record()
-        t_each.append(time.perf_counter() - t1)
-    # Host time to enqueue the K steps (diagnostic).  Once ~40-80 ms of work are in flight hipGraphLaunch BLOCKS until the GPU has
-    # retired a step (tools/host_graph_node_cost.py: the host's lead is the same after 40 and after 240 replays), so the mean over
-    # a long loop is the GPU's rate, not the host's cost: the first calls after the synchronize show what a step costs the host.
+    # Host time to enqueue the K steps (diagnostic): the GPU's rate, not the host's cost -- the eager prologue reads the modality
+    # counts back (`.item()`: it returns when the mask kernels have run, and those queue behind the previous replay), and a bare
+    # replay loop blocks in hipGraphLaunch once 40-80 ms of work are queued (tools/host_graph_node_cost.py).  What a step COSTS the
+    # host is the launch call itself: the median over the timed steps is reported beside the loop mean.
     t_enqueue = time.perf_counter() - t0
-    t_first = sorted(t_each[:4])[len(t_each[:4]) // 2] if t_each else 0.0
+    t_first = sorted(s[1] for s in stamps)[len(stamps) // 2] if stamps else 0.0
+    t_pre = sorted(s[0] for s in stamps)[len(stamps) // 2] if stamps else 0.0
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -667,7 +686,7 @@ def measure(wl: Workload, args, world, dist, steps, warmup, ramp_ms, use_graph):
     # vs 24.1 us by rocprofv3 with an 11.3 us empty pair, profiles/r02_a_*)
     pair_us = 0.5 * _lib.prof_pair_overhead_us(torch.cuda.current_stream(dev).cuda_stream)
     my_edges = sum(wl.edges[(warmup + i) % pool_n] for i in range(steps))
-    return {"dt": dt, "edges": my_edges, "t_enqueue": t_enqueue, "t_first": t_first, "fam_all": fam_all, "fam": fam, "dom": dom,
+    return {"dt": dt, "edges": my_edges, "t_enqueue": t_enqueue, "t_first": t_first, "t_pre": t_pre, "fam_all": fam_all, "fam": fam, "dom": dom,
             "graphs": graphs is not None, "graph_note": graph_note, "ramp_steps": ramp_steps, "pair_us": pair_us,
             "step_ms": step_ms, "loss_check": lc}
 
@@ -973,7 +992,8 @@ def main():
                 "kernels": kernels, "kernels_instrumented_warmup": kernels_warmup,
                 "library_sha16": lib_sha16(),
                 "untimed_clock_ramp_steps": m["ramp_steps"], "host_enqueue_ms_per_step": round(1e3 * m["t_enqueue"] / args.steps, 4),
-                "host_enqueue_ms_first_steps_median": round(1e3 * m.get("t_first", 0.0), 4),
+                "host_graph_launch_ms_median": round(1e3 * m.get("t_first", 0.0), 4),
+                "host_prologue_ms_median": round(1e3 * m.get("t_pre", 0.0), 4),
                 "timed_region": ("hipGraph replay (one captured training step per pool batch"
                                  + (": forward + backward graph, eager flat all-reduce, optimizer graph" if (world > 1 or args.force_collective) else "")
                                  + ("; the modality masks + row compaction run eagerly in front of each replay and feed it" if wl.rows_static is not None else "")

@@ -115,6 +115,33 @@ def test_modality_masks_and_sticky_eval():
     assert not m.pointnet.training and not m.fc_lidar_encoder.training      # < 2 LiDAR rows (clr_att_gnn.py:128-130)
 
 
+def test_modality_rows_begin_end_pipelined():
+    """GNN.modality_rows_begin / _end: several batches begun ahead (with and without a side stream), ended in any order, give
+    torch.nonzero of the presence masks (clr_att_gnn.py:107-121) -- also for a batch without rows and for an empty batch."""
+    from batch3dmot_amd import synth
+    from batch3dmot_amd.clr_att_gnn import modality_present
+    dev = torch.device("cuda:0")
+    m = _model(3, dev)
+    batches = [synth.make_graph(300 + 40 * i, 2000, graph_idx=1500 + i, modalities=True).to(dev) for i in range(3)]
+    batches[1].radar_feats.zero_()                                  # no radar rows at all
+    empty = synth.make_graph(50, 200, graph_idx=1510, modalities=True).to(dev)
+    empty.lidar_feats = empty.lidar_feats[:0]
+    empty.radar_feats = empty.radar_feats[:0]
+    for stream in (None, torch.cuda.Stream(dev)):
+        m.mask_stream = stream
+        hs = [m.modality_rows_begin(b) for b in batches] + [m.modality_rows_begin(empty)]
+        for k in (2, 0, 3, 1):
+            li, ri = m.modality_rows_end(hs[k])
+            b = (batches + [empty])[k]
+            assert li.dtype == torch.int64 and ri.dtype == torch.int64
+            assert torch.equal(li, torch.nonzero(modality_present(b.lidar_feats)).squeeze(1))
+            assert torch.equal(ri, torch.nonzero(modality_present(b.radar_feats)).squeeze(1))
+        a, c = m.modality_rows(batches[0])                            # the one-call form is the two halves back to back
+        assert torch.equal(a, m.modality_rows_end(m.modality_rows_begin(batches[0]))[0]) and c.numel() > 0
+    assert m.modality_rows_end(m.modality_rows_begin(batches[1]))[1].numel() == 0
+    m.mask_stream = None
+
+
 def test_train_step_matches_reference():
     """H1 (train.py:124-160): loss, and every trainable weight after one Adam step."""
     from batch3dmot_amd.train_step import make_optimizer, train_step

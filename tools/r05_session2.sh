@@ -1,4 +1,4 @@
-TAG=r05_t
+TAG=${1:-r05_t}
 R=$PWD
 python -m pytest tests -m gpu -q > gpurun_out/${TAG}_gputest.log 2>&1; tail -3 gpurun_out/${TAG}_gputest.log
 python bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err; tail -c 200 gpurun_out/${TAG}_bench_default.json; echo
