@@ -614,6 +614,49 @@ __device__ __forceinline__ void relu_bwd(v4f* __restrict__ g, const v4f* __restr
   }
 }
 
+// ---- ReLU masks: one bit per saved hidden value (round 5) ----------------------------------------------------------------------
+// The backward sweep needs of a saved hidden activation only (value > 0).  The forward packs that bit for the lane's values of a
+// tensor into words (first value in the highest bit of word 0; 8 sixteen-feature blocks = 32 values per word); the backward consumes
+// a word from its top bit.  Two instructions per value on either side, as the compare + select on the activation itself.
+__device__ __forceinline__ unsigned push_positive(unsigned acc, float v) {
+  float t;
+  asm("v_sub_f32 %0, 0, %1" : "=v"(t) : "v"(v));                   // sign set iff v > 0 (0 - (-0) = +0); not foldable to a negation
+  return __builtin_amdgcn_alignbit(acc, __float_as_uint(t), 31);   // (acc << 1) | sign
+}
+template <int NB>
+__device__ __forceinline__ void relu_mask_words(const v4f (&h)[NB], unsigned (&w)[(NB + 7) / 8]) {
+#pragma unroll
+  for (int wi = 0; wi < (NB + 7) / 8; ++wi) {
+    const int b1 = NB < 8 * wi + 8 ? NB : 8 * wi + 8;
+    unsigned acc = 0u;
+#pragma unroll
+    for (int b = 8 * wi; b < b1; ++b) {
+      acc = push_positive(acc, h[b].x); acc = push_positive(acc, h[b].y);
+      acc = push_positive(acc, h[b].z); acc = push_positive(acc, h[b].w);
+    }
+    w[wi] = acc << (32 - 4 * (b1 - 8 * wi));
+  }
+}
+// g = top bit of w ? g : +0;  w <<= 1.  (w + w leaves the bit in the carry, the select reads it: no temporaries -- an
+// extract-and-mask form let the scheduler keep a tensor's worth of extracted bits alive: 256 registers and spills.)
+__device__ __forceinline__ float keep_if_msb(unsigned& w, float g) {
+  asm("v_add_co_u32 %0, vcc, %0, %0\n\tv_cndmask_b32 %1, 0, %1, vcc" : "+v"(w), "+v"(g) : : "vcc");
+  return g;
+}
+// the blocks [8 wi, 8 wi + 8) of g against word wi of a tensor's mask, for every word
+template <int NB>
+__device__ __forceinline__ void relu_bwd_words(v4f (&g)[NB], const unsigned* __restrict__ words) {
+#pragma unroll
+  for (int wi = 0; wi < (NB + 7) / 8; ++wi) {
+    unsigned w = words[wi];
+#pragma unroll
+    for (int b = 8 * wi; b < (NB < 8 * wi + 8 ? NB : 8 * wi + 8); ++b) {
+      g[b].x = keep_if_msb(w, g[b].x); g[b].y = keep_if_msb(w, g[b].y);
+      g[b].z = keep_if_msb(w, g[b].z); g[b].w = keep_if_msb(w, g[b].w);
+    }
+  }
+}
+
 template <int NBLK>
 __device__ __forceinline__ void add_blocks(v4f* __restrict__ a, const v4f* __restrict__ b) {
 #pragma unroll

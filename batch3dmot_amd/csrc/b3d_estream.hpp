@@ -346,26 +346,6 @@ __device__ __forceinline__ void relu_bwd_blocks(v4f (&g)[kRB][NB], const v4f (&a
 constexpr int kMaskFloatsPerRow = 32;                       // both planes
 struct MaskPlanes { unsigned* a; unsigned* b; };
 struct MaskPlanesC { const unsigned* a; const unsigned* b; };
-__device__ __forceinline__ unsigned push_positive(unsigned acc, float v) {
-  float t;
-  asm("v_sub_f32 %0, 0, %1" : "=v"(t) : "v"(v));                   // sign set iff v > 0 (0 - (-0) = +0); not foldable to a negation
-  return __builtin_amdgcn_alignbit(acc, __float_as_uint(t), 31);   // (acc << 1) | sign
-}
-template <int NB>
-__device__ __forceinline__ void relu_mask_words(const v4f (&h)[NB], unsigned (&w)[(NB + 7) / 8]) {
-#pragma unroll
-  for (int wi = 0; wi < (NB + 7) / 8; ++wi) {
-    constexpr int B1 = 8;
-    const int b1 = NB < 8 * wi + B1 ? NB : 8 * wi + B1;
-    unsigned acc = 0u;
-#pragma unroll
-    for (int b = 8 * wi; b < b1; ++b) {                     // first value ends up in the highest bit
-      acc = push_positive(acc, h[b].x); acc = push_positive(acc, h[b].y);
-      acc = push_positive(acc, h[b].z); acc = push_positive(acc, h[b].w);
-    }
-    w[wi] = acc << (32 - 4 * (b1 - 8 * wi));
-  }
-}
 // words [WORD0, WORD0 + ceil(NB / 8)) of the lane's 16 bytes in `plane`
 template <int NB, int WORD0>
 __device__ __forceinline__ void store_masks(unsigned* __restrict__ plane, const unsigned (&row)[kRB], const v4f (&h)[kRB][NB]) {
@@ -385,26 +365,16 @@ __device__ __forceinline__ void load_mask_plane(const unsigned* __restrict__ pla
 #pragma unroll
   for (int rb = 0; rb < kRB; ++rb) mk[rb] = *reinterpret_cast<const u4v*>(reinterpret_cast<const char*>(plane) + (row[rb] * 16u + 4u * q) * 4u);
 }
-// g = mask bit ? g : +0 (what relu_bwd_blocks computes from the activation).  The word is consumed from its highest bit: w + w
-// leaves the bit in the carry (VCC) and the select reads it -- two instructions per value as before, no temporaries (an
-// extract-and-mask form let the scheduler keep dozens of extracted bits alive: 256 registers and spills).
-__device__ __forceinline__ float keep_if_msb(unsigned& w, float g) {
-  asm("v_add_co_u32 %0, vcc, %0, %0\n\tv_cndmask_b32 %1, 0, %1, vcc" : "+v"(w), "+v"(g) : : "vcc");
-  return g;
-}
+// g = mask bit ? g : +0 (what relu_bwd_blocks computes from the activation): b3d_dev.hpp relu_bwd_words on words [WORD0, ...)
 template <int NB, int WORD0>
 __device__ __forceinline__ void relu_bwd_mask(v4f (&g)[kRB][NB], const u4v (&mk)[kRB]) {
 #pragma unroll
-  for (int rb = 0; rb < kRB; ++rb)
+  for (int rb = 0; rb < kRB; ++rb) {
+    unsigned words[(NB + 7) / 8];
 #pragma unroll
-    for (int wi = 0; wi < (NB + 7) / 8; ++wi) {
-      unsigned w = mk[rb][WORD0 + wi];
-#pragma unroll
-      for (int b = 8 * wi; b < (NB < 8 * wi + 8 ? NB : 8 * wi + 8); ++b) {
-        g[rb][b].x = keep_if_msb(w, g[rb][b].x); g[rb][b].y = keep_if_msb(w, g[rb][b].y);
-        g[rb][b].z = keep_if_msb(w, g[rb][b].z); g[rb][b].w = keep_if_msb(w, g[rb][b].w);
-      }
-    }
+    for (int wi = 0; wi < (NB + 7) / 8; ++wi) words[wi] = mk[rb][WORD0 + wi];
+    relu_bwd_words<NB>(g[rb], words);
+  }
 }
 // the same row table access for every row block of the wavefront
 template <int NB>

@@ -87,8 +87,8 @@ struct EdgeFwdHArgs {
   float* sF1;
   float* sP1;
   const float* wpack;  // Hoist::EdgeFwdSeq images
-  unsigned* rmask;     // es::edge_fwd_kernel<D, true> only: ReLU masks (b3d_estream.hpp), plane A: sH1 | sH2, 64 bytes per edge
-  unsigned* rmask2;    //   plane B: sF1 | sP1
+  unsigned* rmask;     // ReLU masks (b3d_dev.hpp).  es::edge_fwd_kernel<D, true>: plane A (sH1 | sH2), 64 bytes per edge;
+  unsigned* rmask2;    //   plane B (sF1 | sP1).  mp_edge_fwd_h_kernel: rmask = one [E, 16]-float plane (a word per tensor), or nullptr
 };
 
 template <class D, int NW>
@@ -128,11 +128,15 @@ __global__ __launch_bounds__(NW * 64, 2) void mp_edge_fwd_h_kernel(const EdgeFwd
     // there is several microseconds long and the register file is full
     constexpr bool LATE_PI = D::EH1 > 128;
     v4f h2[H2B], en[EB];
+    // ReLU masks of sH1 | sH2 | sF1 | sP1 (b3d_dev.hpp): one word each at these widths, the lane's 16 bytes of a [E, 16]-float plane
+    static_assert(H1B <= 8 && H2B <= 8 && MHB <= 8, "one mask word per tensor (the wide camera+LiDAR+radar stacks use b3d_edge2.hpp)");
+    unsigned mk1[1] = {0u}, mk2[1] = {0u}, mkf[1] = {0u}, mkp[1] = {0u};
     linear_init<Seq, 0, true, false>(ws, more, ein, h1, h1);
     B3D_STAMP(2, 2);
     linear<Seq, 1, true>(ws, more, h1, h2, [&]() {
       B3D_STAMP(2, 10);
       if (a.sH1) store_row<H1B>(a.sH1, row, D::EH1, 0, valid, h1);
+      if (a.rmask) relu_mask_words<H1B>(h1, mk1);
       load_row_u<MHB>(a.T, d, H::TW, H::OF, fi);
       B3D_STAMP(2, 11);
     });
@@ -140,6 +144,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mp_edge_fwd_h_kernel(const EdgeFwd
     linear<Seq, 2, false>(ws, more, h2, en, [&]() {
       B3D_STAMP(2, 12);
       if (a.sH2) store_row<H2B>(a.sH2, row, D::EH2, 0, valid, h2);
+      if (a.rmask) relu_mask_words<H2B>(h2, mk2);
       if constexpr (!LATE_PI) load_row_u<MHB>(a.T, s, H::TW, H::OP, pi);
       B3D_STAMP(2, 13);
     });
@@ -154,12 +159,25 @@ __global__ __launch_bounds__(NW * 64, 2) void mp_edge_fwd_h_kernel(const EdgeFwd
       B3D_STAMP(2, 15);
     });
     B3D_STAMP(2, 5);
-    linear<Seq, 4, false>(ws, more, fi, mo, [&]() { B3D_STAMP(2, 16); if (a.sF1) store_row<MHB>(a.sF1, row, D::MH, 0, valid, fi); B3D_STAMP(2, 17); });
+    linear<Seq, 4, false>(ws, more, fi, mo, [&]() {
+      B3D_STAMP(2, 16);
+      if (a.sF1) store_row<MHB>(a.sF1, row, D::MH, 0, valid, fi);
+      if (a.rmask) relu_mask_words<MHB>(fi, mkf);
+      B3D_STAMP(2, 17);
+    });
     B3D_STAMP(2, 6);
     wait_for(pi);
     linear_init<Seq, 5, true, false>(ws, more, en, pi, pi, [&]() { B3D_STAMP(2, 18); store_row<DMB>(a.fut, row, D::DM, 0, valid, mo); B3D_STAMP(2, 19); });
     B3D_STAMP(2, 7);
-    linear<Seq, 6, false>(ws, more, pi, mo2, [&]() { B3D_STAMP(2, 20); if (a.sP1) store_row<MHB>(a.sP1, row, D::MH, 0, valid, pi); B3D_STAMP(2, 21); });
+    linear<Seq, 6, false>(ws, more, pi, mo2, [&]() {
+      B3D_STAMP(2, 20);
+      if (a.sP1) store_row<MHB>(a.sP1, row, D::MH, 0, valid, pi);
+      if (a.rmask) {
+        relu_mask_words<MHB>(pi, mkp);
+        if (valid) *reinterpret_cast<u4v*>(reinterpret_cast<char*>(a.rmask) + ((size_t)row * 4 + (lane >> 4)) * 16) = u4v{mk1[0], mk2[0], mkf[0], mkp[0]};
+      }
+      B3D_STAMP(2, 21);
+    });
     B3D_STAMP(2, 8);
     store_row<DMB>(a.past, row, D::DM, 0, valid, mo2);
     B3D_STAMP(2, 9);
@@ -241,8 +259,8 @@ struct EdgeBwdHArgs {
   float* GdF1;
   float* GdP1;
   const float* wpack;   // Hoist::EdgeBwdSeq / EdgeBwdSeqNoMsg images
-  const unsigned* rmask;   // es::edge_bwd_kernel only: the forward's ReLU masks (instead of reading sH1 .. sP1 back), planes A and B
-  const unsigned* rmask2;
+  const unsigned* rmask;   // the forward's ReLU masks (instead of reading sH1 .. sP1 back): es::edge_bwd_kernel planes A and B,
+  const unsigned* rmask2;  //   mp_edge_bwd_h_kernel one plane
 };
 
 // Data gradient of the edge phase without the node columns of the three first layers: those are
@@ -272,46 +290,38 @@ __global__ __launch_bounds__(NW * 64, 2) void mp_edge_bwd_h_kernel(const EdgeBwd
     // counter with loads and stores; with the weights resident only the first acquire of the first tile does.)
     v4f de[EB];
     load_row<EB>(a.de_out, row, D::DE, 0, valid, de);
-    v4f act2[H2B], act1[H1B], d2[H2B], d1[H1B];
+    v4f d2[H2B], d1[H1B];
+    // the forward's ReLU masks (words: sH1, sH2, sF1, sP1) instead of the saved activations themselves: 16 bytes per lane for 1.4 KB per edge
+    static_assert(H1B <= 8 && H2B <= 8 && MHB <= 8, "one mask word per tensor");
+    u4v mk = {0u, 0u, 0u, 0u};
+    if (valid) mk = *reinterpret_cast<const u4v*>(reinterpret_cast<const char*>(a.rmask) + ((size_t)row * 4 + (lane >> 4)) * 16);
     if constexpr (MSGS) {
-      v4f dmp[DMB], dmf[DMB], actp[MHB], actf[MHB], dh[MHB], dh2[MHB], dee[EB];
-      load_row<MHB>(a.sP1, row, D::MH, 0, valid, actp);            // needs no index: issued under the index fetch
+      v4f dmp[DMB], dmf[DMB], dh[MHB], dh2[MHB], dee[EB];
       load_row<DMB>(a.dM, d, 2 * D::DM, 0, valid, dmp);            // past messages were summed at dst
       load_row<DMB>(a.dM, s, 2 * D::DM, D::DM, valid, dmf);        // future messages were summed at src
-      wait_for(de); wait_for(dmp); wait_for(actp); wait_for(dmf);   // the prologue's loads have landed
+      wait_for(de); wait_for(dmp); wait_for(dmf);                   // the prologue's loads have landed
       B3D_STAMP(3, 1);
-      linear<Seq, 0, false, false>(ws, more, dmp, dh, [&]() { load_row<MHB>(a.sF1, row, D::MH, 0, valid, actf); });
+      linear<Seq, 0, false, false>(ws, more, dmp, dh);
       B3D_STAMP(3, 2);
-      relu_bwd<MHB>(dh, actp);
-      linear<Seq, 1, false, false>(ws, more, dh, dee, [&]() {
-        store_row<MHB>(a.GdP1, row, D::MH, 0, valid, dh);
-        load_row<H2B>(a.sH2, row, D::EH2, 0, valid, act2);
-      });
+      { const unsigned wd[1] = {mk.w}; relu_bwd_words<MHB>(dh, wd); }
+      linear<Seq, 1, false, false>(ws, more, dh, dee, [&]() { store_row<MHB>(a.GdP1, row, D::MH, 0, valid, dh); });
       B3D_STAMP(3, 3);
       add_blocks<EB>(de, dee);
-      wait_for(actf);
       linear<Seq, 2, false, false>(ws, more, dmf, dh2);
       B3D_STAMP(3, 4);
-      relu_bwd<MHB>(dh2, actf);
-      linear<Seq, 3, false, false>(ws, more, dh2, dee, [&]() {
-        store_row<MHB>(a.GdF1, row, D::MH, 0, valid, dh2);
-        load_row<H1B>(a.sH1, row, D::EH1, 0, valid, act1);
-      });
+      { const unsigned wd[1] = {mk.z}; relu_bwd_words<MHB>(dh2, wd); }
+      linear<Seq, 3, false, false>(ws, more, dh2, dee, [&]() { store_row<MHB>(a.GdF1, row, D::MH, 0, valid, dh2); });
       B3D_STAMP(3, 5);
       add_blocks<EB>(de, dee);
     } else {
-      load_row<H2B>(a.sH2, row, D::EH2, 0, valid, act2);
-      load_row<H1B>(a.sH1, row, D::EH1, 0, valid, act1);
       wait_for(de);
     }
-    wait_for(act2);
     linear<Seq, L0 + 0, false, false>(ws, more, de, d2, [&]() { store_row<EB>(a.Gde, row, D::DE, 0, valid, de); });
     if constexpr (MSGS) B3D_STAMP(3, 6);
-    relu_bwd<H2B>(d2, act2);
-    wait_for(act1);
+    { const unsigned wd[1] = {mk.y}; relu_bwd_words<H2B>(d2, wd); }
     linear<Seq, L0 + 1, false, false>(ws, more, d2, d1, [&]() { store_row<H2B>(a.GdH2, row, D::EH2, 0, valid, d2); });
     if constexpr (MSGS) B3D_STAMP(3, 7);
-    relu_bwd<H1B>(d1, act1);
+    { const unsigned wd[1] = {mk.x}; relu_bwd_words<H1B>(d1, wd); }
     v4f dein[EB + AB];
     linear<Seq, L0 + 2, false, false>(ws, more, d1, dein, [&]() { store_row<H1B>(a.GdH1, row, D::EH1, 0, valid, d1); });
     if constexpr (MSGS) B3D_STAMP(3, 8);

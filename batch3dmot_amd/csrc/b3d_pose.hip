@@ -120,6 +120,7 @@ struct PoseWs {
   float* x[16];      // x[0] = x_enc ... x[depth]
   float* e[16];      // e[0] = encoded edge_attr ... e[depth]
   float *sH1[16], *sH2[16], *sF1[16], *sP1[16], *M[16], *nH1[16], *nH2[16];
+  float* rmask[16];       // hoisted plan: ReLU masks of sH1 | sH2 | sF1 | sP1, 64 bytes per edge and layer (b3d_hoist.hpp)
   float *fut, *past;
   // backward scratch
   float *de[2], *gdst, *gsrc, *dx0_acc;
@@ -213,6 +214,7 @@ static void carve(PoseWs& w, void* ws, size_t ws_bytes, int N, int E, int depth,
     per_layer(w.sH2, e_ * D::EH2);
     per_layer(w.sF1, e_ * D::MH);
     per_layer(w.sP1, e_ * D::MH);
+    per_layer(w.rmask, e_ * 16);
     per_layer(w.M, n_ * D::NIN);
     per_layer(w.nH1, n_ * D::NH1);
     per_layer(w.nH2, n_ * D::NH2);
@@ -607,6 +609,7 @@ extern "C" int b3d_pose_forward(const b3d_pose_weights* pw, const b3d_graph* g, 
       ea.T = w.T; ea.e_in = w.e[l]; ea.a_in = nullptr;
       ea.e_out = w.e[l + 1]; ea.fut = w.fut; ea.past = w.past;
       ea.sH1 = w.sH1[l]; ea.sH2 = w.sH2[l]; ea.sF1 = w.sF1[l]; ea.sP1 = w.sP1[l];
+      ea.rmask = reinterpret_cast<unsigned*>(w.rmask[l]);
       ea.wpack = w.wp_efwd_h;
             B3D_TRY(launch_rows<kNWEdgeH>(mp_edge_fwd_h_kernel<D, kNWEdgeH>, "mp_edge_fwd", ea, E, stream, B3D_K_EDGE_FWD, stream_lds_bytes<HP::EdgeFwdSeq>()));
     } else {
@@ -741,6 +744,7 @@ extern "C" int b3d_pose_backward(const b3d_pose_weights* pw, const b3d_graph* g,
       eb.dM = msgs ? w.dM + l * nLm : nullptr;
       eb.de_out = w.de[cur]; eb.de_in = w.de[cur ^ 1];
       eb.sH1 = w.sH1[l]; eb.sH2 = w.sH2[l]; eb.sF1 = w.sF1[l]; eb.sP1 = w.sP1[l];
+      eb.rmask = reinterpret_cast<const unsigned*>(w.rmask[l]);
       eb.GdH1 = w.GdH1 + l * eL1; eb.GdH2 = w.GdH2 + l * eL2; eb.Gde = w.Gde + l * eLe;
       eb.GdF1 = w.GdF1 + l * eLm; eb.GdP1 = w.GdP1 + l * eLm;
       if (msgs) {
