@@ -69,6 +69,7 @@ struct Att0FwdArgs {
   const float* e0;      // [E, 64]
   float* A0;            // [E, 512] = relu(pre-activation)
   const float* wpack;   // Att0Seq images
+  unsigned* rmask;      // [E, 16] words or nullptr: ReLU mask of A0 (b3d_dev.hpp; word c = the 128 outputs of step c)
 };
 using Att0Seq = LayerSeq<L<64, 128>, L<64, 128>, L<64, 128>, L<64, 128>>;     // W0[128 c .. 128 c + 128, 576:640]
 
@@ -102,6 +103,11 @@ __global__ __launch_bounds__(NW * 64, 2) void att0_fwd_kernel(const Att0FwdArgs 
         }
       });
       store_row<8>(a.A0, row, 512, 128 * C, valid, cur);
+      if (a.rmask) {
+        unsigned w1[1];
+        relu_mask_words<8>(cur, w1);
+        if (valid) a.rmask[((size_t)row * 4 + (lane >> 4)) * 4 + C] = w1[0];
+      }
       if constexpr (C < 3) {
         wait_for(ui); wait_for(uj);
 #pragma unroll

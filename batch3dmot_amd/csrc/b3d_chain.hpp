@@ -274,7 +274,10 @@ struct WideArgs {
   float* out;            // [rows, out_stride]
   int out_stride;
   int out_col0;
-  const float* mask;     // same geometry as out, or nullptr
+  // ReLU masks (b3d_dev.hpp), one [rows, 16]-float plane per tensor: the lane (row m, quarter q) owns 16 bytes, word b / 8 holds its
+  // blocks 8 (b / 8) ... (at most 512 outputs = 4 words)
+  const unsigned* mask_in;   // backward: the output is multiplied by (forward activation > 0) read from here, or nullptr
+  unsigned* mask_out;        // forward (RELU): the bits of THIS layer's output are written here, or nullptr
   const float* wpack;
 };
 
@@ -282,6 +285,8 @@ template <class Seq, bool RELU, bool BIAS, class In, int NW>
 __global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void wide_linear_kernel(const WideArgs<In> a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   static_assert(Seq::NL == 1 && In::NB == Seq::kp(0) / 16, "one layer; loader width = input width");
+  constexpr int NB = Seq::np(0) / 16;
+  static_assert(NB <= 32, "four mask words per lane");
   WStreamT<NW * 64, Seq::SLOT> ws;
   ws.init(a.wpack, smem);
   ws.template start<Seq>();
@@ -294,16 +299,27 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void wide_linear_kernel(c
     v4f in[In::NB];
     a.in(row, valid, in);
     float* orow = a.out + row * (long)a.out_stride + a.out_col0 + 4 * q;
-    const float* mrow = a.mask ? a.mask + row * (long)a.out_stride + a.out_col0 + 4 * q : nullptr;
+    const size_t moff = ((size_t)row * 4 + q) * 4;                 // this lane's four words of a mask plane
+    u4v mk = {0u, 0u, 0u, 0u};
+    if (a.mask_in && valid) mk = *reinterpret_cast<const u4v*>(a.mask_in + moff);
+    unsigned word = 0u;                                            // the mask word being consumed (backward) / built (forward)
+    unsigned* wp = &word;
+    const u4v* mkp = &mk;
+    const bool masked = a.mask_in != nullptr;
+    unsigned* mout = (RELU && a.mask_out && valid) ? a.mask_out + moff : nullptr;
     linear_emit<Seq, 0, RELU, BIAS>(ws, more, in, [=](int mb, v4f v) {
-      if (valid) {
-        if (mrow) {
-          const v4f mk = *reinterpret_cast<const v4f*>(mrow + 16 * mb);
-          v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
-          v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
-        }
-        *reinterpret_cast<v4f*>(orow + 16 * mb) = v;
+      if (masked) {                                                // blocks arrive in ascending order
+        if ((mb & 7) == 0) *wp = (*mkp)[mb >> 3];
+        v.x = keep_if_msb(*wp, v.x); v.y = keep_if_msb(*wp, v.y); v.z = keep_if_msb(*wp, v.z); v.w = keep_if_msb(*wp, v.w);
       }
+      if constexpr (RELU) {
+        if (mout) {
+          if ((mb & 7) == 0) *wp = 0u;
+          *wp = push_positive(*wp, v.x); *wp = push_positive(*wp, v.y); *wp = push_positive(*wp, v.z); *wp = push_positive(*wp, v.w);
+          if ((mb & 7) == 7 || mb == NB - 1) mout[mb >> 3] = *wp << (28 - 4 * (mb & 7));
+        }
+      }
+      if (valid) *reinterpret_cast<v4f*>(orow + 16 * mb) = v;
     });
   }
 }

@@ -132,6 +132,7 @@ struct Ws {
   // activations
   float *ea_pad, *ee_a1, *ee_a2, *pose_pad, *ne_a1, *xsens, *fl_a1, *fr_a1, *fr_a2, *aff_v[3], *s;
   float *A[4], *att;                 // att_edge_encoder hidden [E,512/384/256/128], output [E,64]
+  unsigned* amask[4];                // training: ReLU masks of A[0..3], [E, 16] words each (b3d_dev.hpp); nullptr in inference
   float *x[16], *e[16];
   float *sH1[16], *sH2[16], *sF1[16], *sP1[16], *M[16], *nH1[16], *nH2[16];
   float* rmask[16];       // ReLU masks of sH1 | sH2 | sF1 | sP1 (b3d_estream.hpp: 128 bytes per edge and layer)
@@ -400,6 +401,7 @@ static void carve(Ws& w, void* ws, size_t ws_bytes, int N, int E, int nl, int nr
     w.fl_a1 = c.take<float>(l_ * 192); w.fr_a1 = c.take<float>(r_ * 192); w.fr_a2 = c.take<float>(r_ * 128);
     for (int m = 0; m < 3; ++m) w.aff_v[m] = c.take<float>(n_ * affd[m]);
     for (int i = 0; i < 4; ++i) w.A[i] = c.take<float>(e_ * adims[i]);
+    for (int i = 0; i < 4; ++i) w.amask[i] = reinterpret_cast<unsigned*>(c.take<float>(e_ * 16));
     {
       float* xb = c.take<float>((size_t)(depth + 1) * n_ * D::DX);
       float* eb = c.take<float>((size_t)(depth + 1) * e_ * D::DE);
@@ -660,10 +662,10 @@ static int pack_all(const b3d_clr_weights* pw, Ws& w, bool training, bool knn, h
 }
 
 template <class Seq, bool RELU, bool BIAS, class In>
-static int wide(const char* name, const In& in, long rows, float* out, int ostride, int ocol0, const float* mask,
+static int wide(const char* name, const In& in, long rows, float* out, int ostride, int ocol0, const unsigned* mask_in, unsigned* mask_out,
                 const float* wp, hipStream_t stream, int family = B3D_K_ATT_FWD) {
   WideArgs<In> a;
-  a.rows = (int)rows; a.in = in; a.out = out; a.out_stride = ostride; a.out_col0 = ocol0; a.mask = mask; a.wpack = wp;
+  a.rows = (int)rows; a.in = in; a.out = out; a.out_stride = ostride; a.out_col0 = ocol0; a.mask_in = mask_in; a.mask_out = mask_out; a.wpack = wp;
   return launch_rows<kNWEdge>(wide_linear_kernel<Seq, RELU, BIAS, In, kNWEdge>, name, a, rows, stream, family, chain_lds<Seq>());
 }
 
@@ -842,12 +844,12 @@ extern "C" int b3d_clr_forward(const b3d_clr_weights* pw, const b3d_graph* g, co
   {  // att_edge_encoder( s[dst] | s[src] | e ) 640-512-384-256-128-64 (:161-164)
     B3D_TRY(node_linear<SeqAttU>("att_node_linear", w.s, XS, 0, w.U, 1024, N, w.wp_attU, stream, B3D_K_ATT_FWD));
     Att0FwdArgs fa;
-    fa.E = E; fa.src = g->src; fa.dst = g->dst; fa.U = w.U; fa.e0 = w.e[0]; fa.A0 = w.A[0]; fa.wpack = w.wp_att0;
+    fa.E = E; fa.src = g->src; fa.dst = g->dst; fa.U = w.U; fa.e0 = w.e[0]; fa.A0 = w.A[0]; fa.wpack = w.wp_att0; fa.rmask = w.amask[0];
     B3D_TRY(launch_rows<kNWEdge>(att0_fwd_kernel<kNWEdge>, "att_edge_encoder.0", fa, E, stream, B3D_K_ATT_FWD, stream_lds_bytes<Att0Seq>()));
-    B3D_TRY((wide<SeqAT1, true, true>("att_edge_encoder.2", LoadAligned<32>{w.A[0], nullptr, 512, 0}, E, w.A[1], 384, 0, nullptr, w.wp_at[1], stream)));
-    B3D_TRY((wide<SeqAT2, true, true>("att_edge_encoder.4", LoadAligned<24>{w.A[1], nullptr, 384, 0}, E, w.A[2], 256, 0, nullptr, w.wp_at[2], stream)));
-    B3D_TRY((wide<SeqAT3, true, true>("att_edge_encoder.6", LoadAligned<16>{w.A[2], nullptr, 256, 0}, E, w.A[3], 128, 0, nullptr, w.wp_at[3], stream)));
-    B3D_TRY((wide<SeqAT4, false, true>("att_edge_encoder.8", LoadAligned<8>{w.A[3], nullptr, 128, 0}, E, w.att, 64, 0, nullptr, w.wp_at[4], stream)));
+    B3D_TRY((wide<SeqAT1, true, true>("att_edge_encoder.2", LoadAligned<32>{w.A[0], nullptr, 512, 0}, E, w.A[1], 384, 0, nullptr, w.amask[1], w.wp_at[1], stream)));
+    B3D_TRY((wide<SeqAT2, true, true>("att_edge_encoder.4", LoadAligned<24>{w.A[1], nullptr, 384, 0}, E, w.A[2], 256, 0, nullptr, w.amask[2], w.wp_at[2], stream)));
+    B3D_TRY((wide<SeqAT3, true, true>("att_edge_encoder.6", LoadAligned<16>{w.A[2], nullptr, 256, 0}, E, w.A[3], 128, 0, nullptr, w.amask[3], w.wp_at[3], stream)));
+    B3D_TRY((wide<SeqAT4, false, true>("att_edge_encoder.8", LoadAligned<8>{w.A[3], nullptr, 128, 0}, E, w.att, 64, 0, nullptr, nullptr, w.wp_at[4], stream)));
   }
   for (int l = 0; l < depth; ++l) {
     if ((flags & B3D_FLAG_RUN_DEAD_KNN) && l > 0 && (l % 2 == 0)) B3D_TRY(knn_block(l));
@@ -988,12 +990,12 @@ extern "C" int b3d_clr_backward(const b3d_clr_weights* pw, const b3d_graph* g, c
   B3D_TRY(launch_check("node_bwd_g_kernel"));
 
   // ---- att_edge_encoder backward: d att (summed over the layers) -> d(s[dst] | s[src] | e) ------------
-  B3D_TRY((wide<SeqAT4T, false, false>("att_edge_encoder.8^T", LoadAligned<4>{w.da_acc, nullptr, 64, 0}, E, w.dA[0], 128, 0, w.A[3], w.wp_atT[4], stream, B3D_K_ATT_BWD)));
-  B3D_TRY((wide<SeqAT3T, false, false>("att_edge_encoder.6^T", LoadAligned<8>{w.dA[0], nullptr, 128, 0}, E, w.dA[1], 256, 0, w.A[2], w.wp_atT[3], stream, B3D_K_ATT_BWD)));
-  B3D_TRY((wide<SeqAT2T, false, false>("att_edge_encoder.4^T", LoadAligned<16>{w.dA[1], nullptr, 256, 0}, E, w.dA[2], 384, 0, w.A[1], w.wp_atT[2], stream, B3D_K_ATT_BWD)));
-  B3D_TRY((wide<SeqAT1T, false, false>("att_edge_encoder.2^T", LoadAligned<24>{w.dA[2], nullptr, 384, 0}, E, w.dA[3], 512, 0, w.A[0], w.wp_atT[1], stream, B3D_K_ATT_BWD)));
+  B3D_TRY((wide<SeqAT4T, false, false>("att_edge_encoder.8^T", LoadAligned<4>{w.da_acc, nullptr, 64, 0}, E, w.dA[0], 128, 0, w.amask[3], nullptr, w.wp_atT[4], stream, B3D_K_ATT_BWD)));
+  B3D_TRY((wide<SeqAT3T, false, false>("att_edge_encoder.6^T", LoadAligned<8>{w.dA[0], nullptr, 128, 0}, E, w.dA[1], 256, 0, w.amask[2], nullptr, w.wp_atT[3], stream, B3D_K_ATT_BWD)));
+  B3D_TRY((wide<SeqAT2T, false, false>("att_edge_encoder.4^T", LoadAligned<16>{w.dA[1], nullptr, 256, 0}, E, w.dA[2], 384, 0, w.amask[1], nullptr, w.wp_atT[2], stream, B3D_K_ATT_BWD)));
+  B3D_TRY((wide<SeqAT1T, false, false>("att_edge_encoder.2^T", LoadAligned<24>{w.dA[2], nullptr, 384, 0}, E, w.dA[3], 512, 0, w.amask[0], nullptr, w.wp_atT[1], stream, B3D_K_ATT_BWD)));
   // d e0 per edge; d U per node = sums of d A0 over the CSR / CSC lists; d s = W0[:, 0:288]^T dU_i + W0[:, 288:576]^T dU_j
-  B3D_TRY((wide<SeqAT0eT, false, false>("att_edge_encoder.0[e]^T", LoadAligned<32>{w.dA[3], nullptr, 512, 0}, E, w.de0, 64, 0, nullptr, w.wp_at0eT, stream, B3D_K_ATT_BWD)));
+  B3D_TRY((wide<SeqAT0eT, false, false>("att_edge_encoder.0[e]^T", LoadAligned<32>{w.dA[3], nullptr, 512, 0}, E, w.de0, 64, 0, nullptr, nullptr, w.wp_at0eT, stream, B3D_K_ATT_BWD)));
   AttListSumArgs la;
   la.N = N; la.W = 512; la.dst_ptr = g->dst_ptr; la.dst_perm = g->dst_perm; la.src_ptr = g->src_ptr; la.src_perm = g->src_perm;
   la.G = w.dA[3]; la.dU = w.dU;
