@@ -228,13 +228,13 @@ template <class SeqT, int LI, class Args, class WS>
 __device__ __forceinline__ void chain_bwd_rec(WS& ws, bool more, const Args& a, long row,
                                               bool valid, const v4f* g) {
   constexpr int NB = SeqT::np(LI) / 16;
-  v4f d[NB];
-  linear<SeqT, LI, false, false>(ws, more, g, d);
-  if (a.act[LI]) {
-    v4f act[NB];
-    load_row<NB>(a.act[LI], row, SeqT::np(LI), 0, valid, act);
-    relu_bwd<NB>(d, act);
-  }
+  v4f d[NB], act[NB];
+  // the saved activation is fetched under this layer's products (round 5: it used to be loaded behind them, a round trip per layer
+  // in front of every relu')
+  linear<SeqT, LI, false, false>(ws, more, g, d, [&]() {
+    if (a.act[LI]) load_row<NB>(a.act[LI], row, SeqT::np(LI), 0, valid, act);
+  });
+  if (a.act[LI]) relu_bwd<NB>(d, act);
   if (a.gsave[LI]) store_row<NB>(a.gsave[LI], row, SeqT::np(LI), 0, valid, d);
   if constexpr (LI + 1 < SeqT::NL) {
     chain_bwd_rec<SeqT, LI + 1>(ws, more, a, row, valid, d);
