@@ -160,6 +160,62 @@ def test_clr_layer_forward_backward_match_oracle(n, k):
 
 
 @pytest.mark.parametrize("kind", ["p", "clr"])
+def test_dead_relu_units_carry_no_gradient(kind):
+    """The backward sweep reads ReLU BIT MASKS written by the forward (one bit per saved hidden value, b3d_dev.hpp) instead of the
+    activations: a unit whose pre-activation is EXACTLY zero (dead rows of the Linear in front of the ReLU, here at both ends and
+    across the 32-value word boundaries of every masked tensor) must pass no gradient, as torch's relu' does; everything else as the
+    oracle."""
+    from conftest import assert_grad_close
+    dev = torch.device("cuda:0")
+    d = _graph(220, 8, 23)
+    ora = ref_torch.CausalMessagePassing(kind)
+    seeded_fill_(ora, 12)
+    dead = {}
+    with torch.no_grad():
+        for name, seq in (("edge_update", ora.edge_update), ("create_past_msgs", ora.create_past_msgs),
+                          ("create_future_msgs", ora.create_future_msgs)):
+            lins = [mod for mod in seq if isinstance(mod, torch.nn.Linear)]
+            for li, lin in enumerate(lins[:-1]):                       # every Linear that feeds a ReLU
+                n_out = lin.out_features
+                rows = sorted({0, 1, 7, 8, 31, 32, 33, n_out // 2, n_out - 2, n_out - 1} & set(range(n_out)))
+                lin.weight[rows] = 0.0
+                lin.bias[rows] = 0.0
+                dead[f"{name}.{2 * li}"] = rows
+    if kind == "p":
+        from batch3dmot_amd.pose_gnn import CausalMessagePassing
+        dx, de = 48, 32
+    else:
+        from batch3dmot_amd.clr_att_gnn import CausalMessagePassing
+        dx, de = 96, 64
+    m = CausalMessagePassing()
+    m.load_state_dict(ora.state_dict())
+    m.to(dev)
+    g = torch.Generator().manual_seed(5)
+    N, E = d.pose_feats.size(0), d.edge_index.size(1)
+    x, x0, e = torch.randn(N, dx, generator=g), torch.randn(N, dx, generator=g), torch.randn(E, de, generator=g)
+    att = torch.randn(E, 64, generator=g) if kind == "clr" else None
+    cx, ce = torch.randn(N, dx, generator=g), torch.randn(E, de, generator=g)
+
+    def run(mod, dev_):
+        xs = [t.clone().to(dev_).requires_grad_(True) for t in (x, x0, e)]
+        extra = (att.clone().to(dev_),) if att is not None else ()
+        xn, en = mod(xs[0], d.edge_index.to(dev_), xs[2], xs[1], *extra)
+        ((xn * cx.to(dev_)).sum() + (en * ce.to(dev_)).sum()).backward()
+        return [t.grad.cpu() for t in xs], {k_: p.grad.cpu() for k_, p in mod.named_parameters()}
+
+    ref_in, ref_w = run(ora, torch.device("cpu"))
+    got_in, got_w = run(m, dev)
+    for key, rows in dead.items():
+        assert float(ref_w[key + ".weight"][rows].abs().max()) == 0.0           # the oracle agrees that they are dead
+        assert float(got_w[key + ".weight"][rows].abs().max()) == 0.0, key
+        assert float(got_w[key + ".bias"][rows].abs().max()) == 0.0, key
+    for a, b, name in zip(got_in, ref_in, ("d x", "d initial_x", "d edge_attr")):
+        assert_grad_close(a, b, name)
+    for k_ in ref_w:
+        assert_grad_close(got_w[k_], ref_w[k_], k_)
+
+
+@pytest.mark.parametrize("kind", ["p", "clr"])
 @pytest.mark.parametrize("case", ["inf", "nan", "huge", "denormal", "mixed"])
 def test_non_finite_and_extreme_inputs(kind, case):
     """Edge values through the bf16x6 layers (three-way bf16 split of every operand, six piece products).
