@@ -298,28 +298,34 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void wide_linear_kernel(c
     const bool valid = row < a.rows;
     v4f in[In::NB];
     a.in(row, valid, in);
-    float* orow = a.out + row * (long)a.out_stride + a.out_col0 + 4 * q;
-    const size_t moff = ((size_t)row * 4 + q) * 4;                 // this lane's four words of a mask plane
+    // Output / mask rows as (uniform base) + 32-bit byte offset: hipcc then selects the saddr form of global_store / global_load and
+    // keeps no 64-bit row address alive across the layer -- with pointer pairs the 512-wide instances ran out of registers and
+    // RELOADED the output base from scratch in front of every store, behind an s_waitcnt vmcnt(0) that also drained the weight
+    // chunk in flight (round 5).  The launcher checks that the buffers stay below 4 GB.
+    const unsigned ooff = ((unsigned)row * (unsigned)a.out_stride + (unsigned)a.out_col0 + 4u * (unsigned)q) * 4u;
+    const unsigned moff = ((unsigned)row * 4u + (unsigned)q) * 16u;      // this lane's four words of a mask plane
+    char* const obase = reinterpret_cast<char*>(a.out);
     u4v mk = {0u, 0u, 0u, 0u};
-    if (a.mask_in && valid) mk = *reinterpret_cast<const u4v*>(a.mask_in + moff);
+    if (a.mask_in && valid) mk = *reinterpret_cast<const u4v*>(reinterpret_cast<const char*>(a.mask_in) + moff);
     unsigned word = 0u;                                            // the mask word being consumed (backward) / built (forward)
     unsigned* wp = &word;
     const u4v* mkp = &mk;
     const bool masked = a.mask_in != nullptr;
-    unsigned* mout = (RELU && a.mask_out && valid) ? a.mask_out + moff : nullptr;
+    char* const mbase = reinterpret_cast<char*>(a.mask_out);
+    const bool mwrite = RELU && a.mask_out != nullptr && valid;
     linear_emit<Seq, 0, RELU, BIAS>(ws, more, in, [=](int mb, v4f v) {
       if (masked) {                                                // blocks arrive in ascending order
         if ((mb & 7) == 0) *wp = (*mkp)[mb >> 3];
         v.x = keep_if_msb(*wp, v.x); v.y = keep_if_msb(*wp, v.y); v.z = keep_if_msb(*wp, v.z); v.w = keep_if_msb(*wp, v.w);
       }
       if constexpr (RELU) {
-        if (mout) {
+        if (mwrite) {
           if ((mb & 7) == 0) *wp = 0u;
           *wp = push_positive(*wp, v.x); *wp = push_positive(*wp, v.y); *wp = push_positive(*wp, v.z); *wp = push_positive(*wp, v.w);
-          if ((mb & 7) == 7 || mb == NB - 1) mout[mb >> 3] = *wp << (28 - 4 * (mb & 7));
+          if ((mb & 7) == 7 || mb == NB - 1) *reinterpret_cast<unsigned*>(mbase + moff + 4u * (unsigned)(mb >> 3)) = *wp << (28 - 4 * (mb & 7));
         }
       }
-      if (valid) *reinterpret_cast<v4f*>(orow + 16 * mb) = v;
+      if (valid) *reinterpret_cast<v4f*>(obase + ooff + 64u * (unsigned)mb) = v;
     });
   }
 }

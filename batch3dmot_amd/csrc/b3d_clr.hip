@@ -664,6 +664,8 @@ static int pack_all(const b3d_clr_weights* pw, Ws& w, bool training, bool knn, h
 template <class Seq, bool RELU, bool BIAS, class In>
 static int wide(const char* name, const In& in, long rows, float* out, int ostride, int ocol0, const unsigned* mask_in, unsigned* mask_out,
                 const float* wp, hipStream_t stream, int family = B3D_K_ATT_FWD) {
+  B3D_REQUIRE((unsigned long long)rows * (unsigned long long)ostride * 4ull < (1ull << 32),
+              "wide_linear: %ld rows x %d columns exceed the 32-bit row offsets of this kernel", rows, ostride);
   WideArgs<In> a;
   a.rows = (int)rows; a.in = in; a.out = out; a.out_stride = ostride; a.out_col0 = ocol0; a.mask_in = mask_in; a.mask_out = mask_out; a.wpack = wp;
   return launch_rows<kNWEdge>(wide_linear_kernel<Seq, RELU, BIAS, In, kNWEdge>, name, a, rows, stream, family, chain_lds<Seq>());

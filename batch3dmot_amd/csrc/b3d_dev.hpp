@@ -175,14 +175,17 @@ struct WStreamT {
     const float* src = g + off;
     // opaque per call: hipcc otherwise hoists the per-piece 64-bit source addresses of EVERY chunk of the sequence
     // out of the tile loop (up to ~150 address pairs) and spills them
-    asm volatile("" : "+v"(src));
+    // ... and SCALAR (round 5: "+s", it was "+v"): the chunk base stays in an SGPR pair and a piece's address is base + a 32-bit lane
+    // offset -- the saddr form of global_load_lds.  As a VGPR pair every piece carried its own 64-bit address (v_lshl_add_u64 per
+    // piece, five pairs kept live in the 512-wide kernels, which then spilled the output base and reloaded it behind a vmcnt(0)).
+    asm volatile("" : "+s"(src));
     float* dst = lds + to_slot * SLOT;
 #pragma unroll
     for (int i0 = 0; i0 < n4; i0 += NT) {
       const int base = i0 + wave * 64;                   // wave-uniform
       if (base < n4) {
         __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)(src + (size_t)(base + lane) * 4),
+            (const __attribute__((address_space(1))) void*)(src + (unsigned)(base + lane) * 4u),
             (__attribute__((address_space(3))) void*)(dst + (size_t)base * 4), 16, 0, 0);
       }
     }
@@ -292,12 +295,12 @@ struct WStreamG {
     static_assert(G::group_floats(LEAD) <= GSLOT && n4 % 64 == 0, "group larger than a slot");
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float* src = g + off;
-    asm volatile("" : "+v"(src));          // see WStreamT::issue
+    asm volatile("" : "+s"(src));          // see WStreamT::issue
 #pragma unroll
     for (int i0 = 0; i0 < n4; i0 += NT) {
       const int b = i0 + wave * 64;
       if (b < n4) {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)(b + lane) * 4),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (unsigned)(b + lane) * 4u),
                                          (__attribute__((address_space(3))) void*)(dst + (size_t)b * 4), 16, 0, 0);
       }
     }
