@@ -18,4 +18,8 @@ def __getattr__(name):
     if name == "GNN":
         from .clr_att_gnn import GNN
         return GNN
+    if name == "CausalMessagePassing":
+        # the poses-only widths (pose_gnn.py:89-252); the camera+LiDAR+radar widths live in clr_att_gnn.CausalMessagePassing
+        from .pose_gnn import CausalMessagePassing
+        return CausalMessagePassing
     raise AttributeError(name)

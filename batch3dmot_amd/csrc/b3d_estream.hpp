@@ -40,6 +40,11 @@ namespace es {
 #define B3D_ES_RB 1
 #endif
 constexpr int kRB = B3D_ES_RB;
+// TIMING ABLATIONS (tools only, results are garbage): bit 0 no refill DMA, bit 1 no fragment reads, bit 2 two of twelve MFMAs per step,
+// bit 3 no operand split, bit 4 no rendezvous barrier
+#ifndef B3D_ES_ABL
+#define B3D_ES_ABL 0
+#endif
 constexpr int kWaves = 4, kTileRows = kWaves * 16 * kRB;    // rows per workgroup
 constexpr int kWgPerCu = kRB == 1 ? 2 : 1;
 constexpr int kChunkSteps = 4, kStepBytes = 6144, kChunkBytes = kChunkSteps * kStepBytes, kSlots = 3;
@@ -162,12 +167,13 @@ struct Ring {
   __device__ __forceinline__ void rendezvous() {
     if constexpr (C == 0) { if (first) { first = false; return; } }
     wait_vm<pending<C>()>();
-    __builtin_amdgcn_s_barrier();
+    if constexpr ((B3D_ES_ABL & 16) == 0) __builtin_amdgcn_s_barrier();
   }
   // in front of step J of chunk C: this step's share of the pieces of chunk C + 2
   template <int C, int J>
   __device__ __forceinline__ void refill(bool more) {
     constexpr int NXT = C + kSlots - 1, J0 = J * kPiecesPerWave / kChunkSteps, J1 = (J + 1) * kPiecesPerWave / kChunkSteps;
+    if constexpr ((B3D_ES_ABL & 1) != 0) return;
     if constexpr (NXT < S::NCH) issue_pieces<NXT, J0, J1>();
     else if (more) issue_pieces<NXT - S::NCH, J0, J1>();
   }
@@ -227,6 +233,8 @@ __device__ __forceinline__ void mfma_step(const Bf3& w0, const Bf3& w1, const Bf
   }
   B3D_ES_PRODH(p0, p1) B3D_ES_PRODH(p1, p0) B3D_ES_PRODH(p0, p0)
 #undef B3D_ES_PRODH
+#elif (B3D_ES_ABL & 4)
+  B3D_ES_PROD(p0, p0)
 #else
   B3D_ES_PROD(p0, p2) B3D_ES_PROD(p1, p1) B3D_ES_PROD(p2, p0) B3D_ES_PROD(p0, p1) B3D_ES_PROD(p1, p0) B3D_ES_PROD(p0, p0)
 #endif
@@ -268,7 +276,8 @@ __device__ __forceinline__ void step(RingT& ring, bool more, StepState& st, cons
   }
   // the LDS reads of the NEXT step are issued in front of this step's MFMAs (hipcc otherwise sinks them next to their use)
   Bf3 n0 = st.cur0, n1 = st.cur1;
-  if constexpr (IN_CHUNK + 1 < kChunkSteps) frag_load2(st.base + (IN_CHUNK + 1) * kStepBytes + ring.lane * 16, n0, n1);
+  if constexpr ((B3D_ES_ABL & 2) != 0) {}
+  else if constexpr (IN_CHUNK + 1 < kChunkSteps) frag_load2(st.base + (IN_CHUNK + 1) * kStepBytes + ring.lane * 16, n0, n1);
   else if constexpr (CJ + 1 < S::NCH) frag_load2(ring.template slot_addr<CJ + 1>() + ring.lane * 16, n0, n1);
   else { if (more) frag_load2(ring.template slot_addr<0>() + ring.lane * 16, n0, n1); }
   __builtin_amdgcn_sched_barrier(0);
@@ -302,6 +311,10 @@ __device__ __forceinline__ void split_blocks(const v4f (&a)[kRB][NB], Bf3 (&x)[k
     for (int c = 0; c < NB / 2; ++c) {
 #if B3D_ES_F16
       x[rb][c] = f16_split(a[rb][2 * c], a[rb][2 * c + 1]);
+#elif (B3D_ES_ABL & 8)
+      x[rb][c] = Bf3{__builtin_bit_cast(bf8, u4v{__builtin_bit_cast(unsigned, a[rb][2 * c].x), __builtin_bit_cast(unsigned, a[rb][2 * c].y), __builtin_bit_cast(unsigned, a[rb][2 * c].z), __builtin_bit_cast(unsigned, a[rb][2 * c].w)}),
+                     __builtin_bit_cast(bf8, u4v{__builtin_bit_cast(unsigned, a[rb][2 * c + 1].x), __builtin_bit_cast(unsigned, a[rb][2 * c + 1].y), __builtin_bit_cast(unsigned, a[rb][2 * c + 1].z), __builtin_bit_cast(unsigned, a[rb][2 * c + 1].w)}),
+                     __builtin_bit_cast(bf8, u4v{__builtin_bit_cast(unsigned, a[rb][2 * c].x), __builtin_bit_cast(unsigned, a[rb][2 * c + 1].y), __builtin_bit_cast(unsigned, a[rb][2 * c].z), __builtin_bit_cast(unsigned, a[rb][2 * c + 1].w)})};
 #else
       x[rb][c] = bf_split(a[rb][2 * c], a[rb][2 * c + 1]);
 #endif

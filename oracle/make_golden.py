@@ -342,7 +342,8 @@ class DropoutTape:
         return False
 
 
-def golden_train_mode_step(ref, path, num_nodes=60, k=6, graph_idx=900, lidar_frac=0.7, radar_frac=0.25, salt=40, dropout_live=False):
+def golden_train_mode_step(ref, path, num_nodes=60, k=6, graph_idx=900, lidar_frac=0.7, radar_frac=0.25, salt=40, dropout_live=False,
+                           full_grads=False):
     """The training step as train.py runs it: the model in .train() -- clr_att_gnn.py:26-33 freezes the encoders'
     PARAMETERS but leaves them in train mode, so their BatchNorms use batch statistics and update their running
     statistics (pointnet.py:188-192, radarnet.py:60-64, resnet_fully_conv.py:42-82), and fewer than two rows of a
@@ -402,6 +403,7 @@ def golden_train_mode_step(ref, path, num_nodes=60, k=6, graph_idx=900, lidar_fr
                 "grad_digest": grad_digest(grads), "after_digest": grad_digest(after), "running_stats": stats, "modes": modes,
                 "lidar_rows": int((data.lidar_feats.reshape(n, -1).sum(1) != 0).sum()),
                 "radar_rows": int((data.radar_feats.reshape(n, -1).sum(1) != 0).sum()),
+                **({"grads": grads} if full_grads else {}),        # round 6: every gradient tensor of the train-mode step, in full
                 **({"dropout_masks": tape["masks"], "dropout_p": 0.3} if dropout_live else {})}, path)
     print(f"{path}: loss={loss.item():.6f} modes={modes}" + (f" dropout masks {[tuple(m_.shape) for m_ in tape['masks']]}" if dropout_live else ""))
 
@@ -732,10 +734,10 @@ def main():
         ("g2_clr.pt", lambda p: golden_clr(ref, p)),
         ("g2b_clr_one_lidar.pt", lambda p: golden_clr(ref, p, num_nodes=30, k=4, graph_idx=219, lidar_frac=0.04, radar_frac=0.04, salt=11)),
         ("g3_train_step.pt", lambda p: golden_train_step(ref, p)),
-        ("g9_train_mode_step.pt", lambda p: golden_train_mode_step(ref, p)),
+        ("g9_train_mode_step.pt", lambda p: golden_train_mode_step(ref, p, full_grads=True)),
         ("g9b_train_mode_one_radar_row.pt", lambda p: golden_train_mode_step(ref, p, num_nodes=40, k=5, graph_idx=920, lidar_frac=0.6,
                                                                               radar_frac=0.013, salt=41)),
-        ("g11_train_mode_dropout_live.pt", lambda p: golden_train_mode_step(ref, p, num_nodes=50, k=5, graph_idx=940, salt=42, dropout_live=True)),
+        ("g11_train_mode_dropout_live.pt", lambda p: golden_train_mode_step(ref, p, num_nodes=50, k=5, graph_idx=940, salt=42, dropout_live=True, full_grads=True)),
         ("g4_predict_post.pt", lambda p: golden_predict_post(p)),
         ("g7_loader.pt", lambda p: golden_loader(p)),
         ("g8_tracks.pt", lambda p: golden_tracks(p)),

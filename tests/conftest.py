@@ -65,7 +65,7 @@ def assert_grad_close(have, want, name, tol=5e-4, flip_l2=4.0, flip_max=3e-2):
     # their worst below `flip_max`, and the tensor as a whole within the L2 bound
     l2 = float((a - b).norm() / b.norm().clamp_min(1e-30))
     outside = int((err >= tol).sum())
-    allowed = max(8, int(0.10 * err.numel()))
+    allowed = max(8, int(0.01 * err.numel()))
     WORST.append((name, mx, l2, outside, err.numel()))
     assert l2 < flip_l2 * tol and mx < flip_max and outside <= allowed, (name, mx, l2, outside, err.numel())
 
@@ -112,3 +112,26 @@ def assert_grad_digest_close(have, want, tol=1e-4, floor=3e-8):
         scale = max(float(w["head"].abs().max()), norm / numel ** 0.5)
         d = (h["head"] - w["head"]).abs()
         assert float(d.max()) <= 3 * tol * scale + floor, (n, d.tolist(), scale)
+
+
+def assert_grads_entrywise(have, want, tol=1e-4):
+    """Every gradient ENTRY against the reference's (fixtures that hold the full tensors: g1*, g2*, g3, g5 and -- since round 6 --
+    the train-mode steps g9 / g11): max-norm error relative to the tensor's largest entry.  The q / k thirds of the attention
+    in-projections are dead (the reference holds ~1e-12 rounding noise there, the kernels exact zeros): their v third is compared.
+    Returns the worst (name, error)."""
+    worst = ("", 0.0)
+    for n, w in want.items():
+        h = have.get(n)
+        if w is None:
+            assert h is None, n
+            continue
+        assert h is not None, n
+        if n.endswith("in_proj_weight") or n.endswith("in_proj_bias"):
+            k = 2 * w.shape[0] // 3
+            h, w = h[k:], w[k:]
+        a, b = h.detach().double().cpu(), w.detach().double().cpu()
+        r = float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+        if r > worst[1]:
+            worst = (n, r)
+        assert r < tol, (n, r)
+    return worst

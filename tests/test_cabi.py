@@ -115,3 +115,16 @@ def test_counted_vmcnt_waits_match_the_shipped_isa():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "audit_vmcnt.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("violations 0") >= 4 and r.stdout.strip().endswith("OK"), r.stdout
+
+
+def test_star_import_resolves_every_public_name():
+    """``from batch3dmot_amd import *`` (what a notebook / the reference's ``from batch_3dmot.models... import *`` style does)
+    must resolve every name of ``__all__`` -- the lazy ``__getattr__`` once forgot ``CausalMessagePassing``."""
+    import batch3dmot_amd
+    ns = {}
+    exec("from batch3dmot_amd import *", ns)
+    for name in batch3dmot_amd.__all__:
+        assert name in ns, name
+    assert ns["CausalMessagePassing"] is batch3dmot_amd.pose_gnn.CausalMessagePassing
+    with pytest.raises(AttributeError):
+        batch3dmot_amd.no_such_name
