@@ -245,6 +245,8 @@ def load() -> C.CDLL:
     lib.b3d_tracks_from_edges.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32,
                                           C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
     lib.b3d_prof_enable.argtypes = [C.c_int]
+    lib.b3d_prof_markers.argtypes = [C.c_int]
+    lib.b3d_prof_markers.restype = C.c_int
     lib.b3d_prof_select.argtypes = [C.c_uint32]
     lib.b3d_prof_select.restype = C.c_int
     lib.b3d_prof_read.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]
@@ -355,6 +357,11 @@ def prof_enable(on: bool, families=None) -> None:
     check(load().b3d_prof_select(C.c_uint32(mask)), "b3d_prof_select")
     check(load().b3d_prof_enable(1 if on else 0), "b3d_prof_enable")
     check(load().b3d_prof_reset(), "b3d_prof_reset")
+
+
+def prof_markers(on: bool) -> bool:
+    """roctx ranges named after the kernel family around every launch (rocprofv3 --marker-trace); False if no marker library."""
+    return bool(load().b3d_prof_markers(1 if on else 0))
 
 
 def prof_read() -> dict:

@@ -1,6 +1,7 @@
 // Version / error plumbing of the C ABI.
 #include "b3d_common.hpp"
 
+#include <dlfcn.h>
 #include <mutex>
 #include <utility>
 #include <vector>
@@ -60,6 +61,51 @@ void prof_end(hipStream_t stream) {
   (void)hipEventRecord(p.pool[2 * p.open + 1], stream);
   p.used = (size_t)p.open + 1;
   p.open = -1;
+}
+
+// ---- roctx markers ("rocprofv3 markers around each kernel family") -------------------------------------
+// The marker library is looked up at run time (librocprofiler-sdk-roctx, then the roctracer one): no link-time dependency,
+// and a box without either simply has no ranges.
+namespace {
+struct MarkerState {
+  int on = -1;                                   // -1: not decided (B3D_ROCTX), 0 / 1
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  bool tried = false;
+};
+MarkerState& marker() { static MarkerState m; return m; }
+const char* const kFamilyNames[B3D_K_COUNT] = {"b3d:mp_edge_fwd", "b3d:mp_edge_bwd", "b3d:mp_node_fwd", "b3d:mp_node_bwd", "b3d:wgrad_edge",
+                                               "b3d:wgrad_other", "b3d:other", "b3d:att_fwd", "b3d:att_bwd", "b3d:knn_gat", "b3d:point_feat"};
+bool marker_resolve() {
+  MarkerState& m = marker();
+  if (m.tried) return m.push != nullptr;
+  m.tried = true;
+  for (const char* lib : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+    void* h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
+    if (!h) continue;
+    m.push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+    m.pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+    if (m.push && m.pop) return true;
+    m.push = nullptr; m.pop = nullptr;
+  }
+  return false;
+}
+}  // namespace
+bool marker_on() {
+  MarkerState& m = marker();
+  if (m.on < 0) {
+    const char* ev = getenv("B3D_ROCTX");
+    m.on = (ev && atoi(ev) > 0 && marker_resolve()) ? 1 : 0;
+  }
+  return m.on == 1;
+}
+void marker_push(int family) { if (family >= 0 && family < B3D_K_COUNT) (void)marker().push(kFamilyNames[family]); else (void)marker().push("b3d"); }
+void marker_pop() { (void)marker().pop(); }
+int marker_enable(int on) {
+  MarkerState& m = marker();
+  if (!on) { m.on = 0; return 0; }
+  m.on = marker_resolve() ? 1 : 0;
+  return m.on;
 }
 
 namespace {
@@ -139,6 +185,11 @@ extern "C" int b3d_side_join(b3d_stream stream_) {
     B3D_TRY(b3d::side_join(sd, stream));
   }
   return B3D_OK;
+}
+
+extern "C" int b3d_prof_markers(int on) {
+  // 1 if roctx ranges are now emitted around every kernel-family launch, 0 if switched off or no marker library was found
+  return b3d::marker_enable(on);
 }
 
 extern "C" int b3d_prof_enable(int on) {

@@ -59,11 +59,23 @@ inline int grid_for_tiles(long rows, int tile_rows, int cap = 2048) {
 bool prof_on(int family);
 void prof_begin(int family, hipStream_t stream);
 void prof_end(hipStream_t stream);
+// roctx ranges named after the kernel family around the same launches (b3d_prof_markers / B3D_ROCTX=1): rocprofv3 --marker-trace
+// timelines become self-describing.  Host-side ranges: inside a hipGraph capture they bracket the capture, not the replay.
+bool marker_on();
+void marker_push(int family);
+void marker_pop();
+int marker_enable(int on);
 struct ProfScope {
   hipStream_t s;
-  bool on;
-  ProfScope(int family, hipStream_t stream) : s(stream), on(prof_on(family)) { if (on) prof_begin(family, s); }
-  ~ProfScope() { if (on) prof_end(s); }
+  bool on, mk;
+  ProfScope(int family, hipStream_t stream) : s(stream), on(prof_on(family)), mk(marker_on()) {
+    if (mk) marker_push(family);
+    if (on) prof_begin(family, s);
+  }
+  ~ProfScope() {
+    if (on) prof_end(s);
+    if (mk) marker_pop();
+  }
 };
 
 // Raise a kernel's dynamic-LDS limit once per (kernel, device): hipFuncSetAttribute costs ~2 us of host time

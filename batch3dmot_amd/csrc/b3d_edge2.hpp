@@ -35,7 +35,7 @@ template <class D, bool TRAIN>
 struct FwdHooks {
   using S = typename EdgeSeqs<D>::Fwd;
   __host__ __device__ static constexpr int before(int ci) {
-    constexpr int H1B = D::EH1 / 16, H2B = D::EH2 / 16, EB = D::DE / 16, MHB = D::MH / 16, DMB = D::DM / 16, SV = TRAIN ? 1 : 0;
+    constexpr int H1B = D::EH1 / 16, H2B = D::EH2 / 16, EB = D::DE / 16, MHB = D::MH / 16, DMB = D::DM / 16, SV = (TRAIN && !(B3D_ES_ABL & 32)) ? 1 : 0;
     return kRB * (ci == S::first_chunk(1) ? SV * (H1B + 1) + MHB    // sH1 + its mask store, T[dst] future rows
                 : ci == S::first_chunk(2) ? SV * (H2B + 1) + MHB    // sH2 + mask store, T[src] past rows
                 : ci == S::first_chunk(3) ? EB                      // e' store
@@ -45,14 +45,15 @@ struct FwdHooks {
   }
 };
 
-template <class D, bool TRAIN>
+template <class D, bool TRAIN_>
 __global__ __launch_bounds__(kWaves * 64, kWgPerCu) void edge_fwd_kernel(const EdgeFwdHArgs a) {
+  constexpr bool TRAIN = TRAIN_ && !(B3D_ES_ABL & 32);        // (timing ablation 32: the training forward without its saved activations)
   extern __shared__ __attribute__((aligned(16))) char es_smem[];
   using H = Hoist<D>;
   using S = typename EdgeSeqs<D>::Fwd;
   static_assert(D::DA > 0, "camera+LiDAR+radar widths (e | att columns)");
   constexpr int EB = D::DE / 16, AB = D::DA / 16, H1B = D::EH1 / 16, H2B = D::EH2 / 16, MHB = D::MH / 16, DMB = D::DM / 16;
-  Ring<S, FwdHooks<D, TRAIN>> ring;
+  Ring<S, FwdHooks<D, TRAIN_>> ring;
   ring.init(a.wpack, es_smem);
   ring.start();
   const int lane = threadIdx.x & 63;

@@ -45,9 +45,17 @@ constexpr int kRB = B3D_ES_RB;
 #ifndef B3D_ES_ABL
 #define B3D_ES_ABL 0
 #endif
-constexpr int kWaves = 4, kTileRows = kWaves * 16 * kRB;    // rows per workgroup
-constexpr int kWgPerCu = kRB == 1 ? 2 : 1;
-constexpr int kChunkSteps = 4, kStepBytes = 6144, kChunkBytes = kChunkSteps * kStepBytes, kSlots = 3;
+// EXPERIMENT (round 6, -DB3D_ES_WAVES=8 [-DB3D_ES_SLOTS=6]): ONE workgroup of 8 wavefronts per CU on a 128-row tile, one ring for all of
+// them -- half the LDS-DMA pieces per wavefront and half the L2 -> LDS stream per edge, and room for a deeper ring.
+#ifndef B3D_ES_WAVES
+#define B3D_ES_WAVES 4
+#endif
+#ifndef B3D_ES_SLOTS
+#define B3D_ES_SLOTS 3
+#endif
+constexpr int kWaves = B3D_ES_WAVES, kTileRows = kWaves * 16 * kRB;    // rows per workgroup
+constexpr int kWgPerCu = (kRB == 1 && kWaves == 4) ? 2 : 1;
+constexpr int kChunkSteps = 4, kStepBytes = 6144, kChunkBytes = kChunkSteps * kStepBytes, kSlots = B3D_ES_SLOTS;
 constexpr int kPiecesPerWave = kChunkBytes / 1024 / kWaves;  // 6
 
 // ---- weight stream geometry (host packer: b3d_prep.hip pack_frag_kernel) -------------------------------------------------
@@ -87,7 +95,7 @@ struct Seq {
   static constexpr int TOTAL_FLOATS = TOTAL_BYTES / 4;
   static constexpr int LDS_BYTES = kSlots * kChunkBytes + BIAS_BYTES;
   static_assert(BIAS_BYTES == 4096 || BIAS_BYTES == 8192, "bias DMA: one or two pieces per wavefront");
-  static_assert(LDS_BYTES <= 80 * 1024, "two workgroups per CU (kRB = 1)");
+  static_assert(LDS_BYTES <= (kWgPerCu == 2 ? 80 : 160) * 1024, "two workgroups per CU (kRB = 1)");
 };
 
 // ---- LDS-DMA from inline asm ---------------------------------------------------------------------------------------------
@@ -149,12 +157,18 @@ struct Ring {
   static constexpr int pending() { const int p = HK::before(C); return p < 63 ? p : 63; }
   // Stream start (once per kernel): the biases and chunks 0, 1 in flight, then complete for everybody.
   __device__ __forceinline__ void start() {
-    if constexpr (S::BIAS_BYTES == 8192) {
+    if constexpr (S::BIAS_BYTES / kWaves == 2048) {
       const unsigned woff = (unsigned)wave * 2048;
       dma2(g + S::WEIGHT_BYTES, bias_lds() + woff, woff + lane * 16);
-    } else {
+    } else if constexpr (S::BIAS_BYTES / kWaves == 1024) {
       const unsigned woff = (unsigned)wave * 1024;
       dma1(g + S::WEIGHT_BYTES, bias_lds() + woff, woff + lane * 16);
+    } else {                                    // 4 KB over 8 wavefronts: the first four
+      static_assert(S::BIAS_BYTES / kWaves == 512, "bias DMA");
+      if (wave < 4) {
+        const unsigned woff = (unsigned)wave * 1024;
+        dma1(g + S::WEIGHT_BYTES, bias_lds() + woff, woff + lane * 16);
+      }
     }
     issue_pieces<0, 0, kPiecesPerWave>();
     issue_pieces<1, 0, kPiecesPerWave>();

@@ -973,6 +973,16 @@ def main():
                  "fp32_tflops": round(step_flops / (ms_step * 1e-3) / 1e12, 2),
                  "fp32_frac": round(step_flops / (ms_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
                  "note": "message-passing path only (SURVEY.md 8d): the frozen encoders' FLOPs are not counted"}
+        # SURVEY.md 8d fractions NEXT to the operand fraction (round 6): `frac` above counts the bytes / FLOPs this design hands the
+        # launch (saved activations + G tensors exist because the step stores forward and re-reads backward); these two count what
+        # the reference's algorithm needs -- compulsory bytes of the WHOLE step over the step time, and the dominant family's
+        # algorithmic (unhoisted, per-edge) FLOPs over its launch time against the exact-fp32 MFMA peak (above 1 where hoisting to
+        # per-node work and bf16x6 products beat an fp32 evaluation of the reference's formula).
+        roofline["sec8d_bytes_frac"] = whole["hbm_frac"]
+        roofline["sec8d_flops_frac"] = round(roofline["algorithmic_tflops"] / PEAK_FP32_MFMA_TFLOPS, 4)
+        roofline["sec8d_note"] = ("sec8d_bytes_frac = SURVEY.md 8d compulsory bytes of the whole step / step time / 8 TB/s; sec8d_flops_frac = the "
+                                  "family's algorithmic FLOPs per launch / its launch time / 157.3 TFLOP/s (exact-fp32 MFMA peak); `frac` is the "
+                                  "operand-byte (or executed-FLOP) fraction of the launch as designed, not a section-8d fraction")
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(wl)

@@ -500,6 +500,11 @@ int b3d_prof_enable(int on);
 int b3d_prof_select(uint32_t family_mask);   /* bit f set: family f is timed while enabled (default: all).  Event
                                                pairs cost device time; time one family to measure it undisturbed */
 int b3d_prof_reset(void);
+/* roctx ranges ("b3d:<family>", the names above) around every kernel-family launch, for rocprofv3 --marker-trace timelines
+ * (SURVEY.md section 5).  The marker library (librocprofiler-sdk-roctx / libroctx64) is looked up at run time; returns 1 when
+ * ranges are being emitted, 0 when switched off or no marker library is present.  B3D_ROCTX=1 in the environment switches
+ * them on without a call.  Ranges are host-side: under hipGraph capture they bracket the capture, not the replays. */
+int b3d_prof_markers(int on);
 int b3d_prof_read(int family, double* total_ms /* host */, int* launches /* host */);
 /* Average elapsed time of an event pair around an EMPTY kernel on `stream`, in us (pair cost = this - that kernel). */
 int b3d_prof_pair_overhead_us(b3d_stream stream, int reps, double* out_us /* host */);

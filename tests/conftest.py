@@ -114,11 +114,14 @@ def assert_grad_digest_close(have, want, tol=1e-4, floor=3e-8):
         assert float(d.max()) <= 3 * tol * scale + floor, (n, d.tolist(), scale)
 
 
-def assert_grads_entrywise(have, want, tol=1e-4):
+def assert_grads_entrywise(have, want, tol=1e-4, ref_dev=None):
     """Every gradient ENTRY against the reference's (fixtures that hold the full tensors: g1*, g2*, g3, g5 and -- since round 6 --
     the train-mode steps g9 / g11): max-norm error relative to the tensor's largest entry.  The q / k thirds of the attention
     in-projections are dead (the reference holds ~1e-12 rounding noise there, the kernels exact zeros): their v third is compared.
-    Returns the worst (name, error)."""
+    `ref_dev` (fixtures g9 / g11: "grads_f64_dev"): per tensor, how far the REFERENCE's own fp32 gradient is from a float64
+    evaluation of the same step (oracle/make_golden.py) -- where a ReLU unit of the 50-node fixture sits within rounding of zero the
+    reference's fp32 run and any other correct evaluation differ by whole rows (g11: up to 1e-2; g9: 4e-5); the bound per tensor is
+    max(tol, 3 x that), i.e. `tol` wherever the reference is itself defined to `tol`.  Returns the worst (name, error)."""
     worst = ("", 0.0)
     for n, w in want.items():
         h = have.get(n)
@@ -133,5 +136,6 @@ def assert_grads_entrywise(have, want, tol=1e-4):
         r = float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
         if r > worst[1]:
             worst = (n, r)
-        assert r < tol, (n, r)
+        bound = max(tol, 3.0 * ref_dev.get(n, 0.0)) if ref_dev else tol
+        assert r < bound, (n, r, bound)
     return worst
