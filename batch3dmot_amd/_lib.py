@@ -201,6 +201,9 @@ def load() -> C.CDLL:
     lib.b3d_resnet_encode_workspace_bytes.argtypes = [C.c_int32]
     lib.b3d_modality_rows.restype = C.c_int
     lib.b3d_modality_rows.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.b3d_modality_rows_expect.restype = C.c_int
+    lib.b3d_modality_rows_expect.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                             C.c_void_p]
     lib.b3d_fc_bn_workspace_bytes.restype = C.c_size_t
     lib.b3d_fc_bn_workspace_bytes.argtypes = [C.c_int32, C.c_int32]
     lib.b3d_fc_bn_forward.restype = C.c_int
@@ -305,7 +308,7 @@ def require_cuda(t: torch.Tensor, name: str, dtype=None) -> None:
 class Graph:
     """Device-side graph structure built once per batch and reused by all layers and by backward."""
 
-    def __init__(self, edge_index: torch.Tensor, num_nodes: int, validated: bool = False):
+    def __init__(self, edge_index: torch.Tensor, num_nodes: int, validated: bool = False, ws: Optional[torch.Tensor] = None):
         """``validated``: the caller has already checked that every endpoint lies in [0, num_nodes) (``Data.to`` does
         so on the CPU copy).  Otherwise the build's counter of out-of-range edges is read back (one 4-byte copy, a
         host synchronisation) and a ``ValueError`` is raised, where the reference raises an index error
@@ -317,7 +320,14 @@ class Graph:
         lib = load()
         self.N, self.E = int(num_nodes), int(edge_index.size(1))
         nbytes = lib.b3d_graph_workspace_bytes(self.N, self.E)
-        self.ws = torch.empty(nbytes, dtype=torch.uint8, device=edge_index.device)
+        if ws is not None:
+            # a caller-owned buffer (``Graph.workspace_bytes``): the structure lands at fixed addresses -- what a hipGraph-captured
+            # step needs when the NEXT batch's structure is built under the current step (train_step.EncodeAhead.launch_graph)
+            if ws.dtype != torch.uint8 or ws.device != edge_index.device or ws.numel() < nbytes or not ws.is_contiguous():
+                raise ValueError(f"Graph: workspace must be a contiguous uint8 tensor of >= {nbytes} bytes on {edge_index.device}")
+            self.ws = ws
+        else:
+            self.ws = torch.empty(nbytes, dtype=torch.uint8, device=edge_index.device)
         self.c = b3d_graph()
         check(lib.b3d_graph_build(edge_index.data_ptr(), self.N, self.E, self.ws.data_ptr(), nbytes,
                                   C.byref(self.c), current_stream(edge_index.device)), "b3d_graph_build")
@@ -326,6 +336,10 @@ class Graph:
             bad = self.invalid_edges()
             if bad:
                 raise ValueError(f"edge_index has {bad} edge(s) with an endpoint outside [0, {self.N})")
+
+    @staticmethod
+    def workspace_bytes(num_nodes: int, num_edges: int) -> int:
+        return int(load().b3d_graph_workspace_bytes(int(num_nodes), int(num_edges)))
 
     def invalid_edges(self) -> int:
         """Number of edges with an endpoint outside [0, N) (synchronises)."""

@@ -510,6 +510,32 @@ class GNN(nn.Module):
             return modality_row_ids(lidar_feats), modality_row_ids(radar_feats)
         return self.modality_rows_end(self.modality_rows_begin(data))
 
+    def modality_rows_into(self, data, static_rows, mismatch: torch.Tensor) -> None:
+        """``modality_rows`` without a host read-back, for a caller that has fixed the two counts beforehand -- a hipGraph-captured
+        step, where they are the shapes of everything behind them: the row ids of ``data`` are written into ``static_rows`` =
+        (lidar ids [nl], radar ids [nr]) (int64, device) on the CURRENT stream (capturable), and ``mismatch`` (int32 [1], device) is
+        incremented for each modality whose real count differs from the buffer's length.  The caller reads ``mismatch`` whenever it
+        next synchronises (``bench.py``: after the timed region) -- the replay of a graph on a batch with other counts must fail
+        loudly, just not per step.  Replaces the prologue's ``.item()`` (clr_att_gnn.py:107-121 is ``torch.nonzero``, a read-back)."""
+        lib = _lib.load()
+        if mismatch.dtype != torch.int32 or mismatch.numel() != 1 or not mismatch.is_cuda:
+            raise ValueError("modality_rows_into: mismatch must be a CUDA int32 tensor with one element")
+        for feats, dst in ((data.lidar_feats, static_rows[0]), (data.radar_feats, static_rows[1])):
+            n = feats.size(0)
+            if dst.dtype != torch.int64 or not dst.is_cuda or not dst.is_contiguous() or dst.numel() > n:
+                raise ValueError("modality_rows_into: static row buffers must be contiguous CUDA int64 tensors of at most N entries")
+            if n == 0:
+                continue
+            f = feats.reshape(n, -1).contiguous()
+            _lib.require_cuda(f, "modality features", torch.float32)
+            has = torch.empty(n, dtype=torch.uint8, device=f.device)
+            count = torch.empty(1, dtype=torch.int32, device=f.device)
+            # (a zero-length buffer still gets a valid pointer: the kernel writes nothing past `expected`)
+            rows_ptr = dst.data_ptr() if dst.numel() else has.data_ptr()
+            _lib.check(lib.b3d_modality_rows_expect(f.data_ptr(), n, f.size(1), has.data_ptr(), rows_ptr, int(dst.numel()),
+                                                    count.data_ptr(), mismatch.data_ptr(), _lib.current_stream(f.device)),
+                       "b3d_modality_rows_expect")
+
     def modality_rows_begin(self, data) -> PendingRows:
         """Enqueue the masks + compactions of ``data`` (on ``self.mask_stream`` if set) and the copy of the two counts to pinned
         host memory; nothing waits.  ``modality_rows_end`` returns the row ids."""

@@ -504,8 +504,10 @@ __global__ __launch_bounds__(256) void modality_mask_kernel(const float* __restr
 // Ascending ids of the rows with has[n] != 0 (torch.nonzero of clr_att_gnn.py:107-121's masks) and their count: ONE workgroup, a
 // ballot per wavefront and an LDS scan over the wavefronts per 1,024 rows (N is a few thousand: rocPRIM's partition + reduce +
 // lookback launches cost 75 us per modality in front of every step).
+// `cap` / `mismatch` (b3d_modality_rows_expect): at most cap ids are written, and *mismatch is incremented when the count is not cap --
+// the captured-step form, where the count is a SHAPE baked into the graph and the device, not the host, checks it.
 __global__ __launch_bounds__(1024) void compact_rows_kernel(const uint8_t* __restrict__ has, int N, long long* __restrict__ rows,
-                                                            int* __restrict__ count) {
+                                                            int* __restrict__ count, int cap, int* __restrict__ mismatch) {
   __shared__ int wsum[16];
   __shared__ int base_s;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -520,12 +522,15 @@ __global__ __launch_bounds__(1024) void compact_rows_kernel(const uint8_t* __res
     __syncthreads();
     int off = base_s;
     for (int w = 0; w < wave; ++w) off += wsum[w];
-    if (f) rows[off + below] = n;
+    if (f && off + below < cap) rows[off + below] = n;
     __syncthreads();
     if (tid == 0) { int t = 0; for (int w = 0; w < 16; ++w) t += wsum[w]; base_s += t; }
     __syncthreads();
   }
-  if (tid == 0) *count = base_s;
+  if (tid == 0) {
+    *count = base_s;
+    if (mismatch && base_s != cap) atomicAdd(mismatch, 1);
+  }
 }
 
 struct LinPtrs { const float* w; const float* b; };
@@ -552,7 +557,10 @@ static int check_weights(const b3d_clr_weights* pw) {
   return B3D_OK;
 }
 
-static int pack_all(const b3d_clr_weights* pw, Ws& w, bool training, bool knn, hipStream_t stream) {
+// `bwd_stream`: where the images only the backward sweep reads (transposed weights, the backward fragment streams) are packed --
+// the launch stream, or (round 6) a library side stream forked at the forward's entry and joined at its end: ~40 % of the packing
+// leaves the launch stream's chain and runs under the forward's kernels.
+static int pack_all(const b3d_clr_weights* pw, Ws& w, bool training, bool knn, hipStream_t stream, hipStream_t bwd_stream) {
   LinPtrs L[LIN_COUNT];
   gather_linears(pw, L);
   PackDesc d[224];
@@ -599,6 +607,7 @@ static int pack_all(const b3d_clr_weights* pw, Ws& w, bool training, bool knn, h
   }
   for (int cc = 0; cc < 4; ++cc)
     d[n++] = pack_slice<Att0Seq>(cc, w.wp_att0, a0.w + (size_t)128 * cc * 640 + 2 * XS, nullptr, 128, 64, 640, 0, 128, false);
+  const int n_fwd = n;
   if (training) {
     T(SeqClsT{}, 0, w.wp_clsT, C3); T(SeqClsT{}, 1, w.wp_clsT, C2); T(SeqClsT{}, 2, w.wp_clsT, C1); T(SeqClsT{}, 3, w.wp_clsT, C0);
     T(SeqEET{}, 0, w.wp_eeT, EE2); T(SeqEET{}, 1, w.wp_eeT, EE1);
@@ -632,7 +641,8 @@ static int pack_all(const b3d_clr_weights* pw, Ws& w, bool training, bool knn, h
     d[n++] = pack_slice<SeqAT0eT>(0, w.wp_at0eT, a0.w + 2 * XS, nullptr, 64, 512, 640, 0, 64, true);
   }
   if (n > 224) return fail(B3D_ERR_ARG, "pack descriptor table overflow");
-  B3D_TRY(pack_images(d, n, stream));
+  B3D_TRY(pack_images(d, n_fwd, stream));
+  if (n > n_fwd) B3D_TRY(pack_images(d + n_fwd, n - n_fwd, bwd_stream));
   FragDesc f[kFragMax];
   int m = 0;
   using FS = ES::Fwd;
@@ -643,6 +653,7 @@ static int pack_all(const b3d_clr_weights* pw, Ws& w, bool training, bool knn, h
   f[m++] = frag_desc<FS>(4, w.wp_efwd2, L[FU1].w, L[FU1].b, kDims[FU1].K, false);
   f[m++] = frag_desc<FS>(5, w.wp_efwd2, pa0.w + DX, nullptr, MIN, false);
   f[m++] = frag_desc<FS>(6, w.wp_efwd2, L[PA1].w, L[PA1].b, kDims[PA1].K, false);
+  const int m_fwd = m;
   if (training) {
     using BS = ES::Bwd;
     f[m++] = frag_desc<BS>(0, w.wp_ebwd2, L[PA1].w, nullptr, kDims[PA1].K, true);
@@ -657,7 +668,8 @@ static int pack_all(const b3d_clr_weights* pw, Ws& w, bool training, bool knn, h
     f[m++] = frag_desc<NS>(1, w.wp_ebwd_nm2, L[EU1].w, nullptr, kDims[EU1].K, true);
     f[m++] = frag_desc<NS>(2, w.wp_ebwd_nm2, eu0.w + 2 * DX, nullptr, EIN, true);
   }
-  B3D_TRY(pack_frags(f, m, stream));
+  B3D_TRY(pack_frags(f, m_fwd, stream));
+  if (m > m_fwd) B3D_TRY(pack_frags(f + m_fwd, m - m_fwd, bwd_stream));
   return B3D_OK;
 }
 
@@ -735,7 +747,20 @@ extern "C" int b3d_modality_rows(const float* feats, int32_t N, int32_t width, u
     hipLaunchKernelGGL(modality_mask_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, feats, N, width, has);
     B3D_TRY(launch_check("modality_mask_kernel"));
   }
-  hipLaunchKernelGGL(compact_rows_kernel, dim3(1), dim3(1024), 0, stream, has, N, (long long*)rows, count);
+  hipLaunchKernelGGL(compact_rows_kernel, dim3(1), dim3(1024), 0, stream, has, N, (long long*)rows, count, N, (int*)nullptr);
+  return launch_check("compact_rows_kernel");
+}
+
+extern "C" int b3d_modality_rows_expect(const float* feats, int32_t N, int32_t width, uint8_t* has, int64_t* rows, int32_t expected,
+                                        int32_t* count, int32_t* mismatch, b3d_stream stream_) {
+  B3D_REQUIRE(feats && has && rows && count && mismatch && N >= 0 && width > 0 && expected >= 0 && expected <= N,
+              "b3d_modality_rows_expect: bad argument");
+  hipStream_t stream = (hipStream_t)stream_;
+  if (N > 0) {
+    hipLaunchKernelGGL(modality_mask_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, feats, N, width, has);
+    B3D_TRY(launch_check("modality_mask_kernel"));
+  }
+  hipLaunchKernelGGL(compact_rows_kernel, dim3(1), dim3(1024), 0, stream, has, N, (long long*)rows, count, expected, mismatch);
   return launch_check("compact_rows_kernel");
 }
 
@@ -776,7 +801,13 @@ extern "C" int b3d_clr_forward(const b3d_clr_weights* pw, const b3d_graph* g, co
   if (flags & B3D_FLAG_RUN_DEAD_KNN)
     B3D_REQUIRE(pw->knn_conv.lin && pw->knn_conv.att_src && pw->knn_conv.att_dst && pw->knn_conv.bias,
                 "b3d_clr_forward: knn_conv pointers are required with B3D_FLAG_RUN_DEAD_KNN");
-  B3D_TRY(pack_all(pw, w, tr, (flags & B3D_FLAG_RUN_DEAD_KNN) != 0, stream));
+  Side* pack_side = nullptr;
+  static const bool pack_on_side = []() { const char* ev = getenv("B3D_PACK_SIDE"); return ev && atoi(ev) != 0; }();   // A/B switch, default OFF: measured neutral (round 6: 3.976 / 3.981 vs 3.963 / 3.958 ms) -- with the encode-ahead branch beside it the step is bound by the SUM of its kernels, not by the launch stream's chain
+  if (tr && !(flags & B3D_FLAG_SINGLE_STREAM) && pack_on_side) {
+    B3D_TRY(side_get(1, &pack_side));
+    B3D_TRY(side_fork(stream, pack_side));                  // (the images' previous readers -- the last backward sweep -- are behind us on `stream`)
+  }
+  B3D_TRY(pack_all(pw, w, tr, (flags & B3D_FLAG_RUN_DEAD_KNN) != 0, stream, pack_side ? pack_side->s : stream));
 
   // ---- the part that does not read the frozen encoders' outputs: edge / node encoder, layer 0's per-node table, the
   //      first k-NN block (x[0]); the encoders may still be running on other streams (b3d_clr_inputs::encoders_ready) ----
@@ -884,6 +915,7 @@ extern "C" int b3d_clr_forward(const b3d_clr_weights* pw, const b3d_graph* g, co
     B3D_HIP_CHECK(hipMemcpyAsync(out_prob, w.prob, (size_t)E * sizeof(float), hipMemcpyDeviceToDevice, stream));
   }
   if (knn_side && !((flags & B3D_FLAG_DEFER_SIDE_JOIN) && (flags & B3D_FLAG_TRAINING))) B3D_TRY(side_join(knn_side, stream));
+  if (pack_side) B3D_TRY(side_join(pack_side, stream));     // the backward images are complete before the caller can enqueue the sweep
   return B3D_OK;
 }
 

@@ -94,51 +94,54 @@ __global__ __launch_bounds__(kWaves * 64, kWgPerCu) void edge_fwd_kernel(const E
         for (int b = 0; b < H1B; ++b) h1[rb][b] += tb[rb][b];
     }
     // ---- edge_update ----
+    // (the loads / stores of a layer boundary travel as the next layer's hook: issued in front of it, or -- kLate -- inside its first step)
     {
       Bf3 x0[kRB][(EB + AB) / 2];
       split_blocks<EB + AB>(ein, x0);
       layer<S, 0, true, false, true>(ring, more, st, x0, h1);
     }
-    if constexpr (TRAIN) { store_rows<H1B>(a.sH1, row, D::EH1, h1); store_masks<H1B, 0>(a.rmask, row, h1); }
     v4f fi[kRB][MHB];
-    load_rows<MHB>(a.T, d, H::TW, H::OF, fi);
     v4f h2[kRB][H2B];
     {
       Bf3 x1[kRB][H1B / 2];
       split_blocks<H1B>(h1, x1);
-      layer<S, 1, true, true, false>(ring, more, st, x1, h2);
+      layer<S, 1, true, true, false>(ring, more, st, x1, h2, [&]() {
+        if constexpr (TRAIN) { store_rows<H1B>(a.sH1, row, D::EH1, h1); store_masks<H1B, 0>(a.rmask, row, h1); }
+        load_rows<MHB>(a.T, d, H::TW, H::OF, fi);
+      });
     }
-    if constexpr (TRAIN) { store_rows<H2B>(a.sH2, row, D::EH2, h2); store_masks<H2B, 2>(a.rmask, row, h2); }
     v4f pi[kRB][MHB];
-    load_rows<MHB>(a.T, s, H::TW, H::OP, pi);
     v4f en[kRB][EB];
     {
       Bf3 x2[kRB][H2B / 2];
       split_blocks<H2B>(h2, x2);
-      layer<S, 2, false, true, false>(ring, more, st, x2, en);
+      layer<S, 2, false, true, false>(ring, more, st, x2, en, [&]() {
+        if constexpr (TRAIN) { store_rows<H2B>(a.sH2, row, D::EH2, h2); store_masks<H2B, 2>(a.rmask, row, h2); }
+        load_rows<MHB>(a.T, s, H::TW, H::OP, pi);
+      });
     }
-    store_rows<EB>(a.e_out, row, D::DE, en);
     Bf3 xe[kRB][EB / 2];
     split_blocks<EB>(en, xe);
     // ---- create_future_msgs ----
-    layer<S, 3, true, false, true>(ring, more, st, xe, fi);
-    if constexpr (TRAIN) { store_rows<MHB>(a.sF1, row, D::MH, fi); store_masks<MHB, 0>(a.rmask2, row, fi); }
+    layer<S, 3, true, false, true>(ring, more, st, xe, fi, [&]() { store_rows<EB>(a.e_out, row, D::DE, en); });
+    v4f mo[kRB][DMB];
     {
-      v4f mo[kRB][DMB];
       Bf3 x4[kRB][MHB / 2];
       split_blocks<MHB>(fi, x4);
-      layer<S, 4, false, true, false>(ring, more, st, x4, mo);
-      store_rows<DMB>(a.fut, row, D::DM, mo);
+      layer<S, 4, false, true, false>(ring, more, st, x4, mo, [&]() {
+        if constexpr (TRAIN) { store_rows<MHB>(a.sF1, row, D::MH, fi); store_masks<MHB, 0>(a.rmask2, row, fi); }
+      });
     }
     // ---- create_past_msgs ----
-    layer<S, 5, true, false, true>(ring, more, st, xe, pi);
-    if constexpr (TRAIN) { store_rows<MHB>(a.sP1, row, D::MH, pi); store_masks<MHB, 2>(a.rmask2, row, pi); }
+    layer<S, 5, true, false, true>(ring, more, st, xe, pi, [&]() { store_rows<DMB>(a.fut, row, D::DM, mo); });
     {
-      v4f mo[kRB][DMB];
+      v4f mp[kRB][DMB];
       Bf3 x6[kRB][MHB / 2];
       split_blocks<MHB>(pi, x6);
-      layer<S, 6, false, true, false>(ring, more, st, x6, mo);
-      store_rows<DMB>(a.past, row, D::DM, mo);
+      layer<S, 6, false, true, false>(ring, more, st, x6, mp, [&]() {
+        if constexpr (TRAIN) { store_rows<MHB>(a.sP1, row, D::MH, pi); store_masks<MHB, 2>(a.rmask2, row, pi); }
+      });
+      store_rows<DMB>(a.past, row, D::DM, mp);
     }
   }
 }
@@ -189,25 +192,28 @@ __global__ __launch_bounds__(kWaves * 64, kWgPerCu) void edge_bwd_kernel(const E
     u4v mka[kRB], mkb[kRB];                                    // the forward's ReLU masks of this lane's values (128 bytes per edge)
     if constexpr (MSGS) load_mask_plane(a.rmask2, rc, mkb);    // sF1 | sP1
     else load_mask_plane(a.rmask, rc, mka);                    // sH1 | sH2 (MSGS: behind the message layers)
+    v4f d2[kRB][H2B], d1[kRB][H1B], dein[kRB][EB + AB];
+    v4f prev[kRB][AB];
     if constexpr (MSGS) {
       unsigned s[kRB], d[kRB];
 #pragma unroll
       for (int rb = 0; rb < kRB; ++rb) { s[rb] = (unsigned)a.src[rc[rb]]; d[rb] = (unsigned)a.dst[rc[rb]]; }
       v4f dmp[kRB][DMB], dmf[kRB][DMB];
       load_rows<DMB>(a.dM, d, 2 * D::DM, 0, dmp);             // past messages were summed at dst
-      v4f dh[kRB][MHB], dee[kRB][EB];
+      v4f dh[kRB][MHB], dee[kRB][EB], dh2[kRB][MHB];
       {
         Bf3 x0[kRB][DMB / 2];
         split_blocks<DMB>(dmp, x0);
         layer<S, 0, false, false, false>(ring, more, st, x0, dh);
       }
       relu_bwd_mask<MHB, 2>(dh, mkb);
-      store_rows<MHB>(a.GdP1, row, D::MH, dh);
-      load_rows<DMB>(a.dM, s, 2 * D::DM, D::DM, dmf);         // future messages were summed at src (needed a layer from here)
       {
         Bf3 x1[kRB][MHB / 2];
         split_blocks<MHB>(dh, x1);
-        layer<S, 1, false, false, false>(ring, more, st, x1, dee);
+        layer<S, 1, false, false, false>(ring, more, st, x1, dee, [&]() {
+          store_rows<MHB>(a.GdP1, row, D::MH, dh);
+          load_rows<DMB>(a.dM, s, 2 * D::DM, D::DM, dmf);     // future messages were summed at src (needed a layer from here)
+        });
       }
 #pragma unroll
       for (int rb = 0; rb < kRB; ++rb)
@@ -216,45 +222,46 @@ __global__ __launch_bounds__(kWaves * 64, kWgPerCu) void edge_bwd_kernel(const E
       {
         Bf3 x2[kRB][DMB / 2];
         split_blocks<DMB>(dmf, x2);
-        layer<S, 2, false, false, false>(ring, more, st, x2, dh);
+        layer<S, 2, false, false, false>(ring, more, st, x2, dh2);
       }
-      relu_bwd_mask<MHB, 0>(dh, mkb);
-      store_rows<MHB>(a.GdF1, row, D::MH, dh);
-      load_mask_plane(a.rmask, rc, mka);
+      relu_bwd_mask<MHB, 0>(dh2, mkb);
       {
         Bf3 x3[kRB][MHB / 2];
-        split_blocks<MHB>(dh, x3);
-        layer<S, 3, false, false, false>(ring, more, st, x3, dee);
+        split_blocks<MHB>(dh2, x3);
+        layer<S, 3, false, false, false>(ring, more, st, x3, dee, [&]() {
+          store_rows<MHB>(a.GdF1, row, D::MH, dh2);
+          load_mask_plane(a.rmask, rc, mka);
+        });
       }
 #pragma unroll
       for (int rb = 0; rb < kRB; ++rb)
 #pragma unroll
         for (int b = 0; b < EB; ++b) de[rb][b] += dee[rb][b];
-      store_rows<EB>(a.Gde, row, D::DE, de);
-    } else {
-      store_rows<EB>(a.Gde, row, D::DE, de);
     }
-    v4f d2[kRB][H2B], d1[kRB][H1B], dein[kRB][EB + AB];
     {
       Bf3 x4[kRB][EB / 2];
       split_blocks<EB>(de, x4);
-      layer<S, L0 + 0, false, false, false>(ring, more, st, x4, d2);
+      if constexpr (MSGS) {
+        layer<S, L0 + 0, false, false, false>(ring, more, st, x4, d2, [&]() { store_rows<EB>(a.Gde, row, D::DE, de); });
+      } else {
+        store_rows<EB>(a.Gde, row, D::DE, de);                  // (in front of chunk 0: drained by the first rendezvous like the tile's loads)
+        layer<S, L0 + 0, false, false, false>(ring, more, st, x4, d2);
+      }
     }
     relu_bwd_mask<H2B, 2>(d2, mka);
-    store_rows<H2B>(a.GdH2, row, D::EH2, d2);
     {
       Bf3 x5[kRB][H2B / 2];
       split_blocks<H2B>(d2, x5);
-      layer<S, L0 + 1, false, false, false>(ring, more, st, x5, d1);
+      layer<S, L0 + 1, false, false, false>(ring, more, st, x5, d1, [&]() { store_rows<H2B>(a.GdH2, row, D::EH2, d2); });
     }
     relu_bwd_mask<H1B, 0>(d1, mka);
-    store_rows<H1B>(a.GdH1, row, D::EH1, d1);
-    v4f prev[kRB][AB];
-    load_rows<AB>(a.da_acc, rc, D::DA, 0, prev);
     {
       Bf3 x6[kRB][H1B / 2];
       split_blocks<H1B>(d1, x6);
-      layer<S, L0 + 2, false, false, false>(ring, more, st, x6, dein);
+      layer<S, L0 + 2, false, false, false>(ring, more, st, x6, dein, [&]() {
+        store_rows<H1B>(a.GdH1, row, D::EH1, d1);
+        load_rows<AB>(a.da_acc, rc, D::DA, 0, prev);
+      });
     }
     {
       v4f o[kRB][EB], da[kRB][AB];

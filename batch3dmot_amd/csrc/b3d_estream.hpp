@@ -53,6 +53,14 @@ constexpr int kRB = B3D_ES_RB;
 #ifndef B3D_ES_SLOTS
 #define B3D_ES_SLOTS 3
 #endif
+// EXPERIMENT (round 6, -DB3D_ES_LATE=1): the ordinary loads / stores of a layer boundary are issued BEHIND the rendezvous of the
+// layer's first chunk and behind ALL refill pieces of that chunk (issued at its step 0 instead of spread over its steps): the pieces
+// the next rendezvous waits for are then OLDER than the stores, so a counted wait passes them -- vmcnt is in order, and as shipped the
+// wait one chunk later (vmcnt(0)) drains the boundary's stores; late, they get two chunks.
+#ifndef B3D_ES_LATE
+#define B3D_ES_LATE 0
+#endif
+constexpr bool kLate = B3D_ES_LATE != 0;
 constexpr int kWaves = B3D_ES_WAVES, kTileRows = kWaves * 16 * kRB;    // rows per workgroup
 constexpr int kWgPerCu = (kRB == 1 && kWaves == 4) ? 2 : 1;
 constexpr int kChunkSteps = 4, kStepBytes = 6144, kChunkBytes = kChunkSteps * kStepBytes, kSlots = B3D_ES_SLOTS;
@@ -154,7 +162,14 @@ struct Ring {
   // Pieces of this wavefront younger than its pieces of chunk C + 1 when rendezvous<C> waits: none (chunk C + 2 is issued behind the
   // barrier) -- only the ordinary loads / stores in front of chunk C.
   template <int C>
-  static constexpr int pending() { const int p = HK::before(C); return p < 63 ? p : 63; }
+  static constexpr int pending() {
+    // kLate: the boundary operations of chunk C - 1 (issued behind that chunk's rendezvous and behind the pieces of chunk C + 1)
+    const int p = kLate ? (C >= 1 ? HK::before(C - 1) : 0) : HK::before(C);
+    return p < 63 ? p : 63;
+  }
+  // kLate: does chunk C carry boundary operations (then all its refill pieces are issued at step 0, in front of them)?
+  template <int C>
+  static constexpr bool late_chunk() { return kLate && HK::before(C) > 0; }
   // Stream start (once per kernel): the biases and chunks 0, 1 in flight, then complete for everybody.
   __device__ __forceinline__ void start() {
     if constexpr (S::BIAS_BYTES / kWaves == 2048) {
@@ -182,6 +197,13 @@ struct Ring {
     if constexpr (C == 0) { if (first) { first = false; return; } }
     wait_vm<pending<C>()>();
     if constexpr ((B3D_ES_ABL & 16) == 0) __builtin_amdgcn_s_barrier();
+  }
+  template <int C>
+  __device__ __forceinline__ void refill_all(bool more) {
+    constexpr int NXT = C + kSlots - 1;
+    if constexpr ((B3D_ES_ABL & 1) != 0) return;
+    if constexpr (NXT < S::NCH) issue_pieces<NXT, 0, kPiecesPerWave>();
+    else if (more) issue_pieces<NXT - S::NCH, 0, kPiecesPerWave>();
   }
   // in front of step J of chunk C: this step's share of the pieces of chunk C + 2
   template <int C, int J>
@@ -264,8 +286,10 @@ struct StepState {
 
 // One step of layer LI: 32 inputs (group ks) against the output blocks 2 ob, 2 ob + 1.  io[b] holds the initial value (INIT) on
 // entry of a block and the activation on exit.
-template <class S, int LI, int ST, bool RELU, bool BIAS, bool INIT, class RingT>
-__device__ __forceinline__ void step(RingT& ring, bool more, StepState& st, const Bf3 (&x)[kRB][S::k(LI) / 32], v4f (&io)[kRB][S::n(LI) / 16]) {
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+template <class S, int LI, int ST, bool RELU, bool BIAS, bool INIT, class RingT, class Hook>
+__device__ __forceinline__ void step(RingT& ring, bool more, StepState& st, const Bf3 (&x)[kRB][S::k(LI) / 32], v4f (&io)[kRB][S::n(LI) / 16],
+                                     Hook& hook) {
   constexpr int KS = S::k(LI) / 32;
   constexpr int ob = ST / KS, ks = ST % KS;
   constexpr int GST = S::first_step(LI) + ST;                    // step of the tile
@@ -274,7 +298,12 @@ __device__ __forceinline__ void step(RingT& ring, bool more, StepState& st, cons
     ring.template rendezvous<CJ>();
     st.base = ring.template slot_addr<CJ>();       // (its first fragments were fetched during the previous step)
   }
-  ring.template refill<CJ, IN_CHUNK>(more);
+  if constexpr (RingT::template late_chunk<CJ>()) {
+    static_assert(ST < kChunkSteps, "boundary operations belong to the first chunk of a layer");
+    if constexpr (ST == 0) { ring.template refill_all<CJ>(more); hook(); }
+  } else {
+    ring.template refill<CJ, IN_CHUNK>(more);
+  }
   if constexpr (ks == 0) {
     v4f a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
     if constexpr (BIAS) {
@@ -306,15 +335,18 @@ __device__ __forceinline__ void step(RingT& ring, bool more, StepState& st, cons
     }
   }
 }
-template <class S, int LI, bool RELU, bool BIAS, bool INIT, class RingT, int... ST>
+template <class S, int LI, bool RELU, bool BIAS, bool INIT, class RingT, class Hook, int... ST>
 __device__ __forceinline__ void layer_impl(RingT& ring, bool more, const Bf3 (&x)[kRB][S::k(LI) / 32], v4f (&io)[kRB][S::n(LI) / 16],
-                                           StepState& st, std::integer_sequence<int, ST...>) {
-  (step<S, LI, ST, RELU, BIAS, INIT>(ring, more, st, x, io), ...);
+                                           StepState& st, Hook& hook, std::integer_sequence<int, ST...>) {
+  (step<S, LI, ST, RELU, BIAS, INIT>(ring, more, st, x, io, hook), ...);
 }
-// io = act(W . x (+ b) (+ io)) for every row block of the wavefront
-template <class S, int LI, bool RELU, bool BIAS, bool INIT, class RingT>
-__device__ __forceinline__ void layer(RingT& ring, bool more, StepState& st, const Bf3 (&x)[kRB][S::k(LI) / 32], v4f (&io)[kRB][S::n(LI) / 16]) {
-  layer_impl<S, LI, RELU, BIAS, INIT>(ring, more, x, io, st, std::make_integer_sequence<int, S::steps(LI)>{});
+// io = act(W . x (+ b) (+ io)) for every row block of the wavefront.  `hook`: the ordinary loads / stores of the layer boundary in front
+// of this layer (HK::before(first_chunk(LI)) of them): issued here, in front of the layer -- or, kLate, inside its first step.
+template <class S, int LI, bool RELU, bool BIAS, bool INIT, class RingT, class Hook = NoHook>
+__device__ __forceinline__ void layer(RingT& ring, bool more, StepState& st, const Bf3 (&x)[kRB][S::k(LI) / 32], v4f (&io)[kRB][S::n(LI) / 16],
+                                      Hook hook = Hook{}) {
+  if constexpr (!RingT::template late_chunk<S::first_chunk(LI)>()) hook();
+  layer_impl<S, LI, RELU, BIAS, INIT>(ring, more, x, io, st, hook, std::make_integer_sequence<int, S::steps(LI)>{});
 }
 
 template <int NB>

@@ -211,6 +211,37 @@ class EncodeAhead:
         self.pending = (data, have, static is not None)
         return tuple(out)
 
+    def launch_graph(self, data, ws=None):
+        """The NEXT batch's graph structure (CSR by destination + CSC by source, ``b3d_graph_build``: four integer kernels) on the
+        side stream, under the current step -- SURVEY.md 8f #2 ("pre-build dst-CSR + src-CSC once"); it depends on ``edge_index``
+        only.  Left in ``data._b3d_graph``, where ``GNN.forward`` looks for it; ``take`` joins the side stream.  ``ws``: a caller-owned
+        ``uint8`` buffer of ``_lib.Graph.workspace_bytes(N, E)`` bytes (fixed addresses, for hipGraph-captured steps)."""
+        from . import _lib
+        dev = data.pose_feats.device
+        if self.stream is None or self.stream.device != dev:
+            self.stream = torch.cuda.Stream(dev)
+        self.stream.wait_stream(torch.cuda.current_stream(dev))
+        ei = data.edge_index
+        with torch.cuda.stream(self.stream):
+            g = _lib.Graph(ei if ei.is_contiguous() else ei.contiguous(), data.pose_feats.size(0),
+                           validated=getattr(data, "_b3d_valid_edge_index", None) is ei, ws=ws)
+            if not torch.cuda.is_current_stream_capturing():
+                ei.record_stream(self.stream)
+        data._b3d_graph = g
+        self._graph_for = data
+        return g
+
+    def launch_rows(self, data, static_rows, mismatch):
+        """The NEXT batch's modality row ids on the side stream, written into ``static_rows`` with the counts checked on the device
+        (``GNN.modality_rows_into``): the prologue of a hipGraph-captured step without a host read-back.  Call before the
+        ``launch(..., rows=static_rows)`` calls that consume them (same stream: ordered)."""
+        dev = data.pose_feats.device
+        if self.stream is None or self.stream.device != dev:
+            self.stream = torch.cuda.Stream(dev)
+        self.stream.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(self.stream):
+            self.gnn.modality_rows_into(data, static_rows, mismatch)
+
     def take(self, data):
         if self.pending is None or self.pending[0] is not data:
             raise RuntimeError("EncodeAhead.take: this batch was not the one launched")

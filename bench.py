@@ -223,6 +223,8 @@ class Workload:
         self.rows_static = None
         self.ahead = None
         self.enc_static = None
+        self.graph_ws = None
+        self.row_mismatch = None                                 # device counter: a replayed batch whose modality counts differ from the captured ones
         self._pending = None
         if kind == "clr":
             rows = [self.model.modality_rows(b) for b in self.pool]
@@ -242,16 +244,35 @@ class Workload:
                     f32, i32 = dict(dtype=torch.float32, device=dev), dict(dtype=torch.int32, device=dev)
                     self.enc_static = [(torch.zeros(self.n_nodes, 96, **f32), torch.zeros(r[0].numel(), 256, **f32), torch.zeros(r[0].numel(), **i32),
                                         torch.zeros(r[1].numel(), 256, **f32), torch.zeros(r[1].numel(), **i32)) for r in rows]
+                    # ... and the CSR / CSC structure of batch k + 1 (round 6: EncodeAhead.launch_graph, one build per step as before,
+                    # a step earlier), into per-batch static buffers
+                    # ... and its modality row ids (round 6: masks + compaction inside the captured step, on the same side stream, the
+                    # counts -- shapes of the captured graph -- checked on the DEVICE: no eager prologue, no host read-back per step)
+                    if os.environ.get("B3D_ROWS_IN_GRAPH", "1") != "0":               # A/B switch
+                        self.row_mismatch = torch.zeros(1, dtype=torch.int32, device=dev)
+                    from batch3dmot_amd import _lib
+                    if os.environ.get("B3D_GRAPH_AHEAD", "0") != "0":                 # A/B switch, default OFF: measured neutral (3.974 / 3.981 vs 3.963 / 3.958 ms)
+                      self.graph_ws = [torch.empty(_lib.Graph.workspace_bytes(self.n_nodes, b.edge_index.size(1)), dtype=torch.uint8, device=dev)
+                                     for b in self.pool]
+                      for kb, b in enumerate(self.pool):         # every pool batch holds a structure in ITS static buffer from here on
+                        self.ahead.launch_graph(b, ws=self.graph_ws[kb])
                     self.ahead.launch(self.pool[0], rows=self.rows_static[0], static=self.enc_static[0])
                     self.ahead.take(self.pool[0])
 
     def _run(self, i, kwargs, after_forward=None):
         from batch3dmot_amd.train_step import train_step
         b = self.pool[i % len(self.pool)]
+        keep_graph = None
         if hasattr(b, "_b3d_graph"):
-            del b._b3d_graph                     # the CSR/CSC build is part of every step
+            if self.graph_ws is not None and kwargs is not None and "encoded" in kwargs and self.enc is None:
+                pass                             # encode-ahead step: the structure was built under the previous step (launch_graph)
+            else:
+                keep_graph = b._b3d_graph if self.graph_ws is not None else None
+                del b._b3d_graph                 # the CSR/CSC build is part of every step
         ret = train_step(self.model, b, self.opt, batch_size=self.graphs, loss_kind="cb", logits=self.logits, grad_sync=self.sync,
                          forward_kwargs=kwargs, after_forward=after_forward)
+        if keep_graph is not None:
+            b._b3d_graph = keep_graph            # (a serial pass in between: the encode-ahead steps keep finding the static structure)
         if self.ap_metrics:
             from batch3dmot_amd import metrics
             scores = torch.sigmoid(ret[1]) if self.logits else ret[1]
@@ -261,7 +282,7 @@ class Workload:
     def _run_fb(self, i, kwargs, after_forward=None):
         from batch3dmot_amd.train_step import forward_backward
         b = self.pool[i % len(self.pool)]
-        if hasattr(b, "_b3d_graph"):
+        if hasattr(b, "_b3d_graph") and not (self.graph_ws is not None and kwargs is not None and "encoded" in kwargs and self.enc is None):
             del b._b3d_graph
         return forward_backward(self.model, b, self.opt, batch_size=self.graphs, loss_kind="cb", logits=self.logits, forward_kwargs=kwargs,
                                 after_forward=after_forward)
@@ -288,6 +309,10 @@ class Workload:
         """Step i with the encoders of the NEXT pool batch underneath it: fork (side stream) -> encoders(k + 1) into their static
         buffers | step(k) on the outputs the previous step left for batch k -> join."""
         k, kn = i % len(self.pool), (i + 1) % len(self.pool)
+        if self.graph_ws is not None:
+            self.ahead.launch_graph(self.pool[kn], ws=self.graph_ws[kn])     # one CSR / CSC build per step: the next batch's
+        if self.row_mismatch is not None and rows_next is not None:
+            self.ahead.launch_rows(self.pool[kn], rows_next, self.row_mismatch)   # (captured steps: rows_next IS rows_static[kn])
         launch = lambda parts="all": self.ahead.launch(self.pool[kn], rows=rows_next, static=self.enc_static[kn], parts=parts)       # noqa: E731
         # Where the next batch's encoders enter the current step (same work, same bits; A/B on one box, three rounds each, round 5):
         # everything in front of the forward 4.21 / 4.24 / 4.22 ms, everything behind the forward 4.17 / 4.23 / 4.23, ResNetAE in
@@ -334,8 +359,8 @@ class Workload:
         launches of the batch step i + 1 needs are enqueued here, in front of replay i, and the counts of the batch THIS step needs
         (begun in front of replay i - 1) are read and handed to the replay: the host never waits behind a running step
         (GNN.modality_rows_begin / _end)."""
-        if self.rows_static is None:
-            return
+        if self.rows_static is None or self.row_mismatch is not None:
+            return                                                # (round 6, encode-ahead: masks + compaction are inside the captured step)
         shift = 1 if self.ahead is not None else 0                # the batch whose encoders run in this step
         k, kn = (i + shift) % len(self.pool), (i + 1 + shift) % len(self.pool)
         if self._pending is None or self._pending[0] != k:
@@ -370,7 +395,8 @@ class Workload:
                else "encoder outputs precomputed")
         if self.ahead is not None:
             enc += (" (one encoder pass per step, enqueued for the NEXT pool batch on a side stream under this batch's step -- ResNetAE under "
-                    "its forward, PointNet / RadarNet under its backward sweep: train_step.EncodeAhead)")
+                    "its forward, PointNet / RadarNet under its backward sweep: train_step.EncodeAhead"
+                    + ("; the next batch's CSR/CSC build on the same side stream" if self.graph_ws is not None else "") + ")")
         name = "camera+LiDAR+radar" if self.modalities == "clr" else "camera+LiDAR (radar rows all zero)"
         return (name + " GNN (clr_att_gnn) depth 6, training step (modality masks + " + enc
                 + " + CSR/CSC build + fwd + cb-BCE + bwd + Adam" + (" + flat RCCL grad all-reduce of 5.24 MB" if world > 1 else "")
@@ -650,6 +676,9 @@ def measure(wl: Workload, args, world, dist, steps, warmup, ramp_ms, use_graph):
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if getattr(wl, "row_mismatch", None) is not None and int(wl.row_mismatch.item()) != 0:
+        raise RuntimeError("a replayed step saw modality row counts that differ from the captured graph's (device-side check of "
+                           "GNN.modality_rows_into): the timed region is invalid")
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
     trace(f"timed region done: {1e3 * dt / steps:.3f} ms/step")
     # the replayed step against the eager step, from the same state (N = 1: at N > 1 a step holds a collective)
@@ -1006,7 +1035,9 @@ def main():
                 "host_prologue_ms_median": round(1e3 * m.get("t_pre", 0.0), 4),
                 "timed_region": ("hipGraph replay (one captured training step per pool batch"
                                  + (": forward + backward graph, eager flat all-reduce, optimizer graph" if (world > 1 or args.force_collective) else "")
-                                 + ("; the modality masks + row compaction run eagerly in front of each replay and feed it" if wl.rows_static is not None else "")
+                                 + ("; the modality masks + row compaction of the next batch are part of the captured step, their counts checked on the device"
+                                    if wl.row_mismatch is not None else
+                                    ("; the modality masks + row compaction run eagerly in front of each replay and feed it" if wl.rows_static is not None else ""))
                                  + "); kernel families timed with HIP events in an eager pass of the same K steps right after it")
                                 if m["graphs"] else ("eager" + (f" ({m['graph_note']})" if m["graph_note"] else ""))}
         print(json.dumps(line))

@@ -210,6 +210,11 @@ int b3d_modality_mask(const float* feats, int32_t N, int32_t width, uint8_t* has
  * rows [N] int64 (the first *count entries are valid), count [1] int32 -- two launches, no library scan. */
 int b3d_modality_rows(const float* feats, int32_t N, int32_t width, uint8_t* has, int64_t* rows, int32_t* count,
                       b3d_stream stream);
+/* The same for a caller that has FIXED the count beforehand (a hipGraph-captured step: the count is a shape of everything behind it):
+ * at most `expected` ids are written to rows [expected]; *count receives the real count and *mismatch (int32, device) is incremented
+ * when it differs -- no host read-back; the caller inspects the flag whenever it next synchronises (clr_att_gnn.py:107-121). */
+int b3d_modality_rows_expect(const float* feats, int32_t N, int32_t width, uint8_t* has, int64_t* rows, int32_t expected,
+                             int32_t* count, int32_t* mismatch, b3d_stream stream);
 
 /* ---- one CausalMessagePassing layer as a standalone operator ------------------------------------------
  * Replaces `CausalMessagePassing.forward(x, edge_index, edge_attr, initial_x[, att_edge_attr])`

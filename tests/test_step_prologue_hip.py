@@ -1,0 +1,123 @@
+"""GPU: the parts of a step's prologue that round 6 moved off the launch stream / off the host:
+  * ``GNN.modality_rows_into`` (``b3d_modality_rows_expect``): row ids of clr_att_gnn.py:107-121 without a host read-back, the
+    counts checked on the device -- the capturable form of ``modality_rows``;
+  * ``_lib.Graph(..., ws=...)`` / ``EncodeAhead.launch_graph``: the CSR / CSC structure in a caller-owned buffer, built for the NEXT
+    batch on the side stream;
+  * roctx markers (``b3d_prof_markers``) do not disturb a forward."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(dev):
+    from batch3dmot_amd import encoders
+    from batch3dmot_amd.clr_att_gnn import GNN
+    from oracle.seeded import seeded_fill_
+    m = GNN(encoders.ResNetAE(), encoders.PointNetClassifier(k=7), encoders.RadarNetClassifier(k=7))
+    seeded_fill_(m, 77)
+    return m.to(dev)
+
+
+def test_modality_rows_into_matches_the_read_back_form_and_flags_a_mismatch():
+    from batch3dmot_amd import synth
+    dev = torch.device("cuda:0")
+    m = _model(dev)
+    data = synth.make_batch(2, 150, 900, first_graph_idx=810, modalities=True).to(dev)
+    li, ri = m.modality_rows(data)
+    n = data.pose_feats.size(0)
+    # reference semantics: torch.nonzero of the row sums
+    assert torch.equal(li, torch.nonzero(data.lidar_feats.reshape(n, -1).sum(1) != 0).squeeze(1))
+    assert torch.equal(ri, torch.nonzero(data.radar_feats.reshape(n, -1).sum(1) != 0).squeeze(1))
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    sl, sr = torch.full_like(li, -1), torch.full_like(ri, -1)
+    m.modality_rows_into(data, (sl, sr), flag)
+    torch.cuda.synchronize()
+    assert torch.equal(sl, li) and torch.equal(sr, ri) and int(flag) == 0
+    # a buffer one entry short (a batch with MORE rows than the captured graph expects): nothing is written past it, the flag says so
+    short = torch.full((li.numel() - 1,), -1, dtype=torch.int64, device=dev)
+    guard = torch.full((ri.numel() + 3,), -7, dtype=torch.int64, device=dev)
+    m.modality_rows_into(data, (short, guard[: ri.numel()]), flag)
+    torch.cuda.synchronize()
+    assert torch.equal(short, li[:-1]) and torch.equal(guard[: ri.numel()], ri) and bool((guard[ri.numel():] == -7).all())
+    assert int(flag) == 1
+    # ... and one entry long (FEWER rows than expected)
+    longer = torch.full((li.numel() + 1,), -1, dtype=torch.int64, device=dev)
+    m.modality_rows_into(data, (longer, sr), flag)
+    torch.cuda.synchronize()
+    assert torch.equal(longer[:-1], li) and int(longer[-1]) == -1 and int(flag) == 2
+    with pytest.raises(ValueError):
+        m.modality_rows_into(data, (sl.int(), sr), flag)
+
+
+def test_modality_rows_into_is_capturable():
+    from batch3dmot_amd import synth
+    dev = torch.device("cuda:0")
+    m = _model(dev)
+    data = synth.make_batch(1, 200, 1200, first_graph_idx=820, modalities=True).to(dev)
+    li, ri = m.modality_rows(data)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    sl, sr = torch.zeros_like(li), torch.zeros_like(ri)
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local"):
+        m.modality_rows_into(data, (sl, sr), flag)
+    torch.cuda.current_stream().wait_stream(s)
+    for _ in range(3):
+        sl.fill_(-1); sr.fill_(-1)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(sl, li) and torch.equal(sr, ri)
+    assert int(flag) == 0
+    data.radar_feats.zero_()                  # the next replay sees a batch without radar rows: the device-side check reports it
+    g.replay()
+    torch.cuda.synchronize()
+    assert int(flag) == (1 if ri.numel() else 0)
+
+
+def test_graph_in_a_caller_owned_buffer_and_built_ahead():
+    from batch3dmot_amd import _lib, synth
+    from batch3dmot_amd.train_step import EncodeAhead
+    dev = torch.device("cuda:0")
+    data = synth.make_batch(2, 120, 800, first_graph_idx=830, modalities=True).to(dev)
+    n, e = data.pose_feats.size(0), data.edge_index.size(1)
+    ref = _lib.Graph(data.edge_index, n).arrays()
+    ws = torch.empty(_lib.Graph.workspace_bytes(n, e) + 64, dtype=torch.uint8, device=dev)
+    own = _lib.Graph(data.edge_index, n, ws=ws)
+    assert own.ws is ws
+    for k, v in own.arrays().items():
+        assert torch.equal(v, ref[k]), k
+    with pytest.raises(ValueError):
+        _lib.Graph(data.edge_index, n, ws=ws[:100])
+    m = _model(dev).eval()
+    ahead = EncodeAhead(m)
+    if hasattr(data, "_b3d_graph"):
+        del data._b3d_graph
+    g2 = ahead.launch_graph(data, ws=ws)
+    torch.cuda.current_stream().wait_stream(ahead.stream)
+    assert data._b3d_graph is g2 and g2.ws is ws
+    for k, v in g2.arrays().items():
+        assert torch.equal(v, ref[k]), k
+    with torch.no_grad():
+        a = m(data)[0]                                   # the forward finds the structure and uses it
+        assert data._b3d_graph is g2
+        del data._b3d_graph
+        b = m(data)[0]
+    assert torch.equal(a, b)
+
+
+def test_roctx_markers_switch_on_and_off_around_a_forward():
+    from batch3dmot_amd import _lib, synth
+    from batch3dmot_amd.pose_gnn import PoseGNN
+    dev = torch.device("cuda:0")
+    data = synth.make_graph(120, None, k=5, graph_idx=840).to(dev)
+    m = PoseGNN().to(dev)
+    with torch.no_grad():
+        a = m(data)[0]
+        on = _lib.prof_markers(True)                     # False only where no roctx library exists
+        b = m(data)[0]
+        assert _lib.prof_markers(False) is False
+        c = m(data)[0]
+    torch.cuda.synchronize()
+    assert isinstance(on, bool) and torch.equal(a, b) and torch.equal(a, c)
