@@ -26,7 +26,8 @@ c_float_p = C.POINTER(C.c_float)
 class b3d_graph(C.Structure):
     _fields_ = [("N", C.c_int32), ("E", C.c_int32), ("src", C.c_void_p), ("dst", C.c_void_p),
                 ("dst_ptr", C.c_void_p), ("dst_perm", C.c_void_p), ("src_ptr", C.c_void_p),
-                ("src_perm", C.c_void_p), ("invalid_edges", C.c_void_p)]
+                ("src_perm", C.c_void_p), ("invalid_edges", C.c_void_p), ("dst_unsorted", C.c_void_p),
+                ("past_ptr", C.c_void_p), ("past_rows", C.c_void_p)]
 
 
 class b3d_linear(C.Structure):

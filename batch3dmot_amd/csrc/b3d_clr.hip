@@ -33,6 +33,11 @@ inline int zero_launch(ZeroArgs& z, hipStream_t stream) {
   return launch_check("zero_many_kernel");
 }
 
+// B3D_PAST_RUNS=0: one `past` row per edge whatever the edge order (A/B switch of the in-wave per-destination sums, b3d_edge2.hpp)
+static bool past_runs_enabled() {
+  static const bool on = []() { const char* ev = getenv("B3D_PAST_RUNS"); return !(ev && atoi(ev) == 0); }();
+  return on;
+}
 using D = DimsC;
 using DB = DimsCB;                       // hoisted kernels: bf16x3 images for the edge stacks
 using HC = Hoist<DB>;
@@ -160,6 +165,25 @@ constexpr int kTableCap = 320, kTaskCap = 32768;
 // The cooperative bf16x6 kernel (b3d_wgemm.hpp) takes every block it has a shape for; the per-wavefront streaming kernel
 // (b3d_wstream2.hpp) keeps the rest.  Both share the device tables, split in halves.
 struct Col { const float* p; const int* idx; long vstride; int stride; int col0; int width; };   // activation columns
+// EXPERIMENT (round 6, -DB3D_WGM_HYBRID=1 or B3D_WGM_HYBRID=1 in the environment; default OFF): hybrid task sizes of the cooperative
+// kernel -- the first ~3/4 of a job's rows in tasks of 4 x rows_per_task, the rest in tasks of rows_per_task, so that a matrix gets
+// half as many slabs (31,078 rows at 768 per task: 7 + 13 = 20 instead of 41).  Measured: wgrad family 584 -> 1,513 us per step
+// (gpurun_out/ab_hybrid.txt; parity green): a 768-row task of the largest shapes (six layer variants) already runs ~290 us of the
+// launch's 530, four of them in a row ARE the launch.  The slab traffic (215 MB written, 215 MB read back) is the price of tasks
+// short enough to balance.
+#ifndef B3D_WGM_HYBRID
+#define B3D_WGM_HYBRID 0
+#endif
+struct WgSplit { int r1, big, na, nb; };          // rows in long tasks, their size, number of long / short tasks
+static WgSplit wg_hybrid(long rows, int rpt) {
+  WgSplit s{0, 4 * rpt, 0, (int)((rows + rpt - 1) / rpt)};
+  static const bool on = []() { const char* ev = getenv("B3D_WGM_HYBRID"); return ev ? atoi(ev) != 0 : (B3D_WGM_HYBRID != 0); }();
+  if (!on || rows < 8L * rpt) { if (s.nb < 1) s.nb = 1; return s; }
+  s.na = (int)((rows * 3 / 4) / s.big);
+  s.r1 = s.na * s.big;
+  s.nb = (int)((rows - s.r1 + rpt - 1) / rpt);
+  return s;
+}
 struct WgBuilder {
   const int* iota = nullptr;
   WsLauncher wl, wlc;
@@ -245,8 +269,28 @@ struct WgBuilder {
       }
       wcol += cols[ci].width;
     }
-    for (int j = 0; j < nj; ++j) coop.push_back(jobs[j]);
+    for (int j = 0; j < nj; ++j) push_coop(jobs[j]);
+    ls.nchunks = coop_chunks(rows, rpt);          // (<= the chunks carve() sized the slab for: the reduction sums these)
     return true;
+  }
+  static int coop_chunks(long rows, int rpt) { const WgSplit sp = wg_hybrid(rows, rpt); return sp.na + sp.nb; }
+  // one job -> its long-task part and its short-task part (slabs [0, na) and [na, na + nb) of the same matrix)
+  void push_coop(const WsJob& j) {
+    const WgSplit sp = wg_hybrid(j.rows, j.rows_per_task);
+    if (sp.na == 0) { coop.push_back(j); return; }
+    const size_t cs = (size_t)j.NP * j.KP + j.NP;
+    WsJob a = j;
+    a.rows = sp.r1; a.rows_per_task = sp.big;
+    coop.push_back(a);
+    if (j.rows > sp.r1) {
+      WsJob b = j;
+      b.rows = j.rows - sp.r1;
+      b.slab = j.slab + (size_t)sp.na * cs;
+      if (j.g.idx != iota) b.g.idx = j.g.idx + sp.r1;                       // gathered gradient rows: the index list moves
+      else b.g.ptr = j.g.ptr + (size_t)sp.r1 * j.g.stride;
+      for (int k = 0; k < 3; ++k) b.act[k].ptr = j.act[k].ptr + (size_t)sp.r1 * j.act[k].stride;   // (coop jobs: activations are never gathered)
+      coop.push_back(b);
+    }
   }
   void add_block(LinSlab& ls, long rows, int nvar, int rpt, const float* gp, const int* gidx, long gvs, int gstride, int gcol0,
                  const Col* cols, int ncols, bool with_bias) {
@@ -295,7 +339,8 @@ struct WgBuilder {
     jb.act[2] = jb.act[0];
     jb.wcol[0] = 0; jb.wcol[1] = 64; jb.wrow = 0; jb.write_bias = 1; jb.shape = WGM_256_128;
     jb.rows = (int)rows; jb.nvar = nvar; jb.rows_per_task = rpt; jb.NP = ls.NP; jb.KP = ls.KP; jb.slab = ls.slab;
-    coop.push_back(jb);
+    push_coop(jb);
+    ls.nchunks = coop_chunks(rows, rpt);
   }
   int launch(const float* zrow, hipStream_t stream) {
     // every streaming job has one un-gathered activation segment: LDS-DMA ring form
@@ -360,7 +405,7 @@ static void carve(Ws& w, void* ws, size_t ws_bytes, int N, int E, int nl, int nr
   w.s = c.take<float>(n_ * XS);
   w.att = c.take<float>(e_ * 64);
   w.fut = c.take<float>(e_ * D::DM);
-  w.past = c.take<float>(e_ * D::DM);
+  w.past = c.take<float>((e_ + es::kPastDumpRows) * D::DM);      // + the dump rows of the in-wave per-destination sums (b3d_edge2.hpp)
   w.prob = c.take<float>(e_);
   const int adims[4] = {512, 384, 256, 128};
   const int affd[3] = {96, 128, 64};
@@ -888,12 +933,16 @@ extern "C" int b3d_clr_forward(const b3d_clr_weights* pw, const b3d_graph* g, co
     if ((flags & B3D_FLAG_RUN_DEAD_KNN) && l > 0 && (l % 2 == 0)) B3D_TRY(knn_block(l));
     NodeFwdArgs na;
     memset(&na, 0, sizeof(na));
-    na.N = N; na.dst_ptr = g->dst_ptr; na.dst_perm = g->dst_perm; na.src_ptr = g->src_ptr; na.src_perm = g->src_perm;
+    // the rows of `past` a node sums: the run tails the edge kernel left (edges grouped by destination), or its whole list
+    const bool runs = past_runs_enabled() && g->past_ptr != nullptr && g->past_rows != nullptr && g->dst_unsorted != nullptr;
+    na.N = N; na.dst_ptr = runs ? g->past_ptr : g->dst_ptr; na.dst_perm = runs ? g->past_rows : g->dst_perm;
+    na.src_ptr = g->src_ptr; na.src_perm = g->src_perm;
     na.past = w.past; na.fut = w.fut; na.M = w.M[l]; na.x_out = w.x[l + 1]; na.sH1 = w.nH1[l]; na.sH2 = w.nH2[l];
     EdgeFwdHArgs ea;
     memset(&ea, 0, sizeof(ea));
     ea.E = E; ea.src = g->src; ea.dst = g->dst; ea.T = w.T; ea.e_in = w.e[l]; ea.a_in = w.att;
     ea.e_out = w.e[l + 1]; ea.fut = w.fut; ea.past = w.past;
+    ea.dst_unsorted = runs ? g->dst_unsorted : nullptr; ea.past_dump0 = (unsigned)edge_rows(E);
     ea.sH1 = w.sH1[l]; ea.sH2 = w.sH2[l]; ea.sF1 = w.sF1[l]; ea.sP1 = w.sP1[l]; ea.wpack = w.wp_efwd2;
     ea.rmask = reinterpret_cast<unsigned*>(w.rmask[l]); ea.rmask2 = ea.rmask ? ea.rmask + edge_rows(E) * 16 : nullptr;
     if (tr) B3D_TRY(launch_es(es::edge_fwd_kernel<DB, true>, "edge_fwd", ea, E, stream, B3D_K_EDGE_FWD, ES::Fwd::LDS_BYTES));
@@ -1282,7 +1331,7 @@ static void carve_layer(ClrLayerWs& w, void* ws, size_t ws_bytes, int N, int E, 
   w.T0 = c.take<float>(n_ * 2 * DB::MH);
   w.e_out = c.take<float>(e_ * D::DE);
   w.fut = c.take<float>(e_ * D::DM);
-  w.past = c.take<float>(e_ * D::DM);
+  w.past = c.take<float>((e_ + es::kPastDumpRows) * D::DM);      // + the dump rows of the in-wave per-destination sums (b3d_edge2.hpp)
   if (tr) {
     w.wp_ebwd2 = c.take<float>(ES::Bwd::TOTAL_FLOATS);
     w.wp_gproj = c.take<float>(HC::GradProjSeq::TOTAL_FLOATS);
@@ -1408,6 +1457,8 @@ extern "C" int b3d_clr_layer_forward(const b3d_mp_weights* mw, const b3d_graph* 
   memset(&ea, 0, sizeof(ea));
   ea.E = E; ea.src = g->src; ea.dst = g->dst; ea.T = w.T; ea.e_in = e; ea.a_in = att;
   ea.e_out = w.e_out; ea.fut = w.fut; ea.past = w.past;
+  const bool runs = past_runs_enabled() && g->past_ptr != nullptr && g->past_rows != nullptr && g->dst_unsorted != nullptr;
+  ea.dst_unsorted = runs ? g->dst_unsorted : nullptr; ea.past_dump0 = (unsigned)edge_rows(E);
   ea.sH1 = w.sH1; ea.sH2 = w.sH2; ea.sF1 = w.sF1; ea.sP1 = w.sP1; ea.wpack = w.wp_efwd2;
   ea.rmask = reinterpret_cast<unsigned*>(w.rmask); ea.rmask2 = ea.rmask ? ea.rmask + edge_rows(E) * 16 : nullptr;
   if (tr) B3D_TRY(launch_es(es::edge_fwd_kernel<DB, true>, "edge_fwd", ea, E, stream, B3D_K_EDGE_FWD, ES::Fwd::LDS_BYTES));
@@ -1415,7 +1466,8 @@ extern "C" int b3d_clr_layer_forward(const b3d_mp_weights* mw, const b3d_graph* 
   B3D_HIP_CHECK(hipMemcpyAsync(e_new, w.e_out, (size_t)E * D::DE * sizeof(float), hipMemcpyDeviceToDevice, stream));
   NodeFwdArgs na;
   memset(&na, 0, sizeof(na));
-  na.N = N; na.dst_ptr = g->dst_ptr; na.dst_perm = g->dst_perm; na.src_ptr = g->src_ptr; na.src_perm = g->src_perm;
+  na.N = N; na.dst_ptr = runs ? g->past_ptr : g->dst_ptr; na.dst_perm = runs ? g->past_rows : g->dst_perm;
+  na.src_ptr = g->src_ptr; na.src_perm = g->src_perm;
   na.past = w.past; na.fut = w.fut; na.x_out = x_new; na.wpack = w.wp_nfwd;
   if (tr) { na.M = w.M; na.sH1 = w.nH1; na.sH2 = w.nH2; }
   B3D_TRY((launch_node_split<D, kNodeWavesWide>(mp_node_fwd_split_kernel<D, kNodeWavesWide>, "mp_node_fwd", na, N, stream, B3D_K_NODE_FWD)));

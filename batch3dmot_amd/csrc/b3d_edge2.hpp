@@ -53,6 +53,8 @@ __global__ __launch_bounds__(kWaves * 64, kWgPerCu) void edge_fwd_kernel(const E
   using S = typename EdgeSeqs<D>::Fwd;
   static_assert(D::DA > 0, "camera+LiDAR+radar widths (e | att columns)");
   constexpr int EB = D::DE / 16, AB = D::DA / 16, H1B = D::EH1 / 16, H2B = D::EH2 / 16, MHB = D::MH / 16, DMB = D::DM / 16;
+  // (read in front of the stream start, whose vmcnt(0) covers it: a load at the point of use would sit exposed at the tile's end)
+  const bool past_runs = a.dst_unsorted != nullptr && __builtin_amdgcn_readfirstlane(*a.dst_unsorted) == 0;
   Ring<S, FwdHooks<D, TRAIN_>> ring;
   ring.init(a.wpack, es_smem);
   ring.start();
@@ -141,7 +143,21 @@ __global__ __launch_bounds__(kWaves * 64, kWgPerCu) void edge_fwd_kernel(const E
       layer<S, 6, false, true, false>(ring, more, st, x6, mp, [&]() {
         if constexpr (TRAIN) { store_rows<MHB>(a.sP1, row, D::MH, pi); store_masks<MHB, 2>(a.rmask2, row, pi); }
       });
-      store_rows<DMB>(a.past, row, D::DM, mp);
+      // `past` is summed per destination (clr_att_gnn.py:293-294,336-344): with the edges grouped by destination the run sums are
+      // made here and only a run's last row is kept -- the others land in the dump rows (every lane stores either way: the number of
+      // vector-memory instructions between two rendezvous stays what the hook table says)
+      if (past_runs) {
+        unsigned prow[kRB];
+#pragma unroll
+        for (int rb = 0; rb < kRB; ++rb) {
+          const int key = row[rb] < (unsigned)a.E ? (int)d[rb] : -2 - (int)(lane & 15);     // padding rows join no run
+          const bool whole = run_sums<DMB>(mp[rb], key);
+          prow[rb] = whole ? row[rb] : a.past_dump0 + (row[rb] & (unsigned)(kPastDumpRows - 1));
+        }
+        store_rows<DMB>(a.past, prow, D::DM, mp);
+      } else {
+        store_rows<DMB>(a.past, row, D::DM, mp);
+      }
     }
   }
 }

@@ -435,6 +435,38 @@ __device__ __forceinline__ void relu_bwd_mask(v4f (&g)[kRB][NB], const u4v (&mk)
     relu_bwd_words<NB>(g[rb], words);
   }
 }
+// ---- per-destination sums inside the wavefront (round 6) -------------------------------------------------------------------------
+// The 16 rows of a block sit in the 16 lanes of a DPP row (lane = 16 q + m): with the edges grouped by destination a run of equal
+// keys is contiguous in m, and a Hillis-Steele pass of row_shr 1, 2, 4, 8 leaves in every lane the sum of its run up to itself --
+// a lane adds its left neighbour at distance s iff that neighbour carries the same key (sorted keys: then everything between does).
+// The run's LAST lane holds the whole run.  Fixed order: the result depends on the run's position in the block only.
+constexpr int kPastDumpRows = 1024;
+template <int SH>
+__device__ __forceinline__ int dpp_row_shr_i(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x110 + SH, 0xf, 0xf, false); }
+template <int SH>
+__device__ __forceinline__ float dpp_row_shr_f0(float v) {        // 0 where the row has no lane m - SH
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x110 + SH, 0xf, 0xf, true));
+}
+template <int NB, int SH>
+__device__ __forceinline__ void run_scan_step(v4f (&v)[NB], int key) {
+  const bool same = dpp_row_shr_i<SH>(key, -1) == key;
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const float ux = dpp_row_shr_f0<SH>(v[b].x), uy = dpp_row_shr_f0<SH>(v[b].y), uz = dpp_row_shr_f0<SH>(v[b].z), uw = dpp_row_shr_f0<SH>(v[b].w);
+    v[b].x = same ? v[b].x + ux : v[b].x; v[b].y = same ? v[b].y + uy : v[b].y;
+    v[b].z = same ? v[b].z + uz : v[b].z; v[b].w = same ? v[b].w + uw : v[b].w;
+  }
+}
+// v: the block's rows (lane m = row m).  Returns true in the lanes that hold a whole run (the run's last row); v is summed in place.
+template <int NB>
+__device__ __forceinline__ bool run_sums(v4f (&v)[NB], int key) {
+  run_scan_step<NB, 1>(v, key);
+  run_scan_step<NB, 2>(v, key);
+  run_scan_step<NB, 4>(v, key);
+  run_scan_step<NB, 8>(v, key);
+  return __builtin_amdgcn_update_dpp(-1, key, 0x100 + 1, 0xf, 0xf, false) != key;     // row_shl:1: the key of lane m + 1 (-1 behind lane 15)
+}
+
 // the same row table access for every row block of the wavefront
 template <int NB>
 __device__ __forceinline__ void load_rows(const float* __restrict__ base, const unsigned (&row)[kRB], int stride, int col0, v4f (&dst)[kRB][NB]) {

@@ -89,6 +89,10 @@ struct EdgeFwdHArgs {
   const float* wpack;  // Hoist::EdgeFwdSeq images
   unsigned* rmask;     // ReLU masks (b3d_dev.hpp).  es::edge_fwd_kernel<D, true>: plane A (sH1 | sH2), 64 bytes per edge;
   unsigned* rmask2;    //   plane B (sF1 | sP1).  mp_edge_fwd_h_kernel: rmask = one [E, 16]-float plane (a word per tensor), or nullptr
+  // es::edge_fwd_kernel (round 6): per-destination sums of `past` inside the wavefront when *dst_unsorted == 0 (b3d.h: b3d_graph) --
+  // rows that are not the last of their (destination, 16-row block) run go to the dump rows [past_dump0, past_dump0 + 1024) of `past`
+  const int* dst_unsorted;   // nullptr: one row per edge
+  unsigned past_dump0;
 };
 
 template <class D, int NW>

@@ -14,7 +14,10 @@ __global__ void graph_convert_count(const int64_t* __restrict__ ei, int E, int N
   if (k >= E) return;
   const long s = ei[k], d = ei[(long)E + k];
   long ss = s, dd = d;
+  // bad[1] = b3d_graph.dst_unsorted: the edges are not grouped by destination (or one of them is invalid)
+  if (k + 1 < E && ei[(long)E + k + 1] < d) atomicOr(bad + 1, 1);
   if (s < 0 || s >= N || d < 0 || d >= N) {
+    atomicOr(bad + 1, 1);
     // the reference raises an index error for this input (pose_gnn.py:180); here the edge is counted in `bad`
     // (b3d_graph.invalid_edges, which the caller turns into that error) and rewritten to the self loop (0, 0), which
     // keeps CSR / CSC consistent: nothing downstream can index out of bounds before the caller has looked
@@ -94,8 +97,55 @@ __global__ __launch_bounds__(256) void graph_sort_segments(const int* __restrict
   }
 }
 
+// The rows of `past` the node kernel sums per node (b3d.h: b3d_graph.past_ptr / past_rows): with edges grouped by destination, the
+// last edge of every (destination, aligned 16-edge block) run -- the edge kernel has added the run there --, otherwise every edge of the
+// destination's list.  One workgroup: a scan over the nodes in chunks of 1,024.
+constexpr int kPastBlock = 16;                  // rows of a wavefront of the edge kernels (b3d_estream.hpp)
+__global__ __launch_bounds__(1024) void graph_past_lists(const int* __restrict__ dst_ptr, const int* __restrict__ dst_perm, int N,
+                                                         const int* __restrict__ unsorted, int* __restrict__ past_ptr,
+                                                         int* __restrict__ past_rows) {
+  __shared__ int part[1024];
+  __shared__ int base_s;
+  const int tid = threadIdx.x;
+  const bool tails = *unsorted == 0;
+  if (tid == 0) base_s = 0;
+  __syncthreads();
+  for (int n0 = 0; n0 < N; n0 += 1024) {
+    const int n = n0 + tid;
+    int b = 0, e = 0, c = 0;
+    if (n < N) {
+      b = dst_ptr[n]; e = dst_ptr[n + 1];
+      c = tails ? (e > b ? (e - 1) / kPastBlock - b / kPastBlock + 1 : 0) : e - b;
+    }
+    part[tid] = c;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      const int v = tid >= off ? part[tid - off] : 0;
+      __syncthreads();
+      part[tid] += v;
+      __syncthreads();
+    }
+    int o = base_s + part[tid] - c;
+    if (n < N) {
+      past_ptr[n] = o;
+      if (tails) {
+        for (int t = b / kPastBlock; e > b && t <= (e - 1) / kPastBlock; ++t) {
+          const int last = kPastBlock * t + kPastBlock - 1;
+          past_rows[o++] = last < e - 1 ? last : e - 1;    // (grouped by destination: the list's edge ids are b .. e - 1)
+        }
+      } else {
+        for (int i = b; i < e; ++i) past_rows[o++] = dst_perm[i];
+      }
+    }
+    __syncthreads();
+    if (tid == 1023) base_s += part[1023];
+    __syncthreads();
+  }
+  if (tid == 0) past_ptr[N] = base_s;
+}
+
 struct GraphLayout {
-  int *src, *dst, *dst_ptr, *dst_perm, *src_ptr, *src_perm, *cnt_dst, *cnt_src, *cur_dst, *cur_src, *bad;
+  int *src, *dst, *dst_ptr, *dst_perm, *src_ptr, *src_perm, *cnt_dst, *cnt_src, *cur_dst, *cur_src, *bad, *past_ptr, *past_rows;
   size_t bytes;
   bool ok;
 };
@@ -115,6 +165,8 @@ static GraphLayout graph_layout(void* ws, size_t ws_bytes, int N, int E) {
   g.bad = g.cnt_dst ? g.cnt_dst + 2 * (size_t)N : nullptr;
   g.cur_dst = c.take<int>(N > 0 ? N : 1);
   g.cur_src = c.take<int>(N > 0 ? N : 1);
+  g.past_ptr = c.take<int>(N + 1);
+  g.past_rows = c.take<int>((size_t)(E > 0 ? E : 1) + (size_t)N + 16);       // >= max(E, E / 16 + N)
   g.bytes = c.off + 256;
   g.ok = c.ok();
   return g;
@@ -153,6 +205,8 @@ extern "C" int b3d_graph_build(const int64_t* edge_index, int32_t N, int32_t E, 
                        g.src_ptr, N, g.dst_perm, g.src_perm);
     B3D_TRY(launch_check("graph_sort_segments"));
   }
+  hipLaunchKernelGGL(graph_past_lists, dim3(1), dim3(1024), 0, stream, g.dst_ptr, g.dst_perm, N, g.bad + 1, g.past_ptr, g.past_rows);
+  B3D_TRY(launch_check("graph_past_lists"));
   out->N = N;
   out->E = E;
   out->src = g.src;
@@ -162,6 +216,9 @@ extern "C" int b3d_graph_build(const int64_t* edge_index, int32_t N, int32_t E, 
   out->src_ptr = g.src_ptr;
   out->src_perm = g.src_perm;
   out->invalid_edges = g.bad;
+  out->dst_unsorted = g.bad + 1;
+  out->past_ptr = g.past_ptr;
+  out->past_rows = g.past_rows;
   return B3D_OK;
 }
 

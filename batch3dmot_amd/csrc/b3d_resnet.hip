@@ -387,7 +387,10 @@ __device__ __forceinline__ void wstat_reduce(const float* wstat, float* stat) {
 // conv 3 -> 12 k4 s2 p1 (32 -> 16): 512 pixels = 32 pixel tiles, two per wavefront, K = 48 in 2 k-steps, its output (+ bias) lands
 // in the zero-bordered LDS tile a0; block1.conv1 12 -> 24 k4 s2 p1 (16 -> 8): 8 pixel tiles x 2 channel tiles = 16 wavefronts,
 // K = 192; block1.downsample 12 -> 24 k5 s3 p0 (16 -> 4): 2 pixel tiles x 2 channel tiles = 4 wavefronts, K = 300.
-constexpr int kP0Crops = 2;
+#ifndef B3D_P0_CROPS
+#define B3D_P0_CROPS 2
+#endif
+constexpr int kP0Crops = B3D_P0_CROPS;
 constexpr int kP0X = 3 * 34 * 34, kP0A = 12 * 18 * 18;
 constexpr int kP0Lds = kP0Crops * (kP0X + kP0A) * 4 + 2 * 2 * 192 * 16 + 32 * (conv_ksteps(0) + conv_ksteps(1) + conv_ksteps(3)) * 4
                        + (2 * 48 + 2 * kResWaves * 48) * 4;
@@ -421,7 +424,7 @@ __global__ __launch_bounds__(kResThreads) void resnet_p0_kernel(const ResArgs a)
     conv_mfma<0, 34, 2, 0, 16, kP0Crops, 16, 1, 18>(a, img0, xin, koff0, wbuf, a.bias[0], nullptr, nullptr, a0);
     __syncthreads();                               // a0 is complete
     conv_mfma<1, 18, 2, 0, 8, kP0Crops, 8, 2>(a, img0, a0, koff1, wbuf, a.bias[1], a.z1, wst1);
-    conv_mfma<3, 18, 3, 1, 4, kP0Crops, 2, 2>(a, img0, a0, koffd, wbuf, a.bias[3], a.zd1, wstd);
+    conv_mfma<3, 18, 3, 1, 4, kP0Crops, kP0Crops, 2>(a, img0, a0, koffd, wbuf, a.bias[3], a.zd1, wstd);     // one 16-pixel tile per crop
   }
   if (a.train) {
     __syncthreads();

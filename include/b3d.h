@@ -56,6 +56,17 @@ typedef struct b3d_graph {
                                    index error for them (pose_gnn.py:180); the build rewrites each to the self loop
                                    (0, 0) so that no kernel can index out of bounds, and the caller reads this counter
                                    (one 4-byte copy) to raise the error -- batch3dmot_amd._lib.Graph does            */
+  /* Round 6 -- per-destination sums INSIDE the edge kernel (pose_gnn.py:187-191,228-240 / clr_att_gnn.py:293-294,336-344: the
+   * `past` messages are scatter-added at their destination).  Detection graphs list their edges grouped by destination
+   * (dst non-decreasing); then a wavefront's 16 consecutive edges hold whole runs of one destination, the camera+LiDAR+radar
+   * edge kernel adds each run with DPP row shifts and stores ONE row per (destination, 16-edge block) -- at the run's last
+   * edge -- and the node kernel sums those few rows instead of one row per edge.  dst_unsorted: device int32[1], non-zero
+   * when the edge list is not grouped like that (or holds an invalid edge): the kernels then keep one row per edge.
+   * past_ptr [N+1] / past_rows: the rows of `past` the node kernel sums for node n -- the run tails, or (unsorted) exactly
+   * dst_ptr / dst_perm.  Written by b3d_graph_build; NULL in a hand-made struct means "one row per edge". */
+  const int32_t* dst_unsorted;
+  const int32_t* past_ptr;
+  const int32_t* past_rows;
 } b3d_graph;
 
 size_t b3d_graph_workspace_bytes(int32_t N, int32_t E);

@@ -121,3 +121,47 @@ def test_roctx_markers_switch_on_and_off_around_a_forward():
         c = m(data)[0]
     torch.cuda.synchronize()
     assert isinstance(on, bool) and torch.equal(a, b) and torch.equal(a, c)
+
+
+def test_past_run_sums_follow_the_edge_order():
+    """Round 6: with the edges grouped by destination (how detection graphs list them) the camera+LiDAR+radar edge kernel adds the
+    `past` messages of a destination inside the wavefront (DPP row shifts) and the node kernel sums one row per (destination, 16-edge
+    block) run; any other edge order keeps one row per edge.  Both orders of the SAME graph must give the same model output (fp32
+    summation order aside) -- forward and every gradient -- and the graph build must say which form it chose."""
+    from batch3dmot_amd import _lib, synth
+    dev = torch.device("cuda:0")
+    m = _model(dev).eval()
+    data = synth.make_graph(260, None, k=7, graph_idx=850, modalities=True)
+    e = data.edge_index.size(1)
+    assert bool((data.edge_index[1][1:] >= data.edge_index[1][:-1]).all())          # synthetic graphs are grouped by destination
+    g_sorted = _lib.Graph(data.edge_index.to(dev), 260)
+    flag = lambda g: int(g._view(g.c.dst_unsorted, 1).item())                        # noqa: E731
+    assert flag(g_sorted) == 0
+    n_tail = int(g_sorted._view(g_sorted.c.past_ptr, 261)[-1])
+    assert 0 < n_tail < e and n_tail <= e // 16 + 260 + 1                            # run tails: far fewer rows than edges
+    perm = torch.randperm(e, generator=torch.Generator().manual_seed(3))
+    shuffled = synth.make_graph(260, None, k=7, graph_idx=850, modalities=True)
+    shuffled.edge_index = data.edge_index[:, perm].contiguous()
+    shuffled.edge_attr = data.edge_attr[perm].contiguous()
+    g_shuf = _lib.Graph(shuffled.edge_index.to(dev), 260)
+    assert flag(g_shuf) == 1 and int(g_shuf._view(g_shuf.c.past_ptr, 261)[-1]) == e  # one row per edge
+    outs = []
+    for d, p in ((data, None), (shuffled, perm)):
+        m.zero_grad(set_to_none=True)
+        out, xs = m(d.to(dev))
+        w = torch.linspace(-1.0, 1.0, e, device=dev).reshape(-1, 1)
+        if p is not None:
+            w = w[p.to(dev)]
+        ((out * w).sum() + 0.1 * xs.sum()).backward()
+        o = out.detach().reshape(-1)
+        if p is not None:
+            o = torch.empty_like(o).index_copy_(0, p.to(dev), o)                     # back to the sorted edge order
+        outs.append((o, xs.detach(), {n: q.grad.detach().clone() for n, q in m.named_parameters() if q.grad is not None}))
+    (o1, x1, g1), (o2, x2, g2) = outs
+    rel = lambda a, b: float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30))   # noqa: E731
+    assert rel(o1, o2) < 1e-5 and rel(x1, x2) < 1e-6
+    # two fp32 evaluations with different summation orders everywhere (every per-edge tensor is permuted): 5e-4 of a tensor's largest
+    # entry, with conftest's clause for a ReLU unit that sits within rounding of zero on this 260-node graph
+    from conftest import assert_grad_close
+    for n in g2:
+        assert_grad_close(g1[n], g2[n], "edge order / " + n)
