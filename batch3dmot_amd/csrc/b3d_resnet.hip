@@ -387,6 +387,8 @@ __device__ __forceinline__ void wstat_reduce(const float* wstat, float* stat) {
 // conv 3 -> 12 k4 s2 p1 (32 -> 16): 512 pixels = 32 pixel tiles, two per wavefront, K = 48 in 2 k-steps, its output (+ bias) lands
 // in the zero-bordered LDS tile a0; block1.conv1 12 -> 24 k4 s2 p1 (16 -> 8): 8 pixel tiles x 2 channel tiles = 16 wavefronts,
 // K = 192; block1.downsample 12 -> 24 k5 s3 p0 (16 -> 4): 2 pixel tiles x 2 channel tiles = 4 wavefronts, K = 300.
+// EXPERIMENT (round 6, -DB3D_P0_CROPS=4): four crops per pass (half the passes, twice the pixel tiles per weight fragment): 119.9 -> 116.2 us
+// on 3,000 crops with 23 spilled registers -- not worth them; the phase is bound by the gathers of its im2col operand, not by passes.
 #ifndef B3D_P0_CROPS
 #define B3D_P0_CROPS 2
 #endif

@@ -129,7 +129,10 @@ def test_predict_scene_with_the_embedding_cache_reproduces_the_reference_indices
     # one forward per window (the reference's way) and eight windows per forward give the same scores
     single = predict_scene(m, wins, g["node_cls"].to(dev), g["class_names"], g["thresholds"], cache=True, tracks=False, windows_per_forward=1)
     assert torch.equal(single["kept_pairs"], r["kept_pairs"])
-    torch.testing.assert_close(single["kept_scores"], r["kept_scores"], rtol=0, atol=1e-6)
+    # (round 6: the camera+LiDAR+radar edge kernel adds the `past` messages of a destination per aligned 16-edge block -- where a
+    # window's edges fall in those blocks depends on what was concatenated in front of it, so the two groupings differ in fp32
+    # summation order: measured 1.4e-6 on one score of 113; the index sets above are identical)
+    torch.testing.assert_close(single["kept_scores"], r["kept_scores"], rtol=0, atol=1e-5)
     if clr:
         # the cache fill switches the model to eval and must hand every module back in ITS mode: a parent in train mode with an
         # encoder the sticky switch (clr_att_gnn.py:128-139) had left in eval stays exactly so
