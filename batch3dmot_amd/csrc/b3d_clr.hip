@@ -686,8 +686,12 @@ static int pack_all(const b3d_clr_weights* pw, Ws& w, bool training, bool knn, h
     d[n++] = pack_slice<SeqAT0eT>(0, w.wp_at0eT, a0.w + 2 * XS, nullptr, 64, 512, 640, 0, 64, true);
   }
   if (n > 224) return fail(B3D_ERR_ARG, "pack descriptor table overflow");
-  B3D_TRY(pack_images(d, n_fwd, stream));
-  if (n > n_fwd) B3D_TRY(pack_images(d + n_fwd, n - n_fwd, bwd_stream));
+  if (bwd_stream == stream) {
+    B3D_TRY(pack_images(d, n, stream));                    // one table: the launches are filled to kPackMax descriptors
+  } else {
+    B3D_TRY(pack_images(d, n_fwd, stream));
+    if (n > n_fwd) B3D_TRY(pack_images(d + n_fwd, n - n_fwd, bwd_stream));
+  }
   FragDesc f[kFragMax];
   int m = 0;
   using FS = ES::Fwd;
@@ -713,8 +717,12 @@ static int pack_all(const b3d_clr_weights* pw, Ws& w, bool training, bool knn, h
     f[m++] = frag_desc<NS>(1, w.wp_ebwd_nm2, L[EU1].w, nullptr, kDims[EU1].K, true);
     f[m++] = frag_desc<NS>(2, w.wp_ebwd_nm2, eu0.w + 2 * DX, nullptr, EIN, true);
   }
-  B3D_TRY(pack_frags(f, m_fwd, stream));
-  if (m > m_fwd) B3D_TRY(pack_frags(f + m_fwd, m - m_fwd, bwd_stream));
+  if (bwd_stream == stream) {
+    B3D_TRY(pack_frags(f, m, stream));
+  } else {
+    B3D_TRY(pack_frags(f, m_fwd, stream));
+    if (m > m_fwd) B3D_TRY(pack_frags(f + m_fwd, m - m_fwd, bwd_stream));
+  }
   return B3D_OK;
 }
 

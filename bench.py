@@ -982,6 +982,11 @@ def main():
         except Exception as exc:
             secondary["infer_scene_clr"] = {"error": f"{type(exc).__name__}: {str(exc)[:200]}"}
         torch.cuda.empty_cache()
+        if not args.no_cpu_baseline:
+            try:
+                secondary["config0_mini_pose_cpu"] = config0_mini_pose(dev)
+            except Exception as exc:
+                secondary["config0_mini_pose_cpu"] = {"error": f"{type(exc).__name__}: {str(exc)[:200]}"}
 
     if rank == 0:
         e_avg = m["edges"] / args.steps
@@ -1454,6 +1459,53 @@ def cpu_baseline(wl: Workload):
             "one_thread": {"value": round(v1, 1), "unit": "edges/s", "cores": 1, "sample": sample1},
             "thread_sweep_edges_per_s": {str(t): v_ for t, v_ in sweep.items()},
             "host_cpu": model_name, "host_logical_cores": cores}
+
+
+def config0_mini_pose(dev):
+    """BASELINE.json configs[0] (`mini_config.yaml` poses-only: ONE nuScenes-mini scene graph, the reference's PyTorch forward on CPU --
+    plumbing): the oracle's PoseGNN forward (`pose_gnn.py:58-86` restated, dead k-NN block executed) on a mini-sized synthetic window
+    (5 frames x ~60 detections) on the host cores, the HIP forward of the same graph beside it, and their difference."""
+    from batch3dmot_amd import synth
+    from batch3dmot_amd.pose_gnn import PoseGNN
+    from oracle import ref_torch            # checker / CPU baseline only
+    from oracle.seeded import seeded_fill_
+    data = synth.make_graph(300, 3000, graph_idx=77)
+    ora = ref_torch.PoseGNN(run_dead_knn=True)
+    seeded_fill_(ora, 5621)
+    threads = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    with torch.no_grad():
+        for _ in range(2):
+            o_ref, _x = ora(data)
+        ts = []
+        for _ in range(10):
+            t0 = time.perf_counter()
+            ora(data)
+            ts.append(time.perf_counter() - t0)
+    ts.sort()
+    cpu_ms = 1e3 * ts[len(ts) // 2]
+    m = PoseGNN().to(dev).eval()
+    m.load_state_dict(ora.state_dict())
+    m.run_dead_knn = True
+    dd = data.to(dev)
+    with torch.no_grad():
+        for _ in range(3):
+            o_hip, _x = m(dd)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            m(dd)
+        e1.record()
+        torch.cuda.synchronize()
+    hip_ms = e0.elapsed_time(e1) / 20
+    e = int(data.edge_index.size(1))
+    err = float((o_hip.cpu().double() - o_ref.double()).abs().max() / o_ref.double().abs().max().clamp_min(1e-30))
+    return {"workload": "BASELINE.json configs[0]: poses-only PoseGNN forward on one mini-sized scene window (5 frames), CPU plumbing case",
+            "nodes": int(data.pose_feats.size(0)), "edges": e,
+            "cpu_forward_ms_median": round(cpu_ms, 3), "cpu_edges_per_s": round(e / (cpu_ms * 1e-3), 1), "cores": threads, "kind": "port",
+            "hip_forward_ms_eager": round(hip_ms, 4), "hip_edges_per_s": round(e / (hip_ms * 1e-3), 1),
+            "hip_vs_cpu_max_rel_err": err}
 
 
 if __name__ == "__main__":
