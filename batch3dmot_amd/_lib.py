@@ -18,6 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libb3d_hip_%s.so" % os.environ["B3D_LIB"] if os.
 B3D_FLAG_TRAINING = 1
 B3D_FLAG_RUN_DEAD_KNN = 2
 B3D_FLAG_SINGLE_STREAM = 4
+B3D_FLAG_SKIP_DEAD_LAST_MESSAGES = 16
 B3D_FLAG_DEFER_SIDE_JOIN = 8
 
 c_float_p = C.POINTER(C.c_float)

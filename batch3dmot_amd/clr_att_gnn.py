@@ -23,7 +23,8 @@ import torch
 from torch import nn
 
 from . import _lib
-from ._lib import B3D_FLAG_DEFER_SIDE_JOIN, B3D_FLAG_RUN_DEAD_KNN, B3D_FLAG_SINGLE_STREAM, B3D_FLAG_TRAINING
+from ._lib import (B3D_FLAG_DEFER_SIDE_JOIN, B3D_FLAG_RUN_DEAD_KNN, B3D_FLAG_SINGLE_STREAM, B3D_FLAG_SKIP_DEAD_LAST_MESSAGES,
+                   B3D_FLAG_TRAINING)
 from .pose_gnn import GATConvParams, _linears, _mlp
 
 
@@ -147,7 +148,8 @@ class _GNNFunction(torch.autograd.Function):
         N, E = graph.N, graph.E
         nl, nr = int(lidar_nodes.numel()), int(radar_nodes.numel())
         flags = ((B3D_FLAG_TRAINING if training else 0) | (B3D_FLAG_RUN_DEAD_KNN if module.run_dead_knn else 0)
-                 | (B3D_FLAG_SINGLE_STREAM if module.single_stream else 0))
+                 | (B3D_FLAG_SINGLE_STREAM if module.single_stream else 0)
+                 | (0 if getattr(module, "run_dead_last_messages", True) else B3D_FLAG_SKIP_DEAD_LAST_MESSAGES))
         # optional: let the discarded k-NN block run on under the loss and the backward sweep (measured on
         # MI355X: 4 % slower than joining at the end of forward -- it delays the start of every backward kernel)
         defer = bool(training and module.run_dead_knn and not module.single_stream and module.defer_knn_join)
@@ -435,6 +437,10 @@ class GNN(nn.Module):
         # library's side stream (worth ~4 % before the first layers were hoisted; now it only adds jitter)
         self.single_stream = True
         self.defer_knn_join = False    # True: B3D_FLAG_DEFER_SIDE_JOIN in training forwards
+        # The last layer's create_future_msgs / create_past_msgs / combine_future_past feed nothing (clr_att_gnn.py:188 returns
+        # edge_classifier(edge_attr)); the reference executes them, and so does this model by default.  False skips them
+        # (B3D_FLAG_SKIP_DEAD_LAST_MESSAGES): outputs and gradients are bit-identical.
+        self.run_dead_last_messages = True
         self.keep_workspace = False
         self._last_workspace = None
         self.mask_stream = None         # see modality_rows()

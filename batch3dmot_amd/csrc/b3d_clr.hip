@@ -131,6 +131,7 @@ struct Ws {
   // hoisted first layers
   float *wp_proj0, *wp_nfwd_h, *wp_gproj, *wp_nbwd_h;
   float *wp_efwd2, *wp_ebwd2, *wp_ebwd_nm2;       // fragment-stream images (b3d_estream.hpp)
+  float *wp_efwd_nm2;                             // ... of the last layer's edge_update alone (B3D_FLAG_SKIP_DEAD_LAST_MESSAGES)
   float *T, *T0, *dT, *gx;
   float *wp_attU, *wp_att0, *wp_attDs, *wp_at0eT, *U, *dU, *ds, *de0;     // att_edge_encoder.0 hoisted
   float *wp_clsT, *wp_eeT, *wp_neT, *wp_flT, *wp_frT, *wp_affT[3], *wp_atT[5], *wp_nbwd;
@@ -396,6 +397,7 @@ static void carve(Ws& w, void* ws, size_t ws_bytes, int N, int E, int nl, int nr
   w.wp_proj0 = c.take<float>(Proj0Seq2<DB>::TOTAL_FLOATS);
   w.wp_nfwd_h = c.take<float>(NodeFwdHSeq<DB>::TOTAL_FLOATS);
   w.wp_efwd2 = c.take<float>(ES::Fwd::TOTAL_FLOATS);
+  w.wp_efwd_nm2 = c.take<float>(ES::FwdNoMsg::TOTAL_FLOATS);     // (always carved: the layout must not depend on a forward-only flag)
   w.T = c.take<float>(n_ * HC::TW);
   w.T0 = c.take<float>(n_ * 2 * DB::MH);
   w.wp_attU = c.take<float>(SeqAttU::TOTAL_FLOATS);
@@ -605,7 +607,7 @@ static int check_weights(const b3d_clr_weights* pw) {
 // `bwd_stream`: where the images only the backward sweep reads (transposed weights, the backward fragment streams) are packed --
 // the launch stream, or (round 6) a library side stream forked at the forward's entry and joined at its end: ~40 % of the packing
 // leaves the launch stream's chain and runs under the forward's kernels.
-static int pack_all(const b3d_clr_weights* pw, Ws& w, bool training, bool knn, hipStream_t stream, hipStream_t bwd_stream) {
+static int pack_all(const b3d_clr_weights* pw, Ws& w, bool training, bool knn, hipStream_t stream, hipStream_t bwd_stream, bool fwd_nomsg) {
   LinPtrs L[LIN_COUNT];
   gather_linears(pw, L);
   PackDesc d[224];
@@ -702,6 +704,12 @@ static int pack_all(const b3d_clr_weights* pw, Ws& w, bool training, bool knn, h
   f[m++] = frag_desc<FS>(4, w.wp_efwd2, L[FU1].w, L[FU1].b, kDims[FU1].K, false);
   f[m++] = frag_desc<FS>(5, w.wp_efwd2, pa0.w + DX, nullptr, MIN, false);
   f[m++] = frag_desc<FS>(6, w.wp_efwd2, L[PA1].w, L[PA1].b, kDims[PA1].K, false);
+  if (fwd_nomsg) {
+    using FN = ES::FwdNoMsg;
+    f[m++] = frag_desc<FN>(0, w.wp_efwd_nm2, eu0.w + 2 * DX, nullptr, EIN, false);
+    f[m++] = frag_desc<FN>(1, w.wp_efwd_nm2, L[EU1].w, L[EU1].b, kDims[EU1].K, false);
+    f[m++] = frag_desc<FN>(2, w.wp_efwd_nm2, L[EU2].w, L[EU2].b, kDims[EU2].K, false);
+  }
   const int m_fwd = m;
   if (training) {
     using BS = ES::Bwd;
@@ -860,7 +868,8 @@ extern "C" int b3d_clr_forward(const b3d_clr_weights* pw, const b3d_graph* g, co
     B3D_TRY(side_get(1, &pack_side));
     B3D_TRY(side_fork(stream, pack_side));                  // (the images' previous readers -- the last backward sweep -- are behind us on `stream`)
   }
-  B3D_TRY(pack_all(pw, w, tr, (flags & B3D_FLAG_RUN_DEAD_KNN) != 0, stream, pack_side ? pack_side->s : stream));
+  const bool skip_last_msgs = (flags & B3D_FLAG_SKIP_DEAD_LAST_MESSAGES) != 0;
+  B3D_TRY(pack_all(pw, w, tr, (flags & B3D_FLAG_RUN_DEAD_KNN) != 0, stream, pack_side ? pack_side->s : stream, skip_last_msgs));
 
   // ---- the part that does not read the frozen encoders' outputs: edge / node encoder, layer 0's per-node table, the
   //      first k-NN block (x[0]); the encoders may still be running on other streams (b3d_clr_inputs::encoders_ready) ----
@@ -953,6 +962,13 @@ extern "C" int b3d_clr_forward(const b3d_clr_weights* pw, const b3d_graph* g, co
     ea.dst_unsorted = runs ? g->dst_unsorted : nullptr; ea.past_dump0 = (unsigned)edge_rows(E);
     ea.sH1 = w.sH1[l]; ea.sH2 = w.sH2[l]; ea.sF1 = w.sF1[l]; ea.sP1 = w.sP1[l]; ea.wpack = w.wp_efwd2;
     ea.rmask = reinterpret_cast<unsigned*>(w.rmask[l]); ea.rmask2 = ea.rmask ? ea.rmask + edge_rows(E) * 16 : nullptr;
+    if (skip_last_msgs && l + 1 == depth) {
+      // the last layer's messages and node update feed nothing (clr_att_gnn.py:188): edge_update alone, no node launch
+      ea.wpack = w.wp_efwd_nm2;
+      if (tr) B3D_TRY(launch_es((es::edge_fwd_kernel<DB, true, false>), "edge_fwd_last", ea, E, stream, B3D_K_EDGE_FWD, ES::FwdNoMsg::LDS_BYTES));
+      else B3D_TRY(launch_es((es::edge_fwd_kernel<DB, false, false>), "edge_fwd_last", ea, E, stream, B3D_K_EDGE_FWD, ES::FwdNoMsg::LDS_BYTES));
+      continue;
+    }
     if (tr) B3D_TRY(launch_es(es::edge_fwd_kernel<DB, true>, "edge_fwd", ea, E, stream, B3D_K_EDGE_FWD, ES::Fwd::LDS_BYTES));
     else B3D_TRY(launch_es(es::edge_fwd_kernel<DB, false>, "edge_fwd", ea, E, stream, B3D_K_EDGE_FWD, ES::Fwd::LDS_BYTES));
     if (l + 1 < depth) {                                   // + the per-node table the next layer's edge phase gathers

@@ -26,16 +26,20 @@ struct EdgeSeqs {
                   LY<D::DM, D::MH>, LY<D::MH, D::DE>,                            // future.2^T, future.0[e']^T
                   LY<D::DE, D::EH2>, LY<D::EH2, D::EH1>, LY<D::EH1, KE>>;        // edge_update.4^T / .2^T / .0[e | att]^T
   using BwdNoMsg = Seq<LY<D::DE, D::EH2>, LY<D::EH2, D::EH1>, LY<D::EH1, KE>>;
+  // edge_update only (round 6, B3D_FLAG_SKIP_DEAD_LAST_MESSAGES): the last layer's message stacks and node update feed nothing
+  // (forward returns edge_classifier(edge_attr): clr_att_gnn.py:188)
+  using FwdNoMsg = Seq<LY<KE, D::EH1>, LY<D::EH1, D::EH2>, LY<D::EH2, D::DE>>;
 };
 
 // ---- forward -----------------------------------------------------------------------------------------------------------------
 // loads / stores in front of the first chunk of layers 1 .. 6, per wavefront (kRB row blocks of 16 rows: one 16-byte access per
 // 16-feature block and row block)
-template <class D, bool TRAIN>
+template <class D, bool TRAIN, bool MSGS = true>
 struct FwdHooks {
-  using S = typename EdgeSeqs<D>::Fwd;
+  using S = typename std::conditional<MSGS, typename EdgeSeqs<D>::Fwd, typename EdgeSeqs<D>::FwdNoMsg>::type;
   __host__ __device__ static constexpr int before(int ci) {
     constexpr int H1B = D::EH1 / 16, H2B = D::EH2 / 16, EB = D::DE / 16, MHB = D::MH / 16, DMB = D::DM / 16, SV = (TRAIN && !(B3D_ES_ABL & 32)) ? 1 : 0;
+    if (!MSGS) return kRB * (ci == S::first_chunk(1) ? SV * (H1B + 1) : ci == S::first_chunk(2) ? SV * (H2B + 1) : 0);    // no message rows to gather
     return kRB * (ci == S::first_chunk(1) ? SV * (H1B + 1) + MHB    // sH1 + its mask store, T[dst] future rows
                 : ci == S::first_chunk(2) ? SV * (H2B + 1) + MHB    // sH2 + mask store, T[src] past rows
                 : ci == S::first_chunk(3) ? EB                      // e' store
@@ -45,17 +49,17 @@ struct FwdHooks {
   }
 };
 
-template <class D, bool TRAIN_>
+template <class D, bool TRAIN_, bool MSGS = true>
 __global__ __launch_bounds__(kWaves * 64, kWgPerCu) void edge_fwd_kernel(const EdgeFwdHArgs a) {
   constexpr bool TRAIN = TRAIN_ && !(B3D_ES_ABL & 32);        // (timing ablation 32: the training forward without its saved activations)
   extern __shared__ __attribute__((aligned(16))) char es_smem[];
   using H = Hoist<D>;
-  using S = typename EdgeSeqs<D>::Fwd;
+  using S = typename FwdHooks<D, TRAIN_, MSGS>::S;
   static_assert(D::DA > 0, "camera+LiDAR+radar widths (e | att columns)");
   constexpr int EB = D::DE / 16, AB = D::DA / 16, H1B = D::EH1 / 16, H2B = D::EH2 / 16, MHB = D::MH / 16, DMB = D::DM / 16;
   // (read in front of the stream start, whose vmcnt(0) covers it: a load at the point of use would sit exposed at the tile's end)
   const bool past_runs = a.dst_unsorted != nullptr && __builtin_amdgcn_readfirstlane(*a.dst_unsorted) == 0;
-  Ring<S, FwdHooks<D, TRAIN_>> ring;
+  Ring<S, FwdHooks<D, TRAIN_, MSGS>> ring;
   ring.init(a.wpack, es_smem);
   ring.start();
   const int lane = threadIdx.x & 63;
@@ -109,7 +113,7 @@ __global__ __launch_bounds__(kWaves * 64, kWgPerCu) void edge_fwd_kernel(const E
       split_blocks<H1B>(h1, x1);
       layer<S, 1, true, true, false>(ring, more, st, x1, h2, [&]() {
         if constexpr (TRAIN) { store_rows<H1B>(a.sH1, row, D::EH1, h1); store_masks<H1B, 0>(a.rmask, row, h1); }
-        load_rows<MHB>(a.T, d, H::TW, H::OF, fi);
+        if constexpr (MSGS) load_rows<MHB>(a.T, d, H::TW, H::OF, fi);
       });
     }
     v4f pi[kRB][MHB];
@@ -119,9 +123,12 @@ __global__ __launch_bounds__(kWaves * 64, kWgPerCu) void edge_fwd_kernel(const E
       split_blocks<H2B>(h2, x2);
       layer<S, 2, false, true, false>(ring, more, st, x2, en, [&]() {
         if constexpr (TRAIN) { store_rows<H2B>(a.sH2, row, D::EH2, h2); store_masks<H2B, 2>(a.rmask, row, h2); }
-        load_rows<MHB>(a.T, s, H::TW, H::OP, pi);
+        if constexpr (MSGS) load_rows<MHB>(a.T, s, H::TW, H::OP, pi);
       });
     }
+    if constexpr (!MSGS) {
+      store_rows<EB>(a.e_out, row, D::DE, en);                 // (behind the last rendezvous: drained at the kernel's end)
+    } else {
     Bf3 xe[kRB][EB / 2];
     split_blocks<EB>(en, xe);
     // ---- create_future_msgs ----
@@ -159,6 +166,7 @@ __global__ __launch_bounds__(kWaves * 64, kWgPerCu) void edge_fwd_kernel(const E
         store_rows<DMB>(a.past, row, D::DM, mp);
       }
     }
+    }   // MSGS
   }
 }
 

@@ -196,6 +196,8 @@ class Workload:
             # (a high-priority stream for the masks was measured: 4.75 -> 7.9 ms per step -- stream priorities slow the whole replay here)
             self.logits = False
         self.model.run_dead_knn = not args.no_dead_knn
+        if getattr(args, "no_dead_last_messages", False) and kind == "clr":
+            self.model.run_dead_last_messages = False           # (the last layer's message stacks + node update: their x is never read)
         self.model.single_stream = True
         # The discarded k-NN + GAT block on the library's side stream (forked where x[l] exists, joined at the end of forward):
         # with the encoders inside forward this only adds jitter (A/B round 5: 4.48 vs 4.50 ms; PoseGNN 0.946 vs 0.963), but in the
@@ -875,6 +877,9 @@ def main():
                     help="weak: 2 graphs per GPU and step.  strong: global batch of 16 graphs, 16 / N per GPU (SURVEY.md 8d(4))")
     ap.add_argument("--no-dead-knn", action="store_true",
                     help="skip the k-NN + GAT block whose result the reference discards (secondary figure)")
+    ap.add_argument("--no-dead-last-messages", action="store_true",
+                    help="do not execute the last layer's message stacks and node update (their result is never read: "
+                         "clr_att_gnn.py:188); outputs and gradients are identical.  Reported as secondary.clr_without_dead_work")
     ap.add_argument("--no-graph", action="store_true", help="enqueue every step eagerly")
     ap.add_argument("--serial-encoders", action="store_true",
                     help="encode every batch inside its own forward (rounds 1-4's timed step).  Default since round 5: "
@@ -950,11 +955,17 @@ def main():
             and args.modalities == "clr" and args.scaling == "weak"):
         secondary = {}
         for key, kind, enc, mod in (("clr_serial_encoders", "clr", "frozen", "clr"), ("clr_with_ap_metrics", "clr", "frozen", "clr"),
+                                    ("clr_without_dead_work", "clr", "frozen", "clr"),
                                     ("clr_encoders_precomputed", "clr", "precomputed", "clr"),
                                     ("camera_lidar", "clr", "frozen", "cl"),
                                     ("camera_lidar_encoders_precomputed", "clr", "precomputed", "cl"), ("pose_gnn", "pose", "frozen", "clr")):
             try:
                 a2 = argparse.Namespace(**{**vars(args), "encode_ahead": args.encode_ahead and key != "clr_serial_encoders", "model": kind})
+                if key == "clr_without_dead_work":
+                    # what the reference computes and never reads, left out: the frame-wise k-NN + GAT block (pose_gnn.py:80) and the
+                    # last layer's message stacks + node update (clr_att_gnn.py:188).  Same outputs, same gradients; NOT the headline.
+                    a2.no_dead_knn = True
+                    a2.no_dead_last_messages = True
                 w2 = Workload(kind, dev, rank, world, a2, encoders=enc, modalities=mod, ap_metrics=(key == "clr_with_ap_metrics"))
                 k2 = max(10, args.steps // 2)
                 m2 = measure(w2, args, world, dist, k2, max(3, args.warmup // 2), 60.0, use_graph=not args.no_graph)

@@ -123,6 +123,10 @@ typedef struct b3d_pose_grads {
                                        backward sweep.  The caller MUST keep `workspace` alive and untouched until
                                        b3d_pose_backward / b3d_clr_backward on it has been enqueued (it joins the side
                                        stream into its `stream`), or call b3d_side_join(stream) before releasing it */
+#define B3D_FLAG_SKIP_DEAD_LAST_MESSAGES 16u  /* b3d_clr_forward: do NOT execute the last layer's create_future_msgs / create_past_msgs /
+                                       combine_future_past -- forward returns edge_classifier(edge_attr) (clr_att_gnn.py:188), the `x` of
+                                       the last layer is never read and autograd never visits those stacks.  The reference executes them;
+                                       so does this library by default.  Outputs and gradients are bit-identical either way */
 #define B3D_FLAG_SINGLE_STREAM 4u   /* enqueue every kernel on `stream` itself.  By default work with
                                        no consumer until the end of the call (the discarded k-NN +
                                        GAT block) runs on a library-owned side stream that is forked

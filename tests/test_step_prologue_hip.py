@@ -165,3 +165,32 @@ def test_past_run_sums_follow_the_edge_order():
     from conftest import assert_grad_close
     for n in g2:
         assert_grad_close(g1[n], g2[n], "edge order / " + n)
+
+
+def test_skipping_the_dead_last_layer_messages_changes_nothing():
+    """`GNN.run_dead_last_messages = False` (B3D_FLAG_SKIP_DEAD_LAST_MESSAGES): the last layer's create_future_msgs / create_past_msgs /
+    combine_future_past feed nothing (clr_att_gnn.py:188 returns edge_classifier(edge_attr)) -- scores, x_sens and EVERY gradient are
+    bit-identical with and without them, in training and in inference."""
+    from batch3dmot_amd import synth
+    dev = torch.device("cuda:0")
+    m = _model(dev).train()
+    for sub in (m.pointnet, m.radarnet):
+        sub.dropout.p = 0.0
+    data = synth.make_batch(2, 140, 900, first_graph_idx=860, modalities=True).to(dev)
+    rows = m.modality_rows(data)
+    m.eval()                                                  # (frozen encoders in eval: the two runs must see the same BatchNorm statistics)
+    res = []
+    for run_dead in (True, False):
+        m.run_dead_last_messages = run_dead
+        m.zero_grad(set_to_none=True)
+        out, xs = m(data, rows=rows)
+        w = torch.linspace(-1.0, 1.0, out.numel(), device=dev).reshape(out.shape)
+        ((out * w).sum() + 0.1 * xs.sum()).backward()
+        res.append((out.detach().clone(), xs.detach().clone(), {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}))
+        with torch.no_grad():
+            res[-1] += (m(data, rows=rows)[0].clone(),)
+    (o1, x1, g1, i1), (o2, x2, g2, i2) = res
+    assert torch.equal(o1, o2) and torch.equal(x1, x2) and torch.equal(i1, i2)
+    assert set(g1) == set(g2)
+    for n in g1:
+        assert torch.equal(g1[n], g2[n]), n
