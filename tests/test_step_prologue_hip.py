@@ -194,3 +194,24 @@ def test_skipping_the_dead_last_layer_messages_changes_nothing():
     assert set(g1) == set(g2)
     for n in g1:
         assert torch.equal(g1[n], g2[n]), n
+
+
+def test_a_graph_struct_without_run_lists_keeps_one_row_per_edge():
+    """`b3d_graph.past_ptr / past_rows / dst_unsorted` are optional (include/b3d.h): a hand-made struct that leaves them NULL gets the
+    one-row-per-edge path -- same scores as the run sums up to fp32 summation order."""
+    from batch3dmot_amd import _lib, synth
+    dev = torch.device("cuda:0")
+    m = _model(dev).eval()
+    data = synth.make_graph(220, None, k=6, graph_idx=870, modalities=True).to(dev)
+    rows = m.modality_rows(data)
+    with torch.no_grad():
+        a = m(data, rows=rows)[0].clone()
+        g = data._b3d_graph
+        assert int(g._view(g.c.dst_unsorted, 1).item()) == 0          # grouped by destination: the run sums were used
+        keep = (g.c.past_ptr, g.c.past_rows, g.c.dst_unsorted)
+        g.c.past_ptr, g.c.past_rows, g.c.dst_unsorted = None, None, None
+        b = m(data, rows=rows)[0].clone()
+        g.c.past_ptr, g.c.past_rows, g.c.dst_unsorted = keep
+        c = m(data, rows=rows)[0].clone()
+    assert torch.equal(a, c)                                           # bitwise repeatable
+    assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max())
