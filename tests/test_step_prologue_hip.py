@@ -215,3 +215,32 @@ def test_a_graph_struct_without_run_lists_keeps_one_row_per_edge():
         c = m(data, rows=rows)[0].clone()
     assert torch.equal(a, c)                                           # bitwise repeatable
     assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max())
+
+
+def test_run_tail_lists_are_exact():
+    """Index work is bit-exact (north_star): `b3d_graph.past_ptr / past_rows` against a plain-Python restatement -- for a graph grouped by
+    destination the last edge of every (destination, aligned 16-edge block) run; for any other order the destination's CSR list."""
+    from batch3dmot_amd import _lib, synth
+    dev = torch.device("cuda:0")
+    for n, k, idx in ((37, 3, 880), (260, 7, 881), (700, 13, 882)):
+        data = synth.make_graph(n, None, k=k, graph_idx=idx)
+        ei = data.edge_index
+        e = ei.size(1)
+        g = _lib.Graph(ei.to(dev), n)
+        ptr = g._view(g.c.past_ptr, n + 1).cpu().tolist()
+        rows = g._view(g.c.past_rows, ptr[-1]).cpu().tolist()
+        dst = ei[1].tolist()
+        want_ptr, want_rows = [0], []
+        for node in range(n):
+            edges = [i for i in range(e) if dst[i] == node]            # contiguous: the graph is grouped by destination
+            blocks = sorted({i // 16 for i in edges})
+            want_rows += [max(i for i in edges if i // 16 == b) for b in blocks]
+            want_ptr.append(len(want_rows))
+        assert int(g._view(g.c.dst_unsorted, 1).item()) == 0 and ptr == want_ptr and rows == want_rows, (n, k)
+        # the same graph with its edges reversed: not grouped by ascending destination -> the CSR lists (edge ids ascending per node)
+        rev = torch.flip(ei, dims=[1]).contiguous()
+        g2 = _lib.Graph(rev.to(dev), n)
+        a = g2.arrays()
+        ptr2 = g2._view(g2.c.past_ptr, n + 1).cpu()
+        assert int(g2._view(g2.c.dst_unsorted, 1).item()) == 1
+        assert torch.equal(ptr2, a["dst_ptr"].cpu()) and torch.equal(g2._view(g2.c.past_rows, e).cpu(), a["dst_perm"].cpu())
