@@ -27,7 +27,7 @@ constexpr int kNodeLinWaves = 8;
 constexpr int kNodeLinLds = kLdsBytes;
 
 template <class Seq, int K, int LAST, int SLOTS, int KB>
-__device__ __forceinline__ void node_lin_slices(WStreamT<kNodeLinWaves * 64>& ws, const NodeLinArgs& a, long row, bool valid, v4f* acc) {
+__device__ __forceinline__ void node_lin_slices(NodeRing<kNodeLinWaves * 64>& ws, const NodeLinArgs& a, long row, bool valid, v4f* acc) {
   v4f in[KB];
   linear_split<Seq, K, false, K == 0, kNodeLinWaves>(
       ws, false, in,
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(kNodeLinWaves * 64, 1) void att_node_linear_kernel(
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NS = Seq::NL, KB = Seq::kp(0) / 16, NB = Seq::np(0) / 16;
   constexpr int SLOTS = (NB + kNodeLinWaves - 1) / kNodeLinWaves;
-  WStreamT<kNodeLinWaves * 64> ws;
+  NodeRing<kNodeLinWaves * 64> ws;       // (b3d_node.hpp: the LDS ring, or -- default -- weights straight from global memory)
   ws.init(a.wpack, smem);
   ws.template start<Seq>();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;

@@ -156,6 +156,7 @@ static __device__ long long g_stamps[4][512 * 32];     // one copy per translati
 
 template <int NT, int SLOT = kWBufFloats>
 struct WStreamT {
+  static constexpr bool kDirect = false;
   const float* g;      // packed images of this kernel (global)
   float* lds;          // 2 * SLOT floats
   int slot;            // slot that the NEXT acquire returns
@@ -231,6 +232,28 @@ struct WStreamT {
     return cur;
   }
 };
+
+// ---- no ring at all (round 6 EXPERIMENT behind -DB3D_NODE_DIRECT=1: 3 x SLOWER on row-major images, see b3d_node.hpp) ---------------
+// linear_split gives every 16-row weight block to ONE wavefront, so nothing is shared through the LDS copy the ring makes: with 16 rows
+// per workgroup against ~1 MB of weights those kernels were a chain of 16+ (LDS-DMA chunk in flight -> vmcnt(0) -> barrier -> a few
+// MFMAs) steps, one chunk in flight at a time -- bound by DMA latency at 14-18 % MFMA-busy.  Here a wavefront reads the fragments of its
+// own blocks straight from global memory (L2-resident images) into registers, several groups ahead; the only barrier left per layer
+// is the one that publishes the previous layer's activations.  Same images, same MFMA order, same bits.
+template <int NT>
+struct WDirectT {
+  static constexpr bool kDirect = true;
+  const float* g;
+  __device__ __forceinline__ void init(const float* gw, float*) { g = gw; }
+  template <class Seq>
+  __device__ __forceinline__ void start() {}
+  template <class Seq, int CI>
+  __device__ __forceinline__ const float* acquire(bool) {
+    if constexpr (CI == Seq::first_chunk(Seq::chunk_layer(CI))) __syncthreads();   // the previous layer's LDS writes of every wavefront
+    return g + Seq::chunk_off(CI);
+  }
+};
+typedef const __attribute__((address_space(1))) v4f* gbl_v4f_cp;
+typedef const __attribute__((address_space(1))) float* gbl_f_cp;
 
 // ---- grouped weight stream: consecutive chunks that fit one slot together travel under ONE barrier ----------
 // A Linear of the hoisted edge stacks is 9-25 KB of weights and 32-96 MFMAs per wavefront: with one barrier per

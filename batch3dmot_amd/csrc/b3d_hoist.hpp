@@ -219,7 +219,7 @@ __global__ __launch_bounds__(kNodeWaves * 64, 1) void node_proj0_split_kernel(co
   constexpr int NWS = kNodeWaves;
   constexpr int XB = D::DX / 16, FB = H::OF / 16, T0B = 2 * D::MH / 16;
   static_assert(FB % NWS == 0 && T0B % NWS == 0, "table columns must split over the wavefronts");
-  WStreamT<NWS * 64> ws;      // one barrier per weight chunk: it is also what publishes the previous layer's LDS activations
+  NodeRing<NWS * 64> ws;      // (ring form:) one barrier per weight chunk: it is also what publishes the previous layer's LDS activations
   ws.init(a.wpack, smem);
   ws.template start<Seq>();
   const int lane = threadIdx.x & 63;
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(kGradProjWaves * 64, 1) void node_gradproj_kernel(c
   using Seq = typename H::GradProjSeq;
   constexpr int NWS = kGradProjWaves;
   constexpr int LB = D::EH1 / 16, HB = LB / 2, TB = H::GW / 16;
-  WStreamT<NWS * 64> ws;      // one barrier per weight chunk: it is also what publishes the previous layer's LDS activations
+  NodeRing<NWS * 64> ws;      // (ring form:) one barrier per weight chunk: it is also what publishes the previous layer's LDS activations
   ws.init(a.wpack, smem);
   ws.template start<Seq>();
   v4f* xb = reinterpret_cast<v4f*>(smem + 2 * kWBufFloats);
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(kGradProjWaves * 64, 1) void node_bwd_h_kernel(cons
   constexpr int XB = D::DX / 16, GB = 2 * XB, H1B = D::NH1 / 16, H2B = D::NH2 / 16;
   static_assert(GB <= NWS && H1B <= NWS && H2B <= NWS, "at most one output block per wavefront and layer");
   constexpr int PB = NodeBwdHLds<D>::PB;
-  WStreamT<NWS * 64> ws;      // one barrier per weight chunk: it is also what publishes the previous layer's LDS activations
+  NodeRing<NWS * 64> ws;      // (ring form:) one barrier per weight chunk: it is also what publishes the previous layer's LDS activations
   ws.init(a.wpack, smem);
   ws.template start<Seq>();
   v4f* xt = reinterpret_cast<v4f*>(smem + 2 * kWBufFloats);   // dT tile
@@ -654,7 +654,7 @@ __global__ __launch_bounds__(kNodeBwdGWaves * 64, 1) void node_bwd_g_kernel(cons
   constexpr int XB = D::DX / 16, GB = 2 * XB, H1B = D::NH1 / 16, H2B = D::NH2 / 16;
   static_assert(GB <= NWS && H1B <= NWS && H2B <= NWS, "at most one output block per wavefront and layer");
   constexpr int PB = NodeBwdGLds<D>::PB;
-  WStreamT<NWS * 64> ws;      // one barrier per weight chunk: it is also what publishes the previous layer's LDS activations
+  NodeRing<NWS * 64> ws;      // (ring form:) one barrier per weight chunk: it is also what publishes the previous layer's LDS activations
   ws.init(a.wpack, smem);
   ws.template start<Seq>();
   v4f* xb0 = reinterpret_cast<v4f*>(smem + 2 * kWBufFloats);

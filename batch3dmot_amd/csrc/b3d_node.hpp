@@ -18,6 +18,16 @@
 namespace b3d {
 
 constexpr int kNodeWaves = 4;
+// Ring of the node-sized kernels: the two-slot LDS ring (WStreamT, shipped) or -- EXPERIMENT, round 6, -DB3D_NODE_DIRECT=1 -- none:
+// weights read straight from global memory by the wavefront that owns the block (WDirectT, b3d_dev.hpp).  Measured (gpurun_out/
+// ab_node_direct.txt, parity green): mp_node_fwd 203 -> 597 us per step, mp_node_bwd 413 -> 1,434.  The images are row-major with
+// 400-1,056-byte rows, so a fragment load (lane = row m, 16 bytes) touches 16 half-used cache lines per wave-instruction where an
+// LDS-DMA piece moves one contiguous KB; fragment-major images (as the edge kernels' fragment streams) would be the way, not built.
+#ifndef B3D_NODE_DIRECT
+#define B3D_NODE_DIRECT 0
+#endif
+template <int NT>
+using NodeRing = std::conditional_t<B3D_NODE_DIRECT != 0, WDirectT<NT>, WStreamT<NT>>;
 
 template <class D>
 struct NodeSplit {
@@ -59,7 +69,69 @@ __device__ __forceinline__ void linear_split_chunk(WS& ws, bool more, const v4f*
       emit(mb, v);
     }
   };
-  if constexpr (BF) {
+  if constexpr (WS::kDirect) {
+    // weights straight from global memory (WDirectT, b3d_dev.hpp): this wavefront's blocks only, fragments two groups ahead of the
+    // MFMAs that consume them; one accumulator chain per block, the same fmaf / bf16x6 order as the LDS form
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) {
+      const int mb = first + NWS * j;
+      if (mb >= mbn) break;                                    // wave-uniform
+      const float* wa = w + ((mb - mb0) * 16 + m) * STRIDE + 4 * q;
+      v4f acc = zero4;
+      if constexpr (BIAS) {
+        const gbl_f_cp ba = (gbl_f_cp)(w + ((mb - mb0) * 16 + 4 * q) * STRIDE + bias_col(KP, BF));
+        acc = v4f{ba[0], ba[STRIDE], ba[2 * STRIDE], ba[3 * STRIDE]};
+      }
+      if constexpr (BF) {
+        constexpr int KG = KP / 32, G = 2, NG = (KG + G - 1) / G;          // groups of two 32-wide k groups: six 16-byte loads
+        typedef const __attribute__((address_space(1))) u4v* gbl_u4v_cp;
+        auto ld = [&](int c) {
+          Bf3 f;
+          f.p0 = __builtin_bit_cast(bf8, *(gbl_u4v_cp)(wa + 16 * c));
+          f.p1 = __builtin_bit_cast(bf8, *(gbl_u4v_cp)(wa + 16 * c + KP / 2));
+          f.p2 = __builtin_bit_cast(bf8, *(gbl_u4v_cp)(wa + 16 * c + KP));
+          return f;
+        };
+        Bf3 f[2][G];
+#pragma unroll
+        for (int g = 0; g < 2 && g < NG; ++g)
+#pragma unroll
+          for (int i = 0; i < G; ++i)
+            if (g * G + i < KG) f[g][i] = ld(g * G + i);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+#pragma unroll
+          for (int i = 0; i < G; ++i)
+            if (g * G + i < KG) acc = bf_mfma6(f[g & 1][i], xin.x[g * G + i], acc);
+          if (g + 2 < NG) {
+#pragma unroll
+            for (int i = 0; i < G; ++i)
+              if ((g + 2) * G + i < KG) f[g & 1][i] = ld((g + 2) * G + i);
+          }
+        }
+      } else {
+        constexpr int G = 4, NG = (KB + G - 1) / G;                        // groups of four 16-wide k blocks: four 16-byte loads
+        v4f f[2][G];
+#pragma unroll
+        for (int g = 0; g < 2 && g < NG; ++g)
+#pragma unroll
+          for (int i = 0; i < G; ++i)
+            if (g * G + i < KB) f[g][i] = *(gbl_v4f_cp)(wa + 16 * (g * G + i));
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+#pragma unroll
+          for (int i = 0; i < G; ++i)
+            if (g * G + i < KB) acc = mfma4(f[g & 1][i], in[g * G + i], acc);
+          if (g + 2 < NG) {
+#pragma unroll
+            for (int i = 0; i < G; ++i)
+              if ((g + 2) * G + i < KB) f[g & 1][i] = *(gbl_v4f_cp)(wa + 16 * ((g + 2) * G + i));
+          }
+        }
+      }
+      emit_one(mb, RELU ? relu4(acc) : acc, mb0 / NWS + j);
+    }
+  } else if constexpr (BF) {
     constexpr int KG = KP / 32;
 #pragma unroll
     for (int j = 0; j < JMAX; ++j) {
@@ -146,7 +218,7 @@ __device__ __forceinline__ void node_fwd_split_body(const NodeFwdArgs& a, float*
   static_assert(DMB % 2 == 0 && 2 + 2 * FP == NWS, "message width must split over the wavefronts");
   static_assert(FP == 1 || (FP - 1) * DMB <= NS::XBUF_BLOCKS, "partial sums live in the second exchange buffer");
   if constexpr (PROJ) B3D_STAMP(0, 0);
-  WStreamT<NWS * 64> ws;      // one barrier per weight chunk: it is also what publishes the previous layer's LDS activations
+  NodeRing<NWS * 64> ws;      // (ring form:) one barrier per weight chunk: it is also what publishes the previous layer's LDS activations
   ws.init(a.wpack, smem);
   ws.template start<Seq>();
   v4f* xb0 = reinterpret_cast<v4f*>(smem + 2 * kWBufFloats);
@@ -288,7 +360,7 @@ __global__ __launch_bounds__(kNodeWaves * 64, 1) void mp_node_bwd_split_kernel(c
   constexpr int GB = 2 * XB;                                  // d x' | d x0 contribution
   constexpr int GPW = GB / (NWS / 2);                         // gradient blocks per wavefront (one list each half)
   static_assert(NWS % 2 == 0 && GB % (NWS / 2) == 0, "gradient width must split over half the wavefronts");
-  WStreamT<NWS * 64> ws;      // one barrier per weight chunk: it is also what publishes the previous layer's LDS activations
+  NodeRing<NWS * 64> ws;      // (ring form:) one barrier per weight chunk: it is also what publishes the previous layer's LDS activations
   ws.init(a.wpack, smem);
   ws.template start<Seq>();
   v4f* xb0 = reinterpret_cast<v4f*>(smem + 2 * kWBufFloats);
