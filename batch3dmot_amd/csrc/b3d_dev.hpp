@@ -145,8 +145,19 @@ struct LayerSeq {
 #ifdef B3D_EXP_STAMPS
 static __device__ long long g_stamps[4][512 * 32];     // one copy per translation unit (no relocatable device code)
 #define B3D_STAMP(k, i) do { if (threadIdx.x == 0 && blockIdx.x < 512) b3d::g_stamps[k][blockIdx.x * 32 + (i)] = wall_clock64(); } while (0)
+// time wavefront 0 spends inside the ring's acquire (counted wait + barrier) of the node-sized kernels, summed per workgroup:
+// zeroed where a kernel starts its stamps, saved into one of its stamp slots where it ends them
+static __device__ long long g_acq[512];
+#define B3D_ACQ_ZERO() do { if (threadIdx.x == 0 && blockIdx.x < 512) b3d::g_acq[blockIdx.x] = 0; } while (0)
+#define B3D_ACQ_T0() const long long acq_t0_ = wall_clock64()
+#define B3D_ACQ_ADD() do { if (threadIdx.x == 0 && blockIdx.x < 512) b3d::g_acq[blockIdx.x] += wall_clock64() - acq_t0_; } while (0)
+#define B3D_ACQ_SAVE(k, i) do { if (threadIdx.x == 0 && blockIdx.x < 512) b3d::g_stamps[k][blockIdx.x * 32 + (i)] = b3d::g_acq[blockIdx.x]; } while (0)
 #else
 #define B3D_STAMP(k, i) do {} while (0)
+#define B3D_ACQ_ZERO() do {} while (0)
+#define B3D_ACQ_T0() do {} while (0)
+#define B3D_ACQ_ADD() do {} while (0)
+#define B3D_ACQ_SAVE(k, i) do {} while (0)
 #endif
 
 // ---- weight stream: global -> LDS, two slots ----------------------------------------------

@@ -639,7 +639,9 @@ struct NodeBwdGArgs {
 template <class D>
 struct NodeBwdGLds {
   static constexpr int PB = (D::NH1 > 2 * D::DX ? D::NH1 : 2 * D::DX) / 16;
-  static constexpr int BYTES = kLdsBytes + 2 * PB * 64 * 16;
+  static constexpr int LMAX = (D::EH1 > D::MH ? D::EH1 : D::MH) / 16;          // widest dT tile of the four products (blocks)
+  static constexpr int XBLOCKS = B3D_NODE_TILE_LDS && 2 * LMAX > 2 * PB ? 2 * LMAX : 2 * PB;
+  static constexpr int BYTES = kLdsBytes + XBLOCKS * 64 * 16;
   static_assert(BYTES <= 160 * 1024, "LDS of one CU");
 };
 constexpr int kNodeBwdGWaves = 16;
@@ -654,6 +656,7 @@ __global__ __launch_bounds__(kNodeBwdGWaves * 64, 1) void node_bwd_g_kernel(cons
   constexpr int XB = D::DX / 16, GB = 2 * XB, H1B = D::NH1 / 16, H2B = D::NH2 / 16;
   static_assert(GB <= NWS && H1B <= NWS && H2B <= NWS, "at most one output block per wavefront and layer");
   constexpr int PB = NodeBwdGLds<D>::PB;
+  if constexpr (MLP) { B3D_STAMP(1, 0); B3D_ACQ_ZERO(); }
   NodeRing<NWS * 64> ws;      // (ring form:) one barrier per weight chunk: it is also what publishes the previous layer's LDS activations
   ws.init(a.wpack, smem);
   ws.template start<Seq>();
@@ -672,11 +675,45 @@ __global__ __launch_bounds__(kNodeBwdGWaves * 64, 1) void node_bwd_g_kernel(cons
   v4f own = {0.f, 0.f, 0.f, 0.f};
   v4f dt[LA > LM ? LA : LM];
   auto acc = [&](int, v4f v) { own += v; };
+#if B3D_NODE_TILE_LDS
+  // The operand of a product is the 16-row tile of one list's dT columns.  Every wavefront needs all of it, and a load issued in the
+  // layer's hook queues behind the weight chunk the acquire has just put in flight: 16 loads per lane, ~2 us exposed per product
+  // (tools/phase_stamps_clr.py, profiles/r06_e_node_phase_stamps.txt).  Round 6: the tile goes through LDS -- wavefront w fetches
+  // block w (ONE 16-byte load per lane) a whole product ahead, the hook of product p publishes the tile of product p + 1 into the
+  // other of two LDS buffers and takes its own from the one the previous hook filled (a weight-chunk barrier lies between a buffer's
+  // write and its reads, and between its reads and the next write).  Same operands, same MFMA order: bit-identical gradients.
+  constexpr int LMAX = NodeBwdGLds<D>::LMAX;
+  static_assert(LMAX <= NWS, "one tile block per wavefront");
+  v4f* tile0 = xb0;                       // both buffers are dead before the stages behind the products write xb0 / xb1
+  v4f* tile1 = xb0 + LMAX * 64;
+  v4f pre = {0.f, 0.f, 0.f, 0.f};
+  auto fetch = [&](int off, int nb) { if (wave < nb) load_row<1>(a.dT, row, H::GW, off + 16 * wave, valid, &pre); };
+  auto publish = [&](v4f* t, int nb) { if (wave < nb) t[wave * 64 + lane] = pre; };
+  auto take = [&](const v4f* t, auto nb) {
+#pragma unroll
+    for (int b = 0; b < decltype(nb)::value; ++b) dt[b] = t[b * 64 + lane];
+  };
+  using NA = std::integral_constant<int, LA>;
+  using NM = std::integral_constant<int, LM>;
+  fetch(H::OA, LA);
+  publish(tile0, LA);
+  fetch(H::OB, LA);
+  if constexpr (MLP) B3D_STAMP(1, 1);
+  linear_split<Seq, 0, false, false, NWS>(ws, false, dt, [&]() { take(tile0, NA{}); publish(tile1, LA); fetch(H::OF, LM); }, acc);
+  if constexpr (MLP) B3D_STAMP(1, 2);
+  linear_split<Seq, 1, false, false, NWS>(ws, false, dt, [&]() { take(tile1, NA{}); publish(tile0, LM); fetch(H::OP, LM); }, acc);
+  linear_split<Seq, 2, false, false, NWS>(ws, false, dt, [&]() { take(tile0, NM{}); publish(tile1, LM); }, acc);
+  linear_split<Seq, 3, false, false, NWS>(ws, false, dt, [&]() { take(tile1, NM{}); }, acc);
+#else
   load_row<LA>(a.dT, row, H::GW, H::OA, valid, dt);
+  if constexpr (MLP) B3D_STAMP(1, 1);
   linear_split<Seq, 0, false, false, NWS>(ws, false, dt, [&]() {}, acc);
+  if constexpr (MLP) B3D_STAMP(1, 2);
   linear_split<Seq, 1, false, false, NWS>(ws, false, dt, [&]() { load_row<LA>(a.dT, row, H::GW, H::OB, valid, dt); }, acc);
   linear_split<Seq, 2, false, false, NWS>(ws, false, dt, [&]() { load_row<LM>(a.dT, row, H::GW, H::OF, valid, dt); }, acc);
   linear_split<Seq, 3, false, false, NWS>(ws, false, dt, [&]() { load_row<LM>(a.dT, row, H::GW, H::OP, valid, dt); }, acc);
+#endif
+  if constexpr (MLP) B3D_STAMP(1, 3);
   if constexpr (!MLP) {
     if (wave < GB) store_row<1>(a.gx, row, 2 * D::DX, 16 * wave, valid, &own);
     return;
@@ -696,6 +733,7 @@ __global__ __launch_bounds__(kNodeBwdGWaves * 64, 1) void node_bwd_g_kernel(cons
           for (int b = 0; b < XB; ++b) g[b] = xb0[b * 64 + lane];
         },
         [&](int mb, v4f v) { act2 = mask(v, act2); xb1[mb * 64 + lane] = act2; });          // mb == wave: act2 now holds d H2
+    B3D_STAMP(1, 4);
     linear_split<Seq, 5, false, false, NWS>(
         ws, false, d2,
         [&]() {
@@ -704,6 +742,7 @@ __global__ __launch_bounds__(kNodeBwdGWaves * 64, 1) void node_bwd_g_kernel(cons
           for (int b = 0; b < H2B; ++b) d2[b] = xb1[b * 64 + lane];
         },
         [&](int mb, v4f v) { act1 = mask(v, act1); xb0[mb * 64 + lane] = act1; });
+    B3D_STAMP(1, 5);
     linear_split<Seq, 6, false, false, NWS>(
         ws, false, d1,
         [&]() {
@@ -712,6 +751,8 @@ __global__ __launch_bounds__(kNodeBwdGWaves * 64, 1) void node_bwd_g_kernel(cons
           for (int b = 0; b < H1B; ++b) d1[b] = xb0[b * 64 + lane];
         },
         [&](int mb, v4f v) { store_row<1>(a.dM, row, 2 * D::DM, 16 * mb, valid, &v); });
+    B3D_STAMP(1, 6);
+    B3D_ACQ_SAVE(1, 31);
   }
 }
 

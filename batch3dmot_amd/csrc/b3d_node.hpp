@@ -26,6 +26,11 @@ constexpr int kNodeWaves = 4;
 #ifndef B3D_NODE_DIRECT
 #define B3D_NODE_DIRECT 0
 #endif
+// node_bwd_g (b3d_hoist.hpp): the dT tiles of the four gradient products through LDS, fetched a product ahead (1) or 16 loads per lane
+// in the layer's hook (0, the round-5 form, kept for the A/B)
+#ifndef B3D_NODE_TILE_LDS
+#define B3D_NODE_TILE_LDS 1
+#endif
 template <int NT>
 using NodeRing = std::conditional_t<B3D_NODE_DIRECT != 0, WDirectT<NT>, WStreamT<NT>>;
 
@@ -55,7 +60,9 @@ __device__ __forceinline__ void linear_split_chunk(WS& ws, bool more, const v4f*
   constexpr int JMAX = (mbn - mb0 + NWS - 1) / NWS;          // owned blocks in this chunk (upper bound)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int m = lane & 15, q = lane >> 4;
+  B3D_ACQ_T0();
   const float* w = ws.template acquire<Seq, C0 + CH>(more);
+  B3D_ACQ_ADD();
   if constexpr (CH == 0) { inload(); xin.prepare(in); }       // the operand (bf16 pieces or the blocks themselves): once per layer
   const int first = mb0 + ((wave - mb0 % NWS) + NWS) % NWS;   // first owned block of the chunk
   const v4f zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -217,7 +224,7 @@ __device__ __forceinline__ void node_fwd_split_body(const NodeFwdArgs& a, float*
   constexpr int MB2 = 2 * DMB, BPW = DMB / 2;                // blocks of M per gathering wavefront
   static_assert(DMB % 2 == 0 && 2 + 2 * FP == NWS, "message width must split over the wavefronts");
   static_assert(FP == 1 || (FP - 1) * DMB <= NS::XBUF_BLOCKS, "partial sums live in the second exchange buffer");
-  if constexpr (PROJ) B3D_STAMP(0, 0);
+  if constexpr (PROJ) { B3D_STAMP(0, 0); B3D_ACQ_ZERO(); }
   NodeRing<NWS * 64> ws;      // (ring form:) one barrier per weight chunk: it is also what publishes the previous layer's LDS activations
   ws.init(a.wpack, smem);
   ws.template start<Seq>();
@@ -339,7 +346,7 @@ __device__ __forceinline__ void node_fwd_split_body(const NodeFwdArgs& a, float*
           store_row<1>(a.T, row, TW, 16 * mb, valid, &v);
         });
   }
-  if constexpr (PROJ) B3D_STAMP(0, 5);
+  if constexpr (PROJ) { B3D_STAMP(0, 5); B3D_ACQ_SAVE(0, 31); }
   (void)XB;
 }
 
