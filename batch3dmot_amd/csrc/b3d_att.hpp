@@ -24,8 +24,38 @@ struct NodeLinArgs {
   const float* wpack;
 };
 constexpr int kNodeLinWaves = 8;
-constexpr int kNodeLinLds = kLdsBytes;
+// the ring + (B3D_NODE_TILE_LDS, b3d_node.hpp) two buffers for the operand tile of a K-slice (at most 8 blocks of 1 KB each)
+constexpr int kNodeLinLds = kLdsBytes + (B3D_NODE_TILE_LDS ? 2 * kNodeLinWaves * 64 * 16 : 0);
 
+#if B3D_NODE_TILE_LDS
+// The operand of K-slice k is a 16-row x 16 KB-column tile that EVERY wavefront needs.  Loaded in the slice's hook it was KB loads per
+// lane queued behind the weight chunk just put in flight -- exposed once per slice, sixteen times in the transposed launch.  As in
+// node_bwd_g (b3d_hoist.hpp): wavefront w fetches block w two slices ahead, the hook of slice k publishes the tile of slice k + 1 into
+// the other LDS buffer and takes its own (one weight-chunk barrier between a buffer's write and its reads, and between its reads and
+// the next write).  Same operands and MFMA order: bit-identical results.
+template <class Seq, int K, int LAST, int SLOTS, int KB>
+__device__ __forceinline__ void node_lin_slices(NodeRing<kNodeLinWaves * 64>& ws, const NodeLinArgs& a, long row, bool valid, v4f* acc,
+                                                v4f* tiles, v4f& pre) {
+  static_assert(KB <= kNodeLinWaves, "one tile block per wavefront");
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  v4f in[KB];
+  linear_split<Seq, K, false, K == 0, kNodeLinWaves>(
+      ws, false, in,
+      [&]() {
+        const v4f* mine = tiles + (K & 1) * kNodeLinWaves * 64;
+#pragma unroll
+        for (int b = 0; b < KB; ++b) in[b] = mine[b * 64 + lane];
+        if constexpr (K + 1 <= LAST) {
+          if (wave < KB) tiles[((K + 1) & 1) * kNodeLinWaves * 64 + wave * 64 + lane] = pre;
+        }
+        if constexpr (K + 2 <= LAST) {
+          if (wave < KB) load_row<1>(a.in, row, a.in_stride, a.in_col0 + 16 * KB * (K + 2) + 16 * wave, valid, &pre);
+        }
+      },
+      [&](int, v4f v, int slot) { if (K == 0) acc[slot] = v; else acc[slot] += v; });
+  if constexpr (K < LAST) node_lin_slices<Seq, K + 1, LAST, SLOTS, KB>(ws, a, row, valid, acc, tiles, pre);
+}
+#else
 template <class Seq, int K, int LAST, int SLOTS, int KB>
 __device__ __forceinline__ void node_lin_slices(NodeRing<kNodeLinWaves * 64>& ws, const NodeLinArgs& a, long row, bool valid, v4f* acc) {
   v4f in[KB];
@@ -35,13 +65,14 @@ __device__ __forceinline__ void node_lin_slices(NodeRing<kNodeLinWaves * 64>& ws
       [&](int, v4f v, int slot) { if (K == 0) acc[slot] = v; else acc[slot] += v; });
   if constexpr (K < LAST) node_lin_slices<Seq, K + 1, LAST, SLOTS, KB>(ws, a, row, valid, acc);
 }
+#endif
 
 template <class Seq>
 __global__ __launch_bounds__(kNodeLinWaves * 64, 1) void att_node_linear_kernel(const NodeLinArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NS = Seq::NL, KB = Seq::kp(0) / 16, NB = Seq::np(0) / 16;
   constexpr int SLOTS = (NB + kNodeLinWaves - 1) / kNodeLinWaves;
-  NodeRing<kNodeLinWaves * 64> ws;       // (b3d_node.hpp: the LDS ring, or -- default -- weights straight from global memory)
+  NodeRing<kNodeLinWaves * 64> ws;       // (b3d_node.hpp: the LDS ring, or -- experiment -- weights straight from global memory)
   ws.init(a.wpack, smem);
   ws.template start<Seq>();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -50,7 +81,18 @@ __global__ __launch_bounds__(kNodeLinWaves * 64, 1) void att_node_linear_kernel(
   v4f acc[SLOTS];
 #pragma unroll
   for (int s = 0; s < SLOTS; ++s) acc[s] = v4f{0.f, 0.f, 0.f, 0.f};
+#if B3D_NODE_TILE_LDS
+  v4f* tiles = reinterpret_cast<v4f*>(smem + 2 * kWBufFloats);
+  v4f pre = {0.f, 0.f, 0.f, 0.f};
+  if (wave < KB) {
+    load_row<1>(a.in, row, a.in_stride, a.in_col0 + 16 * wave, valid, &pre);
+    tiles[wave * 64 + lane] = pre;                              // tile of slice 0: visible behind the first chunk's barrier
+    if constexpr (NS > 1) load_row<1>(a.in, row, a.in_stride, a.in_col0 + 16 * KB + 16 * wave, valid, &pre);
+  }
+  node_lin_slices<Seq, 0, NS - 1, SLOTS, KB>(ws, a, row, valid, acc, tiles, pre);
+#else
   node_lin_slices<Seq, 0, NS - 1, SLOTS, KB>(ws, a, row, valid, acc);
+#endif
 #pragma unroll
   for (int s = 0; s < SLOTS; ++s) {
     const int mb = wave + kNodeLinWaves * s;
