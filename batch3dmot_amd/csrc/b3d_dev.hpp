@@ -177,13 +177,19 @@ struct WStreamT {
 
   __device__ __forceinline__ void init(const float* gw, float* l) { g = gw; lds = l; slot = 0; }
 
-  template <class Seq, int CI>
+  // A0, NA (round 6, node-sized kernels): wavefronts [A0, A0 + NA) mod NT / 64 have MFMA work in the chunk that is consumed while this
+  // one is fetched; the OTHERS issue its pieces (an LDS-DMA instruction stalls its issuer for 175-350 cycles: with every wavefront
+  // issuing, the few that own a block of a 3-4 block chunk started their MFMAs that much later).  NA == 0: everyone issues.
+  template <class Seq, int CI, int A0 = 0, int NA = 0>
   __device__ __forceinline__ void issue(int to_slot) {
     constexpr int off = Seq::chunk_off(CI);
     constexpr int n4 = Seq::chunk_size(CI) / 4;          // multiple of 64
     static_assert(Seq::chunk_size(CI) <= SLOT, "chunk larger than a ring slot");
 #if B3D_USE_LDS_DMA
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63;
+    constexpr int NW = NT / 64, NI = NW - NA;            // issuers
+    static_assert(NA >= 0 && NI >= 1, "somebody has to issue");
+    const int wave = NA == 0 ? (int)(threadIdx.x >> 6) : ((int)(threadIdx.x >> 6) - A0 - NA + 2 * NW) % NW;   // issuer index
     const float* src = g + off;
     // opaque per call: hipcc otherwise hoists the per-piece 64-bit source addresses of EVERY chunk of the sequence
     // out of the tile loop (up to ~150 address pairs) and spills them
@@ -193,9 +199,9 @@ struct WStreamT {
     asm volatile("" : "+s"(src));
     float* dst = lds + to_slot * SLOT;
 #pragma unroll
-    for (int i0 = 0; i0 < n4; i0 += NT) {
+    for (int i0 = 0; i0 < n4; i0 += NI * 64) {
       const int base = i0 + wave * 64;                   // wave-uniform
-      if (base < n4) {
+      if ((NA == 0 || wave < NI) && base < n4) {
         __builtin_amdgcn_global_load_lds(
             (const __attribute__((address_space(1))) void*)(src + (unsigned)(base + lane) * 4u),
             (__attribute__((address_space(3))) void*)(dst + (size_t)base * 4), 16, 0, 0);
@@ -218,13 +224,13 @@ struct WStreamT {
 
   // Make chunk CI visible to the whole workgroup and start fetching the next one.
   // more == false suppresses the wrap-around prefetch after the kernel's last chunk.
-  template <class Seq, int CI>
+  template <class Seq, int CI, int A0 = 0, int NA = 0>
   __device__ __forceinline__ const float* acquire(bool more) {
     constexpr int NXT = (CI + 1) % Seq::NCH;
 #if B3D_USE_LDS_DMA
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (NXT != 0 || more) issue<Seq, NXT>(slot ^ 1);
+    if (NXT != 0 || more) issue<Seq, NXT, A0, NA>(slot ^ 1);
 #else
     {
       constexpr int n4 = Seq::chunk_size(CI) / 4;
@@ -257,7 +263,7 @@ struct WDirectT {
   __device__ __forceinline__ void init(const float* gw, float*) { g = gw; }
   template <class Seq>
   __device__ __forceinline__ void start() {}
-  template <class Seq, int CI>
+  template <class Seq, int CI, int A0 = 0, int NA = 0>
   __device__ __forceinline__ const float* acquire(bool) {
     if constexpr (CI == Seq::first_chunk(Seq::chunk_layer(CI))) __syncthreads();   // the previous layer's LDS writes of every wavefront
     return g + Seq::chunk_off(CI);

@@ -31,6 +31,13 @@ constexpr int kNodeWaves = 4;
 #ifndef B3D_NODE_TILE_LDS
 #define B3D_NODE_TILE_LDS 1
 #endif
+// EXPERIMENT (round 6, off): the LDS-DMA pieces of the next weight chunk issued only by the wavefronts that have no block in the current
+// one (1) instead of by all (0).  Measured (profiles/r06_e_ab_node_idle_issue.txt, phase stamps): node_bwd_g 24.5 -> 26.2 us per
+// workgroup, time inside acquire 4.4 -> 8.4 us -- 12 issuers with 4.3 pieces each deliver the chunk later than 16 with 3.25, and the
+// three or four busy wavefronts gain less from starting their MFMAs early than everyone loses at the next barrier.
+#ifndef B3D_NODE_IDLE_ISSUE
+#define B3D_NODE_IDLE_ISSUE 0
+#endif
 template <int NT>
 using NodeRing = std::conditional_t<B3D_NODE_DIRECT != 0, WDirectT<NT>, WStreamT<NT>>;
 
@@ -60,8 +67,10 @@ __device__ __forceinline__ void linear_split_chunk(WS& ws, bool more, const v4f*
   constexpr int JMAX = (mbn - mb0 + NWS - 1) / NWS;          // owned blocks in this chunk (upper bound)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int m = lane & 15, q = lane >> 4;
+  // the wavefronts that own a block of THIS chunk leave the fetch of the next one to the others (WStreamT::issue)
+  constexpr int NACT = B3D_NODE_IDLE_ISSUE && (mbn - mb0) < NWS ? mbn - mb0 : 0;
   B3D_ACQ_T0();
-  const float* w = ws.template acquire<Seq, C0 + CH>(more);
+  const float* w = ws.template acquire<Seq, C0 + CH, mb0 % NWS, NACT>(more);
   B3D_ACQ_ADD();
   if constexpr (CH == 0) { inload(); xin.prepare(in); }       // the operand (bf16 pieces or the blocks themselves): once per layer
   const int first = mb0 + ((wave - mb0 % NWS) + NWS) % NWS;   // first owned block of the chunk
