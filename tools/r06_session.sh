@@ -16,7 +16,7 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${TAG}_pmc_write
 cd $R
 python tools/pmc_traffic.py clr:frozen:knn1 gpurun_out/${TAG}_pmc_fetch gpurun_out/${TAG}_pmc_write gpurun_out/${TAG}_traffic.json gpurun_out/${TAG}_pmc_traffic.txt > /dev/null
 python tools/pmc_traffic.py clr:infer:knn1 gpurun_out/${TAG}_pmc_fetch_infer gpurun_out/${TAG}_pmc_write_infer gpurun_out/${TAG}_traffic.json gpurun_out/${TAG}_pmc_traffic_infer.txt > /dev/null
-python tools/rocprof_per_step.py gpurun_out/${TAG}_prof/k_kernel_stats.csv 13 80 > gpurun_out/${TAG}_last_step_summary.txt 2>&1
+python tools/rocprof_per_step.py gpurun_out/${TAG}_prof/k_kernel_stats.csv 0 80 > gpurun_out/${TAG}_last_step_summary.txt 2>&1
 # the raw counter files are large: keep the summaries
 rm -rf gpurun_out/${TAG}_pmc_fetch gpurun_out/${TAG}_pmc_write gpurun_out/${TAG}_pmc_fetch_infer gpurun_out/${TAG}_pmc_write_infer
 bash tools/pmc_sq_session.sh ${TAG} > /dev/null 2>&1
