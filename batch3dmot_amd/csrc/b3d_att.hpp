@@ -52,7 +52,15 @@ __device__ __forceinline__ void node_lin_slices(NodeRing<kNodeLinWaves * 64>& ws
           if (wave < KB) load_row<1>(a.in, row, a.in_stride, a.in_col0 + 16 * KB * (K + 2) + 16 * wave, valid, &pre);
         }
       },
-      [&](int, v4f v, int slot) { if (K == 0) acc[slot] = v; else acc[slot] += v; });
+      [&](int mb, v4f v) {
+        // block mb belongs to wavefront mb % 8 and is its (mb / 8)-th: a compile-time slot only where a chunk starts on a multiple of
+        // eight blocks (the 128-row chunks of the 64- and 96-wide slices); the 96-row chunks of a 128-wide slice do not, so the slot is
+        // picked by a wave-uniform compare
+        const int s = mb / kNodeLinWaves;
+#pragma unroll
+        for (int t = 0; t < SLOTS; ++t)
+          if (s == t) { if (K == 0) acc[t] = v; else acc[t] += v; }
+      });
   if constexpr (K < LAST) node_lin_slices<Seq, K + 1, LAST, SLOTS, KB>(ws, a, row, valid, acc, tiles, pre);
 }
 #else

@@ -72,7 +72,17 @@ using SeqAT4 = LayerSeq<L<128, 64>>;
 // att_edge_encoder.0 with its node columns hoisted (b3d_att.hpp)
 using SeqAttU = LayerSeq<LF<96, 1024>, LF<96, 1024>, LF<96, 1024>>;       // U = (W0[:, 0:288] s + b0 | W0[:, 288:576] s), three K-slices
 template <class... Ls> struct Rep16 { using type = LayerSeq<Ls..., Ls..., Ls..., Ls..., Ls..., Ls..., Ls..., Ls..., Ls..., Ls..., Ls..., Ls..., Ls..., Ls..., Ls..., Ls...>; };
-using SeqAttDs = Rep16<LF<64, 288>>::type;                                // d s = W0[:, 0:288]^T dU_i + W0[:, 288:576]^T dU_j, sixteen K-slices
+// d s = W0[:, 0:288]^T dU_i + W0[:, 288:576]^T dU_j as K-slices.  Round 6: EIGHT slices of 128 (B3D_ATT_DS_SLICE) instead of sixteen of 64 --
+// a 64-wide slice is 128 + 128 + 32 rows in three part-filled ring chunks (48 chunk barriers per launch for 1.3 MB); a 128-wide one is
+// three full 96-row chunks (24 barriers), six blocks of a chunk busy with 32-MFMA chains.
+#ifndef B3D_PROJ0_WAVES
+#define B3D_PROJ0_WAVES 4     // wavefronts per 16-row tile of node_proj0_split_kernel; 8 (one block of a 128-row chunk per wavefront instead of two) measured 29.8 vs 25.9 us: profiles/r06_experiments.txt
+#endif
+#ifndef B3D_ATT_DS_SLICE
+#define B3D_ATT_DS_SLICE 128
+#endif
+template <class... Ls> struct Rep8 { using type = LayerSeq<Ls..., Ls..., Ls..., Ls..., Ls..., Ls..., Ls..., Ls...>; };
+using SeqAttDs = std::conditional_t<B3D_ATT_DS_SLICE == 128, Rep8<LF<128, 288>>::type, Rep16<LF<64, 288>>::type>;
 using SeqAT0eT = LayerSeq<L<512, 64, 1>>;                                    // d e0 = W0[:, 576:640]^T d A0
 // transposed (data gradient)
 using SeqClsT = LayerSeq<L<16, 16>, L<16, 16>, L<16, 32>, L<32, 64>>;
@@ -683,8 +693,10 @@ static int pack_all(const b3d_clr_weights* pw, Ws& w, bool training, bool knn, h
     gp(NH{}, w.wp_nbwd_h);
     gp(HC::GradProjSeq{}, w.wp_gproj);
     T(NH{}, 4, w.wp_nbwd_h, CF2); T(NH{}, 5, w.wp_nbwd_h, CF1); T(NH{}, 6, w.wp_nbwd_h, CF0);
-    for (int k = 0; k < 16; ++k)                             // slice k: 64 columns of dU_i (k < 8) or dU_j
-      d[n++] = pack_slice<SeqAttDs>(k, w.wp_attDs, a0.w + (size_t)64 * (k & 7) * 640 + (k < 8 ? 0 : XS), nullptr, XS, 64, 640, 0, XS, true);
+    constexpr int DSK = B3D_ATT_DS_SLICE, DSH = 512 / DSK;   // slice width, slices per half
+    static_assert(SeqAttDs::NL == 2 * DSH && SeqAttDs::kp(0) == DSK, "K-slices of the two 512-wide halves of dU");
+    for (int k = 0; k < 2 * DSH; ++k)                        // slice k: DSK columns of dU_i (k < DSH) or dU_j
+      d[n++] = pack_slice<SeqAttDs>(k, w.wp_attDs, a0.w + (size_t)DSK * (k % DSH) * 640 + (k < DSH ? 0 : XS), nullptr, XS, DSK, 640, 0, XS, true);
     d[n++] = pack_slice<SeqAT0eT>(0, w.wp_at0eT, a0.w + 2 * XS, nullptr, 64, 512, 640, 0, 64, true);
   }
   if (n > 224) return fail(B3D_ERR_ARG, "pack descriptor table overflow");
@@ -890,7 +902,7 @@ extern "C" int b3d_clr_forward(const b3d_clr_weights* pw, const b3d_graph* g, co
   // x0 terms of the future / past columns (once per forward) + the per-node table of layer 0
   NodeProj0Args a;
   a.N = N; a.x0 = w.x[0]; a.T0 = w.T0; a.T = w.T; a.wpack = w.wp_proj0;
-  B3D_TRY(launch_node_split<DB>(node_proj0_split_kernel<DB>, "node_proj0", a, N, stream, B3D_K_OTHER));
+  B3D_TRY((launch_node_split<DB, B3D_PROJ0_WAVES>(node_proj0_split_kernel<DB, B3D_PROJ0_WAVES>, "node_proj0", a, N, stream, B3D_K_OTHER)));
   Side* knn_side = nullptr;
   auto knn_block = [&](int l) -> int {                         // the discarded k-NN + GAT block on x[l] (:180-184)
     B3D_REQUIRE(in->node_timestamps != nullptr, "node_timestamps required with B3D_FLAG_RUN_DEAD_KNN");
@@ -1476,7 +1488,7 @@ extern "C" int b3d_clr_layer_forward(const b3d_mp_weights* mw, const b3d_graph* 
   B3D_TRY(pack_layer(mw, w, tr, stream));
   NodeProj0Args pa;
   pa.N = N; pa.x0 = x0; pa.x = x; pa.T0 = w.T0; pa.T = w.T; pa.wpack = w.wp_proj0;
-  B3D_TRY(launch_node_split<DB>(node_proj0_split_kernel<DB>, "node_proj0", pa, N, stream, B3D_K_OTHER));
+  B3D_TRY((launch_node_split<DB, B3D_PROJ0_WAVES>(node_proj0_split_kernel<DB, B3D_PROJ0_WAVES>, "node_proj0", pa, N, stream, B3D_K_OTHER)));
   EdgeFwdHArgs ea;
   memset(&ea, 0, sizeof(ea));
   ea.E = E; ea.src = g->src; ea.dst = g->dst; ea.T = w.T; ea.e_in = e; ea.a_in = att;

@@ -211,12 +211,12 @@ struct NodeProj0Args {
   float* T;             // [N, TW]
   const float* wpack;   // Proj0Seq2 images
 };
-template <class D>
-__global__ __launch_bounds__(kNodeWaves * 64, 1) void node_proj0_split_kernel(const NodeProj0Args a) {
+// NWS: four wavefronts per tile; eight (a 128-row weight chunk is one block per wavefront instead of two) is an experiment of round 6: slower
+template <class D, int NWS = kNodeWaves>
+__global__ __launch_bounds__(NWS * 64, 1) void node_proj0_split_kernel(const NodeProj0Args a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   using H = Hoist<D>;
   using Seq = Proj0Seq2<D>;
-  constexpr int NWS = kNodeWaves;
   constexpr int XB = D::DX / 16, FB = H::OF / 16, T0B = 2 * D::MH / 16;
   static_assert(FB % NWS == 0 && T0B % NWS == 0, "table columns must split over the wavefronts");
   NodeRing<NWS * 64> ws;      // (ring form:) one barrier per weight chunk: it is also what publishes the previous layer's LDS activations
